@@ -1,0 +1,148 @@
+/*
+ * kmx_oracle.h -- CPU restatement of the kmtricks counting/merge hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker (never as the thing measured as
+ * the GPU path or shipped).  The product path is kmtricks_amd/csrc (HIP).
+ *
+ * Parity status: PINNED.  The reference hot path cannot be compiled here
+ * without stand-ins for absent third-party headers (xxHash, lz4, TurboPFor,
+ * spdlog, robin-hood, kff are empty submodules), so this restatement is
+ * pinned against the reference's own golden vectors instead
+ * (tests/golden/, extracted from /root/reference/tests):
+ *   - tests/merge_test.cpp:21-77      merged row counts 57/67/70/82
+ *   - tests/task_main.cpp:85-114      k-mers per super-k-mer file 37/46/12/43, 20/21/58/39
+ *   - tests/task_main.cpp:148-340     the 37 + 20 canonical 31-mers in file order
+ *   - tests/task_main.cpp:374-508     the window hashes in file order
+ *   - tests/repartition_test.cpp:7-18 minimizer -> partition
+ *   - tests/packc_test.cpp:5-40       byte_count_pack / to_n_b
+ *   - tests/data/partitions (.kmer and .hash fixtures): byte round trip
+ *
+ * Every function cites the reference file:line it restates (paths relative
+ * to /root/reference).
+ */
+#ifndef KMX_ORACLE_H
+#define KMX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- primitives ------------------------------------------------------- */
+
+/* XXH64 (Cyan4973/xxHash, specification-stable); call sites
+ * include/kmtricks/gatb/sorting_count.hpp:356, include/kmtricks/repartition.hpp:52 */
+uint64_t orc_xxh64(const void* data, size_t len, uint64_t seed);
+
+/* nucleotide code (c>>1)&3 : A0 C1 T2 G3; gatb tools/misc/api/Data.hpp:179 */
+int orc_nt_valid(unsigned char c);
+
+/* reverse complement of a k-mer held in `kw` little-endian 64-bit words
+ * (kw = 1 for k<=32, 2 for k<=64).  gatb kmer/impl/Model.hpp:857-884 */
+void orc_revcomp(const uint64_t* in, uint64_t* out, int k, int kw);
+
+/* k-mer -> ACTG string (A0 C1 T2 G3), include/kmtricks/kmer.hpp:797-810 */
+void orc_kmer_to_string(const uint64_t* words, int k, char* out /* k+1 */);
+void orc_kmer_from_string(const char* s, int k, uint64_t* words, int kw);
+
+/* ---- minimizer / repartition ------------------------------------------ */
+
+/* LUT[x] = min(x, revcomp_m(x)), or 4^m-1 when it contains AA anywhere but
+ * as prefix.  gatb kmer/impl/Model.hpp:1040-1064, 1220-1251.  out: 4^m u32 */
+void orc_minimizer_lut(int m, uint32_t* lut);
+
+/* minimizer value of one forward k-mer value (rescan rule);
+ * gatb kmer/impl/Model.hpp:1254-1287 */
+uint32_t orc_minimizer_of(const uint64_t* fwd, int k, int kw, int m, const uint32_t* lut);
+
+/* --static-repart: table[m] = XXH64(&m,4,0) % P; include/kmtricks/repartition.hpp:45-56 */
+void orc_repart_static(int m, uint32_t nb_parts, uint16_t* table);
+
+/* ---- super-k-mer partitioner ------------------------------------------ */
+
+typedef struct {
+  uint8_t* data;      /* concatenated records [u8 n][packed nts] (no block framing) */
+  size_t   len, cap;
+  uint64_t nb_kmers;  /* k-mers written */
+  uint64_t nb_superk; /* records written */
+} orc_buf;
+
+/* Split one sequence into super-k-mers, append the 2-bit records to out[p].
+ * gatb kmer/impl/Sequence2SuperKmer.hpp:80-158, Model.hpp:725-765, 1086-1139,
+ * 1388-1433; include/kmtricks/gatb/fill_partitions.hpp:59-105.
+ * pinfo (optional, may be NULL): per partition 2 + 5*256 u64 counters
+ * [nb_kmers, nb_kxmers, radix counters x*256+radix] (PartiInfo<5>). */
+int orc_superk_partition(const char* seq, size_t len, int k, int m,
+                         const uint32_t* lut, const uint16_t* repart,
+                         uint32_t nb_parts, orc_buf* out, uint64_t* pinfo);
+void orc_buf_free(orc_buf* b);
+
+/* ---- count ------------------------------------------------------------ */
+
+/* decode every k-mer of a record stream into canonical values (kw words each);
+ * include/kmtricks/gatb/sorting_count.hpp:141-312.  Returns number of k-mers;
+ * out may be NULL to count only. */
+uint64_t orc_superk_decode(const uint8_t* recs, size_t len, int k, int kw, uint64_t* out);
+
+/* sorted (canonical k-mer, count) with count >= hard_min, saturated to u32;
+ * sorting_count.hpp:637-884 + count_processor.hpp:135-146.  Caller frees *keys,*counts */
+int orc_count_kmer(const uint8_t* recs, size_t len, int k, uint32_t hard_min,
+                   uint64_t** keys, uint32_t** counts, uint64_t* n_out);
+
+/* sorted (window hash, count): XXH64(words, 8*kw, 0) % win + win*part;
+ * sorting_count.hpp:346-363, 387-470, 934-990 + count_processor.hpp:61-70 */
+int orc_count_hash(const uint8_t* recs, size_t len, int k, uint64_t win, uint64_t part,
+                   uint32_t hard_min, uint64_t** hashes, uint32_t** counts, uint64_t* n_out);
+
+/* ---- merge ------------------------------------------------------------ */
+
+typedef struct {
+  const uint64_t* keys;   /* n * kw words, ascending, distinct */
+  const uint32_t* counts; /* n */
+  uint64_t n;
+} orc_list;
+
+/* row callback: key words, N output counts, keep flag (merge.hpp:183-260 / 441-517).
+ * Called for EVERY distinct key, kept or not (Appendix B-7). */
+typedef void (*orc_row_cb)(void* user, const uint64_t* key, const uint32_t* counts, int keep);
+
+/* stats: 6 * N u64, order NON_SOLID, RESCUED, UNIQUE_WO_RESCUE, UNIQUE_W_RESCUE,
+ * TOTAL_WO_RESCUE, TOTAL_W_RESCUE (merge.hpp:49-100) */
+int orc_merge(const orc_list* lists, uint32_t n_lists, int kw,
+              const uint32_t* soft_min, uint32_t rec_min, uint32_t share_min,
+              orc_row_cb cb, void* user, uint64_t* stats);
+
+enum { ORC_MODE_COUNT = 0, ORC_MODE_PA = 1, ORC_MODE_BF = 2, ORC_MODE_BFC = 3, ORC_MODE_BFT = 4 };
+
+/* Full row-writer restatement: returns the matrix file BODY (no header) in a
+ * malloc'ed buffer.  COUNT: rows key + N*u32 (merge.hpp:262-272, 519-529);
+ * PA: key + ceil(N/8) bytes LSB-first (merge.hpp:274-286, utils.hpp:104-116);
+ * BF: one ceil(N/8)-byte row per hash in [lower, upper] (merge.hpp:575-600);
+ * BFC: ceil(N*w/8)-byte rows, bitpacker MSB-first (merge.hpp:602-629, packc.hpp:26-43);
+ * BFT: BF then bit transpose (merge.hpp:631-644).  rows_out = kept rows
+ * (COUNT/PA) or window rows (BF*). */
+int orc_merge_matrix(const orc_list* lists, uint32_t n_lists, int kw,
+                     const uint32_t* soft_min, uint32_t rec_min, uint32_t share_min,
+                     int mode, uint64_t lower, uint64_t upper, int bitw,
+                     uint8_t** body, uint64_t* body_len, uint64_t* rows_out, uint64_t* stats);
+
+/* packc.hpp:18-36 */
+uint32_t orc_to_n_b(uint32_t c, uint32_t max_width);
+uint64_t orc_byte_count_pack(uint64_t n, uint64_t bits);
+
+/* ---- bit matrix transpose --------------------------------------------- */
+
+/* out[c][r] = in[r][c], LSB-first bits, nrows and ncols multiples of 8;
+ * in row stride ncols/8, out row stride nrows/8.  bitmatrix.hpp:238-289 */
+void orc_transpose_bits(const uint8_t* in, uint8_t* out, uint64_t nrows, uint64_t ncols);
+
+void orc_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Extract the reference's golden vectors into tests/golden/ (run in the build
+container only, where /root/reference exists; the outputs are committed).
+
+What is copied is DATA: the fixture files the reference's own tests read
+(tests/data/**) and the expected values its tests assert (parsed out of the
+EXPECT_/ASSERT_ lines of tests/task_main.cpp, tests/merge_test.cpp,
+tests/repartition_test.cpp, tests/packc_test.cpp).  No reference source text
+is stored.
+"""
+import json, os, re, shutil, struct, sys
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def copy_data():
+    for rel in ["1.fasta", "2.fasta", "hash.info", "kmtricks.fof"]:
+        shutil.copyfile(f"{REF}/tests/data/{rel}", f"{OUT}/{rel}")
+    for kind, ext in (("kmers", "kmer"), ("hashes", "hash")):
+        for p in range(4):
+            d = f"{OUT}/partitions/{kind}/partition_{p}"
+            os.makedirs(d, exist_ok=True)
+            for s in ("D1", "D2"):
+                shutil.copyfile(f"{REF}/tests/data/partitions/{kind}/partition_{p}/{s}.{ext}", f"{d}/{s}.{ext}")
+
+
+def repart_sparse():
+    """tests/data/repart_gatb/repartition.minimRepart (2 MB, almost all zero)
+    -> sparse JSON {header fields, non-zero entries}."""
+    raw = open(f"{REF}/tests/data/repart_gatb/repartition.minimRepart", "rb").read()
+    nb_part, nb_minims, nb_pass = struct.unpack_from("<HQH", raw, 0)
+    table = struct.unpack_from(f"<{nb_minims}H", raw, 12)
+    tail = raw[12 + 2 * nb_minims:]
+    has_freq = tail[0]
+    magic = struct.unpack_from("<I", tail, 1)[0]
+    nz = {str(i): v for i, v in enumerate(table) if v}
+    return {"nb_part": nb_part, "nb_minims": nb_minims, "nb_pass": nb_pass,
+            "has_freq": has_freq, "magic": magic, "file_size": len(raw), "nonzero": nz}
+
+
+def task_main_goldens():
+    src = open(f"{REF}/tests/task_main.cpp").read()
+    out = {}
+    # SuperKmerBinInfoFile expected lines (tests/task_main.cpp:85-114)
+    sk = re.findall(r'ASSERT_EQ\(line, "(\d+)"\)', src)
+    out["superk_info_D1"] = [int(x) for x in sk[0:9]]
+    out["superk_info_D2"] = [int(x) for x in sk[9:18]]
+    # blocks of expected k-mers / hashes, in file order
+    blocks = re.split(r'km::KmerReader<8192> kr\("([^"]+)"\)|km::HashReader<4294967296> kr\("([^"]+)"\)', src)
+    # re.split with 2 groups yields [pre, g1, g2, body, g1, g2, body, ...]
+    res = {}
+    for i in range(1, len(blocks), 3):
+        path = blocks[i] or blocks[i + 1]
+        body = blocks[i + 2]
+        body = body.split("km::Kmer<MK> kmer;")[0] if False else body
+        # stop at next reader (already split), keep only this block's asserts
+        kmers = re.findall(r'EXPECT_EQ\(kmer\.to_string\(\), "([ACGT]+)"\); EXPECT_EQ\((\d+), count\)', body)
+        hashes = re.findall(r'EXPECT_EQ\(kmer, (\d+)\); EXPECT_EQ\(count, (\d+)\)', body)
+        nrec = re.search(r'EXPECT_EQ\(n, (\d+)\)', body)
+        key = path.split("km_dir_test/")[1]
+        if kmers:
+            res[key] = {"kmers": [[k, int(c)] for k, c in kmers]}
+        elif hashes:
+            res[key] = {"hashes": [[int(h), int(c)] for h, c in hashes]}
+        elif nrec:
+            res[key] = {"n": int(nrec.group(1))}
+    out["count_files"] = res
+    return out
+
+
+def merge_goldens():
+    src = open(f"{REF}/tests/merge_test.cpp").read()
+    vals = [int(x) for x in re.findall(r'EXPECT_EQ\(count, (\d+)\)', src)]
+    return {"hash_rows": vals[0:4], "kmer_rows": vals[4:8], "soft_min": [1, 1], "rec_min": 1, "share_min": 1}
+
+
+def repartition_goldens():
+    src = open(f"{REF}/tests/repartition_test.cpp").read()
+    ks = re.findall(r'std::string k(\d) = "([ACGT]+)"', src)
+    return {"minimizer_size": 10, "cases": [[k, int(i)] for i, k in ks]}
+
+
+def packc_goldens():
+    src = open(f"{REF}/tests/packc_test.cpp").read()
+    bcp = re.findall(r'byte_count_pack\((\d+), (\d+)\), (\d+)\)', src)
+    tnb = re.findall(r'to_n_b\((\d+), (\d+)\), (\d+)\)', src)
+    return {"byte_count_pack": [[int(a), int(b), int(c)] for a, b, c in bcp],
+            "to_n_b": [[int(a), int(b), int(c)] for a, b, c in tnb]}
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference not mounted; goldens are already committed")
+    copy_data()
+    g = {"repartition_table": repart_sparse(), "task_main": task_main_goldens(),
+         "merge_test": merge_goldens(), "repartition_test": repartition_goldens(),
+         "packc_test": packc_goldens()}
+    json.dump(g, open(f"{OUT}/reference_goldens.json", "w"), indent=1, sort_keys=True)
+    print("wrote", f"{OUT}/reference_goldens.json")

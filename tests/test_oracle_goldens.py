@@ -1,0 +1,174 @@
+"""Pins the CPU oracle (oracle/kmx_oracle.c) against the reference's own golden
+vectors (tests/golden/, extracted from /root/reference/tests by make_golden.py).
+CPU only."""
+import json, os, struct
+import numpy as np
+import pytest
+
+import orc
+import kmfiles
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_goldens.json")))
+GD = os.path.join(os.path.dirname(__file__), "golden")
+K, M, P = 31, 10, 4
+
+
+def repart_table():
+    rt = G["repartition_table"]
+    t = np.zeros(rt["nb_minims"], dtype=np.uint16)
+    for i, v in rt["nonzero"].items():
+        t[int(i)] = v
+    return t
+
+
+def read_fasta(path):
+    seqs, cur = [], []
+    for line in open(path):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur: seqs.append("".join(cur)); cur = []
+        elif line:
+            cur.append(line)
+    if cur: seqs.append("".join(cur))
+    return seqs
+
+
+@pytest.fixture(scope="module")
+def superk():
+    lut = orc.minimizer_lut(M)
+    rep = repart_table()
+    out = {}
+    for name, f in (("D1", "1.fasta"), ("D2", "2.fasta")):
+        out[name] = orc.superk_partition(read_fasta(os.path.join(GD, f)), K, M, lut, rep, P)
+    return out
+
+
+def test_xxh64_known_answers():
+    # XXH64 specification test vectors (xxHash README / sanity tests)
+    assert orc.xxh64(b"", 0) == 0xEF46DB3751D8E999
+    assert orc.xxh64(b"a", 0) == 0xD24EC4F1A98C6E5B
+    assert orc.xxh64(b"abc", 0) == 0x44BC2CF5AD770999
+    try:
+        import xxhash
+    except ImportError:
+        return
+    rng = np.random.default_rng(1)
+    for n in (1, 3, 4, 7, 8, 12, 16, 31, 32, 33, 64, 100):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for seed in (0, 1, 2 ** 63 + 5):
+            assert orc.xxh64(d, seed) == xxhash.xxh64(d, seed=seed).intdigest()
+
+
+def test_repartition_test_minimizers():
+    """tests/repartition_test.cpp:7-18"""
+    lut = orc.minimizer_lut(M)
+    rep = repart_table()
+    for kmer, part in G["repartition_test"]["cases"]:
+        w = orc.kmer_from_string(kmer)
+        assert orc.kmer_to_string(w, K) == kmer
+        # km::Kmer::minimizer (kmer.hpp:848-886) works on the canonical... the gatb model on the forward value;
+        # for these four k-mers both give the asserted partition
+        mini = orc.minimizer_of(w, K, M, lut)
+        assert rep[mini] == part
+
+
+def test_superk_info_counts(superk):
+    """tests/task_main.cpp:85-114: k-mers per super-k-mer file"""
+    for name in ("D1", "D2"):
+        exp = G["task_main"]["superk_info_" + name]
+        assert exp[0] == P
+        got = [superk[name][p][1] for p in range(P)]
+        assert got == exp[1::2]
+
+
+def test_kmer_count_goldens(superk):
+    """tests/task_main.cpp:118-340: canonical 31-mers of partition 0 in file order, record counts elsewhere"""
+    cf = G["task_main"]["count_files"]
+    for name in ("D1", "D2"):
+        for p in range(P):
+            keys, counts = orc.count_kmer(superk[name][p][0], K, 1)
+            exp = cf[f"counts/partition_{p}/{name}.kmer"]
+            if "kmers" in exp:
+                assert [[orc.kmer_to_string(k, K), int(c)] for k, c in zip(keys, counts)] == exp["kmers"]
+            else:
+                assert len(counts) == exp["n"]
+
+
+def test_hash_count_goldens(superk):
+    """tests/task_main.cpp:342-508 with tests/data/hash.info (W = 25 000 000)"""
+    bloom, nparts, wbits, wbytes, msize = struct.unpack("<QQQQI", open(os.path.join(GD, "hash.info"), "rb").read())
+    assert (nparts, wbits, msize) == (4, 25000000, 10)
+    cf = G["task_main"]["count_files"]
+    for name in ("D1", "D2"):
+        for p in range(P):
+            hs, counts = orc.count_hash(superk[name][p][0], K, wbits, p, 1)
+            exp = cf[f"counts/partition_{p}/{name}.hash"]
+            if "hashes" in exp:
+                assert [[int(h), int(c)] for h, c in zip(hs, counts)] == exp["hashes"]
+            else:
+                assert len(counts) == exp["n"]
+            assert np.all((hs >= wbits * p) & (hs < wbits * (p + 1)))
+
+
+def test_count_matches_committed_partition_fixtures(superk):
+    """tests/data/partitions/{kmers,hashes}: the reference's committed count files equal what the
+    oracle computes from the FASTA fixtures (keys; the fixtures were written by a u8-count build)."""
+    for name in ("D1", "D2"):
+        for p in range(P):
+            f = kmfiles.read_kmer_file(f"{GD}/partitions/kmers/partition_{p}/{name}.kmer")
+            keys, counts = orc.count_kmer(superk[name][p][0], K, 1)
+            assert f["k"] == K and np.array_equal(f["keys"], keys) and np.array_equal(f["counts"], counts)
+            h = kmfiles.read_hash_file(f"{GD}/partitions/hashes/partition_{p}/{name}.hash")
+            # the committed .hash fixtures were produced with --bloom-size 1e6: W = round_up64(1e6/4) = 250048
+            # (HashWindow, include/kmtricks/hash.hpp:31-40)
+            hs, hc = orc.count_hash(superk[name][p][0], K, 250048, p, 1)
+            assert np.array_equal(h["keys"], hs) and np.array_equal(h["counts"], hc)
+
+
+@pytest.mark.parametrize("kind", ["kmers", "hashes"])
+def test_merge_test_row_counts(kind):
+    """tests/merge_test.cpp:5-78: 57/67/70/82 rows (next() count = distinct keys)"""
+    mt = G["merge_test"]
+    for p in range(4):
+        lists = []
+        for s in ("D1", "D2"):
+            if kind == "kmers":
+                f = kmfiles.read_kmer_file(f"{GD}/partitions/kmers/partition_{p}/{s}.kmer")
+            else:
+                f = kmfiles.read_hash_file(f"{GD}/partitions/hashes/partition_{p}/{s}.hash")
+            lists.append((f["keys"], f["counts"]))
+        body, rows, stats = orc.merge_matrix(lists, 1, mt["soft_min"], mt["rec_min"], mt["share_min"], orc.MODE_COUNT)
+        assert rows == mt[("kmer" if kind == "kmers" else "hash") + "_rows"][p]
+        assert len(body) == rows * (8 + 2 * 4)
+        m = np.frombuffer(body, dtype=np.uint8).reshape(rows, 16)
+        k = m[:, :8].copy().view(np.uint64).ravel()
+        assert np.all(k[1:] > k[:-1])
+        # every input record is solid (soft-min 1) -> unique == list length
+        assert [int(x) for x in stats[2]] == [len(l[1]) for l in lists]
+
+
+def test_packc_goldens():
+    """tests/packc_test.cpp:5-40"""
+    for n, b, e in G["packc_test"]["byte_count_pack"]:
+        assert orc.byte_count_pack(n, b) == e
+    for c, w, e in G["packc_test"]["to_n_b"]:
+        assert orc.to_n_b(c, w) == e
+
+
+def test_static_repart_matches_xxhash_module():
+    xxhash = pytest.importorskip("xxhash")
+    t = orc.repart_static(6, 7)
+    for m_ in (0, 1, 77, 4095):
+        assert t[m_] == xxhash.xxh64(struct.pack("<I", m_), seed=0).intdigest() % 7
+
+
+def test_transpose_roundtrip():
+    """tests/bit_matrix_test.cpp:60-99: transpose(transpose(x)) == x, and the definition out[c][r]=in[r][c]"""
+    rng = np.random.default_rng(3)
+    for nr, nc in ((8, 8), (16, 8), (24, 40), (64, 128), (200, 72)):
+        m = rng.integers(0, 256, nr * nc // 8, dtype=np.uint8)
+        t = orc.transpose_bits(m, nr, nc)
+        assert np.array_equal(orc.transpose_bits(t, nc, nr), m)
+        bits = np.unpackbits(m.reshape(nr, nc // 8), axis=1, bitorder="little")
+        tb = np.unpackbits(t.reshape(nc, nr // 8), axis=1, bitorder="little")
+        assert np.array_equal(bits.T, tb)
