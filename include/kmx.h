@@ -1,0 +1,161 @@
+/*
+ * kmx.h -- C ABI of the MI355X-native kmtricks counting/merge engine (libkmx.so).
+ *
+ * This is the drop-in boundary: the entry points below are what the
+ * reference's tasks would bind instead of running their CPU classes
+ * (file:line relative to the kmtricks source tree):
+ *
+ *   kmx_merge / kmx_merge_dev   replace km::KmerMerger<MAX_K,MAX_C>::{next,write_as_bin,write_as_pa}
+ *                               (include/kmtricks/merge.hpp:102-361) and km::HashMerger<MAX_C>::
+ *                               {next,write_as_bin,write_as_pa,write_as_bf,write_as_bfc}
+ *                               (merge.hpp:363-629), called from KmerMergeTask::exec / HashMergeTask::exec
+ *                               (include/kmtricks/task.hpp:690-743, 787-863)
+ *   kmx_count_kmer              replaces km::KmerPartCounter::execute + KmerCountProcessor::process
+ *                               (include/kmtricks/gatb/sorting_count.hpp:637-884,
+ *                                include/kmtricks/gatb/count_processor.hpp:135-146), CountTask::exec (task.hpp:367-392)
+ *   kmx_count_hash              replaces km::HashPartCounter::execute + HashCountProcessor::process
+ *                               (sorting_count.hpp:346-363, 908-997; count_processor.hpp:61-70),
+ *                               HashCountTask::exec (task.hpp:447-481)
+ *   kmx_transpose_bits          replaces km::BitMatrix::transpose / __sse_trans
+ *                               (include/kmtricks/bitmatrix.hpp:209-214, 238-289), HashMerger::write_as_bft (merge.hpp:631-644)
+ *   kmx_superk_partition        replaces KmFillPartitions / Sequence2SuperKmer / SuperKmer::save
+ *                               (include/kmtricks/gatb/fill_partitions.hpp:59-105, gatb kmer/impl/Sequence2SuperKmer.hpp:80-158,
+ *                                gatb kmer/impl/Model.hpp:1086-1139, 1388-1433), SuperKTask::exec (task.hpp:255-320)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative KMX_E_* code, with a message in kmx_last_error().
+ * There is NO CPU fallback: without a HIP device kmx_create fails with
+ * KMX_E_NODEVICE.  All integers little-endian.  A ctx is used by one host
+ * thread at a time (one ctx per pool thread, like the reference's tasks).
+ */
+#ifndef KMX_H
+#define KMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMX_VERSION 1
+
+enum {
+  KMX_OK = 0,
+  KMX_E_NODEVICE = -1,   /* no HIP device / HIP runtime error at init */
+  KMX_E_INVAL    = -2,   /* bad argument */
+  KMX_E_NOMEM    = -3,   /* host or device allocation failed */
+  KMX_E_HIP      = -4,   /* HIP runtime error during a call */
+  KMX_E_UNSUPPORTED = -5 /* configuration outside what this build handles (message says which) */
+};
+
+/* matrix row encodings; names follow kmtricks' --mode <kmer|hash>:<count|pa|bf|bfc>:bin */
+enum {
+  KMX_MODE_COUNT = 0,  /* row = key + N * u32           (.count / .count_hash body) */
+  KMX_MODE_PA    = 1,  /* row = key + ceil(N/8) bytes   (.pa / .pa_hash body)       */
+  KMX_MODE_BF    = 2,  /* one ceil(N/8)-byte row per hash of [lower, upper] (.cmbf) */
+  KMX_MODE_BFC   = 3   /* one ceil(N*w/8)-byte row per hash, bitpacker MSB-first    */
+};
+
+typedef struct kmx_ctx kmx_ctx;
+
+int  kmx_version(void);
+int  kmx_create(int device, kmx_ctx** out);
+void kmx_destroy(kmx_ctx* ctx);
+/* last error message of this ctx (or of the failed kmx_create when ctx == NULL) */
+const char* kmx_last_error(const kmx_ctx* ctx);
+/* HIP stream the ctx launches on (a hipStream_t), so callers can order their own work after it */
+void* kmx_stream(kmx_ctx* ctx);
+
+/* ------------------------------------------------------------------ merge */
+
+/* One sample's sorted count list of one partition: `n` packed records of
+ * key_words*8 key bytes (low word first) + a u32 count = the body of a
+ * .kmer count file written with 4-byte counts (io/kmer_file.hpp:102-108).
+ * Keys strictly ascending (most significant word first, kmer.hpp:262-268). */
+typedef struct {
+  const void* recs;
+  uint64_t    n;
+} kmx_list;
+
+/* One merge task = one partition (merge.hpp:115-125, 376-385). */
+typedef struct {
+  uint32_t        n_lists;     /* N samples, fof order = column order (kmdir.hpp:65-72) */
+  uint32_t        key_words;   /* 1: k <= 31 or hash keys; 2: 32 <= k <= 63 */
+  const kmx_list* lists;       /* [n_lists] */
+  const uint32_t* soft_min;    /* [n_lists] per-sample abundance min (m_a_min_vec) */
+  uint32_t        rec_min;     /* recurrence-min (m_r_min) */
+  uint32_t        share_min;   /* share-min / save_if (m_save_if), 0 = no rescue */
+  uint32_t        mode;        /* KMX_MODE_* */
+  uint32_t        bitw;        /* BFC bits per count (--bitw), else ignored */
+  uint64_t        lower, upper;/* BF/BFC: first and last hash of the window (hash.hpp:77-85) */
+  uint64_t        rows_hint;   /* COUNT/PA: expected kept rows (0 = let the engine guess) */
+} kmx_merge_task;
+
+/* statistics layout: 6 * n_lists u64, rows in the order of merge.hpp:72-83:
+ * NON_SOLID, RESCUED, UNIQUE_WO_RESCUE, UNIQUE_W_RESCUE, TOTAL_WO_RESCUE, TOTAL_W_RESCUE */
+#define KMX_STATS_ROWS 6
+
+typedef struct kmx_merge_result kmx_merge_result;
+
+/* Device-resident batch merge: every lists[i].recs is a DEVICE pointer (4-byte
+ * aligned).  Enqueues the whole batch on the ctx stream and returns; the
+ * result stays in HBM until freed.  COUNT/PA rows are produced in row segments
+ * that kmx_result_* hands back in ascending key order. */
+int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, kmx_merge_result** out);
+/* blocks until the batch has finished on the GPU; returns KMX_OK or the error of the run */
+int      kmx_result_wait(kmx_merge_result* r);
+uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA) or window rows (BF/BFC) */
+uint64_t kmx_result_row_bytes(const kmx_merge_result* r, uint32_t task);
+uint64_t kmx_result_body_bytes(const kmx_merge_result* r, uint32_t task);  /* rows * row_bytes */
+/* algorithmic bytes moved for this task: input records + output rows (DESIGN.md roofline) */
+uint64_t kmx_result_algo_bytes(const kmx_merge_result* r, uint32_t task);
+/* copies the matrix file body (rows in ascending key order, exactly what the
+ * reference's writer streams after its header) into host memory */
+int kmx_result_copy_body(kmx_merge_result* r, uint32_t task, void* host_dst, uint64_t dst_bytes);
+int kmx_result_copy_stats(kmx_merge_result* r, uint32_t task, uint64_t* host_stats /* 6 * n_lists */);
+void kmx_result_free(kmx_merge_result* r);
+
+/* Host-buffer convenience around kmx_merge_dev for ONE task: lists[i].recs are
+ * HOST pointers; uploads, merges, returns the body in a buffer to release with
+ * kmx_free.  stats may be NULL. */
+int kmx_merge(kmx_ctx* ctx, const kmx_merge_task* task, void** body, uint64_t* body_bytes,
+              uint64_t* rows, uint64_t* stats);
+
+/* ------------------------------------------------------------------ count */
+
+/* superk: concatenated super-k-mer records [u8 n][2-bit nts] of one
+ * (sample, partition) with the u32 block-size framing of skp.<p> removed
+ * (io/superk_storage.hpp:215-225).  HOST pointers.  Output: ascending
+ * canonical k-mers (key_words = ceil(k/32) words each) with
+ * count >= hard_min, saturated to u32; buffers released with kmx_free. */
+int kmx_count_kmer(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t kmer_size,
+                   uint32_t hard_min, uint64_t** keys, uint32_t** counts, uint64_t* n_out);
+/* window hashes XXH64(words, 8*ceil(k/32), 0) % window + window * partition */
+int kmx_count_hash(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t kmer_size,
+                   uint64_t window, uint64_t partition, uint32_t hard_min,
+                   uint64_t** hashes, uint32_t** counts, uint64_t* n_out);
+
+/* -------------------------------------------------------------- transpose */
+
+/* out[c][r] = in[r][c], bits LSB-first in each byte; nrows, ncols multiples
+ * of 8; in row stride ncols/8 bytes, out row stride nrows/8 bytes.  HOST pointers. */
+int kmx_transpose_bits(kmx_ctx* ctx, const uint8_t* in, uint64_t nrows, uint64_t ncols, uint8_t* out);
+
+/* ------------------------------------------------------ super-k-mer split */
+
+/* Splits `n_seqs` reads (concatenated in `bases`, read i = bases[offsets[i] .. offsets[i+1]))
+ * into super-k-mers and returns, per partition, the concatenated 2-bit records
+ * (same bytes the reference buffers before block framing).  repart: u16[4^m]
+ * minimizer -> partition table.  out_bytes[p] / out_len[p] / out_kmers[p] are
+ * arrays of nb_parts entries; each out_bytes[p] is released with kmx_free. */
+int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                         uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart,
+                         uint32_t nb_parts, uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers);
+
+void kmx_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

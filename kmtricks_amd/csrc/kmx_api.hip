@@ -1,0 +1,481 @@
+// kmx_api.hip -- C ABI of libkmx (include/kmx.h): context, device memory pool, batch merge driver.
+// No CPU fallback anywhere: every entry point needs a live HIP device.
+#include "kmx_host.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+using namespace kmx;
+
+static thread_local std::string g_create_err;
+
+// ---- memory pools ----------------------------------------------------------------------------------
+void* kmx_ctx::dalloc(size_t bytes)
+{
+  if (bytes == 0) bytes = 256;
+  int best = -1;
+  for (size_t i = 0; i < pool.size(); i++)
+    if (!pool[i].used && pool[i].bytes >= bytes && pool[i].bytes <= 2 * bytes + (1u << 20) &&
+        (best < 0 || pool[i].bytes < pool[best].bytes)) best = (int)i;
+  if (best >= 0) { pool[best].used = true; return pool[best].p; }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    // drop cached blocks and retry once
+    for (auto& b : pool) if (!b.used && b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    pool.erase(std::remove_if(pool.begin(), pool.end(), [](const kmx_pool_block& b) { return b.p == nullptr; }), pool.end());
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  }
+  pool.push_back({p, bytes, true});
+  return p;
+}
+void kmx_ctx::dfree(void* p)
+{
+  if (!p) return;
+  for (auto& b : pool) if (b.p == p) { b.used = false; return; }
+}
+void* kmx_ctx::halloc(size_t bytes)
+{
+  if (bytes == 0) bytes = 256;
+  int best = -1;
+  for (size_t i = 0; i < hpool.size(); i++)
+    if (!hpool[i].used && hpool[i].bytes >= bytes && hpool[i].bytes <= 2 * bytes + (1u << 20) &&
+        (best < 0 || hpool[i].bytes < hpool[best].bytes)) best = (int)i;
+  if (best >= 0) { hpool[best].used = true; return hpool[best].p; }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  hpool.push_back({p, bytes, true});
+  return p;
+}
+void kmx_ctx::hfree(void* p)
+{
+  if (!p) return;
+  for (auto& b : hpool) if (b.p == p) { b.used = false; return; }
+}
+
+// ---- context -----------------------------------------------------------------------------------------
+extern "C" int kmx_version(void) { return KMX_VERSION; }
+
+extern "C" int kmx_create(int device, kmx_ctx** out)
+{
+  if (!out) { g_create_err = "kmx_create: out is NULL"; return KMX_E_INVAL; }
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_err = std::string("kmx_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                   "); libkmx has no CPU fallback";
+    return KMX_E_NODEVICE;
+  }
+  if (device < 0 || device >= n) { g_create_err = "kmx_create: device index out of range"; return KMX_E_INVAL; }
+  if ((e = hipSetDevice(device)) != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return KMX_E_NODEVICE; }
+  kmx_ctx* c = new kmx_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
+  c->n_cu = prop.multiProcessorCount;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
+  *out = c;
+  return KMX_OK;
+}
+
+extern "C" void kmx_destroy(kmx_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
+  for (auto& b : ctx->hpool) if (b.p) (void)hipHostFree(b.p);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* kmx_last_error(const kmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" void* kmx_stream(kmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" void kmx_free(void* p) { free(p); }
+
+// ---- merge ---------------------------------------------------------------------------------------------
+struct TaskHost {
+  u32 N = 0, kw = 1, mode = 0, bitw = 0, c = 1, wl = 0, pivot = 0, rt = 0;
+  u32 rec_min = 0, share_min = 0, row_bytes = 0, seg_cap = 0;
+  u64 lower = 0, upper = 0, total_recs = 0, out_cap_rows = 0;
+  std::vector<u32> len;
+  // offsets into the meta blob
+  size_t o_recs = 0, o_len = 0, o_smin = 0, o_bounds = 0, o_stats = 0, o_ctrl = 0, o_segs = 0;
+  u8* d_out = nullptr; size_t out_bytes = 0;
+  Seg* d_segs = nullptr;        // directory in use (inside the meta blob, or d_segs_own after a retry)
+  Seg* d_segs_own = nullptr;
+  // results
+  u64 rows = 0, nsegs = 0;
+  bool done = false;
+};
+
+struct kmx_merge_result {
+  kmx_ctx* ctx = nullptr;
+  std::vector<TaskHost> tasks;
+  u8* d_meta = nullptr; size_t meta_bytes = 0;
+  u8* h_meta = nullptr;              // pinned staging image of the meta blob
+  size_t o_tasks = 0, o_items = 0, o_ticket = 0;
+  u32 n_items = 0, grid = 0, max_n = 0, max_c = 0;
+  int bf_lds = 0;
+  bool is_bf = false, waited = false;
+  int status = KMX_OK;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int launch_batch(kmx_merge_result* R, bool with_bounds)
+{
+  kmx_ctx* ctx = R->ctx;
+  const TaskDev* d_tasks = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_tasks);
+  const uint2* d_items = reinterpret_cast<const uint2*>(R->d_meta + R->o_items);
+  u32* d_ticket = reinterpret_cast<u32*>(R->d_meta + R->o_ticket);
+  const int kw = (int)R->tasks[0].kw, mode = (int)R->tasks[0].mode;
+  const u32 nt = (u32)R->tasks.size();
+  KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 16, ctx->stream));
+  if (R->is_bf) {
+    if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
+    KMX_HIP(ctx, launch_merge_bf(mode == KMX_MODE_BFC, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->bf_lds, ctx->stream));
+  } else {
+    if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
+    KMX_HIP(ctx, launch_merge_rows(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
+  }
+  return KMX_OK;
+}
+
+extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, kmx_merge_result** out)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!tasks || !n_tasks || !out) return ctx->fail(KMX_E_INVAL, "kmx_merge_dev: null argument");
+  *out = nullptr;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  const u32 kw = tasks[0].key_words, mode = tasks[0].mode;
+  if (kw != 1 && kw != 2) return ctx->fail(KMX_E_INVAL, "key_words must be 1 or 2");
+  if (mode > KMX_MODE_BFC) return ctx->fail(KMX_E_INVAL, "unknown mode");
+  const bool is_bf = mode == KMX_MODE_BF || mode == KMX_MODE_BFC;
+  if (is_bf && kw != 1) return ctx->fail(KMX_E_INVAL, "BF/BFC modes take hash keys (key_words = 1)");
+
+  std::unique_ptr<kmx_merge_result> R(new kmx_merge_result());
+  R->ctx = ctx; R->is_bf = is_bf;
+  R->tasks.resize(n_tasks);
+  u64 grand_total = 0;
+  for (u32 t = 0; t < n_tasks; t++) {
+    const kmx_merge_task& K = tasks[t];
+    TaskHost& H = R->tasks[t];
+    if (K.key_words != kw || K.mode != mode) return ctx->fail(KMX_E_INVAL, "all tasks of a batch must share key_words and mode");
+    if (K.n_lists == 0 || !K.lists || !K.soft_min) return ctx->fail(KMX_E_INVAL, "task without lists / soft_min");
+    H.N = K.n_lists; H.kw = kw; H.mode = mode; H.bitw = K.bitw;
+    H.rec_min = K.rec_min; H.share_min = K.share_min; H.lower = K.lower; H.upper = K.upper;
+    if (!is_bf && H.N > (u32)rows_cap()) return ctx->fail(KMX_E_UNSUPPORTED, "more than 4096 lists per merge task (COUNT/PA) not supported yet");
+    H.len.resize(H.N);
+    u32 pivot = 0;
+    for (u32 i = 0; i < H.N; i++) {
+      if (K.lists[i].n > 0xFFFFFFF0ULL) return ctx->fail(KMX_E_UNSUPPORTED, "list longer than 2^32 records");
+      if (K.lists[i].n && !K.lists[i].recs) return ctx->fail(KMX_E_INVAL, "null record pointer");
+      if (((uintptr_t)K.lists[i].recs) & 3u) return ctx->fail(KMX_E_INVAL, "record pointers must be 4-byte aligned");
+      H.len[i] = (u32)K.lists[i].n;
+      H.total_recs += K.lists[i].n;
+      if (H.len[i] > H.len[pivot]) pivot = i;
+    }
+    H.pivot = pivot;
+    grand_total += H.total_recs;
+    if (is_bf) {
+      if (K.upper < K.lower) return ctx->fail(KMX_E_INVAL, "BF window upper < lower");
+      if (mode == KMX_MODE_BFC && (K.bitw == 0 || K.bitw > 32)) return ctx->fail(KMX_E_INVAL, "bitw must be in 1..32");
+      H.row_bytes = mode == KMX_MODE_BF ? (H.N + 7) / 8 : (u32)(((u64)H.N * K.bitw + 7) / 8);
+      u32 rt = (40960u / H.row_bytes) & ~63u; if (rt < 64) rt = 64;
+      if ((u64)rt * H.row_bytes > 96 * 1024) return ctx->fail(KMX_E_UNSUPPORTED, "BF row too wide for one LDS tile");
+      H.rt = rt;
+      H.out_bytes = (size_t)((K.upper - K.lower + 1) * H.row_bytes);
+    } else {
+      H.row_bytes = kw * 8 + (mode == KMX_MODE_COUNT ? 4 * H.N : (H.N + 7) / 8);
+      if (H.row_bytes > 60000) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
+      u32 wl = 0; while ((H.N << (wl + 1)) <= (u32)rows_cap()) wl++;
+      H.wl = wl;
+      u64 guess = K.rows_hint ? K.rows_hint : 2ULL * H.len[pivot] + 4096;
+      if (guess > H.total_recs) guess = H.total_recs;
+      H.out_cap_rows = std::max<u64>(guess, 1);
+      H.out_bytes = (size_t)(H.out_cap_rows * H.row_bytes);
+    }
+  }
+  // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
+  const u32 slots = (u32)ctx->n_cu * 2;
+  const u32 target_items = slots * 3;
+  u32 n_items = 0, max_n = 0, max_c = 0;
+  for (auto& H : R->tasks) {
+    u64 c = grand_total ? (u64)target_items * H.total_recs / grand_total : 1;
+    const u64 cmax_work = std::max<u64>(1, H.total_recs / 16384);
+    c = std::min(c, cmax_work);
+    if (is_bf) {
+      const u64 tiles = ((H.upper - H.lower + 1) + H.rt - 1) / H.rt;
+      c = std::min<u64>(c, tiles);
+    } else c = std::min<u64>(c, std::max<u32>(1, H.len[H.pivot]));
+    H.c = (u32)std::max<u64>(1, c);
+    H.seg_cap = is_bf ? 1 : (u32)std::min<u64>(0x7FFFFFFF, H.total_recs / 512 + 8ULL * H.c + 4096);
+    n_items += H.c;
+    max_n = std::max(max_n, H.N); max_c = std::max(max_c, H.c);
+  }
+  R->n_items = n_items; R->max_n = max_n; R->max_c = max_c;
+  R->grid = std::min(n_items, slots);
+  if (is_bf) {
+    int lds = 0;
+    for (auto& H : R->tasks) lds = std::max(lds, bf_lds_bytes(H.rt, H.row_bytes, H.N));
+    R->bf_lds = lds;
+  }
+
+  // ---- meta blob layout ----
+  size_t off = 0;
+  R->o_tasks = off; off = align_up(off + sizeof(TaskDev) * n_tasks, 256);
+  R->o_items = off; off = align_up(off + sizeof(uint2) * n_items, 256);
+  R->o_ticket = off; off += 256;
+  for (auto& H : R->tasks) {
+    H.o_recs = off; off = align_up(off + 8ull * H.N, 256);
+    H.o_len = off; off = align_up(off + 4ull * H.N, 256);
+    H.o_smin = off; off = align_up(off + 4ull * H.N, 256);
+    H.o_stats = off; off = align_up(off + 8ull * 6 * H.N, 256);
+    H.o_ctrl = off; off += 256;
+  }
+  const size_t upload_bytes = off;            // everything above is written by the host
+  for (auto& H : R->tasks) {
+    H.o_bounds = off; off = align_up(off + 4ull * (H.c + 1) * H.N, 256);
+    H.o_segs = off; off = align_up(off + sizeof(Seg) * (size_t)H.seg_cap, 256);
+  }
+  R->meta_bytes = off;
+  R->d_meta = (u8*)ctx->dalloc(off);
+  R->h_meta = (u8*)ctx->halloc(upload_bytes);
+  if (!R->d_meta || !R->h_meta) { ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); return ctx->fail(KMX_E_NOMEM, "meta allocation failed"); }
+  for (auto& H : R->tasks) {
+    H.d_out = (u8*)ctx->dalloc(H.out_bytes);
+    if (!H.d_out) {
+      for (auto& G : R->tasks) ctx->dfree(G.d_out);
+      ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
+      return ctx->fail(KMX_E_NOMEM, "output arena allocation failed");
+    }
+  }
+  memset(R->h_meta, 0, upload_bytes);
+  TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
+  uint2* items = reinterpret_cast<uint2*>(R->h_meta + R->o_items);
+  u32 it = 0;
+  for (u32 t = 0; t < n_tasks; t++) {
+    TaskHost& H = R->tasks[t];
+    const kmx_merge_task& K = tasks[t];
+    const u8** recs = reinterpret_cast<const u8**>(R->h_meta + H.o_recs);
+    u32* len = reinterpret_cast<u32*>(R->h_meta + H.o_len);
+    u32* smin = reinterpret_cast<u32*>(R->h_meta + H.o_smin);
+    for (u32 i = 0; i < H.N; i++) { recs[i] = (const u8*)K.lists[i].recs; len[i] = H.len[i]; smin[i] = K.soft_min[i]; }
+    TaskDev& D = td[t];
+    D.recs = reinterpret_cast<const u8* const*>(R->d_meta + H.o_recs);
+    D.len = reinterpret_cast<const u32*>(R->d_meta + H.o_len);
+    D.soft_min = reinterpret_cast<const u32*>(R->d_meta + H.o_smin);
+    D.bounds = reinterpret_cast<u32*>(R->d_meta + H.o_bounds);
+    D.stats = reinterpret_cast<u64*>(R->d_meta + H.o_stats);
+    D.out = H.d_out;
+    D.ctrl = reinterpret_cast<u64*>(R->d_meta + H.o_ctrl);
+    H.d_segs = reinterpret_cast<Seg*>(R->d_meta + H.o_segs);
+    D.segs = H.d_segs;
+    D.out_cap_rows = H.out_cap_rows; D.lower = H.lower; D.upper = H.upper;
+    D.seg_cap = H.seg_cap; D.N = H.N; D.c = H.c; D.rec_min = H.rec_min; D.share_min = H.share_min;
+    D.mode = H.mode; D.bitw = H.bitw; D.row_bytes = H.row_bytes; D.wl = H.wl; D.pivot = H.pivot; D.rt = H.rt;
+    D.item0 = it;
+    for (u32 j = 0; j < H.c; j++) items[it++] = make_uint2(t, j);
+  }
+  KMX_HIP(ctx, hipMemcpyAsync(R->d_meta, R->h_meta, upload_bytes, hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch_batch(R.get(), true);
+  if (rc != KMX_OK) return rc;
+  *out = R.release();
+  return KMX_OK;
+}
+
+static int fetch_ctrl(kmx_merge_result* R, bool* overflow)
+{
+  kmx_ctx* ctx = R->ctx;
+  *overflow = false;
+  for (auto& H : R->tasks) {
+    u64 ctrl[4];
+    KMX_HIP(ctx, hipMemcpyAsync(ctrl, R->d_meta + H.o_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    H.rows = ctrl[0]; H.nsegs = ctrl[1];
+    if (ctrl[2]) *overflow = true;
+  }
+  return KMX_OK;
+}
+
+extern "C" int kmx_result_wait(kmx_merge_result* R)
+{
+  if (!R) return KMX_E_INVAL;
+  if (R->waited) return R->status;
+  kmx_ctx* ctx = R->ctx;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (R->is_bf) {
+    for (auto& H : R->tasks) H.rows = H.upper - H.lower + 1;
+    R->waited = true; R->status = KMX_OK;
+    return KMX_OK;
+  }
+  bool overflow = false;
+  int rc = fetch_ctrl(R, &overflow);
+  if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+  if (overflow) {
+    // the kernel kept counting: re-run with arenas / directories of the exact size
+    TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
+    for (size_t t = 0; t < R->tasks.size(); t++) {
+      TaskHost& H = R->tasks[t];
+      if (H.rows > H.out_cap_rows) {
+        ctx->dfree(H.d_out);
+        H.out_cap_rows = H.rows; H.out_bytes = (size_t)(H.rows * H.row_bytes);
+        H.d_out = (u8*)ctx->dalloc(H.out_bytes);
+        if (!H.d_out) { R->waited = true; R->status = ctx->fail(KMX_E_NOMEM, "output arena allocation failed (retry)"); return R->status; }
+        td[t].out = H.d_out; td[t].out_cap_rows = H.out_cap_rows;
+      }
+      if (H.nsegs > H.seg_cap) {   // a larger directory in its own block
+        H.seg_cap = (u32)H.nsegs;
+        if (H.d_segs_own) ctx->dfree(H.d_segs_own);
+        H.d_segs_own = (Seg*)ctx->dalloc(sizeof(Seg) * (size_t)H.seg_cap);
+        if (!H.d_segs_own) { R->waited = true; R->status = ctx->fail(KMX_E_NOMEM, "segment directory allocation failed (retry)"); return R->status; }
+        H.d_segs = H.d_segs_own;
+        td[t].segs = H.d_segs; td[t].seg_cap = H.seg_cap;
+      }
+    }
+    // reset stats + ctrl, upload patched descriptors, run the merge again (bounds are still valid)
+    for (auto& H : R->tasks) {
+      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
+      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 256, ctx->stream));
+    }
+    KMX_HIP(ctx, hipMemcpyAsync(R->d_meta + R->o_tasks, R->h_meta + R->o_tasks, sizeof(TaskDev) * R->tasks.size(),
+                                hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_batch(R, false);
+    if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = fetch_ctrl(R, &overflow);
+    if (rc == KMX_OK && overflow) rc = ctx->fail(KMX_E_HIP, "merge overflowed its exact-size arena (internal error)");
+    if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+  }
+  R->waited = true; R->status = KMX_OK;
+  return KMX_OK;
+}
+
+extern "C" uint64_t kmx_result_rows(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].rows : 0; }
+extern "C" uint64_t kmx_result_row_bytes(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].row_bytes : 0; }
+extern "C" uint64_t kmx_result_body_bytes(const kmx_merge_result* R, uint32_t t)
+{ return (R && t < R->tasks.size()) ? R->tasks[t].rows * R->tasks[t].row_bytes : 0; }
+extern "C" uint64_t kmx_result_algo_bytes(const kmx_merge_result* R, uint32_t t)
+{
+  if (!R || t >= R->tasks.size()) return 0;
+  const TaskHost& H = R->tasks[t];
+  return H.total_recs * (H.kw * 8 + 4) + H.rows * H.row_bytes;
+}
+
+extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, uint64_t dst_bytes)
+{
+  if (!R || t >= R->tasks.size()) return KMX_E_INVAL;
+  kmx_ctx* ctx = R->ctx;
+  int rc = kmx_result_wait(R);
+  if (rc != KMX_OK) return rc;
+  TaskHost& H = R->tasks[t];
+  const u64 body = H.rows * H.row_bytes;
+  if (dst_bytes < body) return ctx->fail(KMX_E_INVAL, "destination too small");
+  if (body == 0) return KMX_OK;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  if (R->is_bf) {
+    KMX_HIP(ctx, hipMemcpyAsync(dst, H.d_out, body, hipMemcpyDeviceToHost, ctx->stream));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KMX_OK;
+  }
+  std::vector<Seg> segs(H.nsegs);
+  KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->stream));
+  u8* tmp = (u8*)malloc(body);
+  if (!tmp) return ctx->fail(KMX_E_NOMEM, "host staging allocation failed");
+  KMX_HIP(ctx, hipMemcpyAsync(tmp, H.d_out, body, hipMemcpyDeviceToHost, ctx->stream));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.range != b.range ? a.range < b.range : a.seq < b.seq; });
+  u8* d = (u8*)dst;
+  u64 done = 0;
+  for (const Seg& s : segs) {
+    const u64 nb = (u64)s.nrows * H.row_bytes;
+    if (s.row_off * H.row_bytes + nb > body || done + nb > body) { free(tmp); return ctx->fail(KMX_E_HIP, "corrupt segment directory"); }
+    memcpy(d + done, tmp + s.row_off * H.row_bytes, nb);
+    done += nb;
+  }
+  free(tmp);
+  if (done != body) return ctx->fail(KMX_E_HIP, "segment directory does not cover the arena");
+  return KMX_OK;
+}
+
+extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* st)
+{
+  if (!R || t >= R->tasks.size() || !st) return KMX_E_INVAL;
+  kmx_ctx* ctx = R->ctx;
+  int rc = kmx_result_wait(R);
+  if (rc != KMX_OK) return rc;
+  TaskHost& H = R->tasks[t];
+  const u32 N = H.N;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  KMX_HIP(ctx, hipMemcpyAsync(st, R->d_meta + H.o_stats, 8ull * 6 * N, hipMemcpyDeviceToHost, ctx->stream));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // kernels fill RESCUED (1), UNIQUE_WO (2), TOTAL_WO (4) and the rescued total (5); derive the rest
+  // exactly as MergeStatistics does (merge.hpp:65-70): every record is either solid or non-solid.
+  for (u32 i = 0; i < N; i++) {
+    const u64 rd = st[1 * (u64)N + i], uwo = st[2 * (u64)N + i], two = st[4 * (u64)N + i], twr = st[5 * (u64)N + i];
+    st[0 * (u64)N + i] = (u64)H.len[i] - uwo;
+    st[3 * (u64)N + i] = uwo + rd;
+    st[5 * (u64)N + i] = two + twr;
+  }
+  return KMX_OK;
+}
+
+extern "C" void kmx_result_free(kmx_merge_result* R)
+{
+  if (!R) return;
+  kmx_ctx* ctx = R->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); }
+  ctx->dfree(R->d_meta);
+  ctx->hfree(R->h_meta);
+  delete R;
+}
+
+extern "C" int kmx_merge(kmx_ctx* ctx, const kmx_merge_task* task, void** body, uint64_t* body_bytes, uint64_t* rows, uint64_t* stats)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!task || !body || !body_bytes || !rows) return ctx->fail(KMX_E_INVAL, "kmx_merge: null argument");
+  *body = nullptr; *body_bytes = 0; *rows = 0;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  if (task->key_words != 1 && task->key_words != 2) return ctx->fail(KMX_E_INVAL, "key_words must be 1 or 2");
+  const size_t rb = task->key_words * 8 + 4;
+  std::vector<kmx_list> dl(task->n_lists);
+  size_t total = 0;
+  for (u32 i = 0; i < task->n_lists; i++) total += align_up(task->lists[i].n * rb, 256);
+  u8* d_in = (u8*)ctx->dalloc(total);
+  if (!d_in) return ctx->fail(KMX_E_NOMEM, "input upload allocation failed");
+  size_t off = 0;
+  for (u32 i = 0; i < task->n_lists; i++) {
+    dl[i].recs = d_in + off; dl[i].n = task->lists[i].n;
+    if (task->lists[i].n) {
+      hipError_t e = hipMemcpyAsync(d_in + off, task->lists[i].recs, task->lists[i].n * rb, hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) { ctx->dfree(d_in); return ctx->fail(KMX_E_HIP, std::string("upload: ") + hipGetErrorString(e)); }
+    }
+    off += align_up(task->lists[i].n * rb, 256);
+  }
+  kmx_merge_task dt = *task;
+  dt.lists = dl.data();
+  kmx_merge_result* R = nullptr;
+  int rc = kmx_merge_dev(ctx, &dt, 1, &R);
+  if (rc == KMX_OK) rc = kmx_result_wait(R);
+  if (rc == KMX_OK) {
+    const u64 nb = kmx_result_body_bytes(R, 0);
+    void* b = malloc(nb ? nb : 1);
+    if (!b) rc = ctx->fail(KMX_E_NOMEM, "host body allocation failed");
+    else {
+      rc = kmx_result_copy_body(R, 0, b, nb);
+      if (rc == KMX_OK && stats) rc = kmx_result_copy_stats(R, 0, stats);
+      if (rc == KMX_OK) { *body = b; *body_bytes = nb; *rows = kmx_result_rows(R, 0); }
+      else free(b);
+    }
+  }
+  if (R) kmx_result_free(R);
+  else (void)hipStreamSynchronize(ctx->stream);
+  ctx->dfree(d_in);
+  return rc;
+}

@@ -1,0 +1,94 @@
+// kmx_dev.hpp -- device-side descriptors and small wave/workgroup helpers shared by the
+// gfx950 kernels of libkmx.  Wave = 64 lanes (CDNA4); no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmx {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+// ---- merge task as the kernels see it (one per partition, array in HBM) ----------------------
+struct Seg {            // one row segment of a COUNT/PA task: rows [row_off, row_off + nrows) of the arena
+  u32 range;            // key range that produced it
+  u32 seq;              // tile sequence number inside the range (ascending = ascending keys)
+  u64 row_off;
+  u32 nrows;
+  u32 pad;
+};
+
+struct TaskDev {
+  const u8* const* recs;   // [N] device pointers to packed records (key words + u32 count)
+  const u32* len;          // [N] records per list
+  const u32* soft_min;     // [N]
+  u32* bounds;             // [(c + 1) * N] first record of range j in list i
+  u64* stats;              // [6 * N]; kernels fill rows 1 (RESCUED), 2 (UNIQUE_WO), 4 (TOTAL_WO), 5 (rescued total)
+  u8* out;                 // COUNT/PA: row arena; BF/BFC: dense window image
+  u64* ctrl;               // [0] rows allocated so far, [1] segments produced, [2] error bits
+  Seg* segs;
+  u64 out_cap_rows;
+  u64 lower, upper;        // BF window [lower, upper]
+  u32 seg_cap;
+  u32 N;                   // lists
+  u32 c;                   // key ranges
+  u32 rec_min, share_min;
+  u32 mode, bitw;
+  u32 row_bytes;           // COUNT/PA: key + payload; BF/BFC: payload
+  u32 wl;                  // log2(window slots per list) for the rows kernel
+  u32 pivot;               // list whose quantiles split the key space
+  u32 rt;                  // BF: rows per tile
+  u32 item0;               // first work item of this task in the batch's flat item space
+};
+
+enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2 };
+
+// ---- keys -------------------------------------------------------------------------------------
+template <int KW> struct Key { u64 w[KW]; };
+
+template <int KW> __device__ __forceinline__ bool key_less(const Key<KW>& a, const Key<KW>& b) {
+  if (KW == 2) { if (a.w[KW - 1] != b.w[KW - 1]) return a.w[KW - 1] < b.w[KW - 1]; }
+  return a.w[0] < b.w[0];
+}
+template <int KW> __device__ __forceinline__ bool key_eq(const Key<KW>& a, const Key<KW>& b) {
+  bool e = a.w[0] == b.w[0];
+  if (KW == 2) e = e && (a.w[KW - 1] == b.w[KW - 1]);
+  return e;
+}
+template <int KW> __device__ __forceinline__ bool key_le(const Key<KW>& a, const Key<KW>& b) { return !key_less<KW>(b, a); }
+template <int KW> __device__ __forceinline__ Key<KW> key_inf() { Key<KW> k; for (int i = 0; i < KW; i++) k.w[i] = ~0ULL; return k; }
+template <int KW> __device__ __forceinline__ Key<KW> key_min(const Key<KW>& a, const Key<KW>& b) { return key_less<KW>(b, a) ? b : a; }
+
+// records are 4-byte aligned only (KW*8 + 4 bytes each): load as dwords
+template <int KW> __device__ __forceinline__ Key<KW> load_key(const u8* p) {
+  const u32* q = reinterpret_cast<const u32*>(p);
+  Key<KW> k;
+#pragma unroll
+  for (int i = 0; i < KW; i++) k.w[i] = (u64)q[2 * i] | ((u64)q[2 * i + 1] << 32);
+  return k;
+}
+
+// ---- wave helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+  u32 lo = __shfl_xor((u32)v, m), hi = __shfl_xor((u32)(v >> 32), m);
+  return (u64)lo | ((u64)hi << 32);
+}
+template <int KW> __device__ __forceinline__ Key<KW> wave_min_key(Key<KW> k) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Key<KW> o;
+#pragma unroll
+    for (int i = 0; i < KW; i++) o.w[i] = shfl_xor_u64(k.w[i], off);
+    k = key_min<KW>(k, o);
+  }
+  return k;
+}
+__device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { u32 t = __shfl_up(v, off); if (lane >= off) v += t; }
+  return v;
+}
+
+}  // namespace kmx

@@ -1,0 +1,47 @@
+// kmx_host.hpp -- host-side declarations shared by the translation units of libkmx.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "kmx_dev.hpp"
+#include "../../include/kmx.h"
+
+namespace kmx {
+
+// kernel launchers (defined next to their kernels)
+int rows_lds_bytes(int kw, u32 n_lists);
+int rows_cap();
+hipError_t launch_range_bounds(int kw, const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);
+hipError_t launch_merge_rows(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
+                             u32 grid_x, u32 max_n, hipStream_t st);
+int bf_lds_bytes(u32 rt, u32 nb, u32 n_lists);
+hipError_t launch_range_bounds_bf(const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);
+hipError_t launch_merge_bf(int bfc, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
+                           u32 grid_x, int lds, hipStream_t st);
+
+}  // namespace kmx
+
+// ---- context -------------------------------------------------------------------------------------
+struct kmx_pool_block { void* p; size_t bytes; bool used; };
+
+struct kmx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cu = 0;
+  std::string err;
+  std::vector<kmx_pool_block> pool;     // device blocks kept for reuse (bench steps allocate nothing)
+  std::vector<kmx_pool_block> hpool;    // pinned host blocks
+
+  void* dalloc(size_t bytes);
+  void dfree(void* p);
+  void* halloc(size_t bytes);
+  void hfree(void* p);
+  int fail(int code, const std::string& msg) { err = msg; return code; }
+};
+
+#define KMX_HIP(ctx, call)                                                                         \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return (ctx)->fail(KMX_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));           \
+  } while (0)

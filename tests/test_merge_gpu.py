@@ -1,0 +1,129 @@
+"""Parity of the HIP merge (libkmx through its C ABI) against the CPU oracle: bit-exact matrix
+bodies and merge statistics.  Needs an MI355X: run with -m gpu."""
+import json, os
+import numpy as np
+import pytest
+
+import orc
+import kmfiles
+from synth import synth_lists, synth_hash_lists
+
+pytestmark = pytest.mark.gpu
+GD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kmtricks_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def check(ctx, lists, kw, soft_min, rec_min, share_min, mode, lower=0, upper=0, bitw=2, rows_hint=0):
+    exp_body, exp_rows, exp_stats = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], kw, soft_min, rec_min,
+                                                     share_min, mode, lower, upper, bitw)
+    body, rows, stats = ctx.merge([(k, c) for k, c in lists], kw, soft_min, rec_min, share_min, mode, lower, upper,
+                                  bitw, rows_hint)
+    assert rows == exp_rows
+    assert len(body) == len(exp_body)
+    if body != exp_body:
+        a = np.frombuffer(body, np.uint8); b = np.frombuffer(exp_body, np.uint8)
+        bad = np.nonzero(a != b)[0]
+        raise AssertionError(f"body differs at {len(bad)} bytes, first at {bad[:8]}")
+    assert np.array_equal(stats, exp_stats), (stats, exp_stats)
+    return rows
+
+
+def fixture_lists(kind, p):
+    out = []
+    for s in ("D1", "D2"):
+        if kind == "kmers":
+            f = kmfiles.read_kmer_file(f"{GD}/partitions/kmers/partition_{p}/{s}.kmer")
+        else:
+            f = kmfiles.read_hash_file(f"{GD}/partitions/hashes/partition_{p}/{s}.hash")
+        out.append((f["keys"].reshape(-1, 1), f["counts"]))
+    return out
+
+
+@pytest.mark.parametrize("kind", ["kmers", "hashes"])
+def test_reference_fixtures_row_counts(ctx, kind):
+    """tests/merge_test.cpp:5-78 on the committed partitions: 57/67/70/82 rows"""
+    G = json.load(open(os.path.join(GD, "reference_goldens.json")))["merge_test"]
+    for p in range(4):
+        lists = fixture_lists(kind, p)
+        for mode in (orc.MODE_COUNT, orc.MODE_PA):
+            rows = check(ctx, lists, 1, [1, 1], 1, 1, mode)
+            assert rows == G["kmer_rows"][p]
+
+
+def test_reference_fixtures_bf(ctx):
+    W = 250048  # window of the committed .hash fixtures (bloom 1e6 / 4 partitions, hash.hpp:31-40)
+    for p in range(4):
+        lists = fixture_lists("hashes", p)
+        check(ctx, lists, 1, [1, 1], 1, 0, orc.MODE_BF, W * p, W * (p + 1) - 1)
+        check(ctx, lists, 1, [1, 1], 1, 0, orc.MODE_BFC, W * p, W * (p + 1) - 1, bitw=2)
+
+
+CASES = [
+    # n_lists, pool, p_present, n_private, soft_min, rec_min, share_min
+    (1, 500, 1.0, 0, 1, 1, 0),
+    (2, 3000, 0.7, 900, 1, 1, 0),
+    (3, 2000, 0.9, 100, 3, 2, 1),
+    (17, 1500, 0.8, 50, 2, 1, 2),
+    (64, 900, 0.95, 20, 5, 3, 2),
+    (100, 700, 0.9, 11, 1, 2, 0),
+    (333, 300, 0.97, 7, 10, 50, 20),
+    (1000, 120, 0.97, 4, 1, 2, 0),
+    (1000, 60, 0.5, 2, 25, 1, 100),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
+def test_synthetic_kmer_rows(ctx, case, mode):
+    n, pool, pp, npriv, smin, rmin, share = case
+    lists = synth_lists(1234 + n, n, pool, pp, npriv, kw=1)
+    soft = [smin + (i % 3) for i in range(n)]
+    check(ctx, lists, 1, soft, rmin, share, mode)
+
+
+@pytest.mark.parametrize("case", [(2, 2500, 0.6, 700, 1, 1, 0), (50, 800, 0.9, 30, 4, 2, 3), (700, 150, 0.95, 5, 1, 2, 0)])
+@pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
+def test_synthetic_k63_rows(ctx, case, mode):
+    """128-bit keys (32 <= k <= 63, Kmer<64>): compare most significant word first"""
+    n, pool, pp, npriv, smin, rmin, share = case
+    lists = synth_lists(77 + n, n, pool, pp, npriv, kw=2, key_bits=126)
+    check(ctx, lists, 2, [smin] * n, rmin, share, mode)
+
+
+def test_sparse_many_distinct_per_tile(ctx):
+    """few long lists: thousands of distinct keys per tile (slow ranking path)"""
+    lists = synth_lists(5, 4, 20000, 0.3, 6000, kw=1)
+    check(ctx, lists, 1, [1] * 4, 1, 0, orc.MODE_COUNT)
+    check(ctx, lists, 1, [2] * 4, 2, 1, orc.MODE_PA)
+
+
+def test_empty_and_ragged(ctx):
+    lists = synth_lists(9, 40, 600, 0.8, 10, ragged=True)
+    check(ctx, lists, 1, [1] * 40, 1, 0, orc.MODE_COUNT)
+    empty = [(np.zeros((0, 1), np.uint64), np.zeros(0, np.uint32)) for _ in range(5)]
+    check(ctx, empty, 1, [1] * 5, 1, 0, orc.MODE_COUNT)
+    check(ctx, empty, 1, [1] * 5, 1, 0, orc.MODE_BF, 640, 640 + 6399)   # Appendix B-6: W zero rows
+    one = [lists[0]] + empty
+    check(ctx, one, 1, [1] * 6, 1, 0, orc.MODE_PA)
+
+
+def test_rows_hint_too_small_retries(ctx):
+    lists = synth_lists(11, 8, 100, 0.5, 5000, kw=1)
+    check(ctx, lists, 1, [1] * 8, 1, 0, orc.MODE_COUNT, rows_hint=3)
+
+
+@pytest.mark.parametrize("n,dens,smin,rmin,share", [(11, 0.3, 10, 3, 2), (100, 0.05, 1, 1, 0), (100, 0.05, 2, 2, 1), (257, 0.02, 3, 1, 5)])
+@pytest.mark.parametrize("mode", [orc.MODE_BF, orc.MODE_BFC])
+def test_synthetic_bf(ctx, n, dens, smin, rmin, share, mode):
+    lower, W = 3 * 19200, 19200
+    lists = synth_hash_lists(42 + n, n, lower, W, dens)
+    check(ctx, lists, 1, [smin + (i % 2) for i in range(n)], rmin, share, mode, lower, lower + W - 1, bitw=2)
+    if mode == orc.MODE_BFC:
+        check(ctx, lists, 1, [1] * n, 1, 0, mode, lower, lower + W - 1, bitw=3)
