@@ -64,6 +64,9 @@ int  kmx_create(int device, kmx_ctx** out);
 void kmx_destroy(kmx_ctx* ctx);
 /* last error message of this ctx (or of the failed kmx_create when ctx == NULL) */
 const char* kmx_last_error(const kmx_ctx* ctx);
+/* When on, the merge driver brackets its dominant kernel (k_merge_rows / k_merge_bf) with HIP
+ * events on the ctx stream so that bench.py can report the kernel's launch duration. */
+int  kmx_set_profiling(kmx_ctx* ctx, int on);
 /* HIP stream the ctx launches on (a hipStream_t), so callers can order their own work after it */
 void* kmx_stream(kmx_ctx* ctx);
 
@@ -105,6 +108,8 @@ typedef struct kmx_merge_result kmx_merge_result;
 int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, kmx_merge_result** out);
 /* blocks until the batch has finished on the GPU; returns KMX_OK or the error of the run */
 int      kmx_result_wait(kmx_merge_result* r);
+/* duration in ms of the batch's merge kernel launch (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
+double   kmx_result_kernel_ms(kmx_merge_result* r);
 uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA) or window rows (BF/BFC) */
 uint64_t kmx_result_row_bytes(const kmx_merge_result* r, uint32_t task);
 uint64_t kmx_result_body_bytes(const kmx_merge_result* r, uint32_t task);  /* rows * row_bytes */

@@ -1,0 +1,248 @@
+// count.hip -- per (sample, partition) k-mer / window-hash counting on gfx950.
+// Replaces km::ReadSuperk / ReadSuperkHash (decode), KmerSort / HashSort (std::sort),
+// KmerPartCounter::executeDump / HashPartCounter::executeDump (run-length) and the hard-min /
+// saturate step of the count processors (reference include/kmtricks/gatb/sorting_count.hpp:141-312,
+// 346-470, 488-533, 694-884, 971-990; include/kmtricks/gatb/count_processor.hpp:61-70, 135-146).
+//
+// Pipeline: 2-bit super-k-mer records (HBM, read coalesced-ish one thread per record) -> canonical
+// k-mers rolled in registers (revcomp by bit tricks, XXH64 in registers for hash mode) -> device
+// radix sort -> run-length encode -> hard-min filter.  The sort / RLE / select primitives are
+// rocPRIM's (plain library ops); the decode + hash kernel is hand-written.
+#include <cstdlib>
+#include <cstring>
+#include "kmx_host.hpp"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_select.hpp>
+
+namespace kmx {
+
+typedef __uint128_t u128;
+
+__device__ __forceinline__ u64 rev_digits64(u64 x)
+{ // reverse the 32 2-bit digits of a word
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  return __builtin_bswap64(x);
+}
+__device__ __forceinline__ u64 revcomp64(u64 x, int k)
+{ // A0 C1 T2 G3: complement = digit ^ 2 (gatb kmer/impl/Model.hpp:857-884)
+  return (rev_digits64(x) ^ 0xAAAAAAAAAAAAAAAAULL) >> (64 - 2 * k);
+}
+__device__ __forceinline__ u128 revcomp128(u128 x, int k)
+{
+  const u64 lo = (u64)x, hi = (u64)(x >> 64);
+  const u128 r = ((u128)(rev_digits64(lo) ^ 0xAAAAAAAAAAAAAAAAULL) << 64) | (u128)(rev_digits64(hi) ^ 0xAAAAAAAAAAAAAAAAULL);
+  return r >> (128 - 2 * k);
+}
+
+// XXH64 of 8 / 16 bytes, seed 0 (Cyan4973/xxHash specification; KmXXHash sorting_count.hpp:346-363)
+#define XP1 0x9E3779B185EBCA87ULL
+#define XP2 0xC2B2AE3D27D4EB4FULL
+#define XP3 0x165667B19E3779F9ULL
+#define XP4 0x85EBCA77C2B2AE63ULL
+#define XP5 0x27D4EB2F165667C5ULL
+__device__ __forceinline__ u64 rotl64d(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ u64 xxh64_words(const u64* w, int nw)
+{
+  u64 h = XP5 + (u64)nw * 8;
+  for (int i = 0; i < nw; i++) {
+    h ^= rotl64d(w[i] * XP2, 31) * XP1;
+    h = rotl64d(h, 27) * XP1 + XP4;
+  }
+  h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+  return h;
+}
+
+// one thread per super-k-mer record: [u8 n][ceil((k+n-1)/4) bytes]; with S the record bytes as a
+// little-endian integer, seed = S mod 4^k and the j-th following nucleotide is (S >> 2(k+j-1)) & 3
+// (gatb Model.hpp:1388-1433; decoder sorting_count.hpp:153-275).
+template <int KW, int HASH>
+__global__ void k_superk_decode(const u8* __restrict__ recs, const u32* __restrict__ rec_off,
+                                const u32* __restrict__ kmer_off, u32 n_recs, int k,
+                                u64 win, u64 part, void* __restrict__ out)
+{
+  const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_recs) return;
+  const u8* p = recs + rec_off[r];
+  const u32 n = p[0];
+  p++;
+  u64 o = kmer_off[r];
+  if (KW == 1) {
+    const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    u64 fwd = 0;
+    const int nbytes = (k + 3) / 4;
+    for (int b = 0; b < nbytes; b++) fwd |= (u64)p[b] << (8 * b);
+    fwd &= mask;
+    u64 rev = revcomp64(fwd, k);
+    for (u32 j = 0;; j++) {
+      const u64 c = fwd < rev ? fwd : rev;
+      if (HASH) reinterpret_cast<u64*>(out)[o + j] = xxh64_words(&c, 1) % win + win * part;
+      else reinterpret_cast<u64*>(out)[o + j] = c;
+      if (j + 1 >= n) break;
+      const int d = k + (int)j;                          // digit index of the next nucleotide
+      const u64 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
+      fwd = ((fwd << 2) | nt) & mask;
+      rev = (rev >> 2) | ((nt ^ 2ULL) << (2 * (k - 1)));
+    }
+  } else {
+    const u128 mask = (k == 64) ? ~(u128)0 : ((((u128)1) << (2 * k)) - 1);
+    u128 fwd = 0;
+    const int nbytes = (k + 3) / 4;
+    for (int b = 0; b < nbytes; b++) fwd |= (u128)p[b] << (8 * b);
+    fwd &= mask;
+    u128 rev = revcomp128(fwd, k);
+    for (u32 j = 0;; j++) {
+      const u128 c = fwd < rev ? fwd : rev;
+      if (HASH) {
+        u64 w[2] = {(u64)c, (u64)(c >> 64)};
+        reinterpret_cast<u64*>(out)[o + j] = xxh64_words(w, 2) % win + win * part;
+      } else reinterpret_cast<u128*>(out)[o + j] = c;
+      if (j + 1 >= n) break;
+      const int d = k + (int)j;
+      const u128 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
+      fwd = ((fwd << 2) | nt) & mask;
+      rev = (rev >> 2) | ((nt ^ (u128)2) << (2 * (k - 1)));
+    }
+  }
+}
+
+__global__ void k_keep_flags(const u32* __restrict__ cnt, u32 n, u32 hard_min, u8* __restrict__ flags)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = cnt[i] >= hard_min;
+}
+
+}  // namespace kmx
+
+using namespace kmx;
+
+// host: record offsets (each record's length depends on its first byte only)
+static int parse_records(const uint8_t* s, uint64_t len, uint32_t k, std::vector<u32>& rec_off, std::vector<u32>& kmer_off, u64* total)
+{
+  u64 pos = 0, nk = 0;
+  while (pos < len) {
+    const u32 n = s[pos];
+    if (n == 0) return -1;
+    const u64 nbytes = ((u64)k + n - 1 + 3) / 4;
+    if (pos + 1 + nbytes > len) return -1;
+    rec_off.push_back((u32)pos);
+    kmer_off.push_back((u32)nk);
+    nk += n;
+    pos += 1 + nbytes;
+  }
+  *total = nk;
+  return 0;
+}
+
+template <typename KeyT>
+static int sort_rle_filter(kmx_ctx* ctx, KeyT* d_keys, u64 n, u32 hard_min, void** out_keys, uint32_t** out_counts, uint64_t* n_out)
+{
+  hipStream_t st = ctx->stream;
+  KeyT* d_sorted = (KeyT*)ctx->dalloc(n * sizeof(KeyT));
+  KeyT* d_uniq = (KeyT*)ctx->dalloc(n * sizeof(KeyT));
+  u32* d_cnt = (u32*)ctx->dalloc(n * 4);
+  u32* d_runs = (u32*)ctx->dalloc(256);
+  u8* d_flags = (u8*)ctx->dalloc(n);
+  KeyT* d_k2 = (KeyT*)ctx->dalloc(n * sizeof(KeyT));
+  u32* d_c2 = (u32*)ctx->dalloc(n * 4);
+  auto release = [&]() { ctx->dfree(d_sorted); ctx->dfree(d_uniq); ctx->dfree(d_cnt); ctx->dfree(d_runs); ctx->dfree(d_flags); ctx->dfree(d_k2); ctx->dfree(d_c2); };
+  if (!d_sorted || !d_uniq || !d_cnt || !d_runs || !d_flags || !d_k2 || !d_c2) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
+  size_t tb = 0, tb2 = 0, tb3 = 0;
+  hipError_t e = rocprim::radix_sort_keys(nullptr, tb, d_keys, d_sorted, (size_t)n, 0, (unsigned)(sizeof(KeyT) * 8), st);
+  if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, tb2, d_sorted, (unsigned)n, d_uniq, d_cnt, d_runs, st);
+  if (e == hipSuccess) e = rocprim::select(nullptr, tb3, d_uniq, d_flags, d_k2, d_runs, (size_t)n, st);
+  size_t tmax = std::max(tb, std::max(tb2, tb3));
+  void* d_tmp = ctx->dalloc(tmax ? tmax : 256);
+  if (e != hipSuccess || !d_tmp) { release(); ctx->dfree(d_tmp); return ctx->fail(KMX_E_HIP, "count: rocPRIM temp sizing failed"); }
+  auto fail = [&](hipError_t er, const char* what) { release(); ctx->dfree(d_tmp); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(er)); };
+  size_t t = tmax;
+  if ((e = rocprim::radix_sort_keys(d_tmp, t, d_keys, d_sorted, (size_t)n, 0, (unsigned)(sizeof(KeyT) * 8), st)) != hipSuccess) return fail(e, "radix_sort_keys");
+  t = tmax;
+  if ((e = rocprim::run_length_encode(d_tmp, t, d_sorted, (unsigned)n, d_uniq, d_cnt, d_runs, st)) != hipSuccess) return fail(e, "run_length_encode");
+  u32 runs = 0;
+  if ((e = hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  KeyT* res_k = d_uniq; u32* res_c = d_cnt; u32 kept = runs;
+  if (hard_min > 1 && runs) {
+    hipLaunchKernelGGL(k_keep_flags, dim3((runs + 255) / 256), dim3(256), 0, st, d_cnt, runs, hard_min, d_flags);
+    t = tmax;
+    if ((e = rocprim::select(d_tmp, t, d_uniq, d_flags, d_k2, d_runs, (size_t)runs, st)) != hipSuccess) return fail(e, "select keys");
+    t = tmax;
+    if ((e = rocprim::select(d_tmp, t, d_cnt, d_flags, d_c2, d_runs, (size_t)runs, st)) != hipSuccess) return fail(e, "select counts");
+    if ((e = hipMemcpyAsync(&kept, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+    res_k = d_k2; res_c = d_c2;
+  }
+  void* hk = malloc(kept ? (size_t)kept * sizeof(KeyT) : 1);
+  uint32_t* hc = (uint32_t*)malloc(kept ? (size_t)kept * 4 : 1);
+  if (!hk || !hc) { free(hk); free(hc); release(); ctx->dfree(d_tmp); return ctx->fail(KMX_E_NOMEM, "count: host allocation failed"); }
+  if (kept) {
+    if ((e = hipMemcpyAsync(hk, res_k, (size_t)kept * sizeof(KeyT), hipMemcpyDeviceToHost, st)) != hipSuccess) { free(hk); free(hc); return fail(e, "memcpy"); }
+    if ((e = hipMemcpyAsync(hc, res_c, (size_t)kept * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) { free(hk); free(hc); return fail(e, "memcpy"); }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { free(hk); free(hc); return fail(e, "sync"); }
+  }
+  release(); ctx->dfree(d_tmp);
+  *out_keys = hk; *out_counts = hc; *n_out = kept;
+  return KMX_OK;
+}
+
+static int count_impl(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t k, int hash, uint64_t win, uint64_t part,
+                      uint32_t hard_min, void** keys, uint32_t** counts, uint64_t* n_out)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!keys || !counts || !n_out || (len && !superk)) return ctx->fail(KMX_E_INVAL, "count: null argument");
+  if (k < 8 || k > 63) return ctx->fail(KMX_E_UNSUPPORTED, "k-mer size outside 8..63");
+  if (hash && win == 0) return ctx->fail(KMX_E_INVAL, "hash window is 0");
+  if (len >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "super-k-mer stream of 4 GiB or more: split it");
+  *keys = nullptr; *counts = nullptr; *n_out = 0;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  const int kw = (k + 31) / 32;
+  std::vector<u32> rec_off, kmer_off;
+  u64 total = 0;
+  if (parse_records(superk, len, k, rec_off, kmer_off, &total)) return ctx->fail(KMX_E_INVAL, "malformed super-k-mer stream");
+  if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one partition file: split it");
+  if (total == 0) {   // header-only count file (task.hpp:466-476)
+    *keys = malloc(1); *counts = (uint32_t*)malloc(1);
+    return KMX_OK;
+  }
+  const u32 nr = (u32)rec_off.size();
+  u8* d_recs = (u8*)ctx->dalloc(len + 16);
+  u32* d_ro = (u32*)ctx->dalloc((size_t)nr * 4);
+  u32* d_ko = (u32*)ctx->dalloc((size_t)nr * 4);
+  const size_t key_bytes = hash ? 8 : (size_t)kw * 8;
+  void* d_keys = ctx->dalloc(total * key_bytes);
+  auto release = [&]() { ctx->dfree(d_recs); ctx->dfree(d_ro); ctx->dfree(d_ko); ctx->dfree(d_keys); };
+  if (!d_recs || !d_ro || !d_ko || !d_keys) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
+  hipStream_t st = ctx->stream;
+  hipError_t e;
+  if ((e = hipMemcpyAsync(d_recs, superk, len, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_ro, rec_off.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_ko, kmer_off.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st)) != hipSuccess) {
+    release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e));
+  }
+  dim3 grid((nr + 255) / 256), block(256);
+  if (kw == 1 && !hash) hipLaunchKernelGGL((k_superk_decode<1, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
+  else if (kw == 1 && hash) hipLaunchKernelGGL((k_superk_decode<1, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
+  else if (kw == 2 && !hash) hipLaunchKernelGGL((k_superk_decode<2, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
+  else hipLaunchKernelGGL((k_superk_decode<2, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
+  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode: ") + hipGetErrorString(e)); }
+  int rc;
+  if (hash || kw == 1) rc = sort_rle_filter<u64>(ctx, (u64*)d_keys, total, hard_min, keys, counts, n_out);
+  else rc = sort_rle_filter<__uint128_t>(ctx, (__uint128_t*)d_keys, total, hard_min, keys, counts, n_out);
+  release();
+  return rc;
+}
+
+extern "C" int kmx_count_kmer(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t kmer_size, uint32_t hard_min,
+                              uint64_t** keys, uint32_t** counts, uint64_t* n_out)
+{
+  return count_impl(ctx, superk, len, kmer_size, 0, 0, 0, hard_min, (void**)keys, counts, n_out);
+}
+
+extern "C" int kmx_count_hash(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t kmer_size, uint64_t window,
+                              uint64_t partition, uint32_t hard_min, uint64_t** hashes, uint32_t** counts, uint64_t* n_out)
+{
+  return count_impl(ctx, superk, len, kmer_size, 1, window, partition, hard_min, (void**)hashes, counts, n_out);
+}

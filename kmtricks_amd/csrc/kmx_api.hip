@@ -94,6 +94,7 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
 extern "C" const char* kmx_last_error(const kmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" void* kmx_stream(kmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void kmx_free(void* p) { free(p); }
+extern "C" int kmx_set_profiling(kmx_ctx* ctx, int on) { if (!ctx) return KMX_E_INVAL; ctx->profiling = on != 0; return KMX_OK; }
 
 // ---- merge ---------------------------------------------------------------------------------------------
 struct TaskHost {
@@ -121,6 +122,7 @@ struct kmx_merge_result {
   int bf_lds = 0;
   bool is_bf = false, waited = false;
   int status = KMX_OK;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -134,13 +136,17 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   const int kw = (int)R->tasks[0].kw, mode = (int)R->tasks[0].mode;
   const u32 nt = (u32)R->tasks.size();
   KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 16, ctx->stream));
+  if (ctx->profiling && !R->ev0) { KMX_HIP(ctx, hipEventCreate(&R->ev0)); KMX_HIP(ctx, hipEventCreate(&R->ev1)); }
   if (R->is_bf) {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
+    if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_bf(mode == KMX_MODE_BFC, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->bf_lds, ctx->stream));
   } else {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
+    if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_rows(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
   }
+  if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
   return KMX_OK;
 }
 
@@ -355,6 +361,13 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   return KMX_OK;
 }
 
+extern "C" double kmx_result_kernel_ms(kmx_merge_result* R)
+{
+  if (!R || !R->ev0 || kmx_result_wait(R) != KMX_OK) return -1.0;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, R->ev0, R->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
 extern "C" uint64_t kmx_result_rows(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].rows : 0; }
 extern "C" uint64_t kmx_result_row_bytes(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].row_bytes : 0; }
 extern "C" uint64_t kmx_result_body_bytes(const kmx_merge_result* R, uint32_t t)
@@ -433,6 +446,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); }
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);
+  if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
   delete R;
 }
 

@@ -29,6 +29,7 @@ struct kmx_ctx {
   hipStream_t stream = nullptr;
   int n_cu = 0;
   std::string err;
+  bool profiling = false;
   std::vector<kmx_pool_block> pool;     // device blocks kept for reuse (bench steps allocate nothing)
   std::vector<kmx_pool_block> hpool;    // pinned host blocks
 

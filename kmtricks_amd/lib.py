@@ -33,6 +33,9 @@ _lib.kmx_last_error.restype = C.c_char_p
 _lib.kmx_last_error.argtypes = [_vp]
 _lib.kmx_stream.restype = _vp
 _lib.kmx_stream.argtypes = [_vp]
+_lib.kmx_set_profiling.argtypes = [_vp, C.c_int]
+_lib.kmx_result_kernel_ms.restype = C.c_double
+_lib.kmx_result_kernel_ms.argtypes = [_vp]
 _lib.kmx_merge_dev.argtypes = [_vp, C.POINTER(KmxMergeTask), C.c_uint32, C.POINTER(_vp)]
 _lib.kmx_result_wait.argtypes = [_vp]
 for _f in ("kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes", "kmx_result_algo_bytes"):
@@ -44,8 +47,13 @@ _lib.kmx_result_free.argtypes = [_vp]
 _lib.kmx_merge.argtypes = [_vp, C.POINTER(KmxMergeTask), C.POINTER(_vp), C.POINTER(C.c_uint64),
                            C.POINTER(C.c_uint64), _vp]
 _lib.kmx_free.argtypes = [_vp]
+_lib.kmx_count_kmer.argtypes = [_vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_vp), C.POINTER(_vp),
+                                C.POINTER(C.c_uint64)]
+_lib.kmx_count_hash.argtypes = [_vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
+                                C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64)]
+_lib.kmx_transpose_bits.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, _vp]
 
-EXPORTS = ["kmx_version", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_version", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_transpose_bits", "kmx_superk_partition",
@@ -92,6 +100,9 @@ class Context:
         if rc != 0:
             raise KmxError(f"{what} failed ({rc}): {_lib.kmx_last_error(self._h).decode()}")
 
+    def set_profiling(self, on=True):
+        self._check(_lib.kmx_set_profiling(self._h, 1 if on else 0), "kmx_set_profiling")
+
     @property
     def stream(self):
         return _lib.kmx_stream(self._h)
@@ -128,18 +139,53 @@ class Context:
         _lib.kmx_free(body)
         return data, rows.value, stats
 
-    def merge_dev(self, tasks):
-        """Device-resident batch merge (kmx_merge_dev).  tasks: list of dicts with keys
-        lists=[(device_ptr, n)], key_words, soft_min, rec_min, share_min, mode, [lower, upper, bitw, rows_hint].
-        -> MergeResult (asynchronous; call .wait())."""
+    def _take(self, kp, cp, n, width):
+        keys = np.frombuffer(C.string_at(kp.value, n * 8 * width), dtype=np.uint64).copy().reshape(n, width) if n \
+            else np.zeros((0, width), np.uint64)
+        cnts = np.frombuffer(C.string_at(cp.value, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
+        _lib.kmx_free(kp)
+        _lib.kmx_free(cp)
+        return keys, cnts
+
+    def count_kmer(self, superk: bytes, k, hard_min):
+        """kmx_count_kmer: super-k-mer record stream -> (canonical k-mers uint64[n, ceil(k/32)], counts)"""
+        kp, cp, n = _vp(), _vp(), C.c_uint64()
+        self._check(_lib.kmx_count_kmer(self._h, superk, len(superk), k, hard_min, C.byref(kp), C.byref(cp),
+                                        C.byref(n)), "kmx_count_kmer")
+        return self._take(kp, cp, n.value, (k + 31) // 32)
+
+    def count_hash(self, superk: bytes, k, window, partition, hard_min):
+        kp, cp, n = _vp(), _vp(), C.c_uint64()
+        self._check(_lib.kmx_count_hash(self._h, superk, len(superk), k, window, partition, hard_min, C.byref(kp),
+                                        C.byref(cp), C.byref(n)), "kmx_count_hash")
+        keys, cnts = self._take(kp, cp, n.value, 1)
+        return keys.reshape(-1), cnts
+
+    def transpose_bits(self, mat, nrows, ncols):
+        mat = np.ascontiguousarray(mat, dtype=np.uint8)
+        out = np.zeros(ncols * (nrows // 8), dtype=np.uint8)
+        self._check(_lib.kmx_transpose_bits(self._h, mat.ctypes.data, nrows, ncols, out.ctypes.data),
+                    "kmx_transpose_bits")
+        return out
+
+    def prepare(self, tasks):
+        """Builds the kmx_merge_task array once (so a timed loop does no Python marshalling).
+        tasks: list of dicts with keys lists=[(device_ptr, n)], key_words, soft_min, rec_min, share_min,
+        mode, [lower, upper, bitw, rows_hint]."""
         keep = []
         arr = (KmxMergeTask * len(tasks))()
         for i, d in enumerate(tasks):
             arr[i] = self._task(d["lists"], d["key_words"], d["soft_min"], d["rec_min"], d["share_min"], d["mode"],
                                 d.get("lower", 0), d.get("upper", 0), d.get("bitw", 2), d.get("rows_hint", 0), keep)
+        return (arr, len(tasks), [len(d["lists"]) for d in tasks], keep)
+
+    def merge_dev(self, tasks):
+        """Device-resident batch merge (kmx_merge_dev) of a task list or a prepare()d batch.
+        -> MergeResult (asynchronous; call .wait())."""
+        prep = tasks if isinstance(tasks, tuple) else self.prepare(tasks)
         res = _vp()
-        self._check(_lib.kmx_merge_dev(self._h, arr, len(tasks), C.byref(res)), "kmx_merge_dev")
-        return MergeResult(self, res, [len(d["lists"]) for d in tasks])
+        self._check(_lib.kmx_merge_dev(self._h, prep[0], prep[1], C.byref(res)), "kmx_merge_dev")
+        return MergeResult(self, res, prep[2])
 
 
 class MergeResult:
@@ -148,6 +194,9 @@ class MergeResult:
 
     def wait(self):
         self._ctx._check(_lib.kmx_result_wait(self._h), "kmx_result_wait")
+
+    def kernel_ms(self):
+        return _lib.kmx_result_kernel_ms(self._h)
 
     def rows(self, t=0):
         return _lib.kmx_result_rows(self._h, t)

@@ -1,0 +1,85 @@
+"""Parity of the HIP count path and bit transpose against the oracle (and the reference goldens)."""
+import json, os
+import numpy as np
+import pytest
+
+import orc
+from test_oracle_goldens import repart_table, read_fasta, GD, G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from kmtricks_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def random_reads(seed, n_reads, length, n_rate=0.002):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_reads):
+        s = rng.choice(list("ACGT"), size=length)
+        bad = rng.random(length) < n_rate
+        s[bad] = "N"
+        out.append("".join(s))
+    return out
+
+
+def test_count_reference_goldens(ctx):
+    """tests/task_main.cpp:118-508 through the HIP path: k-mers and window hashes of partition 0 in file order"""
+    lut = orc.minimizer_lut(10)
+    rep = repart_table()
+    cf = G["task_main"]["count_files"]
+    for name, f in (("D1", "1.fasta"), ("D2", "2.fasta")):
+        sk = orc.superk_partition(read_fasta(os.path.join(GD, f)), 31, 10, lut, rep, 4)
+        for p in range(4):
+            keys, counts = ctx.count_kmer(sk[p][0], 31, 1)
+            exp = cf[f"counts/partition_{p}/{name}.kmer"]
+            if "kmers" in exp:
+                assert [[orc.kmer_to_string(k, 31), int(c)] for k, c in zip(keys, counts)] == exp["kmers"]
+            else:
+                assert len(counts) == exp["n"]
+            hs, hc = ctx.count_hash(sk[p][0], 31, 25000000, p, 1)
+            exph = cf[f"counts/partition_{p}/{name}.hash"]
+            if "hashes" in exph:
+                assert [[int(h), int(c)] for h, c in zip(hs, hc)] == exph["hashes"]
+            else:
+                assert len(hc) == exph["n"]
+
+
+@pytest.mark.parametrize("k,m", [(31, 10), (21, 8), (32, 10), (47, 11), (63, 10), (20, 7)])
+def test_count_random_reads_vs_oracle(ctx, k, m):
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, 8)
+    reads = random_reads(100 + k, 600, 150) + ["ACGT" * 60] * 5 + ["A" * 200, "ACGTN" * 30, "ACG"]
+    sk = orc.superk_partition(reads * 2, k, m, lut, rep, 8)
+    tot = 0
+    for p in range(8):
+        for hard_min in (1, 2, 3):
+            ek, ec = orc.count_kmer(sk[p][0], k, hard_min)
+            gk, gc = ctx.count_kmer(sk[p][0], k, hard_min)
+            assert np.array_equal(ek, gk) and np.array_equal(ec, gc)
+            eh, ehc = orc.count_hash(sk[p][0], k, 1000003, p, hard_min)
+            gh, ghc = ctx.count_hash(sk[p][0], k, 1000003, p, hard_min)
+            assert np.array_equal(eh, gh) and np.array_equal(ehc, ghc)
+        tot += len(ec)
+    assert tot > 1000
+
+
+def test_count_empty_stream(ctx):
+    k_, c_ = ctx.count_kmer(b"", 31, 2)
+    assert len(c_) == 0
+    h_, c_ = ctx.count_hash(b"", 31, 6400, 1, 2)
+    assert len(c_) == 0
+
+
+@pytest.mark.parametrize("nr,nc", [(8, 8), (16, 8), (24, 40), (64, 64), (64, 128), (200, 72), (3136, 104), (4096, 1000 // 8 * 8 + 8)])
+def test_transpose_vs_oracle(ctx, nr, nc):
+    rng = np.random.default_rng(nr * 131 + nc)
+    m = rng.integers(0, 256, nr * nc // 8, dtype=np.uint8)
+    t = ctx.transpose_bits(m, nr, nc)
+    assert np.array_equal(t, orc.transpose_bits(m, nr, nc))
+    assert np.array_equal(ctx.transpose_bits(t, nc, nr), m)   # bit_matrix_test.cpp:60-99
