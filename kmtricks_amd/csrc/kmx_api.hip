@@ -100,7 +100,8 @@ extern "C" int kmx_set_profiling(kmx_ctx* ctx, int on) { if (!ctx) return KMX_E_
 struct TaskHost {
   u32 N = 0, kw = 1, mode = 0, bitw = 0, c = 1, wl = 0, pivot = 0, rt = 0;
   u32 rec_min = 0, share_min = 0, row_bytes = 0, seg_cap = 0;
-  u64 lower = 0, upper = 0, total_recs = 0, out_cap_rows = 0;
+  u64 lower = 0, upper = 0, total_recs = 0, out_cap_rows = 0, rows_guess = 0;
+  u64 arena_rows = 0;            // rows claimed in the arena (kept rows + unused chunk tails)
   std::vector<u32> len;
   // offsets into the meta blob
   size_t o_recs = 0, o_len = 0, o_smin = 0, o_bounds = 0, o_stats = 0, o_ctrl = 0, o_segs = 0;
@@ -196,13 +197,12 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.out_bytes = (size_t)((K.upper - K.lower + 1) * H.row_bytes);
     } else {
       H.row_bytes = kw * 8 + (mode == KMX_MODE_COUNT ? 4 * H.N : (H.N + 7) / 8);
-      if (H.row_bytes > 60000) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
       u32 wl = 0; while ((H.N << (wl + 1)) <= (u32)rows_cap()) wl++;
       H.wl = wl;
+      if (H.row_bytes > rows_image_bytes((int)kw)) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
       u64 guess = K.rows_hint ? K.rows_hint : 2ULL * H.len[pivot] + 4096;
       if (guess > H.total_recs) guess = H.total_recs;
-      H.out_cap_rows = std::max<u64>(guess, 1);
-      H.out_bytes = (size_t)(H.out_cap_rows * H.row_bytes);
+      H.rows_guess = std::max<u64>(guess, 1);   // arena = guess + chunk slack, sized once c is known
     }
   }
   // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
@@ -219,6 +219,10 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     } else c = std::min<u64>(c, std::max<u32>(1, H.len[H.pivot]));
     H.c = (u32)std::max<u64>(1, c);
     H.seg_cap = is_bf ? 1 : (u32)std::min<u64>(0x7FFFFFFF, H.total_recs / 512 + 8ULL * H.c + 4096);
+    if (!is_bf) {   // rows are claimed in chunks: every range may leave one chunk partly unused
+      H.out_cap_rows = H.rows_guess + (u64)(H.c + 1) * rows_chunk_rows(H.row_bytes);
+      H.out_bytes = (size_t)(H.out_cap_rows * H.row_bytes);
+    }
     n_items += H.c;
     max_n = std::max(max_n, H.N); max_c = std::max(max_c, H.c);
   }
@@ -301,7 +305,7 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow)
     u64 ctrl[4];
     KMX_HIP(ctx, hipMemcpyAsync(ctrl, R->d_meta + H.o_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, ctx->stream));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    H.rows = ctrl[0]; H.nsegs = ctrl[1];
+    H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3];
     if (ctrl[2]) *overflow = true;
   }
   return KMX_OK;
@@ -327,9 +331,9 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
     for (size_t t = 0; t < R->tasks.size(); t++) {
       TaskHost& H = R->tasks[t];
-      if (H.rows > H.out_cap_rows) {
+      if (H.arena_rows > H.out_cap_rows) {
         ctx->dfree(H.d_out);
-        H.out_cap_rows = H.rows; H.out_bytes = (size_t)(H.rows * H.row_bytes);
+        H.out_cap_rows = H.arena_rows; H.out_bytes = (size_t)(H.arena_rows * H.row_bytes);
         H.d_out = (u8*)ctx->dalloc(H.out_bytes);
         if (!H.d_out) { R->waited = true; R->status = ctx->fail(KMX_E_NOMEM, "output arena allocation failed (retry)"); return R->status; }
         td[t].out = H.d_out; td[t].out_cap_rows = H.out_cap_rows;
@@ -397,16 +401,17 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
   }
   std::vector<Seg> segs(H.nsegs);
   KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->stream));
-  u8* tmp = (u8*)malloc(body);
+  const u64 arena = H.arena_rows * H.row_bytes;
+  u8* tmp = (u8*)malloc(arena);
   if (!tmp) return ctx->fail(KMX_E_NOMEM, "host staging allocation failed");
-  KMX_HIP(ctx, hipMemcpyAsync(tmp, H.d_out, body, hipMemcpyDeviceToHost, ctx->stream));
+  KMX_HIP(ctx, hipMemcpyAsync(tmp, H.d_out, arena, hipMemcpyDeviceToHost, ctx->stream));
   KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.range != b.range ? a.range < b.range : a.seq < b.seq; });
   u8* d = (u8*)dst;
   u64 done = 0;
   for (const Seg& s : segs) {
     const u64 nb = (u64)s.nrows * H.row_bytes;
-    if (s.row_off * H.row_bytes + nb > body || done + nb > body) { free(tmp); return ctx->fail(KMX_E_HIP, "corrupt segment directory"); }
+    if (s.row_off * H.row_bytes + nb > arena || done + nb > body) { free(tmp); return ctx->fail(KMX_E_HIP, "corrupt segment directory"); }
     memcpy(d + done, tmp + s.row_off * H.row_bytes, nb);
     done += nb;
   }
@@ -437,12 +442,18 @@ extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* 
   return KMX_OK;
 }
 
+#ifdef KMX_PHASE_PROF
+namespace kmx { void rows_phase_prof_dump(); }
+#endif
 extern "C" void kmx_result_free(kmx_merge_result* R)
 {
   if (!R) return;
   kmx_ctx* ctx = R->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+#ifdef KMX_PHASE_PROF
+  if (!R->is_bf) kmx::rows_phase_prof_dump();
+#endif
   for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); }
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);

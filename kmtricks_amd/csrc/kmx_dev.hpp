@@ -10,6 +10,8 @@ typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint16_t u16;
 typedef uint8_t u8;
+// explicit global address space for record streams (global_load instead of flat_load)
+typedef __attribute__((address_space(1))) const u32 gu32;
 
 // ---- merge task as the kernels see it (one per partition, array in HBM) ----------------------
 struct Seg {            // one row segment of a COUNT/PA task: rows [row_off, row_off + nrows) of the arena

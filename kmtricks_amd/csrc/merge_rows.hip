@@ -7,30 +7,40 @@
 // Decomposition (see DESIGN.md "merge kernel"):
 //   * the key space of a partition is cut into c ranges at quantiles of one pivot list
 //     (k_range_bounds: one lower_bound per (range, list));
-//   * a workgroup owns one range and walks it tile by tile.  A tile gives every list a window of
-//     w = 2^wl record slots (w adjacent lanes read w consecutive 12/20-byte records); the tile's
-//     key bound b is the smallest "last key of a window that has more records behind it", so every
-//     record <= b of every list is inside its window: tiles are disjoint, ascending key intervals
-//     that always fit the 4096 register slots, whatever the skew;
-//   * inside a tile the distinct keys are found with an LDS hash set (owner index + recurrence
-//     packed in one u32, claimed with ds_cmpst), kept keys are ranked, and rows are assembled as
-//     a byte-exact file image in LDS, then streamed out with coalesced stores;
-//   * a tile's rows go to a segment of the task's row arena claimed with ONE global atomic; the
-//     (range, seq) directory restores ascending key order when the body is copied out.  Input is
-//     read once, output written once, no inter-workgroup dependency.
+//   * a workgroup owns one range and walks it tile by tile.  A tile gives every list a circular
+//     window of w = 2^wl record slots held in registers (w adjacent lanes, 12/20-byte records);
+//     the tile's key bound b is the smallest "last record of a window that has more records behind
+//     it", so every record <= b of every list is inside its window: tiles are disjoint, ascending
+//     key intervals that always fit the 4096 register slots, whatever the skew.  Consumed slots are
+//     refilled by a prefetch issued right after b is known, so every record is loaded exactly once
+//     and the load latency hides behind the rest of the tile;
+//   * inside a tile the distinct keys are found with an LDS hash set (owner slot + recurrence
+//     packed in one u32, claimed with ds_cmpst; reads first, so dense keys cost no atomics), the
+//     owners publish the kept keys, those are ranked, and rows are assembled as a byte-exact file
+//     image in LDS, then streamed out with coalesced stores;
+//   * rows go to chunks of the task's row arena claimed with one global atomic per chunk; the
+//     (range, seq) chunk directory restores ascending key order when the body is copied out.
+//     Input is read once, output written once, no inter-workgroup dependency.
 #include "kmx_dev.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
 
 namespace kmx {
 
-constexpr int TPB = 512;           // 8 waves; two workgroups per CU at <= 80 KiB LDS
-constexpr int M = 8;               // record slots per thread
+#ifndef KMX_ROWS_TPB
+#define KMX_ROWS_TPB 512
+#endif
+constexpr int TPB = KMX_ROWS_TPB;  // 8 or 16 waves
+constexpr int M = 4096 / TPB;      // record slots per thread
 constexpr int CAP = TPB * M;       // 4096 record slots per tile
 constexpr int TS = 2 * CAP;        // hash set entries (load factor <= 0.5)
-constexpr int KLBYTES = 10240;     // kept-key list: fast path keys + table slots, or u16 sort array
+constexpr int KLBYTES = 12288;     // kept keys: u16 table slots [CAP] (8 KiB) + fast-path key copies (4 KiB)
 constexpr int NWAVE = TPB / 64;
 
-__host__ __device__ inline int rows_emit_bytes(int kw) { return CAP * kw * 8 + TS * 4 + KLBYTES; }
-__host__ __device__ inline int rows_dkmax(int kw) { return 8192 / (kw * 8); }   // + 2 B table slot each
+// LDS image of the row batch being assembled: aliases the staged keys
+__host__ __device__ inline int rows_emit_bytes(int kw) { return CAP * kw * 8; }
+__host__ __device__ inline int rows_fixed_bytes(int kw) { return CAP * kw * 8 + TS * 4 + KLBYTES; }
 
 // ---- range bounds ------------------------------------------------------------------------------
 // bounds[j*N + i] = first record of list i whose key >= Q_j, Q_j = pivot[j * len_pivot / c].
@@ -62,6 +72,10 @@ __global__ void k_range_bounds(const TaskDev* __restrict__ tasks, u32 max_c)
   T.bounds[(u64)j * T.N + i] = res;
 }
 
+#ifdef KMX_PHASE_PROF
+__device__ u64 kmx_phase_prof[16];
+#endif
+
 // ---- the merge kernel ----------------------------------------------------------------------------
 template <int KW> __device__ __forceinline__ u32 key_hash(const Key<KW>& k)
 {
@@ -71,33 +85,45 @@ template <int KW> __device__ __forceinline__ u32 key_hash(const Key<KW>& k)
   return (u32)x & (TS - 1);
 }
 
-// KW = 1: 80 KiB LDS -> two workgroups per CU (4 waves/SIMD, <= 128 VGPRs);
-// KW = 2: 112 KiB LDS -> one workgroup per CU, so it may use 256 VGPRs.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt on gfx950
+// (loads and stores share the counter), which would wait for the record prefetch at every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One workgroup per CU (up to 256 VGPRs): the per-slot state (record being merged, record in
+// flight, cursor, statistics) lives in registers.
 template <int KW, int MODE>
-__global__ __launch_bounds__(TPB, (KW == 1 ? 4 : 2))
+__global__ __launch_bounds__(TPB, TPB / 256)
 void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ items, u32 n_items, u32* ticket)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RB = KW * 8 + 4;
   constexpr int KEYS_BYTES = CAP * KW * 8;
-  constexpr int EMIT_BYTES = KEYS_BYTES + TS * 4 + KLBYTES;
-  constexpr int DKMAX = 8192 / (KW * 8);
+  constexpr int DKMAX = 4096 / (KW * 8);
 
-  Key<KW>* keysL = reinterpret_cast<Key<KW>*>(smem);
-  u32* tab = reinterpret_cast<u32*>(smem + KEYS_BYTES);
-  unsigned char* klist = smem + KEYS_BYTES + TS * 4;
-  Key<KW>* dkeys = reinterpret_cast<Key<KW>*>(klist);
-  u16* dslot = reinterpret_cast<u16*>(klist + 8192);
-  u16* sortv = reinterpret_cast<u16*>(klist);
-  // misc (after the emission image): per-wave partials, then the cursors
-  unsigned char* misc = smem + EMIT_BYTES;
-  Key<KW>* wmin = reinterpret_cast<Key<KW>*>(misc);                 // NWAVE keys (<= 128 B)
-  u32* wsum = reinterpret_cast<u32*>(misc + 128);                    // NWAVE + 1
-  u64* bc64 = reinterpret_cast<u64*>(misc + 192);                    // broadcast slot
-  u32* bc32 = reinterpret_cast<u32*>(misc + 208);                    // broadcast: item / flags
-  u32* cur = reinterpret_cast<u32*>(misc + 256);                     // N cursors
+  Key<KW>* keysL = reinterpret_cast<Key<KW>*>(smem);               // staged keys of the tile ...
+  unsigned char* const img = smem;                                  // ... later the row image (aliased)
+  u32* tab = reinterpret_cast<u32*>(smem + KEYS_BYTES);             // hash set, all zero between tiles
+  u16* dslot = reinterpret_cast<u16*>(smem + KEYS_BYTES + TS * 4);  // table slots of the kept keys (8 KiB)
+  Key<KW>* dkeys = reinterpret_cast<Key<KW>*>(smem + KEYS_BYTES + TS * 4 + 8192);   // their keys, fast path (4 KiB)
+  unsigned char* misc = smem + KEYS_BYTES + TS * 4 + KLBYTES;
+  Key<KW>* wmin = reinterpret_cast<Key<KW>*>(misc);                 // NWAVE keys (<= 256 B)
+  u32* wany = reinterpret_cast<u32*>(misc + 256);                   // NWAVE flags (64 B)
+  u64* bc64 = reinterpret_cast<u64*>(misc + 320);                   // broadcast: row offset
+  u32* bc32 = reinterpret_cast<u32*>(misc + 336);                   // [0] item  [1] can-write  [2] kept counter
+  u32* cur = reinterpret_cast<u32*>(misc + 384);                    // N cursors
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef KMX_PHASE_PROF
+  long long pt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pc = clock64();
+#define PH(i) do { const long long n_ = clock64(); pt[i] += n_ - pc; pc = n_; } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
+  {
+    uint4* t4 = reinterpret_cast<uint4*>(tab);
+    for (int t = tid; t < TS / 4; t += TPB) t4[t] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) bc32[2] = 0;
+  }
 
   for (;;) {
     // ---- next work item (dynamic, ascending ids) ----
@@ -105,213 +131,295 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
     __syncthreads();
     const u32 item = bc32[0];
     __syncthreads();
-    if (item >= n_items) return;
+    if (item >= n_items) {
+#ifdef KMX_PHASE_PROF
+      if (tid == 0) for (int i = 0; i < 9; i++) atomicAdd(&kmx_phase_prof[i], (u64)pt[i]);
+#endif
+      return;
+    }
     const TaskDev& T = tasks[items[item].x];
     const u32 range = items[item].y;
     const u32 N = T.N, wl = T.wl, w = 1u << wl;
     const u32 rec_min = T.rec_min, share_min = T.share_min, row_bytes = T.row_bytes;
+    const u32 sat = max(rec_min, share_min);          // recurrence only matters up to this value
+    const u32* const sminp = T.soft_min;
+    const u32 chunk_rows = max(64u, 262144u / row_bytes);
 
-    // fixed slot -> (list, position in window) mapping of this thread
-    const u8* ptr[M]; u32 endv[M], smin[M], uwo[M]; u64 two[M];
-    u32 li[M];
+    // Slot s = tid + m*TPB serves list s >> wl.  A list's window is circular: lane residue
+    // rr = s & (w-1) always holds the record whose index is == rr (mod w) inside [cur, cur + w),
+    // so a consumed record is replaced in place by record idx + w and every record is loaded once.
+    gu32* ptr[M]; u32 endv[M], idx[M], uwo[M], two[M], smin[M];
+    Key<KW> key[M]; u32 cnt[M];
 #pragma unroll
     for (int m = 0; m < M; m++) {
-      const u32 s = tid + m * TPB;
-      li[m] = s >> wl;
-      uwo[m] = 0; two[m] = 0;
-      if (li[m] < N) {
-        ptr[m] = T.recs[li[m]];
-        endv[m] = T.bounds[(u64)(range + 1) * N + li[m]];
-        smin[m] = T.soft_min[li[m]];
-      } else { ptr[m] = nullptr; endv[m] = 0; smin[m] = 0; }
+      const u32 s = tid + m * TPB, li = s >> wl, rr = s & (w - 1);
+      uwo[m] = 0; two[m] = 0; idx[m] = 0; endv[m] = 0; ptr[m] = (gu32*)nullptr; smin[m] = 0;
+      key[m] = key_inf<KW>(); cnt[m] = 0;
+      if (li < N) {
+        ptr[m] = (gu32*)(uintptr_t)T.recs[li];
+        smin[m] = sminp[li];
+        endv[m] = T.bounds[(u64)(range + 1) * N + li];
+        const u32 c0 = T.bounds[(u64)range * N + li];
+        idx[m] = c0 + ((rr - c0) & (w - 1));
+        if (idx[m] < endv[m]) {
+          gu32* p = ptr[m] + (u64)idx[m] * (RB / 4);
+#pragma unroll
+          for (int q = 0; q < KW; q++) key[m].w[q] = (u64)p[2 * q] | ((u64)p[2 * q + 1] << 32);
+          cnt[m] = p[2 * KW];
+        }
+      }
     }
     for (u32 i = tid; i < N; i += TPB) cur[i] = T.bounds[(u64)range * N + i];
+    // row-space allocator state (thread 0): rows are claimed in chunks, one directory entry per chunk
+    u64 ch_base = 0; u32 ch_used = 0, ch_cap = 0, ch_seq = 0, ch_ok = 1;
     __syncthreads();
 
     u32 seq = 0;
+    PH(0);
     for (;;) {
-      // ---- 1. load the windows ----
-      Key<KW> key[M]; u32 cnt[M]; u32 idx[M];
-      u32 validm = 0;
+      // ---- 1. tile bound b = smallest "last record of a window that has more records behind it" ----
+      u32 validm = 0, consm = 0;
       Key<KW> cand = key_inf<KW>();
 #pragma unroll
       for (int m = 0; m < M; m++) {
-        const u32 s = tid + m * TPB, rr = s & (w - 1);
-        key[m] = key_inf<KW>(); cnt[m] = 0; idx[m] = 0;
-        if (li[m] < N) {
-          idx[m] = cur[li[m]] + rr;
-          if (idx[m] < endv[m]) {
-            const u8* p = ptr[m] + (u64)idx[m] * RB;
-            key[m] = load_key<KW>(p);
-            cnt[m] = reinterpret_cast<const u32*>(p)[2 * KW];
-            validm |= 1u << m;
-            if (rr == w - 1 && idx[m] + 1 < endv[m]) cand = key_min<KW>(cand, key[m]);
-          }
+        if (idx[m] < endv[m]) {
+          validm |= 1u << m;
+          const u32 c0 = cur[(tid + m * TPB) >> wl];
+          if (idx[m] == c0 + w - 1 && idx[m] + 1 < endv[m]) cand = key_min<KW>(cand, key[m]);
         }
       }
       cand = wave_min_key<KW>(cand);
-      if (lane == 0) wmin[wave] = cand;
-      const int any = __syncthreads_or(validm != 0);
-      if (!any) break;
+      const u64 vbal = __ballot(validm != 0);
+      if (lane == 0) { wmin[wave] = cand; wany[wave] = vbal != 0; }
+      lds_barrier();
+      PH(1);
       Key<KW> b = wmin[0];
+      u32 any = wany[0];
 #pragma unroll
-      for (int v = 1; v < NWAVE; v++) b = key_min<KW>(b, wmin[v]);
+      for (int v = 1; v < NWAVE; v++) { b = key_min<KW>(b, wmin[v]); any |= wany[v]; }
+      if (!any) break;
 
-      // ---- 2. consume keys <= b, advance cursors, stage keys, clear the hash set ----
-      u32 consm = 0;
+      // ---- 2. consume keys <= b, advance cursors, stage keys, prefetch the replacements ----
+      // (written as independent batches over the M slots: no LDS round trip is waited for here)
+      Key<KW> nkey[M]; u32 ncnt[M];
 #pragma unroll
-      for (int m = 0; m < M; m++) {
-        const u32 s = tid + m * TPB, rr = s & (w - 1);
-        const int c = ((validm >> m) & 1u) && key_le<KW>(key[m], b);
-        const int nxt = __shfl_down(c, 1);
-        if (c) {
-          consm |= 1u << m;
-          keysL[s] = key[m];
-          if (rr == w - 1 || lane == 63 || !nxt) atomicMax(&cur[li[m]], idx[m] + 1);
+      for (int m = 0; m < M; m++)
+        if (((validm >> m) & 1u) && key_le<KW>(key[m], b)) consm |= 1u << m;
+#pragma unroll
+      for (int m = 0; m < M; m++) {   // the w lanes of a list: their consumed count moves the list cursor
+        const u32 li = (tid + m * TPB) >> wl;
+        const u64 bal = __ballot((consm >> m) & 1u);
+        if (wl >= 6) { if (lane == 0 && bal) atomicAdd(&cur[li], (u32)__popcll(bal)); }
+        else {
+          const u32 grp = (u32)((bal >> (lane & ~(w - 1))) & ((1ULL << w) - 1));
+          if ((lane & (w - 1)) == 0 && grp) atomicAdd(&cur[li], (u32)__popc(grp));
         }
       }
-      {
-        uint4* t4 = reinterpret_cast<uint4*>(tab);
-        for (int t = tid; t < TS / 4; t += TPB) t4[t] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < M; m++) if ((consm >> m) & 1u) keysL[tid + m * TPB] = key[m];
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        nkey[m] = key_inf<KW>(); ncnt[m] = 0;
+        const u32 ni = idx[m] + w;
+        if (((consm >> m) & 1u) && ni < endv[m]) {
+          gu32* p = ptr[m] + (u64)ni * (RB / 4);
+#pragma unroll
+          for (int q = 0; q < KW; q++) nkey[m].w[q] = (u64)p[2 * q] | ((u64)p[2 * q + 1] << 32);
+          ncnt[m] = p[2 * KW];
+        }
       }
-      __syncthreads();
+      lds_barrier();
+      PH(2);
 
       // ---- 3. hash-set insert: entry = owner slot + 1 (low 16) | recurrence (high 16) ----
-      u32 hs[M]; u32 ownm = 0, solidm = 0;
-#pragma unroll
-      for (int m = 0; m < M; m++) {
-        hs[m] = 0;
-        if ((consm >> m) & 1u) {
-          const u32 s = tid + m * TPB;
-          u32 h = key_hash<KW>(key[m]);
-          for (;;) {
-            const u32 old = atomicCAS(&tab[h], 0u, s + 1);
-            if (old == 0) { ownm |= 1u << m; break; }
-            const Key<KW> ok = keysL[(old & 0xFFFFu) - 1];
-            if (key_eq<KW>(ok, key[m])) break;
-            h = (h + 1) & (TS - 1);
-          }
-          hs[m] = h;
-          if (cnt[m] >= smin[m]) { solidm |= 1u << m; atomicAdd(&tab[h], 1u << 16); }
-        }
-      }
-      __syncthreads();
-
-      // ---- 4. kept distinct keys: compact, rank ----
-      u32 dk;
+      // Dense keys are inserted by hundreds of lists at once, so every access reads first: only the
+      // first arrivals issue the ds_cmpst claim and the recurrence counter stops being incremented
+      // at max(rec_min, share_min) -- same-address LDS atomics serialise, same-address reads broadcast.
+      // All M slots of a thread probe together (M independent LDS reads in flight); only hash
+      // collisions fall through to the sequential linear-probing loop.
+      u32 hs[M]; u32 ownm = 0, solidm = 0, unresm = 0;
       {
-        u32 e[16]; u32 nk = 0;
-        const uint4* t4 = reinterpret_cast<const uint4*>(tab) + tid * 4;
+        u32 old[M];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { uint4 v = t4[q]; e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w; }
+        for (int m = 0; m < M; m++) hs[m] = key_hash<KW>(key[m]);
 #pragma unroll
-        for (int q = 0; q < 16; q++) nk += (e[q] != 0 && (e[q] >> 16) >= rec_min) ? 1u : 0u;
-        const u32 incl = wave_incl_scan(nk, lane);
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        u32 base = 0, total = 0;
+        for (int m = 0; m < M; m++) old[m] = ((consm >> m) & 1u) ? tab[hs[m]] : 1u;
 #pragma unroll
-        for (int v = 0; v < NWAVE; v++) { const u32 x = wsum[v]; if (v < wave) base += x; total += x; }
-        dk = total;
-        u32 pos = base + incl - nk;
-        const bool fast = dk <= (u32)DKMAX;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          if (e[q] == 0) continue;
-          const u32 t = tid * 16 + q;
-          if ((e[q] >> 16) >= rec_min) {
-            if (fast) { dkeys[pos] = keysL[(e[q] & 0xFFFFu) - 1]; dslot[pos] = (u16)t; }
-            else sortv[pos] = (u16)t;
-            pos++;
-          } else tab[t] = (e[q] & 0xFFFF0000u) | 0xFFFFu;   // not kept
-        }
-        __syncthreads();
-        if (fast) {
-          // counting rank: kept-rank = number of kept keys smaller than mine (broadcast LDS reads)
-          for (u32 p = tid; p < dk; p += TPB) {
-            const Key<KW> mine = dkeys[p];
-            u32 r = 0;
-            for (u32 q = 0; q < dk; q++) r += key_less<KW>(dkeys[q], mine) ? 1u : 0u;
-            const u32 t = dslot[p];
-            tab[t] = (tab[t] & 0xFFFF0000u) | r;
+        for (int m = 0; m < M; m++) {
+          if (old[m] == 0) {
+            old[m] = atomicCAS(&tab[hs[m]], 0u, (u32)(tid + m * TPB) + 1);
+            if (old[m] == 0) ownm |= 1u << m;
           }
-        } else {
-          // slow path (more than DKMAX kept keys in one tile): LDS bitonic sort of table slots by key
-          u32 p2 = 1; while (p2 < dk) p2 <<= 1;
-          for (u32 p = dk + tid; p < p2; p += TPB) sortv[p] = 0xFFFFu;   // +inf padding
-          __syncthreads();
-          for (u32 k2 = 2; k2 <= p2; k2 <<= 1) {
-            for (u32 j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-              for (u32 p = tid; p < p2; p += TPB) {
-                const u32 q = p ^ j2;
-                if (q > p) {
-                  const u32 a = sortv[p], bb = sortv[q];
-                  bool a_gt_b;
-                  if (a == 0xFFFFu) a_gt_b = (bb != 0xFFFFu);
-                  else if (bb == 0xFFFFu) a_gt_b = false;
-                  else a_gt_b = key_less<KW>(keysL[(tab[bb] & 0xFFFFu) - 1], keysL[(tab[a] & 0xFFFFu) - 1]);
-                  const bool up = (p & k2) == 0;
-                  if (a_gt_b == up) { sortv[p] = (u16)bb; sortv[q] = (u16)a; }
+        }
+        Key<KW> ok[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const bool chk = ((consm >> m) & 1u) && !((ownm >> m) & 1u);
+          ok[m] = keysL[chk ? (old[m] & 0xFFFFu) - 1 : 0];
+          if (chk && !key_eq<KW>(ok[m], key[m])) unresm |= 1u << m;
+        }
+        if (unresm) {
+#pragma unroll
+          for (int m = 0; m < M; m++) {
+            if ((unresm >> m) & 1u) {
+              u32 h = hs[m], o;
+              for (;;) {
+                h = (h + 1) & (TS - 1);
+                o = tab[h];
+                if (o == 0) {
+                  o = atomicCAS(&tab[h], 0u, (u32)(tid + m * TPB) + 1);
+                  if (o == 0) { ownm |= 1u << m; break; }
                 }
+                if (key_eq<KW>(keysL[(o & 0xFFFFu) - 1], key[m])) break;
               }
-              __syncthreads();
+              hs[m] = h; old[m] = o;
             }
           }
-          for (u32 p = tid; p < dk; p += TPB) { const u32 t = sortv[p]; tab[t] = (tab[t] & 0xFFFF0000u) | p; }
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          if (((consm >> m) & 1u) && cnt[m] >= smin[m]) {
+            solidm |= 1u << m;
+            if ((old[m] >> 16) < sat) atomicAdd(&tab[hs[m]], 1u << 16);
+          }
         }
       }
-      // ---- 5. claim the row segment ----
-      if (tid == 0) {
-        u64 off = 0; u32 ok = 1;
+      lds_barrier();
+      PH(3);
+
+      // ---- 4. owners publish the kept keys (recurrence >= rec_min); rank them ----
+      {
+        u32 e[M]; u32 keptm = 0, npre[M], wtot = 0;
+#pragma unroll
+        for (int m = 0; m < M; m++) e[m] = ((ownm >> m) & 1u) ? tab[hs[m]] : 0u;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const bool kept = ((ownm >> m) & 1u) && (e[m] >> 16) >= rec_min;
+          if (kept) keptm |= 1u << m;
+          const u64 bal = __ballot(kept);
+          npre[m] = wtot + (u32)__popcll(bal & ((1ULL << lane) - 1));   // position inside this wave's block
+          wtot += (u32)__popcll(bal);
+        }
+        u32 base = 0;
+        if (wtot) {   // one LDS atomic per wave and tile
+          if (lane == 0) base = atomicAdd(&bc32[2], wtot);
+          base = __shfl(base, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          if ((keptm >> m) & 1u) {
+            const u32 pos = base + npre[m];
+            dslot[pos] = (u16)hs[m];
+            if (pos < (u32)DKMAX) dkeys[pos] = key[m];
+          } else if ((ownm >> m) & 1u) tab[hs[m]] = (e[m] & 0xFFFF0000u) | 0xFFFFu;
+        }
+      }
+      lds_barrier();
+      const u32 dk = bc32[2];
+      if (tid == 0) {   // row space for this tile (ascending inside a chunk; one directory entry per chunk)
+        u64 off = 0;
         if (dk) {
-          off = atomicAdd(&T.ctrl[0], (u64)dk);
-          if (off + dk > T.out_cap_rows) { ok = 0; atomicOr(&T.ctrl[2], (u64)ERR_ROWS_OVERFLOW); }
-          const u64 sidx = atomicAdd(&T.ctrl[1], 1ULL);
-          if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = seq; sg.row_off = off; sg.nrows = dk; sg.pad = 0; T.segs[sidx] = sg; }
-          else atomicOr(&T.ctrl[2], (u64)ERR_SEGS_OVERFLOW);
+          if (ch_used + dk > ch_cap) {
+            if (ch_used) {
+              const u64 sidx = atomicAdd(&T.ctrl[1], 1ULL);
+              if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = ch_seq; sg.row_off = ch_base; sg.nrows = ch_used; sg.pad = 0; T.segs[sidx] = sg; }
+              else atomicOr(&T.ctrl[2], (u64)ERR_SEGS_OVERFLOW);
+              atomicAdd(&T.ctrl[3], (u64)ch_used);
+            }
+            ch_cap = max(chunk_rows, dk);
+            ch_base = atomicAdd(&T.ctrl[0], (u64)ch_cap);
+            ch_used = 0; ch_seq = seq;
+            ch_ok = (ch_base + ch_cap <= T.out_cap_rows) ? 1u : 0u;
+            if (!ch_ok) atomicOr(&T.ctrl[2], (u64)ERR_ROWS_OVERFLOW);
+          }
+          off = ch_base + ch_used; ch_used += dk;
         }
-        bc64[0] = off; bc32[1] = ok;
+        bc64[0] = off; bc32[1] = ch_ok;
       }
-      __syncthreads();
+      if (dk <= (u32)DKMAX) {
+        // counting rank: kept-rank = number of kept keys smaller than mine (broadcast LDS reads)
+        for (u32 p = tid; p < dk; p += TPB) {
+          const Key<KW> mine = dkeys[p];
+          u32 r = 0;
+          for (u32 q = 0; q < dk; q++) r += key_less<KW>(dkeys[q], mine) ? 1u : 0u;
+          const u32 t = dslot[p];
+          tab[t] = (tab[t] & 0xFFFF0000u) | r;
+        }
+      } else {
+        // slow path (more than DKMAX kept keys in one tile): LDS bitonic sort of table slots by key
+        u32 p2 = 1; while (p2 < dk) p2 <<= 1;
+        for (u32 p = dk + tid; p < p2; p += TPB) dslot[p] = 0xFFFFu;   // +inf padding
+        lds_barrier();
+        for (u32 k2 = 2; k2 <= p2; k2 <<= 1) {
+          for (u32 j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (u32 p = tid; p < p2; p += TPB) {
+              const u32 q = p ^ j2;
+              if (q > p) {
+                const u32 a = dslot[p], bb = dslot[q];
+                bool a_gt_b;
+                if (a == 0xFFFFu) a_gt_b = (bb != 0xFFFFu);
+                else if (bb == 0xFFFFu) a_gt_b = false;
+                else a_gt_b = key_less<KW>(keysL[(tab[bb] & 0xFFFFu) - 1], keysL[(tab[a] & 0xFFFFu) - 1]);
+                const bool up = (p & k2) == 0;
+                if (a_gt_b == up) { dslot[p] = (u16)bb; dslot[q] = (u16)a; }
+              }
+            }
+            lds_barrier();
+          }
+        }
+        for (u32 p = tid; p < dk; p += TPB) { const u32 t = dslot[p]; tab[t] = (tab[t] & 0xFFFF0000u) | p; }
+      }
+      lds_barrier();
+      PH(4);
       const u64 row_off = bc64[0];
       const bool can_write = bc32[1] != 0;
+      if (tid == 0) bc32[2] = 0;
+      PH(5);
 
       // ---- 6. per-record decision (merge.hpp:199-247), statistics ----
       u32 kr[M], outc[M];
 #pragma unroll
+      for (int m = 0; m < M; m++) kr[m] = tab[hs[m]];     // M independent reads in flight
+#pragma unroll
       for (int m = 0; m < M; m++) {
+        const u32 e = kr[m];
         kr[m] = 0xFFFFu; outc[m] = 0;
         if ((consm >> m) & 1u) {
-          const u32 e = tab[hs[m]];
           const u32 rec = e >> 16;
           kr[m] = e & 0xFFFFu;
-          if ((solidm >> m) & 1u) { outc[m] = cnt[m]; uwo[m] += 1; two[m] += cnt[m]; }
-          else if (share_min && rec >= share_min) {
+          if ((solidm >> m) & 1u) {
+            outc[m] = cnt[m]; uwo[m] += 1; two[m] += cnt[m];
+            if (two[m] < cnt[m]) atomicAdd(&T.stats[4 * (u64)N + ((tid + m * TPB) >> wl)], 1ULL << 32);
+          } else if (share_min && rec >= share_min) {
             outc[m] = cnt[m];
-            atomicAdd(&T.stats[1 * (u64)N + li[m]], 1ULL);
-            atomicAdd(&T.stats[5 * (u64)N + li[m]], (u64)cnt[m]);
+            atomicAdd(&T.stats[1 * (u64)N + ((tid + m * TPB) >> wl)], 1ULL);
+            atomicAdd(&T.stats[5 * (u64)N + ((tid + m * TPB) >> wl)], (u64)cnt[m]);
           }
         }
       }
-      __syncthreads();   // table fully read: the LDS image may now alias it
+      lds_barrier();   // hash set fully read: owners may clear it, the image may alias the staged keys
+      PH(6);
+#pragma unroll
+      for (int m = 0; m < M; m++) if ((ownm >> m) & 1u) tab[hs[m]] = 0;
 
       // ---- 7. assemble rows as a file-body image in LDS, stream them out ----
       if (dk && can_write) {
-        const u32 rows_per = (u32)EMIT_BYTES / row_bytes;
+        const u32 rows_per = (u32)KEYS_BYTES / row_bytes;
         u8* const dst0 = T.out + row_off * row_bytes;
         for (u32 b0 = 0; b0 < dk; b0 += rows_per) {
           const u32 nb = min(rows_per, dk - b0);
           const u32 bytes = nb * row_bytes;
+          if (b0) lds_barrier();
           {
-            uint4* z = reinterpret_cast<uint4*>(smem);
+            uint4* z = reinterpret_cast<uint4*>(img);
             for (u32 t = tid; t < (bytes + 15) / 16; t += TPB) z[t] = make_uint4(0, 0, 0, 0);
           }
-          __syncthreads();
+          lds_barrier();
 #pragma unroll
           for (int m = 0; m < M; m++) {
             const u32 r = kr[m] - b0;   // wraps for 0xFFFF / other batches
             if (((consm >> m) & 1u) && kr[m] != 0xFFFFu && r < nb) {
-              u8* row = smem + r * row_bytes;
+              u8* row = img + r * row_bytes;
               if ((ownm >> m) & 1u) {
                 if (MODE == 0) {
                   u32* rw = reinterpret_cast<u32*>(row);
@@ -323,42 +431,55 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
                 }
               }
               if (outc[m]) {
-                if (MODE == 0) reinterpret_cast<u32*>(row + KW * 8)[li[m]] = outc[m];
+                const u32 li = (tid + m * TPB) >> wl;
+                if (MODE == 0) reinterpret_cast<u32*>(row + KW * 8)[li] = outc[m];
                 else {
-                  const u32 ob = r * row_bytes + KW * 8 + (li[m] >> 3);
-                  atomicOr(reinterpret_cast<u32*>(smem) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li[m] & 7u)));
+                  const u32 ob = r * row_bytes + KW * 8 + (li >> 3);
+                  atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u)));
                 }
               }
             }
           }
-          __syncthreads();
+          lds_barrier();
           u8* dst = dst0 + (u64)b0 * row_bytes;
           if (MODE == 0) {
-            const u32* src = reinterpret_cast<const u32*>(smem);
+            const u32* src = reinterpret_cast<const u32*>(img);
             u32* d32 = reinterpret_cast<u32*>(dst);
             for (u32 t = tid; t < bytes / 4; t += TPB) d32[t] = src[t];
           } else {
-            for (u32 t = tid; t < bytes; t += TPB) dst[t] = smem[t];
+            for (u32 t = tid; t < bytes; t += TPB) dst[t] = img[t];
           }
-          __syncthreads();
         }
       }
+      // ---- 8. the prefetched records take the consumed slots ----
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        if ((consm >> m) & 1u) { idx[m] += w; key[m] = nkey[m]; cnt[m] = ncnt[m]; }
+      }
+      PH(7);
       seq++;
+      lds_barrier();   // image copied out before the next tile stages its keys over it
     }
 
-    // ---- range done: flush per-list statistics (UNIQUE_WO, TOTAL_WO) ----
+    // ---- range done: close the open chunk, flush per-list statistics (UNIQUE_WO, TOTAL_WO) ----
+    if (tid == 0 && ch_used) {
+      const u64 sidx = atomicAdd(&T.ctrl[1], 1ULL);
+      if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = ch_seq; sg.row_off = ch_base; sg.nrows = ch_used; sg.pad = 0; T.segs[sidx] = sg; }
+      else atomicOr(&T.ctrl[2], (u64)ERR_SEGS_OVERFLOW);
+      atomicAdd(&T.ctrl[3], (u64)ch_used);
+    }
 #pragma unroll
     for (int m = 0; m < M; m++) {
-      u32 a = uwo[m]; u64 t2 = two[m];
-      // reduce over the w adjacent lanes of a list (w <= 64 here; wider windows add per lane)
+      u32 a = uwo[m]; u64 t2 = two[m];   // (carries of the wrapping total were added as they happened)
+      // reduce over the w adjacent lanes of a list (w <= 64 here; wider windows add per wave)
       for (u32 off = 1; off < w && off < 64; off <<= 1) {
         a += __shfl_xor(a, (int)off); t2 += shfl_xor_u64(t2, (int)off);
       }
-      const u32 s = tid + m * TPB;
+      const u32 s = tid + m * TPB, li = s >> wl;
       const bool leader = (w >= 64) ? (lane == 0) : ((s & (w - 1)) == 0);
-      if (li[m] < N && leader && (a | t2)) {
-        atomicAdd(&T.stats[2 * (u64)N + li[m]], (u64)a);
-        atomicAdd(&T.stats[4 * (u64)N + li[m]], t2);
+      if (li < N && leader && (a | t2)) {
+        atomicAdd(&T.stats[2 * (u64)N + li], (u64)a);
+        atomicAdd(&T.stats[4 * (u64)N + li], t2);
       }
     }
     __syncthreads();
@@ -378,8 +499,22 @@ template __global__ void k_merge_rows<2, 1>(const TaskDev*, const uint2*, u32, u
 // ---- host-side launchers (plain functions so other translation units need no device code) -----
 namespace kmx {
 
-int rows_lds_bytes(int kw, u32 n_lists) { return rows_emit_bytes(kw) + 256 + 4 * (int)n_lists; }
+int rows_lds_bytes(int kw, u32 n_lists) { return rows_fixed_bytes(kw) + 384 + 4 * (int)n_lists; }
 int rows_cap() { return CAP; }
+u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, 262144u / row_bytes); }
+u32 rows_image_bytes(int kw) { return (u32)rows_emit_bytes(kw); }
+#ifdef KMX_PHASE_PROF
+void rows_phase_prof_dump()
+{
+  u64 h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_phase_prof), sizeof(h)) != hipSuccess) return;
+  u64 tot = 0; for (int i = 0; i < 9; i++) tot += h[i];
+  static const char* nm[9] = {"setup", "bound(+wait)", "consume+pref", "insert", "publish+rank", "-", "decide", "emit", "-"};
+  for (int i = 0; i < 8; i++) fprintf(stderr, "[phase] %-14s %6.2f%%  %llu\n", nm[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
+  memset(h, 0, sizeof(h));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_phase_prof), h, sizeof(h));
+}
+#endif
 
 hipError_t launch_range_bounds(int kw, const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st)
 {
