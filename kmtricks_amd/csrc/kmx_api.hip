@@ -197,7 +197,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.out_bytes = (size_t)((K.upper - K.lower + 1) * H.row_bytes);
     } else {
       H.row_bytes = kw * 8 + (mode == KMX_MODE_COUNT ? 4 * H.N : (H.N + 7) / 8);
-      u32 wl = 0; while ((H.N << (wl + 1)) <= (u32)rows_cap()) wl++;
+      u32 wl = 0; while (wl < 6 && (H.N << (wl + 1)) <= (u32)rows_cap()) wl++;   // window <= one wave
       H.wl = wl;
       if (H.row_bytes > rows_image_bytes((int)kw)) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
       u64 guess = K.rows_hint ? K.rows_hint : 2ULL * H.len[pivot] + 4096;
@@ -431,11 +431,16 @@ extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* 
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   KMX_HIP(ctx, hipMemcpyAsync(st, R->d_meta + H.o_stats, 8ull * 6 * N, hipMemcpyDeviceToHost, ctx->stream));
   KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // kernels fill RESCUED (1), UNIQUE_WO (2), TOTAL_WO (4) and the rescued total (5); derive the rest
-  // exactly as MergeStatistics does (merge.hpp:65-70): every record is either solid or non-solid.
+  // COUNT/PA kernel fills NON_SOLID (0), RESCUED (1), TOTAL_WO (4) and the rescued total (5); the BF
+  // kernel fills UNIQUE_WO (2) instead of NON_SOLID.  Derive the rest exactly as MergeStatistics does
+  // (merge.hpp:65-70): every input record is either solid or non-solid.
   for (u32 i = 0; i < N; i++) {
-    const u64 rd = st[1 * (u64)N + i], uwo = st[2 * (u64)N + i], two = st[4 * (u64)N + i], twr = st[5 * (u64)N + i];
-    st[0 * (u64)N + i] = (u64)H.len[i] - uwo;
+    const u64 rd = st[1 * (u64)N + i], two = st[4 * (u64)N + i], twr = st[5 * (u64)N + i];
+    u64 ns, uwo;
+    if (R->is_bf) { uwo = st[2 * (u64)N + i]; ns = (u64)H.len[i] - uwo; }
+    else { ns = st[0 * (u64)N + i]; uwo = (u64)H.len[i] - ns; }
+    st[0 * (u64)N + i] = ns;
+    st[2 * (u64)N + i] = uwo;
     st[3 * (u64)N + i] = uwo + rd;
     st[5 * (u64)N + i] = two + twr;
   }

@@ -78,25 +78,42 @@ __device__ u64 kmx_phase_prof[16];
 
 // ---- the merge kernel ----------------------------------------------------------------------------
 template <int KW> __device__ __forceinline__ u32 key_hash(const Key<KW>& k)
-{
-  u64 x = k.w[0];
-  if (KW == 2) x ^= k.w[KW - 1] * 0x9E3779B97F4A7C15ULL;
-  x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
-  return (u32)x & (TS - 1);
+{ // cheap 32-bit mix (a handful of VALU ops); quality only matters for the probe length
+  u32 x = (u32)k.w[0] ^ ((u32)(k.w[0] >> 32) * 0x9E3779B1u);
+  if (KW == 2) x ^= ((u32)k.w[KW - 1] * 0x85EBCA77u) ^ ((u32)(k.w[KW - 1] >> 32) * 0xC2B2AE3Du);
+  x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+  return x & (TS - 1);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt on gfx950
 // (loads and stores share the counter), which would wait for the record prefetch at every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// One workgroup per CU (up to 256 VGPRs): the per-slot state (record being merged, record in
-// flight, cursor, statistics) lives in registers.
+// linear probing past a hash collision (rare): returns table slot (low 32) | previous entry (high 32)
+// of `k`, claiming an empty slot for record slot `s` if the key is new (previous entry 0) -- out of line
+template <int KW>
+__device__ __noinline__ u64 probe_slow(u32* tab, const Key<KW>* keysL, Key<KW> k, u32 h, u32 s)
+{
+  for (;;) {
+    h = (h + 1) & (TS - 1);
+    u32 o = tab[h];
+    if (o == 0) {
+      o = atomicCAS(&tab[h], 0u, s + 1);
+      if (o == 0) return (u64)h;
+    }
+    if (key_eq<KW>(keysL[(o & 0xFFFFu) - 1], k)) return (u64)h | ((u64)o << 32);
+  }
+}
+
+// One workgroup per CU: the per-slot state (record being merged, record in flight, statistics)
+// lives in registers.  The body is written for a low instruction count per record: the kernel is
+// issue-bound long before it is LDS- or HBM-bound.
 template <int KW, int MODE>
 __global__ __launch_bounds__(TPB, TPB / 256)
 void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ items, u32 n_items, u32* ticket)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int RB = KW * 8 + 4;
+  constexpr int RB4 = (KW * 8 + 4) / 4;
   constexpr int KEYS_BYTES = CAP * KW * 8;
   constexpr int DKMAX = 4096 / (KW * 8);
 
@@ -110,7 +127,6 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
   u32* wany = reinterpret_cast<u32*>(misc + 256);                   // NWAVE flags (64 B)
   u64* bc64 = reinterpret_cast<u64*>(misc + 320);                   // broadcast: row offset
   u32* bc32 = reinterpret_cast<u32*>(misc + 336);                   // [0] item  [1] can-write  [2] kept counter
-  u32* cur = reinterpret_cast<u32*>(misc + 384);                    // N cursors
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef KMX_PHASE_PROF
@@ -139,37 +155,41 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
     }
     const TaskDev& T = tasks[items[item].x];
     const u32 range = items[item].y;
-    const u32 N = T.N, wl = T.wl, w = 1u << wl;
+    const u32 N = T.N, wl = T.wl, w = 1u << wl;      // w <= 64: a list's window never leaves its wave
     const u32 rec_min = T.rec_min, share_min = T.share_min, row_bytes = T.row_bytes;
     const u32 sat = max(rec_min, share_min);          // recurrence only matters up to this value
-    const u32* const sminp = T.soft_min;
     const u32 chunk_rows = max(64u, 262144u / row_bytes);
+    const u32 g0 = lane & ~(w - 1);                   // first lane of my list's lane group
+    const u32 nxt = (lane + 1) & (w - 1);             // group-relative lane holding the next window position
+    const u64 wmask = (w == 64) ? ~0ULL : ((1ULL << w) - 1);
 
     // Slot s = tid + m*TPB serves list s >> wl.  A list's window is circular: lane residue
     // rr = s & (w-1) always holds the record whose index is == rr (mod w) inside [cur, cur + w),
     // so a consumed record is replaced in place by record idx + w and every record is loaded once.
-    gu32* ptr[M]; u32 endv[M], idx[M], uwo[M], two[M], smin[M];
+    // lastm bit m: this slot holds the LAST record of its window (its key bounds the tile).
+    gu32* ptr[M]; u32 endv[M], idx[M], smin[M], nso[M]; u64 two[M];
     Key<KW> key[M]; u32 cnt[M];
+    u32 lastm = 0;
 #pragma unroll
     for (int m = 0; m < M; m++) {
       const u32 s = tid + m * TPB, li = s >> wl, rr = s & (w - 1);
-      uwo[m] = 0; two[m] = 0; idx[m] = 0; endv[m] = 0; ptr[m] = (gu32*)nullptr; smin[m] = 0;
+      nso[m] = 0; two[m] = 0; idx[m] = 0; endv[m] = 0; ptr[m] = (gu32*)nullptr; smin[m] = 0;
       key[m] = key_inf<KW>(); cnt[m] = 0;
       if (li < N) {
         ptr[m] = (gu32*)(uintptr_t)T.recs[li];
-        smin[m] = sminp[li];
+        smin[m] = T.soft_min[li];
         endv[m] = T.bounds[(u64)(range + 1) * N + li];
         const u32 c0 = T.bounds[(u64)range * N + li];
         idx[m] = c0 + ((rr - c0) & (w - 1));
+        if (idx[m] == c0 + w - 1) lastm |= 1u << m;
         if (idx[m] < endv[m]) {
-          gu32* p = ptr[m] + (u64)idx[m] * (RB / 4);
+          gu32* p = ptr[m] + (u64)idx[m] * RB4;
 #pragma unroll
           for (int q = 0; q < KW; q++) key[m].w[q] = (u64)p[2 * q] | ((u64)p[2 * q + 1] << 32);
           cnt[m] = p[2 * KW];
         }
       }
     }
-    for (u32 i = tid; i < N; i += TPB) cur[i] = T.bounds[(u64)range * N + i];
     // row-space allocator state (thread 0): rows are claimed in chunks, one directory entry per chunk
     u64 ch_base = 0; u32 ch_used = 0, ch_cap = 0, ch_seq = 0, ch_ok = 1;
     __syncthreads();
@@ -178,18 +198,15 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
     PH(0);
     for (;;) {
       // ---- 1. tile bound b = smallest "last record of a window that has more records behind it" ----
-      u32 validm = 0, consm = 0;
       Key<KW> cand = key_inf<KW>();
+      u32 anyv = 0;
 #pragma unroll
       for (int m = 0; m < M; m++) {
-        if (idx[m] < endv[m]) {
-          validm |= 1u << m;
-          const u32 c0 = cur[(tid + m * TPB) >> wl];
-          if (idx[m] == c0 + w - 1 && idx[m] + 1 < endv[m]) cand = key_min<KW>(cand, key[m]);
-        }
+        anyv |= (idx[m] < endv[m]) ? 1u : 0u;
+        if (((lastm >> m) & 1u) && idx[m] + 1 < endv[m]) cand = key_min<KW>(cand, key[m]);
       }
       cand = wave_min_key<KW>(cand);
-      const u64 vbal = __ballot(validm != 0);
+      const u64 vbal = __ballot(anyv != 0);
       if (lane == 0) { wmin[wave] = cand; wany[wave] = vbal != 0; }
       lds_barrier();
       PH(1);
@@ -199,33 +216,26 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
       for (int v = 1; v < NWAVE; v++) { b = key_min<KW>(b, wmin[v]); any |= wany[v]; }
       if (!any) break;
 
-      // ---- 2. consume keys <= b, advance cursors, stage keys, prefetch the replacements ----
-      // (written as independent batches over the M slots: no LDS round trip is waited for here)
+      // ---- 2. consume keys <= b, stage them, prefetch the replacements ----
       Key<KW> nkey[M]; u32 ncnt[M];
-#pragma unroll
-      for (int m = 0; m < M; m++)
-        if (((validm >> m) & 1u) && key_le<KW>(key[m], b)) consm |= 1u << m;
-#pragma unroll
-      for (int m = 0; m < M; m++) {   // the w lanes of a list: their consumed count moves the list cursor
-        const u32 li = (tid + m * TPB) >> wl;
-        const u64 bal = __ballot((consm >> m) & 1u);
-        if (wl >= 6) { if (lane == 0 && bal) atomicAdd(&cur[li], (u32)__popcll(bal)); }
-        else {
-          const u32 grp = (u32)((bal >> (lane & ~(w - 1))) & ((1ULL << w) - 1));
-          if ((lane & (w - 1)) == 0 && grp) atomicAdd(&cur[li], (u32)__popc(grp));
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < M; m++) if ((consm >> m) & 1u) keysL[tid + m * TPB] = key[m];
+      u32 consm = 0;
 #pragma unroll
       for (int m = 0; m < M; m++) {
-        nkey[m] = key_inf<KW>(); ncnt[m] = 0;
-        const u32 ni = idx[m] + w;
-        if (((consm >> m) & 1u) && ni < endv[m]) {
-          gu32* p = ptr[m] + (u64)ni * (RB / 4);
+        const bool c = idx[m] < endv[m] && key_le<KW>(key[m], b);
+        const u64 g = (__ballot(c) >> g0) & wmask;          // consumed lanes of my list
+        if (g && g != wmask) {                              // the last consumed slot becomes the window's last
+          if (c && !((g >> nxt) & 1ULL)) lastm |= 1u << m; else lastm &= ~(1u << m);
+        }                                                   // (whole window consumed: the last stays the last)
+        if (c) {
+          consm |= 1u << m;
+          keysL[tid + m * TPB] = key[m];
+          const u32 ni = idx[m] + w;
+          if (ni < endv[m]) {
+            gu32* p = ptr[m] + (u64)ni * RB4;
 #pragma unroll
-          for (int q = 0; q < KW; q++) nkey[m].w[q] = (u64)p[2 * q] | ((u64)p[2 * q + 1] << 32);
-          ncnt[m] = p[2 * KW];
+            for (int q = 0; q < KW; q++) nkey[m].w[q] = (u64)p[2 * q] | ((u64)p[2 * q + 1] << 32);
+            ncnt[m] = p[2 * KW];
+          }
         }
       }
       lds_barrier();
@@ -235,83 +245,45 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
       // Dense keys are inserted by hundreds of lists at once, so every access reads first: only the
       // first arrivals issue the ds_cmpst claim and the recurrence counter stops being incremented
       // at max(rec_min, share_min) -- same-address LDS atomics serialise, same-address reads broadcast.
-      // All M slots of a thread probe together (M independent LDS reads in flight); only hash
-      // collisions fall through to the sequential linear-probing loop.
-      u32 hs[M]; u32 ownm = 0, solidm = 0, unresm = 0;
+      u32 hs[M]; u32 ownm = 0, solidm = 0;
       {
         u32 old[M];
 #pragma unroll
-        for (int m = 0; m < M; m++) hs[m] = key_hash<KW>(key[m]);
+        for (int m = 0; m < M; m++) { hs[m] = key_hash<KW>(key[m]); old[m] = 1; }
 #pragma unroll
-        for (int m = 0; m < M; m++) old[m] = ((consm >> m) & 1u) ? tab[hs[m]] : 1u;
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-          if (old[m] == 0) {
-            old[m] = atomicCAS(&tab[hs[m]], 0u, (u32)(tid + m * TPB) + 1);
-            if (old[m] == 0) ownm |= 1u << m;
-          }
-        }
-        Key<KW> ok[M];
+        for (int m = 0; m < M; m++) if ((consm >> m) & 1u) old[m] = tab[hs[m]];
 #pragma unroll
         for (int m = 0; m < M; m++) {
-          const bool chk = ((consm >> m) & 1u) && !((ownm >> m) & 1u);
-          ok[m] = keysL[chk ? (old[m] & 0xFFFFu) - 1 : 0];
-          if (chk && !key_eq<KW>(ok[m], key[m])) unresm |= 1u << m;
-        }
-        if (unresm) {
-#pragma unroll
-          for (int m = 0; m < M; m++) {
-            if ((unresm >> m) & 1u) {
-              u32 h = hs[m], o;
-              for (;;) {
-                h = (h + 1) & (TS - 1);
-                o = tab[h];
-                if (o == 0) {
-                  o = atomicCAS(&tab[h], 0u, (u32)(tid + m * TPB) + 1);
-                  if (o == 0) { ownm |= 1u << m; break; }
-                }
-                if (key_eq<KW>(keysL[(o & 0xFFFFu) - 1], key[m])) break;
-              }
-              hs[m] = h; old[m] = o;
+          if ((consm >> m) & 1u) {
+            bool own = false;
+            if (old[m] == 0) { old[m] = atomicCAS(&tab[hs[m]], 0u, (u32)(tid + m * TPB) + 1); own = old[m] == 0; }
+            if (!own && !key_eq<KW>(keysL[(old[m] & 0xFFFFu) - 1], key[m])) {
+              const u64 pr = probe_slow<KW>(tab, keysL, key[m], hs[m], (u32)(tid + m * TPB));
+              hs[m] = (u32)pr; old[m] = (u32)(pr >> 32); own = old[m] == 0;
             }
-          }
-        }
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-          if (((consm >> m) & 1u) && cnt[m] >= smin[m]) {
-            solidm |= 1u << m;
-            if ((old[m] >> 16) < sat) atomicAdd(&tab[hs[m]], 1u << 16);
+            if (own) ownm |= 1u << m;
+            if (cnt[m] >= smin[m]) {
+              solidm |= 1u << m;
+              if ((old[m] >> 16) < sat) atomicAdd(&tab[hs[m]], 1u << 16);
+            }
           }
         }
       }
       lds_barrier();
       PH(3);
 
-      // ---- 4. owners publish the kept keys (recurrence >= rec_min); rank them ----
-      {
-        u32 e[M]; u32 keptm = 0, npre[M], wtot = 0;
-#pragma unroll
-        for (int m = 0; m < M; m++) e[m] = ((ownm >> m) & 1u) ? tab[hs[m]] : 0u;
+      // ---- 4. owners publish the kept keys (recurrence >= rec_min) ----
+      if (ownm) {
 #pragma unroll
         for (int m = 0; m < M; m++) {
-          const bool kept = ((ownm >> m) & 1u) && (e[m] >> 16) >= rec_min;
-          if (kept) keptm |= 1u << m;
-          const u64 bal = __ballot(kept);
-          npre[m] = wtot + (u32)__popcll(bal & ((1ULL << lane) - 1));   // position inside this wave's block
-          wtot += (u32)__popcll(bal);
-        }
-        u32 base = 0;
-        if (wtot) {   // one LDS atomic per wave and tile
-          if (lane == 0) base = atomicAdd(&bc32[2], wtot);
-          base = __shfl(base, 0);
-        }
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-          if ((keptm >> m) & 1u) {
-            const u32 pos = base + npre[m];
-            dslot[pos] = (u16)hs[m];
-            if (pos < (u32)DKMAX) dkeys[pos] = key[m];
-          } else if ((ownm >> m) & 1u) tab[hs[m]] = (e[m] & 0xFFFF0000u) | 0xFFFFu;
+          if ((ownm >> m) & 1u) {
+            const u32 e = tab[hs[m]];
+            if ((e >> 16) >= rec_min) {
+              const u32 pos = atomicAdd(&bc32[2], 1u);
+              dslot[pos] = (u16)hs[m];
+              if (pos < (u32)DKMAX) dkeys[pos] = key[m];
+            } else tab[hs[m]] = (e & 0xFFFF0000u) | 0xFFFFu;
+          }
         }
       }
       lds_barrier();
@@ -336,6 +308,7 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
         }
         bc64[0] = off; bc32[1] = ch_ok;
       }
+      // ---- 5. rank the kept keys ----
       if (dk <= (u32)DKMAX) {
         // counting rank: kept-rank = number of kept keys smaller than mine (broadcast LDS reads)
         for (u32 p = tid; p < dk; p += TPB) {
@@ -369,56 +342,54 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
         }
         for (u32 p = tid; p < dk; p += TPB) { const u32 t = dslot[p]; tab[t] = (tab[t] & 0xFFFF0000u) | p; }
       }
+      const u32 rows_per = (u32)KEYS_BYTES / row_bytes;
+      {   // the staged keys are dead: zero the first row batch of the image
+        const u32 zb = min(dk, rows_per) * row_bytes;
+        uint4* z = reinterpret_cast<uint4*>(img);
+        for (u32 t = tid; t < (zb + 15) / 16; t += TPB) z[t] = make_uint4(0, 0, 0, 0);
+      }
       lds_barrier();
       PH(4);
       const u64 row_off = bc64[0];
       const bool can_write = bc32[1] != 0;
       if (tid == 0) bc32[2] = 0;
-      PH(5);
 
-      // ---- 6. per-record decision (merge.hpp:199-247), statistics ----
-      u32 kr[M], outc[M];
+      // ---- 6. per-record decision (merge.hpp:199-247), statistics; rows as a file-body image ----
+      u32 kr[M];
 #pragma unroll
-      for (int m = 0; m < M; m++) kr[m] = tab[hs[m]];     // M independent reads in flight
+      for (int m = 0; m < M; m++) kr[m] = ((consm >> m) & 1u) ? tab[hs[m]] : 0xFFFFu;
 #pragma unroll
       for (int m = 0; m < M; m++) {
-        const u32 e = kr[m];
-        kr[m] = 0xFFFFu; outc[m] = 0;
         if ((consm >> m) & 1u) {
-          const u32 rec = e >> 16;
-          kr[m] = e & 0xFFFFu;
-          if ((solidm >> m) & 1u) {
-            outc[m] = cnt[m]; uwo[m] += 1; two[m] += cnt[m];
-            if (two[m] < cnt[m]) atomicAdd(&T.stats[4 * (u64)N + ((tid + m * TPB) >> wl)], 1ULL << 32);
-          } else if (share_min && rec >= share_min) {
-            outc[m] = cnt[m];
-            atomicAdd(&T.stats[1 * (u64)N + ((tid + m * TPB) >> wl)], 1ULL);
-            atomicAdd(&T.stats[5 * (u64)N + ((tid + m * TPB) >> wl)], (u64)cnt[m]);
+          const u32 rec = kr[m] >> 16;
+          kr[m] &= 0xFFFFu;
+          if ((solidm >> m) & 1u) two[m] += cnt[m];
+          else {
+            nso[m] += 1;
+            if (share_min && rec >= share_min) {
+              const u32 li = (tid + m * TPB) >> wl;
+              atomicAdd(&T.stats[1 * (u64)N + li], 1ULL);
+              atomicAdd(&T.stats[5 * (u64)N + li], (u64)cnt[m]);
+            } else cnt[m] = 0;                       // neither solid nor rescued: contributes nothing
           }
         }
       }
-      lds_barrier();   // hash set fully read: owners may clear it, the image may alias the staged keys
-      PH(6);
-#pragma unroll
-      for (int m = 0; m < M; m++) if ((ownm >> m) & 1u) tab[hs[m]] = 0;
-
-      // ---- 7. assemble rows as a file-body image in LDS, stream them out ----
+      PH(5);
       if (dk && can_write) {
-        const u32 rows_per = (u32)KEYS_BYTES / row_bytes;
         u8* const dst0 = T.out + row_off * row_bytes;
         for (u32 b0 = 0; b0 < dk; b0 += rows_per) {
           const u32 nb = min(rows_per, dk - b0);
           const u32 bytes = nb * row_bytes;
-          if (b0) lds_barrier();
-          {
+          if (b0) {
+            lds_barrier();
             uint4* z = reinterpret_cast<uint4*>(img);
             for (u32 t = tid; t < (bytes + 15) / 16; t += TPB) z[t] = make_uint4(0, 0, 0, 0);
+            lds_barrier();
           }
-          lds_barrier();
 #pragma unroll
           for (int m = 0; m < M; m++) {
             const u32 r = kr[m] - b0;   // wraps for 0xFFFF / other batches
-            if (((consm >> m) & 1u) && kr[m] != 0xFFFFu && r < nb) {
+            if (kr[m] != 0xFFFFu && r < nb) {
               u8* row = img + r * row_bytes;
               if ((ownm >> m) & 1u) {
                 if (MODE == 0) {
@@ -430,9 +401,9 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
                   for (int q = 0; q < KW * 8; q++) row[q] = (u8)(key[m].w[q >> 3] >> ((q & 7) * 8));
                 }
               }
-              if (outc[m]) {
+              if (cnt[m]) {
                 const u32 li = (tid + m * TPB) >> wl;
-                if (MODE == 0) reinterpret_cast<u32*>(row + KW * 8)[li] = outc[m];
+                if (MODE == 0) reinterpret_cast<u32*>(row + KW * 8)[li] = cnt[m];
                 else {
                   const u32 ob = r * row_bytes + KW * 8 + (li >> 3);
                   atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u)));
@@ -441,27 +412,43 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
             }
           }
           lds_barrier();
+          if (b0 == 0) {   // the hash set is fully read: owners clear their entries for the next tile
+#pragma unroll
+            for (int m = 0; m < M; m++) if ((ownm >> m) & 1u) tab[hs[m]] = 0;
+          }
           u8* dst = dst0 + (u64)b0 * row_bytes;
           if (MODE == 0) {
-            const u32* src = reinterpret_cast<const u32*>(img);
-            u32* d32 = reinterpret_cast<u32*>(dst);
-            for (u32 t = tid; t < bytes / 4; t += TPB) d32[t] = src[t];
+            if (((reinterpret_cast<uintptr_t>(dst) | bytes) & 7u) == 0) {
+              const u64* src = reinterpret_cast<const u64*>(img);
+              u64* d64 = reinterpret_cast<u64*>(dst);
+              for (u32 t = tid; t < bytes / 8; t += TPB) d64[t] = src[t];
+            } else {
+              const u32* src = reinterpret_cast<const u32*>(img);
+              u32* d32 = reinterpret_cast<u32*>(dst);
+              for (u32 t = tid; t < bytes / 4; t += TPB) d32[t] = src[t];
+            }
           } else {
             for (u32 t = tid; t < bytes; t += TPB) dst[t] = img[t];
           }
         }
+      } else {
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < M; m++) if ((ownm >> m) & 1u) tab[hs[m]] = 0;
       }
-      // ---- 8. the prefetched records take the consumed slots ----
+      // ---- 7. the prefetched records take the consumed slots ----
 #pragma unroll
       for (int m = 0; m < M; m++) {
-        if ((consm >> m) & 1u) { idx[m] += w; key[m] = nkey[m]; cnt[m] = ncnt[m]; }
+        if ((consm >> m) & 1u) {
+          idx[m] += w;
+          if (idx[m] < endv[m]) { key[m] = nkey[m]; cnt[m] = ncnt[m]; }
+        }
       }
-      PH(7);
+      PH(6);
       seq++;
-      lds_barrier();   // image copied out before the next tile stages its keys over it
     }
 
-    // ---- range done: close the open chunk, flush per-list statistics (UNIQUE_WO, TOTAL_WO) ----
+    // ---- range done: close the open chunk, flush per-list statistics (NON_SOLID, TOTAL_WO) ----
     if (tid == 0 && ch_used) {
       const u64 sidx = atomicAdd(&T.ctrl[1], 1ULL);
       if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = ch_seq; sg.row_off = ch_base; sg.nrows = ch_used; sg.pad = 0; T.segs[sidx] = sg; }
@@ -470,15 +457,13 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
     }
 #pragma unroll
     for (int m = 0; m < M; m++) {
-      u32 a = uwo[m]; u64 t2 = two[m];   // (carries of the wrapping total were added as they happened)
-      // reduce over the w adjacent lanes of a list (w <= 64 here; wider windows add per wave)
-      for (u32 off = 1; off < w && off < 64; off <<= 1) {
+      u32 a = nso[m]; u64 t2 = two[m];
+      for (u32 off = 1; off < w; off <<= 1) {      // reduce over the w adjacent lanes of a list
         a += __shfl_xor(a, (int)off); t2 += shfl_xor_u64(t2, (int)off);
       }
       const u32 s = tid + m * TPB, li = s >> wl;
-      const bool leader = (w >= 64) ? (lane == 0) : ((s & (w - 1)) == 0);
-      if (li < N && leader && (a | t2)) {
-        atomicAdd(&T.stats[2 * (u64)N + li], (u64)a);
+      if (li < N && (s & (w - 1)) == 0 && (a | t2)) {
+        if (a) atomicAdd(&T.stats[0 * (u64)N + li], (u64)a);
         atomicAdd(&T.stats[4 * (u64)N + li], t2);
       }
     }
@@ -499,7 +484,7 @@ template __global__ void k_merge_rows<2, 1>(const TaskDev*, const uint2*, u32, u
 // ---- host-side launchers (plain functions so other translation units need no device code) -----
 namespace kmx {
 
-int rows_lds_bytes(int kw, u32 n_lists) { return rows_fixed_bytes(kw) + 384 + 4 * (int)n_lists; }
+int rows_lds_bytes(int kw, u32) { return rows_fixed_bytes(kw) + 384; }
 int rows_cap() { return CAP; }
 u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, 262144u / row_bytes); }
 u32 rows_image_bytes(int kw) { return (u32)rows_emit_bytes(kw); }
@@ -509,7 +494,7 @@ void rows_phase_prof_dump()
   u64 h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_phase_prof), sizeof(h)) != hipSuccess) return;
   u64 tot = 0; for (int i = 0; i < 9; i++) tot += h[i];
-  static const char* nm[9] = {"setup", "bound(+wait)", "consume+pref", "insert", "publish+rank", "-", "decide", "emit", "-"};
+  static const char* nm[9] = {"setup", "bound(+wait)", "consume+pref", "insert", "publish+rank", "decide", "emit+rotate", "-", "-"};
   for (int i = 0; i < 8; i++) fprintf(stderr, "[phase] %-14s %6.2f%%  %llu\n", nm[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
   memset(h, 0, sizeof(h));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_phase_prof), h, sizeof(h));
