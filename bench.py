@@ -75,7 +75,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from kmtricks_amd import lib
+    from kmtricks_amd import lib, shard
     ctx = lib.Context(local)
     ctx.set_profiling(True)
 
@@ -84,8 +84,9 @@ def main():
     p_present = (1.0 - a.subst_rate) ** a.kmer_size
     n_private = int(round(shared * (1.0 - p_present)))
     parts, total_recs = [], 0
-    for p in range(P):
-        rec, offs = gen_partition(torch, dev, 20240601 + rank * 100003 + p, N, shared, p_present, n_private)
+    # weak scaling: the job has P * world partitions, partition g belongs to rank g mod world
+    for g in shard.partitions_of_rank(P * world, world, rank):
+        rec, offs = gen_partition(torch, dev, 20240601 + g, N, shared, p_present, n_private)
         parts.append((rec, offs))
         total_recs += rec.shape[0]
     torch.cuda.synchronize()
@@ -127,15 +128,7 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tr = torch.tensor([float(total_recs)], device=dev, dtype=torch.float64)
-        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
-        job_recs = float(tr.item())
-    else:
-        job_recs = float(total_recs)
+    dt, job_recs = shard.reduce_job(dist if world > 1 else None, dev, dt, float(total_recs))
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -153,7 +146,7 @@ def main():
                        "records_per_step_per_gpu": total_recs, "rows_out_per_step_per_gpu": rows_out,
                        "parallelism": f"partitions sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(a, N, P),
                          "kernel": "k_merge_rows<1,0>", "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes},
         }
         if not a.no_cpu_baseline:
@@ -163,6 +156,17 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def pmc_traffic(a, N, P):
+    """HBM bytes per launch of the merge kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE + WRITE_SIZE, profiles/merge_pmc.json) -- only when they were taken on this workload."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "merge_pmc.json")))
+    except Exception:
+        return None
+    key = f"configs[2] {N}x{P} G={a.genome:.0e} d={a.subst_rate} rec_min={a.rec_min}".replace("e+0", "e")
+    return d["fetch_bytes"] + d["write_bytes"] if d.get("workload") == key else None
 
 
 def cpu_baseline(part, N, rec_min):

@@ -29,7 +29,7 @@
 namespace kmx {
 
 #ifndef KMX_ROWS_TPB
-#define KMX_ROWS_TPB 512
+#define KMX_ROWS_TPB 1024
 #endif
 constexpr int TPB = KMX_ROWS_TPB;  // 8 or 16 waves
 constexpr int M = 4096 / TPB;      // record slots per thread
