@@ -52,6 +52,8 @@ _lib.kmx_count_kmer.argtypes = [_vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uin
 _lib.kmx_count_hash.argtypes = [_vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                 C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64)]
 _lib.kmx_transpose_bits.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, _vp]
+_lib.kmx_superk_partition.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
+                                      C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 EXPORTS = ["kmx_version", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
@@ -166,6 +168,24 @@ class Context:
         out = np.zeros(ncols * (nrows // 8), dtype=np.uint8)
         self._check(_lib.kmx_transpose_bits(self._h, mat.ctypes.data, nrows, ncols, out.ctypes.data),
                     "kmx_transpose_bits")
+        return out
+
+    def superk_partition(self, reads, k, m, repart, nb_parts):
+        """kmx_superk_partition: list of reads (str/bytes) -> [(record stream bytes, n_kmers)] per partition"""
+        bs = [r if isinstance(r, bytes) else r.encode() for r in reads]
+        offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        blob = b"".join(bs)
+        rep = np.ascontiguousarray(repart, dtype=np.uint16)
+        ob = (_vp * nb_parts)()
+        ol = (C.c_uint64 * nb_parts)()
+        okm = (C.c_uint64 * nb_parts)()
+        self._check(_lib.kmx_superk_partition(self._h, blob, offs.ctypes.data, len(bs), k, m, rep.ctypes.data, nb_parts,
+                                              ob, ol, okm), "kmx_superk_partition")
+        out = []
+        for p in range(nb_parts):
+            out.append((C.string_at(ob[p], ol[p]) if ol[p] else b"", int(okm[p])))
+            _lib.kmx_free(ob[p])
         return out
 
     def prepare(self, tasks):

@@ -83,3 +83,31 @@ def test_transpose_vs_oracle(ctx, nr, nc):
     t = ctx.transpose_bits(m, nr, nc)
     assert np.array_equal(t, orc.transpose_bits(m, nr, nc))
     assert np.array_equal(ctx.transpose_bits(t, nc, nr), m)   # bit_matrix_test.cpp:60-99
+
+
+def test_superk_partition_reference_goldens(ctx):
+    """tests/task_main.cpp:85-114 through the HIP partitioner: 37/46/12/43 and 20/21/58/39 k-mers per
+    super-k-mer file, and byte-identical record streams vs the oracle (fixture repartition, k=31, m=10)"""
+    lut = orc.minimizer_lut(10)
+    rep = repart_table()
+    for name, f in (("D1", "1.fasta"), ("D2", "2.fasta")):
+        reads = read_fasta(os.path.join(GD, f))
+        exp = orc.superk_partition(reads, 31, 10, lut, rep, 4)
+        got = ctx.superk_partition(reads, 31, 10, rep, 4)
+        assert [g[1] for g in got] == G["task_main"]["superk_info_" + name][1::2]
+        for p in range(4):
+            assert got[p][0] == exp[p][0] and got[p][1] == exp[p][1]
+
+
+@pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4)])
+def test_superk_partition_random_reads_vs_oracle(ctx, k, m, P):
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    reads = random_reads(7 + k, 900, 150, n_rate=0.004) + ["ACGT" * 70, "A" * 300, "ACGTN" * 40, "ACG", "", "T" * k,
+                                                        "acgtacgtnnacgt" * 12]
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    got = ctx.superk_partition(reads, k, m, rep, P)
+    assert sum(g[1] for g in got) > 10000
+    for p in range(P):
+        assert got[p][1] == exp[p][1]
+        assert got[p][0] == exp[p][0]
