@@ -15,6 +15,7 @@
 namespace kmx {
 
 constexpr int BF_TPB = 512;
+constexpr int UNR = 8;             // record loads in flight per lane while scanning a list
 
 // bounds[j*N + i] = first record of list i with hash >= lower + j * rows_per_range
 __global__ void k_range_bounds_bf(const TaskDev* __restrict__ tasks, u32 max_c)
@@ -107,11 +108,21 @@ void k_merge_bf(const TaskDev* __restrict__ tasks, const uint2* __restrict__ ite
           if (i < N) {
             const u8* base = T.recs[i];
             const u32 e = T.bounds[(u64)(range + 1) * N + i], sm = T.soft_min[i];
-            for (u32 idx = cur[i] + r; idx < e; idx += g) {
-              const u32* p = reinterpret_cast<const u32*>(base + (u64)idx * 12);
-              const u64 h = (u64)p[0] | ((u64)p[1] << 32);
-              if (h >= thi) break;
-              if (p[2] >= sm) { const u32 row = (u32)(h - tlo); atomicAdd(&rec[row >> 1], 1u << ((row & 1u) * 16)); }
+            for (u32 idx = cur[i] + r; idx < e; idx += UNR * g) {   // UNR records in flight per lane
+              u64 hh[UNR]; u32 cc[UNR];
+#pragma unroll
+              for (int q = 0; q < UNR; q++) {
+                const u32 ix = idx + q * g;
+                hh[q] = ~0ULL; cc[q] = 0;
+                if (ix < e) { gu32* p = (gu32*)(uintptr_t)(base + (u64)ix * 12); hh[q] = (u64)p[0] | ((u64)p[1] << 32); cc[q] = p[2]; }
+              }
+              bool stop = false;
+#pragma unroll
+              for (int q = 0; q < UNR; q++) {
+                if (hh[q] >= thi) { stop = true; break; }
+                if (cc[q] >= sm) { const u32 row = (u32)(hh[q] - tlo); atomicAdd(&rec[row >> 1], 1u << ((row & 1u) * 16)); }
+              }
+              if (stop) break;
             }
           }
         }
@@ -126,12 +137,23 @@ void k_merge_bf(const TaskDev* __restrict__ tasks, const uint2* __restrict__ ite
           const u32 e = T.bounds[(u64)(range + 1) * N + i], sm = T.soft_min[i];
           const u32 start = cur[i];
           next = start;
-          for (u32 idx = start + r; idx < e; idx += g) {
-            const u32* p = reinterpret_cast<const u32*>(base + (u64)idx * 12);
-            const u64 h = (u64)p[0] | ((u64)p[1] << 32);
-            if (h >= thi) break;
+          bool stop = false;
+          for (u32 idx0 = start + r; idx0 < e && !stop; idx0 += UNR * g) {   // UNR records in flight per lane
+            u64 hh[UNR]; u32 cc[UNR];
+#pragma unroll
+            for (int q = 0; q < UNR; q++) {
+              const u32 ix = idx0 + q * g;
+              hh[q] = ~0ULL; cc[q] = 0;
+              if (ix < e) { gu32* p = (gu32*)(uintptr_t)(base + (u64)ix * 12); hh[q] = (u64)p[0] | ((u64)p[1] << 32); cc[q] = p[2]; }
+            }
+#pragma unroll
+            for (int q = 0; q < UNR; q++) {
+            if (stop) continue;
+            const u64 h = hh[q];
+            if (h >= thi) { stop = true; continue; }
+            const u32 idx = idx0 + q * g;
             next = idx + 1;
-            const u32 c = p[2];
+            const u32 c = cc[q];
             const u32 row = (u32)(h - tlo);
             const bool solid = c >= sm;
             u32 rc = 0;
@@ -158,6 +180,7 @@ void k_merge_bf(const TaskDev* __restrict__ tasks, const uint2* __restrict__ ite
                   }
                 }
               }
+            }
             }
           }
         }
