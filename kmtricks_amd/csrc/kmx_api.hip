@@ -122,6 +122,7 @@ struct kmx_merge_result {
   u32 n_items = 0, grid = 0, max_n = 0, max_c = 0;
   int bf_lds = 0;
   bool is_bf = false, waited = false;
+  bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
 };
@@ -145,7 +146,8 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   } else {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    KMX_HIP(ctx, launch_merge_rows(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
+    if (R->use_pivot) KMX_HIP(ctx, launch_merge_pivot(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, ctx->stream));
+    else KMX_HIP(ctx, launch_merge_rows(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
   }
   if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
   return KMX_OK;
@@ -228,6 +230,16 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   }
   R->n_items = n_items; R->max_n = max_n; R->max_c = max_c;
   R->grid = std::min(n_items, slots);
+  {
+    // k_merge_rows is the production kernel.  KMX_MERGE_KERNEL=pivot selects the experimental
+    // pivot-tiled kernel (merge_pivot.hip; 64-bit keys, no share-min, <= 1024 lists) for A/B runs; tasks
+    // it flags as not covered by their pivot are re-run with k_merge_rows.
+    bool rescue = false;
+    for (auto& H : R->tasks) rescue |= H.share_min > 0;
+    const char* force = getenv("KMX_MERGE_KERNEL");
+    R->use_pivot = force && !strcmp(force, "pivot") && !is_bf && !rescue && kw == 1 && max_n <= pivot_max_lists();
+    if (R->use_pivot) R->grid = std::min(n_items, (u32)ctx->n_cu);   // one 1024-thread workgroup per CU
+  }
   if (is_bf) {
     int lds = 0;
     for (auto& H : R->tasks) lds = std::max(lds, bf_lds_bytes(H.rt, H.row_bytes, H.N));
@@ -297,16 +309,18 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   return KMX_OK;
 }
 
-static int fetch_ctrl(kmx_merge_result* R, bool* overflow)
+static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = nullptr)
 {
   kmx_ctx* ctx = R->ctx;
   *overflow = false;
+  if (fallback) *fallback = false;
   for (auto& H : R->tasks) {
     u64 ctrl[4];
     KMX_HIP(ctx, hipMemcpyAsync(ctrl, R->d_meta + H.o_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, ctx->stream));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3];
-    if (ctrl[2]) *overflow = true;
+    if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
+    if ((ctrl[2] & ERR_FALLBACK) && fallback) *fallback = true;
   }
   return KMX_OK;
 }
@@ -323,9 +337,24 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     R->waited = true; R->status = KMX_OK;
     return KMX_OK;
   }
-  bool overflow = false;
-  int rc = fetch_ctrl(R, &overflow);
+  bool overflow = false, fallback = false;
+  int rc = fetch_ctrl(R, &overflow, &fallback);
   if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+  if (fallback) {
+    // the pivot did not cover some task's lists (a pivot gap overflowed the tile buffer): run the
+    // batch again with the general kernel.  Bounds stay valid; statistics and row space restart.
+    R->use_pivot = false;
+    R->grid = std::min(R->n_items, (u32)ctx->n_cu * 2);
+    for (auto& H : R->tasks) {
+      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
+      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 256, ctx->stream));
+    }
+    rc = launch_batch(R, false);
+    if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = fetch_ctrl(R, &overflow);
+    if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+  }
   if (overflow) {
     // the kernel kept counting: re-run with arenas / directories of the exact size
     TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
@@ -448,7 +477,7 @@ extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* 
 }
 
 #ifdef KMX_PHASE_PROF
-namespace kmx { void rows_phase_prof_dump(); }
+namespace kmx { void rows_phase_prof_dump(); void pivot_phase_prof_dump(); }
 #endif
 extern "C" void kmx_result_free(kmx_merge_result* R)
 {
@@ -457,7 +486,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
 #ifdef KMX_PHASE_PROF
-  if (!R->is_bf) kmx::rows_phase_prof_dump();
+  if (!R->is_bf) { if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
   for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); }
   ctx->dfree(R->d_meta);

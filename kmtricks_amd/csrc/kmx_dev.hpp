@@ -45,7 +45,7 @@ struct TaskDev {
   u32 item0;               // first work item of this task in the batch's flat item space
 };
 
-enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2 };
+enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2, ERR_FALLBACK = 4 };
 
 // ---- keys -------------------------------------------------------------------------------------
 template <int KW> struct Key { u64 w[KW]; };
