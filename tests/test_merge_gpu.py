@@ -127,3 +127,52 @@ def test_synthetic_bf(ctx, n, dens, smin, rmin, share, mode):
     check(ctx, lists, 1, [smin + (i % 2) for i in range(n)], rmin, share, mode, lower, lower + W - 1, bitw=2)
     if mode == orc.MODE_BFC:
         check(ctx, lists, 1, [1] * n, 1, 0, mode, lower, lower + W - 1, bitw=3)
+
+
+def test_bench_scale_partitions_properties(ctx):
+    """BASELINE configs[2] at its real shape -- 1000 samples, one of the 256 partitions of a 5 Mbp genome
+    (19.5 k shared k-mers, 3 % private per sample, recurrence-min 2) -- through the device-resident batch
+    API used by bench.py.  Checked by size-independent properties on every partition (keys strictly
+    ascending, row set == keys present in >= 2 samples, column sums == per-sample totals of the kept
+    keys, statistics) and bit-exactly against the oracle on the first one."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    N, shared, npriv = 1000, 19531, 605
+    dev = torch.device("cuda", 0)
+    parts = []
+    for seed in (7, 8):
+        lists = synth_lists(seed, N, shared, 0.969, npriv, kw=1, count_max=12)
+        recs = [lib.pack_records(k, c, 1) for k, c in lists]
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+        dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+        parts.append((lists, offs, dt))
+    torch.cuda.synchronize()
+    tasks = [dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                  soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT) for _, offs, dt in parts]
+    res = ctx.merge_dev(tasks)
+    res.wait()
+    for t, (lists, offs, dt) in enumerate(parts):
+        body = np.frombuffer(res.body(t), dtype=np.uint8)
+        rows = res.rows(t)
+        assert res.row_bytes(t) == 8 + 4 * N and len(body) == rows * (8 + 4 * N)
+        m = body.reshape(rows, 8 + 4 * N)
+        keys = m[:, :8].copy().view(np.uint64).ravel()
+        counts = m[:, 8:].copy().view(np.uint32).reshape(rows, N)
+        assert np.all(keys[1:] > keys[:-1])                                   # ascending, distinct
+        allk = np.concatenate([k.ravel() for k, _ in lists])
+        uk, mult = np.unique(allk, return_counts=True)
+        assert np.array_equal(keys, uk[mult >= 2])                            # soft-min 1: recurrence == multiplicity
+        kept = set(keys.tolist())
+        for i in (0, 1, 499, 999):                                            # column sums of a few samples
+            k_i, c_i = lists[i]
+            sel = np.isin(k_i.ravel(), keys)
+            assert int(counts[:, i].sum()) == int(c_i[sel].astype(np.uint64).sum())
+            assert int((counts[:, i] != 0).sum()) == int(sel.sum())
+        st = res.stats(t)
+        assert [int(x) for x in st[0]] == [0] * N                             # nothing is non-solid at soft-min 1
+        assert [int(x) for x in st[2]] == [len(c) for _, c in lists]
+        assert [int(x) for x in st[4]] == [int(c.astype(np.uint64).sum()) for _, c in lists]
+        if t == 0:
+            eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT)
+            assert rows == er and body.tobytes() == eb and np.array_equal(st, es)
+    res.free()
