@@ -138,3 +138,68 @@ def test_cli_errors(inputs, tmp_path):
     r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "x"), "--mode", "hash:bft:bin"],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "not supported" in r.stderr
+
+
+def _synthetic_samples(d, n_samples, genome_len, seed):
+    """SURVEY 8d generator in small: one ancestor, per-sample substitutions, 150-bp error-free reads at 6x,
+    random strand, FASTQ (half of the samples gzipped)."""
+    rng = np.random.default_rng(seed)
+    anc = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=genome_len)
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGTN")] = list(b"TGCAN")
+    reads_all, fof = [], []
+    for s in range(n_samples):
+        g = anc.copy()
+        mut = rng.random(genome_len) < 0.002
+        g[mut] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(mut.sum()))
+        n = genome_len * 6 // 150
+        starts = rng.integers(0, genome_len - 150, n)
+        reads = []
+        for i, st in enumerate(starts):
+            r = g[st:st + 150]
+            if rng.random() < 0.5: r = comp[r][::-1]
+            r = r.copy()
+            if i % 97 == 0: r[rng.integers(0, 150)] = ord("N")        # a few invalid k-mers
+            reads.append(r.tobytes().decode())
+        path = d / (f"S{s:04d}.fastq" + (".gz" if s % 2 else ""))
+        op = gzip.open if s % 2 else open
+        with op(path, "wt") as f:
+            for i, r in enumerate(reads): f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+        reads_all.append(reads); fof.append(f"S{s:04d} : {path}")
+    (d / "syn.fof").write_text("\n".join(fof) + "\n")
+    return reads_all
+
+
+@pytest.mark.parametrize("mode", ["kmer:count:bin", "hash:bf:bin"])
+def test_synthetic_multi_sample_pipeline(tmp_path, mode):
+    """BASELINE configs[1]/[2] in small (12 samples x 120 kbp, 8 static partitions, hard-min 2,
+    recurrence-min 2): FASTQ(.gz) -> `kmx pipeline` -> every matrix body and merge_info bit-exact
+    against the oracle run stage by stage on the same reads."""
+    NS, GL, PP = 12, 120_000, 8
+    reads = _synthetic_samples(tmp_path, NS, GL, 11)
+    out = tmp_path / "run"
+    args = [KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out), "--kmer-size", "31", "--hard-min", "2",
+            "--nb-partitions", str(PP), "--static-repart", "--mode", mode, "--recurrence-min", "2", "--bloom-size", "2000000"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lut = orc.minimizer_lut(10); rep = orc.repart_static(10, PP)
+    assert np.frombuffer(open(out / "repartition_gatb" / "repartition.minimRepart", "rb").read()[12:12 + 2 * 4 ** 10], np.uint16).tolist() == rep.tolist()
+    sk = [orc.superk_partition(rs, 31, 10, lut, rep, PP) for rs in reads]
+    W = ((2000000 + PP - 1) // PP + 63) // 64 * 64
+    total_rows = 0
+    for p in range(PP):
+        if mode.startswith("kmer"):
+            lists = [tuple(x if i else x.reshape(-1) for i, x in enumerate(orc.count_kmer(s[p][0], 31, 2))) for s in sk]
+            body, rows, stats = orc.merge_matrix(lists, 1, [1] * NS, 2, 0, orc.MODE_COUNT)
+            raw = open(out / "matrices" / f"matrix_{p}.count", "rb").read()
+            assert raw[45:] == body
+            total_rows += rows
+        else:
+            lists = [orc.count_hash(s[p][0], 31, W, p, 2) for s in sk]
+            body, rows, stats = orc.merge_matrix(lists, 1, [1] * NS, 2, 0, orc.MODE_BF, W * p, W * (p + 1) - 1)
+            raw = open(out / "matrices" / f"matrix_{p}.cmbf", "rb").read()
+            assert raw[49:] == body
+            total_rows += rows
+        mi = [l.split("\t") for l in open(out / "merge_infos" / f"partition{p}.merge_info").read().splitlines()]
+        for rix in range(6):
+            assert [int(x) for x in mi[rix][1:1 + NS]] == [int(x) for x in stats[rix]]
+    assert total_rows > 50_000
