@@ -229,7 +229,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     max_n = std::max(max_n, H.N); max_c = std::max(max_c, H.c);
   }
   R->n_items = n_items; R->max_n = max_n; R->max_c = max_c;
-  R->grid = std::min(n_items, slots);
+  R->grid = std::min(n_items, is_bf ? slots : (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)kw));
   {
     // k_merge_rows is the production kernel.  KMX_MERGE_KERNEL=pivot selects the experimental
     // pivot-tiled kernel (merge_pivot.hip; 64-bit keys, no share-min, <= 1024 lists) for A/B runs; tasks
@@ -302,9 +302,16 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     D.item0 = it;
     for (u32 j = 0; j < H.c; j++) items[it++] = make_uint2(t, j);
   }
-  KMX_HIP(ctx, hipMemcpyAsync(R->d_meta, R->h_meta, upload_bytes, hipMemcpyHostToDevice, ctx->stream));
+  auto drop = [&]() {   // hand every block back to the pool on a failed launch
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& H : R->tasks) ctx->dfree(H.d_out);
+    ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
+    if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
+  };
+  hipError_t he = hipMemcpyAsync(R->d_meta, R->h_meta, upload_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (he != hipSuccess) { drop(); return ctx->fail(KMX_E_HIP, std::string("meta upload: ") + hipGetErrorString(he)); }
   int rc = launch_batch(R.get(), true);
-  if (rc != KMX_OK) return rc;
+  if (rc != KMX_OK) { drop(); return rc; }
   *out = R.release();
   return KMX_OK;
 }
@@ -344,7 +351,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     // the pivot did not cover some task's lists (a pivot gap overflowed the tile buffer): run the
     // batch again with the general kernel.  Bounds stay valid; statistics and row space restart.
     R->use_pivot = false;
-    R->grid = std::min(R->n_items, (u32)ctx->n_cu * 2);
+    R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
     for (auto& H : R->tasks) {
       KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
       KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 256, ctx->stream));

@@ -11,6 +11,7 @@ namespace kmx {
 // kernel launchers (defined next to their kernels)
 int rows_lds_bytes(int kw, u32 n_lists);
 int rows_cap();
+int rows_wgs_per_cu(int kw);
 u32 rows_chunk_rows(u32 row_bytes);
 u32 rows_image_bytes(int kw);
 hipError_t launch_range_bounds(int kw, const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);

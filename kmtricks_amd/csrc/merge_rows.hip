@@ -31,11 +31,15 @@ namespace kmx {
 #ifndef KMX_ROWS_TPB
 #define KMX_ROWS_TPB 1024
 #endif
+#ifndef KMX_ROWS_CAP
+#define KMX_ROWS_CAP 4096
+#endif
 constexpr int TPB = KMX_ROWS_TPB;  // 8 or 16 waves
-constexpr int M = 4096 / TPB;      // record slots per thread
-constexpr int CAP = TPB * M;       // 4096 record slots per tile
+constexpr int CAP = KMX_ROWS_CAP;  // record slots per tile
+constexpr int M = CAP / TPB;       // record slots per thread
 constexpr int TS = 2 * CAP;        // hash set entries (load factor <= 0.5)
-constexpr int KLBYTES = 12288;     // kept keys: u16 table slots [CAP] (8 KiB) + fast-path key copies (4 KiB)
+constexpr int KLBYTES = CAP * 2 + 4096;   // kept keys: u16 table slots [CAP] + fast-path key copies (4 KiB)
+constexpr int WGS_PER_CU = (TPB <= 512 && (CAP * 8 + TS * 4 + KLBYTES + 384) * 2 <= 160 * 1024) ? 2 : 1;   // KW = 1: LDS and 128-VGPR budget
 constexpr int NWAVE = TPB / 64;
 
 // LDS image of the row batch being assembled: aliases the staged keys
@@ -109,7 +113,7 @@ __device__ __noinline__ u64 probe_slow(u32* tab, const Key<KW>* keysL, Key<KW> k
 // lives in registers.  The body is written for a low instruction count per record: the kernel is
 // issue-bound long before it is LDS- or HBM-bound.
 template <int KW, int MODE>
-__global__ __launch_bounds__(TPB, TPB / 256)
+__global__ __launch_bounds__(TPB, (KW == 1 ? WGS_PER_CU : 1) * TPB / 256)
 void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ items, u32 n_items, u32* ticket)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -121,7 +125,7 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
   unsigned char* const img = smem;                                  // ... later the row image (aliased)
   u32* tab = reinterpret_cast<u32*>(smem + KEYS_BYTES);             // hash set, all zero between tiles
   u16* dslot = reinterpret_cast<u16*>(smem + KEYS_BYTES + TS * 4);  // table slots of the kept keys (8 KiB)
-  Key<KW>* dkeys = reinterpret_cast<Key<KW>*>(smem + KEYS_BYTES + TS * 4 + 8192);   // their keys, fast path (4 KiB)
+  Key<KW>* dkeys = reinterpret_cast<Key<KW>*>(smem + KEYS_BYTES + TS * 4 + CAP * 2);   // their keys, fast path (4 KiB)
   unsigned char* misc = smem + KEYS_BYTES + TS * 4 + KLBYTES;
   Key<KW>* wmin = reinterpret_cast<Key<KW>*>(misc);                 // NWAVE keys (<= 256 B)
   u32* wany = reinterpret_cast<u32*>(misc + 256);                   // NWAVE flags (64 B)
@@ -486,6 +490,7 @@ namespace kmx {
 
 int rows_lds_bytes(int kw, u32) { return rows_fixed_bytes(kw) + 384; }
 int rows_cap() { return CAP; }
+int rows_wgs_per_cu(int kw) { return kw == 1 ? WGS_PER_CU : 1; }
 u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, 262144u / row_bytes); }
 u32 rows_image_bytes(int kw) { return (u32)rows_emit_bytes(kw); }
 #ifdef KMX_PHASE_PROF
