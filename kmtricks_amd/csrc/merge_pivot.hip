@@ -33,7 +33,7 @@ constexpr int PV_OVCAP = 2048;      // overflow records per tile
 constexpr int PV_OT = 2 * PV_OVCAP; // overflow hash set entries
 constexpr int PV_G = 8;             // adjacent lanes per list: one wave load covers 8 lists x 96 contiguous bytes
 constexpr int PV_LPP = PV_TPB / PV_G;   // lists per pass (128)
-constexpr int PV_PB = 4;            // passes whose records are in flight together (8 loads per lane)
+constexpr int PV_PB = 2;            // passes whose records are in flight together (8 loads per lane)
 constexpr int PV_U = 3;             // records per lane and pass in the prefetch batch (24 per list: the tail loop is rare)
 
 template <int KW> struct OvRec { Key<KW> key; u32 cnt; u32 list; };
@@ -165,25 +165,24 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 
       PVPH(1);
       // ---- scan: every list streams its records of the tile's key range ----
-      // Exact row lookup by binary search (slow path: drifted or out-of-window records, tail loop).
-      auto row_slow = [&](const Key<KW>& k, bool& found) -> u32 {
-        u32 lo = 0, n = rte;
+      // The tile's pivot keys sit in registers (uniform values): a record's row is the number of pivot
+      // keys below its key, found by brute-force compares -- no memory access, no dependent chain.
+      Key<KW> pkr[PV_RTMAX];
 #pragma unroll
-        for (int s2 = 0; s2 < 5; s2++) {   // lower_bound among <= 16 pivot keys: 5 fixed steps
-          const u32 half = n >> 1;
-          if (n && key_less<KW>(pk[lo + half], k)) { lo += half + 1; n -= half + 1; } else n = half;
-        }
-        found = lo < rte && key_eq<KW>(pk[lo], k);
-        return lo;
+      for (int j = 0; j < PV_RTMAX; j++) pkr[j] = j < (int)rte ? pk[j] : key_inf<KW>();
+      // exact lookup for the (rare) tail loop
+      auto row_of = [&](const Key<KW>& k, bool& found) -> u32 {
+        u32 rank = 0, eq = 0;
+#pragma unroll
+        for (int j = 0; j < PV_RTMAX; j++) { rank += key_less<KW>(pkr[j], k) ? 1u : 0u; eq += key_eq<KW>(pkr[j], k) ? 1u : 0u; }
+        found = eq != 0;
+        return rank;
       };
-      // a record that is a pivot key of the tile goes straight into row `row` of the image
       auto deposit = [&](u32 row, u32 c, u32 li) {
-        if (prec[row] < sat) atomicAdd(&prec[row], 1u);
         if (MODE == 0) reinterpret_cast<u32*>(img + row * row_bytes + KW * 8)[li] = c;
         else { const u32 ob = row * row_bytes + KW * 8 + (li >> 3);
                atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u))); }
       };
-      const int rlast = (int)rte - 1;
       for (u32 p0 = 0; p0 < npass; p0 += PV_PB) {
         // prefetch batch: PV_U records per lane for PV_PB passes before anything is processed
         Key<KW> kk[PV_PB][PV_U]; u32 cc[PV_PB][PV_U]; u32 c0[PV_PB], ee[PV_PB], sm[PV_PB];
@@ -196,8 +195,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           sm[p] = on ? T.soft_min[li] : 0;
           gu32* base = (gu32*)(uintptr_t)(on ? lt_base[li] : 0);
 #pragma unroll
-          for (int u = 0; u < PV_U; u++) {   // lane r holds PV_U CONSECUTIVE records: 8 lanes = 24 records = 288 contiguous bytes
-            const u32 ix = c0[p] + r * PV_U + u;
+          for (int u = 0; u < PV_U; u++) {
+            const u32 ix = c0[p] + r + u * PV_G;
             kk[p][u] = key_inf<KW>(); cc[p][u] = 0;
             if (ix < ee[p]) { gu32* q = base + (u64)ix * RB4; kk[p][u] = gload_key<KW>(q); cc[p][u] = q[2 * KW]; }
           }
@@ -205,42 +204,25 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 #ifdef KMX_PHASE_PROF
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PVPH(7);
 #endif
-        // A lane's PV_U records are consecutive, so are their rows: the first one is located by its
-        // position in the tile (+-3: the lists drift against the pivot by their private / missing keys,
-        // exact search when the window does not bracket it), the others by walking on from there.
         u32 ovm = 0;                     // bit p*PV_U+u: overflow record
         u32 nx[PV_PB], tn[PV_PB]; u64 tt[PV_PB];
 #pragma unroll
         for (int p = 0; p < PV_PB; p++) {
           nx[p] = c0[p]; tn[p] = 0; tt[p] = 0;
           const u32 li = (p0 + p) * PV_LPP + lg;
-          u32 j;
-          {
-            const Key<KW> k = kk[p][0];
-            const int g0 = (int)(r * PV_U);
-            const int jl = min(max(g0 - 3, 0), max(rlast, 0));
-            // lower_bound inside the window [jl, jl+7): number of window keys < k
-            u32 nless = 0; bool inwin = rte != 0;
-#pragma unroll
-            for (int d = 0; d < 7; d++) { const int jj = min(jl + d, max(rlast, 0)); if (jl + d <= rlast && key_less<KW>(pk[jj], k)) nless++; }
-            j = (u32)jl + nless;
-            // conclusive unless the key lies below the window (and the window does not start the tile)
-            // or above it (and the window does not end the tile)
-            const bool below = rte != 0 && nless == 0 && jl > 0 && key_less<KW>(k, pk[jl]);
-            const bool above = nless == 7 && jl + 7 <= rlast;
-            if (inwin && (below || above)) { bool f; j = row_slow(k, f); }
-          }
 #pragma unroll
           for (int u = 0; u < PV_U; u++) {
-            const u32 ix = c0[p] + r * PV_U + u;
+            const u32 ix = c0[p] + r + u * PV_G;
             const Key<KW> k = kk[p][u];
             const bool valid = ix < ee[p] && (open_end || key_less<KW>(k, khi));
+            u32 rank = 0, eq = 0;
+#pragma unroll
+            for (int j = 0; j < PV_RTMAX; j++) { rank += key_less<KW>(pkr[j], k) ? 1u : 0u; eq += key_eq<KW>(pkr[j], k) ? 1u : 0u; }
+            const bool solid = cc[p][u] >= sm[p];
             if (valid) {
               nx[p] = ix + 1;
-              const bool solid = cc[p][u] >= sm[p];
               if (solid) tt[p] += cc[p][u]; else tn[p]++;
-              while (j < rte && key_less<KW>(pk[j], k)) j++;          // usually 0 or 1 step
-              if (j < rte && key_eq<KW>(pk[j], k)) { if (solid) deposit(j, cc[p][u], li); }
+              if (eq) { if (solid) deposit(rank, cc[p][u], li); }
               else ovm |= 1u << (p * PV_U + u);
             }
           }
@@ -249,9 +231,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 #pragma unroll
         for (int p = 0; p < PV_PB; p++) {
           const u32 li = (p0 + p) * PV_LPP + lg;
-          // the whole prefetched block of the list was consumed (its last record belongs to lane 7):
-          bool more = __shfl(nx[p], (lane & ~(PV_G - 1)) + PV_G - 1) == c0[p] + PV_G * PV_U;
-          for (u32 i0 = c0[p] + PV_G * PV_U + r; __any(more && i0 < ee[p]); i0 += PV_G) {
+          bool more = nx[p] == c0[p] + r + (PV_U - 1) * PV_G + 1;       // my last prefetched record was consumed
+          for (u32 i0 = c0[p] + r + PV_U * PV_G; __any(more && i0 < ee[p]); i0 += PV_G) {
             if (more && i0 < ee[p]) {
               gu32* q = (gu32*)(uintptr_t)lt_base[li] + (u64)i0 * RB4;
               const Key<KW> k = gload_key<KW>(q); const u32 c = q[2 * KW];
@@ -260,7 +241,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
                 nx[p] = i0 + 1;
                 const bool solid = c >= sm[p];
                 if (solid) tt[p] += c; else tn[p]++;
-                bool found; const u32 row = row_slow(k, found);
+                bool found; const u32 row = row_of(k, found);
                 if (found) { if (solid) deposit(row, c, li); }
                 else { const u32 pos = atomicAdd(&sh[1], 1u); if (pos < (u32)PV_OVCAP) { OvRec<KW> o; o.key = k; o.cnt = c; o.list = li; ov[pos] = o; } }
               }
@@ -300,6 +281,21 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 #ifdef KMX_PHASE_PROF
         PVPH(8);
 #endif
+      }
+      // recurrence of the pivot rows = number of lists that deposited a (solid) count: wave j counts row j
+      pv_lds_barrier();
+      {
+        const u32 wv = tid >> 6;
+        for (u32 j = wv; j < rte; j += PV_TPB / 64) {
+          u32 nz = 0;
+          if (MODE == 0) { const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);
+                           for (u32 t = lane; t < N; t += 64) nz += rowc[t] != 0 ? 1u : 0u; }
+          else { const u8* rowb = img + j * row_bytes + KW * 8;
+                 for (u32 t = lane; t < (N + 7) / 8; t += 64) nz += __popc((u32)rowb[t]); }
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) nz += __shfl_xor(nz, off);
+          if (lane == 0) prec[j] = nz;
+        }
       }
       pv_lds_barrier();
       PVPH(2);
