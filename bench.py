@@ -111,18 +111,27 @@ def main():
     kernel_ms, algo_bytes, rows_out = [], 0, 0
 
     def run(n, record):
-        """n steps = n kmx_merge_dev batches queued back to back on the engine's stream (the host prepares
-        batch i+1 while the GPU merges batch i, as the pipeline driver does with consecutive partition
-        batches); every batch is waited for and checked before the clock stops."""
+        """n steps = n kmx_merge_dev batches; batch i+1 is submitted before batch i is waited for (the host
+        prepares the next batch while the GPU merges the current one, as the pipeline driver does with
+        consecutive partition batches); every batch is waited for before the clock stops."""
         nonlocal algo_bytes, rows_out
-        inflight = [ctx.merge_dev(tasks) for _ in range(n)]
-        for res in inflight:
+
+        def finish(res):
             res.wait()
             if record:
                 kernel_ms.append(res.kernel_ms())
                 algo_bytes = sum(res.algo_bytes(t) for t in range(P))
                 rows_out = sum(res.rows(t) for t in range(P))
             res.free()
+
+        prev = None                      # two batches in flight (double buffering: no new device blocks)
+        for _ in range(n):
+            cur = ctx.merge_dev(tasks)
+            if prev is not None:
+                finish(prev)
+            prev = cur
+        if prev is not None:
+            finish(prev)
 
     run(a.warmup, False)
     barrier()

@@ -118,7 +118,7 @@ struct kmx_merge_result {
   std::vector<TaskHost> tasks;
   u8* d_meta = nullptr; size_t meta_bytes = 0;
   u8* h_meta = nullptr;              // pinned staging image of the meta blob
-  size_t o_tasks = 0, o_items = 0, o_ticket = 0;
+  size_t o_tasks = 0, o_items = 0, o_ticket = 0, o_ctrl0 = 0;
   u32 n_items = 0, grid = 0, max_n = 0, max_c = 0;
   int bf_lds = 0;
   bool is_bf = false, waited = false;
@@ -251,12 +251,14 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->o_tasks = off; off = align_up(off + sizeof(TaskDev) * n_tasks, 256);
   R->o_items = off; off = align_up(off + sizeof(uint2) * n_items, 256);
   R->o_ticket = off; off += 256;
+  R->o_ctrl0 = off;                       // control words of all tasks, contiguous: one D2H copy reads them all
+  for (auto& H : R->tasks) { H.o_ctrl = off; off += 64; }
+  off = align_up(off, 256);
   for (auto& H : R->tasks) {
     H.o_recs = off; off = align_up(off + 8ull * H.N, 256);
     H.o_len = off; off = align_up(off + 4ull * H.N, 256);
     H.o_smin = off; off = align_up(off + 4ull * H.N, 256);
     H.o_stats = off; off = align_up(off + 8ull * 6 * H.N, 256);
-    H.o_ctrl = off; off += 256;
   }
   const size_t upload_bytes = off;            // everything above is written by the host
   for (auto& H : R->tasks) {
@@ -321,10 +323,13 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
   kmx_ctx* ctx = R->ctx;
   *overflow = false;
   if (fallback) *fallback = false;
-  for (auto& H : R->tasks) {
-    u64 ctrl[4];
-    KMX_HIP(ctx, hipMemcpyAsync(ctrl, R->d_meta + H.o_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, ctx->stream));
-    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t nt = R->tasks.size();
+  u64* hc = reinterpret_cast<u64*>(R->h_meta + R->o_ctrl0);      // pinned staging (the upload image is no longer needed)
+  KMX_HIP(ctx, hipMemcpyAsync(hc, R->d_meta + R->o_ctrl0, nt * 64, hipMemcpyDeviceToHost, ctx->stream));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t t = 0; t < nt; t++) {
+    TaskHost& H = R->tasks[t];
+    const u64* ctrl = hc + t * 8;
     H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
     if ((ctrl[2] & ERR_FALLBACK) && fallback) *fallback = true;
@@ -354,7 +359,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
     for (auto& H : R->tasks) {
       KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
-      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 256, ctx->stream));
+      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 64, ctx->stream));
     }
     rc = launch_batch(R, false);
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
@@ -386,7 +391,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     // reset stats + ctrl, upload patched descriptors, run the merge again (bounds are still valid)
     for (auto& H : R->tasks) {
       KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
-      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 256, ctx->stream));
+      KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 64, ctx->stream));
     }
     KMX_HIP(ctx, hipMemcpyAsync(R->d_meta + R->o_tasks, R->h_meta + R->o_tasks, sizeof(TaskDev) * R->tasks.size(),
                                 hipMemcpyHostToDevice, ctx->stream));
