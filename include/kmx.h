@@ -141,6 +141,14 @@ int kmx_count_hash(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t k
                    uint64_t window, uint64_t partition, uint32_t hard_min,
                    uint64_t** hashes, uint32_t** counts, uint64_t* n_out);
 
+/* Batched form (one call per sample instead of one per (sample, partition)): superk[p] / len[p] are the
+ * n_parts partition streams of one sample; hash_mode != 0 selects window hashes with
+ * partition_ids[p] as the window index of stream p.  keys / counts / n_out are arrays of n_parts
+ * entries; every keys[p] and counts[p] is released with kmx_free. */
+int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* const* superk, const uint64_t* len,
+                    uint32_t kmer_size, int hash_mode, uint64_t window, const uint64_t* partition_ids,
+                    uint32_t hard_min, uint64_t** keys, uint32_t** counts, uint64_t* n_out);
+
 /* -------------------------------------------------------------- transpose */
 
 /* out[c][r] = in[r][c], bits LSB-first in each byte; nrows, ncols multiples

@@ -10,11 +10,18 @@
 // rocPRIM's (plain library ops); the decode + hash kernel is hand-written.
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <atomic>
+#include <thread>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <cstdio>
+#include <cstdlib>
 #include "kmx_host.hpp"
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace kmx {
 
@@ -99,6 +106,59 @@ __global__ void k_superk_decode(const u8* __restrict__ recs, const u32* __restri
         u64 w[2] = {(u64)c, (u64)(c >> 64)};
         reinterpret_cast<u64*>(out)[o + j] = xxh64_words(w, 2) % win + win * part;
       } else reinterpret_cast<u128*>(out)[o + j] = c;
+      if (j + 1 >= n) break;
+      const int d = k + (int)j;
+      const u128 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
+      fwd = ((fwd << 2) | nt) & mask;
+      rev = (rev >> 2) | ((nt ^ (u128)2) << (2 * (k - 1)));
+    }
+  }
+}
+
+// batch variant: records of several partition streams; rec_part gives each record's partition
+template <int KW, int HASH>
+__global__ void k_superk_decode_batch(const u8* __restrict__ recs, const u32* __restrict__ rec_off,
+                                      const u32* __restrict__ kmer_off, const u16* __restrict__ rec_part,
+                                      const u64* __restrict__ part_ids, u32 n_recs, int k, u64 win, void* __restrict__ out,
+                                      u16* __restrict__ out_part)
+{
+  const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_recs) return;
+  const u8* p = recs + rec_off[r];
+  const u32 n = p[0];
+  p++;
+  const u64 o = kmer_off[r];
+  const u16 pidx = rec_part[r];
+  const u64 part = HASH ? part_ids[pidx] : 0;
+  for (u32 j = 0; j < n; j++) out_part[o + j] = pidx;
+  if (KW == 1) {
+    const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    u64 fwd = 0;
+    const int nbytes = (k + 3) / 4;
+    for (int b = 0; b < nbytes; b++) fwd |= (u64)p[b] << (8 * b);
+    fwd &= mask;
+    u64 rev = revcomp64(fwd, k);
+    for (u32 j = 0;; j++) {
+      const u64 c = fwd < rev ? fwd : rev;
+      if (HASH) reinterpret_cast<u64*>(out)[o + j] = xxh64_words(&c, 1) % win + win * part;
+      else reinterpret_cast<u64*>(out)[o + j] = c;
+      if (j + 1 >= n) break;
+      const int d = k + (int)j;
+      const u64 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
+      fwd = ((fwd << 2) | nt) & mask;
+      rev = (rev >> 2) | ((nt ^ 2ULL) << (2 * (k - 1)));
+    }
+  } else {
+    const u128 mask = (k == 64) ? ~(u128)0 : ((((u128)1) << (2 * k)) - 1);
+    u128 fwd = 0;
+    const int nbytes = (k + 3) / 4;
+    for (int b = 0; b < nbytes; b++) fwd |= (u128)p[b] << (8 * b);
+    fwd &= mask;
+    u128 rev = revcomp128(fwd, k);
+    for (u32 j = 0;; j++) {
+      const u128 c = fwd < rev ? fwd : rev;
+      if (HASH) { u64 w[2] = {(u64)c, (u64)(c >> 64)}; reinterpret_cast<u64*>(out)[o + j] = xxh64_words(w, 2) % win + win * part; }
+      else reinterpret_cast<u128*>(out)[o + j] = c;
       if (j + 1 >= n) break;
       const int d = k + (int)j;
       const u128 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
@@ -245,4 +305,254 @@ extern "C" int kmx_count_hash(kmx_ctx* ctx, const uint8_t* superk, uint64_t len,
                               uint64_t partition, uint32_t hard_min, uint64_t** hashes, uint32_t** counts, uint64_t* n_out)
 {
   return count_impl(ctx, superk, len, kmer_size, 1, window, partition, hard_min, (void**)hashes, counts, n_out);
+}
+
+
+// ---- batched count: every partition stream of one sample in one call ---------------------------------
+struct StageClock {     // KMX_TRACE=1: per-stage wall times of the batched count on stderr
+  bool on; hipStream_t st; std::chrono::steady_clock::time_point t0; std::string log;
+  StageClock(hipStream_t s) : on(getenv("KMX_TRACE") != nullptr), st(s), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    (void)hipStreamSynchronize(st);
+    auto t1 = std::chrono::steady_clock::now();
+    char b[96]; snprintf(b, sizeof b, " %s=%.2fms", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    log += b; t0 = t1;
+  }
+  ~StageClock() { if (on) fprintf(stderr, "[kmx count_batch]%s\n", log.c_str()); }
+};
+
+__global__ void k_run_part_flags(const u32* __restrict__ run_start, const u32* __restrict__ run_cnt, u32 n_runs,
+                                 const u16* __restrict__ sorted_part, u32 hard_min, u16* __restrict__ run_part, u8* __restrict__ flags)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_runs) return;
+  run_part[i] = sorted_part[run_start[i]];      // equal keys always come from one partition
+  flags[i] = run_cnt[i] >= hard_min ? 1 : 0;
+}
+
+template <typename KeyT>
+__global__ void k_gather_runs(const u32* __restrict__ idx, u32 n, const KeyT* __restrict__ uniq, const u32* __restrict__ cnt,
+                              KeyT* __restrict__ out_k, u32* __restrict__ out_c)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 j = idx[i];
+  out_k[i] = uniq[j];
+  out_c[i] = cnt[j];
+}
+
+__global__ void k_gather_u16(const u32* __restrict__ idx, u32 n, const u16* __restrict__ in, u16* __restrict__ out)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
+}
+
+// first index of every partition in the partition-sorted run list (n_parts + 1 entries)
+__global__ void k_part_bounds(const u16* __restrict__ part_sorted, u32 n, u32 n_parts, u32* __restrict__ bounds)
+{
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_parts) return;
+  u32 lo = 0, hi = n;                 // first i with part_sorted[i] >= p
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (part_sorted[mid] < p) lo = mid + 1; else hi = mid; }
+  bounds[p] = lo;
+}
+
+// ---- batched count: every partition stream of one sample in one call ---------------------------------
+// One global radix sort of (key, partition) pairs, one run-length pass, then only the kept runs are
+// regrouped by partition (stable, so each partition's keys stay ascending).
+template <typename KeyT>
+static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kpart, u32 total, u32 n_parts, unsigned key_bits, u32 hard_min,
+                          uint64_t** keys, uint32_t** counts, uint64_t* n_out)
+{
+  hipStream_t st = ctx->stream;
+  KeyT* d_sorted = (KeyT*)ctx->dalloc((size_t)total * sizeof(KeyT));
+  u16* d_spart = (u16*)ctx->dalloc((size_t)total * 2);
+  KeyT* d_uniq = (KeyT*)ctx->dalloc((size_t)total * sizeof(KeyT));
+  u32* d_cnt = (u32*)ctx->dalloc((size_t)total * 4);
+  u32* d_runs = (u32*)ctx->dalloc(256);
+  std::vector<void*> blocks = {d_sorted, d_spart, d_uniq, d_cnt, d_runs};
+  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
+  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count batch: device allocation failed"); }
+  auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+  size_t t1 = 0, t2 = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, t1, d_keys, d_sorted, d_kpart, d_spart, (size_t)total, 0, key_bits, st);
+  if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, t2, d_sorted, total, d_uniq, d_cnt, d_runs, st);
+  if (e != hipSuccess) return fail(e, "rocPRIM temp sizing");
+  size_t tmax = std::max(t1, t2) + 256;
+  void* d_tmp = ctx->dalloc(tmax); blocks.push_back(d_tmp);
+  if (!d_tmp) { release(); return ctx->fail(KMX_E_NOMEM, "count batch: device allocation failed"); }
+  size_t t = tmax;
+  if ((e = rocprim::radix_sort_pairs(d_tmp, t, d_keys, d_sorted, d_kpart, d_spart, (size_t)total, 0, key_bits, st)) != hipSuccess) return fail(e, "radix_sort_pairs");
+  clk.mark("sort");
+  t = tmax;
+  if ((e = rocprim::run_length_encode(d_tmp, t, d_sorted, total, d_uniq, d_cnt, d_runs, st)) != hipSuccess) return fail(e, "run_length_encode");
+  u32 runs = 0;
+  if ((e = hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  clk.mark("rle");
+  // per run: partition + keep flag; kept run indices regrouped by partition
+  u32* d_start = (u32*)ctx->dalloc(((size_t)runs + 1) * 4);
+  u16* d_rpart = (u16*)ctx->dalloc((size_t)runs * 2 + 2), *d_kp = (u16*)ctx->dalloc((size_t)runs * 2 + 2), *d_kp2 = (u16*)ctx->dalloc((size_t)runs * 2 + 2);
+  u8* d_flags = (u8*)ctx->dalloc((size_t)runs + 1);
+  u32* d_idx = (u32*)ctx->dalloc(((size_t)runs + 1) * 4), *d_idx2 = (u32*)ctx->dalloc(((size_t)runs + 1) * 4);
+  u32* d_bounds = (u32*)ctx->dalloc(((size_t)n_parts + 1) * 4);
+  for (void* b : {(void*)d_start, (void*)d_rpart, (void*)d_kp, (void*)d_kp2, (void*)d_flags, (void*)d_idx, (void*)d_idx2, (void*)d_bounds}) blocks.push_back(b);
+  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count batch: device allocation failed"); }
+  unsigned pbits = 1; while ((1u << pbits) < n_parts) pbits++;
+  size_t t3 = 0, t4 = 0, t5 = 0;
+  e = rocprim::exclusive_scan(nullptr, t3, d_cnt, d_start, 0u, (size_t)runs, rocprim::plus<u32>(), st);
+  if (e == hipSuccess) e = rocprim::select(nullptr, t4, rocprim::counting_iterator<u32>(0), d_flags, d_idx, d_runs, (size_t)runs, st);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t5, d_kp, d_kp2, d_idx, d_idx2, (size_t)runs, 0, pbits, st);
+  if (e != hipSuccess) return fail(e, "rocPRIM temp sizing");
+  if (std::max(t3, std::max(t4, t5)) > tmax) {
+    tmax = std::max(t3, std::max(t4, t5)) + 256;
+    void* nt = ctx->dalloc(tmax); blocks.push_back(nt);
+    if (!nt) { release(); return ctx->fail(KMX_E_NOMEM, "count batch: device allocation failed"); }
+    d_tmp = nt;
+  }
+  u32 kept = 0;
+  if (runs) {
+    t = tmax; if ((e = rocprim::exclusive_scan(d_tmp, t, d_cnt, d_start, 0u, (size_t)runs, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan");
+    hipLaunchKernelGGL(k_run_part_flags, dim3((runs + 255) / 256), dim3(256), 0, st, d_start, d_cnt, runs, d_spart, hard_min, d_rpart, d_flags);
+    t = tmax; if ((e = rocprim::select(d_tmp, t, rocprim::counting_iterator<u32>(0), d_flags, d_idx, d_runs, (size_t)runs, st)) != hipSuccess) return fail(e, "select");
+    if ((e = hipMemcpyAsync(&kept, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  }
+  std::vector<u32> bounds(n_parts + 1, 0);
+  KeyT* d_ok = d_sorted; u32* d_oc = (u32*)d_keys;      // both arrays are dead by now: reuse them for the output
+  if (kept) {
+    hipLaunchKernelGGL(k_gather_u16, dim3((kept + 255) / 256), dim3(256), 0, st, d_idx, kept, d_rpart, d_kp);
+    t = tmax; if ((e = rocprim::radix_sort_pairs(d_tmp, t, d_kp, d_kp2, d_idx, d_idx2, (size_t)kept, 0, pbits, st)) != hipSuccess) return fail(e, "regroup");
+    hipLaunchKernelGGL((k_gather_runs<KeyT>), dim3((kept + 255) / 256), dim3(256), 0, st, d_idx2, kept, d_uniq, d_cnt, d_ok, d_oc);
+    hipLaunchKernelGGL(k_part_bounds, dim3((n_parts + 256) / 256), dim3(256), 0, st, d_kp2, kept, n_parts, d_bounds);
+    if ((e = hipMemcpyAsync(bounds.data(), d_bounds, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  }
+  clk.mark("regroup");
+  // one D2H into pinned staging, then the per-partition output arrays are filled by a few host threads
+  // (first-touch page faults of fresh allocations dominate a single-threaded copy)
+  KeyT* h_k = kept ? (KeyT*)ctx->halloc((size_t)kept * sizeof(KeyT)) : nullptr;
+  u32* h_c = kept ? (u32*)ctx->halloc((size_t)kept * 4) : nullptr;
+  auto hrel = [&]() { ctx->hfree(h_k); ctx->hfree(h_c); };
+  if (kept && (!h_k || !h_c)) { hrel(); release(); return ctx->fail(KMX_E_NOMEM, "count batch: host allocation failed"); }
+  if (kept) {
+    if ((e = hipMemcpyAsync(h_k, d_ok, (size_t)kept * sizeof(KeyT), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(h_c, d_oc, (size_t)kept * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (e = hipStreamSynchronize(st)) != hipSuccess) { hrel(); return fail(e, "download"); }
+  }
+  std::atomic<u32> next{0}; std::atomic<int> oom{0};
+  auto fill = [&]() {
+    for (u32 p; (p = next++) < n_parts;) {
+      const size_t n = bounds[p + 1] - bounds[p];
+      keys[p] = (uint64_t*)malloc(n ? n * sizeof(KeyT) : 8);
+      counts[p] = (uint32_t*)malloc(n ? n * 4 : 4);
+      if (!keys[p] || !counts[p]) { oom = 1; continue; }
+      n_out[p] = n;
+      if (n) { memcpy(keys[p], h_k + bounds[p], n * sizeof(KeyT)); memcpy(counts[p], h_c + bounds[p], n * 4); }
+    }
+  };
+  {
+    const unsigned nthr = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), n_parts}));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthr; t++) th.emplace_back(fill);
+    fill();
+    for (auto& x : th) x.join();
+  }
+  hrel();
+  if (oom) { release(); return ctx->fail(KMX_E_NOMEM, "count batch: host allocation failed"); }
+  clk.mark("download");
+  release();
+  return KMX_OK;
+}
+
+extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* const* superk, const uint64_t* len,
+                               uint32_t k, int hash_mode, uint64_t window, const uint64_t* partition_ids, uint32_t hard_min,
+                               uint64_t** keys, uint32_t** counts, uint64_t* n_out)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!n_parts || !superk || !len || !keys || !counts || !n_out) return ctx->fail(KMX_E_INVAL, "kmx_count_batch: null argument");
+  if (k < 8 || k > 63) return ctx->fail(KMX_E_UNSUPPORTED, "k-mer size outside 8..63");
+  if (hash_mode && (window == 0 || !partition_ids)) return ctx->fail(KMX_E_INVAL, "hash mode needs window and partition ids");
+  if (n_parts > 65535) return ctx->fail(KMX_E_UNSUPPORTED, "more than 65535 partitions in one batch");
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  for (u32 p = 0; p < n_parts; p++) { keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
+  const int kw = (k + 31) / 32;
+  // host: record offsets of every stream (a record's length depends on its first byte only).  Streams are
+  // independent, so they are walked by a few threads: once to size the tables, once to fill them.
+  StageClock clk(ctx->stream);
+  std::vector<u64> n_rec(n_parts, 0), n_km(n_parts, 0);
+  std::atomic<u32> next{0}; std::atomic<int> bad{0};
+  const unsigned nthr = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), n_parts}));
+  auto run_threads = [&](auto&& fn) {
+    next = 0;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthr; t++) th.emplace_back([&]() { for (u32 p; (p = next++) < n_parts;) fn(p); });
+    for (u32 p; (p = next++) < n_parts;) fn(p);
+    for (auto& x : th) x.join();
+  };
+  for (u32 p = 0; p < n_parts; p++) if (len[p] && !superk[p]) return ctx->fail(KMX_E_INVAL, "null stream");
+  run_threads([&](u32 p) {
+    const uint8_t* s = superk[p]; u64 pos = 0, nr = 0, nk = 0;
+    while (pos < len[p]) {
+      const u32 n = s[pos];
+      const u64 nb = ((u64)k + n - 1 + 3) / 4;
+      if (n == 0 || pos + 1 + nb > len[p]) { bad = 1; return; }
+      nr++; nk += n; pos += 1 + nb;
+    }
+    n_rec[p] = nr; n_km[p] = nk;
+  });
+  if (bad) return ctx->fail(KMX_E_INVAL, "malformed super-k-mer stream");
+  std::vector<u64> rec_base(n_parts + 1, 0), km_base(n_parts + 1, 0), byte_base(n_parts + 1, 0);
+  for (u32 p = 0; p < n_parts; p++) { rec_base[p + 1] = rec_base[p] + n_rec[p]; km_base[p + 1] = km_base[p] + n_km[p]; byte_base[p + 1] = byte_base[p] + len[p]; }
+  const u64 bytes = byte_base[n_parts], total = km_base[n_parts];
+  if (total >= 0xFFFFFF00ULL || bytes >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers or bytes in one batch: split it");
+  const u32 nr = (u32)rec_base[n_parts];
+  u32* rec_off = (u32*)ctx->halloc((size_t)nr * 4 + 4), *kmer_off = (u32*)ctx->halloc((size_t)nr * 4 + 4);
+  u16* rec_part = (u16*)ctx->halloc((size_t)nr * 2 + 2);
+  auto hrelease = [&]() { ctx->hfree(rec_off); ctx->hfree(kmer_off); ctx->hfree(rec_part); };
+  if (!rec_off || !kmer_off || !rec_part) { hrelease(); return ctx->fail(KMX_E_NOMEM, "count batch: host allocation failed"); }
+  run_threads([&](u32 p) {
+    const uint8_t* s = superk[p]; u64 pos = 0, r = rec_base[p], o = km_base[p];
+    while (pos < len[p]) {
+      const u32 n = s[pos];
+      rec_off[r] = (u32)(byte_base[p] + pos); kmer_off[r] = (u32)o; rec_part[r] = (u16)p;
+      r++; o += n; pos += 1 + ((u64)k + n - 1 + 3) / 4;
+    }
+  });
+  clk.mark("parse");
+  auto empty_out = [&]() { for (u32 p = 0; p < n_parts; p++) { if (!keys[p]) { keys[p] = (uint64_t*)malloc(8); counts[p] = (uint32_t*)malloc(4); n_out[p] = 0; } } };
+  if (total == 0) { hrelease(); empty_out(); return KMX_OK; }
+  const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
+  u8* d_recs = (u8*)ctx->dalloc(bytes + 16);
+  u32* d_ro = (u32*)ctx->dalloc((size_t)nr * 4), *d_ko = (u32*)ctx->dalloc((size_t)nr * 4);
+  u16* d_rp = (u16*)ctx->dalloc((size_t)nr * 2);
+  u64* d_pid = (u64*)ctx->dalloc((size_t)n_parts * 8);
+  void* d_keys = ctx->dalloc(total * key_bytes);
+  u16* d_kpart = (u16*)ctx->dalloc(total * 2);
+  std::vector<void*> blocks = {d_recs, d_ro, d_ko, d_rp, d_pid, d_keys, d_kpart};
+  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); hrelease(); };
+  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count batch: device allocation failed"); }
+  hipStream_t st = ctx->stream; hipError_t e = hipSuccess;
+  u64 off = 0;
+  for (u32 p = 0; p < n_parts && e == hipSuccess; p++) { if (len[p]) e = hipMemcpyAsync(d_recs + off, superk[p], len[p], hipMemcpyHostToDevice, st); off += len[p]; }
+  std::vector<u64> pid(n_parts, 0); if (hash_mode) for (u32 p = 0; p < n_parts; p++) pid[p] = partition_ids[p];
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ro, rec_off, (size_t)nr * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ko, kmer_off, (size_t)nr * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_rp, rec_part, (size_t)nr * 2, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pid, pid.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count batch upload: ") + hipGetErrorString(e)); }
+  dim3 grid((nr + 255) / 256), block(256);
+  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<1, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_batch<1, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<2, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  else hipLaunchKernelGGL((k_superk_decode_batch<2, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode_batch: ") + hipGetErrorString(e)); }
+  clk.mark("upload+decode");
+  unsigned key_bits = 2 * k;
+  if (hash_mode) { u64 top = 0; for (u32 p = 0; p < n_parts; p++) top = std::max(top, pid[p]); key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * (top + 1);
+    if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
+  int rc;
+  if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), hard_min, keys, counts, n_out);
+  else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), hard_min, keys, counts, n_out);
+  release();
+  if (rc != KMX_OK) for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
+  return rc;
 }

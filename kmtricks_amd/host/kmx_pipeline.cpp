@@ -214,17 +214,18 @@ int main(int argc, char** argv)
       }
     }
     if (o.until == "superk") continue;
-    for (uint32_t p = 0; p < P; p++) {
-      const std::string cp = root + "/counts/partition_" + std::to_string(p) + "/" + S.id + (hash_mode ? ".hash" : ".kmer");
-      uint64_t* keys = nullptr; uint32_t* cnts = nullptr; uint64_t n = 0;
-      if (hash_mode) {
-        chk(c, kmx_count_hash(c, streams[p].data(), streams[p].size(), o.k, hw.wbits, p, S.hard_min, &keys, &cnts, &n), "kmx_count_hash");
-        write_hash_file(cp, si, p, keys, cnts, n);
-      } else {
-        chk(c, kmx_count_kmer(c, streams[p].data(), streams[p].size(), o.k, S.hard_min, &keys, &cnts, &n), "kmx_count_kmer");
-        write_kmer_file(cp, o.k, si, p, keys, cnts, n);
+    {   // every partition of the sample in one device pass (CountTask / HashCountTask, task.hpp:367-392, 447-481)
+      std::vector<const uint8_t*> sp(P); std::vector<uint64_t> sl(P), pid(P), n(P);
+      std::vector<uint64_t*> keys(P, nullptr); std::vector<uint32_t*> cnts(P, nullptr);
+      for (uint32_t p = 0; p < P; p++) { sp[p] = streams[p].data(); sl[p] = streams[p].size(); pid[p] = p; }
+      chk(c, kmx_count_batch(c, P, sp.data(), sl.data(), o.k, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, pid.data(), S.hard_min,
+                             keys.data(), cnts.data(), n.data()), "kmx_count_batch");
+      for (uint32_t p = 0; p < P; p++) {
+        const std::string cp = root + "/counts/partition_" + std::to_string(p) + "/" + S.id + (hash_mode ? ".hash" : ".kmer");
+        if (hash_mode) write_hash_file(cp, si, p, keys[p], cnts[p], n[p]);
+        else write_kmer_file(cp, o.k, si, p, keys[p], cnts[p], n[p]);
+        kmx_free(keys[p]); kmx_free(cnts[p]);
       }
-      kmx_free(keys); kmx_free(cnts);
     }
   }
   if (o.until == "superk" || o.until == "count") return 0;

@@ -51,6 +51,9 @@ _lib.kmx_count_kmer.argtypes = [_vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uin
                                 C.POINTER(C.c_uint64)]
 _lib.kmx_count_hash.argtypes = [_vp, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                 C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64)]
+_lib.kmx_count_batch.argtypes = [_vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_int,
+                                 C.c_uint64, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_vp), C.POINTER(_vp),
+                                 C.POINTER(C.c_uint64)]
 _lib.kmx_transpose_bits.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, _vp]
 _lib.kmx_superk_partition.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
                                       C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -58,7 +61,7 @@ _lib.kmx_superk_partition.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint
 EXPORTS = ["kmx_version", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
-           "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_transpose_bits", "kmx_superk_partition",
+           "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
            "kmx_free"]
 
 
@@ -142,9 +145,9 @@ class Context:
         return data, rows.value, stats
 
     def _take(self, kp, cp, n, width):
-        keys = np.frombuffer(C.string_at(kp.value, n * 8 * width), dtype=np.uint64).copy().reshape(n, width) if n \
+        keys = np.ctypeslib.as_array((C.c_uint64 * (n * width)).from_address(kp.value)).copy().reshape(n, width) if n \
             else np.zeros((0, width), np.uint64)
-        cnts = np.frombuffer(C.string_at(cp.value, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
+        cnts = np.ctypeslib.as_array((C.c_uint32 * n).from_address(cp.value)).copy() if n else np.zeros(0, np.uint32)
         _lib.kmx_free(kp)
         _lib.kmx_free(cp)
         return keys, cnts
@@ -162,6 +165,23 @@ class Context:
                                         C.byref(cp), C.byref(n)), "kmx_count_hash")
         keys, cnts = self._take(kp, cp, n.value, 1)
         return keys.reshape(-1), cnts
+
+    def count_batch(self, streams, k, hard_min, window=0, partitions=None):
+        """kmx_count_batch: the partition streams of one sample -> [(keys, counts)] per stream.
+        window != 0 selects window hashes (partitions[p] = window index of stream p)."""
+        n = len(streams)
+        sp = (C.c_char_p * n)(*[s if s else None for s in streams])
+        ln = (C.c_uint64 * n)(*[len(s) for s in streams])
+        pid = (C.c_uint64 * n)(*(partitions if partitions is not None else range(n)))
+        kp, cp, no = (_vp * n)(), (_vp * n)(), (C.c_uint64 * n)()
+        self._check(_lib.kmx_count_batch(self._h, n, sp, ln, k, 1 if window else 0, window, pid, hard_min, kp, cp, no),
+                    "kmx_count_batch")
+        width = 1 if window else (k + 31) // 32
+        out = []
+        for p in range(n):
+            keys, cnts = self._take(_vp(kp[p]), _vp(cp[p]), no[p], width)
+            out.append((keys.reshape(-1) if window else keys, cnts))
+        return out
 
     def transpose_bits(self, mat, nrows, ncols):
         mat = np.ascontiguousarray(mat, dtype=np.uint8)

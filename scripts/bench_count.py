@@ -28,6 +28,12 @@ nk = sum(x[1] for x in sk); nb = sum(len(x[0]) for x in sk)
 ctx.count_kmer(sk[0][0], K, 2)
 t0 = time.perf_counter(); cnt = [ctx.count_kmer(sk[p][0], K, 2) for p in range(P)]; t_ck = time.perf_counter() - t0
 t0 = time.perf_counter(); cnth = [ctx.count_hash(sk[p][0], K, 3125056, p, 2) for p in range(P)]; t_ch = time.perf_counter() - t0
+streams = [x[0] for x in sk]
+ctx.count_batch(streams, K, 2); ctx.count_batch(streams, K, 2, window=3125056)      # warm-up at full size (pinned pools)
+t0 = time.perf_counter(); bk = ctx.count_batch(streams, K, 2); t_bk = time.perf_counter() - t0
+t0 = time.perf_counter(); bh = ctx.count_batch(streams, K, 2, window=3125056); t_bh = time.perf_counter() - t0
+batch_ok = all(np.array_equal(bk[p][0], cnt[p][0]) and np.array_equal(bk[p][1], cnt[p][1]) and
+               np.array_equal(bh[p][0], cnth[p][0]) and np.array_equal(bh[p][1], cnth[p][1]) for p in range(P))
 # oracle on one core, bounded sample: 1/8 of the reads for the split, 4 partitions for the counts
 lut = orc.minimizer_lut(M)
 t0 = time.perf_counter(); osk = orc.superk_partition(reads[: n_reads // 8], K, M, lut, rep, P); t_osk = time.perf_counter() - t0
@@ -37,6 +43,9 @@ print(json.dumps({"reads": n_reads, "bases": n_reads * L, "kmers": nk, "superk_b
                   "gpu_superk_s": t_sk, "gpu_superk_Mbases_per_s": n_reads * L / t_sk / 1e6,
                   "gpu_count_kmer_s": t_ck, "gpu_count_kmer_Mkmers_per_s": nk / t_ck / 1e6,
                   "gpu_count_hash_s": t_ch, "gpu_count_hash_Mkmers_per_s": nk / t_ch / 1e6,
+                  "gpu_count_batch_kmer_s": t_bk, "gpu_count_batch_kmer_Mkmers_per_s": nk / t_bk / 1e6,
+                  "gpu_count_batch_hash_s": t_bh, "gpu_count_batch_hash_Mkmers_per_s": nk / t_bh / 1e6,
+                  "batch_equals_per_partition": bool(batch_ok),
                   "oracle_superk_Mbases_per_s_1core": (n_reads // 8) * L / t_osk / 1e6,
                   "oracle_count_kmer_Mkmers_per_s_1core": sum(sk[p][1] for p in range(4)) / t_ock / 1e6,
                   "count_bit_exact_vs_oracle_4_partitions": bool(ok)}))

@@ -69,6 +69,27 @@ def test_count_random_reads_vs_oracle(ctx, k, m):
     assert tot > 1000
 
 
+@pytest.mark.parametrize("k,m", [(31, 10), (47, 11), (20, 7)])
+def test_count_batch_vs_oracle(ctx, k, m):
+    """kmx_count_batch (all partition streams of a sample at once) == oracle per partition"""
+    P = 16
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    reads = random_reads(7 + k, 900, 120) + ["ACGT" * 60] * 5 + ["A" * 200]
+    sk = orc.superk_partition(reads * 2, k, m, lut, rep, P)
+    streams = [sk[p][0] for p in range(P)]
+    streams[3] = b""                          # an empty partition in the middle of the batch
+    for hard_min in (1, 2):
+        got = ctx.count_batch(streams, k, hard_min)
+        goth = ctx.count_batch(streams, k, hard_min, window=1000003, partitions=list(range(P)))
+        for p in range(P):
+            ek, ec = orc.count_kmer(streams[p], k, hard_min)
+            assert np.array_equal(ek, got[p][0]) and np.array_equal(ec, got[p][1])
+            eh, ehc = orc.count_hash(streams[p], k, 1000003, p, hard_min)
+            assert np.array_equal(eh, goth[p][0]) and np.array_equal(ehc, goth[p][1])
+    assert all(len(c) == 0 for _, c in ctx.count_batch([b"", b""], k, 1))
+
+
 def test_count_empty_stream(ctx):
     k_, c_ = ctx.count_kmer(b"", 31, 2)
     assert len(c_) == 0
