@@ -309,19 +309,6 @@ extern "C" int kmx_count_hash(kmx_ctx* ctx, const uint8_t* superk, uint64_t len,
 
 
 // ---- batched count: every partition stream of one sample in one call ---------------------------------
-struct StageClock {     // KMX_TRACE=1: per-stage wall times of the batched count on stderr
-  bool on; hipStream_t st; std::chrono::steady_clock::time_point t0; std::string log;
-  StageClock(hipStream_t s) : on(getenv("KMX_TRACE") != nullptr), st(s), t0(std::chrono::steady_clock::now()) {}
-  void mark(const char* what) {
-    if (!on) return;
-    (void)hipStreamSynchronize(st);
-    auto t1 = std::chrono::steady_clock::now();
-    char b[96]; snprintf(b, sizeof b, " %s=%.2fms", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-    log += b; t0 = t1;
-  }
-  ~StageClock() { if (on) fprintf(stderr, "[kmx count_batch]%s\n", log.c_str()); }
-};
-
 __global__ void k_run_part_flags(const u32* __restrict__ run_start, const u32* __restrict__ run_cnt, u32 n_runs,
                                  const u16* __restrict__ sorted_part, u32 hard_min, u16* __restrict__ run_part, u8* __restrict__ flags)
 {

@@ -53,3 +53,20 @@ struct kmx_ctx {
     if (e__ != hipSuccess)                                                                         \
       return (ctx)->fail(KMX_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));           \
   } while (0)
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+struct StageClock {     // KMX_TRACE=1: per-stage wall times of the batched count on stderr
+  const char* name; bool on; hipStream_t st; std::chrono::steady_clock::time_point t0; std::string log;
+  StageClock(hipStream_t s, const char* nm = "count_batch") : name(nm), on(getenv("KMX_TRACE") != nullptr), st(s), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    (void)hipStreamSynchronize(st);
+    auto t1 = std::chrono::steady_clock::now();
+    char b[96]; snprintf(b, sizeof b, " %s=%.2fms", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    log += b; t0 = t1;
+  }
+  ~StageClock() { if (on) fprintf(stderr, "[kmx %s]%s\n", name, log.c_str()); }
+};
+

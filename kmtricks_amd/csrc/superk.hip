@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 #include "kmx_host.hpp"
+#include <atomic>
+#include <thread>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -130,6 +132,24 @@ __global__ void k_superk_gather_sizes(const u32* __restrict__ ids, const u32* __
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) sizes_sorted[i] = sizes_unsorted[ids[i]];
 }
+// partition-sorted order: (k-mers << 32 | bytes) per record, so one scan yields both prefixes (both totals < 2^32)
+__global__ void k_superk_gather_sizes2(const u32* __restrict__ ids, const u32* __restrict__ sizes_unsorted, const SkDesc* __restrict__ desc,
+                                       u32 n, u64* __restrict__ sizes_sorted)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const u32 j = ids[i]; sizes_sorted[i] = ((u64)desc[j].n << 32) | sizes_unsorted[j]; }
+}
+// prefix (k-mers << 32 | bytes) at the first record of every partition (nb_parts + 1 entries) + that record's index
+__global__ void k_superk_part_bounds(const u16* __restrict__ part_sorted, u32 n, u32 nb_parts, const u64* __restrict__ prefix,
+                                     u64* __restrict__ part_prefix, u32* __restrict__ part_first)
+{
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > nb_parts) return;
+  u32 lo = 0, hi = n;
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (part_sorted[mid] < p) lo = mid + 1; else hi = mid; }
+  part_prefix[p] = prefix[lo];
+  part_first[p] = lo;
+}
 
 __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __restrict__ desc, const u32* __restrict__ ids,
                               const u64* __restrict__ byte_off, u32 n, int k, u8* __restrict__ out)
@@ -138,7 +158,7 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
   if (i >= n) return;
   const SkDesc d = desc[ids[i]];
   const char* seq = bases + d.base;
-  u8* o = out + byte_off[i];
+  u8* o = out + (u32)byte_off[i];
   const int ndig = k + d.n - 1;
   o[0] = d.n;
   for (int by = 0; by * 4 < ndig; by++) {
@@ -200,6 +220,7 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+  StageClock clk(st, "superk_partition");
   hipError_t e;
   if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
@@ -217,6 +238,7 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   u32 nd = 0;
   if ((e = hipMemcpyAsync(&nd, d_doff + n_seqs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  clk.mark("upload+scan");
   if (nd == 0) { release(); for (u32 p = 0; p < nb_parts; p++) out_bytes[p] = (uint8_t*)malloc(1); return KMX_OK; }
 
   SkDesc* d_desc = (SkDesc*)ctx->dalloc((size_t)nd * sizeof(SkDesc));
@@ -237,37 +259,50 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   if (!d_tmp2) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   if ((e = rocprim::radix_sort_pairs(d_tmp2, tb2, d_keys, d_keys2, d_ids, d_ids2, (size_t)nd, 0, 16, st)) != hipSuccess) return fail(e, "sort");
   if ((e = hipMemsetAsync(d_szs + nd, 0, 8, st)) != hipSuccess) return fail(e, "memset");
-  hipLaunchKernelGGL(k_superk_gather_sizes, g2, b2, 0, st, d_ids2, d_sz, nd, d_szs);
+  hipLaunchKernelGGL(k_superk_gather_sizes2, g2, b2, 0, st, d_ids2, d_sz, d_desc, nd, d_szs);
   if ((e = rocprim::exclusive_scan(d_tmp2, tb3, d_szs, d_boff, (u64)0, (size_t)nd + 1, rocprim::plus<u64>(), st)) != hipSuccess) return fail(e, "scan");
-  u64 total_bytes = 0;
-  if ((e = hipMemcpyAsync(&total_bytes, d_boff + nd, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  u64* d_pp = (u64*)ctx->dalloc(((size_t)nb_parts + 1) * 8); u32* d_pf = (u32*)ctx->dalloc(((size_t)nb_parts + 1) * 4);
+  blocks.push_back(d_pp); blocks.push_back(d_pf);
+  if (!d_pp || !d_pf) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+  hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf);
+  std::vector<u64> pp((size_t)nb_parts + 1); std::vector<u32> pf((size_t)nb_parts + 1);
+  u64 tot = 0;
+  if ((e = hipMemcpyAsync(&tot, d_boff + nd, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(pp.data(), d_pp, ((size_t)nb_parts + 1) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(pf.data(), d_pf, ((size_t)nb_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  clk.mark("emit+sort");
+  if (pf[nb_parts] != nd) { release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
+  const u64 total_bytes = tot & 0xFFFFFFFFULL;
   u8* d_out = (u8*)ctx->dalloc(total_bytes + 16); blocks.push_back(d_out);
-  if (!d_out) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+  u8* h_out = (u8*)ctx->halloc(total_bytes + 16);
+  if (!d_out || !h_out) { ctx->hfree(h_out); release(); return ctx->fail(KMX_E_NOMEM, "superk: allocation failed"); }
   hipLaunchKernelGGL(k_superk_pack, g2, b2, 0, st, d_bases, d_desc, d_ids2, d_boff, nd, (int)k, d_out);
-  if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_superk_pack");
-
-  // host: split the partition-ordered stream (sorted keys + offsets give each partition's span)
-  std::vector<u16> hk(nd); std::vector<u64> hb((size_t)nd + 1); std::vector<SkDesc> hd(nd); std::vector<u32> hid(nd);
-  std::vector<u8> hout(total_bytes ? total_bytes : 1);
-  if ((e = hipMemcpyAsync(hk.data(), d_keys2, (size_t)nd * 2, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(hb.data(), d_boff, ((size_t)nd + 1) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(hd.data(), d_desc, (size_t)nd * sizeof(SkDesc), hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(hid.data(), d_ids2, (size_t)nd * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(hout.data(), d_out, total_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "download");
+  if ((e = hipGetLastError()) != hipSuccess) { ctx->hfree(h_out); return fail(e, "k_superk_pack"); }
+  clk.mark("pack");
+  // the partition-ordered stream comes back in one copy; a few host threads cut it into the per-partition buffers
+  if ((e = hipMemcpyAsync(h_out, d_out, total_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipStreamSynchronize(st)) != hipSuccess) { ctx->hfree(h_out); return fail(e, "download"); }
   release();
-  size_t i = 0;
-  for (u32 p = 0; p < nb_parts; p++) {
-    const size_t first = i;
-    u64 kmers = 0;
-    while (i < nd && hk[i] == p) { kmers += hd[hid[i]].n; i++; }
-    const u64 lo = hb[first], hi = hb[i];
-    out_bytes[p] = (uint8_t*)malloc(hi - lo ? hi - lo : 1);
-    if (!out_bytes[p]) return ctx->fail(KMX_E_NOMEM, "superk: host allocation failed");
-    memcpy(out_bytes[p], hout.data() + lo, hi - lo);
-    out_len[p] = hi - lo; out_kmers[p] = kmers;
+  std::atomic<u32> next{0}; std::atomic<int> oom{0};
+  auto fill = [&]() {
+    for (u32 p; (p = next++) < nb_parts;) {
+      const u64 lo = pp[p] & 0xFFFFFFFFULL, hi = pp[p + 1] & 0xFFFFFFFFULL;
+      out_bytes[p] = (uint8_t*)malloc(hi - lo ? hi - lo : 1);
+      if (!out_bytes[p]) { oom = 1; continue; }
+      memcpy(out_bytes[p], h_out + lo, hi - lo);
+      out_len[p] = hi - lo; out_kmers[p] = (pp[p + 1] >> 32) - (pp[p] >> 32);
+    }
+  };
+  {
+    const unsigned nthr = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), nb_parts}));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthr; t++) th.emplace_back(fill);
+    fill();
+    for (auto& x : th) x.join();
   }
-  if (i != nd) return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts");
+  ctx->hfree(h_out);
+  clk.mark("download");
+  if (oom) return ctx->fail(KMX_E_NOMEM, "superk: host allocation failed");
   return KMX_OK;
 }

@@ -190,17 +190,23 @@ class Context:
                     "kmx_transpose_bits")
         return out
 
-    def superk_partition(self, reads, k, m, repart, nb_parts):
-        """kmx_superk_partition: list of reads (str/bytes) -> [(record stream bytes, n_kmers)] per partition"""
+    @staticmethod
+    def pack_reads(reads):
+        """list of reads (str/bytes) -> (concatenated bases, uint64 offsets[n + 1]) as kmx_superk_partition takes them"""
         bs = [r if isinstance(r, bytes) else r.encode() for r in reads]
         offs = np.zeros(len(bs) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
-        blob = b"".join(bs)
+        return b"".join(bs), offs
+
+    def superk_partition(self, reads, k, m, repart, nb_parts):
+        """kmx_superk_partition: list of reads (str/bytes), or pack_reads() output -> [(record stream bytes, n_kmers)]
+        per partition"""
+        blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
         rep = np.ascontiguousarray(repart, dtype=np.uint16)
         ob = (_vp * nb_parts)()
         ol = (C.c_uint64 * nb_parts)()
         okm = (C.c_uint64 * nb_parts)()
-        self._check(_lib.kmx_superk_partition(self._h, blob, offs.ctypes.data, len(bs), k, m, rep.ctypes.data, nb_parts,
+        self._check(_lib.kmx_superk_partition(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
                                               ob, ol, okm), "kmx_superk_partition")
         out = []
         for p in range(nb_parts):
