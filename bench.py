@@ -117,6 +117,7 @@ def main():
         nonlocal algo_bytes, rows_out
 
         def finish(res):
+            nonlocal algo_bytes, rows_out
             res.wait()
             if record:
                 kernel_ms.append(res.kernel_ms())

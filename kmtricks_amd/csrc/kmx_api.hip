@@ -355,6 +355,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   if (fallback) {
     // the pivot did not cover some task's lists (a pivot gap overflowed the tile buffer): run the
     // batch again with the general kernel.  Bounds stay valid; statistics and row space restart.
+    if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] pivot kernel flagged a task: batch re-run with k_merge_rows\n");
     R->use_pivot = false;
     R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
     for (auto& H : R->tasks) {

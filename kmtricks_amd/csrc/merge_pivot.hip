@@ -2,22 +2,23 @@
 // Same results as k_merge_rows (reference include/kmtricks/merge.hpp:183-286, 441-558), different
 // decomposition, built for the case the metric is quoted on: many lists that share most of their keys.
 //
-//   * The task's longest list is the PIVOT.  A tile is RT consecutive pivot records; its key range
-//     [first key of the range, key of the pivot record after the tile) is walked by every list
-//     with its own sequential cursor, exactly like the Bloom kernel: g adjacent lanes stream a
-//     list's records with 8 loads in flight each (one 12/20-byte record per load, a list's lines
-//     are consumed in one or two visits instead of five).
-//   * A record whose key IS one of the tile's pivot keys (binary search over <= 16 keys in LDS)
-//     goes straight to row j of the tile's LDS image: no hash set, no ranking, no WG-wide bound.
-//     The recurrence counter of a row saturates at max(recurrence-min, share-min) and is read
-//     before it is incremented, so the ~N lanes that hit the same row do not serialise.
-//   * A record whose key is NOT a pivot key (sample-private k-mers, keys the pivot lacks) is put
-//     in an LDS overflow buffer; after the scan the (few) overflow records are merged among
-//     themselves with the hash set of k_merge_rows, kept keys are ranked together with the kept
-//     pivot rows, and their (sparse) rows are written straight to HBM.
-//   * If a tile's overflow does not fit, the tile is retried with half as many pivot records; if
-//     one pivot gap alone does not fit, the task is flagged and the driver re-runs it with
-//     k_merge_rows -- results never depend on how well the pivot covers the other lists.
+//   * The task's longest list is the PIVOT.  A tile is rt consecutive pivot records; its key range
+//     [first key of the tile, key of the pivot record after the tile) is known before any other list
+//     is looked at, so there is no workgroup-wide bound search and no retry.
+//   * Every list keeps a circular window of 16 records in registers (8 adjacent lanes x 2 slots, a
+//     lane serves up to 8 lists).  A record below the tile's upper key is consumed and its slot is
+//     refilled IN PLACE with the record 16 positions further: every record is loaded exactly once,
+//     a wave load covers 8 lists x 96 contiguous bytes, and the refill has a whole tile to land.
+//   * A consumed record whose key IS one of the tile's pivot keys (one probe of a read-only 128-entry
+//     LDS table built per tile: no atomics, same-address reads broadcast) is deposited straight into
+//     row j of the tile's LDS image.  The recurrence of a pivot row is a popcount of its image row.
+//   * A record whose key is NOT a pivot key (sample-private k-mers, keys the pivot lacks) goes to an
+//     LDS overflow buffer; after the scan the (few) overflow records are merged among themselves
+//     with the hash set of k_merge_rows, kept keys are ranked together with the kept pivot rows, and
+//     their (sparse) rows are written straight to HBM.
+//   * If a tile's overflow does not fit (lists that do not resemble their pivot), the task is
+//     flagged and the driver re-runs the batch with k_merge_rows -- results never depend on how well
+//     the pivot covers the other lists.
 // Rows leave through the same chunked arena + (range, seq) directory as k_merge_rows.
 #include "kmx_dev.hpp"
 #include <algorithm>
@@ -26,27 +27,51 @@
 
 namespace kmx {
 
-constexpr int PV_TPB = 1024;
-constexpr int PV_RTMAX = 16;        // pivot records per tile
+#ifndef KMX_PV_RT
+#define KMX_PV_RT 13
+#endif
+#ifndef KMX_PV_TPB
+#define KMX_PV_TPB 1024
+#endif
+constexpr int PV_TPB = KMX_PV_TPB;  // 512: 8 waves with 256 VGPRs each -- the windows of 16 lists per lane plus room to overlap two passes
+constexpr int PV_RTMAX = KMX_PV_RT; // pivot records per tile (< window: a similar list rarely needs a second round)
 constexpr int PV_IMG = 61440;       // LDS row image bytes (15 rows of 1000 u32 counts)
 constexpr int PV_OVCAP = 2048;      // overflow records per tile
 constexpr int PV_OT = 2 * PV_OVCAP; // overflow hash set entries
 constexpr int PV_G = 8;             // adjacent lanes per list: one wave load covers 8 lists x 96 contiguous bytes
-constexpr int PV_LPP = PV_TPB / PV_G;   // lists per pass (128)
-constexpr int PV_PB = 2;            // passes whose records are in flight together (8 loads per lane)
-constexpr int PV_U = 3;             // records per lane and pass in the prefetch batch (24 per list: the tail loop is rare)
+constexpr int PV_U = 2;             // window slots per lane
+constexpr int PV_W = PV_G * PV_U;   // records per window (power of two)
+constexpr int PV_LPP = PV_TPB / PV_G;   // lists per pass
+constexpr int PV_MAXN = 1024;       // lists per task
+constexpr int PV_NP = PV_MAXN / PV_LPP;   // passes
+constexpr int PV_NH = 4;             // helper lists
+constexpr int PV_NC = PV_NH * PV_W;  // candidate keys per tile
+constexpr int PV_PT = 128;          // pivot lookup table entries (load factor <= 1/8)
+static_assert(PV_RTMAX <= 16 && (PV_W & (PV_W - 1)) == 0, "tile geometry");
+
+// a 12-byte record as one register triple: the refill is ONE global_load_dwordx3 straight into the
+// window slot (key and count allocated apart cost a register move, i.e. a wait, right behind the load)
+typedef u32 u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef __attribute__((address_space(1))) const u32x3 gu32x3;
+__device__ __forceinline__ Key<1> rec_key(const u32x3& v) { Key<1> k; k.w[0] = (u64)v.x | ((u64)v.y << 32); return k; }
+__device__ __forceinline__ u32x3 rec_none() { u32x3 v; v.x = ~0u; v.y = ~0u; v.z = 0; return v; }
 
 template <int KW> struct OvRec { Key<KW> key; u32 cnt; u32 list; };
+template <int KW> struct PvEnt { Key<KW> key; u32 idx; u32 pad; };   // idx = row + 1, 0 = empty
 
 __device__ __forceinline__ void pv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KW> __device__ __forceinline__ u32 pv_hash(const Key<KW>& k)
+template <int KW> __device__ __forceinline__ u32 pv_mix(const Key<KW>& k)
 {
   u32 x = (u32)k.w[0] ^ ((u32)(k.w[0] >> 32) * 0x9E3779B1u);
   if (KW == 2) x ^= ((u32)k.w[KW - 1] * 0x85EBCA77u) ^ ((u32)(k.w[KW - 1] >> 32) * 0xC2B2AE3Du);
   x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
-  return x & (PV_OT - 1);
+  return x;
 }
+template <int KW> __device__ __forceinline__ u32 pv_hash(const Key<KW>& k) { return pv_mix<KW>(k) & (PV_OT - 1); }
+// the tile's pivot keys are neighbours in key order: a multiplicative hash of the low bits spreads them
+template <int KW> __device__ __forceinline__ u32 pv_thash(const Key<KW>& k)
+{ return (((u32)k.w[0] ^ (u32)(k.w[0] >> 29)) * 0x9E3779B1u) >> 25; }
 
 template <int KW> __device__ __forceinline__ Key<KW> gload_key(gu32* p)
 {
@@ -56,39 +81,57 @@ template <int KW> __device__ __forceinline__ Key<KW> gload_key(gu32* p)
   return k;
 }
 
+// probing past a collision in the pivot table (rare): row + 1 of `k`, 0 if it is not a pivot key
+template <int KW>
+__device__ __noinline__ u32 pv_lookup_slow(const PvEnt<KW>* ptab, Key<KW> k, u32 h)
+{
+  for (;;) {
+    h = (h + 1) & (PV_PT - 1);
+    const u32 idx = ptab[h].idx;
+    if (idx == 0) return 0;
+    if (key_eq<KW>(ptab[h].key, k)) return idx;
+  }
+}
+
 #ifdef KMX_PHASE_PROF
 __device__ u64 kmx_pivot_prof[16];
 #endif
 
 template <int KW, int MODE>
-__global__ __launch_bounds__(PV_TPB, 4)
+__global__ __launch_bounds__(PV_TPB, PV_TPB / 256)
 void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ items, u32 n_items, u32* ticket)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RB4 = (KW * 8 + 4) / 4;
+  static_assert(KW == 1, "the register windows hold 12-byte records");
   unsigned char* const img = smem;                                                        // [PV_IMG]
   OvRec<KW>* ov = reinterpret_cast<OvRec<KW>*>(smem + PV_IMG);                            // [PV_OVCAP]
   u32* otab = reinterpret_cast<u32*>(smem + PV_IMG + PV_OVCAP * sizeof(OvRec<KW>));       // [PV_OT]
   unsigned char* misc = smem + PV_IMG + PV_OVCAP * sizeof(OvRec<KW>) + PV_OT * 4;
-  Key<KW>* pk = reinterpret_cast<Key<KW>*>(misc);                                         // [PV_RTMAX] pivot keys of the tile
-  u32* prec = reinterpret_cast<u32*>(misc + 256);                                         // [PV_RTMAX] recurrence (saturating)
-  u32* prank = reinterpret_cast<u32*>(misc + 320);                                        // [PV_RTMAX] final row or ~0
-  u16* okl = reinterpret_cast<u16*>(misc + 384);                                          // [PV_OVCAP] table slots of kept overflow keys
-  u16* orank = reinterpret_cast<u16*>(misc + 384 + PV_OVCAP * 2);                         // [PV_OVCAP] their final rows
-  u32* sh = reinterpret_cast<u32*>(misc + 384 + PV_OVCAP * 4);                            // [0] item [1] ovn [2] nok [3] can-write
-  u64* sh64 = reinterpret_cast<u64*>(misc + 384 + PV_OVCAP * 4 + 32);                     // [0] tile row base
-  // per-list state (a list is served by 8 lanes, a lane serves up to 8 lists: the state lives in LDS)
-  unsigned char* lt = misc + 384 + PV_OVCAP * 4 + 64;
+  Key<KW>* pk = reinterpret_cast<Key<KW>*>(misc);                                         // [32] keys of the image rows (pivot rows, then adopted rows)
+  u32* prec = reinterpret_cast<u32*>(misc + 256);                                         // [32] recurrence
+  u32* prank = reinterpret_cast<u32*>(misc + 384);                                        // [32] final row or ~0
+  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] ovn [2] nok [3] can-write [4] adopted rows [5] candidates
+  u64* sh64 = reinterpret_cast<u64*>(misc + 576);                                         // [0] tile row base [1] upper key [2] cut
+  u64* cand = reinterpret_cast<u64*>(misc + 640);                                        // [PV_NC] helper keys the pivot lacks
+  PvEnt<KW>* ptab = reinterpret_cast<PvEnt<KW>*>(misc + 1280);                             // [PV_PT] row key -> row
+  unsigned char* m2 = misc + 1280 + PV_PT * sizeof(PvEnt<KW>);
+  u16* okl = reinterpret_cast<u16*>(m2);                                                  // [PV_OVCAP] table slots of kept overflow keys
+  u16* orank = reinterpret_cast<u16*>(m2 + PV_OVCAP * 2);                                 // [PV_OVCAP] their final rows
+  // per-list state (a list is served by 8 lanes, a lane serves up to 8 lists)
+  unsigned char* lt = m2 + PV_OVCAP * 4;
   u64* lt_base = reinterpret_cast<u64*>(lt);                    // [1024] record base
-  u64* lt_two = reinterpret_cast<u64*>(lt + 8192);              // [1024] TOTAL_WO of the range so far
-  u64* pd_two = reinterpret_cast<u64*>(lt + 16384);             // [1024] ... of the tile attempt (committed on success)
-  u32* lt_cur = reinterpret_cast<u32*>(lt + 24576);             // [1024] cursor
-  u32* pd_nxt = reinterpret_cast<u32*>(lt + 28672);             // [1024] cursor after the tile attempt
-  u32* lt_nso = reinterpret_cast<u32*>(lt + 32768);             // [1024] NON_SOLID so far
-  u32* pd_nso = reinterpret_cast<u32*>(lt + 36864);             // [1024] ... of the tile attempt
+  u64* lt_es = reinterpret_cast<u64*>(lt + 8192);               // [1024] range end (low) | soft-min (high)
+  u64* lt_two = reinterpret_cast<u64*>(lt + 16384);             // [1024] TOTAL_WO of the range so far
+  u32* lt_nso = reinterpret_cast<u32*>(lt + 24576);             // [1024] NON_SOLID so far
+  u32* lt_cur = reinterpret_cast<u32*>(lt + 28672);             // [1024] cursor: first record not yet consumed
+  // row-space allocator state (thread 0 only; kept out of the register file)
+  u64* al64 = reinterpret_cast<u64*>(misc + 608);               // [0] chunk base
+  u32* al = reinterpret_cast<u32*>(misc + 616);                 // [0] used [1] cap [2] seq [3] ok
 
   const int tid = threadIdx.x, lane = tid & 63;
   for (int t = tid; t < PV_OT; t += PV_TPB) otab[t] = 0;
+  for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
 #ifdef KMX_PHASE_PROF
   long long pt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pc = clock64();
 #define PVPH(i) do { const long long n_ = clock64(); pt[i] += n_ - pc; pc = n_; } while (0)
@@ -112,181 +155,265 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     const u32 N = T.N, rec_min = T.rec_min, share_min = T.share_min, row_bytes = T.row_bytes;
     const u32 sat = max(rec_min, share_min);
     const u32 chunk_rows = max(64u, 262144u / row_bytes);
-    const u32 rt_cap = min((u32)PV_RTMAX, (u32)PV_IMG / row_bytes);
+    const u32 rows_cap = max(1u, min(32u, (u32)PV_IMG / row_bytes));      // image rows
+    const u32 rt_cap = min((u32)PV_RTMAX, rows_cap);                      // pivot rows per tile; the rest is for adopted rows
+    if (__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)ERR_FALLBACK) continue;   // the batch is re-run anyway
 
-    // PV_G adjacent lanes per list; list p*PV_LPP + tid/PV_G in pass p (N <= 1024 -> <= 8 passes)
+    // PV_G adjacent lanes per list; list p*PV_LPP + tid/PV_G in pass p
     const u32 npass = (N + PV_LPP - 1) / PV_LPP;
     const u32 lg = tid / PV_G, r = tid & (PV_G - 1);
-    const u32* const endp = T.bounds + (u64)(range + 1) * N;
+    const u32 gsh = lane & ~(PV_G - 1);                         // first lane of my list's lane group
     for (u32 i = tid; i < N; i += PV_TPB) {
       lt_base[i] = (u64)(uintptr_t)T.recs[i];
-      lt_cur[i] = T.bounds[(u64)range * N + i];
+      lt_es[i] = (u64)T.bounds[(u64)(range + 1) * N + i] | ((u64)T.soft_min[i] << 32);
       lt_nso[i] = 0; lt_two[i] = 0;
+      lt_cur[i] = T.bounds[(u64)range * N + i];
     }
-    // the pivot's records of this range define the tiles
+    // circular windows: lane r, slot u of a list holds the record whose index is == r + 8u (mod 16)
+    // inside [cur, cur + 16)
+    u32x3 rec[PV_NP][PV_U];
+#pragma unroll
+    for (int p = 0; p < PV_NP; p++) {
+      const u32 li = p * PV_LPP + lg;
+      const bool on = (u32)p < npass && li < N;
+      const u32 c0 = on ? T.bounds[(u64)range * N + li] : 0;
+      const u32 e = on ? T.bounds[(u64)(range + 1) * N + li] : 0;
+      gu32* base = (gu32*)(uintptr_t)(on ? T.recs[li] : nullptr);
+#pragma unroll
+      for (int u = 0; u < PV_U; u++) {
+        const u32 ix = c0 + ((r + PV_G * u - c0) & (PV_W - 1));
+        rec[p][u] = rec_none();
+        if (ix < e) rec[p][u] = *(gu32x3*)(base + (u64)ix * RB4);
+      }
+    }
+    // the pivot's records of this range define the tiles; a tile's keys are fetched one tile ahead
     gu32* pbase = (gu32*)(uintptr_t)T.recs[T.pivot];
     const u32 pend = T.bounds[(u64)(range + 1) * N + T.pivot];
     u32 ppos = T.bounds[(u64)range * N + T.pivot];
-    u64 ch_base = 0; u32 ch_used = 0, ch_cap = 0, ch_seq = 0, ch_ok = 1;
-    u32 seq = 0, rt_try = rt_cap;
-    bool failed = false, split = false;
-    Key<KW> ksplit = key_inf<KW>();   // artificial upper key of a tile that cuts an oversized pivot gap
+    Key<KW> pkn = key_inf<KW>();
+    if ((u32)tid <= rt_cap && ppos + tid < pend) pkn = gload_key<KW>(pbase + (u64)(ppos + tid) * RB4);
+    // A few more lists lend their keys: a key the pivot lacks is usually present in ~all other lists, and
+    // ~N overflow records per missing key would swamp the overflow buffer.  A key below the tile's
+    // upper key that the pivot does not have but at least two of the helper lists do is ADOPTED as an
+    // extra image row (one helper alone would mostly contribute its private keys); when the rows run
+    // out, the tile is cut in front of the first key that did not get one.
+    // helpers = the first PV_NH lists that are not the pivot (all served in pass 0)
+    const u32 hmax = min(N, (u32)PV_NH + (T.pivot <= (u32)PV_NH ? 1u : 0u));   // lists [0, hmax) minus the pivot
+    if (tid == 0) { al64[0] = 0; al[0] = 0; al[1] = 0; al[2] = 0; al[3] = 1; }
+    u32 seq = 0;
+    bool failed = false;
+    __syncthreads();
 
     PVPH(0);
     for (;;) {
       // ---- tile = pivot records [ppos, ppos + rte); key range up to the next pivot key ----
-      const u32 rte = min(rt_try, pend - ppos);
-      const bool open_end = !split && ppos + rte >= pend;     // last tile of the range: bounded by the lists' range ends
-      Key<KW> khi = key_inf<KW>();
-      if (split) khi = ksplit;
-      else if (!open_end) khi = gload_key<KW>(pbase + (u64)(ppos + rte) * RB4);
-      if (tid < (int)rte) {
-        const Key<KW> k = gload_key<KW>(pbase + (u64)(ppos + tid) * RB4);
-        pk[tid] = k; prec[tid] = 0;
+      const u32 rte = min(rt_cap, pend - ppos);
+      const bool open_end = ppos + rte >= pend;     // last tile of the range: bounded by the lists' range ends
+      if ((u32)tid < rte) {
+        pk[tid] = pkn;
+        u32 h = pv_thash<KW>(pkn);
+        while (atomicCAS(&ptab[h].idx, 0u, (u32)tid + 1) != 0) h = (h + 1) & (PV_PT - 1);
+        ptab[h].key = pkn;
       }
+      if ((u32)tid == rte) { sh64[1] = pkn.w[0]; sh64[2] = open_end ? ~0ULL : pkn.w[0]; }   // upper key; exclusive limit (cuts lower it)
       {
-        const u32 zb = rte * row_bytes;
+        const u32 zb = rows_cap * row_bytes;
         uint4* z = reinterpret_cast<uint4*>(img);
         for (u32 t = tid; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
-        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; }
+        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; }
       }
       pv_lds_barrier();
-      if (tid < (int)rte) {   // row keys
+      Key<KW> khi; khi.w[0] = open_end ? ~0ULL : sh64[1];
+      if ((u32)tid < rte) {   // row keys
+        const Key<KW> mine = pkn;
         u8* row = img + tid * row_bytes;
-        const Key<KW> k = pk[tid];
         if (MODE == 0) { u32* rw = reinterpret_cast<u32*>(row);
 #pragma unroll
-          for (int q = 0; q < KW; q++) { rw[2 * q] = (u32)k.w[q]; rw[2 * q + 1] = (u32)(k.w[q] >> 32); } }
+          for (int q = 0; q < KW; q++) { rw[2 * q] = (u32)mine.w[q]; rw[2 * q + 1] = (u32)(mine.w[q] >> 32); } }
         else {
 #pragma unroll
-          for (int q = 0; q < KW * 8; q++) row[q] = (u8)(k.w[q >> 3] >> ((q & 7) * 8));
+          for (int q = 0; q < KW * 8; q++) row[q] = (u8)(mine.w[q >> 3] >> ((q & 7) * 8));
         }
       }
-
-      PVPH(1);
-      // ---- scan: every list streams its records of the tile's key range ----
-      // The tile's pivot keys sit in registers (uniform values): a record's row is the number of pivot
-      // keys below its key, found by brute-force compares -- no memory access, no dependent chain.
-      Key<KW> pkr[PV_RTMAX];
+      // ---- window check: a list whose whole window lies below khi with records behind it cuts the tile
+      //      at its last window key (everything up to that key is inside every list's window) ----
 #pragma unroll
-      for (int j = 0; j < PV_RTMAX; j++) pkr[j] = j < (int)rte ? pk[j] : key_inf<KW>();
-      // exact lookup for the (rare) tail loop
-      auto row_of = [&](const Key<KW>& k, bool& found) -> u32 {
-        u32 rank = 0, eq = 0;
-#pragma unroll
-        for (int j = 0; j < PV_RTMAX; j++) { rank += key_less<KW>(pkr[j], k) ? 1u : 0u; eq += key_eq<KW>(pkr[j], k) ? 1u : 0u; }
-        found = eq != 0;
-        return rank;
-      };
-      auto deposit = [&](u32 row, u32 c, u32 li) {
-        if (MODE == 0) reinterpret_cast<u32*>(img + row * row_bytes + KW * 8)[li] = c;
-        else { const u32 ob = row * row_bytes + KW * 8 + (li >> 3);
-               atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u))); }
-      };
-      for (u32 p0 = 0; p0 < npass; p0 += PV_PB) {
-        // prefetch batch: PV_U records per lane for PV_PB passes before anything is processed
-        Key<KW> kk[PV_PB][PV_U]; u32 cc[PV_PB][PV_U]; u32 c0[PV_PB], ee[PV_PB], sm[PV_PB];
-#pragma unroll
-        for (int p = 0; p < PV_PB; p++) {
-          const u32 li = (p0 + p) * PV_LPP + lg;
-          const bool on = p0 + p < npass && li < N;
-          c0[p] = on ? lt_cur[li] : 0;
-          ee[p] = on ? endp[li] : 0;
-          sm[p] = on ? T.soft_min[li] : 0;
-          gu32* base = (gu32*)(uintptr_t)(on ? lt_base[li] : 0);
+      for (int p = 0; p < PV_NP; p++) {
+        __builtin_amdgcn_sched_barrier(0);
+        if ((u32)p < npass) {
+          u32 lgx = lg; asm volatile("" : "+v"(lgx));
+          const u32 li = p * PV_LPP + lgx;
+          const u32 end = li < N ? (u32)lt_es[li] : 0u;
+          const u32 cur = li < N ? lt_cur[li] : 0u;
+          u32 allb = 1; u64 lastk = 0; bool holds_last = false;
 #pragma unroll
           for (int u = 0; u < PV_U; u++) {
-            const u32 ix = c0[p] + r + u * PV_G;
-            kk[p][u] = key_inf<KW>(); cc[p][u] = 0;
-            if (ix < ee[p]) { gu32* q = base + (u64)ix * RB4; kk[p][u] = gload_key<KW>(q); cc[p][u] = q[2 * KW]; }
-          }
-        }
-#ifdef KMX_PHASE_PROF
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PVPH(7);
-#endif
-        u32 ovm = 0;                     // bit p*PV_U+u: overflow record
-        u32 nx[PV_PB], tn[PV_PB]; u64 tt[PV_PB];
-#pragma unroll
-        for (int p = 0; p < PV_PB; p++) {
-          nx[p] = c0[p]; tn[p] = 0; tt[p] = 0;
-          const u32 li = (p0 + p) * PV_LPP + lg;
-#pragma unroll
-          for (int u = 0; u < PV_U; u++) {
-            const u32 ix = c0[p] + r + u * PV_G;
-            const Key<KW> k = kk[p][u];
-            const bool valid = ix < ee[p] && (open_end || key_less<KW>(k, khi));
-            u32 rank = 0, eq = 0;
-#pragma unroll
-            for (int j = 0; j < PV_RTMAX; j++) { rank += key_less<KW>(pkr[j], k) ? 1u : 0u; eq += key_eq<KW>(pkr[j], k) ? 1u : 0u; }
-            const bool solid = cc[p][u] >= sm[p];
-            if (valid) {
-              nx[p] = ix + 1;
-              if (solid) tt[p] += cc[p][u]; else tn[p]++;
-              if (eq) { if (solid) deposit(rank, cc[p][u], li); }
-              else ovm |= 1u << (p * PV_U + u);
+            const u32 ix = cur + ((r + PV_G * u - cur) & (PV_W - 1));
+            const Key<KW> k = rec_key(rec[p][u]);
+            const bool below = ix < end && (open_end || key_less<KW>(k, khi));
+            const u64 b = __ballot(below);
+            allb &= ((u32)(b >> gsh) & ((1u << PV_G) - 1)) == ((1u << PV_G) - 1) ? 1u : 0u;
+            if (ix == cur + PV_W - 1) { holds_last = true; lastk = k.w[0]; }
+            if (p == 0 && below && li < hmax && li != T.pivot) {   // a helper's key the pivot lacks: candidate row
+              u32 h = pv_thash<KW>(k);
+              u32 idx = ptab[h].idx;
+              if (idx != 0 && !key_eq<KW>(ptab[h].key, k)) idx = pv_lookup_slow<KW>(ptab, k, h);
+              if (idx == 0) { const u32 pos = atomicAdd(&sh[5], 1u); if (pos < (u32)PV_NC) cand[pos] = k.w[0]; }
             }
           }
+          if (allb && holds_last && cur + PV_W < end) atomicMin(&sh64[2], lastk + 1);
         }
-        // lists with more than PV_U * PV_G records in the tile (much denser than the pivot here): keep going
-#pragma unroll
-        for (int p = 0; p < PV_PB; p++) {
-          const u32 li = (p0 + p) * PV_LPP + lg;
-          bool more = nx[p] == c0[p] + r + (PV_U - 1) * PV_G + 1;       // my last prefetched record was consumed
-          for (u32 i0 = c0[p] + r + PV_U * PV_G; __any(more && i0 < ee[p]); i0 += PV_G) {
-            if (more && i0 < ee[p]) {
-              gu32* q = (gu32*)(uintptr_t)lt_base[li] + (u64)i0 * RB4;
-              const Key<KW> k = gload_key<KW>(q); const u32 c = q[2 * KW];
-              if (!open_end && !key_less<KW>(k, khi)) more = false;
-              else {
-                nx[p] = i0 + 1;
-                const bool solid = c >= sm[p];
-                if (solid) tt[p] += c; else tn[p]++;
-                bool found; const u32 row = row_of(k, found);
-                if (found) { if (solid) deposit(row, c, li); }
-                else { const u32 pos = atomicAdd(&sh[1], 1u); if (pos < (u32)PV_OVCAP) { OvRec<KW> o; o.key = k; o.cnt = c; o.list = li; ov[pos] = o; } }
+      }
+      pv_lds_barrier();
+      {   // candidates seen in >= 2 helpers become rows, smallest keys first; the first one left without a row cuts the tile
+        const u32 nc = min(sh[5], (u32)PV_NC);
+        if ((u32)tid < nc) {
+          const u64 mine = cand[tid];
+          u32 cnt = 0, earlier = 0;
+          for (u32 j = 0; j < nc; j++) { const bool e = cand[j] == mine; cnt += e ? 1u : 0u; earlier += (e && j < (u32)tid) ? 1u : 0u; }
+          if (cnt >= 2 && earlier == 0) {
+            u32 rank = 0;    // qualifying distinct keys below mine
+            for (u32 j = 0; j < nc; j++) {
+              const u64 o = cand[j];
+              if (o < mine) {
+                u32 c2 = 0, e2 = 0;
+                for (u32 q = 0; q < nc; q++) { const bool e = cand[q] == o; c2 += e ? 1u : 0u; e2 += (e && q < j) ? 1u : 0u; }
+                rank += (c2 >= 2 && e2 == 0) ? 1u : 0u;
               }
-            } else more = false;
+            }
+            const u32 row = rte + rank;
+            if (row < rows_cap) {
+              Key<KW> k; k.w[0] = mine;
+              u32 h2 = pv_thash<KW>(k);
+              while (atomicCAS(&ptab[h2].idx, 0u, row + 1) != 0) h2 = (h2 + 1) & (PV_PT - 1);
+              ptab[h2].key = k;
+              pk[row] = k;
+              atomicMax(&sh[4], rank + 1);
+              u8* rowp = img + row * row_bytes;
+              if (MODE == 0) { u32* rw = reinterpret_cast<u32*>(rowp);
+#pragma unroll
+                for (int q = 0; q < KW; q++) { rw[2 * q] = (u32)k.w[q]; rw[2 * q + 1] = (u32)(k.w[q] >> 32); } }
+              else {
+#pragma unroll
+                for (int q = 0; q < KW * 8; q++) rowp[q] = (u8)(k.w[q >> 3] >> ((q & 7) * 8));
+              }
+            } else atomicMin(&sh64[2], mine);
           }
         }
-        {   // aggregated append of this batch's overflow records: one LDS atomic per wave
-          const u32 mine = __popc(ovm), incl = wave_incl_scan(mine, lane), total = __shfl(incl, 63);
-          if (total) {
-            u32 bpos = 0; if (lane == 63) bpos = atomicAdd(&sh[1], total); bpos = __shfl(bpos, 63);
-            u32 pos = bpos + incl - mine;
+      }
+      pv_lds_barrier();
+      const u64 lim = sh64[2];                     // exclusive upper key of the tile
+      const bool unbounded = lim == ~0ULL;         // open-ended tile, not cut
+      const u32 nrows = rte + min(sh[4], rows_cap - rte);
+      u32 rte_eff = 0;
+      for (u32 j = 0; j < rte; j++) rte_eff += (unbounded || pk[j].w[0] < lim) ? 1u : 0u;
+      const bool done = unbounded;
+      {   // next tile's pivot keys
+        const u32 npos = ppos + rte_eff;
+        pkn = key_inf<KW>();
+        if (!done && (u32)tid <= rt_cap && npos + tid < pend) pkn = gload_key<KW>(pbase + (u64)(npos + tid) * RB4);
+      }
+      PVPH(1);
+
+      // ---- scan: every list consumes its records of the tile (keys below lim) ----
+      // Processing and refilling are two sweeps over the passes: a refill issued inside the processing
+      // sweep would sit in front of the next pass's records in the (in-order) load counter, and the
+      // compiler waits for the counter to drain before it touches a window slot.
+      u32 consbits = 0;
 #pragma unroll
-            for (int p = 0; p < PV_PB; p++) {
+      for (int p = 0; p < PV_NP; p++) {
+        __builtin_amdgcn_sched_barrier(0);      // keep the passes apart: interleaving them only costs registers
+        if ((u32)p < npass) {
+          // li is recomputed here on purpose: hoisted out of the tile loop, the per-pass LDS addresses
+          // spill, and a scratch reload has to wait for every record load in flight
+          u32 lgx = lg; asm volatile("" : "+v"(lgx));
+          const u32 li = p * PV_LPP + lgx;
+          const u64 es = li < N ? lt_es[li] : 0ULL;
+          const u32 end = (u32)es, smin = (u32)(es >> 32);
+          const u32 cur = li < N ? lt_cur[li] : 0;
+          u32 consm = 0, ovm = 0, tn = 0; u64 tsum = 0;
+#pragma unroll
+          for (int u = 0; u < PV_U; u++) {
+            const u32 ix = cur + ((r + PV_G * u - cur) & (PV_W - 1));
+            const Key<KW> k = rec_key(rec[p][u]);
+            const bool cons = ix < end && (unbounded || k.w[0] < lim);
+            if (cons) {
+              consm |= 1u << u;
+              const u32 c = rec[p][u].z;
+              const bool solid = c >= smin;
+              if (solid) tsum += c; else tn++;
+              u32 h = pv_thash<KW>(k);
+              u32 idx = ptab[h].idx;
+              if (idx != 0 && !key_eq<KW>(ptab[h].key, k)) idx = pv_lookup_slow<KW>(ptab, k, h);
+              if (idx) {
+                if (solid) {
+                  const u32 row = idx - 1;
+                  if (MODE == 0) reinterpret_cast<u32*>(img + row * row_bytes + KW * 8)[li] = c;
+                  else { const u32 ob = row * row_bytes + KW * 8 + (li >> 3);
+                         atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u))); }
+                }
+              } else ovm |= 1u << u;
+            }
+          }
+          // overflow records of this pass: one LDS atomic per wave
+          {
+            u64 bal[PV_U]; u32 total = 0;
+#pragma unroll
+            for (int u = 0; u < PV_U; u++) { bal[u] = __ballot((ovm >> u) & 1u); total += __popcll(bal[u]); }
+            if (total) {
+              u32 bpos = 0;
+              if (lane == 0) bpos = atomicAdd(&sh[1], total);
+              bpos = __builtin_amdgcn_readfirstlane(bpos);
 #pragma unroll
               for (int u = 0; u < PV_U; u++) {
-                if ((ovm >> (p * PV_U + u)) & 1u) {
-                  if (pos < (u32)PV_OVCAP) { OvRec<KW> o; o.key = kk[p][u]; o.cnt = cc[p][u]; o.list = (p0 + p) * PV_LPP + lg; ov[pos] = o; }
-                  pos++;
+                if ((ovm >> u) & 1u) {
+                  const u32 pos = bpos + __builtin_amdgcn_mbcnt_hi((u32)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal[u], 0u));
+                  if (pos < (u32)PV_OVCAP) { OvRec<KW> o; o.key = rec_key(rec[p][u]); o.cnt = rec[p][u].z; o.list = li; ov[pos] = o; }
                 }
+                bpos += __popcll(bal[u]);
+              }
+            }
+          }
+          // records consumed by my list (a prefix of its window): statistics and the new cursor
+          u32 c = 0;
+#pragma unroll
+          for (int u = 0; u < PV_U; u++) { const u64 b = __ballot((consm >> u) & 1u); c += __popc((u32)(b >> gsh) & ((1u << PV_G) - 1)); }
+          if (consm) {
+            if (tsum) atomicAdd(&lt_two[li], tsum);
+            if (tn) atomicAdd(&lt_nso[li], tn);
+          }
+          if (r == 0 && c) lt_cur[li] = cur + c;
+          consbits |= consm << (PV_U * p);
+        }
+      }
+      // refill sweep: a consumed slot takes the record 16 positions further, in place
+#pragma unroll
+      for (int p = 0; p < PV_NP; p++) {
+        if ((u32)p < npass) {
+          const u32 cm = (consbits >> (PV_U * p)) & ((1u << PV_U) - 1);
+          if (cm) {
+            u32 lgx = lg; asm volatile("" : "+v"(lgx));
+            const u32 li = p * PV_LPP + lgx;
+            const u32 end = (u32)lt_es[li];
+            const u32 cur = lt_cur[li];
+            gu32* base = (gu32*)(uintptr_t)lt_base[li];
+#pragma unroll
+            for (int u = 0; u < PV_U; u++) {
+              if ((cm >> u) & 1u) {
+                const u32 tix = cur + ((r + PV_G * u - cur) & (PV_W - 1));    // the slot's record in the new window
+                rec[p][u] = rec_none();
+                if (tix < end) rec[p][u] = *(gu32x3*)(base + (u64)tix * RB4);
               }
             }
           }
         }
-        // the lists' 8 lanes: new cursor + statistics of this attempt -> pending slots (committed on success)
-#pragma unroll
-        for (int off = 1; off < PV_G; off <<= 1) {
-#pragma unroll
-          for (int p = 0; p < PV_PB; p++) {
-            nx[p] = max(nx[p], (u32)__shfl_xor(nx[p], off)); tn[p] += __shfl_xor(tn[p], off); tt[p] += shfl_xor_u64(tt[p], off);
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < PV_PB; p++) {
-          const u32 li = (p0 + p) * PV_LPP + lg;
-          if (p0 + p < npass && li < N && r == 0) { pd_nxt[li] = nx[p]; pd_nso[li] = tn[p]; pd_two[li] = tt[p]; }
-        }
-#ifdef KMX_PHASE_PROF
-        PVPH(8);
-#endif
       }
-      // recurrence of the pivot rows = number of lists that deposited a (solid) count: wave j counts row j
+      PVPH(8);
       pv_lds_barrier();
+      // recurrence of the image rows = number of lists that deposited a (solid) count: wave j counts row j
       {
         const u32 wv = tid >> 6;
-        for (u32 j = wv; j < rte; j += PV_TPB / 64) {
+        for (u32 j = wv; j < nrows; j += PV_TPB / 64) {
           u32 nz = 0;
           if (MODE == 0) { const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);
                            for (u32 t = lane; t < N; t += 64) nz += rowc[t] != 0 ? 1u : 0u; }
@@ -301,34 +428,19 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       PVPH(2);
       const u32 ovn = sh[1];
       if (ovn > (u32)PV_OVCAP) {
-        // the overflow does not fit: retry this tile with fewer pivot records (the image, counters
-        // and overflow buffer are rebuilt; cursors and statistics were not committed)
-        if (rte > 1 && !split) rt_try = max(1u, rte >> 1);
-        else {
-          // one pivot gap alone holds more than the buffer: cut it at the largest buffered key.  A key
-          // has at most N <= 1024 records, so the buffer holds >= 2 distinct keys and the part below
-          // the cut is strictly smaller -- repeated cuts always terminate.
-          Key<KW> mx; for (int q = 0; q < KW; q++) mx.w[q] = 0;
-          for (u32 t = tid; t < (u32)PV_OVCAP; t += PV_TPB) { const Key<KW> k = ov[t].key; if (key_less<KW>(mx, k)) mx = k; }
-          // max = min of the complemented key
-          Key<KW> cm; for (int q = 0; q < KW; q++) cm.w[q] = ~mx.w[q];
-          cm = wave_min_key<KW>(cm);
-          if (lane == 0) pk[tid >> 6] = cm;        // pk is rebuilt at the top of the next attempt
-          pv_lds_barrier();
-          Key<KW> best = pk[0];
-          for (int v = 1; v < PV_TPB / 64; v++) best = key_min<KW>(best, pk[v]);
-          for (int q = 0; q < KW; q++) ksplit.w[q] = ~best.w[q];
-          split = true;
-        }
-        pv_lds_barrier();
-        continue;
+        // the rows do not cover the other lists here: flag the task, the driver re-runs the batch with
+        // k_merge_rows.  Leave the tables clean for the next work item.
+        for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
+        failed = true;
+        break;
       }
-      for (u32 i = tid; i < N; i += PV_TPB) { lt_cur[i] = pd_nxt[i]; lt_nso[i] += pd_nso[i]; lt_two[i] += pd_two[i]; }   // commit
 
       // ---- overflow records: merge them among themselves (hash set, as k_merge_rows) ----
-      u32 hs[2] = {0, 0}; u32 ownm = 0, solidm = 0;
+      constexpr int OQ = PV_OVCAP / PV_TPB;
+      u32 hs[OQ]; u32 ownm = 0, solidm = 0;
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < OQ; q++) {
+        hs[q] = 0;
         const u32 t = tid + q * PV_TPB;
         if (t < ovn) {
           const OvRec<KW> o = ov[t];
@@ -340,12 +452,12 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             h = (h + 1) & (PV_OT - 1);
           }
           hs[q] = h;
-          if (o.cnt >= T.soft_min[o.list]) { solidm |= 1u << q; if ((old >> 16) < sat) atomicAdd(&otab[h], 1u << 16); }
+          if (o.cnt >= (u32)(lt_es[o.list] >> 32)) { solidm |= 1u << q; if ((old >> 16) < sat) atomicAdd(&otab[h], 1u << 16); }
         }
       }
       pv_lds_barrier();
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < OQ; q++) {
         if ((ownm >> q) & 1u) {
           const u32 e = otab[hs[q]];
           if ((e >> 16) >= rec_min) { const u32 pos = atomicAdd(&sh[2], 1u); okl[pos] = (u16)hs[q]; }
@@ -357,37 +469,39 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       const u32 nok = sh[2];
       // ---- final row order: kept pivot rows and kept overflow keys together ----
       u32 nkp = 0;
-      for (u32 j = 0; j < rte; j++) nkp += prec[j] >= rec_min ? 1u : 0u;
+      for (u32 j = 0; j < nrows; j++) nkp += prec[j] >= rec_min ? 1u : 0u;
       const u32 nk = nkp + nok;
-      for (u32 it = tid; it < rte + nok; it += PV_TPB) {
+      for (u32 it = tid; it < nrows + nok; it += PV_TPB) {
         Key<KW> mine; bool kept = true;
-        if (it < rte) { mine = pk[it]; kept = prec[it] >= rec_min; }
-        else mine = ov[(otab[okl[it - rte]] & 0xFFFFu) - 1].key;
+        if (it < nrows) { mine = pk[it]; kept = prec[it] >= rec_min; }
+        else mine = ov[(otab[okl[it - nrows]] & 0xFFFFu) - 1].key;
         u32 rk = 0;
-        for (u32 j = 0; j < rte; j++) rk += (prec[j] >= rec_min && key_less<KW>(pk[j], mine)) ? 1u : 0u;
+        for (u32 j = 0; j < nrows; j++) rk += (prec[j] >= rec_min && key_less<KW>(pk[j], mine)) ? 1u : 0u;
         for (u32 j = 0; j < nok; j++) rk += key_less<KW>(ov[(otab[okl[j]] & 0xFFFFu) - 1].key, mine) ? 1u : 0u;
-        if (it < rte) prank[it] = kept ? rk : 0xFFFFFFFFu;
-        else orank[it - rte] = (u16)rk;
+        if (it < nrows) prank[it] = kept ? rk : 0xFFFFFFFFu;
+        else orank[it - nrows] = (u16)rk;
       }
       if (tid == 0) {
         u64 off = 0;
         if (nk) {
+          u64 ch_base = al64[0]; u32 ch_used = al[0], ch_cap = al[1], ch_ok = al[3];
           if (ch_used + nk > ch_cap) {
             if (ch_used) {
               const u64 sidx = atomicAdd(&T.ctrl[1], 1ULL);
-              if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = ch_seq; sg.row_off = ch_base; sg.nrows = ch_used; sg.pad = 0; T.segs[sidx] = sg; }
+              if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = al[2]; sg.row_off = ch_base; sg.nrows = ch_used; sg.pad = 0; T.segs[sidx] = sg; }
               else atomicOr(&T.ctrl[2], (u64)ERR_SEGS_OVERFLOW);
               atomicAdd(&T.ctrl[3], (u64)ch_used);
             }
             ch_cap = max(chunk_rows, nk);
             ch_base = atomicAdd(&T.ctrl[0], (u64)ch_cap);
-            ch_used = 0; ch_seq = seq;
+            ch_used = 0; al[2] = seq;
             ch_ok = (ch_base + ch_cap <= T.out_cap_rows) ? 1u : 0u;
             if (!ch_ok) atomicOr(&T.ctrl[2], (u64)ERR_ROWS_OVERFLOW);
           }
           off = ch_base + ch_used; ch_used += nk;
+          al64[0] = ch_base; al[0] = ch_used; al[1] = ch_cap; al[3] = ch_ok;
         }
-        sh64[0] = off; sh[3] = ch_ok;
+        sh64[0] = off; sh[3] = al[3];
       }
       pv_lds_barrier();
       // overflow-key ranks go into their table entries (low 16 bits; the owner index is no longer needed)
@@ -404,16 +518,22 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       // ---- rows out: kept pivot rows from the LDS image; overflow rows zero-filled in HBM ----
       if (can_write) {
         const int wave = tid >> 6;
-        for (u32 j = wave; j < rte + nok; j += PV_TPB / 64) {
-          if (j < rte) {
+        for (u32 j = wave; j < nrows + nok; j += PV_TPB / 64) {
+          if (j < nrows) {
             const u32 rk = prank[j];
             if (rk == 0xFFFFFFFFu) continue;
             const u8* src = img + j * row_bytes;
             u8* dst = out0 + (u64)rk * row_bytes;
-            if (MODE == 0) { for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = reinterpret_cast<const u32*>(src)[t]; }
+            if (MODE == 0) {
+              if (((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(j * row_bytes) | row_bytes) & 7u) == 0) {
+                for (u32 t = lane; t < row_bytes / 8; t += 64) reinterpret_cast<u64*>(dst)[t] = reinterpret_cast<const u64*>(src)[t];
+              } else {
+                for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = reinterpret_cast<const u32*>(src)[t];
+              }
+            }
             else { for (u32 t = lane; t < row_bytes; t += 64) dst[t] = src[t]; }
           } else {
-            u8* dst = out0 + (u64)orank[j - rte] * row_bytes;
+            u8* dst = out0 + (u64)orank[j - nrows] * row_bytes;
             if (MODE == 0) { for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = 0; }
             else { for (u32 t = lane; t < row_bytes; t += 64) dst[t] = 0; }
           }
@@ -422,7 +542,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       __syncthreads();   // zero-filled overflow rows are in memory before their entries are scattered
       PVPH(5);
 #pragma unroll
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < OQ; q++) {
         const u32 t = tid + q * PV_TPB;
         if (t < ovn) {
           const OvRec<KW> o = ov[t];
@@ -461,23 +581,23 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
       pv_lds_barrier();
 #pragma unroll
-      for (int q = 0; q < 2; q++) if ((ownm >> q) & 1u) otab[hs[q]] = 0;   // hash set clean for the next tile
+      for (int q = 0; q < OQ; q++) if ((ownm >> q) & 1u) otab[hs[q]] = 0;   // hash set clean for the next tile
+      for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;            // ... and the row table
       PVPH(6);
-      ppos += rte;
+      ppos += rte_eff;
       seq++;
-      rt_try = rt_cap;
-      split = false;
       // the range ends with its open-ended tile (that one takes everything the lists have left)
-      if (open_end) break;
+      if (done) break;
       pv_lds_barrier();
     }
 
     // ---- range done ----
     if (tid == 0) {
       if (failed) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
+      const u32 ch_used = al[0];
       if (ch_used) {
         const u64 sidx = atomicAdd(&T.ctrl[1], 1ULL);
-        if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = ch_seq; sg.row_off = ch_base; sg.nrows = ch_used; sg.pad = 0; T.segs[sidx] = sg; }
+        if (sidx < T.seg_cap) { Seg sg; sg.range = range; sg.seq = al[2]; sg.row_off = al64[0]; sg.nrows = ch_used; sg.pad = 0; T.segs[sidx] = sg; }
         else atomicOr(&T.ctrl[2], (u64)ERR_SEGS_OVERFLOW);
         atomicAdd(&T.ctrl[3], (u64)ch_used);
       }
@@ -493,8 +613,6 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 
 template __global__ void k_merge_pivot<1, 0>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_pivot<1, 1>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_pivot<2, 0>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_pivot<2, 1>(const TaskDev*, const uint2*, u32, u32*);
 
 #ifdef KMX_PHASE_PROF
 void pivot_phase_prof_dump()
@@ -502,7 +620,7 @@ void pivot_phase_prof_dump()
   u64 h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_pivot_prof), sizeof(h)) != hipSuccess) return;
   u64 tot = 0; for (int i = 0; i < 9; i++) tot += h[i];
-  static const char* nm[9] = {"setup", "tile-init", "scan-rest", "ov-hash", "publish+rank", "rows-out", "ov-scatter", "scan-loadwait", "scan-process"};
+  static const char* nm[9] = {"setup", "tile-init", "recurrence", "ov-hash", "publish+rank", "rows-out", "ov-scatter", "-", "scan"};
   for (int i = 0; i < 9; i++) fprintf(stderr, "[pivot] %-14s %6.2f%%  %llu\n", nm[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
   memset(h, 0, sizeof(h));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_pivot_prof), h, sizeof(h));
@@ -510,8 +628,8 @@ void pivot_phase_prof_dump()
 #endif
 
 int pivot_lds_bytes(int kw)
-{ return PV_IMG + PV_OVCAP * (kw * 8 + 8) + PV_OT * 4 + 384 + PV_OVCAP * 4 + 64 + 40960; }   // image + overflow + hash set + list state
-u32 pivot_max_lists() { return PV_TPB; }
+{ return PV_IMG + PV_OVCAP * (kw * 8 + 8) + PV_OT * 4 + 1280 + PV_PT * (kw * 8 + 8) + PV_OVCAP * 4 + 32768; }   // image + overflow + hash set + tables + list state
+u32 pivot_max_lists() { return PV_MAXN; }
 
 hipError_t launch_merge_pivot(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
                               u32 grid_x, hipStream_t st)
@@ -527,8 +645,6 @@ hipError_t launch_merge_pivot(int kw, int mode, const TaskDev* tasks, const uint
   } while (0)
   if (kw == 1 && mode == 0) KMX_LAUNCH(1, 0);
   else if (kw == 1 && mode == 1) KMX_LAUNCH(1, 1);
-  else if (kw == 2 && mode == 0) KMX_LAUNCH(2, 0);
-  else if (kw == 2 && mode == 1) KMX_LAUNCH(2, 1);
   else return hipErrorInvalidValue;
 #undef KMX_LAUNCH
   return hipGetLastError();
