@@ -108,7 +108,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, algo_bytes, rows_out = [], 0, 0
+    kernel_ms, algo_bytes, rows_out, kernel_name = [], 0, 0, ""
 
     def run(n, record):
         """n steps = n kmx_merge_dev batches; batch i+1 is submitted before batch i is waited for (the host
@@ -117,12 +117,13 @@ def main():
         nonlocal algo_bytes, rows_out
 
         def finish(res):
-            nonlocal algo_bytes, rows_out
+            nonlocal algo_bytes, rows_out, kernel_name
             res.wait()
             if record:
                 kernel_ms.append(res.kernel_ms())
                 algo_bytes = sum(res.algo_bytes(t) for t in range(P))
                 rows_out = sum(res.rows(t) for t in range(P))
+                kernel_name = res.kernel()
             res.free()
 
         prev = None                      # two batches in flight (double buffering: no new device blocks)
@@ -158,8 +159,8 @@ def main():
                        "records_per_step_per_gpu": total_recs, "rows_out_per_step_per_gpu": rows_out,
                        "parallelism": f"partitions sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(a, N, P),
-                         "kernel": "k_merge_rows<1,0>", "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes},
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(a, N, P, kernel_name),
+                         "kernel": kernel_name + "<1,0>", "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(parts[0], N, a.rec_min)
@@ -170,7 +171,7 @@ def main():
     ctx.close()
 
 
-def pmc_traffic(a, N, P):
+def pmc_traffic(a, N, P, kernel):
     """HBM bytes per launch of the merge kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE + WRITE_SIZE, profiles/merge_pmc.json) -- only when they were taken on this workload."""
     try:
@@ -178,6 +179,7 @@ def pmc_traffic(a, N, P):
     except Exception:
         return None
     key = f"configs[2] {N}x{P} G={a.genome:.0e} d={a.subst_rate} rec_min={a.rec_min}".replace("e+0", "e")
+    d = d.get(kernel, {})
     return d["fetch_bytes"] + d["write_bytes"] if d.get("workload") == key else None
 
 

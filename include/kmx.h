@@ -110,6 +110,9 @@ int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, k
 int      kmx_result_wait(kmx_merge_result* r);
 /* duration in ms of the batch's merge kernel launch (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
 double   kmx_result_kernel_ms(kmx_merge_result* r);
+/* name of the device kernel that produced the result ("k_merge_rows", "k_merge_pivot", "k_merge_bf"); valid after
+ * kmx_result_wait (a pivot batch handed back to k_merge_rows reports k_merge_rows) */
+const char* kmx_result_kernel(const kmx_merge_result* r);
 uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA) or window rows (BF/BFC) */
 uint64_t kmx_result_row_bytes(const kmx_merge_result* r, uint32_t task);
 uint64_t kmx_result_body_bytes(const kmx_merge_result* r, uint32_t task);  /* rows * row_bytes */

@@ -231,13 +231,19 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->n_items = n_items; R->max_n = max_n; R->max_c = max_c;
   R->grid = std::min(n_items, is_bf ? slots : (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)kw));
   {
-    // k_merge_rows is the production kernel.  KMX_MERGE_KERNEL=pivot selects the experimental
-    // pivot-tiled kernel (merge_pivot.hip; 64-bit keys, no share-min, <= 1024 lists) for A/B runs; tasks
-    // it flags as not covered by their pivot are re-run with k_merge_rows.
-    bool rescue = false;
-    for (auto& H : R->tasks) rescue |= H.share_min > 0;
+    // Two COUNT/PA kernels.  k_merge_rows is the general one.  k_merge_pivot (merge_pivot.hip; 64-bit keys,
+    // no share-min, <= 1024 lists) is faster when MANY lists share most of their keys -- the cohort
+    // case the metric is quoted on -- and flags tasks it does not suit (they are re-run with
+    // k_merge_rows, see kmx_result_wait).  Default: pivot for batches of more than 512 lists per task
+    // (where k_merge_rows is down to 4-record windows).
+    // KMX_MERGE_KERNEL=rows|pivot forces one of them (pivot only where it is applicable).
+    bool rescue = false; u32 min_n = 0xFFFFFFFFu;
+    for (auto& H : R->tasks) { rescue |= H.share_min > 0; min_n = std::min(min_n, H.N); }
     const char* force = getenv("KMX_MERGE_KERNEL");
-    R->use_pivot = force && !strcmp(force, "pivot") && !is_bf && !rescue && kw == 1 && max_n <= pivot_max_lists();
+    const bool can = !is_bf && !rescue && kw == 1 && max_n <= pivot_max_lists();
+    if (force && !strcmp(force, "pivot")) R->use_pivot = can;
+    else if (force && !strcmp(force, "rows")) R->use_pivot = false;
+    else R->use_pivot = can && min_n > 512;
     if (R->use_pivot) R->grid = std::min(n_items, (u32)ctx->n_cu);   // one 1024-thread workgroup per CU
   }
   if (is_bf) {
@@ -406,6 +412,9 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   R->waited = true; R->status = KMX_OK;
   return KMX_OK;
 }
+
+extern "C" const char* kmx_result_kernel(const kmx_merge_result* R)
+{ return !R ? "" : R->is_bf ? "k_merge_bf" : R->use_pivot ? "k_merge_pivot" : "k_merge_rows"; }
 
 extern "C" double kmx_result_kernel_ms(kmx_merge_result* R)
 {

@@ -71,7 +71,7 @@ template <int KW> __device__ __forceinline__ u32 pv_mix(const Key<KW>& k)
 template <int KW> __device__ __forceinline__ u32 pv_hash(const Key<KW>& k) { return pv_mix<KW>(k) & (PV_OT - 1); }
 // the tile's pivot keys are neighbours in key order: a multiplicative hash of the low bits spreads them
 template <int KW> __device__ __forceinline__ u32 pv_thash(const Key<KW>& k)
-{ return (((u32)k.w[0] ^ (u32)(k.w[0] >> 29)) * 0x9E3779B1u) >> 25; }
+{ return (__umul24(((u32)k.w[0] ^ (u32)(k.w[0] >> 23)) & 0xFFFFFFu, 0x9E3779u) >> 15) & (PV_PT - 1); }
 
 template <int KW> __device__ __forceinline__ Key<KW> gload_key(gu32* p)
 {
@@ -111,7 +111,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   Key<KW>* pk = reinterpret_cast<Key<KW>*>(misc);                                         // [32] keys of the image rows (pivot rows, then adopted rows)
   u32* prec = reinterpret_cast<u32*>(misc + 256);                                         // [32] recurrence
   u32* prank = reinterpret_cast<u32*>(misc + 384);                                        // [32] final row or ~0
-  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] ovn [2] nok [3] can-write [4] adopted rows [5] candidates
+  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] ovn [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed
   u64* sh64 = reinterpret_cast<u64*>(misc + 576);                                         // [0] tile row base [1] upper key [2] cut
   u64* cand = reinterpret_cast<u64*>(misc + 640);                                        // [PV_NC] helper keys the pivot lacks
   PvEnt<KW>* ptab = reinterpret_cast<PvEnt<KW>*>(misc + 1280);                             // [PV_PT] row key -> row
@@ -121,10 +121,9 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   // per-list state (a list is served by 8 lanes, a lane serves up to 8 lists)
   unsigned char* lt = m2 + PV_OVCAP * 4;
   u64* lt_base = reinterpret_cast<u64*>(lt);                    // [1024] record base
-  u64* lt_es = reinterpret_cast<u64*>(lt + 8192);               // [1024] range end (low) | soft-min (high)
-  u64* lt_two = reinterpret_cast<u64*>(lt + 16384);             // [1024] TOTAL_WO of the range so far
-  u32* lt_nso = reinterpret_cast<u32*>(lt + 24576);             // [1024] NON_SOLID so far
-  u32* lt_cur = reinterpret_cast<u32*>(lt + 28672);             // [1024] cursor: first record not yet consumed
+  uint4* lt_st = reinterpret_cast<uint4*>(lt + 8192);           // [1024] x: range end, y: soft-min, z: cursor (first record not yet consumed)
+  u64* lt_two = reinterpret_cast<u64*>(lt + 24576);             // [1024] TOTAL_WO of the range so far
+  u32* lt_nso = reinterpret_cast<u32*>(lt + 32768);             // [1024] NON_SOLID so far
   // row-space allocator state (thread 0 only; kept out of the register file)
   u64* al64 = reinterpret_cast<u64*>(misc + 608);               // [0] chunk base
   u32* al = reinterpret_cast<u32*>(misc + 616);                 // [0] used [1] cap [2] seq [3] ok
@@ -133,7 +132,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   for (int t = tid; t < PV_OT; t += PV_TPB) otab[t] = 0;
   for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
 #ifdef KMX_PHASE_PROF
-  long long pt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pc = clock64();
+  long long pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pc = clock64();
 #define PVPH(i) do { const long long n_ = clock64(); pt[i] += n_ - pc; pc = n_; } while (0)
 #else
 #define PVPH(i) do {} while (0)
@@ -146,7 +145,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     __syncthreads();
     if (item >= n_items) {
 #ifdef KMX_PHASE_PROF
-      if (tid == 0) for (int i = 0; i < 9; i++) atomicAdd(&kmx_pivot_prof[i], (u64)pt[i]);
+      if (tid == 0) for (int i = 0; i < 16; i++) atomicAdd(&kmx_pivot_prof[i], (u64)pt[i]);
 #endif
       return;
     }
@@ -165,9 +164,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     const u32 gsh = lane & ~(PV_G - 1);                         // first lane of my list's lane group
     for (u32 i = tid; i < N; i += PV_TPB) {
       lt_base[i] = (u64)(uintptr_t)T.recs[i];
-      lt_es[i] = (u64)T.bounds[(u64)(range + 1) * N + i] | ((u64)T.soft_min[i] << 32);
+      lt_st[i] = make_uint4(T.bounds[(u64)(range + 1) * N + i], T.soft_min[i], T.bounds[(u64)range * N + i], 0u);
       lt_nso[i] = 0; lt_two[i] = 0;
-      lt_cur[i] = T.bounds[(u64)range * N + i];
     }
     // circular windows: lane r, slot u of a list holds the record whose index is == r + 8u (mod 16)
     // inside [cur, cur + 16)
@@ -200,7 +198,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     // helpers = the first PV_NH lists that are not the pivot (all served in pass 0)
     const u32 hmax = min(N, (u32)PV_NH + (T.pivot <= (u32)PV_NH ? 1u : 0u));   // lists [0, hmax) minus the pivot
     if (tid == 0) { al64[0] = 0; al[0] = 0; al[1] = 0; al[2] = 0; al[3] = 1; }
-    u32 seq = 0;
+    u32 seq = 0, ovsum = 0, conssum = 0;
     bool failed = false;
     __syncthreads();
 
@@ -220,9 +218,10 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         const u32 zb = rows_cap * row_bytes;
         uint4* z = reinterpret_cast<uint4*>(img);
         for (u32 t = tid; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
-        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; }
+        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
       }
       pv_lds_barrier();
+      PVPH(1);
       Key<KW> khi; khi.w[0] = open_end ? ~0ULL : sh64[1];
       if ((u32)tid < rte) {   // row keys
         const Key<KW> mine = pkn;
@@ -237,14 +236,16 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
       // ---- window check: a list whose whole window lies below khi with records behind it cuts the tile
       //      at its last window key (everything up to that key is inside every list's window) ----
+      uint4 stn = lg < N ? lt_st[lg] : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int p = 0; p < PV_NP; p++) {
         __builtin_amdgcn_sched_barrier(0);
         if ((u32)p < npass) {
           u32 lgx = lg; asm volatile("" : "+v"(lgx));
           const u32 li = p * PV_LPP + lgx;
-          const u32 end = li < N ? (u32)lt_es[li] : 0u;
-          const u32 cur = li < N ? lt_cur[li] : 0u;
+          const uint4 st = stn;                          // this pass's list state was read one pass ahead
+          if (p + 1 < PV_NP && (u32)(p + 1) < npass) stn = li + PV_LPP < N ? lt_st[li + PV_LPP] : make_uint4(0, 0, 0, 0);
+          const u32 end = st.x, cur = st.z;
           u32 allb = 1; u64 lastk = 0; bool holds_last = false;
 #pragma unroll
           for (int u = 0; u < PV_U; u++) {
@@ -264,7 +265,9 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           if (allb && holds_last && cur + PV_W < end) atomicMin(&sh64[2], lastk + 1);
         }
       }
+      PVPH(9);
       pv_lds_barrier();
+      PVPH(10);
       {   // candidates seen in >= 2 helpers become rows, smallest keys first; the first one left without a row cuts the tile
         const u32 nc = min(sh[5], (u32)PV_NC);
         if ((u32)tid < nc) {
@@ -301,7 +304,9 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           }
         }
       }
+      PVPH(11);
       pv_lds_barrier();
+      PVPH(12);
       const u64 lim = sh64[2];                     // exclusive upper key of the tile
       const bool unbounded = lim == ~0ULL;         // open-ended tile, not cut
       const u32 nrows = rte + min(sh[4], rows_cap - rte);
@@ -313,13 +318,11 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         pkn = key_inf<KW>();
         if (!done && (u32)tid <= rt_cap && npos + tid < pend) pkn = gload_key<KW>(pbase + (u64)(npos + tid) * RB4);
       }
-      PVPH(1);
+      PVPH(13);
 
       // ---- scan: every list consumes its records of the tile (keys below lim) ----
-      // Processing and refilling are two sweeps over the passes: a refill issued inside the processing
-      // sweep would sit in front of the next pass's records in the (in-order) load counter, and the
-      // compiler waits for the counter to drain before it touches a window slot.
-      u32 consbits = 0;
+      stn = lg < N ? lt_st[lg] : make_uint4(0, 0, 0, 0);
+      u32 wcons = 0;                            // records consumed by this wave (uniform)
 #pragma unroll
       for (int p = 0; p < PV_NP; p++) {
         __builtin_amdgcn_sched_barrier(0);      // keep the passes apart: interleaving them only costs registers
@@ -328,31 +331,35 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           // spill, and a scratch reload has to wait for every record load in flight
           u32 lgx = lg; asm volatile("" : "+v"(lgx));
           const u32 li = p * PV_LPP + lgx;
-          const u64 es = li < N ? lt_es[li] : 0ULL;
-          const u32 end = (u32)es, smin = (u32)(es >> 32);
-          const u32 cur = li < N ? lt_cur[li] : 0;
+          const uint4 st = stn;
+          if (p + 1 < PV_NP && (u32)(p + 1) < npass) stn = li + PV_LPP < N ? lt_st[li + PV_LPP] : make_uint4(0, 0, 0, 0);
+          const u32 end = st.x, smin = st.y, cur = st.z;
           u32 consm = 0, ovm = 0, tn = 0; u64 tsum = 0;
+          // both slots probe the row table before either result is looked at
+          uint4 pe[PV_U];
+#pragma unroll
+          for (int u = 0; u < PV_U; u++) pe[u] = reinterpret_cast<const uint4*>(ptab)[pv_thash<KW>(rec_key(rec[p][u]))];
 #pragma unroll
           for (int u = 0; u < PV_U; u++) {
+            // straight-line on purpose: one table probe (16-byte entry in one LDS read) for every lane,
+            // masks instead of nested branches
             const u32 ix = cur + ((r + PV_G * u - cur) & (PV_W - 1));
             const Key<KW> k = rec_key(rec[p][u]);
             const bool cons = ix < end && (unbounded || k.w[0] < lim);
-            if (cons) {
-              consm |= 1u << u;
-              const u32 c = rec[p][u].z;
-              const bool solid = c >= smin;
-              if (solid) tsum += c; else tn++;
-              u32 h = pv_thash<KW>(k);
-              u32 idx = ptab[h].idx;
-              if (idx != 0 && !key_eq<KW>(ptab[h].key, k)) idx = pv_lookup_slow<KW>(ptab, k, h);
-              if (idx) {
-                if (solid) {
-                  const u32 row = idx - 1;
-                  if (MODE == 0) reinterpret_cast<u32*>(img + row * row_bytes + KW * 8)[li] = c;
-                  else { const u32 ob = row * row_bytes + KW * 8 + (li >> 3);
-                         atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u))); }
-                }
-              } else ovm |= 1u << u;
+            const u32 c = rec[p][u].z;
+            const bool solid = cons && c >= smin;
+            const uint4 e = pe[u];                                       // key lo, key hi, idx, pad
+            u32 idx = e.z;
+            if (((e.x ^ (u32)k.w[0]) | (e.y ^ (u32)(k.w[0] >> 32))) != 0 && idx != 0) idx = pv_lookup_slow<KW>(ptab, k, pv_thash<KW>(k));
+            consm |= (cons ? 1u : 0u) << u;
+            ovm |= ((cons && idx == 0) ? 1u : 0u) << u;
+            tsum += solid ? c : 0u;
+            tn += (cons && !solid) ? 1u : 0u;
+            if (solid && idx != 0) {
+              const u32 row = idx - 1;
+              if (MODE == 0) reinterpret_cast<u32*>(img + __umul24(row, row_bytes) + KW * 8)[li] = c;
+              else { const u32 ob = __umul24(row, row_bytes) + KW * 8 + (li >> 3);
+                     atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u))); }
             }
           }
           // overflow records of this pass: one LDS atomic per wave
@@ -377,30 +384,22 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           // records consumed by my list (a prefix of its window): statistics and the new cursor
           u32 c = 0;
 #pragma unroll
-          for (int u = 0; u < PV_U; u++) { const u64 b = __ballot((consm >> u) & 1u); c += __popc((u32)(b >> gsh) & ((1u << PV_G) - 1)); }
+          for (int u = 0; u < PV_U; u++) { const u64 b = __ballot((consm >> u) & 1u); c += __popc((u32)(b >> gsh) & ((1u << PV_G) - 1)); wcons += __popcll(b); }
           if (consm) {
             if (tsum) atomicAdd(&lt_two[li], tsum);
             if (tn) atomicAdd(&lt_nso[li], tn);
           }
-          if (r == 0 && c) lt_cur[li] = cur + c;
-          consbits |= consm << (PV_U * p);
-        }
-      }
-      // refill sweep: a consumed slot takes the record 16 positions further, in place
-#pragma unroll
-      for (int p = 0; p < PV_NP; p++) {
-        if ((u32)p < npass) {
-          const u32 cm = (consbits >> (PV_U * p)) & ((1u << PV_U) - 1);
-          if (cm) {
-            u32 lgx = lg; asm volatile("" : "+v"(lgx));
-            const u32 li = p * PV_LPP + lgx;
-            const u32 end = (u32)lt_es[li];
-            const u32 cur = lt_cur[li];
+          if (r == 0 && c) reinterpret_cast<u32*>(lt_st + li)[2] = cur + c;
+          // refill in place: a consumed slot takes the record 16 positions further.  Every window slot
+          // was touched (and its pending load waited for) by the window sweep, so these loads do not
+          // stall the passes behind this one; they land while the rest of the tile is processed.
+          if (consm) {
             gu32* base = (gu32*)(uintptr_t)lt_base[li];
+            const u32 ncur = cur + c;
 #pragma unroll
             for (int u = 0; u < PV_U; u++) {
-              if ((cm >> u) & 1u) {
-                const u32 tix = cur + ((r + PV_G * u - cur) & (PV_W - 1));    // the slot's record in the new window
+              if ((consm >> u) & 1u) {
+                const u32 tix = ncur + ((r + PV_G * u - ncur) & (PV_W - 1));    // the slot's record in the new window
                 rec[p][u] = rec_none();
                 if (tix < end) rec[p][u] = *(gu32x3*)(base + (u64)tix * RB4);
               }
@@ -408,15 +407,23 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           }
         }
       }
+      if (lane == 0 && wcons) atomicAdd(&sh[6], wcons);
       PVPH(8);
+      PVPH(14);
       pv_lds_barrier();
+      PVPH(15);
       // recurrence of the image rows = number of lists that deposited a (solid) count: wave j counts row j
       {
         const u32 wv = tid >> 6;
         for (u32 j = wv; j < nrows; j += PV_TPB / 64) {
           u32 nz = 0;
-          if (MODE == 0) { const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);
-                           for (u32 t = lane; t < N; t += 64) nz += rowc[t] != 0 ? 1u : 0u; }
+          if (MODE == 0) {
+            const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);   // 8-byte aligned: row_bytes = 8 + 4N
+            if ((row_bytes & 7u) == 0) {
+              const uint2* row2 = reinterpret_cast<const uint2*>(rowc);
+              for (u32 t = lane; t < N / 2; t += 64) { const uint2 v = row2[t]; nz += (v.x != 0 ? 1u : 0u) + (v.y != 0 ? 1u : 0u); }
+            } else for (u32 t = lane; t < N; t += 64) nz += rowc[t] != 0 ? 1u : 0u;
+          }
           else { const u8* rowb = img + j * row_bytes + KW * 8;
                  for (u32 t = lane; t < (N + 7) / 8; t += 64) nz += __popc((u32)rowb[t]); }
 #pragma unroll
@@ -427,8 +434,11 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       pv_lds_barrier();
       PVPH(2);
       const u32 ovn = sh[1];
-      if (ovn > (u32)PV_OVCAP) {
-        // the rows do not cover the other lists here: flag the task, the driver re-runs the batch with
+      ovsum += ovn; conssum += sh[6];
+      if (ovn > (u32)PV_OVCAP || (conssum > 65536u && ovsum * 8u > conssum)) {
+        // the rows do not cover the other lists here (overflow buffer full, or more than 1/8 of the
+        // range's records so far are not row keys: lists that do not resemble each other --
+        // k_merge_rows does better there): flag the task, the driver re-runs the batch with
         // k_merge_rows.  Leave the tables clean for the next work item.
         for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
         failed = true;
@@ -452,7 +462,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             h = (h + 1) & (PV_OT - 1);
           }
           hs[q] = h;
-          if (o.cnt >= (u32)(lt_es[o.list] >> 32)) { solidm |= 1u << q; if ((old >> 16) < sat) atomicAdd(&otab[h], 1u << 16); }
+          if (o.cnt >= lt_st[o.list].y) { solidm |= 1u << q; if ((old >> 16) < sat) atomicAdd(&otab[h], 1u << 16); }
         }
       }
       pv_lds_barrier();
@@ -619,16 +629,17 @@ void pivot_phase_prof_dump()
 {
   u64 h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_pivot_prof), sizeof(h)) != hipSuccess) return;
-  u64 tot = 0; for (int i = 0; i < 9; i++) tot += h[i];
-  static const char* nm[9] = {"setup", "tile-init", "recurrence", "ov-hash", "publish+rank", "rows-out", "ov-scatter", "-", "scan"};
-  for (int i = 0; i < 9; i++) fprintf(stderr, "[pivot] %-14s %6.2f%%  %llu\n", nm[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
+  u64 tot = 0; for (int i = 0; i < 16; i++) tot += h[i];
+  static const char* nm[16] = {"setup", "T0+barrier", "popcount+bar", "ov-hash", "publish+rank", "rows-out", "ov-scatter+clr", "-", "process-sweep",
+                               "window-sweep", "bar(window)", "candidates", "bar(cand)", "lim+prefetch", "refill-sweep", "bar(scan)"};
+  for (int i = 0; i < 16; i++) fprintf(stderr, "[pivot] %-14s %6.2f%%  %llu\n", nm[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
   memset(h, 0, sizeof(h));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_pivot_prof), h, sizeof(h));
 }
 #endif
 
 int pivot_lds_bytes(int kw)
-{ return PV_IMG + PV_OVCAP * (kw * 8 + 8) + PV_OT * 4 + 1280 + PV_PT * (kw * 8 + 8) + PV_OVCAP * 4 + 32768; }   // image + overflow + hash set + tables + list state
+{ return PV_IMG + PV_OVCAP * (kw * 8 + 8) + PV_OT * 4 + 1280 + PV_PT * (kw * 8 + 8) + PV_OVCAP * 4 + 36864; }   // image + overflow + hash set + tables + list state
 u32 pivot_max_lists() { return PV_MAXN; }
 
 hipError_t launch_merge_pivot(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,

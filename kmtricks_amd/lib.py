@@ -34,6 +34,8 @@ _lib.kmx_last_error.argtypes = [_vp]
 _lib.kmx_stream.restype = _vp
 _lib.kmx_stream.argtypes = [_vp]
 _lib.kmx_set_profiling.argtypes = [_vp, C.c_int]
+_lib.kmx_result_kernel.restype = C.c_char_p
+_lib.kmx_result_kernel.argtypes = [_vp]
 _lib.kmx_result_kernel_ms.restype = C.c_double
 _lib.kmx_result_kernel_ms.argtypes = [_vp]
 _lib.kmx_merge_dev.argtypes = [_vp, C.POINTER(KmxMergeTask), C.c_uint32, C.POINTER(_vp)]
@@ -58,7 +60,7 @@ _lib.kmx_transpose_bits.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, _vp]
 _lib.kmx_superk_partition.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
                                       C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
-EXPORTS = ["kmx_version", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_version", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -243,6 +245,9 @@ class MergeResult:
 
     def kernel_ms(self):
         return _lib.kmx_result_kernel_ms(self._h)
+
+    def kernel(self):
+        return _lib.kmx_result_kernel(self._h).decode()
 
     def rows(self, t=0):
         return _lib.kmx_result_rows(self._h, t)

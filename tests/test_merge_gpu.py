@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 GD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+@pytest.fixture(autouse=True, params=["rows", "pivot"])
+def merge_kernel(request, monkeypatch):
+    """Every merge test runs once per COUNT/PA kernel: k_merge_rows, and k_merge_pivot (which hands tasks it
+    does not suit -- dissimilar lists, 128-bit keys, share-min -- back to k_merge_rows inside libkmx)."""
+    monkeypatch.setenv("KMX_MERGE_KERNEL", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ctx():
     from kmtricks_amd import lib
