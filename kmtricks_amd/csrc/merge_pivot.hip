@@ -4,11 +4,13 @@
 //
 //   * The task's longest list is the PIVOT.  A tile is rt consecutive pivot records; its key range
 //     [first key of the tile, key of the pivot record after the tile) is known before any other list
-//     is looked at, so there is no workgroup-wide bound search and no retry.
-//   * Every list keeps a circular window of 16 records in registers (8 adjacent lanes x 2 slots, a
-//     lane serves up to 8 lists).  A record below the tile's upper key is consumed and its slot is
-//     refilled IN PLACE with the record 16 positions further: every record is loaded exactly once,
-//     a wave load covers 8 lists x 96 contiguous bytes, and the refill has a whole tile to land.
+//     is looked at.  A list whose whole window lies below that key (it is denser than the pivot here)
+//     cuts the tile at its last window key, so everything below the tile's limit is always inside
+//     every list's window: no second round, no retry.
+//   * Every list keeps a circular window of 16 records in registers (4 adjacent lanes x 4 slots, a
+//     lane serves up to 4 lists).  A record below the tile's upper key is consumed and its slot is
+//     refilled IN PLACE with the record 16 positions further: every record is loaded exactly once
+//     (one global_load_dwordx3 straight into the slot), and the refill has a whole tile to land.
 //   * A consumed record whose key IS one of the tile's pivot keys (one probe of a read-only 128-entry
 //     LDS table built per tile: no atomics, same-address reads broadcast) is deposited straight into
 //     row j of the tile's LDS image.  The recurrence of a pivot row is a popcount of its image row.
@@ -16,9 +18,11 @@
 //     LDS overflow buffer; after the scan the (few) overflow records are merged among themselves
 //     with the hash set of k_merge_rows, kept keys are ranked together with the kept pivot rows, and
 //     their (sparse) rows are written straight to HBM.
-//   * If a tile's overflow does not fit (lists that do not resemble their pivot), the task is
-//     flagged and the driver re-runs the batch with k_merge_rows -- results never depend on how well
-//     the pivot covers the other lists.
+//   * A key the pivot lacks but at least two of four helper lists have is adopted as an extra image
+//     row before the scan (a key missing from the pivot is usually present in ~all other lists).
+//   * If the overflow does not fit, or more than 1/8 of the records are not row keys (lists that do
+//     not resemble each other), the task is flagged and the driver re-runs the batch with
+//     k_merge_rows -- results never depend on how well the pivot covers the other lists.
 // Rows leave through the same chunked arena + (range, seq) directory as k_merge_rows.
 #include "kmx_dev.hpp"
 #include <algorithm>
@@ -38,8 +42,12 @@ constexpr int PV_RTMAX = KMX_PV_RT; // pivot records per tile (< window: a simil
 constexpr int PV_IMG = 61440;       // LDS row image bytes (15 rows of 1000 u32 counts)
 constexpr int PV_OVCAP = 2048;      // overflow records per tile
 constexpr int PV_OT = 2 * PV_OVCAP; // overflow hash set entries
-constexpr int PV_G = 8;             // adjacent lanes per list: one wave load covers 8 lists x 96 contiguous bytes
-constexpr int PV_U = 2;             // window slots per lane
+constexpr int PV_OVW = PV_OVCAP / (KMX_PV_TPB / 64);   // ... of which every wave owns a private slice (no atomics to append)
+#ifndef KMX_PV_G
+#define KMX_PV_G 4
+#endif
+constexpr int PV_G = KMX_PV_G;      // adjacent lanes per list: one wave load covers 64/G lists x 12G contiguous bytes
+constexpr int PV_U = 16 / PV_G;     // window slots per lane
 constexpr int PV_W = PV_G * PV_U;   // records per window (power of two)
 constexpr int PV_LPP = PV_TPB / PV_G;   // lists per pass
 constexpr int PV_MAXN = 1024;       // lists per task
@@ -111,8 +119,9 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   Key<KW>* pk = reinterpret_cast<Key<KW>*>(misc);                                         // [32] keys of the image rows (pivot rows, then adopted rows)
   u32* prec = reinterpret_cast<u32*>(misc + 256);                                         // [32] recurrence
   u32* prank = reinterpret_cast<u32*>(misc + 384);                                        // [32] final row or ~0
-  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] ovn [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed
+  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] - [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed
   u64* sh64 = reinterpret_cast<u64*>(misc + 576);                                         // [0] tile row base [1] upper key [2] cut
+  u32* wcnt = reinterpret_cast<u32*>(misc + 1152);                                        // [waves] overflow records in each wave's slice
   u64* cand = reinterpret_cast<u64*>(misc + 640);                                        // [PV_NC] helper keys the pivot lacks
   PvEnt<KW>* ptab = reinterpret_cast<PvEnt<KW>*>(misc + 1280);                             // [PV_PT] row key -> row
   unsigned char* m2 = misc + 1280 + PV_PT * sizeof(PvEnt<KW>);
@@ -322,7 +331,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 
       // ---- scan: every list consumes its records of the tile (keys below lim) ----
       stn = lg < N ? lt_st[lg] : make_uint4(0, 0, 0, 0);
-      u32 wcons = 0;                            // records consumed by this wave (uniform)
+      u32 wcons = 0, wov = 0;                   // records consumed / overflow records of this wave (uniform)
 #pragma unroll
       for (int p = 0; p < PV_NP; p++) {
         __builtin_amdgcn_sched_barrier(0);      // keep the passes apart: interleaving them only costs registers
@@ -362,23 +371,17 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
                      atomicOr(reinterpret_cast<u32*>(img) + (ob >> 2), 1u << (((ob & 3u) << 3) + (li & 7u))); }
             }
           }
-          // overflow records of this pass: one LDS atomic per wave
+          // overflow records of this pass go to the wave's own slice of the buffer: positions from ballots,
+          // the running count stays in a scalar register -- no atomic, no LDS round trip
           {
-            u64 bal[PV_U]; u32 total = 0;
 #pragma unroll
-            for (int u = 0; u < PV_U; u++) { bal[u] = __ballot((ovm >> u) & 1u); total += __popcll(bal[u]); }
-            if (total) {
-              u32 bpos = 0;
-              if (lane == 0) bpos = atomicAdd(&sh[1], total);
-              bpos = __builtin_amdgcn_readfirstlane(bpos);
-#pragma unroll
-              for (int u = 0; u < PV_U; u++) {
-                if ((ovm >> u) & 1u) {
-                  const u32 pos = bpos + __builtin_amdgcn_mbcnt_hi((u32)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal[u], 0u));
-                  if (pos < (u32)PV_OVCAP) { OvRec<KW> o; o.key = rec_key(rec[p][u]); o.cnt = rec[p][u].z; o.list = li; ov[pos] = o; }
-                }
-                bpos += __popcll(bal[u]);
+            for (int u = 0; u < PV_U; u++) {
+              const u64 bal = __ballot((ovm >> u) & 1u);
+              if ((ovm >> u) & 1u) {
+                const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                if (pos < (u32)PV_OVW) { OvRec<KW> o; o.key = rec_key(rec[p][u]); o.cnt = rec[p][u].z; o.list = li; ov[(tid >> 6) * PV_OVW + pos] = o; }
               }
+              wov += __popcll(bal);
             }
           }
           // records consumed by my list (a prefix of its window): statistics and the new cursor
@@ -407,7 +410,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           }
         }
       }
-      if (lane == 0 && wcons) atomicAdd(&sh[6], wcons);
+      if (lane == 0) { if (wcons) atomicAdd(&sh[6], wcons); wcnt[tid >> 6] = wov; }
       PVPH(8);
       PVPH(14);
       pv_lds_barrier();
@@ -416,26 +419,39 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       {
         const u32 wv = tid >> 6;
         for (u32 j = wv; j < nrows; j += PV_TPB / 64) {
+          // ballots + scalar popcounts: no cross-lane reduction (its LDS round trips cost more than the row)
           u32 nz = 0;
           if (MODE == 0) {
             const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);   // 8-byte aligned: row_bytes = 8 + 4N
             if ((row_bytes & 7u) == 0) {
               const uint2* row2 = reinterpret_cast<const uint2*>(rowc);
-              for (u32 t = lane; t < N / 2; t += 64) { const uint2 v = row2[t]; nz += (v.x != 0 ? 1u : 0u) + (v.y != 0 ? 1u : 0u); }
-            } else for (u32 t = lane; t < N; t += 64) nz += rowc[t] != 0 ? 1u : 0u;
-          }
-          else { const u8* rowb = img + j * row_bytes + KW * 8;
-                 for (u32 t = lane; t < (N + 7) / 8; t += 64) nz += __popc((u32)rowb[t]); }
+              for (u32 t0 = 0; t0 < N / 2; t0 += 64) {
+                const u32 t = t0 + lane;
+                uint2 v = make_uint2(0, 0);
+                if (t < N / 2) v = row2[t];
+                nz += __popcll(__ballot(v.x != 0)) + __popcll(__ballot(v.y != 0));
+              }
+            } else {
+              for (u32 t0 = 0; t0 < N; t0 += 64) { const u32 t = t0 + lane; nz += __popcll(__ballot(t < N && rowc[t] != 0)); }
+            }
+          } else {
+            const u8* rowb = img + j * row_bytes + KW * 8;
+            u32 part = 0;
+            for (u32 t = lane; t < (N + 7) / 8; t += 64) part += __popc((u32)rowb[t]);
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) nz += __shfl_xor(nz, off);
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            nz = part;
+          }
           if (lane == 0) prec[j] = nz;
         }
       }
       pv_lds_barrier();
       PVPH(2);
-      const u32 ovn = sh[1];
+      u32 ovn = 0, ovmax = 0;
+#pragma unroll
+      for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = wcnt[v]; ovn += w; ovmax = max(ovmax, w); }
       ovsum += ovn; conssum += sh[6];
-      if (ovn > (u32)PV_OVCAP || (conssum > 65536u && ovsum * 8u > conssum)) {
+      if (ovmax > (u32)PV_OVW || (conssum > 65536u && ovsum * 8u > conssum)) {
         // the rows do not cover the other lists here (overflow buffer full, or more than 1/8 of the
         // range's records so far are not row keys: lists that do not resemble each other --
         // k_merge_rows does better there): flag the task, the driver re-runs the batch with
@@ -452,7 +468,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       for (int q = 0; q < OQ; q++) {
         hs[q] = 0;
         const u32 t = tid + q * PV_TPB;
-        if (t < ovn) {
+        if ((t & (PV_OVW - 1)) < wcnt[t / PV_OVW]) {
           const OvRec<KW> o = ov[t];
           u32 h = pv_hash<KW>(o.key), old;
           for (;;) {
@@ -477,19 +493,40 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       pv_lds_barrier();
       PVPH(3);
       const u32 nok = sh[2];
-      // ---- final row order: kept pivot rows and kept overflow keys together ----
-      u32 nkp = 0;
-      for (u32 j = 0; j < nrows; j++) nkp += prec[j] >= rec_min ? 1u : 0u;
-      const u32 nk = nkp + nok;
-      for (u32 it = tid; it < nrows + nok; it += PV_TPB) {
-        Key<KW> mine; bool kept = true;
-        if (it < nrows) { mine = pk[it]; kept = prec[it] >= rec_min; }
-        else mine = ov[(otab[okl[it - nrows]] & 0xFFFFu) - 1].key;
-        u32 rk = 0;
-        for (u32 j = 0; j < nrows; j++) rk += (prec[j] >= rec_min && key_less<KW>(pk[j], mine)) ? 1u : 0u;
-        for (u32 j = 0; j < nok; j++) rk += key_less<KW>(ov[(otab[okl[j]] & 0xFFFFu) - 1].key, mine) ? 1u : 0u;
-        if (it < nrows) prank[it] = kept ? rk : 0xFFFFFFFFu;
-        else orank[it - nrows] = (u16)rk;
+      // ---- final row order: kept image rows and kept overflow keys together ----
+      u32 nk = 0;
+      if (nrows + nok <= 64) {
+        // the usual case, done by wave 0 alone: every lane holds one key, the others are read with
+        // v_readlane -- no LDS round trip per comparison
+        if (tid < 64) {
+          const u32 it = lane, n = nrows + nok;
+          Key<KW> mine = key_inf<KW>(); bool kept = false;
+          if (it < nrows) { mine = pk[it]; kept = prec[it] >= rec_min; }
+          else if (it < n) { mine = ov[(otab[okl[it - nrows]] & 0xFFFFu) - 1].key; kept = true; }
+          const u64 keptmask = __ballot(kept);
+          u32 rk = 0;
+          for (u32 j = 0; j < n; j++) {
+            const u64 kj = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine.w[0], (int)j) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine.w[0] >> 32), (int)j) << 32);
+            rk += (((keptmask >> j) & 1ULL) && kj < mine.w[0]) ? 1u : 0u;
+          }
+          if (it < nrows) prank[it] = kept ? rk : 0xFFFFFFFFu;
+          else if (it < n) orank[it - nrows] = (u16)rk;
+          nk = (u32)__popcll(keptmask);
+        }
+      } else {
+        u32 nkp = 0;
+        for (u32 j = 0; j < nrows; j++) nkp += prec[j] >= rec_min ? 1u : 0u;
+        nk = nkp + nok;
+        for (u32 it = tid; it < nrows + nok; it += PV_TPB) {
+          Key<KW> mine; bool kept = true;
+          if (it < nrows) { mine = pk[it]; kept = prec[it] >= rec_min; }
+          else mine = ov[(otab[okl[it - nrows]] & 0xFFFFu) - 1].key;
+          u32 rk = 0;
+          for (u32 j = 0; j < nrows; j++) rk += (prec[j] >= rec_min && key_less<KW>(pk[j], mine)) ? 1u : 0u;
+          for (u32 j = 0; j < nok; j++) rk += key_less<KW>(ov[(otab[okl[j]] & 0xFFFFu) - 1].key, mine) ? 1u : 0u;
+          if (it < nrows) prank[it] = kept ? rk : 0xFFFFFFFFu;
+          else orank[it - nrows] = (u16)rk;
+        }
       }
       if (tid == 0) {
         u64 off = 0;
@@ -554,7 +591,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 #pragma unroll
       for (int q = 0; q < OQ; q++) {
         const u32 t = tid + q * PV_TPB;
-        if (t < ovn) {
+        if ((t & (PV_OVW - 1)) < wcnt[t / PV_OVW]) {
           const OvRec<KW> o = ov[t];
           const u32 e = otab[hs[q]];
           const u32 rec = e >> 16, rk = e & 0xFFFFu;

@@ -4,4 +4,4 @@ set -e
 cd $GRAFT_REPO_ROOT/kmtricks_amd/csrc
 make clean >/dev/null; make -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DKMX_PHASE_PROF $1" >/dev/null 2>&1
 cd ../..
-python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -12 | cut -c1-260
+python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | tail -24 | cut -c1-260
