@@ -66,6 +66,22 @@ __global__ void k_range_bounds(const TaskDev* __restrict__ tasks, u32 max_c)
     const Key<KW> q = load_key<KW>(T.recs[T.pivot] + (u64)pos * RB);
     const u8* base = T.recs[i];
     u32 lo = 0, hi = n;
+    if (n) {
+      // lists of a cohort resemble their pivot: gallop outwards from the proportional position, then
+      // bisect the bracket (a handful of dependent loads instead of log2(n))
+      const u32 g = (u32)min((u64)n - 1, ((u64)pos * n) / np);
+      if (key_less<KW>(load_key<KW>(base + (u64)g * RB), q)) {
+        lo = g + 1;
+        u32 step = 1, pr = g + 1;
+        while (pr < n && key_less<KW>(load_key<KW>(base + (u64)pr * RB), q)) { lo = pr + 1; step <<= 1; pr = g + step; }
+        hi = min(pr, n);
+      } else {
+        hi = g;
+        u32 step = 1;
+        while (step <= g && !key_less<KW>(load_key<KW>(base + (u64)(g - step) * RB), q)) { hi = g - step; step <<= 1; }
+        lo = step <= g ? g - step + 1 : 0;
+      }
+    }
     while (lo < hi) {
       u32 mid = lo + ((hi - lo) >> 1);
       Key<KW> k = load_key<KW>(base + (u64)mid * RB);
