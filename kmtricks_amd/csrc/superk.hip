@@ -4,13 +4,14 @@
 // 857-884, 1010-1139, 1254-1287, 1388-1433; kmer/impl/Sequence2SuperKmer.hpp:80-158;
 // include/kmtricks/gatb/fill_partitions.hpp:59-105).
 //
-//   pass 1  k_superk_scan<false>: one thread per read rolls the forward k-mer, tracks the window
-//           minimizer with the reference's rules (LUT[m-mer] = min(m-mer, revcomp) or 4^m-1 when it
-//           contains AA except as prefix; a new m-mer wins only if strictly smaller; rescan from the
-//           rightmost m-mer when the minimizer leaves the window) and counts its super-k-mers
-//           (cut on minimizer change, invalid k-mer, or maxs k-mers);
+//   pass 1  k_superk_wave<false>: one WAVE per read, one lane per k-mer position; bases become ballot
+//           bit planes, the m-mer value (min(m-mer, revcomp), or 4^m-1 when it contains AA except as
+//           prefix) is computed instead of looked up, the window minimizer is a doubling min-scan with
+//           wave shuffles (the reference's rolling minimizer always equals the window minimum, whatever
+//           its tie rules), super-k-mer cuts (minimizer change, invalid k-mer, maxs k-mers) are ballots;
+//           counts the read's super-k-mers;
 //   scan    exclusive scan of the per-read counts (rocPRIM);
-//   pass 2  k_superk_scan<true>: the same walk writes one descriptor per super-k-mer
+//   pass 2  k_superk_wave<true>: the same walk writes one descriptor per super-k-mer
 //           {first base, n, partition, record bytes};
 //   order   stable radix sort of the descriptors by partition + exclusive scan of their sizes
 //           (rocPRIM) = the byte offset of every record inside its partition's stream, in read
@@ -38,86 +39,117 @@ __device__ __forceinline__ bool nt_valid(u8 c)
   return u == 'A' || u == 'C' || u == 'G' || u == 'T';
 }
 
-// m-mer at digit offset `s` (from the last base) of the forward k-mer ending at base `end` (inclusive)
-__device__ __forceinline__ u32 mmer_at(const char* __restrict__ seq, u64 end, int s, int m)
+// value of an m-mer as the reference's minimizer table gives it: min(x, revcomp_m(x)), or 4^m - 1 when
+// that contains AA anywhere but as a prefix (Model.hpp:1040-1064, 1220-1251) -- computed, not looked up
+__device__ __forceinline__ u32 mmer_value(u32 x, int m)
 {
-  u32 v = 0;
-  for (int j = m - 1; j >= 0; j--) v = (v << 2) | (((u8)seq[end - s - j] >> 1) & 3u);
-  return v;
+  const u32 n1 = (1u << (2 * m)) - 1;                                     // m <= 15
+  u32 t = __brev(x);
+  t = ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);                 // digits reversed, bits of a digit in order
+  const u32 rc = (t >> (32 - 2 * m)) ^ (0xAAAAAAAAu & n1);                 // complement: A0 C1 T2 G3 -> digit ^ 2
+  const u32 v = rc < x ? rc : x;
+  const u64 mask_ma1 = 0x5555555555555555ULL & ((1ULL << ((m - 2) * 2)) - 1);
+  u64 a1 = v; a1 = ~(a1 | (a1 >> 2)); a1 = ((a1 >> 1) & a1) & mask_ma1;
+  return a1 ? n1 : v;
+}
+// bit i of y -> bit 2i (i < 16)
+__device__ __forceinline__ u32 spread16(u32 y)
+{
+  y = (y | (y << 8)) & 0x00FF00FFu; y = (y | (y << 4)) & 0x0F0F0F0Fu;
+  y = (y | (y << 2)) & 0x33333333u; y = (y | (y << 1)) & 0x55555555u;
+  return y;
 }
 
+// One WAVE per read, one lane per k-mer position (a chunk = 64 consecutive base positions):
+//   * the chunk's bases become three 64-bit bit planes (two code bits, one "invalid" bit) with ballots;
+//     a lane funnel-shifts them to its own position: its m-mer is m bits of each plane, its k-mer is
+//     valid iff k bits of the invalid plane are zero -- no per-lane base loop, no table;
+//   * the minimizer of the k-mer at lane l is the minimum of the m-mer values of lanes l .. l+k-m
+//     (what the reference's rolling minimizer always equals, whatever its tie rules): a doubling
+//     min-scan with wave shuffles;
+//   * super-k-mers are runs of valid k-mers with one minimizer, cut every `maxs` k-mers
+//     (Sequence2SuperKmer.hpp:90-158): break / start / end flags are ballots, a lane that ends a
+//     super-k-mer finds its start with a count-leading-zeros on the start mask.  Only the state of the
+//     last owned k-mer is carried to the next chunk (64-(k-m)-1 positions further).
 template <bool EMIT>
-__global__ void k_superk_scan(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
-                              int k, int m, int maxs, const u32* __restrict__ lut, const u16* __restrict__ repart,
-                              u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc)
+__global__ __launch_bounds__(256)
+void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
+                   int k, int m, int maxs, const u16* __restrict__ repart,
+                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc)
 {
-  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (r >= n_seqs) return;
   const u64 b0 = offsets[r], len = offsets[r + 1] - b0;
   u32 nsk = 0;
   if (len >= (u64)k) {
     const char* seq = bases + b0;
-    const u32 maskm = (1u << (2 * m)) - 1;
-    const int nbm = k - m + 1;
+    const int nbm = k - m + 1;                       // m-mers per k-mer (<= 60)
+    const u32 C = 64u - (u32)nbm + 1u;               // k-mer positions of a chunk with their whole m-mer window in the chunk
+    const u32 own = C - 1;                           // the last one only serves as look-ahead
+    const u64 nk = len - (u64)k + 1;
+    const u64 kmask = (1ULL << k) - 1;               // k <= 63
+    const u32 mmask = (1u << m) - 1;
     u32 out = EMIT ? desc_off[r] : 0;
-    // first k-mer: last bad character, rolling m-mer (Model.hpp:636-657)
-    int bad = -1;
-    for (int i = 0; i < k; i++) if (!nt_valid((u8)seq[i])) bad = i;
-    u32 cur_mm = 0;
-    for (int i = k - m; i < k; i++) cur_mm = ((cur_mm << 2) | (((u8)seq[i] >> 1) & 3u)) & maskm;
-    // minimizer of the first k-mer: scan from the rightmost m-mer, strict '<' (Model.hpp:1254-1287)
-    u32 minim = maskm; int pos = -1;
-    for (int idx = nbm - 1, s = 0; idx >= 0; idx--, s++) {
-      const u32 cand = lut[mmer_at(seq, (u64)k - 1, s, m)];
-      if (cand < minim) { minim = cand; pos = idx; }
-    }
-    // super-k-mer state (Sequence2SuperKmer.hpp:90-132)
-    u32 sk_min = 0; bool sk_valid = false; u32 sk_n = 0; u64 sk_first = 0;
-    u64 end = (u64)k - 1;   // index of the last base of the current k-mer
-    for (;;) {
-      const bool valid = bad < 0;
-      if (!valid) {
-        if (sk_valid && sk_n) {
-          if (EMIT) { SkDesc d; d.base = (u32)(b0 + sk_first); d.part = repart[sk_min]; d.n = (u8)sk_n; d.pad = 0; desc[out++] = d; }
-          nsk++;
-        }
-        sk_n = 0; sk_valid = false;
-      } else {
-        if (!sk_valid) { sk_min = minim; sk_valid = true; }
-        if (minim != sk_min || sk_n >= (u32)maxs) {
-          if (sk_n) {
-            if (EMIT) { SkDesc d; d.base = (u32)(b0 + sk_first); d.part = repart[sk_min]; d.n = (u8)sk_n; d.pad = 0; desc[out++] = d; }
-            nsk++;
-          }
-          sk_n = 0;
-        }
-        sk_min = minim;
-        if (sk_n == 0) sk_first = end + 1 - (u64)k;
-        sk_n++;
+    bool pv = false; u32 pmin = 0; u64 run_start = 0, open_start = 0;   // state of the last owned k-mer of the previous chunk
+    for (u64 p0 = 0; p0 < nk; p0 += own) {
+      const u64 q = p0 + lane;
+      const u8 c0 = q < len ? (u8)seq[q] : (u8)'N';
+      const u8 c1 = q + 64 < len ? (u8)seq[q + 64] : (u8)'N';
+      const u64 I0 = __ballot(!nt_valid(c0)), I1 = __ballot(!nt_valid(c1));
+      const u64 A0 = __ballot((c0 >> 1) & 1), A1 = __ballot((c1 >> 1) & 1);
+      const u64 B0 = __ballot((c0 >> 2) & 1), B1 = __ballot((c1 >> 2) & 1);
+      const u64 fi = lane ? (I0 >> lane) | (I1 << (64 - lane)) : I0;
+      const u64 fa = lane ? (A0 >> lane) | (A1 << (64 - lane)) : A0;
+      const u64 fb = lane ? (B0 >> lane) | (B1 << (64 - lane)) : B0;
+      // m-mer starting at my base: base j is digit m-1-j
+      const u32 y0 = __brev((u32)fa & mmask) >> (32 - m), y1 = __brev((u32)fb & mmask) >> (32 - m);
+      const u32 v = mmer_value(spread16(y0) | (spread16(y1) << 1), m);
+      // minimizer of the k-mer starting at my base: min of v over lanes [lane, lane + nbm)
+      u32 s1 = min(v, (u32)__shfl_down(v, 1)), s2 = min(s1, (u32)__shfl_down(s1, 2)), s3 = min(s2, (u32)__shfl_down(s2, 4));
+      u32 s4 = min(s3, (u32)__shfl_down(s3, 8)), s5 = min(s4, (u32)__shfl_down(s4, 16));
+      u32 mini = 0xFFFFFFFFu; int off = 0;
+      if (nbm & 32) { mini = min(mini, (u32)__shfl_down(s5, off)); off += 32; }
+      if (nbm & 16) { mini = min(mini, (u32)__shfl_down(s4, off)); off += 16; }
+      if (nbm & 8) { mini = min(mini, (u32)__shfl_down(s3, off)); off += 8; }
+      if (nbm & 4) { mini = min(mini, (u32)__shfl_down(s2, off)); off += 4; }
+      if (nbm & 2) { mini = min(mini, (u32)__shfl_down(s1, off)); off += 2; }
+      if (nbm & 1) { mini = min(mini, (u32)__shfl_down(v, off)); }
+      const u64 pk = p0 + lane;                                           // my k-mer
+      const bool valid = (u32)lane < C && pk < nk && (fi & kmask) == 0;
+      u32 pmin_l = (u32)__shfl_up(mini, 1); int pv_l = __shfl_up((int)valid, 1);
+      if (lane == 0) { pmin_l = pmin; pv_l = pv; }
+      const bool brk = valid && (!pv_l || mini != pmin_l);                 // first k-mer of a run
+      const u64 lowmask = (2ULL << lane) - 1;                              // lanes <= mine (lane 63: all)
+      const u64 Bm = __ballot(brk) & lowmask;
+      const u64 rs = Bm ? p0 + (63 - __clzll(Bm)) : run_start;            // start of my run
+      const bool start = valid && (brk || (u32)((pk - rs) % (u64)maxs) == 0);
+      const u64 Sall = __ballot(start);
+      const int nvalid = __shfl_down((int)valid, 1), nstart = __shfl_down((int)start, 1);
+      const bool owned = (u32)lane < own && pk < nk;
+      const bool endf = valid && owned && (pk + 1 == nk || !nvalid || nstart);   // last k-mer of a super-k-mer
+      const u64 Em = __ballot(endf);
+      if (EMIT && endf) {
+        const u64 sb = Sall & lowmask;
+        const u64 ps = sb ? p0 + (63 - __clzll(sb)) : open_start;
+        SkDesc d; d.base = (u32)(b0 + ps); d.part = repart[mini]; d.n = (u8)(pk - ps + 1); d.pad = 0;
+        desc[out + __popcll(Em & ((1ULL << lane) - 1))] = d;
       }
-      if (end + 1 >= len) break;
-      // next k-mer (Model.hpp:740-757, 1106-1139)
-      end++;
-      const u8 ch = (u8)seq[end];
-      if (!nt_valid(ch)) bad = k - 1; else bad--;
-      cur_mm = ((cur_mm << 2) | ((ch >> 1) & 3u)) & maskm;
-      const u32 mmer = lut[cur_mm];
-      pos--;
-      if (mmer < minim) { minim = mmer; pos = nbm - 1; }
-      else if (pos < 0) {
-        minim = maskm; pos = -1;
-        for (int idx = nbm - 1, s = 0; idx >= 0; idx--, s++) {
-          const u32 cand = lut[mmer_at(seq, end, s, m)];
-          if (cand < minim) { minim = cand; pos = idx; }
-        }
+      const u32 ne = (u32)__popcll(Em);
+      nsk += ne; out += ne;
+      // carry the state of the last owned k-mer
+      const u64 rem = nk - p0;
+      const int lo = (int)(rem < (u64)own ? rem : (u64)own) - 1;
+      pv = __builtin_amdgcn_readlane((int)valid, lo) != 0;
+      pmin = (u32)__builtin_amdgcn_readlane((int)mini, lo);
+      if (pv) {
+        run_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)rs, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(rs >> 32), lo) << 32);
+        const u64 sb = Sall & ((2ULL << lo) - 1);
+        if (sb) open_start = p0 + (63 - __clzll(sb));
       }
-    }
-    if (sk_valid && sk_n) {   // Sequence2SuperKmer.hpp:155
-      if (EMIT) { SkDesc d; d.base = (u32)(b0 + sk_first); d.part = repart[sk_min]; d.n = (u8)sk_n; d.pad = 0; desc[out++] = d; }
-      nsk++;
     }
   }
-  if (!EMIT) counts[r] = nsk;
+  if (!EMIT && lane == 0) counts[r] = nsk;
 }
 
 __global__ void k_superk_sizes(const SkDesc* __restrict__ desc, u32 n, int k, u16* __restrict__ keys, u32* __restrict__ ids, u32* __restrict__ sizes_unsorted)
@@ -173,20 +205,6 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
   }
 }
 
-// LUT[x] = min(x, revcomp_m(x)), 4^m-1 if it contains AA except as prefix (Model.hpp:1040-1064, 1220-1251)
-__global__ void k_minimizer_lut(int m, u32* __restrict__ lut)
-{
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 n = 1u << (2 * m);
-  if (x >= n) return;
-  u32 rc = 0, t = x;
-  for (int i = 0; i < m; i++) { rc = (rc << 2) | ((t & 3u) ^ 2u); t >>= 2; }
-  u32 v = rc < x ? rc : x;
-  const u64 mask_ma1 = 0x5555555555555555ULL & ((1ULL << ((m - 2) * 2)) - 1);
-  u64 a1 = v; a1 = ~(a1 | (a1 >> 2)); a1 = ((a1 >> 1) & a1) & mask_ma1;
-  lut[x] = a1 ? (n - 1) : v;
-}
-
 }  // namespace kmx
 
 using namespace kmx;
@@ -212,11 +230,10 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
 
   char* d_bases = (char*)ctx->dalloc(total_bases + 16);
   u64* d_offs = (u64*)ctx->dalloc((n_seqs + 1) * 8);
-  u32* d_lut = (u32*)ctx->dalloc(nm * 4);
   u16* d_rep = (u16*)ctx->dalloc(nm * 2);
   u32* d_cnt = (u32*)ctx->dalloc((n_seqs + 1) * 4);
   u32* d_doff = (u32*)ctx->dalloc((n_seqs + 1) * 4);
-  std::vector<void*> blocks = {d_bases, d_offs, d_lut, d_rep, d_cnt, d_doff};
+  std::vector<void*> blocks = {d_bases, d_offs, d_rep, d_cnt, d_doff};
   auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
@@ -225,10 +242,9 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if ((e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload repartition");
-  hipLaunchKernelGGL(k_minimizer_lut, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, (int)m, d_lut);
   if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
-  const dim3 g1((unsigned)((n_seqs + 127) / 128)), b1(128);
-  hipLaunchKernelGGL((k_superk_scan<false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_lut, d_rep, d_cnt,
+  const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
+  hipLaunchKernelGGL((k_superk_wave<false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                      (const u32*)nullptr, (SkDesc*)nullptr);
   size_t tb = 0;
   if ((e = rocprim::exclusive_scan(nullptr, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan size");
@@ -248,7 +264,7 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   u64* d_szs = (u64*)ctx->dalloc(((size_t)nd + 1) * 8), *d_boff = (u64*)ctx->dalloc(((size_t)nd + 1) * 8);
   for (void* b : {(void*)d_desc, (void*)d_keys, (void*)d_keys2, (void*)d_ids, (void*)d_ids2, (void*)d_sz, (void*)d_szs, (void*)d_boff}) blocks.push_back(b);
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-  hipLaunchKernelGGL((k_superk_scan<true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_lut, d_rep, d_cnt,
+  hipLaunchKernelGGL((k_superk_wave<true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                      (const u32*)d_doff, d_desc);
   const dim3 g2((nd + 255) / 256), b2(256);
   hipLaunchKernelGGL(k_superk_sizes, g2, b2, 0, st, d_desc, nd, (int)k, d_keys, d_ids, d_sz);
