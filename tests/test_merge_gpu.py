@@ -184,3 +184,31 @@ def test_bench_scale_partitions_properties(ctx):
             eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT)
             assert rows == er and body.tobytes() == eb and np.array_equal(st, es)
     res.free()
+
+
+@pytest.mark.parametrize("similar", [True, False])
+def test_kernel_selection_and_handback(ctx, monkeypatch, similar):
+    """Default kernel choice (KMX_MERGE_KERNEL unset): a task of more than 512 lists goes to k_merge_pivot; when
+    the lists do not resemble each other it flags the task and libkmx re-runs the batch with k_merge_rows.
+    Either way the body and the statistics equal the oracle's."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    N = 600
+    lists = synth_lists(4242, N, 6000, 0.97, 180, kw=1) if similar else synth_lists(4243, N, 6000, 0.25, 1500, kw=1)
+    dev = torch.device("cuda", 0)
+    recs = [lib.pack_records(k, c, 1) for k, c in lists]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT)
+    res = ctx.merge_dev([task])
+    res.wait()
+    assert res.kernel() == ("k_merge_pivot" if similar else "k_merge_rows")
+    exp_body, exp_rows, exp_stats = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT, 0, 0, 2)
+    assert res.rows(0) == exp_rows
+    assert res.body(0) == exp_body
+    st = res.stats(0)
+    assert np.array_equal(st, exp_stats)
+    res.free()
