@@ -415,6 +415,20 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       PVPH(14);
       pv_lds_barrier();
       PVPH(15);
+      u32 ovn = 0, ovmax = 0;
+#pragma unroll
+      for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = wcnt[v]; ovn += w; ovmax = max(ovmax, w); }
+      ovsum += ovn; conssum += sh[6];
+      if (ovmax > (u32)PV_OVW || (conssum > 65536u && ovsum * 8u > conssum)) {
+        // the rows do not cover the other lists here (overflow buffer full, or more than 1/8 of the
+        // range's records so far are not row keys: lists that do not resemble each other --
+        // k_merge_rows does better there): flag the task, the driver re-runs the batch with
+        // k_merge_rows.  Leave the tables clean for the next work item.
+        for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
+        failed = true;
+        break;
+      }
+
       // recurrence of the image rows = number of lists that deposited a (solid) count: wave j counts row j
       {
         const u32 wv = tid >> 6;
@@ -445,22 +459,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           if (lane == 0) prec[j] = nz;
         }
       }
-      pv_lds_barrier();
-      PVPH(2);
-      u32 ovn = 0, ovmax = 0;
-#pragma unroll
-      for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = wcnt[v]; ovn += w; ovmax = max(ovmax, w); }
-      ovsum += ovn; conssum += sh[6];
-      if (ovmax > (u32)PV_OVW || (conssum > 65536u && ovsum * 8u > conssum)) {
-        // the rows do not cover the other lists here (overflow buffer full, or more than 1/8 of the
-        // range's records so far are not row keys: lists that do not resemble each other --
-        // k_merge_rows does better there): flag the task, the driver re-runs the batch with
-        // k_merge_rows.  Leave the tables clean for the next work item.
-        for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
-        failed = true;
-        break;
-      }
-
+      PVPH(2);   // no barrier here: the overflow insert below does not touch the image or prec
       // ---- overflow records: merge them among themselves (hash set, as k_merge_rows) ----
       constexpr int OQ = PV_OVCAP / PV_TPB;
       u32 hs[OQ]; u32 ownm = 0, solidm = 0;
@@ -556,8 +555,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         const u32 t = okl[q];
         otab[t] = (otab[t] & 0xFFFF0000u) | orank[q];
       }
-      __syncthreads();
-      PVPH(4);
+      PVPH(4);   // no barrier: rows-out reads prank/orank (complete since the barrier above), not the table
       const u64 tile_base = sh64[0];
       const bool can_write = sh[3] != 0;
       u8* const out0 = T.out + tile_base * row_bytes;
@@ -586,7 +584,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           }
         }
       }
-      __syncthreads();   // zero-filled overflow rows are in memory before their entries are scattered
+      if (nok) __syncthreads();   // zero-filled overflow rows are in memory, and their ranks in the table, before the scatter
       PVPH(5);
 #pragma unroll
       for (int q = 0; q < OQ; q++) {
