@@ -429,6 +429,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         break;
       }
 
+      for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;   // the row table is dead after the scan: clean for the next tile
       // recurrence of the image rows = number of lists that deposited a (solid) count: wave j counts row j
       {
         const u32 wv = tid >> 6;
@@ -627,13 +628,14 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       pv_lds_barrier();
 #pragma unroll
       for (int q = 0; q < OQ; q++) if ((ownm >> q) & 1u) otab[hs[q]] = 0;   // hash set clean for the next tile
-      for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;            // ... and the row table
       PVPH(6);
       ppos += rte_eff;
       seq++;
       // the range ends with its open-ended tile (that one takes everything the lists have left)
       if (done) break;
-      pv_lds_barrier();
+      // no barrier: the next tile's set-up writes pk, the (already cleared) row table, the image and the
+      // counters, all of which were last read before the barrier above; the hash set is next touched
+      // several barriers from here
     }
 
     // ---- range done ----
