@@ -170,7 +170,6 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     // PV_G adjacent lanes per list; list p*PV_LPP + tid/PV_G in pass p
     const u32 npass = (N + PV_LPP - 1) / PV_LPP;
     const u32 lg = tid / PV_G, r = tid & (PV_G - 1);
-    const u32 gsh = lane & ~(PV_G - 1);                         // first lane of my list's lane group
     for (u32 i = tid; i < N; i += PV_TPB) {
       lt_base[i] = (u64)(uintptr_t)T.recs[i];
       lt_st[i] = make_uint4(T.bounds[(u64)(range + 1) * N + i], T.soft_min[i], T.bounds[(u64)range * N + i], 0u);
@@ -255,15 +254,14 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           const uint4 st = stn;                          // this pass's list state was read one pass ahead
           if (p + 1 < PV_NP && (u32)(p + 1) < npass) stn = li + PV_LPP < N ? lt_st[li + PV_LPP] : make_uint4(0, 0, 0, 0);
           const u32 end = st.x, cur = st.z;
-          u32 allb = 1; u64 lastk = 0; bool holds_last = false;
+          // lists are sorted: the whole window lies below khi iff its LAST record does -- one compare in the
+          // one slot that holds it, no ballots
 #pragma unroll
           for (int u = 0; u < PV_U; u++) {
             const u32 ix = cur + ((r + PV_G * u - cur) & (PV_W - 1));
             const Key<KW> k = rec_key(rec[p][u]);
             const bool below = ix < end && (open_end || key_less<KW>(k, khi));
-            const u64 b = __ballot(below);
-            allb &= ((u32)(b >> gsh) & ((1u << PV_G) - 1)) == ((1u << PV_G) - 1) ? 1u : 0u;
-            if (ix == cur + PV_W - 1) { holds_last = true; lastk = k.w[0]; }
+            if (below && ix == cur + PV_W - 1 && cur + PV_W < end) atomicMin(&sh64[2], k.w[0] + 1);
             if (p == 0 && below && li < hmax && li != T.pivot) {   // a helper's key the pivot lacks: candidate row
               u32 h = pv_thash<KW>(k);
               u32 idx = ptab[h].idx;
@@ -271,7 +269,6 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
               if (idx == 0) { const u32 pos = atomicAdd(&sh[5], 1u); if (pos < (u32)PV_NC) cand[pos] = k.w[0]; }
             }
           }
-          if (allb && holds_last && cur + PV_W < end) atomicMin(&sh64[2], lastk + 1);
         }
       }
       PVPH(9);
@@ -331,7 +328,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 
       // ---- scan: every list consumes its records of the tile (keys below lim) ----
       stn = lg < N ? lt_st[lg] : make_uint4(0, 0, 0, 0);
-      u32 wcons = 0, wov = 0;                   // records consumed / overflow records of this wave (uniform)
+      u32 lcons = 0, wov = 0;                   // records consumed by this lane / overflow records of this wave (uniform)
 #pragma unroll
       for (int p = 0; p < PV_NP; p++) {
         __builtin_amdgcn_sched_barrier(0);      // keep the passes apart: interleaving them only costs registers
@@ -385,9 +382,11 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             }
           }
           // records consumed by my list (a prefix of its window): statistics and the new cursor
-          u32 c = 0;
+          // (count = the list's group sum of per-lane counts: lane-crossing adds, no ballot / scalar round trips)
+          u32 c = __popc(consm);
+          lcons += c;
 #pragma unroll
-          for (int u = 0; u < PV_U; u++) { const u64 b = __ballot((consm >> u) & 1u); c += __popc((u32)(b >> gsh) & ((1u << PV_G) - 1)); wcons += __popcll(b); }
+          for (int off = 1; off < PV_G; off <<= 1) c += __shfl_xor(c, off);
           if (consm) {
             if (tsum) atomicAdd(&lt_two[li], tsum);
             if (tn) atomicAdd(&lt_nso[li], tn);
@@ -410,7 +409,12 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           }
         }
       }
-      if (lane == 0) { if (wcons) atomicAdd(&sh[6], wcons); wcnt[tid >> 6] = wov; }
+      {
+        u32 wcons = lcons;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wcons += __shfl_xor(wcons, off);
+        if (lane == 0) { if (wcons) atomicAdd(&sh[6], wcons); wcnt[tid >> 6] = wov; }
+      }
       PVPH(8);
       PVPH(14);
       pv_lds_barrier();
