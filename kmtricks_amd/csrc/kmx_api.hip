@@ -187,6 +187,15 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.total_recs += K.lists[i].n;
       if (H.len[i] > H.len[pivot]) pivot = i;
     }
+    const u32 longest = H.len[pivot];
+    if (H.N >= 5) {
+      // The pivot (range quantiles; row template of k_merge_pivot): in a cohort any list will do, and an
+      // outlier (a sample with extra content, an empty one) is the worst template -- take the list of
+      // median length among five spread over the task (O(1): this runs per task on the submit path).
+      u32 cand[5] = {0, H.N / 4, H.N / 2, (3 * H.N) / 4, H.N - 1};
+      std::sort(cand, cand + 5, [&](u32 a, u32 b) { return H.len[a] < H.len[b]; });
+      if (H.len[cand[2]] > 0) pivot = cand[2];
+    }
     H.pivot = pivot;
     grand_total += H.total_recs;
     if (is_bf) {
@@ -202,7 +211,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       u32 wl = 0; while (wl < 6 && (H.N << (wl + 1)) <= (u32)rows_cap()) wl++;   // window <= one wave
       H.wl = wl;
       if (H.row_bytes > rows_image_bytes((int)kw)) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
-      u64 guess = K.rows_hint ? K.rows_hint : 2ULL * H.len[pivot] + 4096;
+      u64 guess = K.rows_hint ? K.rows_hint : 2ULL * longest + 4096;
       if (guess > H.total_recs) guess = H.total_recs;
       H.rows_guess = std::max<u64>(guess, 1);   // arena = guess + chunk slack, sized once c is known
     }

@@ -212,3 +212,16 @@ def test_kernel_selection_and_handback(ctx, monkeypatch, similar):
     st = res.stats(0)
     assert np.array_equal(st, exp_stats)
     res.free()
+
+
+@pytest.mark.parametrize("n", [513, 1024])
+@pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
+def test_pivot_list_count_edges(ctx, n, mode):
+    """the pivot kernel at the edges of its list range (one past the selection threshold, the maximum), odd
+    soft-min / recurrence-min values, a list that is empty and one that is much denser than the pivot"""
+    lists = synth_lists(900 + n, n, 400, 0.96, 9, kw=1)
+    lists[7] = (lists[7][0][:0], lists[7][1][:0])                                   # empty list
+    dense = synth_lists(901 + n, 1, 400, 1.0, 2500, kw=1)[0]                         # 7x the records of the others
+    lists[11] = dense
+    soft = [1 + (i % 4) for i in range(n)]
+    check(ctx, lists, 1, soft, 3, 0, mode)
