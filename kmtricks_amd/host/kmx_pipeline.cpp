@@ -12,6 +12,11 @@
 #include <sys/resource.h>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <future>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <filesystem>
 #include <iomanip>
@@ -179,29 +184,70 @@ int main(int argc, char** argv)
   write_repartition(rpath, (uint16_t)P, table);
   if (o.until == "repart") return 0;
 
+  // wall-clock per stage (one line on stderr at the end; parsed by scripts/bench_pipeline.py)
+  using clk = std::chrono::steady_clock;
+  const auto t_start = clk::now();
+  double s_read = 0, s_split = 0, s_count = 0, s_merge_io = 0, s_merge = 0;
+  uint64_t n_bases = 0, n_kmers = 0, n_merge_recs = 0;
+  auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
+  auto report = [&]() {
+    fprintf(stderr, "[kmx pipeline] {\"samples\": %u, \"partitions\": %u, \"bases\": %llu, \"kmers\": %llu, \"merge_records\": %llu, "
+                    "\"read_s\": %.4f, \"superk_s\": %.4f, \"count_s\": %.4f, \"merge_io_s\": %.4f, \"merge_s\": %.4f, \"total_s\": %.4f}\n",
+            N, P, (unsigned long long)n_bases, (unsigned long long)n_kmers, (unsigned long long)n_merge_recs,
+            s_read, s_split, s_count, s_merge_io, s_merge, since(t_start));
+  };
   Ctx gpu(o.gpus);
   // ---- superk + count, sample by sample (task_scheduler.hpp:251-348) ----
+  // A reader thread parses the FASTA/FASTQ files one batch ahead of the device (a sample's files are read one
+  // after another, io/fof.hpp:82-87); the main thread splits and counts.
+  struct ReadBatch { uint32_t si; bool last; std::string bases; std::vector<uint64_t> offs; };
+  std::mutex qm; std::condition_variable qcv; std::deque<ReadBatch> rq; bool reader_done = false;
+  std::thread reader([&]() {
+    auto push = [&](ReadBatch&& b) {
+      std::unique_lock<std::mutex> lk(qm);
+      qcv.wait(lk, [&]() { return rq.size() < 2; });
+      rq.push_back(std::move(b)); qcv.notify_all();
+    };
+    for (uint32_t si = 0; si < N; si++) {
+      ReadBatch b; b.si = si; b.last = false; b.offs.assign(1, 0);
+      for (const std::string& f : samples[si].files) {
+        SeqReader rd(f); std::string seq;
+        auto t0 = clk::now();
+        while (rd.next(seq)) {
+          b.bases += seq; b.offs.push_back(b.bases.size());
+          if (b.bases.size() > (256u << 20)) {
+            s_read += since(t0);
+            push(std::move(b));
+            b = ReadBatch(); b.si = si; b.last = false; b.offs.assign(1, 0);
+            t0 = clk::now();
+          }
+        }
+        s_read += since(t0);
+      }
+      b.last = true; push(std::move(b));
+    }
+    { std::lock_guard<std::mutex> lk(qm); reader_done = true; } qcv.notify_all();
+  });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
   for (uint32_t si = 0; si < N; si++) {
     const Sample& S = samples[si];
     kmx_ctx* c = gpu.c[si % gpu.c.size()];
     std::vector<std::vector<uint8_t>> streams(P);
     std::vector<uint64_t> nk(P, 0);
-    std::string bases; std::vector<uint64_t> offs{0};
-    auto flush_batch = [&]() {
-      if (offs.size() == 1) return;
-      std::vector<uint8_t*> ob(P); std::vector<uint64_t> ol(P), ok(P);
-      chk(c, kmx_superk_partition(c, bases.data(), offs.data(), offs.size() - 1, o.k, o.msize, table.data(), P, ob.data(), ol.data(), ok.data()), "kmx_superk_partition");
-      for (uint32_t p = 0; p < P; p++) { streams[p].insert(streams[p].end(), ob[p], ob[p] + ol[p]); nk[p] += ok[p]; kmx_free(ob[p]); }
-      bases.clear(); offs.assign(1, 0);
-    };
-    for (const std::string& f : S.files) {           // a sample's files are read one after another (io/fof.hpp:82-87)
-      SeqReader rd(f); std::string seq;
-      while (rd.next(seq)) {
-        bases += seq; offs.push_back(bases.size());
-        if (bases.size() > (256u << 20)) flush_batch();
+    for (;;) {
+      ReadBatch b;
+      { std::unique_lock<std::mutex> lk(qm); qcv.wait(lk, [&]() { return !rq.empty(); }); b = std::move(rq.front()); rq.pop_front(); qcv.notify_all(); }
+      if (b.offs.size() > 1) {
+        const auto t0 = clk::now();
+        n_bases += b.bases.size();
+        std::vector<uint8_t*> ob(P); std::vector<uint64_t> ol(P), ok(P);
+        chk(c, kmx_superk_partition(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, ob.data(), ol.data(), ok.data()), "kmx_superk_partition");
+        for (uint32_t p = 0; p < P; p++) { streams[p].insert(streams[p].end(), ob[p], ob[p] + ol[p]); nk[p] += ok[p]; kmx_free(ob[p]); }
+        s_split += since(t0);
       }
+      if (b.last) break;
     }
-    flush_batch();
+    for (uint32_t p = 0; p < P; p++) n_kmers += nk[p];
     { std::ofstream pi(root + "/partition_infos/" + S.id + ".pinfo"); for (uint32_t p = 0; p < P; p++) pi << nk[p] << "\n"; }   // gatb_utils.hpp:46-51
     if (o.keep_tmp || o.until == "superk") {
       const std::string sd = root + "/superkmers/" + S.id; fs::create_directories(sd);
@@ -214,6 +260,7 @@ int main(int argc, char** argv)
       }
     }
     if (o.until == "superk") continue;
+    const auto t_count = clk::now();
     {   // every partition of the sample in one device pass (CountTask / HashCountTask, task.hpp:367-392, 447-481)
       std::vector<const uint8_t*> sp(P); std::vector<uint64_t> sl(P), pid(P), n(P);
       std::vector<uint64_t*> keys(P, nullptr); std::vector<uint32_t*> cnts(P, nullptr);
@@ -227,21 +274,35 @@ int main(int argc, char** argv)
         kmx_free(keys[p]); kmx_free(cnts[p]);
       }
     }
+    s_count += since(t_count);
   }
-  if (o.until == "superk" || o.until == "count") return 0;
+  if (o.until == "superk" || o.until == "count") { report(); return 0; }
 
   // ---- merge, one task per partition (task_scheduler.hpp:381-417) ----
   Plugin plug; if (!o.plugin.empty()) plug.load(o.plugin, o.k);
   std::vector<uint32_t> soft(N, o.soft_min);
-  for (uint32_t p = 0; p < P; p++) {
-    kmx_ctx* c = gpu.of_partition(p);
-    std::vector<std::vector<uint8_t>> recs(N); std::vector<kmx_list> lists(N);
+  // the count files of partition p + 1 are read while partition p is merged
+  auto load_partition = [&](uint32_t p) {
+    std::vector<std::vector<uint8_t>> r(N);
     for (uint32_t i = 0; i < N; i++) {
       const std::string cp = root + "/counts/partition_" + std::to_string(p) + "/" + samples[i].id + (hash_mode ? ".hash" : ".kmer");
       if (!fs::exists(cp)) die(cp + " is missing.");                                  // kmdir.hpp:69-70
-      recs[i] = hash_mode ? read_hash_records(cp, nullptr) : read_kmer_records(cp, nullptr, nullptr);
-      lists[i].recs = recs[i].data(); lists[i].n = recs[i].size() / ((hash_mode ? 1 : kw) * 8 + 4);
+      r[i] = hash_mode ? read_hash_records(cp, nullptr) : read_kmer_records(cp, nullptr, nullptr);
     }
+    return r;
+  };
+  std::future<std::vector<std::vector<uint8_t>>> next_recs;
+  if (P) next_recs = std::async(std::launch::async, load_partition, 0u);
+  for (uint32_t p = 0; p < P; p++) {
+    kmx_ctx* c = gpu.of_partition(p);
+    auto t_io = clk::now();
+    std::vector<std::vector<uint8_t>> recs = next_recs.get(); std::vector<kmx_list> lists(N);
+    if (p + 1 < P) next_recs = std::async(std::launch::async, load_partition, p + 1);
+    for (uint32_t i = 0; i < N; i++) {
+      lists[i].recs = recs[i].data(); lists[i].n = recs[i].size() / ((hash_mode ? 1 : kw) * 8 + 4);
+      n_merge_recs += lists[i].n;
+    }
+    s_merge_io += since(t_io);
     kmx_merge_task t{};
     t.n_lists = N; t.key_words = hash_mode ? 1 : kw; t.lists = lists.data(); t.soft_min = soft.data();
     t.rec_min = o.rec_min; t.share_min = o.share_min; t.bitw = o.bitw;
@@ -254,7 +315,10 @@ int main(int argc, char** argv)
       t.rec_min = 0; t.mode = KMX_MODE_COUNT;
     }
     void* body = nullptr; uint64_t nbytes = 0, rows = 0; std::vector<uint64_t> stats((size_t)6 * N);
+    const auto t_m = clk::now();
     chk(c, kmx_merge(c, &t, &body, &nbytes, &rows, stats.data()), "kmx_merge");
+    s_merge += since(t_m);
+    t_io = clk::now();
     const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
     Out out(root + "/matrices/matrix_" + std::to_string(p) + "." + ext);
     if (what == "count") { if (hash_mode) matrix_count_hash_header(out, N, p); else matrix_count_header(out, o.k, N, p); }
@@ -285,7 +349,9 @@ int main(int argc, char** argv)
     }
     if (!o.keep_tmp)                                                                  // task.hpp:676-688
       for (uint32_t i = 0; i < N; i++) fs::remove(root + "/counts/partition_" + std::to_string(p) + "/" + samples[i].id + (hash_mode ? ".hash" : ".kmer"));
+    s_merge_io += since(t_io);
   }
+  report();
   struct rusage ru; getrusage(RUSAGE_SELF, &ru);
   { std::ofstream ri(root + "/run_infos.txt");                                         // task_scheduler.hpp:453-457
     ri << "Time: " << std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() << " seconds\n"
