@@ -67,6 +67,11 @@ __device__ __forceinline__ u32x3 rec_none() { u32x3 v; v.x = ~0u; v.y = ~0u; v.z
 template <int KW> struct OvRec { Key<KW> key; u32 cnt; u32 list; };
 template <int KW> struct PvEnt { Key<KW> key; u32 idx; u32 pad; };   // idx = row + 1, 0 = empty
 
+// values every lane reads from the same LDS word are uniform, but only a readfirstlane tells the compiler: they
+// then live in scalar registers instead of occupying (and spilling) vector registers across the scan
+__device__ __forceinline__ u32 pv_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 pv_uni64(u64 v) { return (u64)pv_uni((u32)v) | ((u64)pv_uni((u32)(v >> 32)) << 32); }
+
 __device__ __forceinline__ void pv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int KW> __device__ __forceinline__ u32 pv_mix(const Key<KW>& k)
@@ -150,7 +155,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   for (;;) {
     if (tid == 0) sh[0] = atomicAdd(ticket, 1u);
     __syncthreads();
-    const u32 item = sh[0];
+    const u32 item = pv_uni(sh[0]);      // scalar: the task descriptor is then read with scalar loads into SGPRs
     __syncthreads();
     if (item >= n_items) {
 #ifdef KMX_PHASE_PROF
@@ -230,7 +235,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
       pv_lds_barrier();
       PVPH(1);
-      Key<KW> khi; khi.w[0] = open_end ? ~0ULL : sh64[1];
+      Key<KW> khi; khi.w[0] = open_end ? ~0ULL : pv_uni64(sh64[1]);
       if ((u32)tid < rte) {   // row keys
         const Key<KW> mine = pkn;
         u8* row = img + tid * row_bytes;
@@ -275,7 +280,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       pv_lds_barrier();
       PVPH(10);
       {   // candidates seen in >= 2 helpers become rows, smallest keys first; the first one left without a row cuts the tile
-        const u32 nc = min(sh[5], (u32)PV_NC);
+        const u32 nc = min(pv_uni(sh[5]), (u32)PV_NC);
         if ((u32)tid < nc) {
           const u64 mine = cand[tid];
           u32 cnt = 0, earlier = 0;
@@ -313,11 +318,12 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       PVPH(11);
       pv_lds_barrier();
       PVPH(12);
-      const u64 lim = sh64[2];                     // exclusive upper key of the tile
+      const u64 lim = pv_uni64(sh64[2]);           // exclusive upper key of the tile
       const bool unbounded = lim == ~0ULL;         // open-ended tile, not cut
-      const u32 nrows = rte + min(sh[4], rows_cap - rte);
+      const u32 nrows = rte + min(pv_uni(sh[4]), rows_cap - rte);
       u32 rte_eff = 0;
       for (u32 j = 0; j < rte; j++) rte_eff += (unbounded || pk[j].w[0] < lim) ? 1u : 0u;
+      rte_eff = pv_uni(rte_eff);
       const bool done = unbounded;
       {   // next tile's pivot keys
         const u32 npos = ppos + rte_eff;
@@ -421,8 +427,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       PVPH(15);
       u32 ovn = 0, ovmax = 0;
 #pragma unroll
-      for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = wcnt[v]; ovn += w; ovmax = max(ovmax, w); }
-      ovsum += ovn; conssum += sh[6];
+      for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = pv_uni(wcnt[v]); ovn += w; ovmax = max(ovmax, w); }
+      ovsum += ovn; conssum += pv_uni(sh[6]);
       if (ovmax > (u32)PV_OVW || (conssum > 65536u && ovsum * 8u > conssum)) {
         // the rows do not cover the other lists here (overflow buffer full, or more than 1/8 of the
         // range's records so far are not row keys: lists that do not resemble each other --
@@ -436,7 +442,10 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;   // the row table is dead after the scan: clean for the next tile
       // recurrence of the image rows = number of lists that deposited a (solid) count: wave j counts row j
       {
-        const u32 wv = tid >> 6;
+        // (wave index recomputed here: as a loop invariant the row addresses derived from it get spilled, and
+        //  a scratch reload right behind the scan waits for every refill load in flight)
+        u32 wv = pv_uni((u32)tid >> 6); asm volatile("" : "+s"(wv));
+        u32 ln = lane; asm volatile("" : "+v"(ln));
         for (u32 j = wv; j < nrows; j += PV_TPB / 64) {
           // ballots + scalar popcounts: no cross-lane reduction (its LDS round trips cost more than the row)
           u32 nz = 0;
@@ -445,18 +454,18 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             if ((row_bytes & 7u) == 0) {
               const uint2* row2 = reinterpret_cast<const uint2*>(rowc);
               for (u32 t0 = 0; t0 < N / 2; t0 += 64) {
-                const u32 t = t0 + lane;
+                const u32 t = t0 + ln;
                 uint2 v = make_uint2(0, 0);
                 if (t < N / 2) v = row2[t];
                 nz += __popcll(__ballot(v.x != 0)) + __popcll(__ballot(v.y != 0));
               }
             } else {
-              for (u32 t0 = 0; t0 < N; t0 += 64) { const u32 t = t0 + lane; nz += __popcll(__ballot(t < N && rowc[t] != 0)); }
+              for (u32 t0 = 0; t0 < N; t0 += 64) { const u32 t = t0 + ln; nz += __popcll(__ballot(t < N && rowc[t] != 0)); }
             }
           } else {
             const u8* rowb = img + j * row_bytes + KW * 8;
             u32 part = 0;
-            for (u32 t = lane; t < (N + 7) / 8; t += 64) part += __popc((u32)rowb[t]);
+            for (u32 t = ln; t < (N + 7) / 8; t += 64) part += __popc((u32)rowb[t]);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
             nz = part;
@@ -496,7 +505,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
       pv_lds_barrier();
       PVPH(3);
-      const u32 nok = sh[2];
+      const u32 nok = pv_uni(sh[2]);
       // ---- final row order: kept image rows and kept overflow keys together ----
       u32 nk = 0;
       if (nrows + nok <= 64) {
@@ -561,8 +570,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         otab[t] = (otab[t] & 0xFFFF0000u) | orank[q];
       }
       PVPH(4);   // no barrier: rows-out reads prank/orank (complete since the barrier above), not the table
-      const u64 tile_base = sh64[0];
-      const bool can_write = sh[3] != 0;
+      const u64 tile_base = pv_uni64(sh64[0]);
+      const bool can_write = pv_uni(sh[3]) != 0;
       u8* const out0 = T.out + tile_base * row_bytes;
 
       // ---- rows out: kept pivot rows from the LDS image; overflow rows zero-filled in HBM ----
