@@ -127,7 +127,8 @@ def test_rows_hint_too_small_retries(ctx):
     check(ctx, lists, 1, [1] * 8, 1, 0, orc.MODE_COUNT, rows_hint=3)
 
 
-@pytest.mark.parametrize("n,dens,smin,rmin,share", [(11, 0.3, 10, 3, 2), (100, 0.05, 1, 1, 0), (100, 0.05, 2, 2, 1), (257, 0.02, 3, 1, 5)])
+@pytest.mark.parametrize("n,dens,smin,rmin,share", [(11, 0.3, 10, 3, 2), (100, 0.05, 1, 1, 0), (100, 0.05, 2, 2, 1), (257, 0.02, 3, 1, 5),
+                                                     (2500, 0.004, 2, 1, 3)])   # BASELINE configs[3] shape: 2500 samples, low-abundance rescue
 @pytest.mark.parametrize("mode", [orc.MODE_BF, orc.MODE_BFC])
 def test_synthetic_bf(ctx, n, dens, smin, rmin, share, mode):
     lower, W = 3 * 19200, 19200
