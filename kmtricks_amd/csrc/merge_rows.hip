@@ -165,7 +165,7 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
     // ---- next work item (dynamic, ascending ids) ----
     if (tid == 0) bc32[0] = atomicAdd(ticket, 1u);
     __syncthreads();
-    const u32 item = bc32[0];
+    const u32 item = (u32)__builtin_amdgcn_readfirstlane((int)bc32[0]);   // scalar: the task descriptor is read with scalar loads
     __syncthreads();
     if (item >= n_items) {
 #ifdef KMX_PHASE_PROF
@@ -307,7 +307,7 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
         }
       }
       lds_barrier();
-      const u32 dk = bc32[2];
+      const u32 dk = (u32)__builtin_amdgcn_readfirstlane((int)bc32[2]);
       if (tid == 0) {   // row space for this tile (ascending inside a chunk; one directory entry per chunk)
         u64 off = 0;
         if (dk) {
