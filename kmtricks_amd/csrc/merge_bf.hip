@@ -91,6 +91,11 @@ void k_merge_bf(const TaskDev* __restrict__ tasks, const uint2* __restrict__ ite
     const u32 r = tid & (g - 1);
 
     for (u32 i = tid; i < N; i += BF_TPB) cur[i] = T.bounds[(u64)range * N + i];
+    // one pass covers all lists (N <= lists per pass): a lane serves the same list in every tile, so its
+    // record base, range end and soft-min are read once per range instead of once per tile
+    const bool single = passes == 1;
+    const u8* base1 = nullptr; u32 e1 = 0, sm1 = 0;
+    if (single && tid / g < N) { const u32 i1 = tid / g; base1 = T.recs[i1]; e1 = T.bounds[(u64)(range + 1) * N + i1]; sm1 = T.soft_min[i1]; }
     __syncthreads();
 
     for (u64 tile = tile0; tile < tile1; tile++) {
@@ -106,8 +111,8 @@ void k_merge_bf(const TaskDev* __restrict__ tasks, const uint2* __restrict__ ite
         for (u32 ps = 0; ps < passes; ps++) {
           const u32 i = ps * lpp + tid / g;
           if (i < N) {
-            const u8* base = T.recs[i];
-            const u32 e = T.bounds[(u64)(range + 1) * N + i], sm = T.soft_min[i];
+            const u8* base = single ? base1 : T.recs[i];
+            const u32 e = single ? e1 : T.bounds[(u64)(range + 1) * N + i], sm = single ? sm1 : T.soft_min[i];
             for (u32 idx = cur[i] + r; idx < e; idx += UNR * g) {   // UNR records in flight per lane
               u64 hh[UNR]; u32 cc[UNR];
 #pragma unroll
@@ -133,8 +138,8 @@ void k_merge_bf(const TaskDev* __restrict__ tasks, const uint2* __restrict__ ite
         const u32 i = ps * lpp + tid / g;
         u32 uwo = 0; u64 two = 0; u32 next = 0;
         if (i < N) {
-          const u8* base = T.recs[i];
-          const u32 e = T.bounds[(u64)(range + 1) * N + i], sm = T.soft_min[i];
+          const u8* base = single ? base1 : T.recs[i];
+          const u32 e = single ? e1 : T.bounds[(u64)(range + 1) * N + i], sm = single ? sm1 : T.soft_min[i];
           const u32 start = cur[i];
           next = start;
           bool stop = false;
