@@ -182,6 +182,17 @@ int main(int argc, char** argv)
     for (uint64_t m = 0; m < table.size(); m++) table[m] = (uint16_t)(xxh64_u32((uint32_t)m) % P);
   } else die("the sampled repartition is not built yet: pass --static-repart (or --repart-from / --repart-file)");
   write_repartition(rpath, (uint16_t)P, table);
+  if (o.msize <= 12) {   // minimizers/minimizers.<p>: every m-mer assigned to partition p, one per line (task.hpp:160-168, repartition.hpp:116-124)
+    fs::create_directories(root + "/minimizers");
+    std::vector<std::string> buf(P);
+    std::string mm(o.msize, 'A');
+    for (uint64_t v = 0; v < table.size(); v++) {
+      uint64_t t = v;
+      for (int i = (int)o.msize - 1; i >= 0; i--) { mm[i] = "ACTG"[t & 3]; t >>= 2; }   // Mmer::to_string (kmer.hpp:115-127)
+      std::string& b = buf[table[v]]; b += mm; b += '\n';
+    }
+    for (uint32_t p = 0; p < P; p++) { std::ofstream f(root + "/minimizers/minimizers." + std::to_string(p)); f.write(buf[p].data(), (std::streamsize)buf[p].size()); }
+  }
   if (o.until == "repart") return 0;
 
   // wall-clock per stage (one line on stderr at the end; parsed by scripts/bench_pipeline.py)

@@ -59,6 +59,16 @@ def test_kmer_count_pipeline(inputs, tmp_path):
     for f in ("kmtricks.fof", "options.txt", "build_infos.txt", "run_infos.txt", "hash.info"):
         assert (out / f).is_file()
     assert open(out / "repartition_gatb" / "repartition.minimRepart", "rb").read() == open(inputs / "fixture.minimRepart", "rb").read()
+    # minimizers/minimizers.<p>: every 10-mer once, in the partition the table gives it, ascending inside a file
+    rep_tab = np.frombuffer(open(inputs / "fixture.minimRepart", "rb").read()[12:12 + 2 * 4 ** 10], np.uint16)
+    total = 0
+    for p in range(P):
+        mm = open(out / "minimizers" / f"minimizers.{p}").read().split()
+        vals = [sum("ACTG".index(c) << (2 * (9 - j)) for j, c in enumerate(m)) for m in (mm if len(mm) <= 100 else mm[:50] + mm[-50:])]
+        assert all(len(m) == 10 for m in mm) and all(rep_tab[v] == p for v in vals) and vals == sorted(vals)
+        assert len(mm) == int((rep_tab == p).sum())
+        total += len(mm)
+    assert total == 4 ** 10
     lists = oracle_lists(False)
     rows_exp = G["merge_test"]["kmer_rows"]
     for p in range(P):
