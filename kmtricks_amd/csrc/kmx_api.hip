@@ -111,6 +111,7 @@ struct TaskHost {
   // results
   u64 rows = 0, nsegs = 0;
   bool done = false;
+  bool handed_back = false;     // the pivot kernel flagged this task: it is (was) re-run with k_merge_rows
 };
 
 struct kmx_merge_result {
@@ -122,6 +123,8 @@ struct kmx_merge_result {
   u32 n_items = 0, grid = 0, max_n = 0, max_c = 0;
   int bf_lds = 0;
   bool is_bf = false, waited = false;
+  bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
+  bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
@@ -252,7 +255,11 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     const bool can = !is_bf && !rescue && kw == 1 && max_n <= pivot_max_lists();
     if (force && !strcmp(force, "pivot")) R->use_pivot = can;
     else if (force && !strcmp(force, "rows")) R->use_pivot = false;
-    else R->use_pivot = can && min_n > 512;
+    else {
+      R->use_pivot = can && min_n > 512;
+      if (R->use_pivot && ctx->pivot_skip) { ctx->pivot_skip--; R->use_pivot = false; }   // cohort that did not suit it recently
+      R->pivot_auto = R->use_pivot;
+    }
     if (R->use_pivot) R->grid = std::min(n_items, (u32)ctx->n_cu);   // one 1024-thread workgroup per CU
   }
   if (is_bf) {
@@ -347,7 +354,7 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
     const u64* ctrl = hc + t * 8;
     H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
-    if ((ctrl[2] & ERR_FALLBACK) && fallback) *fallback = true;
+    if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; }
   }
   return KMX_OK;
 }
@@ -368,21 +375,45 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   int rc = fetch_ctrl(R, &overflow, &fallback);
   if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
   if (fallback) {
-    // the pivot did not cover some task's lists (a pivot gap overflowed the tile buffer): run the
-    // batch again with the general kernel.  Bounds stay valid; statistics and row space restart.
-    if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] pivot kernel flagged a task: batch re-run with k_merge_rows\n");
-    R->use_pivot = false;
-    R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
+    // The pivot kernel handed some tasks back (lists that do not resemble each other): those tasks -- only those --
+    // run again with the general kernel.  Bounds stay valid; their statistics and row space restart.
+    const uint2* all_items = reinterpret_cast<const uint2*>(R->h_meta + R->o_items);
+    std::vector<uint2> redo;
+    u32 n_back = 0;
+    for (auto& H : R->tasks) n_back += H.handed_back ? 1u : 0u;
+    for (u32 i = 0; i < R->n_items; i++) if (R->tasks[all_items[i].x].handed_back) redo.push_back(all_items[i]);
+    if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] pivot kernel handed back %u of %zu tasks: re-run with k_merge_rows\n", n_back, R->tasks.size());
+    if (R->pivot_auto && n_back * 4 >= R->tasks.size()) {   // a cohort it does not suit: back off for the next batches
+      ctx->pivot_backoff = std::min(64u, std::max(1u, ctx->pivot_backoff * 2)); ctx->pivot_skip = ctx->pivot_backoff;
+    }
+    R->pivot_auto = false;
+    if (n_back == R->tasks.size()) R->use_pivot = false;     // (kmx_result_kernel: the kernel that produced most of the result)
     for (auto& H : R->tasks) {
+      if (!H.handed_back) continue;
       KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
       KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 64, ctx->stream));
     }
-    rc = launch_batch(R, false);
-    if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
-    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+      uint2* stage = reinterpret_cast<uint2*>(R->h_meta + R->o_items);          // pinned; the full list is rebuilt below
+      std::vector<uint2> keep(all_items, all_items + R->n_items);
+      memcpy(stage, redo.data(), redo.size() * sizeof(uint2));
+      KMX_HIP(ctx, hipMemcpyAsync(R->d_meta + R->o_items, stage, redo.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+      const bool was_pivot = R->use_pivot; const u32 was_items = R->n_items, was_grid = R->grid;
+      R->use_pivot = false; R->n_items = (u32)redo.size();
+      R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
+      rc = launch_batch(R, false);
+      if (rc == KMX_OK) { hipError_t he = hipStreamSynchronize(ctx->stream); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
+      // restore the full item list (an arena-overflow retry below re-runs the whole batch, with k_merge_rows)
+      memcpy(stage, keep.data(), keep.size() * sizeof(uint2));
+      R->n_items = was_items; R->grid = was_grid; R->use_pivot = was_pivot && n_back != R->tasks.size();
+      if (rc == KMX_OK) { hipError_t he = hipMemcpyAsync(R->d_meta + R->o_items, stage, keep.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
+      if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+    }
     rc = fetch_ctrl(R, &overflow);
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+    R->rerun_rows = true;
   }
+  if (R->pivot_auto) ctx->pivot_backoff = 0;   // the pivot kernel completed this batch
   if (overflow) {
     // the kernel kept counting: re-run with arenas / directories of the exact size
     TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
@@ -411,6 +442,10 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     }
     KMX_HIP(ctx, hipMemcpyAsync(R->d_meta + R->o_tasks, R->h_meta + R->o_tasks, sizeof(TaskDev) * R->tasks.size(),
                                 hipMemcpyHostToDevice, ctx->stream));
+    if (R->rerun_rows && R->use_pivot) {   // tasks the pivot kernel handed back must not go through it again
+      R->use_pivot = false;
+      R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
+    }
     rc = launch_batch(R, false);
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
     KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -39,6 +39,9 @@ struct kmx_ctx {
   bool profiling = false;
   std::vector<kmx_pool_block> pool;     // device blocks kept for reuse (bench steps allocate nothing)
   std::vector<kmx_pool_block> hpool;    // pinned host blocks
+  // the pivot merge kernel handed a batch back: the next `pivot_skip` eligible batches go straight to k_merge_rows
+  // (doubling back-off, reset by the first batch the pivot kernel completes)
+  unsigned pivot_backoff = 0, pivot_skip = 0;
 
   void* dalloc(size_t bytes);
   void dfree(void* p);

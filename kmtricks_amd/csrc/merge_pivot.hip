@@ -52,8 +52,8 @@ constexpr int PV_W = PV_G * PV_U;   // records per window (power of two)
 constexpr int PV_LPP = PV_TPB / PV_G;   // lists per pass
 constexpr int PV_MAXN = 1024;       // lists per task
 constexpr int PV_NP = PV_MAXN / PV_LPP;   // passes
-constexpr int PV_NH = 4;             // helper lists
-constexpr int PV_NC = PV_NH * PV_W;  // candidate keys per tile
+constexpr int PV_NH = 8;             // helper lists
+constexpr int PV_NC = 64;            // candidate keys per tile (one per lane of wave 0)
 constexpr int PV_PT = 128;          // pivot lookup table entries (load factor <= 1/8)
 static_assert(PV_RTMAX <= 16 && (PV_W & (PV_W - 1)) == 0, "tile geometry");
 
@@ -124,7 +124,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   Key<KW>* pk = reinterpret_cast<Key<KW>*>(misc);                                         // [32] keys of the image rows (pivot rows, then adopted rows)
   u32* prec = reinterpret_cast<u32*>(misc + 256);                                         // [32] recurrence
   u32* prank = reinterpret_cast<u32*>(misc + 384);                                        // [32] final row or ~0
-  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] - [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed
+  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] - [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed [7] task error bits
   u64* sh64 = reinterpret_cast<u64*>(misc + 576);                                         // [0] tile row base [1] upper key [2] cut
   u32* wcnt = reinterpret_cast<u32*>(misc + 1152);                                        // [waves] overflow records in each wave's slice
   u64* cand = reinterpret_cast<u64*>(misc + 640);                                        // [PV_NC] helper keys the pivot lacks
@@ -212,13 +212,14 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     const u32 hmax = min(N, (u32)PV_NH + (T.pivot <= (u32)PV_NH ? 1u : 0u));   // lists [0, hmax) minus the pivot
     if (tid == 0) { al64[0] = 0; al[0] = 0; al[1] = 0; al[2] = 0; al[3] = 1; }
     u32 seq = 0, ovsum = 0, conssum = 0;
+    u32 rt_cur = rt_cap;                 // pivot rows per tile: shrinks where the lists carry many keys that are not row keys
     bool failed = false;
     __syncthreads();
 
     PVPH(0);
     for (;;) {
       // ---- tile = pivot records [ppos, ppos + rte); key range up to the next pivot key ----
-      const u32 rte = min(rt_cap, pend - ppos);
+      const u32 rte = min(rt_cur, pend - ppos);
       const bool open_end = ppos + rte >= pend;     // last tile of the range: bounded by the lists' range ends
       if ((u32)tid < rte) {
         pk[tid] = pkn;
@@ -231,7 +232,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         const u32 zb = rows_cap * row_bytes;
         uint4* z = reinterpret_cast<uint4*>(img);
         for (u32 t = tid; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
-        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
+        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0;
+                        sh[7] = (u32)__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // hand-back flag, looked at after the scan
       }
       pv_lds_barrier();
       PVPH(1);
@@ -279,22 +281,25 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       PVPH(9);
       pv_lds_barrier();
       PVPH(10);
-      {   // candidates seen in >= 2 helpers become rows, smallest keys first; the first one left without a row cuts the tile
+      {   // candidates seen in >= 2 helpers become rows, smallest keys first; the first one left without a row cuts the
+          // tile.  Wave 0 alone: one candidate per lane, the others read with v_readlane.
         const u32 nc = min(pv_uni(sh[5]), (u32)PV_NC);
-        if ((u32)tid < nc) {
-          const u64 mine = cand[tid];
+        if (nc && tid < 64) {
+          const u64 mine = (u32)lane < nc ? cand[lane] : ~0ULL;
           u32 cnt = 0, earlier = 0;
-          for (u32 j = 0; j < nc; j++) { const bool e = cand[j] == mine; cnt += e ? 1u : 0u; earlier += (e && j < (u32)tid) ? 1u : 0u; }
-          if (cnt >= 2 && earlier == 0) {
-            u32 rank = 0;    // qualifying distinct keys below mine
-            for (u32 j = 0; j < nc; j++) {
-              const u64 o = cand[j];
-              if (o < mine) {
-                u32 c2 = 0, e2 = 0;
-                for (u32 q = 0; q < nc; q++) { const bool e = cand[q] == o; c2 += e ? 1u : 0u; e2 += (e && q < j) ? 1u : 0u; }
-                rank += (c2 >= 2 && e2 == 0) ? 1u : 0u;
-              }
-            }
+          for (u32 j = 0; j < nc; j++) {
+            const u64 o = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine, (int)j) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine >> 32), (int)j) << 32);
+            const bool e = o == mine;
+            cnt += e ? 1u : 0u; earlier += (e && j < (u32)lane) ? 1u : 0u;
+          }
+          const bool qual = (u32)lane < nc && cnt >= 2 && earlier == 0;
+          const u64 qmask = __ballot(qual);
+          u32 rank = 0;    // qualifying distinct keys below mine
+          for (u32 j = 0; j < nc; j++) {
+            const u64 o = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine, (int)j) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine >> 32), (int)j) << 32);
+            rank += (((qmask >> j) & 1ULL) && o < mine) ? 1u : 0u;
+          }
+          if (qual) {
             const u32 row = rte + rank;
             if (row < rows_cap) {
               Key<KW> k; k.w[0] = mine;
@@ -429,15 +434,19 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 #pragma unroll
       for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = pv_uni(wcnt[v]); ovn += w; ovmax = max(ovmax, w); }
       ovsum += ovn; conssum += pv_uni(sh[6]);
-      if (ovmax > (u32)PV_OVW || (conssum > 65536u && ovsum * 8u > conssum)) {
+      const bool unfit = ovmax > (u32)PV_OVW || (conssum > 65536u && ovsum * 8u > conssum);
+      if (unfit || (pv_uni(sh[7]) & (u32)ERR_FALLBACK)) {   // ... or another workgroup already handed this task back
         // the rows do not cover the other lists here (overflow buffer full, or more than 1/8 of the
         // range's records so far are not row keys: lists that do not resemble each other --
         // k_merge_rows does better there): flag the task, the driver re-runs the batch with
         // k_merge_rows.  Leave the tables clean for the next work item.
         for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
-        failed = true;
+        failed = unfit;
         break;
       }
+      // the fuller the fullest overflow slice, the fewer pivot rows the next tile takes (and back up when it empties)
+      if (ovmax > (u32)PV_OVW * 5 / 8) rt_cur = max(3u, rt_cur - 3u);
+      else if (ovmax < (u32)PV_OVW / 4 && rt_cur < rt_cap) rt_cur++;
 
       for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;   // the row table is dead after the scan: clean for the next tile
       // recurrence of the image rows = number of lists that deposited a (solid) count: wave j counts row j

@@ -195,6 +195,7 @@ def test_kernel_selection_and_handback(ctx, monkeypatch, similar):
     torch = pytest.importorskip("torch")
     from kmtricks_amd import lib
     monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    ctx = lib.Context(0)          # own context: a hand-back makes a context skip the pivot kernel for its next batches
     N = 600
     lists = synth_lists(4242, N, 6000, 0.97, 180, kw=1) if similar else synth_lists(4243, N, 6000, 0.25, 1500, kw=1)
     dev = torch.device("cuda", 0)
@@ -213,6 +214,11 @@ def test_kernel_selection_and_handback(ctx, monkeypatch, similar):
     st = res.stats(0)
     assert np.array_equal(st, exp_stats)
     res.free()
+    if not similar:               # back-off: the next eligible batch of this context goes straight to k_merge_rows
+        res = ctx.merge_dev([task]); res.wait()
+        assert res.kernel() == "k_merge_rows" and res.body(0) == exp_body
+        res.free()
+    ctx.close()
 
 
 @pytest.mark.parametrize("n", [513, 1024])
