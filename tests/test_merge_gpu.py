@@ -232,3 +232,17 @@ def test_pivot_list_count_edges(ctx, n, mode):
     lists[11] = dense
     soft = [1 + (i % 4) for i in range(n)]
     check(ctx, lists, 1, soft, 3, 0, mode)
+
+
+def test_bench_workload_full_size_parity():
+    """The bench workload at full size (32 partitions x 1000 samples, 625 M records): k_merge_pivot and k_merge_rows give
+    byte-identical bodies and statistics on every partition, keys ascend, partition 0 equals the oracle
+    (scripts/verify_bench_parity.py).  Runs once (not per kernel parameter)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("KMX_MERGE_KERNEL") != "rows":      # the autouse fixture runs every test twice: do the work once
+        pytest.skip("covered by the other parameter")
+    env = dict(os.environ); env.pop("KMX_MERGE_KERNEL", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "verify_bench_parity.py")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '"pivot_equals_rows_sha256": true' in r.stdout
