@@ -212,6 +212,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     const u32 hmax = min(N, (u32)PV_NH + (T.pivot <= (u32)PV_NH ? 1u : 0u));   // lists [0, hmax) minus the pivot
     if (tid == 0) { al64[0] = 0; al[0] = 0; al[1] = 0; al[2] = 0; al[3] = 1; }
     u32 seq = 0, ovsum = 0, conssum = 0;
+    u32 hb = 0;                          // thread 0: the task's error word as of the start of the tile
     u32 rt_cur = rt_cap;                 // pivot rows per tile: shrinks where the lists carry many keys that are not row keys
     bool failed = false;
     __syncthreads();
@@ -232,8 +233,9 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         const u32 zb = rows_cap * row_bytes;
         uint4* z = reinterpret_cast<uint4*>(img);
         for (u32 t = tid; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
-        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0;
-                        sh[7] = (u32)__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // hand-back flag, looked at after the scan
+        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
+        // hand-back flag of the task: loaded now, stored to LDS only behind the scan, so nobody waits for the load
+        if (tid == 0) hb = (u32)__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       pv_lds_barrier();
       PVPH(1);
@@ -425,6 +427,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wcons += __shfl_xor(wcons, off);
         if (lane == 0) { if (wcons) atomicAdd(&sh[6], wcons); wcnt[tid >> 6] = wov; }
+        if (tid == 0) sh[7] = hb;
       }
       PVPH(8);
       PVPH(14);
