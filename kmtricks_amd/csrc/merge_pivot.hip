@@ -124,7 +124,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   Key<KW>* pk = reinterpret_cast<Key<KW>*>(misc);                                         // [32] keys of the image rows (pivot rows, then adopted rows)
   u32* prec = reinterpret_cast<u32*>(misc + 256);                                         // [32] recurrence
   u32* prank = reinterpret_cast<u32*>(misc + 384);                                        // [32] final row or ~0
-  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] - [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed [7] task error bits
+  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] - [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed [7] task error bits [8] some overflow key may be kept
   u64* sh64 = reinterpret_cast<u64*>(misc + 576);                                         // [0] tile row base [1] upper key [2] cut
   u32* wcnt = reinterpret_cast<u32*>(misc + 1152);                                        // [waves] overflow records in each wave's slice
   u64* cand = reinterpret_cast<u64*>(misc + 640);                                        // [PV_NC] helper keys the pivot lacks
@@ -233,7 +233,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         const u32 zb = rows_cap * row_bytes;
         uint4* z = reinterpret_cast<uint4*>(img);
         for (u32 t = tid; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
-        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; }
+        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; sh[8] = rec_min <= 1 ? 1u : 0u; }
         // hand-back flag of the task: loaded now, stored to LDS only behind the scan, so nobody waits for the load
         if (tid == 0) hb = (u32)__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -503,21 +503,28 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             h = (h + 1) & (PV_OT - 1);
           }
           hs[q] = h;
-          if (o.cnt >= lt_st[o.list].y) { solidm |= 1u << q; if ((old >> 16) < sat) atomicAdd(&otab[h], 1u << 16); }
+          if (o.cnt >= lt_st[o.list].y) {
+            solidm |= 1u << q;
+            if ((old >> 16) < sat) { const u32 prev = atomicAdd(&otab[h], 1u << 16); if ((prev >> 16) + 1 >= rec_min) sh[8] = 1; }
+          }
         }
       }
       pv_lds_barrier();
+      // the usual tile has no overflow key that reaches the recurrence: then nothing is published, ranked or scattered
+      const bool anykept = pv_uni(sh[8]) != 0;
+      if (anykept) {
 #pragma unroll
-      for (int q = 0; q < OQ; q++) {
-        if ((ownm >> q) & 1u) {
-          const u32 e = otab[hs[q]];
-          if ((e >> 16) >= rec_min) { const u32 pos = atomicAdd(&sh[2], 1u); okl[pos] = (u16)hs[q]; }
-          else otab[hs[q]] = (e & 0xFFFF0000u) | 0xFFFFu;
+        for (int q = 0; q < OQ; q++) {
+          if ((ownm >> q) & 1u) {
+            const u32 e = otab[hs[q]];
+            if ((e >> 16) >= rec_min) { const u32 pos = atomicAdd(&sh[2], 1u); okl[pos] = (u16)hs[q]; }
+            else otab[hs[q]] = (e & 0xFFFF0000u) | 0xFFFFu;
+          }
         }
+        pv_lds_barrier();
       }
-      pv_lds_barrier();
       PVPH(3);
-      const u32 nok = pv_uni(sh[2]);
+      const u32 nok = anykept ? pv_uni(sh[2]) : 0u;
       // ---- final row order: kept image rows and kept overflow keys together ----
       u32 nk = 0;
       if (nrows + nok <= 64) {
@@ -612,6 +619,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
       if (nok) __syncthreads();   // zero-filled overflow rows are in memory, and their ranks in the table, before the scatter
       PVPH(5);
+      if (anykept) {
 #pragma unroll
       for (int q = 0; q < OQ; q++) {
         const u32 t = tid + q * PV_TPB;
@@ -649,6 +657,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             }
           }
         }
+      }
       }
       pv_lds_barrier();
 #pragma unroll
