@@ -221,7 +221,8 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   }
   // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
   const u32 slots = (u32)ctx->n_cu * 2;
-  const u32 target_items = slots * 3;
+  const char* ipc = getenv("KMX_ITEMS_PER_SLOT");            // tuning knob (default 3): work items per resident workgroup slot
+  const u32 target_items = slots * (ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : 3u);
   u32 n_items = 0, max_n = 0, max_c = 0;
   for (auto& H : R->tasks) {
     u64 c = grand_total ? (u64)target_items * H.total_recs / grand_total : 1;
