@@ -246,3 +246,34 @@ def test_bench_workload_full_size_parity():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "verify_bench_parity.py")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert '"pivot_equals_rows_sha256": true' in r.stdout
+
+
+def test_partial_handback_in_a_batch(monkeypatch):
+    """A batch of three tasks of 600 lists: two cohorts the pivot kernel suits and one set of unrelated lists.  The
+    pivot kernel hands the third task back, libkmx re-runs that task alone with k_merge_rows, and all three bodies
+    and statistics equal the oracle's."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "pivot":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    ctx = lib.Context(0)
+    N = 600
+    sets = [synth_lists(5100, N, 5000, 0.97, 150, kw=1), synth_lists(5101, N, 5000, 0.25, 1200, kw=1), synth_lists(5102, N, 4000, 0.96, 160, kw=1)]
+    dev = torch.device("cuda", 0)
+    keep, tasks = [], []
+    for lists in sets:
+        recs = [lib.pack_records(k, c, 1) for k, c in lists]
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+        dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+        keep.append(dt)
+        tasks.append(dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                          soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT))
+    torch.cuda.synchronize()
+    res = ctx.merge_dev(tasks)
+    res.wait()
+    assert res.kernel() == "k_merge_pivot"            # two of the three tasks were completed by it
+    for t, lists in enumerate(sets):
+        eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT, 0, 0, 2)
+        assert res.rows(t) == er and res.body(t) == eb and np.array_equal(res.stats(t), es), t
+    res.free(); ctx.close()
