@@ -72,6 +72,10 @@ template <int KW> struct PvEnt { Key<KW> key; u32 idx; u32 pad; };   // idx = ro
 __device__ __forceinline__ u32 pv_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 pv_uni64(u64 v) { return (u64)pv_uni((u32)v) | ((u64)pv_uni((u32)(v >> 32)) << 32); }
 
+// a value the compiler must re-derive here: what is computed from it is not hoisted out of the tile loop (hoisted
+// addresses get spilled, and a scratch reload waits for every record load in flight)
+__device__ __forceinline__ int pv_fresh(int v) { asm volatile("" : "+v"(v)); return v; }
+
 __device__ __forceinline__ void pv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int KW> __device__ __forceinline__ u32 pv_mix(const Key<KW>& k)
@@ -220,29 +224,30 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     PVPH(0);
     for (;;) {
       // ---- tile = pivot records [ppos, ppos + rte); key range up to the next pivot key ----
+      const int tidA = pv_fresh(tid);
       const u32 rte = min(rt_cur, pend - ppos);
       const bool open_end = ppos + rte >= pend;     // last tile of the range: bounded by the lists' range ends
-      if ((u32)tid < rte) {
-        pk[tid] = pkn;
+      if ((u32)tidA < rte) {
+        pk[tidA] = pkn;
         u32 h = pv_thash<KW>(pkn);
-        while (atomicCAS(&ptab[h].idx, 0u, (u32)tid + 1) != 0) h = (h + 1) & (PV_PT - 1);
+        while (atomicCAS(&ptab[h].idx, 0u, (u32)tidA + 1) != 0) h = (h + 1) & (PV_PT - 1);
         ptab[h].key = pkn;
       }
-      if ((u32)tid == rte) { sh64[1] = pkn.w[0]; sh64[2] = open_end ? ~0ULL : pkn.w[0]; }   // upper key; exclusive limit (cuts lower it)
+      if ((u32)tidA == rte) { sh64[1] = pkn.w[0]; sh64[2] = open_end ? ~0ULL : pkn.w[0]; }   // upper key; exclusive limit (cuts lower it)
       {
         const u32 zb = rows_cap * row_bytes;
         uint4* z = reinterpret_cast<uint4*>(img);
-        for (u32 t = tid; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
-        if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; sh[8] = rec_min <= 1 ? 1u : 0u; }
+        for (u32 t = tidA; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
+        if (tidA == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; sh[8] = rec_min <= 1 ? 1u : 0u; }
         // hand-back flag of the task: loaded now, stored to LDS only behind the scan, so nobody waits for the load
-        if (tid == 0) hb = (u32)__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tidA == 0) hb = (u32)__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       pv_lds_barrier();
       PVPH(1);
       Key<KW> khi; khi.w[0] = open_end ? ~0ULL : pv_uni64(sh64[1]);
-      if ((u32)tid < rte) {   // row keys
+      if ((u32)tidA < rte) {   // row keys
         const Key<KW> mine = pkn;
-        u8* row = img + tid * row_bytes;
+        u8* row = img + tidA * row_bytes;
         if (MODE == 0) { u32* rw = reinterpret_cast<u32*>(row);
 #pragma unroll
           for (int q = 0; q < KW; q++) { rw[2 * q] = (u32)mine.w[q]; rw[2 * q + 1] = (u32)(mine.w[q] >> 32); } }
@@ -433,6 +438,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       PVPH(14);
       pv_lds_barrier();
       PVPH(15);
+      const int tidB = pv_fresh(tid), laneB = tidB & 63;
       u32 ovn = 0, ovmax = 0;
 #pragma unroll
       for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = pv_uni(wcnt[v]); ovn += w; ovmax = max(ovmax, w); }
@@ -443,7 +449,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         // range's records so far are not row keys: lists that do not resemble each other --
         // k_merge_rows does better there): flag the task, the driver re-runs the batch with
         // k_merge_rows.  Leave the tables clean for the next work item.
-        for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
+        for (int t = tidB; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;
         failed = unfit;
         break;
       }
@@ -451,15 +457,15 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       if (ovmax > (u32)PV_OVW * 5 / 8) rt_cur = max(3u, rt_cur - 3u);
       else if (ovmax < (u32)PV_OVW / 4 && rt_cur < rt_cap) rt_cur++;
 
-      for (int t = tid; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;   // the row table is dead after the scan: clean for the next tile
+      for (int t = tidB; t < PV_PT; t += PV_TPB) ptab[t].idx = 0;   // the row table is dead after the scan: clean for the next tile
       // recurrence of the image rows = number of lists that deposited a (solid) count: wave j counts row j
       {
         // (wave index recomputed here: as a loop invariant the row addresses derived from it get spilled, and
         //  a scratch reload right behind the scan waits for every refill load in flight)
-        u32 wv = pv_uni((u32)tid >> 6); asm volatile("" : "+s"(wv));
-        u32 ln = lane; asm volatile("" : "+v"(ln));
+        u32 wv = pv_uni((u32)tidB >> 6); asm volatile("" : "+s"(wv));
+        u32 ln = laneB; asm volatile("" : "+v"(ln));
         for (u32 j = wv; j < nrows; j += PV_TPB / 64) {
-          // ballots + scalar popcounts: no cross-lane reduction (its LDS round trips cost more than the row)
+          // ballots + scalar popcounts: no cross-laneB reduction (its LDS round trips cost more than the row)
           u32 nz = 0;
           if (MODE == 0) {
             const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);   // 8-byte aligned: row_bytes = 8 + 4N
@@ -482,7 +488,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
             nz = part;
           }
-          if (lane == 0) prec[j] = nz;
+          if (laneB == 0) prec[j] = nz;
         }
       }
       PVPH(2);   // no barrier here: the overflow insert below does not touch the image or prec
@@ -492,7 +498,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 #pragma unroll
       for (int q = 0; q < OQ; q++) {
         hs[q] = 0;
-        const u32 t = tid + q * PV_TPB;
+        const u32 t = tidB + q * PV_TPB;
         if ((t & (PV_OVW - 1)) < wcnt[t / PV_OVW]) {
           const OvRec<KW> o = ov[t];
           u32 h = pv_hash<KW>(o.key), old;
@@ -528,10 +534,10 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       // ---- final row order: kept image rows and kept overflow keys together ----
       u32 nk = 0;
       if (nrows + nok <= 64) {
-        // the usual case, done by wave 0 alone: every lane holds one key, the others are read with
+        // the usual case, done by wave 0 alone: every laneB holds one key, the others are read with
         // v_readlane -- no LDS round trip per comparison
-        if (tid < 64) {
-          const u32 it = lane, n = nrows + nok;
+        if (tidB < 64) {
+          const u32 it = laneB, n = nrows + nok;
           Key<KW> mine = key_inf<KW>(); bool kept = false;
           if (it < nrows) { mine = pk[it]; kept = prec[it] >= rec_min; }
           else if (it < n) { mine = ov[(otab[okl[it - nrows]] & 0xFFFFu) - 1].key; kept = true; }
@@ -549,7 +555,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         u32 nkp = 0;
         for (u32 j = 0; j < nrows; j++) nkp += prec[j] >= rec_min ? 1u : 0u;
         nk = nkp + nok;
-        for (u32 it = tid; it < nrows + nok; it += PV_TPB) {
+        for (u32 it = tidB; it < nrows + nok; it += PV_TPB) {
           Key<KW> mine; bool kept = true;
           if (it < nrows) { mine = pk[it]; kept = prec[it] >= rec_min; }
           else mine = ov[(otab[okl[it - nrows]] & 0xFFFFu) - 1].key;
@@ -560,7 +566,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           else orank[it - nrows] = (u16)rk;
         }
       }
-      if (tid == 0) {
+      if (tidB == 0) {
         u64 off = 0;
         if (nk) {
           u64 ch_base = al64[0]; u32 ch_used = al[0], ch_cap = al[1], ch_ok = al[3];
@@ -584,7 +590,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
       pv_lds_barrier();
       // overflow-key ranks go into their table entries (low 16 bits; the owner index is no longer needed)
-      for (u32 q = tid; q < nok; q += PV_TPB) {
+      for (u32 q = tidB; q < nok; q += PV_TPB) {
         const u32 t = okl[q];
         otab[t] = (otab[t] & 0xFFFF0000u) | orank[q];
       }
@@ -595,7 +601,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
 
       // ---- rows out: kept pivot rows from the LDS image; overflow rows zero-filled in HBM ----
       if (can_write) {
-        const int wave = tid >> 6;
+        const int wave = tidB >> 6;
         for (u32 j = wave; j < nrows + nok; j += PV_TPB / 64) {
           if (j < nrows) {
             const u32 rk = prank[j];
@@ -604,16 +610,16 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             u8* dst = out0 + (u64)rk * row_bytes;
             if (MODE == 0) {
               if (((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(j * row_bytes) | row_bytes) & 7u) == 0) {
-                for (u32 t = lane; t < row_bytes / 8; t += 64) reinterpret_cast<u64*>(dst)[t] = reinterpret_cast<const u64*>(src)[t];
+                for (u32 t = laneB; t < row_bytes / 8; t += 64) reinterpret_cast<u64*>(dst)[t] = reinterpret_cast<const u64*>(src)[t];
               } else {
-                for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = reinterpret_cast<const u32*>(src)[t];
+                for (u32 t = laneB; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = reinterpret_cast<const u32*>(src)[t];
               }
             }
-            else { for (u32 t = lane; t < row_bytes; t += 64) dst[t] = src[t]; }
+            else { for (u32 t = laneB; t < row_bytes; t += 64) dst[t] = src[t]; }
           } else {
             u8* dst = out0 + (u64)orank[j - nrows] * row_bytes;
-            if (MODE == 0) { for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = 0; }
-            else { for (u32 t = lane; t < row_bytes; t += 64) dst[t] = 0; }
+            if (MODE == 0) { for (u32 t = laneB; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = 0; }
+            else { for (u32 t = laneB; t < row_bytes; t += 64) dst[t] = 0; }
           }
         }
       }
@@ -622,7 +628,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       if (anykept) {
 #pragma unroll
       for (int q = 0; q < OQ; q++) {
-        const u32 t = tid + q * PV_TPB;
+        const u32 t = tidB + q * PV_TPB;
         if ((t & (PV_OVW - 1)) < wcnt[t / PV_OVW]) {
           const OvRec<KW> o = ov[t];
           const u32 e = otab[hs[q]];
