@@ -202,7 +202,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
     }
     // the pivot's records of this range define the tiles; a tile's keys are fetched one tile ahead
-    gu32* pbase = (gu32*)(uintptr_t)T.recs[T.pivot];
+    gu32* pbase = (gu32*)(uintptr_t)pv_uni64((u64)(uintptr_t)T.recs[T.pivot]);   // scalar: it lives across every tile
     const u32 pend = T.bounds[(u64)(range + 1) * N + T.pivot];
     u32 ppos = T.bounds[(u64)range * N + T.pivot];
     Key<KW> pkn = key_inf<KW>();
@@ -632,16 +632,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         if ((t & (PV_OVW - 1)) < wcnt[t / PV_OVW]) {
           const OvRec<KW> o = ov[t];
           const u32 e = otab[hs[q]];
-          const u32 rec = e >> 16, rk = e & 0xFFFFu;
-          u32 outc = 0;
-          if ((solidm >> q) & 1u) outc = o.cnt;
-          else {
-            if (share_min && rec >= share_min) {
-              outc = o.cnt;
-              atomicAdd(&T.stats[1 * (u64)N + o.list], 1ULL);
-              atomicAdd(&T.stats[5 * (u64)N + o.list], (u64)o.cnt);
-            }
-          }
+          const u32 rk = e & 0xFFFFu;
+          const u32 outc = ((solidm >> q) & 1u) ? o.cnt : 0u;   // no rescue here: tasks with share-min go to k_merge_rows
           if (can_write && rk != 0xFFFFu) {
             u8* dst = out0 + (u64)rk * row_bytes;
             if ((ownm >> q) & 1u) {   // the owner writes the row key
