@@ -493,13 +493,14 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       }
       PVPH(2);   // no barrier here: the overflow insert below does not touch the image or prec
       // ---- overflow records: merge them among themselves (hash set, as k_merge_rows) ----
-      constexpr int OQ = PV_OVCAP / PV_TPB;
+      constexpr int OQ = PV_OVW / 64;            // a wave merges its own slice: lane l takes slots l, l + 64, ... of it
+      const u32 wov_mine = pv_uni(wcnt[(u32)tidB >> 6]);
       u32 hs[OQ]; u32 ownm = 0, solidm = 0;
 #pragma unroll
       for (int q = 0; q < OQ; q++) {
         hs[q] = 0;
-        const u32 t = tidB + q * PV_TPB;
-        if ((t & (PV_OVW - 1)) < wcnt[t / PV_OVW]) {
+        const u32 t = ((u32)tidB >> 6) * PV_OVW + (u32)laneB + 64u * q;
+        if (64u * q < wov_mine && (u32)laneB + 64u * q < wov_mine) {
           const OvRec<KW> o = ov[t];
           u32 h = pv_hash<KW>(o.key), old;
           for (;;) {
@@ -628,8 +629,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       if (anykept) {
 #pragma unroll
       for (int q = 0; q < OQ; q++) {
-        const u32 t = tidB + q * PV_TPB;
-        if ((t & (PV_OVW - 1)) < wcnt[t / PV_OVW]) {
+        const u32 t = ((u32)tidB >> 6) * PV_OVW + (u32)laneB + 64u * q;
+        if (64u * q < wov_mine && (u32)laneB + 64u * q < wov_mine) {
           const OvRec<KW> o = ov[t];
           const u32 e = otab[hs[q]];
           const u32 rk = e & 0xFFFFu;
