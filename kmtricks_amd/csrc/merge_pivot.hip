@@ -333,9 +333,8 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       const u64 lim = pv_uni64(sh64[2]);           // exclusive upper key of the tile
       const bool unbounded = lim == ~0ULL;         // open-ended tile, not cut
       const u32 nrows = rte + min(pv_uni(sh[4]), rows_cap - rte);
-      u32 rte_eff = 0;
-      for (u32 j = 0; j < rte; j++) rte_eff += (unbounded || pk[j].w[0] < lim) ? 1u : 0u;
-      rte_eff = pv_uni(rte_eff);
+      // pivot rows below the limit (lane j looks at row j: one LDS read per lane, not rte per lane)
+      const u32 rte_eff = (u32)__popcll(__ballot((u32)lane < rte && (unbounded || pk[lane < 32 ? lane : 0].w[0] < lim)));
       const bool done = unbounded;
       {   // next tile's pivot keys
         const u32 npos = ppos + rte_eff;
@@ -471,11 +470,12 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);   // 8-byte aligned: row_bytes = 8 + 4N
             if ((row_bytes & 7u) == 0) {
               const uint2* row2 = reinterpret_cast<const uint2*>(rowc);
-              for (u32 t0 = 0; t0 < N / 2; t0 += 64) {
-                const u32 t = t0 + ln;
-                uint2 v = make_uint2(0, 0);
-                if (t < N / 2) v = row2[t];
-                nz += __popcll(__ballot(v.x != 0)) + __popcll(__ballot(v.y != 0));
+              for (u32 t0 = 0; t0 < N / 2; t0 += 128) {      // two reads in flight per lane
+                const u32 ta = t0 + ln, tb = t0 + 64 + ln;
+                uint2 va = make_uint2(0, 0), vb = make_uint2(0, 0);
+                if (ta < N / 2) va = row2[ta];
+                if (tb < N / 2) vb = row2[tb];
+                nz += __popcll(__ballot(va.x != 0)) + __popcll(__ballot(va.y != 0)) + __popcll(__ballot(vb.x != 0)) + __popcll(__ballot(vb.y != 0));
               }
             } else {
               for (u32 t0 = 0; t0 < N; t0 += 64) { const u32 t = t0 + ln; nz += __popcll(__ballot(t < N && rowc[t] != 0)); }
