@@ -470,12 +470,12 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             const u32* rowc = reinterpret_cast<const u32*>(img + j * row_bytes + KW * 8);   // 8-byte aligned: row_bytes = 8 + 4N
             if ((row_bytes & 7u) == 0) {
               const uint2* row2 = reinterpret_cast<const uint2*>(rowc);
-              for (u32 t0 = 0; t0 < N / 2; t0 += 128) {      // two reads in flight per lane
-                const u32 ta = t0 + ln, tb = t0 + 64 + ln;
-                uint2 va = make_uint2(0, 0), vb = make_uint2(0, 0);
-                if (ta < N / 2) va = row2[ta];
-                if (tb < N / 2) vb = row2[tb];
-                nz += __popcll(__ballot(va.x != 0)) + __popcll(__ballot(va.y != 0)) + __popcll(__ballot(vb.x != 0)) + __popcll(__ballot(vb.y != 0));
+              for (u32 t0 = 0; t0 < N / 2; t0 += 256) {      // four reads in flight per lane
+                uint2 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const u32 t = t0 + 64 * q + ln; v[q] = make_uint2(0, 0); if (t < N / 2) v[q] = row2[t]; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) nz += __popcll(__ballot(v[q].x != 0)) + __popcll(__ballot(v[q].y != 0));
               }
             } else {
               for (u32 t0 = 0; t0 < N; t0 += 64) { const u32 t = t0 + ln; nz += __popcll(__ballot(t < N && rowc[t] != 0)); }
@@ -611,7 +611,13 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             u8* dst = out0 + (u64)rk * row_bytes;
             if (MODE == 0) {
               if (((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(j * row_bytes) | row_bytes) & 7u) == 0) {
-                for (u32 t = laneB; t < row_bytes / 8; t += 64) reinterpret_cast<u64*>(dst)[t] = reinterpret_cast<const u64*>(src)[t];
+                for (u32 t0 = 0; t0 < row_bytes / 8; t0 += 256) {      // four row words in flight per lane
+                  u64 w[4];
+#pragma unroll
+                  for (int q = 0; q < 4; q++) { const u32 t = t0 + 64 * q + laneB; w[q] = t < row_bytes / 8 ? reinterpret_cast<const u64*>(src)[t] : 0ULL; }
+#pragma unroll
+                  for (int q = 0; q < 4; q++) { const u32 t = t0 + 64 * q + laneB; if (t < row_bytes / 8) reinterpret_cast<u64*>(dst)[t] = w[q]; }
+                }
               } else {
                 for (u32 t = laneB; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(dst)[t] = reinterpret_cast<const u32*>(src)[t];
               }
