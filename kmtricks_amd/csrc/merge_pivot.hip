@@ -402,8 +402,13 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
           // (count = the list's group sum of per-lane counts: lane-crossing adds, no ballot / scalar round trips)
           u32 c = __popc(consm);
           lcons += c;
+          if (PV_G == 4) {   // quad sum with DPP lane permutes: no LDS round trip on the way to the refill addresses
+            c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+          } else {
 #pragma unroll
-          for (int off = 1; off < PV_G; off <<= 1) c += __shfl_xor(c, off);
+            for (int off = 1; off < PV_G; off <<= 1) c += __shfl_xor(c, off);
+          }
           if (consm) {
             if (tsum) atomicAdd(&lt_two[li], tsum);
             if (tn) atomicAdd(&lt_nso[li], tn);
