@@ -53,6 +53,7 @@ constexpr int PV_LPP = PV_TPB / PV_G;   // lists per pass
 constexpr int PV_MAXN = 1024;       // lists per task
 constexpr int PV_NP = PV_MAXN / PV_LPP;   // passes
 constexpr int PV_NH = 8;             // helper lists
+constexpr int PV_HSTRIDE = 64 / PV_G;   // lists per wave and pass: helpers sit one wave apart
 constexpr int PV_NC = 64;            // candidate keys per tile (one per lane of wave 0)
 constexpr int PV_PT = 128;          // pivot lookup table entries (load factor <= 1/8)
 static_assert(PV_RTMAX <= 16 && (PV_W & (PV_W - 1)) == 0, "tile geometry");
@@ -213,7 +214,9 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     // extra image row (one helper alone would mostly contribute its private keys); when the rows run
     // out, the tile is cut in front of the first key that did not get one.
     // helpers = the first PV_NH lists that are not the pivot (all served in pass 0)
-    const u32 hmax = min(N, (u32)PV_NH + (T.pivot <= (u32)PV_NH ? 1u : 0u));   // lists [0, hmax) minus the pivot
+    // helpers: every PV_HSTRIDE-th list of the first pass (one per wave, so the candidate probes run in parallel
+    // instead of all landing on wave 0), the pivot excepted
+    const u32 hmax = min(N, (u32)(PV_NH + 1) * PV_HSTRIDE);
     if (tid == 0) { al64[0] = 0; al[0] = 0; al[1] = 0; al[2] = 0; al[3] = 1; }
     u32 seq = 0, ovsum = 0, conssum = 0;
     u32 hb = 0;                          // thread 0: the task's error word as of the start of the tile
@@ -276,7 +279,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
             const Key<KW> k = rec_key(rec[p][u]);
             const bool below = ix < end && (open_end || key_less<KW>(k, khi));
             if (below && ix == cur + PV_W - 1 && cur + PV_W < end) atomicMin(&sh64[2], k.w[0] + 1);
-            if (p == 0 && below && li < hmax && li != T.pivot) {   // a helper's key the pivot lacks: candidate row
+            if (p == 0 && below && li < hmax && (li % PV_HSTRIDE) == 0 && li != T.pivot) {   // a helper's key the pivot lacks: candidate row
               u32 h = pv_thash<KW>(k);
               u32 idx = ptab[h].idx;
               if (idx != 0 && !key_eq<KW>(ptab[h].key, k)) idx = pv_lookup_slow<KW>(ptab, k, h);
