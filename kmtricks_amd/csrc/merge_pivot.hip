@@ -113,6 +113,9 @@ __device__ __noinline__ u32 pv_lookup_slow(const PvEnt<KW>* ptab, Key<KW> k, u32
 
 #ifdef KMX_PHASE_PROF
 __device__ u64 kmx_pivot_prof[16];
+#ifndef KMX_PROF_TID
+#define KMX_PROF_TID 0      // the thread whose clock64 deltas are summed (wave 0 does the serial work; try 512 for a typical wave)
+#endif
 #endif
 
 template <int KW, int MODE>
@@ -164,7 +167,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     __syncthreads();
     if (item >= n_items) {
 #ifdef KMX_PHASE_PROF
-      if (tid == 0) for (int i = 0; i < 16; i++) atomicAdd(&kmx_pivot_prof[i], (u64)pt[i]);
+      if (tid == KMX_PROF_TID) for (int i = 0; i < 16; i++) atomicAdd(&kmx_pivot_prof[i], (u64)pt[i]);
 #endif
       return;
     }
