@@ -132,7 +132,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
   Key<KW>* pk = reinterpret_cast<Key<KW>*>(misc);                                         // [32] keys of the image rows (pivot rows, then adopted rows)
   u32* prec = reinterpret_cast<u32*>(misc + 256);                                         // [32] recurrence
   u32* prank = reinterpret_cast<u32*>(misc + 384);                                        // [32] final row or ~0
-  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] - [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed [7] task error bits [8] some overflow key may be kept
+  u32* sh = reinterpret_cast<u32*>(misc + 512);                                           // [0] item [1] overflow records [2] nok [3] can-write [4] adopted rows [5] candidates [6] records consumed [7] task error bits [8] some overflow key may be kept [9] fullest overflow slice
   u64* sh64 = reinterpret_cast<u64*>(misc + 576);                                         // [0] tile row base [1] upper key [2] cut
   u32* wcnt = reinterpret_cast<u32*>(misc + 1152);                                        // [waves] overflow records in each wave's slice
   u64* cand = reinterpret_cast<u64*>(misc + 640);                                        // [PV_NC] helper keys the pivot lacks
@@ -244,7 +244,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         const u32 zb = rows_cap * row_bytes;
         uint4* z = reinterpret_cast<uint4*>(img);
         for (u32 t = tidA; t < (zb + 15) / 16; t += PV_TPB) z[t] = make_uint4(0, 0, 0, 0);
-        if (tidA == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; sh[8] = rec_min <= 1 ? 1u : 0u; }
+        if (tidA == 0) { sh[1] = 0; sh[2] = 0; sh[4] = 0; sh[5] = 0; sh[6] = 0; sh[8] = rec_min <= 1 ? 1u : 0u; sh[9] = 0; }
         // hand-back flag of the task: loaded now, stored to LDS only behind the scan, so nobody waits for the load
         if (tidA == 0) hb = (u32)__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -438,10 +438,11 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
         }
       }
       {
-        u32 wcons = lcons;
+        // wave sum of the per-lane counts (<= 16 each) bit by bit with ballots: scalar work, no cross-lane LDS traffic
+        u32 wcons = 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wcons += __shfl_xor(wcons, off);
-        if (lane == 0) { if (wcons) atomicAdd(&sh[6], wcons); wcnt[tid >> 6] = wov; }
+        for (int b = 0; b < 5; b++) wcons += (u32)__popcll(__ballot((lcons >> b) & 1u)) << b;
+        if (lane == 0) { if (wcons) atomicAdd(&sh[6], wcons); wcnt[tid >> 6] = wov; if (wov) { atomicAdd(&sh[1], wov); atomicMax(&sh[9], wov); } }
         if (tid == 0) sh[7] = hb;
       }
       PVPH(8);
@@ -449,9 +450,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
       pv_lds_barrier();
       PVPH(15);
       const int tidB = pv_fresh(tid), laneB = tidB & 63;
-      u32 ovn = 0, ovmax = 0;
-#pragma unroll
-      for (int v = 0; v < PV_TPB / 64; v++) { const u32 w = pv_uni(wcnt[v]); ovn += w; ovmax = max(ovmax, w); }
+      const u32 ovn = pv_uni(sh[1]), ovmax = pv_uni(sh[9]);     // overflow records of the tile, fullest slice
       ovsum += ovn; conssum += pv_uni(sh[6]);
       const bool unfit = ovmax > (u32)PV_OVW || (conssum > 65536u && ovsum * 8u > conssum);
       if (unfit || (pv_uni(sh[7]) & (u32)ERR_FALLBACK)) {   // ... or another workgroup already handed this task back
