@@ -45,6 +45,11 @@ struct TaskDev {
   u32 item0;               // first work item of this task in the batch's flat item space
 };
 
+// rows are claimed from a task's arena in chunks of this many bytes (one global atomic + one directory entry per chunk)
+#ifndef KMX_CHUNK_BYTES
+#define KMX_CHUNK_BYTES 262144
+#endif
+
 enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2, ERR_FALLBACK = 4 };
 
 // ---- keys -------------------------------------------------------------------------------------

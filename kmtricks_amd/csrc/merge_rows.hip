@@ -178,7 +178,7 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
     const u32 N = T.N, wl = T.wl, w = 1u << wl;      // w <= 64: a list's window never leaves its wave
     const u32 rec_min = T.rec_min, share_min = T.share_min, row_bytes = T.row_bytes;
     const u32 sat = max(rec_min, share_min);          // recurrence only matters up to this value
-    const u32 chunk_rows = max(64u, 262144u / row_bytes);
+    const u32 chunk_rows = max(64u, (u32)KMX_CHUNK_BYTES / row_bytes);
     const u32 g0 = lane & ~(w - 1);                   // first lane of my list's lane group
     const u32 nxt = (lane + 1) & (w - 1);             // group-relative lane holding the next window position
     const u64 wmask = (w == 64) ? ~0ULL : ((1ULL << w) - 1);
@@ -507,7 +507,7 @@ namespace kmx {
 int rows_lds_bytes(int kw, u32) { return rows_fixed_bytes(kw) + 384; }
 int rows_cap() { return CAP; }
 int rows_wgs_per_cu(int kw) { return kw == 1 ? WGS_PER_CU : 1; }
-u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, 262144u / row_bytes); }
+u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, (u32)KMX_CHUNK_BYTES / row_bytes); }
 u32 rows_image_bytes(int kw) { return (u32)rows_emit_bytes(kw); }
 #ifdef KMX_PHASE_PROF
 void rows_phase_prof_dump()
