@@ -183,6 +183,14 @@ __global__ void k_superk_part_bounds(const u16* __restrict__ part_sorted, u32 n,
   part_first[p] = lo;
 }
 
+// four ASCII bases (one unaligned dword) -> four 2-bit codes in one byte, first base in the low bits
+__device__ __forceinline__ u32 pack4(u32 w)
+{
+  w = (w >> 1) & 0x03030303u;
+  return (w | (w >> 6) | (w >> 12) | (w >> 18)) & 0xFFu;
+}
+__device__ __forceinline__ u32 load4(const char* p) { u32 w; __builtin_memcpy(&w, p, 4); return w; }
+
 __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __restrict__ desc, const u32* __restrict__ ids,
                               const u64* __restrict__ byte_off, u32 n, int k, u8* __restrict__ out)
 {
@@ -193,13 +201,22 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
   u8* o = out + (u32)byte_off[i];
   const int ndig = k + d.n - 1;
   o[0] = d.n;
+  // Bytes are made of four digits; digit d < k is base[k-1-d] (the first k-mer, last base first), digit d >= k is
+  // base[d].  A byte that lies wholly in one of the two parts comes from ONE 4-byte load of the read; only the byte
+  // that straddles digit k and the last, partial byte are assembled digit by digit.
   for (int by = 0; by * 4 < ndig; by++) {
-    u32 v = 0;
-    for (int q = 0; q < 4; q++) {
-      const int dg = by * 4 + q;
-      if (dg >= ndig) break;
-      const int bi = dg < k ? (k - 1 - dg) : dg;
-      v |= (((u32)(u8)seq[bi] >> 1) & 3u) << (2 * q);
+    const int d0 = by * 4;
+    u32 v;
+    if (d0 + 3 < k) v = pack4(__builtin_bswap32(load4(seq + (k - d0 - 4))));     // bases k-d0-4 .. k-d0-1, reversed
+    else if (d0 >= k && d0 + 3 < ndig) v = pack4(load4(seq + d0));
+    else {
+      v = 0;
+      for (int q = 0; q < 4; q++) {
+        const int dg = d0 + q;
+        if (dg >= ndig) break;
+        const int bi = dg < k ? (k - 1 - dg) : dg;
+        v |= (((u32)(u8)seq[bi] >> 1) & 3u) << (2 * q);
+      }
     }
     o[1 + by] = (u8)v;
   }
