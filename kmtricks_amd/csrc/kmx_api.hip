@@ -112,6 +112,11 @@ struct TaskHost {
   u64 rows = 0, nsegs = 0;
   bool done = false;
   bool handed_back = false;     // the pivot kernel flagged this task: it is (was) re-run with k_merge_rows
+  // column-blocked kernel (merge_cols.hip)
+  u32 nblk = 0, nb = 0, rt_cols = 0, slots_cap = 0;
+  size_t o_skel = 0, o_nskel = 0, o_rbounds = 0;
+  u8* d_ov = nullptr;           // keys + counts of the records that are not row keys
+  int kernel = 0;               // the kernel that completed (or is to complete) the task: 0 rows, 1 pivot, 2 cols
 };
 
 struct kmx_merge_result {
@@ -126,6 +131,11 @@ struct kmx_merge_result {
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
+  // column-blocked kernel first (merge_cols.hip): its row keys come from a merge of a few lists of every task
+  bool use_cols = false, cols_auto = false, can_pivot = false, pivot_part = false;
+  std::vector<TaskHost> subs;        // the row-key merges, one per task
+  size_t o_subtasks = 0, o_subitems = 0, o_cols = 0, o_citems = 0;
+  u32 n_subitems = 0, n_citems = 0, sub_grid = 0, cols_grid = 0, sub_max_c = 0, sub_max_n = 0, items_grid = 0;
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
 };
@@ -146,6 +156,23 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_bf(mode == KMX_MODE_BFC, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->bf_lds, ctx->stream));
+  } else if (R->use_cols) {
+    // row keys first (bounds + k_merge_rows over a few lists of every task, gathered by k_cols_prep), then the
+    // column-blocked merge, then the check that no key outside the rows reaches the recurrence
+    const TaskDev* d_subs = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_subtasks);
+    const uint2* d_subitems = reinterpret_cast<const uint2*>(R->d_meta + R->o_subitems);
+    const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
+    const uint2* d_citems = reinterpret_cast<const uint2*>(R->d_meta + R->o_citems);
+    KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 64, ctx->stream));
+    KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
+    KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ctx->stream));
+    KMX_HIP(ctx, launch_merge_rows(kw, mode, d_subs, d_subitems, R->n_subitems, d_ticket + 8, R->sub_grid, R->sub_max_n, ctx->stream));
+    KMX_HIP(ctx, launch_cols_prep(d_tasks, d_subs, d_cols, nt, ctx->stream));
+    if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
+    KMX_HIP(ctx, launch_merge_cols(d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
+    if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
+    KMX_HIP(ctx, launch_cols_check(d_tasks, d_cols, d_items, R->n_items, ctx->stream));
+    return KMX_OK;
   } else {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
@@ -219,13 +246,51 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.rows_guess = std::max<u64>(guess, 1);   // arena = guess + chunk slack, sized once c is known
     }
   }
+  // ---- which COUNT/PA kernel ----
+  // k_merge_rows is the general one.  k_merge_pivot (merge_pivot.hip; 64-bit keys, no share-min, <= 1024
+  // lists) is faster when MANY lists share most of their keys -- the cohort case the metric is quoted on --
+  // and k_merge_cols (merge_cols.hip; COUNT rows, a small recurrence-min) faster still there.  Both flag tasks
+  // they do not suit, and those are re-run with the next kernel down (cols -> pivot -> rows, see
+  // kmx_result_wait).  Default: more than 512 lists per task (where k_merge_rows is down to 4-record windows)
+  // go to cols when 2 <= recurrence-min <= 4, to pivot otherwise.
+  // KMX_MERGE_KERNEL=rows|pivot|cols forces one of them (where it is applicable).
+  {
+    bool rescue = false; u32 min_n = 0xFFFFFFFFu, mx_n = 0, min_rec = 0xFFFFFFFFu, max_rec = 0;
+    for (auto& H : R->tasks) {
+      rescue |= H.share_min > 0; min_n = std::min(min_n, H.N); mx_n = std::max(mx_n, H.N);
+      min_rec = std::min(min_rec, H.rec_min); max_rec = std::max(max_rec, H.rec_min);
+    }
+    const char* force = getenv("KMX_MERGE_KERNEL");
+    const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
+    const bool can_cols = !is_bf && mode == KMX_MODE_COUNT && !rescue && kw == 1 && mx_n <= (u32)rows_cap() && min_rec >= 1;
+    R->can_pivot = can;
+    if (force && !strcmp(force, "cols")) { R->use_cols = can_cols; R->use_pivot = !can_cols && can; }
+    else if (force && !strcmp(force, "pivot")) R->use_pivot = can;
+    else if (force && !strcmp(force, "rows")) R->use_pivot = false;
+    else {
+      R->use_cols = can_cols && min_n > 512 && min_rec >= 2 && max_rec <= 4;
+      if (R->use_cols && ctx->cols_skip) { ctx->cols_skip--; R->use_cols = false; }
+      R->cols_auto = R->use_cols;
+      R->use_pivot = !R->use_cols && can && min_n > 512;
+      if (R->use_pivot && ctx->pivot_skip) { ctx->pivot_skip--; R->use_pivot = false; }   // cohort that did not suit it recently
+      R->pivot_auto = R->use_pivot;
+    }
+  }
   // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
   const u32 slots = (u32)ctx->n_cu * 2;
   const char* ipc = getenv("KMX_ITEMS_PER_SLOT");            // tuning knob (default 3): work items per resident workgroup slot
-  const u32 target_items = slots * (ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : 3u);
+  const u32 per_slot = ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : 3u;
+  const u32 target_items = (R->use_cols ? (u32)ctx->n_cu : slots) * per_slot;   // (cols: one workgroup per CU, and a work item is a column block of a range)
   u32 n_items = 0, max_n = 0, max_c = 0;
   for (auto& H : R->tasks) {
+    if (R->use_cols) {
+      H.nblk = (H.N + cols_block_lists() - 1) / cols_block_lists();
+      H.nb = std::min<u32>(cols_block_lists(), (((H.N + H.nblk - 1) / H.nblk) + 1) & ~1u);
+      H.nblk = (H.N + H.nb - 1) / H.nb;
+      H.rt_cols = cols_tile_rows(H.nb);
+    }
     u64 c = grand_total ? (u64)target_items * H.total_recs / grand_total : 1;
+    if (R->use_cols) c = (c + H.nblk / 2) / H.nblk;
     const u64 cmax_work = std::max<u64>(1, H.total_recs / 16384);
     c = std::min(c, cmax_work);
     if (is_bf) {
@@ -238,30 +303,45 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.out_cap_rows = H.rows_guess + (u64)(H.c + 1) * rows_chunk_rows(H.row_bytes);
       H.out_bytes = (size_t)(H.out_cap_rows * H.row_bytes);
     }
+    if (R->use_cols) H.slots_cap = (u32)std::min<u64>(0x7FFFFFF0ULL, H.out_cap_rows / H.rt_cols + H.c + 2);
     n_items += H.c;
     max_n = std::max(max_n, H.N); max_c = std::max(max_c, H.c);
   }
   R->n_items = n_items; R->max_n = max_n; R->max_c = max_c;
   R->grid = std::min(n_items, is_bf ? slots : (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)kw));
-  {
-    // Two COUNT/PA kernels.  k_merge_rows is the general one.  k_merge_pivot (merge_pivot.hip; 64-bit keys,
-    // no share-min, <= 1024 lists) is faster when MANY lists share most of their keys -- the cohort
-    // case the metric is quoted on -- and flags tasks it does not suit (they are re-run with
-    // k_merge_rows, see kmx_result_wait).  Default: pivot for batches of more than 512 lists per task
-    // (where k_merge_rows is down to 4-record windows).
-    // KMX_MERGE_KERNEL=rows|pivot forces one of them (pivot only where it is applicable).
-    bool rescue = false; u32 min_n = 0xFFFFFFFFu;
-    for (auto& H : R->tasks) { rescue |= H.share_min > 0; min_n = std::min(min_n, H.N); }
-    const char* force = getenv("KMX_MERGE_KERNEL");
-    const bool can = !is_bf && !rescue && kw == 1 && max_n <= pivot_max_lists();
-    if (force && !strcmp(force, "pivot")) R->use_pivot = can;
-    else if (force && !strcmp(force, "rows")) R->use_pivot = false;
-    else {
-      R->use_pivot = can && min_n > 512;
-      if (R->use_pivot && ctx->pivot_skip) { ctx->pivot_skip--; R->use_pivot = false; }   // cohort that did not suit it recently
-      R->pivot_auto = R->use_pivot;
+  if (R->use_pivot) R->grid = std::min(n_items, (u32)ctx->n_cu);   // one 1024-thread workgroup per CU
+  if (R->use_cols) {
+    // the row-key merges: up to 8 lists spread over each task, same recurrence-min
+    R->subs.resize(n_tasks);
+    u32 nsub = 0, ncit = 0;
+    for (u32 t = 0; t < n_tasks; t++) {
+      const TaskHost& H = R->tasks[t];
+      TaskHost& Q = R->subs[t];
+      Q.N = std::min<u32>(8, H.N); Q.kw = kw; Q.mode = mode; Q.rec_min = H.rec_min; Q.share_min = 0;
+      Q.len.resize(Q.N);
+      u32 piv = 0;
+      for (u32 i = 0; i < Q.N; i++) {
+        const u32 src = (u32)(((2ull * i + 1) * H.N) / (2ull * Q.N));
+        Q.len[i] = H.len[src]; Q.total_recs += H.len[src];
+        if (Q.len[i] > Q.len[piv]) piv = i;
+      }
+      Q.pivot = (Q.N >= 2 && Q.len[Q.N / 2] > 0) ? Q.N / 2 : piv;
+      Q.row_bytes = kw * 8 + 4 * Q.N;
+      u32 wl = 0; while (wl < 6 && (Q.N << (wl + 1)) <= (u32)rows_cap()) wl++;
+      Q.wl = wl;
+      Q.rows_guess = std::max<u64>(1, std::min<u64>(H.rows_guess, Q.total_recs));
+      u64 c = std::min<u64>(64, std::max<u64>(1, Q.total_recs / 16384));
+      c = std::min<u64>(c, std::max<u32>(1, Q.len[Q.pivot]));
+      Q.c = (u32)c;
+      Q.seg_cap = (u32)std::min<u64>(0x7FFFFFFF, Q.total_recs / 512 + 8ULL * Q.c + 64);
+      Q.out_cap_rows = Q.rows_guess + (u64)(Q.c + 1) * rows_chunk_rows(Q.row_bytes);
+      Q.out_bytes = (size_t)(Q.out_cap_rows * Q.row_bytes);
+      nsub += Q.c; ncit += H.c * H.nblk;
+      R->sub_max_c = std::max(R->sub_max_c, Q.c); R->sub_max_n = std::max(R->sub_max_n, Q.N);
     }
-    if (R->use_pivot) R->grid = std::min(n_items, (u32)ctx->n_cu);   // one 1024-thread workgroup per CU
+    R->n_subitems = nsub; R->n_citems = ncit;
+    R->sub_grid = std::min(nsub, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)kw));
+    R->cols_grid = std::min(ncit, (u32)ctx->n_cu);
   }
   if (is_bf) {
     int lds = 0;
@@ -269,7 +349,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     R->bf_lds = lds;
   }
 
+  for (auto& H : R->tasks) H.kernel = R->use_cols ? 2 : R->use_pivot ? 1 : 0;
   // ---- meta blob layout ----
+  const bool cols = R->use_cols;
   size_t off = 0;
   R->o_tasks = off; off = align_up(off + sizeof(TaskDev) * n_tasks, 256);
   R->o_items = off; off = align_up(off + sizeof(uint2) * n_items, 256);
@@ -277,41 +359,58 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->o_ctrl0 = off;                       // control words of all tasks, contiguous: one D2H copy reads them all
   for (auto& H : R->tasks) { H.o_ctrl = off; off += 64; }
   off = align_up(off, 256);
-  for (auto& H : R->tasks) {
+  auto lay_lists = [&](TaskHost& H) {
     H.o_recs = off; off = align_up(off + 8ull * H.N, 256);
     H.o_len = off; off = align_up(off + 4ull * H.N, 256);
     H.o_smin = off; off = align_up(off + 4ull * H.N, 256);
     H.o_stats = off; off = align_up(off + 8ull * 6 * H.N, 256);
+  };
+  for (auto& H : R->tasks) lay_lists(H);
+  if (cols) {
+    R->o_subtasks = off; off = align_up(off + sizeof(TaskDev) * n_tasks, 256);
+    R->o_subitems = off; off = align_up(off + sizeof(uint2) * R->n_subitems, 256);
+    R->o_cols = off; off = align_up(off + sizeof(ColsDev) * n_tasks, 256);
+    R->o_citems = off; off = align_up(off + sizeof(uint2) * R->n_citems, 256);
+    for (auto& Q : R->subs) { Q.o_ctrl = off; off += 64; }
+    off = align_up(off, 256);
+    for (auto& Q : R->subs) lay_lists(Q);
   }
   const size_t upload_bytes = off;            // everything above is written by the host
-  for (auto& H : R->tasks) {
+  auto lay_work = [&](TaskHost& H) {
     H.o_bounds = off; off = align_up(off + 4ull * (H.c + 1) * H.N, 256);
     H.o_segs = off; off = align_up(off + sizeof(Seg) * (size_t)H.seg_cap, 256);
+  };
+  for (auto& H : R->tasks) lay_work(H);
+  if (cols) {
+    for (auto& Q : R->subs) lay_work(Q);
+    for (auto& H : R->tasks) {
+      H.o_skel = off; off = align_up(off + 8ull * H.out_cap_rows, 256);
+      H.o_nskel = off; off += 256;
+      H.o_rbounds = off; off = align_up(off + 4ull * (H.c + 1), 256);
+    }
   }
   R->meta_bytes = off;
   R->d_meta = (u8*)ctx->dalloc(off);
   R->h_meta = (u8*)ctx->halloc(upload_bytes);
   if (!R->d_meta || !R->h_meta) { ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); return ctx->fail(KMX_E_NOMEM, "meta allocation failed"); }
+  auto drop_blocks = [&]() {
+    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); }
+    for (auto& G : R->subs) ctx->dfree(G.d_out);
+    ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
+  };
   for (auto& H : R->tasks) {
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
-    if (!H.d_out) {
-      for (auto& G : R->tasks) ctx->dfree(G.d_out);
-      ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
-      return ctx->fail(KMX_E_NOMEM, "output arena allocation failed");
-    }
+    if (H.d_out && cols) H.d_ov = (u8*)ctx->dalloc((size_t)(cols_scratch_keys(H.slots_cap, H.nblk) * 8 + cols_scratch_counts(H.slots_cap, H.nblk) * 4));
+    if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
+  }
+  for (auto& Q : R->subs) {
+    Q.d_out = (u8*)ctx->dalloc(Q.out_bytes);
+    if (!Q.d_out) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "row-key arena allocation failed"); }
   }
   memset(R->h_meta, 0, upload_bytes);
   TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
   uint2* items = reinterpret_cast<uint2*>(R->h_meta + R->o_items);
-  u32 it = 0;
-  for (u32 t = 0; t < n_tasks; t++) {
-    TaskHost& H = R->tasks[t];
-    const kmx_merge_task& K = tasks[t];
-    const u8** recs = reinterpret_cast<const u8**>(R->h_meta + H.o_recs);
-    u32* len = reinterpret_cast<u32*>(R->h_meta + H.o_len);
-    u32* smin = reinterpret_cast<u32*>(R->h_meta + H.o_smin);
-    for (u32 i = 0; i < H.N; i++) { recs[i] = (const u8*)K.lists[i].recs; len[i] = H.len[i]; smin[i] = K.soft_min[i]; }
-    TaskDev& D = td[t];
+  auto fill_dev = [&](TaskHost& H, TaskDev& D) {   // everything but the list tables
     D.recs = reinterpret_cast<const u8* const*>(R->d_meta + H.o_recs);
     D.len = reinterpret_cast<const u32*>(R->d_meta + H.o_len);
     D.soft_min = reinterpret_cast<const u32*>(R->d_meta + H.o_smin);
@@ -324,13 +423,53 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     D.out_cap_rows = H.out_cap_rows; D.lower = H.lower; D.upper = H.upper;
     D.seg_cap = H.seg_cap; D.N = H.N; D.c = H.c; D.rec_min = H.rec_min; D.share_min = H.share_min;
     D.mode = H.mode; D.bitw = H.bitw; D.row_bytes = H.row_bytes; D.wl = H.wl; D.pivot = H.pivot; D.rt = H.rt;
+  };
+  u32 it = 0;
+  for (u32 t = 0; t < n_tasks; t++) {
+    TaskHost& H = R->tasks[t];
+    const kmx_merge_task& K = tasks[t];
+    const u8** recs = reinterpret_cast<const u8**>(R->h_meta + H.o_recs);
+    u32* len = reinterpret_cast<u32*>(R->h_meta + H.o_len);
+    u32* smin = reinterpret_cast<u32*>(R->h_meta + H.o_smin);
+    for (u32 i = 0; i < H.N; i++) { recs[i] = (const u8*)K.lists[i].recs; len[i] = H.len[i]; smin[i] = K.soft_min[i]; }
+    TaskDev& D = td[t];
+    fill_dev(H, D);
     D.item0 = it;
     for (u32 j = 0; j < H.c; j++) items[it++] = make_uint2(t, j);
   }
+  if (cols) {
+    TaskDev* sd = reinterpret_cast<TaskDev*>(R->h_meta + R->o_subtasks);
+    uint2* sitems = reinterpret_cast<uint2*>(R->h_meta + R->o_subitems);
+    ColsDev* cd = reinterpret_cast<ColsDev*>(R->h_meta + R->o_cols);
+    uint2* citems = reinterpret_cast<uint2*>(R->h_meta + R->o_citems);
+    u32 si = 0, ci = 0;
+    for (u32 t = 0; t < n_tasks; t++) {
+      TaskHost& H = R->tasks[t];
+      TaskHost& Q = R->subs[t];
+      const kmx_merge_task& K = tasks[t];
+      const u8** recs = reinterpret_cast<const u8**>(R->h_meta + Q.o_recs);
+      u32* len = reinterpret_cast<u32*>(R->h_meta + Q.o_len);
+      u32* smin = reinterpret_cast<u32*>(R->h_meta + Q.o_smin);
+      for (u32 i = 0; i < Q.N; i++) {
+        const u32 src = (u32)(((2ull * i + 1) * H.N) / (2ull * Q.N));
+        recs[i] = (const u8*)K.lists[src].recs; len[i] = Q.len[i]; smin[i] = K.soft_min[src];
+      }
+      fill_dev(Q, sd[t]);
+      sd[t].item0 = si;
+      for (u32 j = 0; j < Q.c; j++) sitems[si++] = make_uint2(t, j);
+      ColsDev& C = cd[t];
+      C.skel = reinterpret_cast<u64*>(R->d_meta + H.o_skel);
+      C.nskel = reinterpret_cast<u32*>(R->d_meta + H.o_nskel);
+      C.rbounds = reinterpret_cast<u32*>(R->d_meta + H.o_rbounds);
+      C.ovkeys = reinterpret_cast<u64*>(H.d_ov);
+      C.ovcnt = reinterpret_cast<u32*>(H.d_ov + cols_scratch_keys(H.slots_cap, H.nblk) * 8);
+      C.slots_cap = H.slots_cap; C.nblk = H.nblk; C.nb = H.nb; C.rt = H.rt_cols;
+      for (u32 j = 0; j < H.c * H.nblk; j++) citems[ci++] = make_uint2(t, j);   // y = range * nblk + block
+    }
+  }
   auto drop = [&]() {   // hand every block back to the pool on a failed launch
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& H : R->tasks) ctx->dfree(H.d_out);
-    ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
+    drop_blocks();
     if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
   };
   hipError_t he = hipMemcpyAsync(R->d_meta, R->h_meta, upload_bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -355,6 +494,7 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
     const u64* ctrl = hc + t * 8;
     H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
+    H.handed_back = false;
     if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; }
   }
   return KMX_OK;
@@ -375,20 +515,30 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   bool overflow = false, fallback = false;
   int rc = fetch_ctrl(R, &overflow, &fallback);
   if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
-  if (fallback) {
-    // The pivot kernel handed some tasks back (lists that do not resemble each other): those tasks -- only those --
-    // run again with the general kernel.  Bounds stay valid; their statistics and row space restart.
+  while (fallback) {
+    // The column-blocked / pivot kernel handed some tasks back (lists that do not resemble each other): those tasks
+    // -- only those -- run again with the next kernel down (cols -> pivot -> rows).  Bounds stay valid; their
+    // statistics and row space restart.
+    const bool from_cols = R->use_cols;
+    const bool to_pivot = from_cols && R->can_pivot;
     const uint2* all_items = reinterpret_cast<const uint2*>(R->h_meta + R->o_items);
     std::vector<uint2> redo;
     u32 n_back = 0;
     for (auto& H : R->tasks) n_back += H.handed_back ? 1u : 0u;
     for (u32 i = 0; i < R->n_items; i++) if (R->tasks[all_items[i].x].handed_back) redo.push_back(all_items[i]);
-    if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] pivot kernel handed back %u of %zu tasks: re-run with k_merge_rows\n", n_back, R->tasks.size());
-    if (R->pivot_auto && n_back * 4 >= R->tasks.size()) {   // a cohort it does not suit: back off for the next batches
-      ctx->pivot_backoff = std::min(64u, std::max(1u, ctx->pivot_backoff * 2)); ctx->pivot_skip = ctx->pivot_backoff;
+    if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] %s handed back %u of %zu tasks: re-run with %s\n", from_cols ? "k_merge_cols" : "k_merge_pivot",
+                                     n_back, R->tasks.size(), to_pivot ? "k_merge_pivot" : "k_merge_rows");
+    if (from_cols) {
+      if (R->cols_auto && n_back * 4 >= R->tasks.size()) {   // a cohort it does not suit: back off for the next batches
+        ctx->cols_backoff = std::min(64u, std::max(1u, ctx->cols_backoff * 2)); ctx->cols_skip = ctx->cols_backoff;
+      }
+      R->cols_auto = false;
+    } else {
+      if (R->pivot_auto && n_back * 4 >= R->tasks.size()) {
+        ctx->pivot_backoff = std::min(64u, std::max(1u, ctx->pivot_backoff * 2)); ctx->pivot_skip = ctx->pivot_backoff;
+      }
+      R->pivot_auto = false;
     }
-    R->pivot_auto = false;
-    if (n_back == R->tasks.size()) R->use_pivot = false;     // (kmx_result_kernel: the kernel that produced most of the result)
     for (auto& H : R->tasks) {
       if (!H.handed_back) continue;
       KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
@@ -399,21 +549,28 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
       std::vector<uint2> keep(all_items, all_items + R->n_items);
       memcpy(stage, redo.data(), redo.size() * sizeof(uint2));
       KMX_HIP(ctx, hipMemcpyAsync(R->d_meta + R->o_items, stage, redo.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-      const bool was_pivot = R->use_pivot; const u32 was_items = R->n_items, was_grid = R->grid;
-      R->use_pivot = false; R->n_items = (u32)redo.size();
-      R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
+      const bool was_pivot = R->use_pivot, was_cols = R->use_cols; const u32 was_items = R->n_items, was_grid = R->grid;
+      R->use_cols = false; R->use_pivot = to_pivot; R->n_items = (u32)redo.size();
+      R->grid = to_pivot ? std::min(R->n_items, (u32)ctx->n_cu)
+                         : std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
       rc = launch_batch(R, false);
       if (rc == KMX_OK) { hipError_t he = hipStreamSynchronize(ctx->stream); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
       // restore the full item list (an arena-overflow retry below re-runs the whole batch, with k_merge_rows)
       memcpy(stage, keep.data(), keep.size() * sizeof(uint2));
-      R->n_items = was_items; R->grid = was_grid; R->use_pivot = was_pivot && n_back != R->tasks.size();
+      R->n_items = was_items; R->grid = was_grid;
       if (rc == KMX_OK) { hipError_t he = hipMemcpyAsync(R->d_meta + R->o_items, stage, keep.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
       if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+      (void)was_pivot; (void)was_cols;
+      for (auto& H : R->tasks) if (H.handed_back) H.kernel = to_pivot ? 1 : 0;
     }
-    rc = fetch_ctrl(R, &overflow);
-    if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
     R->rerun_rows = true;
+    bool ov2 = false;
+    rc = fetch_ctrl(R, &ov2, &fallback);
+    if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+    overflow = ov2;
+    if (!to_pivot) { fallback = false; R->use_pivot = false; }
   }
+  if (R->cols_auto) ctx->cols_backoff = 0;      // the column-blocked kernel completed this batch
   if (R->pivot_auto) ctx->pivot_backoff = 0;   // the pivot kernel completed this batch
   if (overflow) {
     // the kernel kept counting: re-run with arenas / directories of the exact size
@@ -443,8 +600,9 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     }
     KMX_HIP(ctx, hipMemcpyAsync(R->d_meta + R->o_tasks, R->h_meta + R->o_tasks, sizeof(TaskDev) * R->tasks.size(),
                                 hipMemcpyHostToDevice, ctx->stream));
-    if (R->rerun_rows && R->use_pivot) {   // tasks the pivot kernel handed back must not go through it again
-      R->use_pivot = false;
+    if (R->use_cols || (R->rerun_rows && R->use_pivot)) {   // tasks a kernel handed back must not go through it again
+      R->use_pivot = false; R->use_cols = false;
+      for (auto& H : R->tasks) H.kernel = 0;
       R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
     }
     rc = launch_batch(R, false);
@@ -459,7 +617,13 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
 }
 
 extern "C" const char* kmx_result_kernel(const kmx_merge_result* R)
-{ return !R ? "" : R->is_bf ? "k_merge_bf" : R->use_pivot ? "k_merge_pivot" : "k_merge_rows"; }
+{
+  if (!R) return "";
+  if (R->is_bf) return "k_merge_bf";
+  size_t n[3] = {0, 0, 0};            // the kernel that produced most of the result
+  for (auto& H : R->tasks) n[H.kernel]++;
+  return n[2] >= n[1] && n[2] >= n[0] && n[2] ? "k_merge_cols" : n[1] >= n[0] && n[1] ? "k_merge_pivot" : "k_merge_rows";
+}
 
 extern "C" double kmx_result_kernel_ms(kmx_merge_result* R)
 {
@@ -555,7 +719,8 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
 #ifdef KMX_PHASE_PROF
   if (!R->is_bf) { if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
-  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); }
+  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); }
+  for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }

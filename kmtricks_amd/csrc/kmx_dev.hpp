@@ -45,6 +45,19 @@ struct TaskDev {
   u32 item0;               // first work item of this task in the batch's flat item space
 };
 
+// ---- column-blocked merge (merge_cols.hip): per-task companion of TaskDev ------------------------------
+struct ColsDev {
+  u64* skel;               // [out_cap_rows] ascending row keys (the keys kept by a merge of a few of the task's lists)
+  u32* nskel;              // -> number of row keys
+  u32* rbounds;            // [c + 1] first row key of each key range
+  u64* ovkeys;             // [slots_cap][nblk][16][CL_OVW] keys of solid records that are not row keys
+  u32* ovcnt;              // [slots_cap][nblk][16] how many of them
+  u32 slots_cap;           // tile slots (tile q of range j: (rbounds[j] + q * rt) / rt + j)
+  u32 nblk;                // column blocks
+  u32 nb;                  // lists per column block (the last one may hold fewer)
+  u32 rt;                  // row keys per tile
+};
+
 // rows are claimed from a task's arena in chunks of this many bytes (one global atomic + one directory entry per chunk)
 #ifndef KMX_CHUNK_BYTES
 #define KMX_CHUNK_BYTES 262144

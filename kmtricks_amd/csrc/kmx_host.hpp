@@ -21,6 +21,14 @@ int pivot_lds_bytes(int kw);
 u32 pivot_max_lists();
 hipError_t launch_merge_pivot(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
                               u32 grid_x, hipStream_t st);
+int cols_lds_bytes();
+u32 cols_block_lists();
+u32 cols_tile_rows(u32 nb);
+u64 cols_scratch_keys(u32 slots, u32 nblk);
+u64 cols_scratch_counts(u32 slots, u32 nblk);
+hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st);
+hipError_t launch_merge_cols(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
+hipError_t launch_cols_check(const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st);
 int bf_lds_bytes(u32 rt, u32 nb, u32 n_lists);
 hipError_t launch_range_bounds_bf(const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);
 hipError_t launch_merge_bf(int bfc, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
@@ -42,6 +50,7 @@ struct kmx_ctx {
   // the pivot merge kernel handed a batch back: the next `pivot_skip` eligible batches go straight to k_merge_rows
   // (doubling back-off, reset by the first batch the pivot kernel completes)
   unsigned pivot_backoff = 0, pivot_skip = 0;
+  unsigned cols_backoff = 0, cols_skip = 0;   // the same for the column-blocked kernel
 
   void* dalloc(size_t bytes);
   void dfree(void* p);

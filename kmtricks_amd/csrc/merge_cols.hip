@@ -1,0 +1,439 @@
+// merge_cols.hip -- column-blocked streaming merge for large cohorts of related samples (COUNT rows) on gfx950.
+// Same results as k_merge_rows / k_merge_pivot (reference include/kmtricks/merge.hpp:183-286, 441-558).
+//
+// k_merge_pivot gives every list a 16-record register window and a workgroup all N lists, so a list hands
+// over ~13 records (156 bytes) per tile: each 128-byte line of a list is touched in two tiles and, with
+// 32 workgroups x 1000 lists per L2, fetched twice.  Here a workgroup owns a BLOCK of <= 256 lists (columns)
+// of a key range and gives each a 64-record window: ~56 records (672 bytes) per list and tile, 1.2x line
+// traffic instead of 1.8x, and a quarter of the per-tile fixed work.  What makes that possible:
+//   * the ROW KEYS are known before the merge runs: a handful of the task's lists are merged first (with
+//     k_merge_rows, same recurrence-min), and the keys that merge keeps -- every one of them is kept by the
+//     full merge too -- are the rows (k_cols_prep gathers them into one ascending array and cuts it into
+//     the task's key ranges).  Row r of the result is row key r: every column block writes its slice of the
+//     row at a position known up front, no cross-block ranking, no row directory;
+//   * a tile is rt consecutive row keys; a record below the tile's upper key is consumed, its slot is
+//     refilled in place with the record 64 positions further (one global_load_dwordx3), a record whose key
+//     is a row key (one probe of a read-only LDS table) is deposited into the block's LDS image of the
+//     tile, and the image leaves as rt slices of <= 1 KB;
+//   * a solid record whose key is NOT a row key (sample-private k-mers) is appended to a per-(tile, block, wave)
+//     slice in HBM.  k_cols_check then counts, tile by tile and across the blocks, in how many lists each of
+//     those keys is solid: if one reaches the recurrence the rows were incomplete and the task is handed
+//     back (ERR_FALLBACK: the driver re-runs it with k_merge_pivot / k_merge_rows).  So are tasks whose
+//     slices overflow.  Results never depend on how well the row keys cover the lists.
+// Applicable to COUNT rows, 64-bit keys, no share-min; chosen for > 512 lists and 2 <= recurrence-min <= 4.
+#include "kmx_dev.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace kmx {
+
+constexpr int CL_TPB = 1024;
+constexpr int CL_G = 4;                  // adjacent lanes per list
+#ifndef KMX_CL_W
+#define KMX_CL_W 64
+#endif
+constexpr int CL_W = KMX_CL_W;                 // records per window
+constexpr int CL_U = CL_W / CL_G;        // window slots per lane
+constexpr int CL_NB = CL_TPB / CL_G;     // lists per column block
+constexpr int CL_IMG = 61440;            // LDS image bytes (rt rows x nb u32 counts)
+constexpr int CL_PT = 256;               // row-key table entries (two tables: the next tile's is built while this one is written out)
+constexpr int CL_OVW = 128;              // keys per (tile, block, wave) slice of records that are not row keys
+constexpr int CL_RT = 56;                // row keys per tile (< window: a similar list needs no second round)
+constexpr int CL_NW = CL_TPB / 64;
+constexpr int CK_TS = 4096;              // k_cols_check: hash set entries (48 KB of LDS with the counts)
+constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
+
+namespace {
+
+typedef u32 u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef __attribute__((address_space(1))) const u32x3 gu32x3;
+typedef __attribute__((address_space(1))) u64 gu64w;
+struct ClEnt { u32 klo, khi, idx, pad; };   // idx = row + 1, 0 = empty
+
+__device__ __forceinline__ u64 cl_key(const u32x3& v) { return (u64)v.x | ((u64)v.y << 32); }
+__device__ __forceinline__ u32x3 cl_none() { u32x3 v; v.x = ~0u; v.y = ~0u; v.z = 0; return v; }
+__device__ __forceinline__ u32 cl_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 cl_uni64(u64 v) { return (u64)cl_uni((u32)v) | ((u64)cl_uni((u32)(v >> 32)) << 32); }
+__device__ __forceinline__ void cl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ u32 cl_thash(u64 k)
+{ return (__umul24(((u32)k ^ (u32)(k >> 23)) & 0xFFFFFFu, 0x9E3779u) >> 14) & (CL_PT - 1); }
+__device__ __forceinline__ u32 cl_mix(u64 k)
+{
+  u32 x = (u32)k ^ ((u32)(k >> 32) * 0x9E3779B1u);
+  x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
+  return x;
+}
+__device__ __noinline__ u32 cl_lookup_slow(const ClEnt* tab, u64 k, u32 h)
+{
+  for (;;) {
+    h = (h + 1) & (CL_PT - 1);
+    const ClEnt e = tab[h];
+    if (e.idx == 0) return 0;
+    if (e.klo == (u32)k && e.khi == (u32)(k >> 32)) return e.idx;
+  }
+}
+__device__ __forceinline__ void cl_insert(ClEnt* tab, u64 k, u32 row)
+{
+  u32 h = cl_thash(k);
+  while (atomicCAS(&tab[h].idx, 0u, row + 1) != 0) h = (h + 1) & (CL_PT - 1);
+  tab[h].klo = (u32)k; tab[h].khi = (u32)(k >> 32);
+}
+
+}  // namespace
+
+// ---- row keys: gather the kept keys of the few-lists merge into one ascending array, cut it into ranges ----
+__global__ __launch_bounds__(256)
+void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ subs, const ColsDev* __restrict__ cols)
+{
+  const TaskDev& T = tasks[blockIdx.x];
+  const TaskDev& S = subs[blockIdx.x];
+  const ColsDev& C = cols[blockIdx.x];
+  __shared__ u32 s_off[CP_MAXSEG];
+  const u32 tid = threadIdx.x;
+  const u64 serr = S.ctrl[2], nseg64 = S.ctrl[1], rows = S.ctrl[3];
+  const u64 slots = rows / C.rt + T.c + 2;
+  const bool bad = serr != 0 || nseg64 > (u64)CP_MAXSEG || nseg64 > S.seg_cap || rows > T.out_cap_rows || rows > 0xFFFFFF00ULL ||
+                   slots > C.slots_cap;
+  if (bad) {   // the row keys could not be built (arena too small, ...): the general kernels take the task
+    if (tid == 0) { atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK); *C.nskel = 0; }
+    for (u32 j = tid; j <= T.c; j += 256) C.rbounds[j] = 0;
+    return;
+  }
+  const u32 nseg = (u32)nseg64;
+  const u32 srb = S.row_bytes;
+  for (u32 i = tid; i < nseg; i += 256) {   // position of a segment = rows of the segments in front of it in (range, seq) order
+    const Seg a = S.segs[i];
+    u32 off = 0;
+    for (u32 j = 0; j < nseg; j++) {
+      const Seg b = S.segs[j];
+      if (b.range < a.range || (b.range == a.range && b.seq < a.seq)) off += b.nrows;
+    }
+    s_off[i] = off;
+  }
+  __syncthreads();
+  for (u32 i = 0; i < nseg; i++) {
+    const Seg a = S.segs[i];
+    const u8* src = S.out + a.row_off * srb;
+    for (u32 r = tid; r < a.nrows; r += 256) C.skel[(u64)s_off[i] + r] = load_key<1>(src + (u64)r * srb).w[0];
+  }
+  __syncthreads();
+  const u32 np = T.len[T.pivot];
+  for (u32 j = tid; j <= T.c; j += 256) {
+    u32 res;
+    if (j == 0) res = 0;
+    else if (j == T.c) res = (u32)rows;
+    else {   // same boundary keys as k_range_bounds: Q_j = pivot[j * len_pivot / c]
+      const u32 pos = (u32)(((u64)j * np) / T.c);
+      const u64 q = load_key<1>(T.recs[T.pivot] + (u64)pos * 12).w[0];
+      u32 lo = 0, hi = (u32)rows;
+      while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (C.skel[mid] < q) lo = mid + 1; else hi = mid; }
+      res = lo;
+    }
+    C.rbounds[j] = res;
+  }
+  if (tid == 0) {
+    *C.nskel = (u32)rows;
+    T.ctrl[0] = rows; T.ctrl[1] = 1; T.ctrl[3] = rows;
+    Seg sg; sg.range = 0; sg.seq = 0; sg.row_off = 0; sg.nrows = (u32)rows; sg.pad = 0;
+    T.segs[0] = sg;
+  }
+}
+
+// ---- the merge: work item = (task, key range, column block) ----------------------------------------------
+__global__ __launch_bounds__(CL_TPB, 1)
+void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
+                  u32 n_items, u32* ticket)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32* const img = reinterpret_cast<u32*>(smem);                                   // [rt][nb] counts of the tile
+  ClEnt* const ptab = reinterpret_cast<ClEnt*>(smem + CL_IMG);                     // [2][CL_PT] row key -> row
+  u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + 2 * CL_PT * sizeof(ClEnt)); // [0] item [1],[2] "another round" flags
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const u32 wave = cl_uni((u32)tid >> 6);
+  for (int t = tid; t < CL_IMG / 16; t += CL_TPB) reinterpret_cast<uint4*>(img)[t] = make_uint4(0, 0, 0, 0);
+  for (int t = tid; t < 2 * CL_PT; t += CL_TPB) ptab[t].idx = 0;
+  if (tid == 0) { sh[1] = 0; sh[2] = 0; }
+
+  for (;;) {
+    if (tid == 0) sh[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const u32 item = cl_uni(sh[0]);
+    __syncthreads();
+    if (item >= n_items) return;
+    const TaskDev& T = tasks[items[item].x];
+    const ColsDev& C = cols[items[item].x];
+    if (__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) continue;
+    // (everything per work item is uniform; the readfirstlanes tell the compiler, which otherwise treats the tile loop's
+    //  conditions as divergent and branches on them per window slot)
+    const u32 N = cl_uni(T.N), row_bytes = cl_uni(T.row_bytes), nblk = cl_uni(C.nblk), nbs = cl_uni(C.nb), rt = cl_uni(C.rt);
+    const u32 range = cl_uni(items[item].y) / nblk, blk = cl_uni(items[item].y) - range * nblk;
+    const u32 col0 = blk * nbs, nbl = min(nbs, N - col0);
+    const u32 s_lo = cl_uni(C.rbounds[range]), s_hi = cl_uni(C.rbounds[range + 1]);
+    const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
+    const u32 slot0 = s_lo / rt + range;
+    const u64* const skel = C.skel;
+
+    // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + 4u (mod 64)
+    // inside [cur, cur + 64)
+    const u32 lg = (u32)tid / CL_G, r = (u32)tid & (CL_G - 1);
+    const bool on = lg < nbl;
+    const u32 li = col0 + (on ? lg : 0u);
+    u32 cur = on ? T.bounds[(u64)range * N + li] : 0u;
+    const u32 end = on ? T.bounds[(u64)(range + 1) * N + li] : 0u;
+    const u32 smin = T.soft_min[li];
+    gu32* const base = (gu32*)(uintptr_t)T.recs[li];
+    u32x3 rec[CL_U];
+#pragma unroll
+    for (int u = 0; u < CL_U; u++) {
+      const u32 ix = cur + ((r + CL_G * u - cur) & (CL_W - 1));
+      rec[u] = cl_none();
+      if (ix < end) rec[u] = *(gu32x3*)(base + (u64)ix * 3);
+    }
+    u64 tsum = 0; u32 tn = 0;            // TOTAL_WO / NON_SOLID of my share of my list
+    // first tile: row keys, table, (block 0) the key column of the result
+    u64 skn = ~0ULL;
+    if (tid < 64) {
+      if ((u32)tid < rt && s_lo + tid < s_hi) {
+        skn = skel[s_lo + tid];
+        cl_insert(ptab, skn, (u32)tid);
+        if (blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(s_lo + tid) * row_bytes); kp[0] = (u32)skn; kp[1] = (u32)(skn >> 32); }
+      }
+    }
+    u64 khi_n = ntiles > 1 ? skel[s_lo + rt] : ~0ULL;     // upper key of tile 0 (uniform address: scalar load)
+    u32 rnd = 0;
+    bool failed = false;
+    cl_barrier();
+
+    for (u32 q = 0; q < ntiles; q++) {
+      const u32 s0 = s_lo + q * rt;
+      const u32 rte = min(rt, s_hi - s0);
+      const bool last = cl_uni(q + 1 == ntiles ? 1u : 0u) != 0;            // takes everything the lists have left in the range
+      const u64 khi = cl_uni64(khi_n);
+      if (!last) {
+        // the next tile's row keys are wave 0's business alone: nobody else ever waits for these loads
+        if (tid < 64) { skn = ~0ULL; if ((u32)tid < rt && s0 + rt + tid < s_hi) skn = skel[s0 + rt + tid]; }
+        khi_n = q + 2 < ntiles ? skel[s0 + 2 * rt] : ~0ULL;
+      }
+      const ClEnt* const tab = ptab + (q & 1u) * CL_PT;
+      gu64w* const ovk = (gu64w*)(uintptr_t)(C.ovkeys + ((((u64)(slot0 + q) * nblk + blk) * CL_NW + wave) * CL_OVW));
+      u32 wov = 0;                                  // records of this wave that are not row keys (uniform)
+
+      for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
+        if (tid == 0) sh[1 + ((rnd + 1) & 1u)] = 0;
+        // which slots are consumed (this is where the window loads are waited for, all at once: the
+        // refills issued further down then never stall a slot that is looked at after them)
+        u32 consm = 0;
+        if (last) {
+#pragma unroll
+          for (int u = 0; u < CL_U; u++) consm |= ((cur + ((r + CL_G * u - cur) & (CL_W - 1))) < end ? 1u : 0u) << u;
+        } else {
+#pragma unroll
+          for (int u = 0; u < CL_U; u++) consm |= (cl_key(rec[u]) < khi ? 1u : 0u) << u;      // (an empty slot holds the largest key)
+        }
+        asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
+#pragma unroll
+        for (int g = 0; g < CL_U; g += 4) {
+          __builtin_amdgcn_sched_barrier(0);
+          u32 curg = cur; asm volatile("" : "+v"(curg));      // (re-derived per group: 16 slot indices kept live get spilled)
+          uint4 pe[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) pe[j] = reinterpret_cast<const uint4*>(tab)[cl_thash(cl_key(rec[g + j]))];
+          u32 ovm = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int u = g + j;
+            const bool cons = (consm >> u) & 1u;
+            const u64 k = cl_key(rec[u]);
+            const u32 c = rec[u].z;
+            const bool solid = cons && c >= smin;
+            u32 idx = pe[j].z;
+            if (((pe[j].x ^ (u32)k) | (pe[j].y ^ (u32)(k >> 32))) != 0 && idx != 0) idx = cl_lookup_slow(tab, k, cl_thash(k));
+            tsum += solid ? c : 0u;
+            tn += (cons && !solid) ? 1u : 0u;
+            if (solid && idx != 0) img[__umul24(idx - 1, nbs) + lg] = c;
+            ovm |= ((solid && idx == 0) ? 1u : 0u) << j;
+          }
+          asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
+          // solid records that are not row keys: appended to the wave's slice of the tile (positions from ballots)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const u64 bal = __ballot((ovm >> j) & 1u);
+            if ((ovm >> j) & 1u) {
+              const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+              if (pos < (u32)CL_OVW) ovk[pos] = cl_key(rec[g + j]);
+            }
+            wov += (u32)__popcll(bal);
+          }
+          // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record
+          // is the one 64 positions further
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int u = g + j;
+            if ((consm >> u) & 1u) {
+              const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + CL_W;
+              rec[u] = cl_none();
+              if (ix < end) rec[u] = *(gu32x3*)(base + (u64)ix * 3);
+            }
+          }
+        }
+        u32 c = __popc(consm);
+        c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        cur += c;
+        if (c == (u32)CL_W && cur < end) sh[1 + (rnd & 1u)] = 1;
+        cl_barrier();
+        const u32 more = cl_uni(sh[1 + (rnd & 1u)]);
+        rnd++;
+        if (!more) break;
+      }
+      if (lane == 0) {
+        C.ovcnt[((u64)(slot0 + q) * nblk + blk) * CL_NW + wave] = wov;
+        if (wov > (u32)CL_OVW) failed = true;
+      }
+
+      // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
+      if (wave == 0) {
+        ClEnt* const old = ptab + (q & 1u) * CL_PT;
+        for (int t = lane; t < CL_PT; t += 64) old[t].idx = 0;
+        if (!last) {
+          const u32 sn = s0 + rt;
+          if ((u32)lane < rt && sn + lane < s_hi) {
+            cl_insert(ptab + ((q + 1) & 1u) * CL_PT, skn, (u32)lane);
+            if (blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(sn + lane) * row_bytes); kp[0] = (u32)skn; kp[1] = (u32)(skn >> 32); }
+          }
+        }
+      } else {
+        u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + 4ull * col0;
+        const bool wide = ((row_bytes | (4u * col0) | (4u * nbs)) & 7u) == 0;
+        for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
+          u32* const src = img + j * nbs;
+          u8* const dst = out0 + (u64)j * row_bytes;
+          if (wide) {
+            const u32 n2 = nbl >> 1;
+            for (u32 t0 = 0; t0 < n2; t0 += 256) {
+              u64 w[4];
+#pragma unroll
+              for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; w[x] = 0; if (t < n2) { w[x] = reinterpret_cast<u64*>(src)[t]; reinterpret_cast<u64*>(src)[t] = 0; } }
+#pragma unroll
+              for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; if (t < n2) reinterpret_cast<u64*>(dst)[t] = w[x]; }
+            }
+            if ((nbl & 1u) && lane == 0) { reinterpret_cast<u32*>(dst)[nbl - 1] = src[nbl - 1]; src[nbl - 1] = 0; }
+          } else {
+            for (u32 t = lane; t < nbl; t += 64) { const u32 w = src[t]; src[t] = 0; reinterpret_cast<u32*>(dst)[t] = w; }
+          }
+        }
+      }
+      cl_barrier();
+    }
+
+    // ---- item done: statistics of my list (the 4 lanes of a list add up) ----
+    {
+      u32 tlo = (u32)tsum, thi = (u32)(tsum >> 32);
+      u64 ts = tsum;
+#pragma unroll
+      for (int off = 1; off < CL_G; off <<= 1) {
+        const u32 olo = __shfl_xor(tlo, off), ohi = __shfl_xor(thi, off);
+        ts += (u64)olo | ((u64)ohi << 32);
+        tlo = (u32)ts; thi = (u32)(ts >> 32);
+        tn += __shfl_xor(tn, off);
+      }
+      if (on && r == 0) {
+        if (tn) atomicAdd(&T.stats[0 * (u64)N + li], (u64)tn);
+        if (ts) atomicAdd(&T.stats[4 * (u64)N + li], ts);
+      }
+    }
+    if (failed) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
+    __syncthreads();
+  }
+}
+
+// ---- after the merge: does any key outside the rows reach the recurrence?  One workgroup per (task, range), a tile
+//      at a time: the records the column blocks set aside for the tile are counted per key in an LDS hash set ----
+__global__ __launch_bounds__(CL_TPB)
+void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
+{
+  __shared__ u64 keys[CK_TS];
+  __shared__ u32 cnt[CK_TS];
+  __shared__ u32 flag, total, special;
+  const u32 item = blockIdx.x;
+  if (item >= n_items) return;
+  const TaskDev& T = tasks[items[item].x];
+  const ColsDev& C = cols[items[item].x];
+  if (T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) return;
+  const u32 range = items[item].y, rec_min = T.rec_min, rt = C.rt, nsl = C.nblk * CL_NW;
+  const u32 s_lo = C.rbounds[range], s_hi = C.rbounds[range + 1];
+  const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
+  const u32 slot0 = s_lo / rt + range;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (u32 t = tid; t < (u32)CK_TS; t += CL_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
+  if (tid == 0) { flag = 0; total = 0; special = 0; }
+  __syncthreads();
+  for (u32 q = 0; q < ntiles; q++) {
+    const u64 sbase = (u64)(slot0 + q) * nsl;
+    u32 mine = 0;
+    for (u32 sl = wave; sl < nsl; sl += CL_NW) mine += C.ovcnt[sbase + sl];
+    if (lane == 0 && mine) atomicAdd(&total, mine);
+    __syncthreads();
+    const u32 tot = total;
+    __syncthreads();
+    if (tot == 0) continue;
+    if (tid == 0) total = 0;
+    if (tot > (u32)CK_TS * 3 / 4) { if (tid == 0) flag = 1; break; }     // (a slice over its capacity lands here too)
+    for (u32 sl = wave; sl < nsl; sl += CL_NW) {
+      const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
+      const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
+      for (u32 e = lane; e < n; e += 64) {
+        const u64 k = kp[e];
+        u32 c;
+        if (k == ~0ULL) c = atomicAdd(&special, 1u) + 1;
+        else {
+          u32 h = cl_mix(k) & (CK_TS - 1);
+          for (;;) {
+            const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)k);
+            if (old == ~0ULL || old == k) break;
+            h = (h + 1) & (CK_TS - 1);
+          }
+          c = atomicAdd(&cnt[h], 1u) + 1;
+        }
+        if (c >= rec_min) flag = 1;
+      }
+    }
+    __syncthreads();
+    if (flag) break;
+    for (u32 t = tid; t < (u32)CK_TS; t += CL_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
+    if (tid == 0) special = 0;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0 && flag) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+int cols_lds_bytes() { return CL_IMG + 2 * CL_PT * (int)sizeof(ClEnt) + 64; }
+u32 cols_block_lists() { return CL_NB; }
+u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }
+u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * nblk * CL_NW * CL_OVW; }
+u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * nblk * CL_NW; }
+
+hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(256), 0, st, tasks, subs, cols);
+  return hipGetLastError();
+}
+hipError_t launch_merge_cols(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
+{
+  const int lds = cols_lds_bytes();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_merge_cols, dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
+  return hipGetLastError();
+}
+hipError_t launch_cols_check(const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cols_check, dim3(n_items), dim3(CL_TPB), 0, st, tasks, cols, range_items, n_items);
+  return hipGetLastError();
+}
+
+}  // namespace kmx

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size cross-check on the bench workload (BASELINE configs[2], 32 partitions x 1000 samples on one GPU): the
-matrix bodies and statistics produced by k_merge_pivot and by k_merge_rows are compared byte for byte (sha256 per
+matrix bodies and statistics produced by k_merge_cols, k_merge_pivot and k_merge_rows are compared byte for byte (sha256 per
 partition), rows are checked ascending, and the first partition is compared with the oracle."""
 import hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,7 @@ ctx = lib.Context(0)
 tasks = [dict(lists=[(rec.data_ptr() + 12 * offs[i], offs[i + 1] - offs[i]) for i in range(N)], key_words=1, soft_min=[1] * N,
               rec_min=2, share_min=0, mode=lib.MODE_COUNT, rows_hint=shared + 4096) for rec, offs in parts]
 out = {}
-for kern in ("rows", "pivot"):
+for kern in ("rows", "pivot", "cols"):
     os.environ["KMX_MERGE_KERNEL"] = kern
     res = ctx.merge_dev(tasks); res.wait()
     hs, rows = [], []
@@ -28,11 +28,11 @@ for kern in ("rows", "pivot"):
         body = res.body(t); st = res.stats(t)
         hs.append(hashlib.sha256(body).hexdigest() + hashlib.sha256(st.tobytes()).hexdigest())
         rows.append(res.rows(t))
-        if kern == "pivot":
+        if kern != "rows":
             m = np.frombuffer(body, np.uint8).reshape(res.rows(t), 8 + 4 * N)
             keys = m[:, :8].copy().view(np.uint64).ravel()
             assert np.all(keys[1:] > keys[:-1])
-        if t == 0 and kern == "pivot":
+        if t == 0 and kern != "rows":
             rec, offs = parts[0]; h = rec.cpu().numpy()
             lists = [(np.ascontiguousarray(h[offs[i]:offs[i + 1], :2]).view(np.uint64).reshape(-1),
                       np.ascontiguousarray(h[offs[i]:offs[i + 1], 2]).view(np.uint32)) for i in range(N)]
@@ -40,8 +40,9 @@ for kern in ("rows", "pivot"):
             assert er == res.rows(0) and eb == body and np.array_equal(es, st)
     out[kern] = (res.kernel(), hs, rows)
     res.free()
-assert out["rows"][0] == "k_merge_rows" and out["pivot"][0] == "k_merge_pivot"
+assert out["rows"][0] == "k_merge_rows" and out["pivot"][0] == "k_merge_pivot" and out["cols"][0] == "k_merge_cols", [out[k][0] for k in out]
 same = out["rows"][1] == out["pivot"][1]
+same_cols = out["rows"][1] == out["cols"][1]
 print(json.dumps({"partitions": P, "samples": N, "rows_total": int(sum(out["pivot"][2])), "pivot_equals_rows_sha256": bool(same),
-                  "partition0_equals_oracle": True, "keys_ascending": True}))
-assert same
+                  "cols_equals_rows_sha256": bool(same_cols), "partition0_equals_oracle": True, "keys_ascending": True}))
+assert same and same_cols

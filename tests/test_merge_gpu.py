@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 GD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["rows", "pivot"])
+@pytest.fixture(autouse=True, params=["rows", "pivot", "cols"])
 def merge_kernel(request, monkeypatch):
-    """Every merge test runs once per COUNT/PA kernel: k_merge_rows, and k_merge_pivot (which hands tasks it
-    does not suit -- dissimilar lists, 128-bit keys, share-min -- back to k_merge_rows inside libkmx)."""
+    """Every merge test runs once per COUNT/PA kernel: k_merge_rows, k_merge_pivot and k_merge_cols (which hand tasks
+    they do not suit -- dissimilar lists, 128-bit keys, share-min, PA rows -- down to the next kernel inside libkmx)."""
     monkeypatch.setenv("KMX_MERGE_KERNEL", request.param)
     return request.param
 
@@ -189,9 +189,9 @@ def test_bench_scale_partitions_properties(ctx):
 
 @pytest.mark.parametrize("similar", [True, False])
 def test_kernel_selection_and_handback(ctx, monkeypatch, similar):
-    """Default kernel choice (KMX_MERGE_KERNEL unset): a task of more than 512 lists goes to k_merge_pivot; when
-    the lists do not resemble each other it flags the task and libkmx re-runs the batch with k_merge_rows.
-    Either way the body and the statistics equal the oracle's."""
+    """Default kernel choice (KMX_MERGE_KERNEL unset): a COUNT task of more than 512 lists with recurrence-min 2 goes
+    to k_merge_cols; when the lists do not resemble each other it flags the task and libkmx re-runs it with
+    k_merge_pivot, which hands it on to k_merge_rows.  Either way the body and the statistics equal the oracle's."""
     torch = pytest.importorskip("torch")
     from kmtricks_amd import lib
     monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
@@ -207,7 +207,7 @@ def test_kernel_selection_and_handback(ctx, monkeypatch, similar):
                 soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT)
     res = ctx.merge_dev([task])
     res.wait()
-    assert res.kernel() == ("k_merge_pivot" if similar else "k_merge_rows")
+    assert res.kernel() == ("k_merge_cols" if similar else "k_merge_rows")
     exp_body, exp_rows, exp_stats = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT, 0, 0, 2)
     assert res.rows(0) == exp_rows
     assert res.body(0) == exp_body
@@ -245,18 +245,18 @@ def test_bench_workload_full_size_parity():
     env = dict(os.environ); env.pop("KMX_MERGE_KERNEL", None)
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "verify_bench_parity.py")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert '"pivot_equals_rows_sha256": true' in r.stdout
+    assert '"pivot_equals_rows_sha256": true' in r.stdout and '"cols_equals_rows_sha256": true' in r.stdout
 
 
 def test_partial_handback_in_a_batch(monkeypatch):
-    """A batch of three tasks of 600 lists: two cohorts the pivot kernel suits and one set of unrelated lists.  The
-    pivot kernel hands the third task back, libkmx re-runs that task alone with k_merge_rows, and all three bodies
-    and statistics equal the oracle's."""
+    """A batch of three tasks of 600 lists: two cohorts the pivot / column-blocked kernel suits and one set of unrelated
+    lists.  The kernel hands the second task back, libkmx re-runs that task alone with the next kernel down (cols ->
+    pivot -> rows), and all three bodies and statistics equal the oracle's."""
     torch = pytest.importorskip("torch")
     from kmtricks_amd import lib
-    if os.environ.get("KMX_MERGE_KERNEL") != "pivot":
-        pytest.skip("one run is enough")
-    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    first = os.environ.get("KMX_MERGE_KERNEL")
+    if first == "rows":
+        pytest.skip("nothing to hand back")
     ctx = lib.Context(0)
     N = 600
     sets = [synth_lists(5100, N, 5000, 0.97, 150, kw=1), synth_lists(5101, N, 5000, 0.25, 1200, kw=1), synth_lists(5102, N, 4000, 0.96, 160, kw=1)]
@@ -272,8 +272,54 @@ def test_partial_handback_in_a_batch(monkeypatch):
     torch.cuda.synchronize()
     res = ctx.merge_dev(tasks)
     res.wait()
-    assert res.kernel() == "k_merge_pivot"            # two of the three tasks were completed by it
+    assert res.kernel() == "k_merge_" + first            # two of the three tasks were completed by it
     for t, lists in enumerate(sets):
         eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT, 0, 0, 2)
         assert res.rows(t) == er and res.body(t) == eb and np.array_equal(res.stats(t), es), t
     res.free(); ctx.close()
+
+
+def test_cols_kept_key_outside_the_row_keys():
+    """k_merge_cols takes its row keys from a merge of 8 of the lists.  A key none of those 8 has, but two other lists
+    in DIFFERENT column blocks do, reaches recurrence-min 2: only k_cols_check (which counts the set-aside records
+    across the blocks) can see it, and the task must come back complete through the next kernel."""
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("column-blocked kernel only")
+    ctx = lib.Context(0)
+    N = 600
+    lists = synth_lists(6100, N, 3000, 0.97, 40, kw=1)
+    sampled = {((2 * i + 1) * N) // 16 for i in range(8)}
+    a, b = 5, 450                                    # blocks 0 and 1 (300 lists each)
+    assert a not in sampled and b not in sampled
+    extra = np.array([[(1 << 61) + 12345]], dtype=np.uint64)
+    for i in (a, b):
+        k, c = lists[i]
+        k2 = np.concatenate([k, extra]); c2 = np.concatenate([c, np.array([7], np.uint32)])
+        o = np.argsort(k2[:, 0]); lists[i] = (np.ascontiguousarray(k2[o]), np.ascontiguousarray(c2[o]))
+    rows = check(ctx, lists, 1, [1] * N, 2, 0, orc.MODE_COUNT)
+    assert rows > 0
+    # and without the planted key the column-blocked kernel completes the task itself
+    lists2 = synth_lists(6100, N, 3000, 0.97, 40, kw=1)
+    recs = [(k, c) for k, c in lists2]
+    check(ctx, recs, 1, [1] * N, 2, 0, orc.MODE_COUNT)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [9, 257, 700])
+def test_cols_long_private_runs_and_odd_blocks(ctx, n):
+    """column-blocked kernel: list counts that do not fill the blocks, a list with a run of private keys longer
+    than its 64-record window between two row keys (second round of a tile), an empty list, soft-min > 1"""
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("column-blocked kernel only")
+    lists = synth_lists(7000 + n, n, 500, 0.95, 6, kw=1)
+    lists[3] = (lists[3][0][:0], lists[3][1][:0])
+    k, c = lists[4]
+    lo = int(k[len(k) // 2, 0])
+    run = (np.arange(1, 301, dtype=np.uint64) + np.uint64(lo)).reshape(-1, 1)       # 300 consecutive keys nobody else has
+    run = run[~np.isin(run[:, 0], k[:, 0])]
+    k2 = np.concatenate([k, run]); c2 = np.concatenate([c, np.full(len(run), 3, np.uint32)])
+    o = np.argsort(k2[:, 0]); lists[4] = (np.ascontiguousarray(k2[o]), np.ascontiguousarray(c2[o]))
+    soft = [1 + (i % 3) for i in range(n)]
+    check(ctx, lists, 1, soft, 2, 0, orc.MODE_COUNT)
+    check(ctx, lists, 1, soft, 3, 0, orc.MODE_COUNT)
