@@ -330,7 +330,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       u32 wl = 0; while (wl < 6 && (Q.N << (wl + 1)) <= (u32)rows_cap()) wl++;
       Q.wl = wl;
       Q.rows_guess = std::max<u64>(1, std::min<u64>(H.rows_guess, Q.total_recs));
-      u64 c = std::min<u64>(64, std::max<u64>(1, Q.total_recs / 16384));
+      u64 c = std::min<u64>(256, std::max<u64>(1, Q.total_recs / 4096));
       c = std::min<u64>(c, std::max<u32>(1, Q.len[Q.pivot]));
       Q.c = (u32)c;
       Q.seg_cap = (u32)std::min<u64>(0x7FFFFFFF, Q.total_recs / 512 + 8ULL * Q.c + 64);
@@ -708,7 +708,7 @@ extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* 
 }
 
 #ifdef KMX_PHASE_PROF
-namespace kmx { void rows_phase_prof_dump(); void pivot_phase_prof_dump(); }
+namespace kmx { void rows_phase_prof_dump(); void pivot_phase_prof_dump(); void cols_phase_prof_dump(); }
 #endif
 extern "C" void kmx_result_free(kmx_merge_result* R)
 {
@@ -717,7 +717,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
 #ifdef KMX_PHASE_PROF
-  if (!R->is_bf) { if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
+  if (!R->is_bf) { if (R->use_cols) kmx::cols_phase_prof_dump(); else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
   for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);

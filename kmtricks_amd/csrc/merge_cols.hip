@@ -140,6 +140,13 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
   }
 }
 
+#ifdef KMX_PHASE_PROF
+__device__ u64 kmx_cols_prof[8];
+#ifndef KMX_PROF_TID
+#define KMX_PROF_TID 512
+#endif
+#endif
+
 // ---- the merge: work item = (task, key range, column block) ----------------------------------------------
 __global__ __launch_bounds__(CL_TPB, 1)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
@@ -148,20 +155,31 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32* const img = reinterpret_cast<u32*>(smem);                                   // [rt][nb] counts of the tile
   ClEnt* const ptab = reinterpret_cast<ClEnt*>(smem + CL_IMG);                     // [2][CL_PT] row key -> row
-  u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + 2 * CL_PT * sizeof(ClEnt)); // [0] item [1],[2] "another round" flags
+  u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + 2 * CL_PT * sizeof(ClEnt)); // [0] item [1..3] "another round" flags, used in turn
 
   const int tid = threadIdx.x, lane = tid & 63;
   const u32 wave = cl_uni((u32)tid >> 6);
   for (int t = tid; t < CL_IMG / 16; t += CL_TPB) reinterpret_cast<uint4*>(img)[t] = make_uint4(0, 0, 0, 0);
   for (int t = tid; t < 2 * CL_PT; t += CL_TPB) ptab[t].idx = 0;
-  if (tid == 0) { sh[1] = 0; sh[2] = 0; }
+  if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[3] = 0; }
+#ifdef KMX_PHASE_PROF
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pc = clock64();
+#define CLPH(i) do { const long long n_ = clock64(); pt[i] += n_ - pc; pc = n_; } while (0)
+#else
+#define CLPH(i) do {} while (0)
+#endif
 
   for (;;) {
     if (tid == 0) sh[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     const u32 item = cl_uni(sh[0]);
     __syncthreads();
-    if (item >= n_items) return;
+    if (item >= n_items) {
+#ifdef KMX_PHASE_PROF
+      if (tid == KMX_PROF_TID) for (int i = 0; i < 8; i++) atomicAdd(&kmx_cols_prof[i], (u64)pt[i]);
+#endif
+      return;
+    }
     const TaskDev& T = tasks[items[item].x];
     const ColsDev& C = cols[items[item].x];
     if (__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) continue;
@@ -202,9 +220,10 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       }
     }
     u64 khi_n = ntiles > 1 ? skel[s_lo + rt] : ~0ULL;     // upper key of tile 0 (uniform address: scalar load)
-    u32 rnd = 0;
+    u32 rnd = 0;                         // round number mod 3
     bool failed = false;
     cl_barrier();
+    CLPH(0);
 
     for (u32 q = 0; q < ntiles; q++) {
       const u32 s0 = s_lo + q * rt;
@@ -221,7 +240,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       u32 wov = 0;                                  // records of this wave that are not row keys (uniform)
 
       for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
-        if (tid == 0) sh[1 + ((rnd + 1) & 1u)] = 0;
+        // (three flags in turn: the one cleared here was last read two rounds ago, a barrier away)
+        if (tid == 0) sh[1 + (rnd == 2 ? 0 : rnd + 1)] = 0;
         // which slots are consumed (this is where the window loads are waited for, all at once: the
         // refills issued further down then never stall a slot that is looked at after them)
         u32 consm = 0;
@@ -232,7 +252,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 #pragma unroll
           for (int u = 0; u < CL_U; u++) consm |= (cl_key(rec[u]) < khi ? 1u : 0u) << u;      // (an empty slot holds the largest key)
         }
-        asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
+        asm volatile("" : "+v"(consm));
+        CLPH(1);      // one bit mask in a vector register, not 16 lane masks in scalar registers
 #pragma unroll
         for (int g = 0; g < CL_U; g += 4) {
           __builtin_amdgcn_sched_barrier(0);
@@ -282,10 +303,12 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
         cur += c;
-        if (c == (u32)CL_W && cur < end) sh[1 + (rnd & 1u)] = 1;
+        if (c == (u32)CL_W && cur < end) sh[1 + rnd] = 1;
+        CLPH(2);
         cl_barrier();
-        const u32 more = cl_uni(sh[1 + (rnd & 1u)]);
-        rnd++;
+        CLPH(3);
+        const u32 more = cl_uni(sh[1 + rnd]);
+        rnd = rnd == 2 ? 0 : rnd + 1;
         if (!more) break;
       }
       if (lane == 0) {
@@ -325,7 +348,9 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           }
         }
       }
+      CLPH(4);
       cl_barrier();
+      CLPH(5);
     }
 
     // ---- item done: statistics of my list (the 4 lanes of a list add up) ----
@@ -351,7 +376,9 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 
 // ---- after the merge: does any key outside the rows reach the recurrence?  One workgroup per (task, range), a tile
 //      at a time: the records the column blocks set aside for the tile are counted per key in an LDS hash set ----
-__global__ __launch_bounds__(CL_TPB)
+constexpr int CK_TPB = 256;              // k_cols_check: threads (3 workgroups per CU by LDS)
+constexpr int CK_Z = 16;                 // ... and workgroups sharing the tiles of a range
+__global__ __launch_bounds__(CK_TPB)
 void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
   __shared__ u64 keys[CK_TS];
@@ -367,13 +394,13 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
   const u32 slot0 = s_lo / rt + range;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (u32 t = tid; t < (u32)CK_TS; t += CL_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
+  for (u32 t = tid; t < (u32)CK_TS; t += CK_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
   if (tid == 0) { flag = 0; total = 0; special = 0; }
   __syncthreads();
-  for (u32 q = 0; q < ntiles; q++) {
+  for (u32 q = blockIdx.y; q < ntiles; q += CK_Z) {
     const u64 sbase = (u64)(slot0 + q) * nsl;
     u32 mine = 0;
-    for (u32 sl = wave; sl < nsl; sl += CL_NW) mine += C.ovcnt[sbase + sl];
+    for (u32 sl = wave; sl < nsl; sl += CK_TPB / 64) mine += C.ovcnt[sbase + sl];
     if (lane == 0 && mine) atomicAdd(&total, mine);
     __syncthreads();
     const u32 tot = total;
@@ -381,7 +408,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     if (tot == 0) continue;
     if (tid == 0) total = 0;
     if (tot > (u32)CK_TS * 3 / 4) { if (tid == 0) flag = 1; break; }     // (a slice over its capacity lands here too)
-    for (u32 sl = wave; sl < nsl; sl += CL_NW) {
+    for (u32 sl = wave; sl < nsl; sl += CK_TPB / 64) {
       const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
       const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
       for (u32 e = lane; e < n; e += 64) {
@@ -402,13 +429,26 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     }
     __syncthreads();
     if (flag) break;
-    for (u32 t = tid; t < (u32)CK_TS; t += CL_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
+    for (u32 t = tid; t < (u32)CK_TS; t += CK_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
     if (tid == 0) special = 0;
     __syncthreads();
   }
   __syncthreads();
   if (tid == 0 && flag) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
 }
+
+#ifdef KMX_PHASE_PROF
+void cols_phase_prof_dump()
+{
+  u64 h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_cols_prof), sizeof(h)) != hipSuccess) return;
+  u64 tot = 0; for (int i = 0; i < 8; i++) tot += h[i];
+  static const char* nm[8] = {"item setup", "window wait", "scan", "bar(scan)", "tile out", "bar(out)", "-", "-"};
+  for (int i = 0; i < 6; i++) fprintf(stderr, "[cols] %-12s %6.2f%%  %llu\n", nm[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
+  memset(h, 0, sizeof(h));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_prof), h, sizeof(h));
+}
+#endif
 
 // ---- host side ------------------------------------------------------------------------------------------
 int cols_lds_bytes() { return CL_IMG + 2 * CL_PT * (int)sizeof(ClEnt) + 64; }
@@ -432,7 +472,7 @@ hipError_t launch_merge_cols(const TaskDev* tasks, const ColsDev* cols, const ui
 }
 hipError_t launch_cols_check(const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_cols_check, dim3(n_items), dim3(CL_TPB), 0, st, tasks, cols, range_items, n_items);
+  hipLaunchKernelGGL(k_cols_check, dim3(n_items, CK_Z), dim3(CK_TPB), 0, st, tasks, cols, range_items, n_items);
   return hipGetLastError();
 }
 
