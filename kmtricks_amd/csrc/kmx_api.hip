@@ -10,6 +10,7 @@
 using namespace kmx;
 
 static thread_local std::string g_create_err;
+namespace kmx { void cols_dbg_dump(); }
 
 // ---- memory pools ----------------------------------------------------------------------------------
 void* kmx_ctx::dalloc(size_t bytes)
@@ -526,6 +527,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     u32 n_back = 0;
     for (auto& H : R->tasks) n_back += H.handed_back ? 1u : 0u;
     for (u32 i = 0; i < R->n_items; i++) if (R->tasks[all_items[i].x].handed_back) redo.push_back(all_items[i]);
+    if (getenv("KMX_TRACE") && from_cols) kmx::cols_dbg_dump();
     if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] %s handed back %u of %zu tasks: re-run with %s\n", from_cols ? "k_merge_cols" : "k_merge_pivot",
                                      n_back, R->tasks.size(), to_pivot ? "k_merge_pivot" : "k_merge_rows");
     if (from_cols) {

@@ -37,7 +37,8 @@ constexpr int CL_W = KMX_CL_W;                 // records per window
 constexpr int CL_U = CL_W / CL_G;        // window slots per lane
 constexpr int CL_NB = CL_TPB / CL_G;     // lists per column block
 constexpr int CL_IMG = 61440;            // LDS image bytes (rt rows x nb u32 counts)
-constexpr int CL_PT = 256;               // row-key table entries (two tables: the next tile's is built while this one is written out)
+constexpr int CL_PT = 2048;              // row-key table entries (two tables: the next tile's is built while this one is written out)
+constexpr int CL_SEEDS = 48;             // hash multipliers tried per tile for a collision-free table
 constexpr int CL_OVW = 128;              // keys per (tile, block, wave) slice of records that are not row keys
 constexpr int CL_RT = 56;                // row keys per tile (< window: a similar list needs no second round)
 constexpr int CL_NW = CL_TPB / 64;
@@ -56,28 +57,37 @@ __device__ __forceinline__ u32x3 cl_none() { u32x3 v; v.x = ~0u; v.y = ~0u; v.z 
 __device__ __forceinline__ u32 cl_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 cl_uni64(u64 v) { return (u64)cl_uni((u32)v) | ((u64)cl_uni((u32)(v >> 32)) << 32); }
 __device__ __forceinline__ void cl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ u32 cl_thash(u64 k)
-{ return (__umul24(((u32)k ^ (u32)(k >> 23)) & 0xFFFFFFu, 0x9E3779u) >> 14) & (CL_PT - 1); }
+// the row keys of a tile sit in a PERFECT hash table: wave 0 tries multipliers until the (<= 56) keys land in
+// distinct entries of the 1024, so a lookup is one LDS read and one compare -- no probing, no branch
+// (a hash = 24-bit multiplier | shift << 24: the shift picks which key bits are folded into the 24 that get multiplied,
+//  so two keys that agree in those 24 bits under one hash do not under the next)
+__device__ __forceinline__ u32 cl_thash(u64 k, u32 hf)
+{
+  const u32 x = ((u32)k ^ (u32)(k >> (hf >> 24))) & 0xFFFFFFu;
+  return ((u32)__umul24(x, hf) >> 21) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
+}
+__device__ __forceinline__ u32 cl_mult(u32 seed) { return ((0x9E3779u + seed * 0x5A6B2u) & 0xFFFFFFu) | ((13u + (seed * 7u) % 19u) << 24); }
 __device__ __forceinline__ u32 cl_mix(u64 k)
 {
   u32 x = (u32)k ^ ((u32)(k >> 32) * 0x9E3779B1u);
   x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
   return x;
 }
-__device__ __noinline__ u32 cl_lookup_slow(const ClEnt* tab, u64 k, u32 h)
+// wave 0: lane j < n holds row key j.  -> the multiplier, 0 when no try worked; *slot = my key's entry
+__device__ __forceinline__ u32 cl_build(ClEnt* tab, u64 key, bool have, u32 lane, u32* slot)
 {
-  for (;;) {
-    h = (h + 1) & (CL_PT - 1);
-    const ClEnt e = tab[h];
-    if (e.idx == 0) return 0;
-    if (e.klo == (u32)k && e.khi == (u32)(k >> 32)) return e.idx;
+  for (u32 s = 0; s < (u32)CL_SEEDS; s++) {
+    const u32 mult = cl_mult(s);
+    const u32 h = cl_thash(key, mult);
+    const u32 old = have ? atomicCAS(&tab[h].idx, 0u, lane + 1) : 0u;
+    if (__ballot(old != 0) == 0) {
+      if (have) { tab[h].klo = (u32)key; tab[h].khi = (u32)(key >> 32); }
+      *slot = h;
+      return mult;
+    }
+    if (have && old == 0) atomicExch(&tab[h].idx, 0u);      // take my claim back, next multiplier
   }
-}
-__device__ __forceinline__ void cl_insert(ClEnt* tab, u64 k, u32 row)
-{
-  u32 h = cl_thash(k);
-  while (atomicCAS(&tab[h].idx, 0u, row + 1) != 0) h = (h + 1) & (CL_PT - 1);
-  tab[h].klo = (u32)k; tab[h].khi = (u32)(k >> 32);
+  return 0;
 }
 
 }  // namespace
@@ -140,6 +150,9 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
   }
 }
 
+__device__ const u32 kmx_cols_sentinel[4] = {~0u, ~0u, 0u, 0u};      // the record "past the end of a list": largest key, count 0
+
+__device__ u32 kmx_cols_dbg[8];
 #ifdef KMX_PHASE_PROF
 __device__ u64 kmx_cols_prof[8];
 #ifndef KMX_PROF_TID
@@ -155,7 +168,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32* const img = reinterpret_cast<u32*>(smem);                                   // [rt][nb] counts of the tile
   ClEnt* const ptab = reinterpret_cast<ClEnt*>(smem + CL_IMG);                     // [2][CL_PT] row key -> row
-  u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + 2 * CL_PT * sizeof(ClEnt)); // [0] item [1..3] "another round" flags, used in turn
+  u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + 2 * CL_PT * sizeof(ClEnt)); // [0] item [1..3] "another round" flags, used in turn [4],[5] the tables' multipliers
+  const u32 dummy = (u32)(CL_IMG + 2 * CL_PT * sizeof(ClEnt)) / 4 + 16 + (u32)(threadIdx.x & 63);   // image index of a scratch word of my own (deposits that are none)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const u32 wave = cl_uni((u32)tid >> 6);
@@ -202,6 +216,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const u32 end = on ? T.bounds[(u64)(range + 1) * N + li] : 0u;
     const u32 smin = T.soft_min[li];
     gu32* const base = (gu32*)(uintptr_t)T.recs[li];
+    gu32* const sentinel = (gu32*)(uintptr_t)kmx_cols_sentinel;
     u32x3 rec[CL_U];
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
@@ -212,16 +227,19 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     u64 tsum = 0; u32 tn = 0;            // TOTAL_WO / NON_SOLID of my share of my list
     // first tile: row keys, table, (block 0) the key column of the result
     u64 skn = ~0ULL;
+    u32 myslot = 0;                      // wave 0: the table entry of my row key of the tile in hand
+    bool failed = false;
     if (tid < 64) {
-      if ((u32)tid < rt && s_lo + tid < s_hi) {
+      const bool have = (u32)tid < rt && s_lo + tid < s_hi;
+      if (have) {
         skn = skel[s_lo + tid];
-        cl_insert(ptab, skn, (u32)tid);
         if (blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(s_lo + tid) * row_bytes); kp[0] = (u32)skn; kp[1] = (u32)(skn >> 32); }
       }
+      const u32 mult = cl_build(ptab, skn, have, (u32)tid, &myslot);
+      if (tid == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
     }
     u64 khi_n = ntiles > 1 ? skel[s_lo + rt] : ~0ULL;     // upper key of tile 0 (uniform address: scalar load)
     u32 rnd = 0;                         // round number mod 3
-    bool failed = false;
     cl_barrier();
     CLPH(0);
 
@@ -236,6 +254,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         khi_n = q + 2 < ntiles ? skel[s0 + 2 * rt] : ~0ULL;
       }
       const ClEnt* const tab = ptab + (q & 1u) * CL_PT;
+      const u32 mult = cl_uni(sh[4 + (q & 1u)]);
       gu64w* const ovk = (gu64w*)(uintptr_t)(C.ovkeys + ((((u64)(slot0 + q) * nblk + blk) * CL_NW + wave) * CL_OVW));
       u32 wov = 0;                                  // records of this wave that are not row keys (uniform)
 
@@ -252,51 +271,52 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 #pragma unroll
           for (int u = 0; u < CL_U; u++) consm |= (cl_key(rec[u]) < khi ? 1u : 0u) << u;      // (an empty slot holds the largest key)
         }
-        asm volatile("" : "+v"(consm));
-        CLPH(1);      // one bit mask in a vector register, not 16 lane masks in scalar registers
+        asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
+        CLPH(1);
 #pragma unroll
         for (int g = 0; g < CL_U; g += 4) {
           __builtin_amdgcn_sched_barrier(0);
           u32 curg = cur; asm volatile("" : "+v"(curg));      // (re-derived per group: 16 slot indices kept live get spilled)
           uint4 pe[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) pe[j] = reinterpret_cast<const uint4*>(tab)[cl_thash(cl_key(rec[g + j]))];
+          for (int j = 0; j < 4; j++) pe[j] = reinterpret_cast<const uint4*>(tab)[cl_thash(cl_key(rec[g + j]), mult)];
           u32 ovm = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
+            // straight-line: masks and selects, no branches (a deposit that is none goes to a scratch word)
             const int u = g + j;
             const bool cons = (consm >> u) & 1u;
             const u64 k = cl_key(rec[u]);
             const u32 c = rec[u].z;
             const bool solid = cons && c >= smin;
-            u32 idx = pe[j].z;
-            if (((pe[j].x ^ (u32)k) | (pe[j].y ^ (u32)(k >> 32))) != 0 && idx != 0) idx = cl_lookup_slow(tab, k, cl_thash(k));
+            const bool hit = pe[j].x == (u32)k && pe[j].y == (u32)(k >> 32) && pe[j].z != 0;
             tsum += solid ? c : 0u;
             tn += (cons && !solid) ? 1u : 0u;
-            if (solid && idx != 0) img[__umul24(idx - 1, nbs) + lg] = c;
-            ovm |= ((solid && idx == 0) ? 1u : 0u) << j;
+            img[(solid && hit) ? __umul24(pe[j].z - 1, nbs) + lg : dummy] = c;
+            ovm |= ((solid && !hit) ? 1u : 0u) << j;
           }
           asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
           // solid records that are not row keys: appended to the wave's slice of the tile (positions from ballots)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const u64 bal = __ballot((ovm >> j) & 1u);
-            if ((ovm >> j) & 1u) {
-              const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-              if (pos < (u32)CL_OVW) ovk[pos] = cl_key(rec[g + j]);
+            if (bal) {
+              if ((ovm >> j) & 1u) {
+                const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                if (pos < (u32)CL_OVW) ovk[pos] = cl_key(rec[g + j]);
+              }
+              wov += (u32)__popcll(bal);
             }
-            wov += (u32)__popcll(bal);
           }
-          // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record
-          // is the one 64 positions further
+          // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record is
+          // the one 64 positions further.  No branch: a slot that was not consumed loads its record again (same
+          // lines as its neighbours' refills), one past the list's end loads the sentinel.
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int u = g + j;
-            if ((consm >> u) & 1u) {
-              const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + CL_W;
-              rec[u] = cl_none();
-              if (ix < end) rec[u] = *(gu32x3*)(base + (u64)ix * 3);
-            }
+            const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + (((consm >> u) & 1u) ? (u32)CL_W : 0u);
+            gu32* const src = ix < end ? base + (u64)ix * 3 : sentinel;
+            rec[u] = *(gu32x3*)src;
           }
         }
         u32 c = __popc(consm);
@@ -313,19 +333,19 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       }
       if (lane == 0) {
         C.ovcnt[((u64)(slot0 + q) * nblk + blk) * CL_NW + wave] = wov;
-        if (wov > (u32)CL_OVW) failed = true;
+        if (wov > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); atomicAdd(&kmx_cols_dbg[q == 0 ? 4 : (q & 1u) ? 5 : 6], 1u); if (rte < rt) atomicAdd(&kmx_cols_dbg[7], 1u); }
       }
 
       // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
       if (wave == 0) {
         ClEnt* const old = ptab + (q & 1u) * CL_PT;
-        for (int t = lane; t < CL_PT; t += 64) old[t].idx = 0;
+        if ((u32)lane < rte) old[myslot].idx = 0;        // (keys may stay: an entry without a row is never a hit)
         if (!last) {
           const u32 sn = s0 + rt;
-          if ((u32)lane < rt && sn + lane < s_hi) {
-            cl_insert(ptab + ((q + 1) & 1u) * CL_PT, skn, (u32)lane);
-            if (blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(sn + lane) * row_bytes); kp[0] = (u32)skn; kp[1] = (u32)(skn >> 32); }
-          }
+          const bool have = (u32)lane < rt && sn + lane < s_hi;
+          if (have && blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(sn + lane) * row_bytes); kp[0] = (u32)skn; kp[1] = (u32)(skn >> 32); }
+          const u32 m2 = cl_build(ptab + ((q + 1) & 1u) * CL_PT, skn, have, (u32)lane, &myslot);
+          if (lane == 0) { sh[4 + ((q + 1) & 1u)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
         u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + 4ull * col0;
@@ -407,7 +427,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     __syncthreads();
     if (tot == 0) continue;
     if (tid == 0) total = 0;
-    if (tot > (u32)CK_TS * 3 / 4) { if (tid == 0) flag = 1; break; }     // (a slice over its capacity lands here too)
+    if (tot > (u32)CK_TS * 3 / 4) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }     // (a slice over its capacity lands here too)
     for (u32 sl = wave; sl < nsl; sl += CK_TPB / 64) {
       const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
       const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
@@ -424,7 +444,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           }
           c = atomicAdd(&cnt[h], 1u) + 1;
         }
-        if (c >= rec_min) flag = 1;
+        if (c >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
       }
     }
     __syncthreads();
@@ -437,6 +457,13 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   if (tid == 0 && flag) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
 }
 
+void cols_dbg_dump()
+{
+  u32 h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_cols_dbg), sizeof(h)) != hipSuccess) return;
+  fprintf(stderr, "[cols dbg] build-fail %u  slice-overflow %u  kept-outside %u  check-full %u | q0 %u qodd %u qeven %u short-tile %u\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_dbg), h, sizeof(h));
+}
 #ifdef KMX_PHASE_PROF
 void cols_phase_prof_dump()
 {
@@ -451,7 +478,7 @@ void cols_phase_prof_dump()
 #endif
 
 // ---- host side ------------------------------------------------------------------------------------------
-int cols_lds_bytes() { return CL_IMG + 2 * CL_PT * (int)sizeof(ClEnt) + 64; }
+int cols_lds_bytes() { return CL_IMG + 2 * CL_PT * (int)sizeof(ClEnt) + 64 + 256; }
 u32 cols_block_lists() { return CL_NB; }
 u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }
 u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * nblk * CL_NW * CL_OVW; }
