@@ -167,7 +167,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 64, ctx->stream));
     KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ctx->stream));
-    KMX_HIP(ctx, launch_merge_rows(kw, mode, d_subs, d_subitems, R->n_subitems, d_ticket + 8, R->sub_grid, R->sub_max_n, ctx->stream));
+    KMX_HIP(ctx, launch_cols_skel(d_subs, d_subitems, R->n_subitems, ctx->stream));
     KMX_HIP(ctx, launch_cols_prep(d_tasks, d_subs, d_cols, nt, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_cols(d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
@@ -327,15 +327,16 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         if (Q.len[i] > Q.len[piv]) piv = i;
       }
       Q.pivot = (Q.N >= 2 && Q.len[Q.N / 2] > 0) ? Q.N / 2 : piv;
-      Q.row_bytes = kw * 8 + 4 * Q.N;
+      Q.row_bytes = 8;                                   // k_cols_skel writes keys only
       u32 wl = 0; while (wl < 6 && (Q.N << (wl + 1)) <= (u32)rows_cap()) wl++;
       Q.wl = wl;
       Q.rows_guess = std::max<u64>(1, std::min<u64>(H.rows_guess, Q.total_recs));
-      u64 c = std::min<u64>(256, std::max<u64>(1, Q.total_recs / 4096));
+      // ranges of ~800 records over the lists (k_cols_skel sorts a range in LDS, <= 2048 records): one segment per range
+      u64 c = std::min<u64>(2000, std::max<u64>(1, Q.total_recs / 800));
       c = std::min<u64>(c, std::max<u32>(1, Q.len[Q.pivot]));
       Q.c = (u32)c;
-      Q.seg_cap = (u32)std::min<u64>(0x7FFFFFFF, Q.total_recs / 512 + 8ULL * Q.c + 64);
-      Q.out_cap_rows = Q.rows_guess + (u64)(Q.c + 1) * rows_chunk_rows(Q.row_bytes);
+      Q.seg_cap = Q.c;
+      Q.out_cap_rows = (u64)Q.c * cols_skel_cap();
       Q.out_bytes = (size_t)(Q.out_cap_rows * Q.row_bytes);
       nsub += Q.c; ncit += H.c * H.nblk;
       R->sub_max_c = std::max(R->sub_max_c, Q.c); R->sub_max_n = std::max(R->sub_max_n, Q.N);

@@ -26,6 +26,8 @@ u32 cols_block_lists();
 u32 cols_tile_rows(u32 nb);
 u64 cols_scratch_keys(u32 slots, u32 nblk);
 u64 cols_scratch_counts(u32 slots, u32 nblk);
+u32 cols_skel_cap();
+hipError_t launch_cols_skel(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st);
 hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st);
 hipError_t launch_merge_cols(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
 hipError_t launch_cols_check(const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st);

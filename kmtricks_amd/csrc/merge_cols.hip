@@ -92,14 +92,89 @@ __device__ __forceinline__ u32 cl_build(ClEnt* tab, u64 key, bool have, u32 lane
 
 }  // namespace
 
+// ---- row keys, step 1: the keys a merge of a few lists keeps.  One workgroup per key range of <= SK_CAP records:
+//      the solid keys of the range are sorted in LDS (bitonic), a key is kept when its run is at least
+//      recurrence-min long, kept keys leave in order.  Segment j of the result = range j (k_cols_prep strings them
+//      together). ----
+constexpr int SK_TPB = 256;
+constexpr int SK_CAP = 2048;             // records per range (all lists), and the row capacity of a range
+
+__global__ __launch_bounds__(SK_TPB)
+void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ items, u32 n_items)
+{
+  __shared__ u64 ks[SK_CAP];
+  __shared__ u32 wsum[SK_TPB / 64];
+  const u32 item = blockIdx.x;
+  if (item >= n_items) return;
+  const TaskDev& S = subs[items[item].x];
+  const u32 range = items[item].y, N = S.N, rec_min = max(1u, S.rec_min);
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  u32 total = 0;
+  for (u32 i = 0; i < N; i++) total += S.bounds[(u64)(range + 1) * N + i] - S.bounds[(u64)range * N + i];
+  Seg sg; sg.range = range; sg.seq = 0; sg.row_off = (u64)range * SK_CAP; sg.nrows = 0; sg.pad = 0;
+  if (total > (u32)SK_CAP) {   // lists that do not line up with the range cuts: no row keys, the general kernels take the task
+    if (tid == 0) { atomicOr(&S.ctrl[2], (u64)ERR_ROWS_OVERFLOW); S.segs[range] = sg; atomicAdd(&S.ctrl[1], 1ULL); }
+    return;
+  }
+  u32 P = 2; while (P < total) P <<= 1;
+  {   // SK_TPB / N threads per list, every list at once
+    const u32 tpl = max(1u, (u32)SK_TPB / N);
+    for (u32 i = tid / tpl; i < N; i += (u32)SK_TPB / tpl) {
+      u32 off = 0;
+      for (u32 j = 0; j < i; j++) off += S.bounds[(u64)(range + 1) * N + j] - S.bounds[(u64)range * N + j];
+      const u32 lo = S.bounds[(u64)range * N + i], n = S.bounds[(u64)(range + 1) * N + i] - lo, smin = S.soft_min[i];
+      const u8* base = S.recs[i] + (u64)lo * 12;
+      for (u32 e = tid % tpl; e < n; e += tpl) {
+        const u32* rp = reinterpret_cast<const u32*>(base + (u64)e * 12);
+        ks[off + e] = rp[2] >= smin ? ((u64)rp[0] | ((u64)rp[1] << 32)) : ~0ULL;      // (a non-solid record counts for nothing)
+      }
+    }
+  }
+  for (u32 t = total + tid; t < P; t += SK_TPB) ks[t] = ~0ULL;
+  __syncthreads();
+  for (u32 k = 2; k <= P; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+      for (u32 t = tid; t < P / 2; t += SK_TPB) {
+        const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;      // the pair (a, a + j)
+        const u64 x = ks[a], y = ks[b];
+        const bool up = (a & k) == 0;
+        if ((x > y) == up) { ks[a] = y; ks[b] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  // kept: first record of a run of >= recurrence-min equal keys
+  const u32 per = P / SK_TPB ? P / SK_TPB : 1;
+  u32 mine = 0, keptm = 0;
+  for (u32 x = 0; x < per; x++) {
+    const u32 i = tid * per + x;
+    if (i < P) {
+      const u64 k = ks[i];
+      const bool kept = k != ~0ULL && (i == 0 || ks[i - 1] != k) && i + rec_min - 1 < P && ks[i + rec_min - 1] == k;
+      keptm |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
+    }
+  }
+  const u32 incl = wave_incl_scan(mine, (int)lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 base = incl - mine, nk = 0;
+  for (u32 w = 0; w < SK_TPB / 64; w++) { if (w < wave) base += wsum[w]; nk += wsum[w]; }
+  u64* out = reinterpret_cast<u64*>(S.out) + (u64)range * SK_CAP;
+  for (u32 x = 0; x < per; x++) if ((keptm >> x) & 1u) out[base++] = ks[tid * per + x];
+  if (tid == 0) { sg.nrows = nk; S.segs[range] = sg; atomicAdd(&S.ctrl[1], 1ULL); atomicAdd(&S.ctrl[3], (u64)nk); }
+}
+
 // ---- row keys: gather the kept keys of the few-lists merge into one ascending array, cut it into ranges ----
-__global__ __launch_bounds__(256)
+constexpr int CP_TPB = 1024;
+__global__ __launch_bounds__(CP_TPB)
 void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ subs, const ColsDev* __restrict__ cols)
 {
   const TaskDev& T = tasks[blockIdx.x];
   const TaskDev& S = subs[blockIdx.x];
   const ColsDev& C = cols[blockIdx.x];
   __shared__ u32 s_off[CP_MAXSEG];
+  __shared__ u64 s_ord[CP_MAXSEG];
+  __shared__ u32 s_n[CP_MAXSEG];
   const u32 tid = threadIdx.x;
   const u64 serr = S.ctrl[2], nseg64 = S.ctrl[1], rows = S.ctrl[3];
   const u64 slots = rows / C.rt + T.c + 2;
@@ -107,29 +182,28 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
                    slots > C.slots_cap;
   if (bad) {   // the row keys could not be built (arena too small, ...): the general kernels take the task
     if (tid == 0) { atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK); *C.nskel = 0; }
-    for (u32 j = tid; j <= T.c; j += 256) C.rbounds[j] = 0;
+    for (u32 j = tid; j <= T.c; j += CP_TPB) C.rbounds[j] = 0;
     return;
   }
   const u32 nseg = (u32)nseg64;
   const u32 srb = S.row_bytes;
-  for (u32 i = tid; i < nseg; i += 256) {   // position of a segment = rows of the segments in front of it in (range, seq) order
-    const Seg a = S.segs[i];
+  for (u32 i = tid; i < nseg; i += CP_TPB) { const Seg a = S.segs[i]; s_ord[i] = ((u64)a.range << 32) | a.seq; s_n[i] = a.nrows; }
+  __syncthreads();
+  for (u32 i = tid; i < nseg; i += CP_TPB) {   // position of a segment = rows of the segments in front of it in (range, seq) order
+    const u64 mine = s_ord[i];
     u32 off = 0;
-    for (u32 j = 0; j < nseg; j++) {
-      const Seg b = S.segs[j];
-      if (b.range < a.range || (b.range == a.range && b.seq < a.seq)) off += b.nrows;
-    }
+    for (u32 j = 0; j < nseg; j++) off += s_ord[j] < mine ? s_n[j] : 0u;
     s_off[i] = off;
   }
   __syncthreads();
-  for (u32 i = 0; i < nseg; i++) {
+  for (u32 i = tid >> 6; i < nseg; i += CP_TPB / 64) {   // a wave per segment
     const Seg a = S.segs[i];
     const u8* src = S.out + a.row_off * srb;
-    for (u32 r = tid; r < a.nrows; r += 256) C.skel[(u64)s_off[i] + r] = load_key<1>(src + (u64)r * srb).w[0];
+    for (u32 r = tid & 63u; r < a.nrows; r += 64) C.skel[(u64)s_off[i] + r] = load_key<1>(src + (u64)r * srb).w[0];
   }
   __syncthreads();
   const u32 np = T.len[T.pivot];
-  for (u32 j = tid; j <= T.c; j += 256) {
+  for (u32 j = tid; j <= T.c; j += CP_TPB) {
     u32 res;
     if (j == 0) res = 0;
     else if (j == T.c) res = (u32)rows;
@@ -309,14 +383,16 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             }
           }
           // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record is
-          // the one 64 positions further.  No branch: a slot that was not consumed loads its record again (same
-          // lines as its neighbours' refills), one past the list's end loads the sentinel.
+          // the one 64 positions further (one past the list's end: the sentinel).  A slot that was not consumed is left
+          // alone: loading it again would fetch the window's last line twice (it is evicted from L2 by the next tile).
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int u = g + j;
-            const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + (((consm >> u) & 1u) ? (u32)CL_W : 0u);
-            gu32* const src = ix < end ? base + (u64)ix * 3 : sentinel;
-            rec[u] = *(gu32x3*)src;
+            if ((consm >> u) & 1u) {
+              const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + (u32)CL_W;
+              gu32* const src = ix < end ? base + (u64)ix * 3 : sentinel;
+              rec[u] = *(gu32x3*)src;
+            }
           }
         }
         u32 c = __popc(consm);
@@ -414,43 +490,54 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
   const u32 slot0 = s_lo / rt + range;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (u32 t = tid; t < (u32)CK_TS; t += CK_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
+  auto wipe = [&]() {
+    for (u32 t = tid; t < (u32)CK_TS / 2; t += CK_TPB) reinterpret_cast<uint4*>(keys)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (u32 t = tid; t < (u32)CK_TS / 4; t += CK_TPB) reinterpret_cast<uint4*>(cnt)[t] = make_uint4(0, 0, 0, 0);
+  };
+  wipe();
   if (tid == 0) { flag = 0; total = 0; special = 0; }
   __syncthreads();
+  (void)lane; (void)wave;
   for (u32 q = blockIdx.y; q < ntiles; q += CK_Z) {
+    // four threads per (block, wave) slice of the tile: every slice's count, then every slice's keys, are in flight
+    // at once (a wave walking its slices one after the other pays two dependent memory round trips per slice)
     const u64 sbase = (u64)(slot0 + q) * nsl;
-    u32 mine = 0;
-    for (u32 sl = wave; sl < nsl; sl += CK_TPB / 64) mine += C.ovcnt[sbase + sl];
-    if (lane == 0 && mine) atomicAdd(&total, mine);
-    __syncthreads();
-    const u32 tot = total;
-    __syncthreads();
-    if (tot == 0) continue;
-    if (tid == 0) total = 0;
-    if (tot > (u32)CK_TS * 3 / 4) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }     // (a slice over its capacity lands here too)
-    for (u32 sl = wave; sl < nsl; sl += CK_TPB / 64) {
-      const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
+    for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
+      const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
+      const u32 nraw = sl < nsl ? C.ovcnt[sbase + sl] : 0u;
+      if (sub == 0 && nraw) atomicAdd(&total, nraw);
+      const u32 n = min(nraw, (u32)CL_OVW);
       const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
-      for (u32 e = lane; e < n; e += 64) {
-        const u64 k = kp[e];
-        u32 c;
-        if (k == ~0ULL) c = atomicAdd(&special, 1u) + 1;
-        else {
-          u32 h = cl_mix(k) & (CK_TS - 1);
-          for (;;) {
-            const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)k);
-            if (old == ~0ULL || old == k) break;
-            h = (h + 1) & (CK_TS - 1);
+      for (u32 e0 = sub; e0 < n; e0 += 16) {
+        u64 kk[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) { const u32 e = e0 + 4 * x; kk[x] = e < n ? kp[e] : 0ULL; }
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          if (e0 + 4 * x >= n) continue;
+          const u64 k = kk[x];
+          u32 c;
+          if (k == ~0ULL) c = atomicAdd(&special, 1u) + 1;
+          else {
+            u32 h = cl_mix(k) & (CK_TS - 1), probes = 0;
+            for (;;) {
+              const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)k);
+              if (old == ~0ULL || old == k) break;
+              h = (h + 1) & (CK_TS - 1);
+              if (++probes >= (u32)CK_TS) { flag = 1; break; }     // (table full: more records set aside than it holds)
+            }
+            c = atomicAdd(&cnt[h], 1u) + 1;
           }
-          c = atomicAdd(&cnt[h], 1u) + 1;
+          if (c >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
         }
-        if (c >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
       }
     }
     __syncthreads();
-    if (flag) break;
-    for (u32 t = tid; t < (u32)CK_TS; t += CK_TPB) { keys[t] = ~0ULL; cnt[t] = 0; }
-    if (tid == 0) special = 0;
+    const u32 tot = total;
+    if (flag || tot > (u32)CK_TS * 3 / 4) { if (tid == 0) flag = 1; break; }     // (a slice over its capacity lands here too)
+    __syncthreads();
+    if (tot) wipe();
+    if (tid == 0) { special = 0; total = 0; }
     __syncthreads();
   }
   __syncthreads();
@@ -484,9 +571,15 @@ u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)
 u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * nblk * CL_NW * CL_OVW; }
 u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * nblk * CL_NW; }
 
+u32 cols_skel_cap() { return SK_CAP; }
+hipError_t launch_cols_skel(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cols_skel, dim3(n_items), dim3(SK_TPB), 0, st, subs, items, n_items);
+  return hipGetLastError();
+}
 hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(256), 0, st, tasks, subs, cols);
+  hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(CP_TPB), 0, st, tasks, subs, cols);
   return hipGetLastError();
 }
 hipError_t launch_merge_cols(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
