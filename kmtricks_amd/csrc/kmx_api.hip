@@ -77,6 +77,7 @@ extern "C" int kmx_create(int device, kmx_ctx** out)
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
   c->n_cu = prop.multiProcessorCount;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
+  if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return KMX_E_NODEVICE; }
   *out = c;
   return KMX_OK;
 }
@@ -86,14 +87,16 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->aux);
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
   for (auto& b : ctx->hpool) if (b.p) (void)hipHostFree(b.p);
   (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->aux);
   delete ctx;
 }
 
 extern "C" const char* kmx_last_error(const kmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
-extern "C" void* kmx_stream(kmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" void* kmx_stream(kmx_ctx* ctx) { if (ctx) ctx->stream_shared = true; return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void kmx_free(void* p) { free(p); }
 extern "C" int kmx_set_profiling(kmx_ctx* ctx, int on) { if (!ctx) return KMX_E_INVAL; ctx->profiling = on != 0; return KMX_OK; }
 
@@ -139,6 +142,7 @@ struct kmx_merge_result {
   u32 n_subitems = 0, n_citems = 0, sub_grid = 0, cols_grid = 0, sub_max_c = 0, sub_max_n = 0, items_grid = 0;
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
+  hipEvent_t ev_pre = nullptr;               // cols: preparation (second stream) done
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -151,7 +155,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   u32* d_ticket = reinterpret_cast<u32*>(R->d_meta + R->o_ticket);
   const int kw = (int)R->tasks[0].kw, mode = (int)R->tasks[0].mode;
   const u32 nt = (u32)R->tasks.size();
-  KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 16, ctx->stream));
+  if (!R->use_cols) KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 16, ctx->stream));      // (cols runs once per result: the upload zeroed it)
   if (ctx->profiling && !R->ev0) { KMX_HIP(ctx, hipEventCreate(&R->ev0)); KMX_HIP(ctx, hipEventCreate(&R->ev1)); }
   if (R->is_bf) {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
@@ -164,11 +168,19 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     const uint2* d_subitems = reinterpret_cast<const uint2*>(R->d_meta + R->o_subitems);
     const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
     const uint2* d_citems = reinterpret_cast<const uint2*>(R->d_meta + R->o_citems);
-    KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 64, ctx->stream));
-    KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
-    KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ctx->stream));
-    KMX_HIP(ctx, launch_cols_skel(d_subs, d_subitems, R->n_subitems, ctx->stream));
-    KMX_HIP(ctx, launch_cols_prep(d_tasks, d_subs, d_cols, nt, ctx->stream));
+    // (the preparation -- small, latency-bound kernels -- goes to the second stream: it fills the CUs the previous
+    //  batch's merge leaves idle towards its end, and runs beside that batch's check)
+    if (!R->ev_pre) KMX_HIP(ctx, hipEventCreateWithFlags(&R->ev_pre, hipEventDisableTiming));
+    if (ctx->stream_shared) {   // whatever the caller queued on the stream (producers of the lists) comes first
+      KMX_HIP(ctx, hipEventRecord(R->ev_pre, ctx->stream));
+      KMX_HIP(ctx, hipStreamWaitEvent(ctx->aux, R->ev_pre, 0));
+    }
+    KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->aux));
+    KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ctx->aux));
+    KMX_HIP(ctx, launch_cols_skel(d_subs, d_subitems, R->n_subitems, ctx->aux));
+    KMX_HIP(ctx, launch_cols_prep(d_tasks, d_subs, d_cols, nt, ctx->aux));
+    KMX_HIP(ctx, hipEventRecord(R->ev_pre, ctx->aux));
+    KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_cols(d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
@@ -331,8 +343,8 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       u32 wl = 0; while (wl < 6 && (Q.N << (wl + 1)) <= (u32)rows_cap()) wl++;
       Q.wl = wl;
       Q.rows_guess = std::max<u64>(1, std::min<u64>(H.rows_guess, Q.total_recs));
-      // ranges of ~800 records over the lists (k_cols_skel sorts a range in LDS, <= 2048 records): one segment per range
-      u64 c = std::min<u64>(2000, std::max<u64>(1, Q.total_recs / 800));
+      // ranges of ~1500 records over the lists (k_cols_skel sorts a range in LDS, <= 2048 records): one segment per range
+      u64 c = std::min<u64>(2000, std::max<u64>(1, Q.total_recs / 1500));
       c = std::min<u64>(c, std::max<u32>(1, Q.len[Q.pivot]));
       Q.c = (u32)c;
       Q.seg_cap = Q.c;
@@ -471,10 +483,11 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   }
   auto drop = [&]() {   // hand every block back to the pool on a failed launch
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux);
     drop_blocks();
     if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
   };
-  hipError_t he = hipMemcpyAsync(R->d_meta, R->h_meta, upload_bytes, hipMemcpyHostToDevice, ctx->stream);
+  hipError_t he = hipMemcpyAsync(R->d_meta, R->h_meta, upload_bytes, hipMemcpyHostToDevice, R->use_cols ? ctx->aux : ctx->stream);
   if (he != hipSuccess) { drop(); return ctx->fail(KMX_E_HIP, std::string("meta upload: ") + hipGetErrorString(he)); }
   int rc = launch_batch(R.get(), true);
   if (rc != KMX_OK) { drop(); return rc; }
@@ -727,6 +740,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
+  if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
   delete R;
 }
 
@@ -752,6 +766,8 @@ extern "C" int kmx_merge(kmx_ctx* ctx, const kmx_merge_task* task, void** body, 
     }
     off += align_up(task->lists[i].n * rb, 256);
   }
+  { hipError_t e = hipStreamSynchronize(ctx->stream);      // (the batch's preparation runs on the second stream)
+    if (e != hipSuccess) { ctx->dfree(d_in); return ctx->fail(KMX_E_HIP, std::string("upload: ") + hipGetErrorString(e)); } }
   kmx_merge_task dt = *task;
   dt.lists = dl.data();
   kmx_merge_result* R = nullptr;

@@ -44,6 +44,8 @@ struct kmx_pool_block { void* p; size_t bytes; bool used; };
 struct kmx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool stream_shared = false;           // the caller asked for the stream (kmx_stream): its own work may be queued on it
+  hipStream_t aux = nullptr;            // second stream: the small kernels that prepare a batch run beside the previous batch's merge
   int n_cu = 0;
   std::string err;
   bool profiling = false;

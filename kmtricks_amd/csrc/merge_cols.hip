@@ -504,33 +504,34 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const u64 sbase = (u64)(slot0 + q) * nsl;
     for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
       const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
-      const u32 nraw = sl < nsl ? C.ovcnt[sbase + sl] : 0u;
+      const bool ok = sl < nsl;
+      const u64* kp = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW;
+      // the slice's count and its first 32 keys (8 per thread; the slice's memory is there whatever the count) leave
+      // together: one memory round trip per tile, not two
+      const u32 nraw = ok ? C.ovcnt[sbase + sl] : 0u;
+      u64 kk[8];
+#pragma unroll
+      for (int x = 0; x < 8; x++) kk[x] = kp[sub + 4 * x];
       if (sub == 0 && nraw) atomicAdd(&total, nraw);
       const u32 n = min(nraw, (u32)CL_OVW);
-      const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
-      for (u32 e0 = sub; e0 < n; e0 += 16) {
-        u64 kk[4];
-#pragma unroll
-        for (int x = 0; x < 4; x++) { const u32 e = e0 + 4 * x; kk[x] = e < n ? kp[e] : 0ULL; }
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-          if (e0 + 4 * x >= n) continue;
-          const u64 k = kk[x];
-          u32 c;
-          if (k == ~0ULL) c = atomicAdd(&special, 1u) + 1;
-          else {
-            u32 h = cl_mix(k) & (CK_TS - 1), probes = 0;
-            for (;;) {
-              const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)k);
-              if (old == ~0ULL || old == k) break;
-              h = (h + 1) & (CK_TS - 1);
-              if (++probes >= (u32)CK_TS) { flag = 1; break; }     // (table full: more records set aside than it holds)
-            }
-            c = atomicAdd(&cnt[h], 1u) + 1;
+      auto put = [&](u64 k) {
+        u32 c;
+        if (k == ~0ULL) c = atomicAdd(&special, 1u) + 1;
+        else {
+          u32 h = cl_mix(k) & (CK_TS - 1), probes = 0;
+          for (;;) {
+            const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)k);
+            if (old == ~0ULL || old == k) break;
+            h = (h + 1) & (CK_TS - 1);
+            if (++probes >= (u32)CK_TS) { flag = 1; break; }     // (table full: more records set aside than it holds)
           }
-          if (c >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
+          c = atomicAdd(&cnt[h], 1u) + 1;
         }
-      }
+        if (c >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
+      };
+#pragma unroll
+      for (int x = 0; x < 8; x++) if (sub + 4 * x < n) put(kk[x]);
+      for (u32 e = sub + 32; e < n; e += 4) put(kp[e]);
     }
     __syncthreads();
     const u32 tot = total;

@@ -323,3 +323,29 @@ def test_cols_long_private_runs_and_odd_blocks(ctx, n):
     soft = [1 + (i % 3) for i in range(n)]
     check(ctx, lists, 1, soft, 2, 0, orc.MODE_COUNT)
     check(ctx, lists, 1, soft, 3, 0, orc.MODE_COUNT)
+
+
+def test_cols_many_tiles_per_work_item(monkeypatch):
+    """column-blocked kernel with work items of several tiles (the row-key table is rebuilt, the image reused, the
+    window refilled in place tile after tile): 600 lists x ~20k records, few work items"""
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("column-blocked kernel only")
+    monkeypatch.setenv("KMX_ITEMS_PER_SLOT", "1")
+    ctx = lib.Context(0)
+    N = 600
+    lists = synth_lists(8100, N, 20000, 0.97, 600, kw=1, count_max=9)
+    soft = [1 + (i % 2) for i in range(N)]
+    exp_body, exp_rows, exp_stats = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, soft, 2, 0, orc.MODE_COUNT)
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    recs = [lib.pack_records(k, c, 1) for k, c in lists]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                soft_min=soft, rec_min=2, share_min=0, mode=lib.MODE_COUNT)
+    res = ctx.merge_dev([task]); res.wait()
+    assert res.kernel() == "k_merge_cols"
+    assert res.rows(0) == exp_rows and res.body(0) == exp_body and np.array_equal(res.stats(0), exp_stats)
+    res.free(); ctx.close()
