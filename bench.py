@@ -160,7 +160,7 @@ def main():
                        "parallelism": f"partitions sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(a, N, P, kernel_name),
-                         "kernel": kernel_name + "<1,0>", "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
+                         "kernel": kernel_name + ("" if kernel_name == "k_merge_cols" else "<1,0>"), "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
                          # streaming read rate of this access pattern measured on an MI355X (profiles/r01_h_fetch_calibration.txt)
                          "measured_stream_peak": 5654.0, "frac_of_measured": (achieved / 5654.0) if achieved else None},
         }

@@ -102,7 +102,9 @@ typedef struct {
 typedef struct kmx_merge_result kmx_merge_result;
 
 /* Device-resident batch merge: every lists[i].recs is a DEVICE pointer (4-byte
- * aligned).  Enqueues the whole batch on the ctx stream and returns; the
+ * aligned) whose records are complete, or produced by work queued on kmx_stream(ctx)
+ * (libkmx prepares a batch on a second stream of the context; once kmx_stream has been
+ * called that stream is ordered behind the first).  Enqueues the whole batch and returns; the
  * result stays in HBM until freed.  COUNT/PA rows are produced in row segments
  * that kmx_result_* hands back in ascending key order. */
 int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, kmx_merge_result** out);
