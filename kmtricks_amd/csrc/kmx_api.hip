@@ -78,6 +78,7 @@ extern "C" int kmx_create(int device, kmx_ctx** out)
   c->n_cu = prop.multiProcessorCount;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
   if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return KMX_E_NODEVICE; }
+  if ((e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->aux); delete c; return KMX_E_NODEVICE; }
   *out = c;
   return KMX_OK;
 }
@@ -88,10 +89,12 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->aux);
+  (void)hipStreamSynchronize(ctx->copy);
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
   for (auto& b : ctx->hpool) if (b.p) (void)hipHostFree(b.p);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->aux);
+  (void)hipStreamDestroy(ctx->copy);
   delete ctx;
 }
 
@@ -143,6 +146,8 @@ struct kmx_merge_result {
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
   hipEvent_t ev_pre = nullptr;               // cols: preparation (second stream) done
+  hipEvent_t ev_done = nullptr;              // behind the last kernel queued for this result: what wait / read-back / free wait for
+                                             // (not the stream: later batches are queued on it already)
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -184,7 +189,10 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_cols(d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
+    // (the check stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
     KMX_HIP(ctx, launch_cols_check(d_tasks, d_cols, d_items, R->n_items, ctx->stream));
+    if (!R->ev_done) KMX_HIP(ctx, hipEventCreateWithFlags(&R->ev_done, hipEventDisableTiming));
+    KMX_HIP(ctx, hipEventRecord(R->ev_done, ctx->stream));
     return KMX_OK;
   } else {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
@@ -193,6 +201,8 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     else KMX_HIP(ctx, launch_merge_rows(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
   }
   if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
+  if (!R->ev_done) KMX_HIP(ctx, hipEventCreateWithFlags(&R->ev_done, hipEventDisableTiming));
+  KMX_HIP(ctx, hipEventRecord(R->ev_done, ctx->stream));
   return KMX_OK;
 }
 
@@ -502,8 +512,9 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
   if (fallback) *fallback = false;
   const size_t nt = R->tasks.size();
   u64* hc = reinterpret_cast<u64*>(R->h_meta + R->o_ctrl0);      // pinned staging (the upload image is no longer needed)
-  KMX_HIP(ctx, hipMemcpyAsync(hc, R->d_meta + R->o_ctrl0, nt * 64, hipMemcpyDeviceToHost, ctx->stream));
-  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KMX_HIP(ctx, hipStreamWaitEvent(ctx->copy, R->ev_done, 0));
+  KMX_HIP(ctx, hipMemcpyAsync(hc, R->d_meta + R->o_ctrl0, nt * 64, hipMemcpyDeviceToHost, ctx->copy));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
   for (size_t t = 0; t < nt; t++) {
     TaskHost& H = R->tasks[t];
     const u64* ctrl = hc + t * 8;
@@ -521,7 +532,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   if (R->waited) return R->status;
   kmx_ctx* ctx = R->ctx;
   KMX_HIP(ctx, hipSetDevice(ctx->device));
-  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KMX_HIP(ctx, hipEventSynchronize(R->ev_done));
   if (R->is_bf) {
     for (auto& H : R->tasks) H.rows = H.upper - H.lower + 1;
     R->waited = true; R->status = KMX_OK;
@@ -570,11 +581,12 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
       R->grid = to_pivot ? std::min(R->n_items, (u32)ctx->n_cu)
                          : std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
       rc = launch_batch(R, false);
-      if (rc == KMX_OK) { hipError_t he = hipStreamSynchronize(ctx->stream); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
+      if (rc == KMX_OK) { hipError_t he = hipEventSynchronize(R->ev_done); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
       // restore the full item list (an arena-overflow retry below re-runs the whole batch, with k_merge_rows)
       memcpy(stage, keep.data(), keep.size() * sizeof(uint2));
       R->n_items = was_items; R->grid = was_grid;
       if (rc == KMX_OK) { hipError_t he = hipMemcpyAsync(R->d_meta + R->o_items, stage, keep.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
+      if (rc == KMX_OK) { hipError_t he = hipEventRecord(R->ev_done, ctx->stream); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }   // (free must not hand the pinned image back under this copy)
       if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
       (void)was_pivot; (void)was_cols;
       for (auto& H : R->tasks) if (H.handed_back) H.kernel = to_pivot ? 1 : 0;
@@ -623,7 +635,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     }
     rc = launch_batch(R, false);
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
-    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KMX_HIP(ctx, hipEventSynchronize(R->ev_done));
     rc = fetch_ctrl(R, &overflow);
     if (rc == KMX_OK && overflow) rc = ctx->fail(KMX_E_HIP, "merge overflowed its exact-size arena (internal error)");
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
@@ -671,17 +683,17 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
   if (body == 0) return KMX_OK;
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   if (R->is_bf) {
-    KMX_HIP(ctx, hipMemcpyAsync(dst, H.d_out, body, hipMemcpyDeviceToHost, ctx->stream));
-    KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KMX_HIP(ctx, hipMemcpyAsync(dst, H.d_out, body, hipMemcpyDeviceToHost, ctx->copy));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
     return KMX_OK;
   }
   std::vector<Seg> segs(H.nsegs);
-  KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->stream));
+  KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->copy));
   const u64 arena = H.arena_rows * H.row_bytes;
   u8* tmp = (u8*)malloc(arena);
   if (!tmp) return ctx->fail(KMX_E_NOMEM, "host staging allocation failed");
-  KMX_HIP(ctx, hipMemcpyAsync(tmp, H.d_out, arena, hipMemcpyDeviceToHost, ctx->stream));
-  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KMX_HIP(ctx, hipMemcpyAsync(tmp, H.d_out, arena, hipMemcpyDeviceToHost, ctx->copy));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
   std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.range != b.range ? a.range < b.range : a.seq < b.seq; });
   u8* d = (u8*)dst;
   u64 done = 0;
@@ -705,8 +717,8 @@ extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* 
   TaskHost& H = R->tasks[t];
   const u32 N = H.N;
   KMX_HIP(ctx, hipSetDevice(ctx->device));
-  KMX_HIP(ctx, hipMemcpyAsync(st, R->d_meta + H.o_stats, 8ull * 6 * N, hipMemcpyDeviceToHost, ctx->stream));
-  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KMX_HIP(ctx, hipMemcpyAsync(st, R->d_meta + H.o_stats, 8ull * 6 * N, hipMemcpyDeviceToHost, ctx->copy));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
   // COUNT/PA kernel fills NON_SOLID (0), RESCUED (1), TOTAL_WO (4) and the rescued total (5); the BF
   // kernel fills UNIQUE_WO (2) instead of NON_SOLID.  Derive the rest exactly as MergeStatistics does
   // (merge.hpp:65-70): every input record is either solid or non-solid.
@@ -731,7 +743,8 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   if (!R) return;
   kmx_ctx* ctx = R->ctx;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (R->ev_done) (void)hipEventSynchronize(R->ev_done);      // (this result's work, not the stream: later batches are queued behind it)
+  else (void)hipStreamSynchronize(ctx->stream);
 #ifdef KMX_PHASE_PROF
   if (!R->is_bf) { if (R->use_cols) kmx::cols_phase_prof_dump(); else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
@@ -741,6 +754,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   ctx->hfree(R->h_meta);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
   if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
+  if (R->ev_done) (void)hipEventDestroy(R->ev_done);
   delete R;
 }
 

@@ -306,7 +306,7 @@ def test_cols_kept_key_outside_the_row_keys():
     ctx.close()
 
 
-@pytest.mark.parametrize("n", [9, 257, 700])
+@pytest.mark.parametrize("n", [9, 257, 700, 2500])
 def test_cols_long_private_runs_and_odd_blocks(ctx, n):
     """column-blocked kernel: list counts that do not fill the blocks, a list with a run of private keys longer
     than its 64-record window between two row keys (second round of a tile), an empty list, soft-min > 1"""
