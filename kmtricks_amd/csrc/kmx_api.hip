@@ -145,12 +145,23 @@ struct kmx_merge_result {
   u32 n_subitems = 0, n_citems = 0, sub_grid = 0, cols_grid = 0, sub_max_c = 0, sub_max_n = 0, items_grid = 0;
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
+  u64* d_hctrl = nullptr;                    // device address of the control words' place in h_meta
   hipEvent_t ev_pre = nullptr;               // cols: preparation (second stream) done
   hipEvent_t ev_done = nullptr;              // behind the last kernel queued for this result: what wait / read-back / free wait for
                                              // (not the stream: later batches are queued on it already)
 };
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// The tasks' control words go to the (pinned) host image of the meta blob with the batch itself: a device-to-host copy
+// issued later is a blit kernel here, and it would wait for a CU behind the NEXT batch's merge.
+__global__ void k_ctrl_mirror(const u64* __restrict__ src, u64* __restrict__ dst, u32 n)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+  __threadfence_system();
+}
+static int mirror_and_mark(kmx_merge_result* R);
 
 static int launch_batch(kmx_merge_result* R, bool with_bounds)
 {
@@ -191,9 +202,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
     // (the check stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
     KMX_HIP(ctx, launch_cols_check(d_tasks, d_cols, d_items, R->n_items, ctx->stream));
-    if (!R->ev_done) KMX_HIP(ctx, hipEventCreateWithFlags(&R->ev_done, hipEventDisableTiming));
-    KMX_HIP(ctx, hipEventRecord(R->ev_done, ctx->stream));
-    return KMX_OK;
+    return mirror_and_mark(R);
   } else {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
@@ -201,6 +210,21 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     else KMX_HIP(ctx, launch_merge_rows(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
   }
   if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
+  return mirror_and_mark(R);
+}
+
+static int mirror_and_mark(kmx_merge_result* R)
+{
+  kmx_ctx* ctx = R->ctx;
+  if (!R->d_hctrl) {
+    void* dp = nullptr;
+    KMX_HIP(ctx, hipHostGetDevicePointer(&dp, R->h_meta + R->o_ctrl0, 0));
+    R->d_hctrl = reinterpret_cast<u64*>(dp);
+  }
+  const u32 n = (u32)R->tasks.size() * 8;
+  hipLaunchKernelGGL(k_ctrl_mirror, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<const u64*>(R->d_meta + R->o_ctrl0), R->d_hctrl, n);
+  KMX_HIP(ctx, hipGetLastError());
   if (!R->ev_done) KMX_HIP(ctx, hipEventCreateWithFlags(&R->ev_done, hipEventDisableTiming));
   KMX_HIP(ctx, hipEventRecord(R->ev_done, ctx->stream));
   return KMX_OK;
@@ -303,7 +327,10 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   const u32 slots = (u32)ctx->n_cu * 2;
   const char* ipc = getenv("KMX_ITEMS_PER_SLOT");            // tuning knob (default 3): work items per resident workgroup slot
   const u32 per_slot = ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : 3u;
-  const u32 target_items = (R->use_cols ? (u32)ctx->n_cu : slots) * per_slot;   // (cols: one workgroup per CU, and a work item is a column block of a range)
+  // (cols: one workgroup per CU, and a work item is a column block of a range.  Leaving a few CUs to the small kernels
+  //  that prepare the NEXT batch on the second stream was tried: the merge then needs finer work items, net +5 %)
+  const u32 cols_cus = (u32)ctx->n_cu;
+  const u32 target_items = (R->use_cols ? cols_cus : slots) * per_slot;
   u32 n_items = 0, max_n = 0, max_c = 0;
   for (auto& H : R->tasks) {
     if (R->use_cols) {
@@ -365,7 +392,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     }
     R->n_subitems = nsub; R->n_citems = ncit;
     R->sub_grid = std::min(nsub, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)kw));
-    R->cols_grid = std::min(ncit, (u32)ctx->n_cu);
+    R->cols_grid = std::min(ncit, cols_cus);
   }
   if (is_bf) {
     int lds = 0;
@@ -511,10 +538,8 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
   *overflow = false;
   if (fallback) *fallback = false;
   const size_t nt = R->tasks.size();
-  u64* hc = reinterpret_cast<u64*>(R->h_meta + R->o_ctrl0);      // pinned staging (the upload image is no longer needed)
-  KMX_HIP(ctx, hipStreamWaitEvent(ctx->copy, R->ev_done, 0));
-  KMX_HIP(ctx, hipMemcpyAsync(hc, R->d_meta + R->o_ctrl0, nt * 64, hipMemcpyDeviceToHost, ctx->copy));
-  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+  const u64* hc = reinterpret_cast<const u64*>(R->h_meta + R->o_ctrl0);      // written by k_ctrl_mirror behind the batch's last kernel
+  KMX_HIP(ctx, hipEventSynchronize(R->ev_done));
   for (size_t t = 0; t < nt; t++) {
     TaskHost& H = R->tasks[t];
     const u64* ctrl = hc + t * 8;

@@ -29,18 +29,22 @@
 namespace kmx {
 
 constexpr int CL_TPB = 1024;
-constexpr int CL_G = 4;                  // adjacent lanes per list
-#ifndef KMX_CL_W
-#define KMX_CL_W 64
+#ifndef KMX_CL_G
+#define KMX_CL_G 8
 #endif
-constexpr int CL_W = KMX_CL_W;                 // records per window
-constexpr int CL_U = CL_W / CL_G;        // window slots per lane
+constexpr int CL_G = KMX_CL_G;           // adjacent lanes per list (4: 64-record windows, 256 lists per block; 8: 128 and 128)
+constexpr int CL_U = 16;                 // window slots per lane
+constexpr int CL_W = CL_G * CL_U;        // records per window
 constexpr int CL_NB = CL_TPB / CL_G;     // lists per column block
 constexpr int CL_IMG = 61440;            // LDS image bytes (rt rows x nb u32 counts)
-constexpr int CL_PT = 2048;              // row-key table entries (two tables: the next tile's is built while this one is written out)
-constexpr int CL_SEEDS = 48;             // hash multipliers tried per tile for a collision-free table
-constexpr int CL_OVW = 128;              // keys per (tile, block, wave) slice of records that are not row keys
-constexpr int CL_RT = 56;                // row keys per tile (< window: a similar list needs no second round)
+constexpr int CL_RT = CL_W * 7 / 8;      // row keys per tile (< window: a similar list needs no second round)
+constexpr int CL_KPL = (CL_RT + 63) / 64;   // row keys per lane of wave 0 (which builds the row table)
+constexpr int CL_NT = CL_KPL == 1 ? 2 : 1;  // row tables: two of 2048 entries (the next tile's is built beside this tile's), or one of 4096
+constexpr int CL_PT = 4096 / CL_NT;      // row-key table entries
+constexpr int CL_PTSHIFT = CL_NT == 2 ? 21 : 20;
+constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 56 rows (k_cols_check takes a slice group at a time)
+constexpr int CL_SEEDS = 64;             // hash multipliers tried per tile for a collision-free table
+constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
 constexpr int CL_NW = CL_TPB / 64;
 constexpr int CK_TS = 4096;              // k_cols_check: hash set entries (48 KB of LDS with the counts)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
@@ -64,7 +68,7 @@ __device__ __forceinline__ void cl_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ u32 cl_thash(u64 k, u32 hf)
 {
   const u32 x = ((u32)k ^ (u32)(k >> (hf >> 24))) & 0xFFFFFFu;
-  return ((u32)__umul24(x, hf) >> 21) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
+  return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
 }
 __device__ __forceinline__ u32 cl_mult(u32 seed) { return ((0x9E3779u + seed * 0x5A6B2u) & 0xFFFFFFu) | ((13u + (seed * 7u) % 19u) << 24); }
 __device__ __forceinline__ u32 cl_mix(u64 k)
@@ -73,19 +77,26 @@ __device__ __forceinline__ u32 cl_mix(u64 k)
   x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
   return x;
 }
-// wave 0: lane j < n holds row key j.  -> the multiplier, 0 when no try worked; *slot = my key's entry
-__device__ __forceinline__ u32 cl_build(ClEnt* tab, u64 key, bool have, u32 lane, u32* slot)
+// wave 0: lane j holds row keys j, j + 64, ...  -> the hash, 0 when no try worked; slot[x] = entry of my key x
+__device__ __forceinline__ u32 cl_build(ClEnt* tab, const u64 (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL])
 {
   for (u32 s = 0; s < (u32)CL_SEEDS; s++) {
     const u32 mult = cl_mult(s);
-    const u32 h = cl_thash(key, mult);
-    const u32 old = have ? atomicCAS(&tab[h].idx, 0u, lane + 1) : 0u;
-    if (__ballot(old != 0) == 0) {
-      if (have) { tab[h].klo = (u32)key; tab[h].khi = (u32)(key >> 32); }
-      *slot = h;
+    u32 h[CL_KPL], old[CL_KPL];
+    bool clash = false;
+#pragma unroll
+    for (int x = 0; x < CL_KPL; x++) {
+      h[x] = cl_thash(key[x], mult);
+      old[x] = have[x] ? atomicCAS(&tab[h[x]].idx, 0u, lane + 64u * x + 1) : 0u;
+      clash |= old[x] != 0;
+    }
+    if (__ballot(clash) == 0) {
+#pragma unroll
+      for (int x = 0; x < CL_KPL; x++) { if (have[x]) { tab[h[x]].klo = (u32)key[x]; tab[h[x]].khi = (u32)(key[x] >> 32); } slot[x] = h[x]; }
       return mult;
     }
-    if (have && old == 0) atomicExch(&tab[h].idx, 0u);      // take my claim back, next multiplier
+#pragma unroll
+    for (int x = 0; x < CL_KPL; x++) if (have[x] && old[x] == 0) atomicExch(&tab[h[x]].idx, 0u);      // take my claims back, next hash
   }
   return 0;
 }
@@ -241,14 +252,14 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32* const img = reinterpret_cast<u32*>(smem);                                   // [rt][nb] counts of the tile
-  ClEnt* const ptab = reinterpret_cast<ClEnt*>(smem + CL_IMG);                     // [2][CL_PT] row key -> row
-  u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + 2 * CL_PT * sizeof(ClEnt)); // [0] item [1..3] "another round" flags, used in turn [4],[5] the tables' multipliers
-  const u32 dummy = (u32)(CL_IMG + 2 * CL_PT * sizeof(ClEnt)) / 4 + 16 + (u32)(threadIdx.x & 63);   // image index of a scratch word of my own (deposits that are none)
+  ClEnt* const ptab = reinterpret_cast<ClEnt*>(smem + CL_IMG);                     // [CL_NT][CL_PT] row key -> row
+  u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt)); // [0] item [1..3] "another round" flags, used in turn [4],[5] the tables' multipliers
+  const u32 dummy = (u32)(CL_IMG + CL_NT * CL_PT * sizeof(ClEnt)) / 4 + 16 + (u32)(threadIdx.x & 63);   // image index of a scratch word of my own (deposits that are none)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const u32 wave = cl_uni((u32)tid >> 6);
   for (int t = tid; t < CL_IMG / 16; t += CL_TPB) reinterpret_cast<uint4*>(img)[t] = make_uint4(0, 0, 0, 0);
-  for (int t = tid; t < 2 * CL_PT; t += CL_TPB) ptab[t].idx = 0;
+  for (int t = tid; t < CL_NT * CL_PT; t += CL_TPB) ptab[t].idx = 0;
   if (tid == 0) { sh[1] = 0; sh[2] = 0; sh[3] = 0; }
 #ifdef KMX_PHASE_PROF
   long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pc = clock64();
@@ -300,19 +311,27 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     }
     u64 tsum = 0; u32 tn = 0;            // TOTAL_WO / NON_SOLID of my share of my list
     // first tile: row keys, table, (block 0) the key column of the result
-    u64 skn = ~0ULL;
-    u32 myslot = 0;                      // wave 0: the table entry of my row key of the tile in hand
+    u64 skn[CL_KPL];
+    u32 myslot[CL_KPL];                  // wave 0: the table entries of my row keys of the tile in hand
     bool failed = false;
+#pragma unroll
+    for (int x = 0; x < CL_KPL; x++) { skn[x] = ~0ULL; myslot[x] = 0; }
     if (tid < 64) {
-      const bool have = (u32)tid < rt && s_lo + tid < s_hi;
-      if (have) {
-        skn = skel[s_lo + tid];
-        if (blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(s_lo + tid) * row_bytes); kp[0] = (u32)skn; kp[1] = (u32)(skn >> 32); }
+      bool have[CL_KPL];
+#pragma unroll
+      for (int x = 0; x < CL_KPL; x++) {
+        const u32 j = (u32)tid + 64u * x;
+        have[x] = j < rt && s_lo + j < s_hi;
+        if (have[x]) {
+          skn[x] = skel[s_lo + j];
+          if (blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes); kp[0] = (u32)skn[x]; kp[1] = (u32)(skn[x] >> 32); }
+        }
       }
-      const u32 mult = cl_build(ptab, skn, have, (u32)tid, &myslot);
+      const u32 mult = cl_build(ptab, skn, have, (u32)tid, myslot);
       if (tid == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
     }
     u64 khi_n = ntiles > 1 ? skel[s_lo + rt] : ~0ULL;     // upper key of tile 0 (uniform address: scalar load)
+    u64 kmid_n = (CL_HALVES > 1 && s_lo + 56 < s_hi) ? skel[s_lo + 56] : ~0ULL;      // ... and the key its second slice group starts at
     u32 rnd = 0;                         // round number mod 3
     cl_barrier();
     CLPH(0);
@@ -322,15 +341,22 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       const u32 rte = min(rt, s_hi - s0);
       const bool last = cl_uni(q + 1 == ntiles ? 1u : 0u) != 0;            // takes everything the lists have left in the range
       const u64 khi = cl_uni64(khi_n);
+      const u64 kmid = cl_uni64(kmid_n);
       if (!last) {
         // the next tile's row keys are wave 0's business alone: nobody else ever waits for these loads
-        if (tid < 64) { skn = ~0ULL; if ((u32)tid < rt && s0 + rt + tid < s_hi) skn = skel[s0 + rt + tid]; }
+        if (tid < 64) {
+#pragma unroll
+          for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)tid + 64u * x; skn[x] = ~0ULL; if (j < rt && s0 + rt + j < s_hi) skn[x] = skel[s0 + rt + j]; }
+        }
         khi_n = q + 2 < ntiles ? skel[s0 + 2 * rt] : ~0ULL;
+        kmid_n = (CL_HALVES > 1 && s0 + rt + 56 < s_hi) ? skel[s0 + rt + 56] : ~0ULL;
       }
-      const ClEnt* const tab = ptab + (q & 1u) * CL_PT;
-      const u32 mult = cl_uni(sh[4 + (q & 1u)]);
-      gu64w* const ovk = (gu64w*)(uintptr_t)(C.ovkeys + ((((u64)(slot0 + q) * nblk + blk) * CL_NW + wave) * CL_OVW));
-      u32 wov = 0;                                  // records of this wave that are not row keys (uniform)
+      const ClEnt* const tab = ptab + (q % CL_NT) * CL_PT;
+      const u32 mult = cl_uni(sh[4 + (q % CL_NT)]);
+      // the wave's slices of the tile's slice groups (records below / from the tile's middle row key)
+      gu64w* const ovk0 = (gu64w*)(uintptr_t)(C.ovkeys + (((((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave) * CL_OVW));
+      gu64w* const ovk1 = ovk0 + (u64)nblk * CL_NW * CL_OVW;
+      u32 wov = 0, wov1 = 0;                        // records of this wave that are not row keys (uniform), per slice group
 
       for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
         // (three flags in turn: the one cleared here was last read two rounds ago, a barrier away)
@@ -375,11 +401,23 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           for (int j = 0; j < 4; j++) {
             const u64 bal = __ballot((ovm >> j) & 1u);
             if (bal) {
-              if ((ovm >> j) & 1u) {
-                const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                if (pos < (u32)CL_OVW) ovk[pos] = cl_key(rec[g + j]);
+              const u64 kk = cl_key(rec[g + j]);
+              if (CL_HALVES == 1) {
+                if ((ovm >> j) & 1u) {
+                  const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                  if (pos < (u32)CL_OVW) ovk0[pos] = kk;
+                }
+                wov += (u32)__popcll(bal);
+              } else {
+                const u64 hi = __ballot(((ovm >> j) & 1u) && kk >= kmid), lo = bal & ~hi;
+                if ((ovm >> j) & 1u) {
+                  const bool up = kk >= kmid;
+                  const u64 m = up ? hi : lo;
+                  const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                  if (pos < (u32)CL_OVW) (up ? ovk1 : ovk0)[pos] = kk;
+                }
+                wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
               }
-              wov += (u32)__popcll(bal);
             }
           }
           // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record is
@@ -398,6 +436,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         u32 c = __popc(consm);
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        if (CL_G == 8) c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of my 8
         cur += c;
         if (c == (u32)CL_W && cur < end) sh[1 + rnd] = 1;
         CLPH(2);
@@ -408,20 +447,27 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         if (!more) break;
       }
       if (lane == 0) {
-        C.ovcnt[((u64)(slot0 + q) * nblk + blk) * CL_NW + wave] = wov;
-        if (wov > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); atomicAdd(&kmx_cols_dbg[q == 0 ? 4 : (q & 1u) ? 5 : 6], 1u); if (rte < rt) atomicAdd(&kmx_cols_dbg[7], 1u); }
+        C.ovcnt[(((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave] = wov;
+        if (CL_HALVES > 1) C.ovcnt[(((u64)(slot0 + q) * CL_HALVES + 1) * nblk + blk) * CL_NW + wave] = wov1;
+        if (max(wov, wov1) > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); atomicAdd(&kmx_cols_dbg[q == 0 ? 4 : (q & 1u) ? 5 : 6], 1u); if (rte < rt) atomicAdd(&kmx_cols_dbg[7], 1u); }
       }
 
       // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
       if (wave == 0) {
-        ClEnt* const old = ptab + (q & 1u) * CL_PT;
-        if ((u32)lane < rte) old[myslot].idx = 0;        // (keys may stay: an entry without a row is never a hit)
+        ClEnt* const old = ptab + (q % CL_NT) * CL_PT;
+#pragma unroll
+        for (int x = 0; x < CL_KPL; x++) if ((u32)lane + 64u * x < rte) old[myslot[x]].idx = 0;        // (keys may stay: an entry without a row is never a hit)
         if (!last) {
           const u32 sn = s0 + rt;
-          const bool have = (u32)lane < rt && sn + lane < s_hi;
-          if (have && blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(sn + lane) * row_bytes); kp[0] = (u32)skn; kp[1] = (u32)(skn >> 32); }
-          const u32 m2 = cl_build(ptab + ((q + 1) & 1u) * CL_PT, skn, have, (u32)lane, &myslot);
-          if (lane == 0) { sh[4 + ((q + 1) & 1u)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
+          bool have[CL_KPL];
+#pragma unroll
+          for (int x = 0; x < CL_KPL; x++) {
+            const u32 j = (u32)lane + 64u * x;
+            have[x] = j < rt && sn + j < s_hi;
+            if (have[x] && blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes); kp[0] = (u32)skn[x]; kp[1] = (u32)(skn[x] >> 32); }
+          }
+          const u32 m2 = cl_build(ptab + ((q + 1) % CL_NT) * CL_PT, skn, have, (u32)lane, myslot);
+          if (lane == 0) { sh[4 + ((q + 1) % CL_NT)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
         u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + 4ull * col0;
@@ -488,7 +534,8 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   const u32 range = items[item].y, rec_min = T.rec_min, rt = C.rt, nsl = C.nblk * CL_NW;
   const u32 s_lo = C.rbounds[range], s_hi = C.rbounds[range + 1];
   const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
-  const u32 slot0 = s_lo / rt + range;
+  const u32 slot0 = (s_lo / rt + range) * CL_HALVES;
+  const u32 ngroups = ntiles * CL_HALVES;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto wipe = [&]() {
     for (u32 t = tid; t < (u32)CK_TS / 2; t += CK_TPB) reinterpret_cast<uint4*>(keys)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -498,7 +545,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   if (tid == 0) { flag = 0; total = 0; special = 0; }
   __syncthreads();
   (void)lane; (void)wave;
-  for (u32 q = blockIdx.y; q < ntiles; q += CK_Z) {
+  for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) {
     // four threads per (block, wave) slice of the tile: every slice's count, then every slice's keys, are in flight
     // at once (a wave walking its slices one after the other pays two dependent memory round trips per slice)
     const u64 sbase = (u64)(slot0 + q) * nsl;
@@ -566,11 +613,12 @@ void cols_phase_prof_dump()
 #endif
 
 // ---- host side ------------------------------------------------------------------------------------------
-int cols_lds_bytes() { return CL_IMG + 2 * CL_PT * (int)sizeof(ClEnt) + 64 + 256; }
+int cols_lds_bytes() { return CL_IMG + CL_NT * CL_PT * (int)sizeof(ClEnt) + 64 + 256; }
+u32 cols_halves() { return CL_HALVES; }
 u32 cols_block_lists() { return CL_NB; }
 u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }
-u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * nblk * CL_NW * CL_OVW; }
-u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * nblk * CL_NW; }
+u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW; }
+u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW; }
 
 u32 cols_skel_cap() { return SK_CAP; }
 hipError_t launch_cols_skel(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st)
