@@ -3,22 +3,23 @@
 //
 // k_merge_pivot gives every list a 16-record register window and a workgroup all N lists, so a list hands
 // over ~13 records (156 bytes) per tile: each 128-byte line of a list is touched in two tiles and, with
-// 32 workgroups x 1000 lists per L2, fetched twice.  Here a workgroup owns a BLOCK of <= 256 lists (columns)
-// of a key range and gives each a 64-record window: ~56 records (672 bytes) per list and tile, 1.2x line
-// traffic instead of 1.8x, and a quarter of the per-tile fixed work.  What makes that possible:
-//   * the ROW KEYS are known before the merge runs: a handful of the task's lists are merged first (with
-//     k_merge_rows, same recurrence-min), and the keys that merge keeps -- every one of them is kept by the
+// 32 workgroups x 1000 lists per L2, fetched twice.  Here a workgroup owns a BLOCK of <= 128 lists (columns)
+// of a key range and gives each a 128-record window (8 adjacent lanes x 16 slots): ~112 records (1.3 KB) per
+// list and tile, 1.13x line traffic instead of 1.85x, and an eighth of the per-tile fixed work per record.
+// What makes that possible:
+//   * the ROW KEYS are known before the merge runs: a handful of the task's lists are merged first
+//     (k_cols_skel, same recurrence-min), and the keys that merge keeps -- every one of them is kept by the
 //     full merge too -- are the rows (k_cols_prep gathers them into one ascending array and cuts it into
 //     the task's key ranges).  Row r of the result is row key r: every column block writes its slice of the
 //     row at a position known up front, no cross-block ranking, no row directory;
 //   * a tile is rt consecutive row keys; a record below the tile's upper key is consumed, its slot is
-//     refilled in place with the record 64 positions further (one global_load_dwordx3), a record whose key
-//     is a row key (one probe of a read-only LDS table) is deposited into the block's LDS image of the
-//     tile, and the image leaves as rt slices of <= 1 KB;
-//   * a solid record whose key is NOT a row key (sample-private k-mers) is appended to a per-(tile, block, wave)
-//     slice in HBM.  k_cols_check then counts, tile by tile and across the blocks, in how many lists each of
-//     those keys is solid: if one reaches the recurrence the rows were incomplete and the task is handed
-//     back (ERR_FALLBACK: the driver re-runs it with k_merge_pivot / k_merge_rows).  So are tasks whose
+//     refilled in place with the record one window further (one global_load_dwordx3), a record whose key
+//     is a row key (one read of a collision-free LDS table built per tile) is deposited into the block's LDS
+//     image of the tile, and the image leaves as rt slices of ~500 bytes;
+//   * a solid record whose key is NOT a row key (sample-private k-mers) is appended to a per-(half tile, block,
+//     wave) slice in HBM.  k_cols_check then counts, half tile by half tile and across the blocks, in how many
+//     lists each of those keys is solid: if one reaches the recurrence the rows were incomplete and the task is
+//     handed back (ERR_FALLBACK: the driver re-runs it with k_merge_pivot / k_merge_rows).  So are tasks whose
 //     slices overflow.  Results never depend on how well the row keys cover the lists.
 // Applicable to COUNT rows, 64-bit keys, no share-min; chosen for > 512 lists and 2 <= recurrence-min <= 4.
 #include "kmx_dev.hpp"
@@ -292,8 +293,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const u32 slot0 = s_lo / rt + range;
     const u64* const skel = C.skel;
 
-    // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + 4u (mod 64)
-    // inside [cur, cur + 64)
+    // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + CL_G * u
+    // (mod CL_W) inside [cur, cur + CL_W)
     const u32 lg = (u32)tid / CL_G, r = (u32)tid & (CL_G - 1);
     const bool on = lg < nbl;
     const u32 li = col0 + (on ? lg : 0u);
