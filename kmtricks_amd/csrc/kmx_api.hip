@@ -147,6 +147,7 @@ struct kmx_merge_result {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
   u64* d_hctrl = nullptr;                    // device address of the control words' place in h_meta
   hipEvent_t ev_pre = nullptr;               // cols: preparation (second stream) done
+  hipEvent_t ev_up = nullptr;                // cols: meta blob uploaded (second stream)
   hipEvent_t ev_done = nullptr;              // behind the last kernel queued for this result: what wait / read-back / free wait for
                                              // (not the stream: later batches are queued on it already)
 };
@@ -191,11 +192,13 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
       KMX_HIP(ctx, hipEventRecord(R->ev_pre, ctx->stream));
       KMX_HIP(ctx, hipStreamWaitEvent(ctx->aux, R->ev_pre, 0));
     }
-    KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->aux));
     KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ctx->aux));
     KMX_HIP(ctx, launch_cols_skel(d_subs, d_subitems, R->n_subitems, ctx->aux));
     KMX_HIP(ctx, launch_cols_prep(d_tasks, d_subs, d_cols, nt, ctx->aux));
     KMX_HIP(ctx, hipEventRecord(R->ev_pre, ctx->aux));
+    // (the task's own range bounds need the upload only: on the main stream, beside the row-key kernels)
+    KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_up, 0));
+    KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_cols(d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
@@ -523,9 +526,17 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     (void)hipStreamSynchronize(ctx->aux);
     drop_blocks();
     if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
+    if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
+    if (R->ev_up) (void)hipEventDestroy(R->ev_up);
+    if (R->ev_done) (void)hipEventDestroy(R->ev_done);
   };
   hipError_t he = hipMemcpyAsync(R->d_meta, R->h_meta, upload_bytes, hipMemcpyHostToDevice, R->use_cols ? ctx->aux : ctx->stream);
   if (he != hipSuccess) { drop(); return ctx->fail(KMX_E_HIP, std::string("meta upload: ") + hipGetErrorString(he)); }
+  if (R->use_cols) {
+    he = hipEventCreateWithFlags(&R->ev_up, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventRecord(R->ev_up, ctx->aux);
+    if (he != hipSuccess) { drop(); return ctx->fail(KMX_E_HIP, std::string("meta upload event: ") + hipGetErrorString(he)); }
+  }
   int rc = launch_batch(R.get(), true);
   if (rc != KMX_OK) { drop(); return rc; }
   *out = R.release();
@@ -779,6 +790,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   ctx->hfree(R->h_meta);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
   if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
+  if (R->ev_up) (void)hipEventDestroy(R->ev_up);
   if (R->ev_done) (void)hipEventDestroy(R->ev_done);
   delete R;
 }

@@ -108,7 +108,10 @@ __device__ __forceinline__ u32 cl_build(ClEnt* tab, const u64 (&key)[CL_KPL], co
 //      the solid keys of the range are sorted in LDS (bitonic), a key is kept when its run is at least
 //      recurrence-min long, kept keys leave in order.  Segment j of the result = range j (k_cols_prep strings them
 //      together). ----
-constexpr int SK_TPB = 256;
+#ifndef KMX_SK_TPB
+#define KMX_SK_TPB 256
+#endif
+constexpr int SK_TPB = KMX_SK_TPB;
 constexpr int SK_CAP = 2048;             // records per range (all lists), and the row capacity of a range
 
 __global__ __launch_bounds__(SK_TPB)
@@ -519,8 +522,14 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 
 // ---- after the merge: does any key outside the rows reach the recurrence?  One workgroup per (task, range), a tile
 //      at a time: the records the column blocks set aside for the tile are counted per key in an LDS hash set ----
-constexpr int CK_TPB = 256;              // k_cols_check: threads (3 workgroups per CU by LDS)
-constexpr int CK_Z = 16;                 // ... and workgroups sharing the tiles of a range
+#ifndef KMX_CK_TPB
+#define KMX_CK_TPB 512
+#endif
+#ifndef KMX_CK_Z
+#define KMX_CK_Z 16
+#endif
+constexpr int CK_TPB = KMX_CK_TPB;       // k_cols_check: threads (3 workgroups per CU by LDS; 256 threads: step +1.7 %)
+constexpr int CK_Z = KMX_CK_Z;           // ... and workgroups sharing the tiles of a range
 __global__ __launch_bounds__(CK_TPB)
 void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
