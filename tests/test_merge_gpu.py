@@ -349,3 +349,36 @@ def test_cols_many_tiles_per_work_item(monkeypatch):
     assert res.kernel() == "k_merge_cols"
     assert res.rows(0) == exp_rows and res.body(0) == exp_body and np.array_equal(res.stats(0), exp_stats)
     res.free(); ctx.close()
+
+
+def test_batches_in_flight_waited_out_of_order():
+    """Three batches queued back to back on one context (the preparation of one runs beside the merge of the one
+    before), waited for and freed out of order; the third after the caller asked for the stream (its lists count as
+    produced on it).  Every body and every statistic equals the oracle's, whatever kernel took the batch."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    ctx = lib.Context(0)
+    dev = torch.device("cuda", 0)
+    N = 600
+    sets = [synth_lists(9100 + i, N, 2500 + 700 * i, 0.97, 60, kw=1) for i in range(3)]
+    keep, tasks, exp = [], [], []
+    for lists in sets:
+        recs = [lib.pack_records(k, c, 1) for k, c in lists]
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+        dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+        keep.append(dt)
+        tasks.append(dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                          soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT))
+        exp.append(orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT))
+    torch.cuda.synchronize()
+    r0 = ctx.merge_dev([tasks[0]]); r1 = ctx.merge_dev([tasks[1], tasks[0]])
+    assert ctx.stream is not None
+    r2 = ctx.merge_dev([tasks[2]])
+    r1.wait()
+    for t, e in ((0, exp[1]), (1, exp[0])):
+        assert r1.rows(t) == e[1] and r1.body(t) == e[0] and np.array_equal(r1.stats(t), e[2])
+    r2.wait(); r0.wait()
+    assert r2.rows(0) == exp[2][1] and r2.body(0) == exp[2][0] and np.array_equal(r2.stats(0), exp[2][2])
+    r1.free()
+    assert r0.rows(0) == exp[0][1] and r0.body(0) == exp[0][0] and np.array_equal(r0.stats(0), exp[0][2])
+    r2.free(); r0.free(); ctx.close()
