@@ -154,6 +154,20 @@ struct kmx_merge_result {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// k_merge_cols takes its row keys from a merge of S of the task's lists: the fewest (8..32) for which a key that 3.5 % of
+// the lists lack is in fewer than recurrence-min of the S with probability < 2e-9 (C(S, m) q^m, m = S - r + 1 misses).
+// 0: none up to 32 (recurrence-min above 21): the column-blocked kernel is not chosen.
+static u32 cols_row_lists(u32 rec_min)
+{
+  for (u32 S = std::max<u32>(8, rec_min + 2); S <= 32; S++) {
+    const u32 m = S - rec_min + 1;
+    double p = 1.0;
+    for (u32 i = 0; i < m; i++) p *= (double)(S - i) / (double)(i + 1) * 0.035;
+    if (p < 2e-9) return S;
+  }
+  return 0;
+}
+
 // The tasks' control words go to the (pinned) host image of the meta blob with the batch itself: a device-to-host copy
 // issued later is a blit kernel here, and it would wait for a CU behind the NEXT batch's merge.
 __global__ void k_ctrl_mirror(const u64* __restrict__ src, u64* __restrict__ dst, u32 n)
@@ -302,7 +316,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   // and k_merge_cols (merge_cols.hip; COUNT rows, a small recurrence-min) faster still there.  Both flag tasks
   // they do not suit, and those are re-run with the next kernel down (cols -> pivot -> rows, see
   // kmx_result_wait).  Default: more than 512 lists per task (where k_merge_rows is down to 4-record windows)
-  // go to cols when 2 <= recurrence-min <= 4, to pivot otherwise.
+  // go to cols when 2 <= recurrence-min <= 21, to pivot otherwise.
   // KMX_MERGE_KERNEL=rows|pivot|cols forces one of them (where it is applicable).
   {
     bool rescue = false; u32 min_n = 0xFFFFFFFFu, mx_n = 0, min_rec = 0xFFFFFFFFu, max_rec = 0;
@@ -318,7 +332,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     else if (force && !strcmp(force, "pivot")) R->use_pivot = can;
     else if (force && !strcmp(force, "rows")) R->use_pivot = false;
     else {
-      R->use_cols = can_cols && min_n > 512 && min_rec >= 2 && max_rec <= 4;
+      R->use_cols = can_cols && min_n > 512 && min_rec >= 2 && cols_row_lists(max_rec) != 0;      // (recurrence-min <= 21)
       if (R->use_cols && ctx->cols_skip) { ctx->cols_skip--; R->use_cols = false; }
       R->cols_auto = R->use_cols;
       R->use_pivot = !R->use_cols && can && min_n > 512;
@@ -370,7 +384,8 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     for (u32 t = 0; t < n_tasks; t++) {
       const TaskHost& H = R->tasks[t];
       TaskHost& Q = R->subs[t];
-      Q.N = std::min<u32>(8, H.N); Q.kw = kw; Q.mode = mode; Q.rec_min = H.rec_min; Q.share_min = 0;
+      { const u32 S = cols_row_lists(H.rec_min); Q.N = std::min<u32>(S ? S : 32u, H.N); }
+      Q.kw = kw; Q.mode = mode; Q.rec_min = H.rec_min; Q.share_min = 0;
       Q.len.resize(Q.N);
       u32 piv = 0;
       for (u32 i = 0; i < Q.N; i++) {

@@ -21,7 +21,8 @@
 //     lists each of those keys is solid: if one reaches the recurrence the rows were incomplete and the task is
 //     handed back (ERR_FALLBACK: the driver re-runs it with k_merge_pivot / k_merge_rows).  So are tasks whose
 //     slices overflow.  Results never depend on how well the row keys cover the lists.
-// Applicable to COUNT rows, 64-bit keys, no share-min; chosen for > 512 lists and 2 <= recurrence-min <= 4.
+// Applicable to COUNT rows, 64-bit keys, no share-min; chosen for > 512 lists and 2 <= recurrence-min <= 21
+// (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
 #include "kmx_dev.hpp"
 #include <algorithm>
 #include <cstdio>

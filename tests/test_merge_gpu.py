@@ -382,3 +382,29 @@ def test_batches_in_flight_waited_out_of_order():
     r1.free()
     assert r0.rows(0) == exp[0][1] and r0.body(0) == exp[0][0] and np.array_equal(r0.stats(0), exp[0][2])
     r2.free(); r0.free(); ctx.close()
+
+
+@pytest.mark.parametrize("rec_min", [5, 12, 21, 22])
+def test_default_kernel_for_larger_recurrence_min(monkeypatch, rec_min):
+    """KMX_MERGE_KERNEL unset, 600 similar lists: recurrence-min up to 21 goes to k_merge_cols (row keys from up to 32
+    lists), above that to k_merge_pivot; the result is the oracle's either way."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    ctx = lib.Context(0)
+    N = 600
+    lists = synth_lists(9300 + rec_min, N, 4000, 0.975, 100, kw=1)
+    dev = torch.device("cuda", 0)
+    recs = [lib.pack_records(k, c, 1) for k, c in lists]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                soft_min=[1] * N, rec_min=rec_min, share_min=0, mode=lib.MODE_COUNT)
+    res = ctx.merge_dev([task]); res.wait()
+    assert res.kernel() == ("k_merge_cols" if rec_min <= 21 else "k_merge_pivot")
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, rec_min, 0, orc.MODE_COUNT)
+    assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
+    res.free(); ctx.close()
