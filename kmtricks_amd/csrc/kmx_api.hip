@@ -215,7 +215,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    KMX_HIP(ctx, launch_merge_cols(d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
+    KMX_HIP(ctx, launch_merge_cols(mode, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
     // (the check stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
     KMX_HIP(ctx, launch_cols_check(d_tasks, d_cols, d_items, R->n_items, ctx->stream));
@@ -313,7 +313,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   // ---- which COUNT/PA kernel ----
   // k_merge_rows is the general one.  k_merge_pivot (merge_pivot.hip; 64-bit keys, no share-min, <= 1024
   // lists) is faster when MANY lists share most of their keys -- the cohort case the metric is quoted on --
-  // and k_merge_cols (merge_cols.hip; COUNT rows, a small recurrence-min) faster still there.  Both flag tasks
+  // and k_merge_cols (merge_cols.hip; a small recurrence-min) faster still there.  Both flag tasks
   // they do not suit, and those are re-run with the next kernel down (cols -> pivot -> rows, see
   // kmx_result_wait).  Default: more than 512 lists per task (where k_merge_rows is down to 4-record windows)
   // go to cols when 2 <= recurrence-min <= 21, to pivot otherwise.
@@ -326,7 +326,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     }
     const char* force = getenv("KMX_MERGE_KERNEL");
     const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
-    const bool can_cols = !is_bf && mode == KMX_MODE_COUNT && !rescue && kw == 1 && mx_n <= (u32)rows_cap() && min_rec >= 1;
+    const bool can_cols = !is_bf && !rescue && kw == 1 && mx_n <= (u32)rows_cap() && min_rec >= 1;
     R->can_pivot = can;
     if (force && !strcmp(force, "cols")) { R->use_cols = can_cols; R->use_pivot = !can_cols && can; }
     else if (force && !strcmp(force, "pivot")) R->use_pivot = can;
@@ -352,7 +352,8 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   for (auto& H : R->tasks) {
     if (R->use_cols) {
       H.nblk = (H.N + cols_block_lists() - 1) / cols_block_lists();
-      H.nb = std::min<u32>(cols_block_lists(), (((H.N + H.nblk - 1) / H.nblk) + 1) & ~1u);
+      // (lists per block: even for count rows -- 8-byte stores --, a multiple of 8 for PA rows -- whole bytes per block)
+      H.nb = std::min<u32>(cols_block_lists(), mode == KMX_MODE_COUNT ? ((((H.N + H.nblk - 1) / H.nblk) + 1) & ~1u) : ((((H.N + H.nblk - 1) / H.nblk) + 7) & ~7u));
       H.nblk = (H.N + H.nb - 1) / H.nb;
       H.rt_cols = cols_tile_rows(H.nb);
     }

@@ -1,4 +1,4 @@
-// merge_cols.hip -- column-blocked streaming merge for large cohorts of related samples (COUNT rows) on gfx950.
+// merge_cols.hip -- column-blocked streaming merge for large cohorts of related samples (COUNT and PA rows) on gfx950.
 // Same results as k_merge_rows / k_merge_pivot (reference include/kmtricks/merge.hpp:183-286, 441-558).
 //
 // k_merge_pivot gives every list a 16-record register window and a workgroup all N lists, so a list hands
@@ -21,7 +21,7 @@
 //     lists each of those keys is solid: if one reaches the recurrence the rows were incomplete and the task is
 //     handed back (ERR_FALLBACK: the driver re-runs it with k_merge_pivot / k_merge_rows).  So are tasks whose
 //     slices overflow.  Results never depend on how well the row keys cover the lists.
-// Applicable to COUNT rows, 64-bit keys, no share-min; chosen for > 512 lists and 2 <= recurrence-min <= 21
+// Applicable to COUNT and PA rows, 64-bit keys, no share-min; chosen for > 512 lists and 2 <= recurrence-min <= 21
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
 #include "kmx_dev.hpp"
 #include <algorithm>
@@ -251,6 +251,7 @@ __device__ u64 kmx_cols_prof[8];
 #endif
 
 // ---- the merge: work item = (task, key range, column block) ----------------------------------------------
+template <int MODE>      // 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
 __global__ __launch_bounds__(CL_TPB, 1)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
                   u32 n_items, u32* ticket)
@@ -292,6 +293,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const u32 N = cl_uni(T.N), row_bytes = cl_uni(T.row_bytes), nblk = cl_uni(C.nblk), nbs = cl_uni(C.nb), rt = cl_uni(C.rt);
     const u32 range = cl_uni(items[item].y) / nblk, blk = cl_uni(items[item].y) - range * nblk;
     const u32 col0 = blk * nbs, nbl = min(nbs, N - col0);
+    const u32 iw = MODE == 0 ? nbs : (nbs + 31) / 32;      // image words per row
     const u32 s_lo = cl_uni(C.rbounds[range]), s_hi = cl_uni(C.rbounds[range + 1]);
     const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
     const u32 slot0 = s_lo / rt + range;
@@ -397,7 +399,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             const bool hit = pe[j].x == (u32)k && pe[j].y == (u32)(k >> 32) && pe[j].z != 0;
             tsum += solid ? c : 0u;
             tn += (cons && !solid) ? 1u : 0u;
-            img[(solid && hit) ? __umul24(pe[j].z - 1, nbs) + lg : dummy] = c;
+            if (MODE == 0) img[(solid && hit) ? __umul24(pe[j].z - 1, iw) + lg : dummy] = c;
+            else if (solid && hit) atomicOr(&img[__umul24(pe[j].z - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
             ovm |= ((solid && !hit) ? 1u : 0u) << j;
           }
           asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
@@ -475,23 +478,35 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           if (lane == 0) { sh[4 + ((q + 1) % CL_NT)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
-        u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + 4ull * col0;
-        const bool wide = ((row_bytes | (4u * col0) | (4u * nbs)) & 7u) == 0;
-        for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
-          u32* const src = img + j * nbs;
-          u8* const dst = out0 + (u64)j * row_bytes;
-          if (wide) {
-            const u32 n2 = nbl >> 1;
-            for (u32 t0 = 0; t0 < n2; t0 += 256) {
-              u64 w[4];
+        if (MODE == 0) {
+          u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + 4ull * col0;
+          const bool wide = ((row_bytes | (4u * col0) | (4u * nbs)) & 7u) == 0;
+          for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
+            u32* const src = img + j * nbs;
+            u8* const dst = out0 + (u64)j * row_bytes;
+            if (wide) {
+              const u32 n2 = nbl >> 1;
+              for (u32 t0 = 0; t0 < n2; t0 += 256) {
+                u64 w[4];
 #pragma unroll
-              for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; w[x] = 0; if (t < n2) { w[x] = reinterpret_cast<u64*>(src)[t]; reinterpret_cast<u64*>(src)[t] = 0; } }
+                for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; w[x] = 0; if (t < n2) { w[x] = reinterpret_cast<u64*>(src)[t]; reinterpret_cast<u64*>(src)[t] = 0; } }
 #pragma unroll
-              for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; if (t < n2) reinterpret_cast<u64*>(dst)[t] = w[x]; }
+                for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; if (t < n2) reinterpret_cast<u64*>(dst)[t] = w[x]; }
+              }
+              if ((nbl & 1u) && lane == 0) { reinterpret_cast<u32*>(dst)[nbl - 1] = src[nbl - 1]; src[nbl - 1] = 0; }
+            } else {
+              for (u32 t = lane; t < nbl; t += 64) { const u32 w = src[t]; src[t] = 0; reinterpret_cast<u32*>(dst)[t] = w; }
             }
-            if ((nbl & 1u) && lane == 0) { reinterpret_cast<u32*>(dst)[nbl - 1] = src[nbl - 1]; src[nbl - 1] = 0; }
-          } else {
-            for (u32 t = lane; t < nbl; t += 64) { const u32 w = src[t]; src[t] = 0; reinterpret_cast<u32*>(dst)[t] = w; }
+          }
+        } else {
+          // a row's slice is (lists of the block) / 8 bytes (the block starts at a multiple of 8 lists): a byte per lane
+          u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + (col0 >> 3);
+          const u32 nby = (nbl + 7) >> 3;
+          for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
+            u32* const src = img + j * iw;
+            u8* const dst = out0 + (u64)j * row_bytes;
+            for (u32 t = lane; t < nby; t += 64) dst[t] = (u8)(src[t >> 2] >> ((t & 3u) * 8));
+            for (u32 t = lane; t < iw; t += 64) src[t] = 0;      // (same wave, behind the reads)
           }
         }
       }
@@ -627,7 +642,7 @@ void cols_phase_prof_dump()
 int cols_lds_bytes() { return CL_IMG + CL_NT * CL_PT * (int)sizeof(ClEnt) + 64 + 256; }
 u32 cols_halves() { return CL_HALVES; }
 u32 cols_block_lists() { return CL_NB; }
-u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }
+u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }      // (sized for count rows; PA rows need less)
 u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW; }
 u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW; }
 
@@ -642,12 +657,18 @@ hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const Col
   hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(CP_TPB), 0, st, tasks, subs, cols);
   return hipGetLastError();
 }
-hipError_t launch_merge_cols(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
+hipError_t launch_merge_cols(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
   const int lds = cols_lds_bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_merge_cols, dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
+  if (mode == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_merge_cols<0>, dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
+  } else {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_merge_cols<1>, dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
+  }
   return hipGetLastError();
 }
 hipError_t launch_cols_check(const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)

@@ -408,3 +408,30 @@ def test_default_kernel_for_larger_recurrence_min(monkeypatch, rec_min):
     eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, rec_min, 0, orc.MODE_COUNT)
     assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
     res.free(); ctx.close()
+
+
+@pytest.mark.parametrize("n", [600, 1001])
+def test_default_kernel_for_presence_absence_rows(monkeypatch, n):
+    """KMX_MERGE_KERNEL unset: PA rows of a cohort of more than 512 lists go to k_merge_cols too (a bit per list in the
+    block's image, a byte per 8 lists out); list counts that are not a multiple of 8, an empty list, soft-min 2."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    ctx = lib.Context(0)
+    lists = synth_lists(9500 + n, n, 5000, 0.97, 130, kw=1, count_max=6)
+    lists[17] = (lists[17][0][:0], lists[17][1][:0])
+    soft = [1 + (i % 2) for i in range(n)]
+    dev = torch.device("cuda", 0)
+    recs = [lib.pack_records(k, c, 1) for k, c in lists]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(n)], key_words=1,
+                soft_min=soft, rec_min=3, share_min=0, mode=lib.MODE_PA)
+    res = ctx.merge_dev([task]); res.wait()
+    assert res.kernel() == "k_merge_cols"
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, soft, 3, 0, orc.MODE_PA)
+    assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
+    res.free(); ctx.close()
