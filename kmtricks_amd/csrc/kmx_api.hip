@@ -315,8 +315,8 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   // lists) is faster when MANY lists share most of their keys -- the cohort case the metric is quoted on --
   // and k_merge_cols (merge_cols.hip; a small recurrence-min) faster still there.  Both flag tasks
   // they do not suit, and those are re-run with the next kernel down (cols -> pivot -> rows, see
-  // kmx_result_wait).  Default: more than 512 lists per task (where k_merge_rows is down to 4-record windows)
-  // go to cols when 2 <= recurrence-min <= 21, to pivot otherwise.
+  // kmx_result_wait; below 513 lists cols -> rows).  Default: from 128 lists per task and 2 <= recurrence-min <= 21
+  // cols; otherwise pivot above 512 lists (where k_merge_rows is down to 4-record windows), else rows.
   // KMX_MERGE_KERNEL=rows|pivot|cols forces one of them (where it is applicable).
   {
     bool rescue = false; u32 min_n = 0xFFFFFFFFu, mx_n = 0, min_rec = 0xFFFFFFFFu, max_rec = 0;
@@ -327,12 +327,14 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     const char* force = getenv("KMX_MERGE_KERNEL");
     const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
     const bool can_cols = !is_bf && !rescue && kw == 1 && mx_n <= (u32)rows_cap() && min_rec >= 1;
-    R->can_pivot = can;
+    R->can_pivot = can && min_n > 512;      // (as the next kernel down from cols: below 512 lists k_merge_rows is the faster of the two)
     if (force && !strcmp(force, "cols")) { R->use_cols = can_cols; R->use_pivot = !can_cols && can; }
     else if (force && !strcmp(force, "pivot")) R->use_pivot = can;
     else if (force && !strcmp(force, "rows")) R->use_pivot = false;
     else {
-      R->use_cols = can_cols && min_n > 512 && min_rec >= 2 && cols_row_lists(max_rec) != 0;      // (recurrence-min <= 21)
+      // (cols: from 128 lists -- below, k_merge_rows' wide windows win -- and 1 M records per batch -- below, its seven
+      //  launches cost more than they save; recurrence-min 2..21)
+      R->use_cols = can_cols && min_n >= 128 && grand_total >= (1ull << 20) && min_rec >= 2 && cols_row_lists(max_rec) != 0;
       if (R->use_cols && ctx->cols_skip) { ctx->cols_skip--; R->use_cols = false; }
       R->cols_auto = R->use_cols;
       R->use_pivot = !R->use_cols && can && min_n > 512;

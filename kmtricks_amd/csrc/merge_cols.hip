@@ -571,48 +571,74 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   if (tid == 0) { flag = 0; total = 0; special = 0; }
   __syncthreads();
   (void)lane; (void)wave;
+  const bool single = nsl <= (u32)CK_TPB / 4;      // every slice of a group has its four threads at once
   for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) {
-    // four threads per (block, wave) slice of the tile: every slice's count, then every slice's keys, are in flight
-    // at once (a wave walking its slices one after the other pays two dependent memory round trips per slice)
+    // four threads per (block, wave) slice of the group: every slice's count and first 32 keys (8 per thread; the
+    // slice's memory is there whatever the count) are requested together -- one memory round trip per group (a wave
+    // walking its slices one after the other pays two dependent round trips per slice).
+    // A group with more keys than the table takes (cohorts with many sample-private k-mers) is counted in 2 or 4
+    // passes, a pass taking the keys whose hash has its bits: equal keys meet in the same pass.
     const u64 sbase = (u64)(slot0 + q) * nsl;
+    u32 n0 = 0; u64 kk0[8];
+    const u64* kp0 = C.ovkeys;
     for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
       const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
       const bool ok = sl < nsl;
-      const u64* kp = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW;
-      // the slice's count and its first 32 keys (8 per thread; the slice's memory is there whatever the count) leave
-      // together: one memory round trip per tile, not two
       const u32 nraw = ok ? C.ovcnt[sbase + sl] : 0u;
-      u64 kk[8];
+      if (single) {
+        kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW;
 #pragma unroll
-      for (int x = 0; x < 8; x++) kk[x] = kp[sub + 4 * x];
+        for (int x = 0; x < 8; x++) kk0[x] = kp0[sub + 4 * x];
+        n0 = min(nraw, (u32)CL_OVW);
+      }
       if (sub == 0 && nraw) atomicAdd(&total, nraw);
-      const u32 n = min(nraw, (u32)CL_OVW);
+    }
+    __syncthreads();
+    const u32 tot = total;
+    __syncthreads();
+    if (tot == 0) continue;
+    if (tid == 0) total = 0;      // (barriers follow before the next group adds to it)
+    if (tot > (u32)CK_TS * 3) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }     // (a slice over its capacity lands here too)
+    const u32 npass = tot <= (u32)CK_TS * 3 / 4 ? 1u : tot <= (u32)CK_TS * 3 / 2 ? 2u : 4u;
+    for (u32 pass = 0; pass < npass; pass++) {
       auto put = [&](u64 k) {
         u32 c;
-        if (k == ~0ULL) c = atomicAdd(&special, 1u) + 1;
+        if (k == ~0ULL) { if (pass != 0) return; c = atomicAdd(&special, 1u) + 1; }
         else {
-          u32 h = cl_mix(k) & (CK_TS - 1), probes = 0;
+          const u32 hx = cl_mix(k);
+          if (((hx >> 20) & (npass - 1)) != pass) return;
+          u32 h = hx & (CK_TS - 1), probes = 0;
           for (;;) {
             const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)k);
             if (old == ~0ULL || old == k) break;
             h = (h + 1) & (CK_TS - 1);
-            if (++probes >= (u32)CK_TS) { flag = 1; break; }     // (table full: more records set aside than it holds)
+            if (++probes >= (u32)CK_TS) { flag = 1; return; }     // (table full: an uneven split; the general kernels take the task)
           }
           c = atomicAdd(&cnt[h], 1u) + 1;
         }
         if (c >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
       };
+      if (single) {
+        const u32 sub = tid & 3u;
 #pragma unroll
-      for (int x = 0; x < 8; x++) if (sub + 4 * x < n) put(kk[x]);
-      for (u32 e = sub + 32; e < n; e += 4) put(kp[e]);
+        for (int x = 0; x < 8; x++) if (sub + 4 * x < n0) put(kk0[x]);
+        for (u32 e = sub + 32; e < n0; e += 4) put(kp0[e]);
+      } else {
+        for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
+          const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
+          if (sl >= nsl) continue;
+          const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
+          const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
+          for (u32 e = sub; e < n; e += 4) put(kp[e]);
+        }
+      }
+      __syncthreads();
+      if (flag) break;
+      wipe();
+      if (tid == 0) special = 0;
+      __syncthreads();
     }
-    __syncthreads();
-    const u32 tot = total;
-    if (flag || tot > (u32)CK_TS * 3 / 4) { if (tid == 0) flag = 1; break; }     // (a slice over its capacity lands here too)
-    __syncthreads();
-    if (tot) wipe();
-    if (tid == 0) { special = 0; total = 0; }
-    __syncthreads();
+    if (flag) break;
   }
   __syncthreads();
   if (tid == 0 && flag) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);

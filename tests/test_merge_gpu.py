@@ -189,15 +189,15 @@ def test_bench_scale_partitions_properties(ctx):
 
 @pytest.mark.parametrize("similar", [True, False])
 def test_kernel_selection_and_handback(ctx, monkeypatch, similar):
-    """Default kernel choice (KMX_MERGE_KERNEL unset): a COUNT task of more than 512 lists with recurrence-min 2 goes
-    to k_merge_cols; when the lists do not resemble each other it flags the task and libkmx re-runs it with
-    k_merge_pivot, which hands it on to k_merge_rows.  Either way the body and the statistics equal the oracle's."""
+    """Default kernel choice (KMX_MERGE_KERNEL unset): a batch of 600-list tasks with recurrence-min 2 goes to
+    k_merge_cols; lists that do not resemble each other are flagged and
+    re-run with k_merge_rows.  Either way the body and the statistics equal the oracle's."""
     torch = pytest.importorskip("torch")
     from kmtricks_amd import lib
     monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
     ctx = lib.Context(0)          # own context: a hand-back makes a context skip the pivot kernel for its next batches
     N = 600
-    lists = synth_lists(4242, N, 6000, 0.97, 180, kw=1) if similar else synth_lists(4243, N, 6000, 0.25, 1500, kw=1)
+    lists = synth_lists(4242, N, 8000, 0.97, 240, kw=1) if similar else synth_lists(4243, N, 6000, 0.25, 1500, kw=1)
     dev = torch.device("cuda", 0)
     recs = [lib.pack_records(k, c, 1) for k, c in lists]
     offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
@@ -433,5 +433,31 @@ def test_default_kernel_for_presence_absence_rows(monkeypatch, n):
     res = ctx.merge_dev([task]); res.wait()
     assert res.kernel() == "k_merge_cols"
     eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, soft, 3, 0, orc.MODE_PA)
+    assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
+    res.free(); ctx.close()
+
+
+@pytest.mark.parametrize("similar", [True, False])
+def test_default_kernel_from_128_lists(monkeypatch, similar):
+    """KMX_MERGE_KERNEL unset, 200 lists x 25k records: a cohort goes to k_merge_cols;
+    unrelated lists are handed straight down to k_merge_rows (k_merge_pivot is not in the chain below 513 lists)."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    ctx = lib.Context(0)
+    N = 200
+    lists = synth_lists(9700, N, 25000, 0.97, 700, kw=1) if similar else synth_lists(9701, N, 60000, 0.3, 7000, kw=1)
+    dev = torch.device("cuda", 0)
+    recs = [lib.pack_records(k, c, 1) for k, c in lists]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT)
+    res = ctx.merge_dev([task]); res.wait()
+    assert res.kernel() == ("k_merge_cols" if similar else "k_merge_rows")
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT)
     assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
     res.free(); ctx.close()
