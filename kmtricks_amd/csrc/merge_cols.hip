@@ -242,7 +242,7 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
 
 __device__ const u32 kmx_cols_sentinel[4] = {~0u, ~0u, 0u, 0u};      // the record "past the end of a list": largest key, count 0
 
-__device__ u32 kmx_cols_dbg[8];
+__device__ u32 kmx_cols_dbg[8];      // why tasks were handed back (KMX_TRACE=1 prints and clears them)
 #ifdef KMX_PHASE_PROF
 __device__ u64 kmx_cols_prof[8];
 #ifndef KMX_PROF_TID
@@ -457,7 +457,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       if (lane == 0) {
         C.ovcnt[(((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave] = wov;
         if (CL_HALVES > 1) C.ovcnt[(((u64)(slot0 + q) * CL_HALVES + 1) * nblk + blk) * CL_NW + wave] = wov1;
-        if (max(wov, wov1) > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); atomicAdd(&kmx_cols_dbg[q == 0 ? 4 : (q & 1u) ? 5 : 6], 1u); if (rte < rt) atomicAdd(&kmx_cols_dbg[7], 1u); }
+        if (max(wov, wov1) > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); }
       }
 
       // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
@@ -648,7 +648,7 @@ void cols_dbg_dump()
 {
   u32 h[8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_cols_dbg), sizeof(h)) != hipSuccess) return;
-  fprintf(stderr, "[cols dbg] build-fail %u  slice-overflow %u  kept-outside %u  check-full %u | q0 %u qodd %u qeven %u short-tile %u\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  fprintf(stderr, "[kmx merge] k_merge_cols hand-back reasons: no collision-free row table %u, slice overflow %u (wave-tiles), kept key outside the row keys %u, check table full %u\n", h[0], h[1], h[2], h[3]);
   memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_dbg), h, sizeof(h));
 }
 #ifdef KMX_PHASE_PROF
