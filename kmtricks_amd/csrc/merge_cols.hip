@@ -48,7 +48,7 @@ constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 5
 constexpr int CL_SEEDS = 64;             // hash multipliers tried per tile for a collision-free table
 constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
 constexpr int CL_NW = CL_TPB / 64;
-constexpr int CK_TS = 4096;              // k_cols_check: hash set entries (48 KB of LDS with the counts)
+constexpr int CK_TS = 8192;              // k_cols_check: hash set entries (32-bit: a tag of the key, or tag + count; 32 KB of LDS)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
 
 namespace {
@@ -549,9 +549,10 @@ constexpr int CK_Z = KMX_CK_Z;           // ... and workgroups sharing the tiles
 __global__ __launch_bounds__(CK_TPB)
 void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
-  __shared__ u64 keys[CK_TS];
-  __shared__ u32 cnt[CK_TS];
-  __shared__ u32 flag, total, special;
+  __shared__ u32 tab[CK_TS];
+  __shared__ u64 susp[8];          // keys whose tag reached the recurrence-min: checked exactly before the task is flagged
+  __shared__ u32 scount[8];
+  __shared__ u32 flag, total, special, nsusp;
   const u32 item = blockIdx.x;
   if (item >= n_items) return;
   const TaskDev& T = tasks[items[item].x];
@@ -564,11 +565,11 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   const u32 ngroups = ntiles * CL_HALVES;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto wipe = [&]() {
-    for (u32 t = tid; t < (u32)CK_TS / 2; t += CK_TPB) reinterpret_cast<uint4*>(keys)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    for (u32 t = tid; t < (u32)CK_TS / 4; t += CK_TPB) reinterpret_cast<uint4*>(cnt)[t] = make_uint4(0, 0, 0, 0);
+    for (u32 t = tid; t < (u32)CK_TS / 4; t += CK_TPB) reinterpret_cast<uint4*>(tab)[t] = make_uint4(0, 0, 0, 0);
   };
   wipe();
-  if (tid == 0) { flag = 0; total = 0; special = 0; }
+  if (tid == 0) { flag = 0; total = 0; special = 0; nsusp = 0; }
+  if (tid < 8) scount[tid] = 0;
   __syncthreads();
   (void)lane; (void)wave;
   const bool single = nsl <= (u32)CK_TPB / 4;      // every slice of a group has its four threads at once
@@ -605,18 +606,40 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         u32 c;
         if (k == ~0ULL) { if (pass != 0) return; c = atomicAdd(&special, 1u) + 1; }
         else {
+          // The set holds 32-bit TAGS of the keys, not the keys (64-bit entries at twice the load made the probe chains --
+          // dependent LDS atomics, the wave waiting for its slowest lane -- this kernel's time).  Equal keys have equal
+          // tags and probe sequences, so a key that is there twice is always seen; two different keys with one tag in
+          // one chain are told apart before anything is flagged (the suspects of a pass are counted exactly below).
+          // recurrence-min 2: the tag alone (nonzero); above: tag in the upper 27 bits, count in the lower 5.
           const u32 hx = cl_mix(k);
           if (((hx >> 20) & (npass - 1)) != pass) return;
+          const u32 t2 = (u32)(k >> 32) * 0x85EBCA77u ^ (u32)k * 0xC2B2AE3Du ^ (hx >> 7);
           u32 h = hx & (CK_TS - 1), probes = 0;
-          for (;;) {
-            const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[h]), ~0ULL, (unsigned long long)k);
-            if (old == ~0ULL || old == k) break;
-            h = (h + 1) & (CK_TS - 1);
-            if (++probes >= (u32)CK_TS) { flag = 1; return; }     // (table full: an uneven split; the general kernels take the task)
+          if (rec_min <= 2) {
+            const u32 tag = t2 | 1u;
+            c = 1;
+            for (;;) {
+              const u32 old = atomicCAS(&tab[h], 0u, tag);
+              if (old == 0) break;
+              if (old == tag) { c = 2; break; }
+              h = (h + 1) & (CK_TS - 1);
+              if (++probes >= (u32)CK_TS) { flag = 1; return; }     // (table full: an uneven split; the general kernels take the task)
+            }
+          } else {
+            const u32 tag = (t2 | 1u) << 5;
+            for (;;) {
+              const u32 old = atomicCAS(&tab[h], 0u, tag | 1u);
+              if (old == 0) { c = 1; break; }
+              if ((old & ~31u) == tag) { c = (atomicAdd(&tab[h], 1u) & 31u) + 1; break; }      // (recurrence-min <= 21: no carry into the tag)
+              h = (h + 1) & (CK_TS - 1);
+              if (++probes >= (u32)CK_TS) { flag = 1; return; }
+            }
           }
-          c = atomicAdd(&cnt[h], 1u) + 1;
         }
-        if (c >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
+        if (c >= rec_min) {
+          if (k == ~0ULL) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
+          else { const u32 ps = atomicAdd(&nsusp, 1u); if (ps < 8) susp[ps] = k; else flag = 1; }
+        }
       };
       if (single) {
         const u32 sub = tid & 3u;
@@ -634,6 +657,30 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       }
       __syncthreads();
       if (flag) break;
+      const u32 ns = min(nsusp, 8u);
+      if (ns) {   // exact count of the suspect keys over the group's keys (rare: a real hit hands the task back anyway)
+        auto vote = [&](u64 k) { for (u32 j = 0; j < ns; j++) if (k == susp[j]) atomicAdd(&scount[j], 1u); };
+        if (single) {
+          const u32 sub = tid & 3u;
+#pragma unroll
+          for (int x = 0; x < 8; x++) if (sub + 4 * x < n0) vote(kk0[x]);
+          for (u32 e = sub + 32; e < n0; e += 4) vote(kp0[e]);
+        } else {
+          for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
+            const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
+            if (sl >= nsl) continue;
+            const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
+            const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
+            for (u32 e = sub; e < n; e += 4) vote(kp[e]);
+          }
+        }
+        __syncthreads();
+        if (tid < ns && scount[tid] >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
+        __syncthreads();
+        if (tid < 8) scount[tid] = 0;
+        if (tid == 0) nsusp = 0;
+        if (flag) break;
+      }
       wipe();
       if (tid == 0) special = 0;
       __syncthreads();
