@@ -326,7 +326,19 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     }
     const char* force = getenv("KMX_MERGE_KERNEL");
     const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
-    const bool can_cols = !is_bf && !rescue && kw == 1 && mx_n <= (u32)rows_cap() && min_rec >= 1;
+    bool can_cols = !is_bf && !rescue && kw == 1 && mx_n <= (u32)rows_cap() && min_rec >= 1;
+    if (can_cols) {
+      // k_merge_cols keeps worst-case room for the records it sets aside (a slice per half tile, block and wave: ~2.3 KB per
+      // row at 1000 lists): not for batches where that would take more than KMX_COLS_SCRATCH_GB (default 32) of HBM
+      u64 scratch = 0;
+      for (auto& H : R->tasks) {
+        const u32 nblk = (H.N + cols_block_lists() - 1) / cols_block_lists();
+        const u32 sl = (u32)std::min<u64>(0x7FFFFFF0ULL, H.rows_guess / cols_tile_rows(cols_block_lists()) + 64);
+        scratch += cols_scratch_keys(sl, nblk) * 8 + cols_scratch_counts(sl, nblk) * 4;
+      }
+      const char* gb = getenv("KMX_COLS_SCRATCH_GB");
+      can_cols = scratch <= (u64)(gb && atoi(gb) > 0 ? atoi(gb) : 32) << 30;
+    }
     R->can_pivot = can && min_n > 512;      // (as the next kernel down from cols: below 512 lists k_merge_rows is the faster of the two)
     if (force && !strcmp(force, "cols")) { R->use_cols = can_cols; R->use_pivot = !can_cols && can; }
     else if (force && !strcmp(force, "pivot")) R->use_pivot = can;
