@@ -48,7 +48,9 @@ constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 5
 constexpr int CL_SEEDS = 64;             // hash multipliers tried per tile for a collision-free table
 constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
 constexpr int CL_NW = CL_TPB / 64;
-constexpr int CK_TS = 8192;              // k_cols_check: hash set entries (32-bit: a tag of the key, or tag + count; 32 KB of LDS)
+constexpr int CK_BITS = 1 << 18;         // k_cols_check: bits of the key map (32 KB of LDS)
+constexpr int CK_NSUSP = 32;             // ... suspects per pass (keys that found their bit set)
+constexpr int CK_PASS = 2048;            // ... keys per pass (~8 suspects expected at that many)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
 
 namespace {
@@ -549,9 +551,14 @@ constexpr int CK_Z = KMX_CK_Z;           // ... and workgroups sharing the tiles
 __global__ __launch_bounds__(CK_TPB)
 void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
-  __shared__ u32 tab[CK_TS];
-  __shared__ u64 susp[8];          // keys whose tag reached the recurrence-min: checked exactly before the task is flagged
-  __shared__ u32 scount[8];
+  // Per slice group: (1) every key sets its bit of a 256 Kbit LDS map (one ds_or, no probing -- a hash set's probe chains,
+  // dependent LDS atomics with the wave waiting for its slowest lane, were this kernel's time); a key that finds its
+  // bit set is a SUSPECT (a handful per group: the second of two equal keys always, two different keys with one bit
+  // now and then); (2) the suspects are counted exactly over the group's keys.  A suspect in recurrence-min or more
+  // lists means the rows were incomplete.
+  __shared__ u32 bits[CK_BITS / 32];
+  __shared__ u64 susp[CK_NSUSP];
+  __shared__ u32 scount[CK_NSUSP];
   __shared__ u32 flag, total, special, nsusp;
   const u32 item = blockIdx.x;
   if (item >= n_items) return;
@@ -563,22 +570,22 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
   const u32 slot0 = (s_lo / rt + range) * CL_HALVES;
   const u32 ngroups = ntiles * CL_HALVES;
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 tid = threadIdx.x;
   auto wipe = [&]() {
-    for (u32 t = tid; t < (u32)CK_TS / 4; t += CK_TPB) reinterpret_cast<uint4*>(tab)[t] = make_uint4(0, 0, 0, 0);
+    for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
+    if (tid < (u32)CK_NSUSP) scount[tid] = 0;
+    if (tid == 0) { special = 0; nsusp = 0; }
   };
   wipe();
-  if (tid == 0) { flag = 0; total = 0; special = 0; nsusp = 0; }
-  if (tid < 8) scount[tid] = 0;
+  if (tid == 0) { flag = 0; total = 0; }
   __syncthreads();
-  (void)lane; (void)wave;
   const bool single = nsl <= (u32)CK_TPB / 4;      // every slice of a group has its four threads at once
   for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) {
     // four threads per (block, wave) slice of the group: every slice's count and first 32 keys (8 per thread; the
     // slice's memory is there whatever the count) are requested together -- one memory round trip per group (a wave
     // walking its slices one after the other pays two dependent round trips per slice).
-    // A group with more keys than the table takes (cohorts with many sample-private k-mers) is counted in 2 or 4
-    // passes, a pass taking the keys whose hash has its bits: equal keys meet in the same pass.
+    // A group with many keys (cohorts with many sample-private k-mers) is counted in 2, 4 or 8 passes, a pass taking the
+    // keys whose hash has its bits (equal keys meet in the same pass): the suspects of a pass stay a handful.
     const u64 sbase = (u64)(slot0 + q) * nsl;
     u32 n0 = 0; u64 kk0[8];
     const u64* kp0 = C.ovkeys;
@@ -599,90 +606,46 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     __syncthreads();
     if (tot == 0) continue;
     if (tid == 0) total = 0;      // (barriers follow before the next group adds to it)
-    if (tot > (u32)CK_TS * 3) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }     // (a slice over its capacity lands here too)
-    const u32 npass = tot <= (u32)CK_TS * 3 / 4 ? 1u : tot <= (u32)CK_TS * 3 / 2 ? 2u : 4u;
+    if (tot > (u32)CK_PASS * 8) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }     // (a slice over its capacity lands here too)
+    const u32 npass = tot <= (u32)CK_PASS ? 1u : tot <= (u32)CK_PASS * 2 ? 2u : tot <= (u32)CK_PASS * 4 ? 4u : 8u;
     for (u32 pass = 0; pass < npass; pass++) {
-      auto put = [&](u64 k) {
-        u32 c;
-        if (k == ~0ULL) { if (pass != 0) return; c = atomicAdd(&special, 1u) + 1; }
-        else {
-          // The set holds 32-bit TAGS of the keys, not the keys (64-bit entries at twice the load made the probe chains --
-          // dependent LDS atomics, the wave waiting for its slowest lane -- this kernel's time).  Equal keys have equal
-          // tags and probe sequences, so a key that is there twice is always seen; two different keys with one tag in
-          // one chain are told apart before anything is flagged (the suspects of a pass are counted exactly below).
-          // recurrence-min 2: the tag alone (nonzero); above: tag in the upper 27 bits, count in the lower 5.
-          const u32 hx = cl_mix(k);
-          if (((hx >> 20) & (npass - 1)) != pass) return;
-          const u32 t2 = (u32)(k >> 32) * 0x85EBCA77u ^ (u32)k * 0xC2B2AE3Du ^ (hx >> 7);
-          u32 h = hx & (CK_TS - 1), probes = 0;
-          if (rec_min <= 2) {
-            const u32 tag = t2 | 1u;
-            c = 1;
-            for (;;) {
-              const u32 old = atomicCAS(&tab[h], 0u, tag);
-              if (old == 0) break;
-              if (old == tag) { c = 2; break; }
-              h = (h + 1) & (CK_TS - 1);
-              if (++probes >= (u32)CK_TS) { flag = 1; return; }     // (table full: an uneven split; the general kernels take the task)
-            }
-          } else {
-            const u32 tag = (t2 | 1u) << 5;
-            for (;;) {
-              const u32 old = atomicCAS(&tab[h], 0u, tag | 1u);
-              if (old == 0) { c = 1; break; }
-              if ((old & ~31u) == tag) { c = (atomicAdd(&tab[h], 1u) & 31u) + 1; break; }      // (recurrence-min <= 21: no carry into the tag)
-              h = (h + 1) & (CK_TS - 1);
-              if (++probes >= (u32)CK_TS) { flag = 1; return; }
-            }
-          }
-        }
-        if (c >= rec_min) {
-          if (k == ~0ULL) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
-          else { const u32 ps = atomicAdd(&nsusp, 1u); if (ps < 8) susp[ps] = k; else flag = 1; }
-        }
-      };
-      if (single) {
-        const u32 sub = tid & 3u;
-#pragma unroll
-        for (int x = 0; x < 8; x++) if (sub + 4 * x < n0) put(kk0[x]);
-        for (u32 e = sub + 32; e < n0; e += 4) put(kp0[e]);
-      } else {
-        for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
-          const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
-          if (sl >= nsl) continue;
-          const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
-          const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
-          for (u32 e = sub; e < n; e += 4) put(kp[e]);
-        }
-      }
-      __syncthreads();
-      if (flag) break;
-      const u32 ns = min(nsusp, 8u);
-      if (ns) {   // exact count of the suspect keys over the group's keys (rare: a real hit hands the task back anyway)
-        auto vote = [&](u64 k) { for (u32 j = 0; j < ns; j++) if (k == susp[j]) atomicAdd(&scount[j], 1u); };
+      // each of my keys through f(key)
+      auto each = [&](auto&& f) {
         if (single) {
           const u32 sub = tid & 3u;
 #pragma unroll
-          for (int x = 0; x < 8; x++) if (sub + 4 * x < n0) vote(kk0[x]);
-          for (u32 e = sub + 32; e < n0; e += 4) vote(kp0[e]);
+          for (int x = 0; x < 8; x++) if (sub + 4 * x < n0) f(kk0[x]);
+          for (u32 e = sub + 32; e < n0; e += 4) f(kp0[e]);
         } else {
           for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
             const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
             if (sl >= nsl) continue;
             const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
             const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
-            for (u32 e = sub; e < n; e += 4) vote(kp[e]);
+            for (u32 e = sub; e < n; e += 4) f(kp[e]);
           }
         }
+      };
+      each([&](u64 k) {
+        if (k == ~0ULL) { if (pass == 0 && atomicAdd(&special, 1u) + 1 >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); } return; }
+        const u32 hx = cl_mix(k);
+        if (((hx >> 24) & (npass - 1)) != pass) return;
+        const u32 bit = hx & (CK_BITS - 1);
+        const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
+        if ((old >> (bit & 31u)) & 1u) { const u32 ps = atomicAdd(&nsusp, 1u); if (ps < (u32)CK_NSUSP) susp[ps] = k; else flag = 1; }
+      });
+      __syncthreads();
+      if (flag) break;
+      const u32 ns = min(nsusp, (u32)CK_NSUSP);
+      if (ns) {
+        each([&](u64 k) { for (u32 j = 0; j < ns; j++) if (k == susp[j]) atomicAdd(&scount[j], 1u); });
         __syncthreads();
+        // (a key that is a suspect twice is counted twice in both entries: each holds the key's true count)
         if (tid < ns && scount[tid] >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
         __syncthreads();
-        if (tid < 8) scount[tid] = 0;
-        if (tid == 0) nsusp = 0;
         if (flag) break;
       }
       wipe();
-      if (tid == 0) special = 0;
       __syncthreads();
     }
     if (flag) break;
