@@ -559,6 +559,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   __shared__ u32 bits[CK_BITS / 32];
   __shared__ u64 susp[CK_NSUSP];
   __shared__ u32 scount[CK_NSUSP];
+  __shared__ u32 sbm[128];         // 4096 bits: where the suspects are (the exact count looks at a key only if its bit is set here)
   __shared__ u32 flag, total, special, nsusp;
   const u32 item = blockIdx.x;
   if (item >= n_items) return;
@@ -574,6 +575,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   auto wipe = [&]() {
     for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
     if (tid < (u32)CK_NSUSP) scount[tid] = 0;
+    if (tid < 128) sbm[tid] = 0;
     if (tid == 0) { special = 0; nsusp = 0; }
   };
   wipe();
@@ -632,13 +634,22 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         if (((hx >> 24) & (npass - 1)) != pass) return;
         const u32 bit = hx & (CK_BITS - 1);
         const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
-        if ((old >> (bit & 31u)) & 1u) { const u32 ps = atomicAdd(&nsusp, 1u); if (ps < (u32)CK_NSUSP) susp[ps] = k; else flag = 1; }
+        if ((old >> (bit & 31u)) & 1u) {
+          const u32 ps = atomicAdd(&nsusp, 1u);
+          if (ps < (u32)CK_NSUSP) susp[ps] = k; else flag = 1;
+          const u32 b2 = (hx >> 6) & 4095u;
+          atomicOr(&sbm[b2 >> 5], 1u << (b2 & 31u));
+        }
       });
       __syncthreads();
       if (flag) break;
       const u32 ns = min(nsusp, (u32)CK_NSUSP);
       if (ns) {
-        each([&](u64 k) { for (u32 j = 0; j < ns; j++) if (k == susp[j]) atomicAdd(&scount[j], 1u); });
+        each([&](u64 k) {
+          const u32 b2 = (cl_mix(k) >> 6) & 4095u;
+          if (!((sbm[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
+          for (u32 j = 0; j < ns; j++) if (k == susp[j]) atomicAdd(&scount[j], 1u);
+        });
         __syncthreads();
         // (a key that is a suspect twice is counted twice in both entries: each holds the key's true count)
         if (tid < ns && scount[tid] >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
