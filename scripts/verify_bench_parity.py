@@ -11,7 +11,7 @@ import bench
 from kmtricks_amd import lib
 import orc
 
-N, P, G, d, K = 1000, 32, 5e6, 0.001, 31
+N, P, G, d, K = 1000, 32, 5e6, float(os.environ.get("KMX_VERIFY_D", "0.001")), 31
 dev = torch.device("cuda", 0)
 shared = int(G / 256); pp = (1.0 - d) ** K; npriv = int(round(shared * (1.0 - pp)))
 parts = [bench.gen_partition(torch, dev, 20240601 + g, N, shared, pp, npriv) for g in range(P)]
@@ -40,9 +40,10 @@ for kern in ("rows", "pivot", "cols"):
             assert er == res.rows(0) and eb == body and np.array_equal(es, st)
     out[kern] = (res.kernel(), hs, rows)
     res.free()
-assert out["rows"][0] == "k_merge_rows" and out["pivot"][0] == "k_merge_pivot" and out["cols"][0] == "k_merge_cols", [out[k][0] for k in out]
+if d == 0.001:      # (more divergent cohorts: the forced kernels may hand tasks down -- the bodies must agree all the same)
+    assert out["rows"][0] == "k_merge_rows" and out["pivot"][0] == "k_merge_pivot" and out["cols"][0] == "k_merge_cols", [out[k][0] for k in out]
 same = out["rows"][1] == out["pivot"][1]
 same_cols = out["rows"][1] == out["cols"][1]
 print(json.dumps({"partitions": P, "samples": N, "rows_total": int(sum(out["pivot"][2])), "pivot_equals_rows_sha256": bool(same),
-                  "cols_equals_rows_sha256": bool(same_cols), "partition0_equals_oracle": True, "keys_ascending": True}))
+                  "cols_equals_rows_sha256": bool(same_cols), "kernels": [out[k][0] for k in ("rows", "pivot", "cols")], "subst_rate": d, "partition0_equals_oracle": True, "keys_ascending": True}))
 assert same and same_cols
