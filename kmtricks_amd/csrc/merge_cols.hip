@@ -48,6 +48,10 @@ constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 5
 constexpr int CL_SEEDS = 64;             // hash multipliers tried per tile for a collision-free table
 constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
 constexpr int CL_NW = CL_TPB / 64;
+#ifndef KMX_CK_SPEC
+#define KMX_CK_SPEC 5
+#endif
+constexpr int CK_SPEC = KMX_CK_SPEC;     // k_cols_check: keys per thread requested together with the slice's count
 constexpr int CK_BITS = 1 << 18;         // k_cols_check: bits of the key map (32 KB of LDS)
 constexpr int CK_NSUSP = 32;             // ... suspects per pass (keys that found their bit set)
 constexpr int CK_PASS = 2048;            // ... keys per pass (~8 suspects expected at that many)
@@ -601,13 +605,13 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   __syncthreads();
   const bool single = nsl <= (u32)CK_TPB / 4;      // every slice of a group has its four threads at once
   for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) {
-    // four threads per (block, wave) slice of the group: every slice's count and first 32 keys (8 per thread; the
+    // four threads per (block, wave) slice of the group: every slice's count and first 20 keys (5 per thread -- the usual slice holds ~13; the
     // slice's memory is there whatever the count) are requested together -- one memory round trip per group (a wave
     // walking its slices one after the other pays two dependent round trips per slice).
     // A group with many keys (cohorts with many sample-private k-mers) is counted in 2, 4 or 8 passes, a pass taking the
     // keys whose hash has its bits (equal keys meet in the same pass): the suspects of a pass stay a handful.
     const u64 sbase = (u64)(slot0 + q) * nsl;
-    u32 n0 = 0; u64 kk0[8];
+    u32 n0 = 0; u64 kk0[CK_SPEC];
     const u64* kp0 = C.ovkeys;
     for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
       const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
@@ -616,7 +620,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       if (single) {
         kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW;
 #pragma unroll
-        for (int x = 0; x < 8; x++) kk0[x] = kp0[sub + 4 * x];
+        for (int x = 0; x < CK_SPEC; x++) kk0[x] = kp0[sub + 4 * x];
         n0 = min(nraw, (u32)CL_OVW);
       }
       if (sub == 0 && nraw) atomicAdd(&total, nraw);
@@ -634,8 +638,8 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         if (single) {
           const u32 sub = tid & 3u;
 #pragma unroll
-          for (int x = 0; x < 8; x++) if (sub + 4 * x < n0) f(kk0[x]);
-          for (u32 e = sub + 32; e < n0; e += 4) f(kp0[e]);
+          for (int x = 0; x < CK_SPEC; x++) if (sub + 4 * x < n0) f(kk0[x]);
+          for (u32 e = sub + 4 * CK_SPEC; e < n0; e += 4) f(kp0[e]);
         } else {
           for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
             const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
