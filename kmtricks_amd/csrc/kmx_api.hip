@@ -139,7 +139,8 @@ struct kmx_merge_result {
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
   // column-blocked kernel first (merge_cols.hip): its row keys come from a merge of a few lists of every task
-  bool use_cols = false, cols_auto = false, can_pivot = false, pivot_part = false;
+  bool use_cols = false, cols_auto = false, can_pivot = false, auto_sel = false;
+  u32 given = 0;                     // tasks the kernel in hand was given (all of them, or the ones handed down to it)
   std::vector<TaskHost> subs;        // the row-key merges, one per task
   size_t o_subtasks = 0, o_subitems = 0, o_cols = 0, o_citems = 0;
   u32 n_subitems = 0, n_citems = 0, sub_grid = 0, cols_grid = 0, sub_max_c = 0, sub_max_n = 0, items_grid = 0;
@@ -352,7 +353,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       R->use_pivot = !R->use_cols && can && min_n > 512;
       if (R->use_pivot && ctx->pivot_skip) { ctx->pivot_skip--; R->use_pivot = false; }   // cohort that did not suit it recently
       R->pivot_auto = R->use_pivot;
+      R->auto_sel = true;
     }
+    R->given = n_tasks;
   }
   // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
   const u32 slots = (u32)ctx->n_cu * 2;
@@ -622,13 +625,17 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] %s handed back %u of %zu tasks: re-run with %s\n", from_cols ? "k_merge_cols" : "k_merge_pivot",
                                      n_back, R->tasks.size(), to_pivot ? "k_merge_pivot" : "k_merge_rows");
     if (from_cols) {
-      if (R->cols_auto && n_back * 4 >= R->tasks.size()) {   // a cohort it does not suit: back off for the next batches
-        ctx->cols_backoff = std::min(64u, std::max(1u, ctx->cols_backoff * 2)); ctx->cols_skip = ctx->cols_backoff;
+      if (R->cols_auto && n_back * 4 >= R->given) {   // a cohort it does not suit: back off for the next batches
+        // (doubling; at once to the longest pause when three quarters of the batch came back: a try costs a whole merge)
+        ctx->cols_backoff = n_back * 4 >= 3 * R->given ? 64u : std::min(64u, std::max(1u, ctx->cols_backoff * 2));
+        ctx->cols_skip = ctx->cols_backoff;
       }
       R->cols_auto = false;
     } else {
-      if (R->pivot_auto && n_back * 4 >= R->tasks.size()) {
-        ctx->pivot_backoff = std::min(64u, std::max(1u, ctx->pivot_backoff * 2)); ctx->pivot_skip = ctx->pivot_backoff;
+      // (also when it ran as the next kernel down from cols in a batch libkmx chose the kernels for)
+      if ((R->pivot_auto || R->auto_sel) && n_back * 4 >= R->given) {
+        ctx->pivot_backoff = n_back * 4 >= 3 * R->given ? 64u : std::min(64u, std::max(1u, ctx->pivot_backoff * 2));
+        ctx->pivot_skip = ctx->pivot_backoff;
       }
       R->pivot_auto = false;
     }
@@ -656,6 +663,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
       if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
       (void)was_pivot; (void)was_cols;
       for (auto& H : R->tasks) if (H.handed_back) H.kernel = to_pivot ? 1 : 0;
+      R->given = n_back;
     }
     R->rerun_rows = true;
     bool ov2 = false;
