@@ -140,6 +140,7 @@ struct kmx_merge_result {
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
   // column-blocked kernel first (merge_cols.hip): its row keys come from a merge of a few lists of every task
   bool use_cols = false, cols_auto = false, can_pivot = false, auto_sel = false;
+  bool divergent = false;            // k_cols_prep found lists that share too few keys: the tasks handed back go straight to k_merge_rows
   u32 given = 0;                     // tasks the kernel in hand was given (all of them, or the ones handed down to it)
   std::vector<TaskHost> subs;        // the row-key merges, one per task
   size_t o_subtasks = 0, o_subitems = 0, o_cols = 0, o_citems = 0;
@@ -590,7 +591,7 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
     H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
     H.handed_back = false;
-    if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; }
+    if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; if (ctrl[2] & ERR_DIVERGENT) R->divergent = true; }
   }
   return KMX_OK;
 }
@@ -615,7 +616,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     // -- only those -- run again with the next kernel down (cols -> pivot -> rows).  Bounds stay valid; their
     // statistics and row space restart.
     const bool from_cols = R->use_cols;
-    const bool to_pivot = from_cols && R->can_pivot;
+    const bool to_pivot = from_cols && R->can_pivot && !R->divergent;
     const uint2* all_items = reinterpret_cast<const uint2*>(R->h_meta + R->o_items);
     std::vector<uint2> redo;
     u32 n_back = 0;
@@ -630,6 +631,8 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
         ctx->cols_backoff = n_back * 4 >= 3 * R->given ? 64u : std::min(64u, std::max(1u, ctx->cols_backoff * 2));
         ctx->cols_skip = ctx->cols_backoff;
       }
+      // (lists that share too few keys for k_merge_cols are beyond k_merge_pivot as well: pause both)
+      if (R->divergent && R->auto_sel) { ctx->pivot_backoff = 64u; ctx->pivot_skip = 64u; }
       R->cols_auto = false;
     } else {
       // (also when it ran as the next kernel down from cols in a batch libkmx chose the kernels for)

@@ -63,7 +63,8 @@ struct ColsDev {
 #define KMX_CHUNK_BYTES 262144
 #endif
 
-enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2, ERR_FALLBACK = 4 };
+enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2, ERR_FALLBACK = 4,
+       ERR_DIVERGENT = 8 };   // (with ERR_FALLBACK, from k_cols_prep: the lists share too few keys for the kernels built for cohorts)
 
 // ---- keys -------------------------------------------------------------------------------------
 template <int KW> struct Key { u64 w[KW]; };

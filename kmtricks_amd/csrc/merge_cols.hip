@@ -57,6 +57,8 @@ constexpr int CK_NSUSP = 32;             // ... suspects per pass (keys that fou
 constexpr int CK_PASS = 2048;            // ... keys per pass (~8 suspects expected at that many)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
 
+__device__ u32 kmx_cols_dbg[8];      // why tasks were handed back (KMX_TRACE=1 prints and clears them)
+
 namespace {
 
 typedef u32 u32x3 __attribute__((ext_vector_type(3), aligned(4)));
@@ -185,15 +187,24 @@ void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ ite
   }
   // kept: first record of a run of >= recurrence-min equal keys
   const u32 per = P / SK_TPB ? P / SK_TPB : 1;
-  u32 mine = 0, keptm = 0;
+  u32 mine = 0, keptm = 0, nsolid = 0, ncov = 0;      // ... and how many of the lists' solid records the kept keys cover
   for (u32 x = 0; x < per; x++) {
     const u32 i = tid * per + x;
     if (i < P) {
       const u64 k = ks[i];
       const bool kept = k != ~0ULL && (i == 0 || ks[i - 1] != k) && i + rec_min - 1 < P && ks[i + rec_min - 1] == k;
       keptm |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
+      if (k != ~0ULL) {
+        nsolid++;
+        bool cov = false;      // my record's run of equal keys is at least recurrence-min long
+        for (u32 j = 0; j < rec_min && !cov; j++) cov = i >= j && i - j + rec_min - 1 < P && ks[i - j] == k && ks[i - j + rec_min - 1] == k;
+        ncov += cov ? 1u : 0u;
+      }
     }
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { nsolid += __shfl_xor(nsolid, off); ncov += __shfl_xor(ncov, off); }
+  if (lane == 0 && nsolid) { atomicAdd(&S.ctrl[4], (u64)nsolid); atomicAdd(&S.ctrl[5], (u64)ncov); }
   const u32 incl = wave_incl_scan(mine, (int)lane);
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
@@ -220,6 +231,15 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
   const u64 slots = rows / C.rt + T.c + 2;
   const bool bad = serr != 0 || nseg64 > (u64)CP_MAXSEG || nseg64 > S.seg_cap || rows > T.out_cap_rows || rows > 0xFFFFFF00ULL ||
                    slots > C.slots_cap;
+  // the share of the merged lists' solid records that the row keys do not cover estimates what every list would set aside:
+  // above 1/8 the slices would overflow (and k_merge_pivot gives up at the same point): straight to k_merge_rows
+  const u64 nsolid = S.ctrl[4], ncov = S.ctrl[5];
+  const bool divergent = (nsolid - ncov) * 8 > nsolid;
+  if (divergent && !bad) {
+    if (tid == 0) { atomicOr(&T.ctrl[2], (u64)(ERR_FALLBACK | ERR_DIVERGENT)); *C.nskel = 0; atomicAdd(&kmx_cols_dbg[4], 1u); }
+    for (u32 j = tid; j <= T.c; j += CP_TPB) C.rbounds[j] = 0;
+    return;
+  }
   if (bad) {   // the row keys could not be built (arena too small, ...): the general kernels take the task
     if (tid == 0) { atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK); *C.nskel = 0; }
     for (u32 j = tid; j <= T.c; j += CP_TPB) C.rbounds[j] = 0;
@@ -266,7 +286,6 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
 
 __device__ const u32 kmx_cols_sentinel[4] = {~0u, ~0u, 0u, 0u};      // the record "past the end of a list": largest key, count 0
 
-__device__ u32 kmx_cols_dbg[8];      // why tasks were handed back (KMX_TRACE=1 prints and clears them)
 #ifdef KMX_PHASE_PROF
 __device__ u64 kmx_cols_prof[8];
 #ifndef KMX_PROF_TID
@@ -691,7 +710,7 @@ void cols_dbg_dump()
 {
   u32 h[8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_cols_dbg), sizeof(h)) != hipSuccess) return;
-  fprintf(stderr, "[kmx merge] k_merge_cols hand-back reasons: no collision-free row table %u, slice overflow %u (wave-tiles), kept key outside the row keys %u, check table full %u\n", h[0], h[1], h[2], h[3]);
+  fprintf(stderr, "[kmx merge] k_merge_cols hand-back reasons: no collision-free row table %u, slice overflow %u (wave-tiles), kept key outside the row keys %u, check table full %u, lists too divergent %u (tasks)\n", h[0], h[1], h[2], h[3], h[4]);
   memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_dbg), h, sizeof(h));
 }
 #ifdef KMX_PHASE_PROF
