@@ -364,7 +364,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   const u32 per_slot = ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : 3u;
   // (cols: one workgroup per CU, and a work item is a column block of a range.  Leaving a few CUs to the small kernels
   //  that prepare the NEXT batch on the second stream was tried: the merge then needs finer work items, net +5 %)
-  const u32 cols_cus = (u32)ctx->n_cu;
+  const u32 cols_cus = (u32)ctx->n_cu * cols_wgs_per_cu();
   const u32 target_items = (R->use_cols ? cols_cus : slots) * per_slot;
   u32 n_items = 0, max_n = 0, max_c = 0;
   for (auto& H : R->tasks) {

@@ -23,6 +23,7 @@ hipError_t launch_merge_pivot(int kw, int mode, const TaskDev* tasks, const uint
                               u32 grid_x, hipStream_t st);
 int cols_lds_bytes();
 u32 cols_block_lists();
+u32 cols_wgs_per_cu();
 u32 cols_tile_rows(u32 nb);
 u64 cols_scratch_keys(u32 slots, u32 nblk);
 u64 cols_scratch_counts(u32 slots, u32 nblk);

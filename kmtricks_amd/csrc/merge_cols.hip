@@ -30,7 +30,11 @@
 
 namespace kmx {
 
-constexpr int CL_TPB = 1024;
+#ifndef KMX_CL_TPB
+#define KMX_CL_TPB 1024
+#endif
+constexpr int CL_TPB = KMX_CL_TPB;       // 1024: one workgroup per CU; 512: two, each with half the lists of a block and half the image
+constexpr int CL_WGS = 1024 / CL_TPB;
 #ifndef KMX_CL_G
 #define KMX_CL_G 8
 #endif
@@ -38,12 +42,12 @@ constexpr int CL_G = KMX_CL_G;           // adjacent lanes per list (4: 64-recor
 constexpr int CL_U = 16;                 // window slots per lane
 constexpr int CL_W = CL_G * CL_U;        // records per window
 constexpr int CL_NB = CL_TPB / CL_G;     // lists per column block
-constexpr int CL_IMG = 61440;            // LDS image bytes (rt rows x nb u32 counts)
+constexpr int CL_IMG = 61440 / CL_WGS;   // LDS image bytes (rt rows x nb u32 counts)
 constexpr int CL_RT = CL_W * 7 / 8;      // row keys per tile (< window: a similar list needs no second round)
 constexpr int CL_KPL = (CL_RT + 63) / 64;   // row keys per lane of wave 0 (which builds the row table)
-constexpr int CL_NT = CL_KPL == 1 ? 2 : 1;  // row tables: two of 2048 entries (the next tile's is built beside this tile's), or one of 4096
-constexpr int CL_PT = 4096 / CL_NT;      // row-key table entries
-constexpr int CL_PTSHIFT = CL_NT == 2 ? 21 : 20;
+constexpr int CL_NT = (CL_KPL == 1 && CL_WGS == 1) ? 2 : 1;  // row tables: two of 2048 entries (the next tile's is built beside this tile's), or one of 4096
+constexpr int CL_PT = CL_KPL == 1 ? 2048 : 4096;      // row-key table entries
+constexpr int CL_PTSHIFT = CL_PT == 2048 ? 21 : 20;
 constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 56 rows (k_cols_check takes a slice group at a time)
 constexpr int CL_SEEDS = 64;             // hash multipliers tried per tile for a collision-free table
 constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
@@ -295,7 +299,7 @@ __device__ u64 kmx_cols_prof[8];
 
 // ---- the merge: work item = (task, key range, column block) ----------------------------------------------
 template <int MODE>      // 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
-__global__ __launch_bounds__(CL_TPB, 1)
+__global__ __launch_bounds__(CL_TPB, CL_WGS)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
                   u32 n_items, u32* ticket)
 {
@@ -729,6 +733,7 @@ void cols_phase_prof_dump()
 // ---- host side ------------------------------------------------------------------------------------------
 int cols_lds_bytes() { return CL_IMG + CL_NT * CL_PT * (int)sizeof(ClEnt) + 64 + 256; }
 u32 cols_halves() { return CL_HALVES; }
+u32 cols_wgs_per_cu() { return CL_WGS; }
 u32 cols_block_lists() { return CL_NB; }
 u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }      // (sized for count rows; PA rows need less)
 u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW; }
