@@ -653,6 +653,7 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     __syncthreads();
     if (tot == 0) continue;
     if (tid == 0) total = 0;      // (barriers follow before the next group adds to it)
+    if (rec_min <= 1) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); } break; }      // (every key set aside is a row then)
     if (tot > (u32)CK_PASS * 8) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }     // (a slice over its capacity lands here too)
     const u32 npass = tot <= (u32)CK_PASS ? 1u : tot <= (u32)CK_PASS * 2 ? 2u : tot <= (u32)CK_PASS * 4 ? 4u : 8u;
     for (u32 pass = 0; pass < npass; pass++) {

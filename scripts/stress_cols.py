@@ -1,0 +1,40 @@
+"""Randomised parity of the column-blocked merge against the oracle: list counts, partition sizes, similarity, private
+k-mers, recurrence-min, soft-min, count / PA rows, few work items (many tiles each) or many.  KMX_MERGE_KERNEL=cols is
+forced, so a case the kernel does not suit exercises the hand-back chain instead."""
+import os, sys, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from synth import synth_lists
+from kmtricks_amd import lib
+import orc
+
+os.environ["KMX_MERGE_KERNEL"] = "cols"
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = lib.Context(0)
+kernels = {}
+for case in range(n_cases):
+    N = rng.choice([9, 64, 127, 128, 129, 200, 256, 257, 384, 511, 600, 777, 1000, 1024, 1500])
+    pool = rng.choice([40, 300, 1500, 6000, 15000]) if N <= 600 else rng.choice([40, 300, 1500, 5000])
+    p = rng.choice([0.999, 0.97, 0.9, 0.6, 0.2])
+    priv = int(pool * rng.choice([0.0, 0.01, 0.03, 0.1, 0.4]))
+    rec_min = rng.choice([1, 2, 2, 2, 3, 5, 9])
+    mode = rng.choice([lib.MODE_COUNT, lib.MODE_COUNT, lib.MODE_PA])
+    os.environ["KMX_ITEMS_PER_SLOT"] = rng.choice(["1", "3"])
+    lists = synth_lists(rng.randrange(1 << 30), N, pool, p, priv, kw=1, count_max=rng.choice([2, 5, 50]), ragged=rng.random() < 0.2)
+    if rng.random() < 0.3:      # a list with a long run of keys nobody else has
+        i = rng.randrange(N); k, c = lists[i]
+        if len(k):
+            lo = int(k[len(k) // 2, 0]); run = (np.arange(1, 400, dtype=np.uint64) + np.uint64(lo)).reshape(-1, 1)
+            run = run[~np.isin(run[:, 0], k[:, 0])]
+            k2 = np.concatenate([k, run]); c2 = np.concatenate([c, np.full(len(run), 3, np.uint32)])
+            o = np.argsort(k2[:, 0]); lists[i] = (np.ascontiguousarray(k2[o]), np.ascontiguousarray(c2[o]))
+    soft = [rng.choice([1, 1, 2, 3]) for _ in range(N)]
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, soft, rec_min, 0, mode)
+    body, rows, stats = ctx.merge(lists, 1, soft, rec_min, 0, mode)
+    ok = rows == er and body == eb and np.array_equal(stats, es)
+    print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} mode={mode} rows={rows} {'ok' if ok else 'MISMATCH'}", flush=True)
+    if not ok:
+        sys.exit(1)
+print("all", n_cases, "cases equal the oracle")

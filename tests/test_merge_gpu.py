@@ -489,3 +489,14 @@ def test_cols_scratch_budget(monkeypatch):
         assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
         res.free()
     ctx.close()
+
+
+def test_cols_recurrence_min_1_key_outside_the_row_keys(ctx):
+    """column-blocked kernel forced at recurrence-min 1: a key that only a list outside the row-key lists holds is a
+    row (found by scripts/stress_cols.py: the check must hand the task back for ANY key it was given)"""
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("column-blocked kernel only")
+    lists = synth_lists(9950, 9, 40, 0.97, 1, kw=1)
+    check(ctx, lists, 1, [1] * 9, 1, 0, orc.MODE_COUNT)
+    lists = synth_lists(9951, 200, 300, 0.9, 3, kw=1)
+    check(ctx, lists, 1, [1] * 200, 1, 0, orc.MODE_PA)
