@@ -677,20 +677,23 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   }
   if (R->cols_auto) ctx->cols_backoff = 0;      // the column-blocked kernel completed this batch
   if (R->pivot_auto) ctx->pivot_backoff = 0;   // the pivot kernel completed this batch
-  if (overflow) {
-    // the kernel kept counting: re-run with arenas / directories of the exact size
+  for (int attempt = 0; overflow; attempt++) {
+    // the kernel kept counting: re-run with arenas / directories of the size it asked for (a second time when the
+    // re-run -- possibly with another kernel -- asks for more still)
     TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
     for (size_t t = 0; t < R->tasks.size(); t++) {
       TaskHost& H = R->tasks[t];
       if (H.arena_rows > H.out_cap_rows) {
         ctx->dfree(H.d_out);
-        H.out_cap_rows = H.arena_rows; H.out_bytes = (size_t)(H.arena_rows * H.row_bytes);
+        // (what the kernel claimed, plus a chunk per range: the retry may run with another kernel -- tasks a cohort
+        //  kernel handed back are re-run with k_merge_rows -- whose tiles leave other chunk tails unused)
+        H.out_cap_rows = H.arena_rows + (u64)(H.c + 1) * rows_chunk_rows(H.row_bytes); H.out_bytes = (size_t)(H.out_cap_rows * H.row_bytes);
         H.d_out = (u8*)ctx->dalloc(H.out_bytes);
         if (!H.d_out) { R->waited = true; R->status = ctx->fail(KMX_E_NOMEM, "output arena allocation failed (retry)"); return R->status; }
         td[t].out = H.d_out; td[t].out_cap_rows = H.out_cap_rows;
       }
       if (H.nsegs > H.seg_cap) {   // a larger directory in its own block
-        H.seg_cap = (u32)H.nsegs;
+        H.seg_cap = (u32)std::min<u64>(0x7FFFFFFF, H.nsegs + 8ULL * H.c + 4096);
         if (H.d_segs_own) ctx->dfree(H.d_segs_own);
         H.d_segs_own = (Seg*)ctx->dalloc(sizeof(Seg) * (size_t)H.seg_cap);
         if (!H.d_segs_own) { R->waited = true; R->status = ctx->fail(KMX_E_NOMEM, "segment directory allocation failed (retry)"); return R->status; }
@@ -714,7 +717,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
     KMX_HIP(ctx, hipEventSynchronize(R->ev_done));
     rc = fetch_ctrl(R, &overflow);
-    if (rc == KMX_OK && overflow) rc = ctx->fail(KMX_E_HIP, "merge overflowed its exact-size arena (internal error)");
+    if (rc == KMX_OK && overflow && attempt >= 2) rc = ctx->fail(KMX_E_HIP, "merge overflowed its exact-size arena (internal error)");
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
   }
   R->waited = true; R->status = KMX_OK;

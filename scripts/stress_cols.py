@@ -9,7 +9,8 @@ from synth import synth_lists
 from kmtricks_amd import lib
 import orc
 
-os.environ["KMX_MERGE_KERNEL"] = "cols"
+if len(sys.argv) > 3 and sys.argv[3] == "auto": os.environ.pop("KMX_MERGE_KERNEL", None)      # libkmx chooses (and backs off)
+else: os.environ["KMX_MERGE_KERNEL"] = "cols"
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = lib.Context(0)
@@ -31,6 +32,7 @@ for case in range(n_cases):
             k2 = np.concatenate([k, run]); c2 = np.concatenate([c, np.full(len(run), 3, np.uint32)])
             o = np.argsort(k2[:, 0]); lists[i] = (np.ascontiguousarray(k2[o]), np.ascontiguousarray(c2[o]))
     soft = [rng.choice([1, 1, 2, 3]) for _ in range(N)]
+    print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} mode={mode} ...", flush=True)
     eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, soft, rec_min, 0, mode)
     body, rows, stats = ctx.merge(lists, 1, soft, rec_min, 0, mode)
     ok = rows == er and body == eb and np.array_equal(stats, es)

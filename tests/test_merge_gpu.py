@@ -500,3 +500,16 @@ def test_cols_recurrence_min_1_key_outside_the_row_keys(ctx):
     check(ctx, lists, 1, [1] * 9, 1, 0, orc.MODE_COUNT)
     lists = synth_lists(9951, 200, 300, 0.9, 3, kw=1)
     check(ctx, lists, 1, [1] * 200, 1, 0, orc.MODE_PA)
+
+
+def test_cols_randomised_stress():
+    """scripts/stress_cols.py: 30 random cohorts (list counts, sizes, similarity, recurrence-min, soft-min, count / PA)
+    through the forced column-blocked kernel and its hand-back chain, seed 23 (whose case 23 once overflowed the retry
+    arena after a cols -> pivot -> rows chain), every body and statistic equal to the oracle's."""
+    import subprocess, sys
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("one run is enough")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("KMX_MERGE_KERNEL", None); env.pop("KMX_ITEMS_PER_SLOT", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_cols.py"), "30", "23"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "all 30 cases equal the oracle" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
