@@ -11,6 +11,7 @@ import orc
 
 if len(sys.argv) > 3 and sys.argv[3] == "auto": os.environ.pop("KMX_MERGE_KERNEL", None)      # libkmx chooses (and backs off)
 else: os.environ["KMX_MERGE_KERNEL"] = "cols"
+big = "big" in sys.argv[3:]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = lib.Context(0)
@@ -18,8 +19,9 @@ kernels = {}
 for case in range(n_cases):
     N = rng.choice([9, 64, 127, 128, 129, 200, 256, 257, 384, 511, 600, 777, 1000, 1024, 1500])
     pool = rng.choice([40, 300, 1500, 6000, 15000]) if N <= 600 else rng.choice([40, 300, 1500, 5000])
-    p = rng.choice([0.999, 0.97, 0.9, 0.6, 0.2])
-    priv = int(pool * rng.choice([0.0, 0.01, 0.03, 0.1, 0.4]))
+    if big: N = rng.choice([300, 600, 1000]); pool = rng.choice([20000, 40000])      # work items of many tiles
+    p = rng.choice([0.999, 0.97, 0.9, 0.6, 0.2]) if not big else rng.choice([0.999, 0.97, 0.93, 0.85])
+    priv = int(pool * (rng.choice([0.0, 0.01, 0.03, 0.1, 0.4]) if not big else rng.choice([0.0, 0.01, 0.03, 0.08])))
     rec_min = rng.choice([1, 2, 2, 2, 3, 5, 9])
     mode = rng.choice([lib.MODE_COUNT, lib.MODE_COUNT, lib.MODE_PA])
     os.environ["KMX_ITEMS_PER_SLOT"] = rng.choice(["1", "3"])
