@@ -123,6 +123,7 @@ struct TaskHost {
   u32 nblk = 0, nb = 0, rt_cols = 0, slots_cap = 0;
   size_t o_skel = 0, o_nskel = 0, o_rbounds = 0;
   u8* d_ov = nullptr;           // keys + counts of the records that are not row keys
+  std::vector<u32> src;         // (row-key merge of a task: which of the task's lists it merges)
   int kernel = 0;               // the kernel that completed (or is to complete) the task: 0 rows, 1 pivot, 2 cols
 };
 
@@ -407,8 +408,17 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       Q.kw = kw; Q.mode = mode; Q.rec_min = H.rec_min; Q.share_min = 0;
       Q.len.resize(Q.N);
       u32 piv = 0;
+      Q.src.resize(Q.N);
+      std::vector<u32> win;
       for (u32 i = 0; i < Q.N; i++) {
-        const u32 src = (u32)(((2ull * i + 1) * H.N) / (2ull * Q.N));
+        // one list from each of Q.N stretches of the task: the one of median length there (an empty or an outlier
+        // list is a poor witness of what the cohort shares)
+        const u32 w0 = (u32)(((u64)i * H.N) / Q.N), w1 = std::max(w0 + 1, (u32)(((u64)(i + 1) * H.N) / Q.N));
+        win.clear();
+        for (u32 j = w0; j < w1; j++) win.push_back(j);
+        std::nth_element(win.begin(), win.begin() + win.size() / 2, win.end(), [&](u32 a, u32 b) { return H.len[a] != H.len[b] ? H.len[a] < H.len[b] : a < b; });
+        const u32 src = win[win.size() / 2];
+        Q.src[i] = src;
         Q.len[i] = H.len[src]; Q.total_recs += H.len[src];
         if (Q.len[i] > Q.len[piv]) piv = i;
       }
@@ -539,7 +549,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       u32* len = reinterpret_cast<u32*>(R->h_meta + Q.o_len);
       u32* smin = reinterpret_cast<u32*>(R->h_meta + Q.o_smin);
       for (u32 i = 0; i < Q.N; i++) {
-        const u32 src = (u32)(((2ull * i + 1) * H.N) / (2ull * Q.N));
+        const u32 src = Q.src[i];
         recs[i] = (const u8*)K.lists[src].recs; len[i] = Q.len[i]; smin[i] = K.soft_min[src];
       }
       fill_dev(Q, sd[t]);

@@ -289,14 +289,19 @@ def test_cols_kept_key_outside_the_row_keys():
     ctx = lib.Context(0)
     N = 600
     lists = synth_lists(6100, N, 3000, 0.97, 40, kw=1)
-    sampled = {((2 * i + 1) * N) // 16 for i in range(8)}
-    a, b = 5, 450                                    # blocks 0 and 1 (300 lists each)
-    assert a not in sampled and b not in sampled
+    a, b = 5, 450                                    # two different column blocks (128 lists each)
     extra = np.array([[(1 << 61) + 12345]], dtype=np.uint64)
     for i in (a, b):
         k, c = lists[i]
         k2 = np.concatenate([k, extra]); c2 = np.concatenate([c, np.array([7], np.uint32)])
         o = np.argsort(k2[:, 0]); lists[i] = (np.ascontiguousarray(k2[o]), np.ascontiguousarray(c2[o]))
+    # the 8 merged lists: the one of median length (ties: lower index) in each eighth of the task (kmx_api.hip)
+    lens = [len(c) for _, c in lists]
+    sampled = set()
+    for i in range(8):
+        w = sorted(range(i * N // 8, (i + 1) * N // 8), key=lambda j: (lens[j], j))
+        sampled.add(w[len(w) // 2])
+    assert a not in sampled and b not in sampled
     rows = check(ctx, lists, 1, [1] * N, 2, 0, orc.MODE_COUNT)
     assert rows > 0
     # and without the planted key the column-blocked kernel completes the task itself
