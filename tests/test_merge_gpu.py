@@ -518,3 +518,34 @@ def test_cols_randomised_stress():
     env = dict(os.environ); env.pop("KMX_MERGE_KERNEL", None); env.pop("KMX_ITEMS_PER_SLOT", None)
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_cols.py"), "30", "23"], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "all 30 cases equal the oracle" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_batch_of_tasks_with_different_list_counts(monkeypatch):
+    """One kmx_merge_dev batch of four tasks with 130, 1000, 257 and 600 lists (different block counts, tile sizes and
+    row widths side by side), count and PA, libkmx's own kernel choice: every task equals the oracle."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    ctx = lib.Context(0)
+    dev = torch.device("cuda", 0)
+    for mode in (lib.MODE_COUNT, lib.MODE_PA):
+        sets = [synth_lists(9960 + i, n, pool, 0.97, pool // 40, kw=1) for i, (n, pool) in enumerate(((130, 9000), (1000, 2500), (257, 4000), (600, 3000)))]
+        keep, tasks = [], []
+        for lists in sets:
+            n = len(lists)
+            recs = [lib.pack_records(k, c, 1) for k, c in lists]
+            offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+            dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+            keep.append(dt)
+            tasks.append(dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(n)], key_words=1,
+                              soft_min=[1] * n, rec_min=2, share_min=0, mode=mode))
+        torch.cuda.synchronize()
+        res = ctx.merge_dev(tasks); res.wait()
+        assert res.kernel() == "k_merge_cols"
+        for t, lists in enumerate(sets):
+            eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * len(lists), 2, 0, mode)
+            assert res.rows(t) == er and res.body(t) == eb and np.array_equal(res.stats(t), es), (mode, t)
+        res.free()
+    ctx.close()
