@@ -198,7 +198,7 @@ void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ ite
       const u64 k = ks[i];
       const bool kept = k != ~0ULL && (i == 0 || ks[i - 1] != k) && i + rec_min - 1 < P && ks[i + rec_min - 1] == k;
       keptm |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
-      if (k != ~0ULL) {
+      if (k != ~0ULL && (range & 7u) == 0) {      // (an estimate: every eighth range)
         nsolid++;
         bool cov = false;      // my record's run of equal keys is at least recurrence-min long
         for (u32 j = 0; j < rec_min && !cov; j++) cov = i >= j && i - j + rec_min - 1 < P && ks[i - j] == k && ks[i - j + rec_min - 1] == k;
@@ -206,9 +206,11 @@ void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ ite
       }
     }
   }
+  if ((range & 7u) == 0) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { nsolid += __shfl_xor(nsolid, off); ncov += __shfl_xor(ncov, off); }
-  if (lane == 0 && nsolid) { atomicAdd(&S.ctrl[4], (u64)nsolid); atomicAdd(&S.ctrl[5], (u64)ncov); }
+    for (int off = 32; off > 0; off >>= 1) { nsolid += __shfl_xor(nsolid, off); ncov += __shfl_xor(ncov, off); }
+    if (lane == 0 && nsolid) { atomicAdd(&S.ctrl[4], (u64)nsolid); atomicAdd(&S.ctrl[5], (u64)ncov); }
+  }
   const u32 incl = wave_incl_scan(mine, (int)lane);
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
