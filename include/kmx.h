@@ -17,7 +17,8 @@
  *                               (sorting_count.hpp:346-363, 908-997; count_processor.hpp:61-70),
  *                               HashCountTask::exec (task.hpp:447-481)
  *   kmx_transpose_bits          replaces km::BitMatrix::transpose / __sse_trans
- *                               (include/kmtricks/bitmatrix.hpp:209-214, 238-289), HashMerger::write_as_bft (merge.hpp:631-644)
+ *                               (include/kmtricks/bitmatrix.hpp:209-214, 238-289); HashMerger::write_as_bft (merge.hpp:631-644)
+ *                               as a whole is kmx_merge* with KMX_MODE_BFT (merge + transpose without leaving HBM)
  *   kmx_superk_partition        replaces KmFillPartitions / Sequence2SuperKmer / SuperKmer::save
  *                               (include/kmtricks/gatb/fill_partitions.hpp:59-105, gatb kmer/impl/Sequence2SuperKmer.hpp:80-158,
  *                                gatb kmer/impl/Model.hpp:1086-1139, 1388-1433), SuperKTask::exec (task.hpp:255-320)
@@ -54,7 +55,10 @@ enum {
   KMX_MODE_COUNT = 0,  /* row = key + N * u32           (.count / .count_hash body) */
   KMX_MODE_PA    = 1,  /* row = key + ceil(N/8) bytes   (.pa / .pa_hash body)       */
   KMX_MODE_BF    = 2,  /* one ceil(N/8)-byte row per hash of [lower, upper] (.cmbf) */
-  KMX_MODE_BFC   = 3   /* one ceil(N*w/8)-byte row per hash, bitpacker MSB-first    */
+  KMX_MODE_BFC   = 3,  /* one ceil(N*w/8)-byte row per hash, bitpacker MSB-first    */
+  KMX_MODE_BFT   = 4   /* the BF matrix bit-transposed on the device: round_up8(N) rows (row s = sample s) of
+                          round_up8(W)/8 bytes -- what HashMerger::write_as_bft dumps (merge.hpp:631-644), and
+                          the layout the per-sample Bloom filter files are cut from (howde_utils.hpp:133-187) */
 };
 
 typedef struct kmx_ctx kmx_ctx;
@@ -64,8 +68,9 @@ int  kmx_create(int device, kmx_ctx** out);
 void kmx_destroy(kmx_ctx* ctx);
 /* last error message of this ctx (or of the failed kmx_create when ctx == NULL) */
 const char* kmx_last_error(const kmx_ctx* ctx);
-/* When on, the merge driver brackets its dominant kernel (k_merge_rows / k_merge_bf) with HIP
- * events on the ctx stream so that bench.py can report the kernel's launch duration. */
+/* When on, the merge driver brackets its dominant kernel (k_merge_cols / k_merge_pivot / k_merge_rows /
+ * k_merge_bf, whichever the batch runs) with HIP events on the ctx stream so that bench.py can report
+ * the kernel's launch duration. */
 int  kmx_set_profiling(kmx_ctx* ctx, int on);
 /* HIP stream the ctx launches on (a hipStream_t), so callers can order their own work after it */
 void* kmx_stream(kmx_ctx* ctx);
@@ -112,10 +117,16 @@ int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, k
 int      kmx_result_wait(kmx_merge_result* r);
 /* duration in ms of the batch's merge kernel launch (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
 double   kmx_result_kernel_ms(kmx_merge_result* r);
-/* name of the device kernel that produced the result ("k_merge_rows", "k_merge_pivot", "k_merge_bf"); valid after
- * kmx_result_wait (a pivot batch handed back to k_merge_rows reports k_merge_rows) */
+/* name of the device kernel that produced (most of) the result: "k_merge_cols", "k_merge_pivot", "k_merge_rows"
+ * or "k_merge_bf"; valid after kmx_result_wait (tasks a cohort kernel handed back count for the kernel that
+ * completed them) */
+/* BFT: duration in ms of the batch's transposes (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
+double   kmx_result_transpose_ms(kmx_merge_result* r);
+/* BF / BFC / BFT: DEVICE pointer to the task's dense body (rows * row_bytes bytes), valid until kmx_result_free;
+ * NULL for COUNT / PA results (their rows lie in segments: use kmx_result_copy_body) */
+const void* kmx_result_body_dev(kmx_merge_result* r, uint32_t task);
 const char* kmx_result_kernel(const kmx_merge_result* r);
-uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA) or window rows (BF/BFC) */
+uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA), window rows (BF/BFC), round_up8(N) (BFT) */
 uint64_t kmx_result_row_bytes(const kmx_merge_result* r, uint32_t task);
 uint64_t kmx_result_body_bytes(const kmx_merge_result* r, uint32_t task);  /* rows * row_bytes */
 /* algorithmic bytes moved for this task: input records + output rows (DESIGN.md roofline) */

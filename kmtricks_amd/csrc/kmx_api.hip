@@ -113,6 +113,8 @@ struct TaskHost {
   // offsets into the meta blob
   size_t o_recs = 0, o_len = 0, o_smin = 0, o_bounds = 0, o_stats = 0, o_ctrl = 0, o_segs = 0;
   u8* d_out = nullptr; size_t out_bytes = 0;
+  u8* d_img = nullptr; size_t img_bytes = 0;   // BFT: the hash-major Bloom image k_merge_bf writes, transposed into d_out
+  u64 t_rows = 0, t_cols = 0;                   // BFT: rows / columns of that image rounded up to 8 (merge.hpp:634)
   Seg* d_segs = nullptr;        // directory in use (inside the meta blob, or d_segs_own after a retry)
   Seg* d_segs_own = nullptr;
   // results
@@ -135,7 +137,7 @@ struct kmx_merge_result {
   size_t o_tasks = 0, o_items = 0, o_ticket = 0, o_ctrl0 = 0;
   u32 n_items = 0, grid = 0, max_n = 0, max_c = 0;
   int bf_lds = 0;
-  bool is_bf = false, waited = false;
+  bool is_bf = false, is_bft = false, waited = false;
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
@@ -148,6 +150,7 @@ struct kmx_merge_result {
   u32 n_subitems = 0, n_citems = 0, sub_grid = 0, cols_grid = 0, sub_max_c = 0, sub_max_n = 0, items_grid = 0;
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
+  hipEvent_t ev2 = nullptr;                  // BFT: behind the transposes (ev1 .. ev2 = their duration)
   u64* d_hctrl = nullptr;                    // device address of the control words' place in h_meta
   hipEvent_t ev_pre = nullptr;               // cols: preparation (second stream) done
   hipEvent_t ev_up = nullptr;                // cols: meta blob uploaded (second stream)
@@ -194,7 +197,16 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   if (R->is_bf) {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
+    if (R->is_bft)   // rows W .. round_up8(W) - 1 of the image are not written by the merge
+      for (auto& H : R->tasks) { const u64 W = H.upper - H.lower + 1; if (H.t_rows > W) KMX_HIP(ctx, hipMemsetAsync(H.d_img + W * H.row_bytes, 0, (H.t_rows - W) * H.row_bytes, ctx->stream)); }
     KMX_HIP(ctx, launch_merge_bf(mode == KMX_MODE_BFC, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->bf_lds, ctx->stream));
+    if (R->is_bft) {
+      if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
+      if (ctx->profiling && !R->ev2) { KMX_HIP(ctx, hipEventCreate(&R->ev2)); }
+      for (auto& H : R->tasks) KMX_HIP(ctx, launch_bit_transpose(H.d_img, H.d_out, H.t_rows, H.t_cols, ctx->stream));
+      if (R->ev2) KMX_HIP(ctx, hipEventRecord(R->ev2, ctx->stream));
+      return mirror_and_mark(R);
+    }
   } else if (R->use_cols) {
     // row keys first (bounds + k_merge_rows over a few lists of every task, gathered by k_cols_prep), then the
     // column-blocked merge, then the check that no key outside the rows reaches the recurrence
@@ -258,12 +270,13 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   const u32 kw = tasks[0].key_words, mode = tasks[0].mode;
   if (kw != 1 && kw != 2) return ctx->fail(KMX_E_INVAL, "key_words must be 1 or 2");
-  if (mode > KMX_MODE_BFC) return ctx->fail(KMX_E_INVAL, "unknown mode");
-  const bool is_bf = mode == KMX_MODE_BF || mode == KMX_MODE_BFC;
+  if (mode > KMX_MODE_BFT) return ctx->fail(KMX_E_INVAL, "unknown mode");
+  const bool is_bft = mode == KMX_MODE_BFT;
+  const bool is_bf = mode == KMX_MODE_BF || mode == KMX_MODE_BFC || is_bft;
   if (is_bf && kw != 1) return ctx->fail(KMX_E_INVAL, "BF/BFC modes take hash keys (key_words = 1)");
 
   std::unique_ptr<kmx_merge_result> R(new kmx_merge_result());
-  R->ctx = ctx; R->is_bf = is_bf;
+  R->ctx = ctx; R->is_bf = is_bf; R->is_bft = is_bft;
   R->tasks.resize(n_tasks);
   u64 grand_total = 0;
   for (u32 t = 0; t < n_tasks; t++) {
@@ -298,11 +311,16 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     if (is_bf) {
       if (K.upper < K.lower) return ctx->fail(KMX_E_INVAL, "BF window upper < lower");
       if (mode == KMX_MODE_BFC && (K.bitw == 0 || K.bitw > 32)) return ctx->fail(KMX_E_INVAL, "bitw must be in 1..32");
-      H.row_bytes = mode == KMX_MODE_BF ? (H.N + 7) / 8 : (u32)(((u64)H.N * K.bitw + 7) / 8);
+      H.row_bytes = mode != KMX_MODE_BFC ? (H.N + 7) / 8 : (u32)(((u64)H.N * K.bitw + 7) / 8);
       u32 rt = (40960u / H.row_bytes) & ~63u; if (rt < 64) rt = 64;
       if ((u64)rt * H.row_bytes > 96 * 1024) return ctx->fail(KMX_E_UNSUPPORTED, "BF row too wide for one LDS tile");
       H.rt = rt;
       H.out_bytes = (size_t)((K.upper - K.lower + 1) * H.row_bytes);
+      if (is_bft) {   // write_as_bft (merge.hpp:631-644): BitMatrix(ROUND_UP(W, 8), ROUND_UP(N, 8) / 8), transposed, dumped whole
+        H.t_rows = (K.upper - K.lower + 1 + 7) & ~7ULL; H.t_cols = (u64)H.row_bytes * 8;
+        H.img_bytes = (size_t)(H.t_rows * H.row_bytes);
+        H.out_bytes = (size_t)(H.t_cols * (H.t_rows >> 3));
+      }
     } else {
       H.row_bytes = kw * 8 + (mode == KMX_MODE_COUNT ? 4 * H.N : (H.N + 7) / 8);
       u32 wl = 0; while (wl < 6 && (H.N << (wl + 1)) <= (u32)rows_cap()) wl++;   // window <= one wave
@@ -492,7 +510,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->h_meta = (u8*)ctx->halloc(upload_bytes);
   if (!R->d_meta || !R->h_meta) { ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); return ctx->fail(KMX_E_NOMEM, "meta allocation failed"); }
   auto drop_blocks = [&]() {
-    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); }
+    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); }
     for (auto& G : R->subs) ctx->dfree(G.d_out);
     ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
   };
@@ -500,6 +518,10 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
     if (H.d_out && cols) H.d_ov = (u8*)ctx->dalloc((size_t)(cols_scratch_keys(H.slots_cap, H.nblk) * 8 + cols_scratch_counts(H.slots_cap, H.nblk) * 4));
     if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
+    if (is_bft) {
+      H.d_img = (u8*)ctx->dalloc(H.img_bytes);
+      if (!H.d_img) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "Bloom image allocation failed"); }
+    }
   }
   for (auto& Q : R->subs) {
     Q.d_out = (u8*)ctx->dalloc(Q.out_bytes);
@@ -514,7 +536,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     D.soft_min = reinterpret_cast<const u32*>(R->d_meta + H.o_smin);
     D.bounds = reinterpret_cast<u32*>(R->d_meta + H.o_bounds);
     D.stats = reinterpret_cast<u64*>(R->d_meta + H.o_stats);
-    D.out = H.d_out;
+    D.out = H.d_img ? H.d_img : H.d_out;      // (BFT: k_merge_bf fills the hash-major image, the transpose fills d_out)
     D.ctrl = reinterpret_cast<u64*>(R->d_meta + H.o_ctrl);
     H.d_segs = reinterpret_cast<Seg*>(R->d_meta + H.o_segs);
     D.segs = H.d_segs;
@@ -614,7 +636,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   KMX_HIP(ctx, hipEventSynchronize(R->ev_done));
   if (R->is_bf) {
-    for (auto& H : R->tasks) H.rows = H.upper - H.lower + 1;
+    for (auto& H : R->tasks) H.rows = R->is_bft ? H.t_cols : H.upper - H.lower + 1;
     R->waited = true; R->status = KMX_OK;
     return KMX_OK;
   }
@@ -751,14 +773,27 @@ extern "C" double kmx_result_kernel_ms(kmx_merge_result* R)
   return (double)ms;
 }
 extern "C" uint64_t kmx_result_rows(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].rows : 0; }
-extern "C" uint64_t kmx_result_row_bytes(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].row_bytes : 0; }
+extern "C" uint64_t kmx_result_row_bytes(const kmx_merge_result* R, uint32_t t)
+{ return (R && t < R->tasks.size()) ? (R->is_bft ? R->tasks[t].t_rows >> 3 : R->tasks[t].row_bytes) : 0; }
 extern "C" uint64_t kmx_result_body_bytes(const kmx_merge_result* R, uint32_t t)
-{ return (R && t < R->tasks.size()) ? R->tasks[t].rows * R->tasks[t].row_bytes : 0; }
+{ return (R && t < R->tasks.size()) ? R->tasks[t].rows * kmx_result_row_bytes(R, t) : 0; }
 extern "C" uint64_t kmx_result_algo_bytes(const kmx_merge_result* R, uint32_t t)
 {
   if (!R || t >= R->tasks.size()) return 0;
   const TaskHost& H = R->tasks[t];
-  return H.total_recs * (H.kw * 8 + 4) + H.rows * H.row_bytes;
+  return H.total_recs * (H.kw * 8 + 4) + H.rows * kmx_result_row_bytes(R, t);
+}
+extern "C" double kmx_result_transpose_ms(kmx_merge_result* R)
+{
+  if (!R || !R->ev2 || kmx_result_wait(R) != KMX_OK) return -1.0;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, R->ev1, R->ev2) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+extern "C" const void* kmx_result_body_dev(kmx_merge_result* R, uint32_t t)
+{
+  if (!R || t >= R->tasks.size() || !R->is_bf || kmx_result_wait(R) != KMX_OK) return nullptr;
+  return R->tasks[t].d_out;
 }
 
 extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, uint64_t dst_bytes)
@@ -768,7 +803,7 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
   int rc = kmx_result_wait(R);
   if (rc != KMX_OK) return rc;
   TaskHost& H = R->tasks[t];
-  const u64 body = H.rows * H.row_bytes;
+  const u64 body = kmx_result_body_bytes(R, t);
   if (dst_bytes < body) return ctx->fail(KMX_E_INVAL, "destination too small");
   if (body == 0) return KMX_OK;
   KMX_HIP(ctx, hipSetDevice(ctx->device));
@@ -838,11 +873,12 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
 #ifdef KMX_PHASE_PROF
   if (!R->is_bf) { if (R->use_cols) kmx::cols_phase_prof_dump(); else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
-  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); }
+  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
+  if (R->ev2) (void)hipEventDestroy(R->ev2);
   if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
   if (R->ev_up) (void)hipEventDestroy(R->ev_up);
   if (R->ev_done) (void)hipEventDestroy(R->ev_done);

@@ -48,7 +48,7 @@ __global__ void k_range_bounds_bf(const TaskDev* __restrict__ tasks, u32 max_c)
 __device__ __forceinline__ u32 to_n_b_dev(u32 c, u32 w)
 { // packc.hpp:26-35
   if (!c) return 0;
-  const u32 r = 32 - __clz(c), cap = (1u << w) - 1;
+  const u32 r = 32 - __clz(c), cap = w >= 32 ? 0xFFFFFFFFu : (1u << w) - 1;   // (bitw 32: a 32-bit shift would wrap to 0)
   return r > cap ? cap : r;
 }
 

@@ -241,7 +241,9 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   if (total_bases && !bases) return ctx->fail(KMX_E_INVAL, "null bases");
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const int span_bits = (int)((k + 31) / 32) * 64;
+  // Type::getSize() of the k-mer type the reference instantiates: k < 32 -> MAX_K 32 (64 bits), else MAX_K 64 (128 bits)
+  // (loop_executor.hpp:47-52: first KMER_LIST entry with k < entry) -- so k = 32 already gets 60, not 28
+  const int span_bits = k < 32 ? 64 : 128;
   int maxs = (span_bits - 8) / 2; if (maxs > 255) maxs = 255;   // Sequence2SuperKmer.hpp:146
   const u64 nm = 1ULL << (2 * m);
 

@@ -10,7 +10,7 @@ if not os.path.exists(LIB_PATH):
                       "(libkmx has no CPU fallback)")
 _lib = C.CDLL(LIB_PATH)
 
-MODE_COUNT, MODE_PA, MODE_BF, MODE_BFC = 0, 1, 2, 3
+MODE_COUNT, MODE_PA, MODE_BF, MODE_BFC, MODE_BFT = 0, 1, 2, 3, 4
 STATS_ROWS = 6
 
 
@@ -38,6 +38,10 @@ _lib.kmx_result_kernel.restype = C.c_char_p
 _lib.kmx_result_kernel.argtypes = [_vp]
 _lib.kmx_result_kernel_ms.restype = C.c_double
 _lib.kmx_result_kernel_ms.argtypes = [_vp]
+_lib.kmx_result_transpose_ms.restype = C.c_double
+_lib.kmx_result_transpose_ms.argtypes = [_vp]
+_lib.kmx_result_body_dev.restype = _vp
+_lib.kmx_result_body_dev.argtypes = [_vp, C.c_uint32]
 _lib.kmx_merge_dev.argtypes = [_vp, C.POINTER(KmxMergeTask), C.c_uint32, C.POINTER(_vp)]
 _lib.kmx_result_wait.argtypes = [_vp]
 for _f in ("kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes", "kmx_result_algo_bytes"):
@@ -60,7 +64,7 @@ _lib.kmx_transpose_bits.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, _vp]
 _lib.kmx_superk_partition.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
                                       C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
-EXPORTS = ["kmx_version", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_version", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -248,6 +252,13 @@ class MergeResult:
 
     def kernel(self):
         return _lib.kmx_result_kernel(self._h).decode()
+
+    def transpose_ms(self):
+        return _lib.kmx_result_transpose_ms(self._h)
+
+    def body_dev(self, t=0):
+        """device address of a BF / BFC / BFT body (None for COUNT / PA)"""
+        return _lib.kmx_result_body_dev(self._h, t)
 
     def rows(self, t=0):
         return _lib.kmx_result_rows(self._h, t)

@@ -253,7 +253,9 @@ int orc_superk_partition(const char* seq, size_t len, int k, int m,
   if (k < m || k > 64 || m > 15) return -3;
   if ((int64_t)len - k + 1 <= 0) return 0;                 /* Sequence2SuperKmer.hpp:143-144 */
   const int kw = (k + 31) / 32;
-  const int span_bits = kw * 64;                            /* Type::getSize() */
+  /* Type::getSize(): the reference dispatches k to the first KMER_LIST entry with k < entry
+   * (include/kmtricks/loop_executor.hpp:47-52), so k = 32 runs as Kmer<64> (128 bits) */
+  const int span_bits = k < 32 ? 64 : 128;
   int maxs = (span_bits - 8) / 2; if (maxs > 255) maxs = 255; /* Sequence2SuperKmer.hpp:146 */
   const int nbm = k - m + 1;                                /* _nbMinimizers */
   const uint32_t maskm = (uint32_t)(((uint64_t)1 << (2 * m)) - 1);

@@ -97,7 +97,8 @@ def test_count_empty_stream(ctx):
     assert len(c_) == 0
 
 
-@pytest.mark.parametrize("nr,nc", [(8, 8), (16, 8), (24, 40), (64, 64), (64, 128), (200, 72), (3136, 104), (4096, 1000 // 8 * 8 + 8)])
+@pytest.mark.parametrize("nr,nc", [(8, 8), (16, 8), (24, 40), (64, 64), (64, 128), (200, 72), (3136, 104), (4096, 1000 // 8 * 8 + 8),
+                                   (520, 2504), (1000, 24), (19208, 2504), (1032, 1032), (8, 4104)])
 def test_transpose_vs_oracle(ctx, nr, nc):
     rng = np.random.default_rng(nr * 131 + nc)
     m = rng.integers(0, 256, nr * nc // 8, dtype=np.uint8)

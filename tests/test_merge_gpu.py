@@ -138,6 +138,47 @@ def test_synthetic_bf(ctx, n, dens, smin, rmin, share, mode):
         check(ctx, lists, 1, [1] * n, 1, 0, mode, lower, lower + W - 1, bitw=3)
 
 
+@pytest.mark.parametrize("n,dens,smin,rmin,share,W", [(2, 0.3, 1, 1, 0, 6400), (11, 0.3, 10, 3, 2, 19200), (100, 0.05, 1, 1, 0, 19264), (257, 0.02, 3, 1, 5, 1000),
+                                                       (1001, 0.01, 1, 2, 0, 12345),
+                                                       (2500, 0.004, 2, 1, 1, 19200)])   # BASELINE configs[3]: 2500 samples, --soft-min 2 --share-min 1
+def test_synthetic_bft(ctx, merge_kernel, n, dens, smin, rmin, share, W):
+    """hash:bft:bin -- HashMerger::write_as_bft (merge.hpp:631-644): the BF rows bit-transposed on the device
+    (k_merge_bf -> k_bit_transpose without leaving HBM); windows that are no multiple of 8 / 64 / the tile"""
+    if merge_kernel != "rows":
+        pytest.skip("Bloom modes have one kernel")
+    lower = 5 * W
+    lists = synth_hash_lists(4242 + n, n, lower, W, dens)
+    rows = check(ctx, lists, 1, [smin + (i % 2) for i in range(n)], rmin, share, orc.MODE_BFT, lower, lower + W - 1)
+    assert rows == (n + 7) // 8 * 8
+
+
+def test_bft_rows_are_the_per_sample_filters(ctx, merge_kernel):
+    """row s of the BFT body == column s of the BF body (what howde_utils.hpp:133-187 copies into sample s's filter)"""
+    if merge_kernel != "rows":
+        pytest.skip("Bloom modes have one kernel")
+    n, W, lower = 37, 6400, 6400
+    lists = synth_hash_lists(7, n, lower, W, 0.1)
+    bf, _, _ = ctx.merge(lists, 1, [1] * n, 1, 0, orc.MODE_BF, lower, lower + W - 1)
+    bft, rows, _ = ctx.merge(lists, 1, [1] * n, 1, 0, orc.MODE_BFT, lower, lower + W - 1)
+    bits = np.unpackbits(np.frombuffer(bf, np.uint8).reshape(W, -1), axis=1, bitorder="little")
+    tb = np.unpackbits(np.frombuffer(bft, np.uint8).reshape(rows, W // 8), axis=1, bitorder="little")
+    for s in range(n):
+        assert np.array_equal(tb[s], bits[:, s])
+        hs = lists[s][0].reshape(-1) - np.uint64(lower)
+        assert np.array_equal(np.nonzero(tb[s])[0], hs.astype(np.int64))      # (soft-min 1, recurrence-min 1: every hash is a bit)
+    assert not tb[n:].any()
+
+
+def test_bfc_full_width_counts(ctx, merge_kernel):
+    """--bitw 32: the cap 2^w - 1 must not wrap (packc.hpp:26-35)"""
+    if merge_kernel != "rows":
+        pytest.skip("Bloom modes have one kernel")
+    lower, W = 0, 6400
+    lists = synth_hash_lists(99, 9, lower, W, 0.2, count_max=100000)
+    for w in (31, 32):
+        check(ctx, lists, 1, [1] * 9, 1, 0, orc.MODE_BFC, lower, lower + W - 1, bitw=w)
+
+
 def test_bench_scale_partitions_properties(ctx):
     """BASELINE configs[2] at its real shape -- 1000 samples, one of the 256 partitions of a 5 Mbp genome
     (19.5 k shared k-mers, 3 % private per sample, recurrence-min 2) -- through the device-resident batch
