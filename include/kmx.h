@@ -182,6 +182,29 @@ int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint64_t* offset
                          uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart,
                          uint32_t nb_parts, uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers);
 
+/* The statistics the reference keeps beside the split (gatb PartiInfo<5>): every array is optional (NULL = not wanted)
+ * and is ADDED to, so that the batches of a sample -- or the samples of a cohort -- accumulate:
+ *   part_counters  [nb_parts * KMX_PINFO_STRIDE]: per partition nb_kmers, nb_kxmers, then nbk_per_radix[x * 256 + radix]
+ *                  for x = 0..4 (kx-mers of x + 1 k-mers; fill_partitions.hpp:67-102, PartiInfo.hpp:266-287 PartiInfoFile order)
+ *   minim_superks / minim_kmers [4^m]: super-k-mers and k-mers per minimizer (incSuperKmer_per_minimBin)
+ *   minim_kxmers   [4^m]: kx-mers per minimizer -- what the sampled repartition balances
+ *                  (SampleRepart, gatb RepartitionAlgorithm.cpp:182-215; Repartitor::computeDistrib, PartiInfo.cpp:48-103)
+ *   nb_superk      running total of super-k-mers (needs minim_superks) */
+#define KMX_PINFO_STRIDE (2 + 5 * 256)
+typedef struct {
+  uint64_t* part_counters;
+  uint64_t* minim_superks;
+  uint64_t* minim_kmers;
+  uint64_t* minim_kxmers;
+  uint64_t  nb_superk;
+} kmx_superk_stats;
+/* kmx_superk_partition + statistics.  out_bytes == NULL (then out_len / out_kmers are ignored): statistics only,
+ * nothing is packed -- the sampling pass of the repartition, where `repart` may be any table (all zeros). */
+int kmx_superk_partition_stats(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                               uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart,
+                               uint32_t nb_parts, uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers,
+                               kmx_superk_stats* stats);
+
 void kmx_free(void* p);
 
 #ifdef __cplusplus

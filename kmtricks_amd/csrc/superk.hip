@@ -71,11 +71,24 @@ __device__ __forceinline__ u32 spread16(u32 y)
 //     (Sequence2SuperKmer.hpp:90-158): break / start / end flags are ballots, a lane that ends a
 //     super-k-mer finds its start with a count-leading-zeros on the start mask.  Only the state of the
 //     last owned k-mer is carried to the next chunk (64-(k-m)-1 positions further).
-template <bool EMIT>
+//   * STATS (PartiInfo<5>, fill_partitions.hpp:67-102; SampleRepart, RepartitionAlgorithm.cpp:182-215): a lane knows its
+//     k-mer's strand (forward < reverse complement: the first digit where the k-mer differs from its reverse
+//     complement, found with a bit reversal of the code planes and a count-trailing-zeros); kx-mers are runs of at
+//     most 5 k-mers of one strand inside a super-k-mer -- start / end flags are ballots again --, the lane that ends
+//     one adds 1 to the (partition, run length, radix) counter, radix = top 4 nucleotides of the run's first
+//     canonical k-mer (forward run) or of its last one (reverse run).
+struct SkStats {          // device tables, zeroed by the caller; any of them may be null
+  u32* pc;                // [nb_parts][5][256] kx-mers per (partition, x, radix)
+  u32* ms;                // [4^m] super-k-mers per minimizer
+  u32* mk;                // [4^m] k-mers per minimizer
+  u32* mx;                // [4^m] kx-mers per minimizer
+};
+
+template <bool EMIT, bool STATS>
 __global__ __launch_bounds__(256)
 void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
                    int k, int m, int maxs, const u16* __restrict__ repart,
-                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc)
+                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S)
 {
   const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -92,6 +105,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
     const u32 mmask = (1u << m) - 1;
     u32 out = EMIT ? desc_off[r] : 0;
     bool pv = false; u32 pmin = 0; u64 run_start = 0, open_start = 0;   // state of the last owned k-mer of the previous chunk
+    int pw = 0; u64 t_start = 0, x_start = 0; u32 rf_open = 0;          // (STATS) its strand, strand-run start, kx-mer start + that k-mer's radix
     for (u64 p0 = 0; p0 < nk; p0 += own) {
       const u64 q = p0 + lane;
       const u8 c0 = q < len ? (u8)seq[q] : (u8)'N';
@@ -129,11 +143,53 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
       const bool owned = (u32)lane < own && pk < nk;
       const bool endf = valid && owned && (pk + 1 == nk || !nvalid || nstart);   // last k-mer of a super-k-mer
       const u64 Em = __ballot(endf);
-      if (EMIT && endf) {
+      u64 ps = 0;
+      if ((EMIT || STATS) && endf) {
         const u64 sb = Sall & lowmask;
-        const u64 ps = sb ? p0 + (63 - __clzll(sb)) : open_start;
+        ps = sb ? p0 + (63 - __clzll(sb)) : open_start;
+      }
+      if (EMIT && endf) {
         SkDesc d; d.base = (u32)(b0 + ps); d.part = repart[mini]; d.n = (u8)(pk - ps + 1); d.pad = 0;
         desc[out + __popcll(Em & ((1ULL << lane) - 1))] = d;
+      }
+      int w = 0; u64 ts = 0, xs = 0; u32 rf_s = 0;
+      if (STATS) {
+        // strand: digit i of the k-mer is base i, digit i of its reverse complement is comp(base k-1-i) = code ^ 2
+        const u64 fa_k = fa & kmask, fb_k = fb & kmask;
+        const u64 ra = __brevll(fa_k) >> (64 - k), nrb = ~(__brevll(fb_k) >> (64 - k)) & kmask;
+        const u64 D = (fa_k ^ ra) | (fb_k ^ nrb);
+        if (D) {
+          const int i0 = __builtin_ctzll(D);
+          const u32 xb = (u32)(fb_k >> i0) & 1u, yb = (u32)(nrb >> i0) & 1u, xa = (u32)(fa_k >> i0) & 1u, ya = (u32)(ra >> i0) & 1u;
+          w = xb != yb ? xb < yb : xa < ya;          // forward is the smaller one (KmerCanonical::which, Model.hpp:294; a palindrome counts as reverse)
+        }
+        int w_l = __shfl_up(w, 1); if (lane == 0) w_l = pw;
+        const bool T = valid && (start || w != w_l);                       // first k-mer of a run of one strand
+        const u64 Tm = __ballot(T) & lowmask;
+        ts = Tm ? p0 + (63 - __clzll(Tm)) : t_start;
+        const bool X = valid && (T || (u32)((pk - ts) % 5u) == 0);         // first k-mer of a kx-mer (x <= 4)
+        const u64 Xall = __ballot(X);
+        const int nX = __shfl_down((int)X, 1);
+        const bool xend = valid && owned && (endf || nX);
+        const u64 xm = Xall & lowmask;
+        xs = xm ? p0 + (63 - __clzll(xm)) : x_start;
+        u32 rf = 0, rr = 0;                                                // top 4 nucleotides of my k-mer / of its reverse complement
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          rf |= ((((u32)(fb >> j) & 1u) << 1) | ((u32)(fa >> j) & 1u)) << (6 - 2 * j);
+          rr |= (((((u32)(fb >> (k - 1 - j)) & 1u) ^ 1u) << 1) | ((u32)(fa >> (k - 1 - j)) & 1u)) << (6 - 2 * j);
+        }
+        rf_s = (u32)__shfl((int)rf, xs >= p0 ? (int)(xs - p0) : 0);
+        if (xs < p0) rf_s = rf_open;
+        if (xend) {
+          const u32 x = (u32)(pk - xs), radix = w ? rf_s : rr;
+          if (S.pc) atomicAdd(&S.pc[((u32)repart[mini] * 5u + x) * 256u + radix], 1u);
+          if (S.mx) atomicAdd(&S.mx[mini], 1u);
+        }
+        if (endf) {
+          if (S.ms) atomicAdd(&S.ms[mini], 1u);
+          if (S.mk) atomicAdd(&S.mk[mini], (u32)(pk - ps + 1));
+        }
       }
       const u32 ne = (u32)__popcll(Em);
       nsk += ne; out += ne;
@@ -146,6 +202,12 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
         run_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)rs, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(rs >> 32), lo) << 32);
         const u64 sb = Sall & ((2ULL << lo) - 1);
         if (sb) open_start = p0 + (63 - __clzll(sb));
+      }
+      if (STATS) {
+        pw = __builtin_amdgcn_readlane(w, lo);
+        t_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)ts, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ts >> 32), lo) << 32);
+        x_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)xs, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(xs >> 32), lo) << 32);
+        rf_open = (u32)__builtin_amdgcn_readlane((int)rf_s, lo);
       }
     }
   }
@@ -226,16 +288,68 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
 
 using namespace kmx;
 
-extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
-                                    uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
-                                    uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers)
+// stats tables of one call (u32 on the device, added to the caller's u64 arrays)
+struct StatsDev {
+  SkStats S{nullptr, nullptr, nullptr, nullptr};
+  kmx_superk_stats* dst = nullptr; u32 nb_parts = 0; u64 nm = 0;
+  int alloc(kmx_ctx* ctx, kmx_superk_stats* st, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s) {
+    dst = st; nb_parts = P; nm = nminim;
+    if (!st) return KMX_OK;
+    auto get = [&](bool want, size_t n) -> u32* {
+      if (!want) return nullptr;
+      u32* p = (u32*)ctx->dalloc(n * 4); blocks.push_back(p);
+      if (p) (void)hipMemsetAsync(p, 0, n * 4, s);
+      return p;
+    };
+    S.pc = get(st->part_counters != nullptr, (size_t)P * 1280);
+    S.ms = get(st->minim_superks != nullptr, nminim);
+    S.mk = get(st->minim_kmers != nullptr, nminim);
+    S.mx = get(st->minim_kxmers != nullptr, nminim);
+    if ((st->part_counters && !S.pc) || (st->minim_superks && !S.ms) || (st->minim_kmers && !S.mk) || (st->minim_kxmers && !S.mx))
+      return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
+    return KMX_OK;
+  }
+  bool any() const { return S.pc || S.ms || S.mk || S.mx; }
+  // after the kernel: download and accumulate (PartiInfo::incKmer_and_rad / incSuperKmer_per_minimBin / incKxmer_per_minimBin)
+  int collect(kmx_ctx* ctx, hipStream_t s) {
+    if (!dst || !any()) return KMX_OK;
+    std::vector<u32> h;
+    auto pull = [&](const u32* d, size_t n) -> int {
+      h.resize(n);
+      hipError_t e = hipMemcpyAsync(h.data(), d, n * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      return e == hipSuccess ? KMX_OK : ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
+    };
+    int rc;
+    if (S.pc) {
+      if ((rc = pull(S.pc, (size_t)nb_parts * 1280)) != KMX_OK) return rc;
+      for (u32 p = 0; p < nb_parts; p++) {
+        uint64_t* o = dst->part_counters + (size_t)p * KMX_PINFO_STRIDE;
+        for (u32 x = 0; x < 5; x++) for (u32 r = 0; r < 256; r++) {
+          const u64 c = h[((size_t)p * 5 + x) * 256 + r];
+          if (!c) continue;
+          o[0] += c * (x + 1); o[1] += c; o[2 + x * 256 + r] += c;
+        }
+      }
+    }
+    if (S.ms) { if ((rc = pull(S.ms, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) { dst->minim_superks[i] += h[i]; dst->nb_superk += h[i]; } }
+    if (S.mk) { if ((rc = pull(S.mk, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) dst->minim_kmers[i] += h[i]; }
+    if (S.mx) { if ((rc = pull(S.mx, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) dst->minim_kxmers[i] += h[i]; }
+    return KMX_OK;
+  }
+};
+
+static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                       uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
+                       uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats)
 {
   if (!ctx) return KMX_E_INVAL;
-  if (!offsets || !repart || !out_bytes || !out_len || !out_kmers || nb_parts == 0 || nb_parts > 65535)
+  const bool want_streams = out_bytes != nullptr;
+  if (!offsets || !repart || (want_streams && (!out_len || !out_kmers)) || (!want_streams && !stats) || nb_parts == 0 || nb_parts > 65535)
     return ctx->fail(KMX_E_INVAL, "kmx_superk_partition: bad argument");
   if (k < 8 || k > 63 || m < 4 || m > 15 || m > k) return ctx->fail(KMX_E_UNSUPPORTED, "k outside 8..63 or minimizer size outside 4..15");
-  for (u32 p = 0; p < nb_parts; p++) { out_bytes[p] = nullptr; out_len[p] = 0; out_kmers[p] = 0; }
-  if (n_seqs == 0) { for (u32 p = 0; p < nb_parts; p++) out_bytes[p] = (uint8_t*)malloc(1); return KMX_OK; }
+  if (want_streams) for (u32 p = 0; p < nb_parts; p++) { out_bytes[p] = nullptr; out_len[p] = 0; out_kmers[p] = 0; }
+  if (n_seqs == 0) { if (want_streams) for (u32 p = 0; p < nb_parts; p++) out_bytes[p] = (uint8_t*)malloc(1); return KMX_OK; }
   const u64 total_bases = offsets[n_seqs];
   if (total_bases >= 0xFFFFFF00ULL || n_seqs >= 0x7FFFFFFFULL) return ctx->fail(KMX_E_UNSUPPORTED, "batch of 4 Gbases or more: split it");
   if (total_bases && !bases) return ctx->fail(KMX_E_INVAL, "null bases");
@@ -262,9 +376,19 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if ((e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload repartition");
   if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
+  StatsDev sd;
+  { const int rc = sd.alloc(ctx, stats, nb_parts, nm, blocks, st); if (rc != KMX_OK) { release(); return rc; } }
   const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
-  hipLaunchKernelGGL((k_superk_wave<false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                     (const u32*)nullptr, (SkDesc*)nullptr);
+  if (!want_streams) {   // statistics only (the sampling pass of the repartition): one walk, nothing emitted
+    hipLaunchKernelGGL((k_superk_wave<false, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_superk_wave");
+    const int rc = sd.collect(ctx, st);
+    release();
+    return rc;
+  }
+  hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                     (const u32*)nullptr, (SkDesc*)nullptr, sd.S);
   size_t tb = 0;
   if ((e = rocprim::exclusive_scan(nullptr, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan size");
   void* d_tmp = ctx->dalloc(tb ? tb : 256); blocks.push_back(d_tmp);
@@ -283,8 +407,10 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   u64* d_szs = (u64*)ctx->dalloc(((size_t)nd + 1) * 8), *d_boff = (u64*)ctx->dalloc(((size_t)nd + 1) * 8);
   for (void* b : {(void*)d_desc, (void*)d_keys, (void*)d_keys2, (void*)d_ids, (void*)d_ids2, (void*)d_sz, (void*)d_szs, (void*)d_boff}) blocks.push_back(b);
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-  hipLaunchKernelGGL((k_superk_wave<true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                     (const u32*)d_doff, d_desc);
+  if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                                    (const u32*)d_doff, d_desc, sd.S);
+  else hipLaunchKernelGGL((k_superk_wave<true, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                          (const u32*)d_doff, d_desc, sd.S);
   const dim3 g2((nd + 255) / 256), b2(256);
   hipLaunchKernelGGL(k_superk_sizes, g2, b2, 0, st, d_desc, nd, (int)k, d_keys, d_ids, d_sz);
   size_t tb2 = 0, tb3 = 0;
@@ -307,6 +433,7 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
       (e = hipMemcpyAsync(pf.data(), d_pf, ((size_t)nb_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   clk.mark("emit+sort");
+  { const int rc = sd.collect(ctx, st); if (rc != KMX_OK) { release(); return rc; } }
   if (pf[nb_parts] != nd) { release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
   const u64 total_bytes = tot & 0xFFFFFFFFULL;
   u8* d_out = (u8*)ctx->dalloc(total_bytes + 16); blocks.push_back(d_out);
@@ -340,4 +467,19 @@ extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint6
   clk.mark("download");
   if (oom) return ctx->fail(KMX_E_NOMEM, "superk: host allocation failed");
   return KMX_OK;
+}
+
+extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                                    uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
+                                    uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers)
+{
+  if (ctx && !out_bytes) return ctx->fail(KMX_E_INVAL, "kmx_superk_partition: bad argument");
+  return superk_impl(ctx, bases, offsets, n_seqs, k, m, repart, nb_parts, out_bytes, out_len, out_kmers, nullptr);
+}
+
+extern "C" int kmx_superk_partition_stats(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                                          uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
+                                          uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats)
+{
+  return superk_impl(ctx, bases, offsets, n_seqs, k, m, repart, nb_parts, out_bytes, out_len, out_kmers, stats);
 }

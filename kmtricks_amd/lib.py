@@ -64,7 +64,17 @@ _lib.kmx_transpose_bits.argtypes = [_vp, _vp, C.c_uint64, C.c_uint64, _vp]
 _lib.kmx_superk_partition.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
                                       C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
-EXPORTS = ["kmx_version", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+class KmxSuperkStats(C.Structure):
+    _fields_ = [("part_counters", _vp), ("minim_superks", _vp), ("minim_kmers", _vp), ("minim_kxmers", _vp),
+                ("nb_superk", C.c_uint64)]
+
+
+PINFO_STRIDE = 2 + 5 * 256
+_lib.kmx_superk_partition_stats.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
+                                            C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.POINTER(KmxSuperkStats)]
+
+EXPORTS = ["kmx_version", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -219,6 +229,29 @@ class Context:
             out.append((C.string_at(ob[p], ol[p]) if ol[p] else b"", int(okm[p])))
             _lib.kmx_free(ob[p])
         return out
+
+    def superk_partition_stats(self, reads, k, m, repart, nb_parts, streams=True):
+        """kmx_superk_partition_stats -> ([(record stream, n_kmers)] or None, pinfo[nb_parts, 2 + 5*256], minim_superks,
+        minim_kmers, minim_kxmers); streams=False: the statistics-only pass"""
+        blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
+        rep = np.ascontiguousarray(repart, dtype=np.uint16)
+        pin = np.zeros(nb_parts * PINFO_STRIDE, dtype=np.uint64)
+        ms, mk, mx = (np.zeros(4 ** m, dtype=np.uint64) for _ in range(3))
+        st = KmxSuperkStats(pin.ctypes.data, ms.ctypes.data, mk.ctypes.data, mx.ctypes.data, 0)
+        ob = (_vp * nb_parts)()
+        ol = (C.c_uint64 * nb_parts)()
+        okm = (C.c_uint64 * nb_parts)()
+        self._check(_lib.kmx_superk_partition_stats(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data,
+                                                    nb_parts, ob if streams else None, ol, okm, C.byref(st)),
+                    "kmx_superk_partition_stats")
+        out = None
+        if streams:
+            out = []
+            for p in range(nb_parts):
+                out.append((C.string_at(ob[p], ol[p]) if ol[p] else b"", int(okm[p])))
+                _lib.kmx_free(ob[p])
+        assert st.nb_superk == int(ms.sum())
+        return out, pin.reshape(nb_parts, -1), ms, mk, mx
 
     def prepare(self, tasks):
         """Builds the kmx_merge_task array once (so a timed loop does no Python marshalling).

@@ -191,10 +191,24 @@ static inline unsigned radix_of(const uint64_t* v, int k, int kw)
   return kw_low_bits(v, k - 4, 255u, kw);
 }
 
+/* per-minimizer records of the call in progress (orc_superk_partition_stats): [0] nb_superks, [1] nb_kmers,
+ * [2] nb_kxmers, each 4^m entries; PartiInfo::incSuperKmer_per_minimBin / incKxmer_per_minimBin */
+static __thread uint64_t* g_mstats[3] = {0, 0, 0};
+
 static int superk_flush(superk_t* sk, int k, int kw, const uint16_t* repart, uint32_t nb_parts,
                         orc_buf* out, uint64_t* pinfo)
 { /* fill_partitions.hpp:59-105 + gatb Model.hpp:1388-1433 (SuperKmer::save) */
   if (!sk->valid || sk->n == 0) return 0;
+  if (g_mstats[0]) { g_mstats[0][sk->minimizer] += 1; g_mstats[1][sk->minimizer] += (uint64_t)sk->n; }
+  if (g_mstats[2]) { /* SampleRepart::processSuperkmer, gatb RepartitionAlgorithm.cpp:182-215 */
+    int prev = sk->which[0]; int kx = 0;
+    for (int ii = 1; ii < sk->n; ii++) {
+      if (sk->which[ii] != prev || kx >= 4) { g_mstats[2][sk->minimizer] += 1; kx = 0; } else kx++;
+      prev = sk->which[ii];
+    }
+    g_mstats[2][sk->minimizer] += 1;
+  }
+  if (!out) return 0;                                       /* statistics only */
   uint32_t p = repart[sk->minimizer];
   if (p >= nb_parts) return -2;
   orc_buf* b = &out[p];
@@ -342,6 +356,18 @@ int orc_superk_partition(const char* seq, size_t len, int k, int m,
   free(sk);
   return rc;
 }
+
+int orc_superk_partition_stats(const char* seq, size_t len, int k, int m,
+                               const uint32_t* lut, const uint16_t* repart,
+                               uint32_t nb_parts, orc_buf* out, uint64_t* pinfo,
+                               uint64_t* minim_superks, uint64_t* minim_kmers, uint64_t* minim_kxmers)
+{
+  g_mstats[0] = minim_superks; g_mstats[1] = minim_kmers; g_mstats[2] = minim_kxmers;
+  int rc = orc_superk_partition(seq, len, k, m, lut, repart, nb_parts, out, pinfo);
+  g_mstats[0] = g_mstats[1] = g_mstats[2] = 0;
+  return rc;
+}
+
 
 /* ===================================================================== */
 /* count */

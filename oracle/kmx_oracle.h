@@ -79,6 +79,14 @@ typedef struct {
 int orc_superk_partition(const char* seq, size_t len, int k, int m,
                          const uint32_t* lut, const uint16_t* repart,
                          uint32_t nb_parts, orc_buf* out, uint64_t* pinfo);
+/* the same walk with the per-minimizer records of PartiInfo<5> added to (4^m entries each, any may be NULL):
+ * nb_superks / nb_kmers (fill_partitions.hpp:65, PartiInfo.hpp incSuperKmer_per_minimBin) and nb_kxmers as the
+ * sampling pass of the repartition counts them (gatb kmer/impl/RepartitionAlgorithm.cpp:182-215).
+ * out may be NULL (statistics only; minim_superks and minim_kmers must then be given or NULL together). */
+int orc_superk_partition_stats(const char* seq, size_t len, int k, int m,
+                               const uint32_t* lut, const uint16_t* repart,
+                               uint32_t nb_parts, orc_buf* out, uint64_t* pinfo,
+                               uint64_t* minim_superks, uint64_t* minim_kmers, uint64_t* minim_kxmers);
 void orc_buf_free(orc_buf* b);
 
 /* ---- count ------------------------------------------------------------ */

@@ -26,6 +26,8 @@ _lib.orc_minimizer_of.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_voi
 _lib.orc_repart_static.argtypes = [C.c_int, C.c_uint32, C.c_void_p]
 _lib.orc_superk_partition.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.POINTER(OrcBuf), C.c_void_p]
+_lib.orc_superk_partition_stats.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_uint32, C.POINTER(OrcBuf), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.orc_buf_free.argtypes = [C.POINTER(OrcBuf)]
 _lib.orc_superk_decode.restype = C.c_uint64
 _lib.orc_superk_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
@@ -106,6 +108,23 @@ def superk_partition(seqs, k, m, lut, repart, nb_parts, with_pinfo=False):
         out.append((C.string_at(bufs[p].data, bufs[p].len) if bufs[p].len else b"", bufs[p].nb_kmers, bufs[p].nb_superk))
         _lib.orc_buf_free(C.byref(bufs[p]))
     return (out, pinfo.reshape(nb_parts, -1)) if with_pinfo else out
+
+
+def superk_stats(seqs, k, m, lut, repart, nb_parts):
+    """PartiInfo<5> of a read set: (pinfo[nb_parts, 2 + 5*256], minim_superks, minim_kmers, minim_kxmers) -- the
+    per-partition counters of fill_partitions.hpp:67-102 and the per-minimizer records (kx-mers counted as the
+    sampling pass of the repartition does, RepartitionAlgorithm.cpp:182-215)"""
+    bufs = (OrcBuf * nb_parts)()
+    pinfo = np.zeros(nb_parts * (2 + 5 * 256), dtype=np.uint64)
+    ms, mk, mx = (np.zeros(4 ** m, dtype=np.uint64) for _ in range(3))
+    for s in seqs:
+        b = s if isinstance(s, bytes) else s.encode()
+        rc = _lib.orc_superk_partition_stats(b, len(b), k, m, lut.ctypes.data, repart.ctypes.data, nb_parts, bufs,
+                                             pinfo.ctypes.data, ms.ctypes.data, mk.ctypes.data, mx.ctypes.data)
+        assert rc == 0, rc
+    for p in range(nb_parts):
+        _lib.orc_buf_free(C.byref(bufs[p]))
+    return pinfo.reshape(nb_parts, -1), ms, mk, mx
 
 
 def superk_decode(recs: bytes, k):

@@ -121,6 +121,27 @@ def test_superk_partition_reference_goldens(ctx):
             assert got[p][0] == exp[p][0] and got[p][1] == exp[p][1]
 
 
+@pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4), (12, 4, 2)])
+def test_superk_statistics_vs_oracle(ctx, k, m, P):
+    """PartiInfo<5> from the HIP split (fill_partitions.hpp:67-102): kx-mer / radix counters per partition, super-k-mers,
+    k-mers and kx-mers per minimizer; long reads (strand runs and kx-mers that straddle the 64-position chunks),
+    palindromes, N's; the statistics-only pass (the repartition's sampling) gives the same per-minimizer numbers"""
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    reads = random_reads(70 + k, 300, 150, n_rate=0.004) + random_reads(71 + k, 20, 3000, n_rate=0.001) + \
+        ["ACGT" * 70, "A" * 300, "ACGTN" * 40, "ACG", "", "T" * k, "acgtacgtnnacgt" * 12, "AT" * 200, "GAATTC" * 50]
+    epin, ems, emk, emx = orc.superk_stats(reads, k, m, lut, rep, P)
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    got, pin, ms, mk, mx = ctx.superk_partition_stats(reads, k, m, rep, P)
+    for p in range(P):
+        assert got[p][0] == exp[p][0] and got[p][1] == exp[p][1]
+    assert np.array_equal(pin, epin), np.nonzero(pin != epin)
+    assert np.array_equal(ms, ems) and np.array_equal(mk, emk) and np.array_equal(mx, emx)
+    assert int(pin[:, 0].sum()) == sum(g[1] for g in got) == int(mk.sum())
+    none, pin2, ms2, mk2, mx2 = ctx.superk_partition_stats(reads, k, m, np.zeros(4 ** m, np.uint16), 1, streams=False)
+    assert none is None and np.array_equal(ms2, ems) and np.array_equal(mk2, emk) and np.array_equal(mx2, emx)
+
+
 @pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4)])
 def test_superk_partition_random_reads_vs_oracle(ctx, k, m, P):
     lut = orc.minimizer_lut(m)
