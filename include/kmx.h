@@ -64,6 +64,7 @@ enum {
 typedef struct kmx_ctx kmx_ctx;
 
 int  kmx_version(void);
+int  kmx_device_count(void);   /* HIP devices visible to this process (0: none -- libkmx has no CPU fallback) */
 int  kmx_create(int device, kmx_ctx** out);
 void kmx_destroy(kmx_ctx* ctx);
 /* last error message of this ctx (or of the failed kmx_create when ctx == NULL) */
@@ -137,6 +138,15 @@ int kmx_result_copy_body(kmx_merge_result* r, uint32_t task, void* host_dst, uin
 int kmx_result_copy_stats(kmx_merge_result* r, uint32_t task, uint64_t* host_stats /* 6 * n_lists */);
 void kmx_result_free(kmx_merge_result* r);
 
+/* kmx_merge_dev with HOST list pointers (what a merge task that has just read its count files holds): the
+ * lists are uploaded on a stream of their own -- in ONE copy when they lie back to back in one buffer, best a
+ * pinned one (kmx_alloc_pinned) -- so a batch travels while the previous one merges; the host buffers may be
+ * reused once kmx_result_wait has returned.  Results are read with the kmx_result_* calls above. */
+int kmx_merge_host(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, kmx_merge_result** out);
+/* page-locked host memory for list buffers / result bodies (plain malloc memory works too, slower) */
+void* kmx_alloc_pinned(size_t bytes);
+void  kmx_free_pinned(void* p);
+
 /* Host-buffer convenience around kmx_merge_dev for ONE task: lists[i].recs are
  * HOST pointers; uploads, merges, returns the body in a buffer to release with
  * kmx_free.  stats may be NULL. */
@@ -204,6 +214,15 @@ int kmx_superk_partition_stats(kmx_ctx* ctx, const char* bases, const uint64_t* 
                                uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart,
                                uint32_t nb_parts, uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers,
                                kmx_superk_stats* stats);
+
+/* The sampling pass of the sampled repartition (gatb RepartitionAlgorithm.cpp:182-215, 395-496): statistics
+ * (normally minim_kxmers only) of the SHORTEST PREFIX of the reads that holds more than `budget` super-k-mers -- the
+ * reference's bank iterator is cancelled by the super-k-mer that brings its count past the sample size and stops
+ * before the next read.  n_used = reads in that prefix (n_seqs when the batch does not reach the budget),
+ * n_superk = their super-k-mers. */
+int kmx_superk_sample(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                      uint32_t kmer_size, uint32_t minim_size, uint64_t budget, kmx_superk_stats* stats,
+                      uint64_t* n_used, uint64_t* n_superk);
 
 void kmx_free(void* p);
 

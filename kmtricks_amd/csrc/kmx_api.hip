@@ -57,6 +57,7 @@ void kmx_ctx::hfree(void* p)
 
 // ---- context -----------------------------------------------------------------------------------------
 extern "C" int kmx_version(void) { return KMX_VERSION; }
+extern "C" int kmx_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
 extern "C" int kmx_create(int device, kmx_ctx** out)
 {
@@ -79,6 +80,7 @@ extern "C" int kmx_create(int device, kmx_ctx** out)
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
   if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return KMX_E_NODEVICE; }
   if ((e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->aux); delete c; return KMX_E_NODEVICE; }
+  if ((e = hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->aux); (void)hipStreamDestroy(c->copy); delete c; return KMX_E_NODEVICE; }
   *out = c;
   return KMX_OK;
 }
@@ -90,17 +92,26 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->aux);
   (void)hipStreamSynchronize(ctx->copy);
+  (void)hipStreamSynchronize(ctx->up);
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
   for (auto& b : ctx->hpool) if (b.p) (void)hipHostFree(b.p);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->aux);
   (void)hipStreamDestroy(ctx->copy);
+  (void)hipStreamDestroy(ctx->up);
   delete ctx;
 }
 
 extern "C" const char* kmx_last_error(const kmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" void* kmx_stream(kmx_ctx* ctx) { if (ctx) ctx->stream_shared = true; return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void kmx_free(void* p) { free(p); }
+extern "C" void* kmx_alloc_pinned(size_t bytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 256, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+extern "C" void kmx_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 extern "C" int kmx_set_profiling(kmx_ctx* ctx, int on) { if (!ctx) return KMX_E_INVAL; ctx->profiling = on != 0; return KMX_OK; }
 
 // ---- merge ---------------------------------------------------------------------------------------------
@@ -151,6 +162,8 @@ struct kmx_merge_result {
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
   hipEvent_t ev2 = nullptr;                  // BFT: behind the transposes (ev1 .. ev2 = their duration)
+  u8* d_in = nullptr;                        // kmx_merge_host: the uploaded lists (freed with the result)
+  hipEvent_t ev_in = nullptr;                // ... and the end of their upload
   u64* d_hctrl = nullptr;                    // device address of the control words' place in h_meta
   hipEvent_t ev_pre = nullptr;               // cols: preparation (second stream) done
   hipEvent_t ev_up = nullptr;                // cols: meta blob uploaded (second stream)
@@ -815,8 +828,9 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
   std::vector<Seg> segs(H.nsegs);
   KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->copy));
   const u64 arena = H.arena_rows * H.row_bytes;
-  u8* tmp = (u8*)malloc(arena);
+  u8* tmp = (u8*)ctx->halloc(arena);          // pinned staging (pooled): the arena comes back at PCIe speed
   if (!tmp) return ctx->fail(KMX_E_NOMEM, "host staging allocation failed");
+  struct Rel { kmx_ctx* c; u8* p; ~Rel() { c->hfree(p); } } rel{ctx, tmp};
   KMX_HIP(ctx, hipMemcpyAsync(tmp, H.d_out, arena, hipMemcpyDeviceToHost, ctx->copy));
   KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
   std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.range != b.range ? a.range < b.range : a.seq < b.seq; });
@@ -824,11 +838,10 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
   u64 done = 0;
   for (const Seg& s : segs) {
     const u64 nb = (u64)s.nrows * H.row_bytes;
-    if (s.row_off * H.row_bytes + nb > arena || done + nb > body) { free(tmp); return ctx->fail(KMX_E_HIP, "corrupt segment directory"); }
+    if (s.row_off * H.row_bytes + nb > arena || done + nb > body) return ctx->fail(KMX_E_HIP, "corrupt segment directory");
     memcpy(d + done, tmp + s.row_off * H.row_bytes, nb);
     done += nb;
   }
-  free(tmp);
   if (done != body) return ctx->fail(KMX_E_HIP, "segment directory does not cover the arena");
   return KMX_OK;
 }
@@ -877,12 +890,82 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);
+  ctx->dfree(R->d_in);
+  if (R->ev_in) (void)hipEventDestroy(R->ev_in);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
   if (R->ev2) (void)hipEventDestroy(R->ev2);
   if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
   if (R->ev_up) (void)hipEventDestroy(R->ev_up);
   if (R->ev_done) (void)hipEventDestroy(R->ev_done);
   delete R;
+}
+
+extern "C" int kmx_merge_host(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, kmx_merge_result** out)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!tasks || !n_tasks || !out) return ctx->fail(KMX_E_INVAL, "kmx_merge_host: null argument");
+  *out = nullptr;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  // the lists of a batch usually lie back to back in one (pinned) buffer: then the whole batch is one copy
+  uintptr_t lo = ~(uintptr_t)0, hi = 0; u64 sum = 0, nl = 0;
+  for (u32 t = 0; t < n_tasks; t++) {
+    const kmx_merge_task& K = tasks[t];
+    if (K.key_words != 1 && K.key_words != 2) return ctx->fail(KMX_E_INVAL, "key_words must be 1 or 2");
+    if (!K.lists && K.n_lists) return ctx->fail(KMX_E_INVAL, "task without lists");
+    const size_t rb = K.key_words * 8 + 4;
+    for (u32 i = 0; i < K.n_lists; i++) {
+      const u64 nb = K.lists[i].n * rb;
+      if (!nb) continue;
+      if (!K.lists[i].recs) return ctx->fail(KMX_E_INVAL, "null record pointer");
+      const uintptr_t a = (uintptr_t)K.lists[i].recs;
+      if (a & 3u) return ctx->fail(KMX_E_INVAL, "record pointers must be 4-byte aligned");
+      lo = std::min(lo, a); hi = std::max(hi, (uintptr_t)(a + nb)); sum += nb; nl++;
+    }
+  }
+  const bool one_span = nl && (u64)(hi - lo) <= sum + sum / 4 + 4096;
+  u64 total = 0;
+  if (one_span) total = hi - lo;
+  else for (u32 t = 0; t < n_tasks; t++) for (u32 i = 0; i < tasks[t].n_lists; i++) total += align_up(tasks[t].lists[i].n * (tasks[t].key_words * 8 + 4), 256);
+  u8* d_in = (u8*)ctx->dalloc(total ? total : 256);
+  if (!d_in) return ctx->fail(KMX_E_NOMEM, "input upload allocation failed");
+  std::vector<kmx_merge_task> dt(tasks, tasks + n_tasks);
+  std::vector<std::vector<kmx_list>> dl(n_tasks);
+  hipError_t e = hipSuccess;
+  if (one_span) e = hipMemcpyAsync(d_in, (const void*)lo, total, hipMemcpyHostToDevice, ctx->up);
+  u64 off = 0;
+  for (u32 t = 0; t < n_tasks && e == hipSuccess; t++) {
+    const kmx_merge_task& K = tasks[t];
+    const size_t rb = K.key_words * 8 + 4;
+    dl[t].resize(K.n_lists);
+    for (u32 i = 0; i < K.n_lists && e == hipSuccess; i++) {
+      const u64 nb = K.lists[i].n * rb;
+      dl[t][i].n = K.lists[i].n;
+      if (one_span) dl[t][i].recs = nb ? d_in + ((uintptr_t)K.lists[i].recs - lo) : d_in;
+      else {
+        dl[t][i].recs = d_in + off;
+        if (nb) e = hipMemcpyAsync(d_in + off, K.lists[i].recs, nb, hipMemcpyHostToDevice, ctx->up);
+        off += align_up(nb, 256);
+      }
+    }
+    dt[t].lists = dl[t].data();
+  }
+  hipEvent_t ev = nullptr;
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(ev, ctx->up);
+  // everything this batch queues on the merge streams comes behind its upload (the previous batch's kernels are
+  // already queued in front: the copy runs beside them)
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->aux, ev, 0);
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(ctx->up); ctx->dfree(d_in); if (ev) (void)hipEventDestroy(ev);
+    return ctx->fail(KMX_E_HIP, std::string("upload: ") + hipGetErrorString(e));
+  }
+  kmx_merge_result* R = nullptr;
+  const int rc = kmx_merge_dev(ctx, dt.data(), n_tasks, &R);
+  if (rc != KMX_OK) { (void)hipStreamSynchronize(ctx->up); ctx->dfree(d_in); (void)hipEventDestroy(ev); return rc; }
+  R->d_in = d_in; R->ev_in = ev;
+  *out = R;
+  return KMX_OK;
 }
 
 extern "C" int kmx_merge(kmx_ctx* ctx, const kmx_merge_task* task, void** body, uint64_t* body_bytes, uint64_t* rows, uint64_t* stats)

@@ -48,6 +48,7 @@ struct kmx_ctx {
   hipStream_t stream = nullptr;
   bool stream_shared = false;           // the caller asked for the stream (kmx_stream): its own work may be queued on it
   hipStream_t copy = nullptr;           // third stream: results are read back without queueing behind later batches
+  hipStream_t up = nullptr;             // uploads of kmx_merge_host: the next batch's lists travel while this batch merges
   hipStream_t aux = nullptr;            // second stream: the small kernels that prepare a batch run beside the previous batch's merge
   int n_cu = 0;
   std::string err;

@@ -341,14 +341,17 @@ struct StatsDev {
 
 static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
                        uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
-                       uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats)
+                       uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats,
+                       bool sampling = false, uint64_t budget = 0, uint64_t* n_used = nullptr, uint64_t* n_superk = nullptr)
 {
   if (!ctx) return KMX_E_INVAL;
   const bool want_streams = out_bytes != nullptr;
-  if (!offsets || !repart || (want_streams && (!out_len || !out_kmers)) || (!want_streams && !stats) || nb_parts == 0 || nb_parts > 65535)
+  if (!offsets || (!repart && want_streams) || (want_streams && (!out_len || !out_kmers)) || (!want_streams && !stats) || nb_parts == 0 || nb_parts > 65535)
     return ctx->fail(KMX_E_INVAL, "kmx_superk_partition: bad argument");
   if (k < 8 || k > 63 || m < 4 || m > 15 || m > k) return ctx->fail(KMX_E_UNSUPPORTED, "k outside 8..63 or minimizer size outside 4..15");
   if (want_streams) for (u32 p = 0; p < nb_parts; p++) { out_bytes[p] = nullptr; out_len[p] = 0; out_kmers[p] = 0; }
+  if (n_used) *n_used = 0;
+  if (n_superk) *n_superk = 0;
   if (n_seqs == 0) { if (want_streams) for (u32 p = 0; p < nb_parts; p++) out_bytes[p] = (uint8_t*)malloc(1); return KMX_OK; }
   const u64 total_bases = offsets[n_seqs];
   if (total_bases >= 0xFFFFFF00ULL || n_seqs >= 0x7FFFFFFFULL) return ctx->fail(KMX_E_UNSUPPORTED, "batch of 4 Gbases or more: split it");
@@ -374,13 +377,28 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   hipError_t e;
   if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
-  if ((e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload repartition");
+  if (repart) { if ((e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload repartition"); }
+  else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
   if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
   StatsDev sd;
   { const int rc = sd.alloc(ctx, stats, nb_parts, nm, blocks, st); if (rc != KMX_OK) { release(); return rc; } }
   const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
   if (!want_streams) {   // statistics only (the sampling pass of the repartition): one walk, nothing emitted
-    hipLaunchKernelGGL((k_superk_wave<false, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+    u64 use = n_seqs;
+    if (sampling) {
+      // the shortest prefix of the reads that holds more than `budget` super-k-mers (the reference's iterator is cancelled by the
+      // super-k-mer that brings the count past the sample size, and stops before the next read; RepartitionAlgorithm.cpp:205-211)
+      hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                         (const u32*)nullptr, (SkDesc*)nullptr, sd.S);
+      std::vector<u32> cnt(n_seqs);
+      if ((e = hipMemcpyAsync(cnt.data(), d_cnt, n_seqs * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sample counts");
+      u64 acc = 0; use = 0;
+      while (use < n_seqs) { acc += cnt[use++]; if (acc > budget) break; }
+      if (n_superk) *n_superk = acc;
+    }
+    if (n_used) *n_used = use;
+    const dim3 gs((unsigned)((use + 3) / 4));
+    hipLaunchKernelGGL((k_superk_wave<false, true>), gs, b1, 0, st, d_bases, d_offs, (u64)use, (int)k, (int)m, maxs, d_rep, d_cnt,
                        (const u32*)nullptr, (SkDesc*)nullptr, sd.S);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_superk_wave");
     const int rc = sd.collect(ctx, st);
@@ -482,4 +500,11 @@ extern "C" int kmx_superk_partition_stats(kmx_ctx* ctx, const char* bases, const
                                           uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats)
 {
   return superk_impl(ctx, bases, offsets, n_seqs, k, m, repart, nb_parts, out_bytes, out_len, out_kmers, stats);
+}
+
+extern "C" int kmx_superk_sample(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                                 uint32_t k, uint32_t m, uint64_t budget, kmx_superk_stats* stats, uint64_t* n_used, uint64_t* n_superk)
+{
+  if (ctx && (!stats || !n_used || !n_superk)) return ctx->fail(KMX_E_INVAL, "kmx_superk_sample: null argument");
+  return superk_impl(ctx, bases, offsets, n_seqs, k, m, nullptr, 1, nullptr, nullptr, nullptr, stats, true, budget, n_used, n_superk);
 }

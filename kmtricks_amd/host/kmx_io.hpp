@@ -1,8 +1,10 @@
 // kmx_io.hpp -- byte-exact readers/writers of the kmtricks run-directory files the counting/merge
 // path touches (layouts: SURVEY.md Appendix A; reference include/kmtricks/io/{io_common,kmer_file,
 // hash_file,matrix_file,pa_matrix_file,vector_matrix_file,superk_file}.hpp, hash.hpp:52-60,
-// repartition.hpp:58-67, merge.hpp:72-83).  Plain structs + free functions; headers are written field
-// by field exactly as the reference's serialize() methods do.  Uncompressed bodies only (--cpr is out of scope).
+// repartition.hpp:58-67, merge.hpp:72-83, howde_utils.hpp:56-187; gatb PartiInfo.hpp:266-287,
+// Configuration.cpp:145-178).  Plain structs + free functions; headers are written field by field exactly
+// as the reference's serialize() methods do.  Bodies are raw, or one lz4 frame with --cpr
+// (io/lz4_stream.hpp:89-159: any LZ4F reader reads it; the compressed bytes themselves are not pinned).
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -11,7 +13,24 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+
+// The lz4 frame API (liblz4 >= 1.7, stable ABI): the image ships liblz4.so.1 without its development header, so the
+// few entry points used are declared here (signatures of lz4frame.h; preferences / options are always NULL).
+extern "C" {
+typedef struct LZ4F_dctx_s LZ4F_dctx;
+size_t LZ4F_compressFrameBound(size_t srcSize, const void* preferences);
+size_t LZ4F_compressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* preferences);
+unsigned LZ4F_isError(size_t code);
+const char* LZ4F_getErrorName(size_t code);
+size_t LZ4F_createDecompressionContext(LZ4F_dctx** dctx, unsigned version);
+size_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx);
+size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dst, size_t* dstSize, const void* src, size_t* srcSize, const void* options);
+}
+#define KMX_LZ4F_VERSION 100
 
 namespace kmxio {
 
@@ -23,48 +42,102 @@ constexpr uint64_t MAGIC_BITMATRIX = 0x74616d746962ULL, MAGIC_SUPERK = 0x6b72657
 
 struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
 
+// ---- lz4 frames (--cpr) ---------------------------------------------------------------------------------
+inline std::vector<uint8_t> lz4_compress(const void* src, size_t n) {
+  std::vector<uint8_t> out(LZ4F_compressFrameBound(n, nullptr));
+  const size_t r = LZ4F_compressFrame(out.data(), out.size(), src, n, nullptr);
+  if (LZ4F_isError(r)) throw IoError(std::string("lz4 compression failed: ") + LZ4F_getErrorName(r));
+  out.resize(r);
+  return out;
+}
+inline std::vector<uint8_t> lz4_decompress(const uint8_t* src, size_t n, const std::string& what) {
+  LZ4F_dctx* d = nullptr;
+  if (LZ4F_isError(LZ4F_createDecompressionContext(&d, KMX_LZ4F_VERSION))) throw IoError("lz4: no decompression context");
+  std::vector<uint8_t> out; std::vector<uint8_t> buf(1 << 20);
+  size_t pos = 0;
+  while (pos < n) {
+    size_t dn = buf.size(), sn = n - pos;
+    const size_t r = LZ4F_decompress(d, buf.data(), &dn, src + pos, &sn, nullptr);
+    if (LZ4F_isError(r)) { LZ4F_freeDecompressionContext(d); throw IoError("corrupt lz4 body: " + what); }
+    out.insert(out.end(), buf.begin(), buf.begin() + dn);
+    pos += sn;
+    if (r == 0 && sn == 0 && dn == 0) break;
+  }
+  LZ4F_freeDecompressionContext(d);
+  return out;
+}
+
+// A kmtricks file being written: raw header (first layer), then the body -- streamed as is, or gathered and
+// written as one lz4 frame when the file is compressed.
 class Out {
  public:
   explicit Out(const std::string& path) : f_(fopen(path.c_str(), "wb")), path_(path) {
     if (!f_) throw IoError("Unable to write at " + path);
     setvbuf(f_, nullptr, _IOFBF, 1 << 20);
   }
-  ~Out() { if (f_) fclose(f_); }
+  Out(const Out&) = delete;
+  ~Out() { try { close(); } catch (...) {} }
   template <typename T> void put(T v) { raw(&v, sizeof(T)); }
-  void raw(const void* p, size_t n) { if (n && fwrite(p, 1, n, f_) != n) throw IoError("write failed: " + path_); }
-  void base_header(bool compressed = false) { put<uint64_t>(MAGIC_BASE); put<uint32_t>(0); put<uint8_t>(compressed ? 1 : 0); }
+  void raw(const void* p, size_t n) {
+    if (!n) return;
+    if (cpr_) { const uint8_t* b = (const uint8_t*)p; body_.insert(body_.end(), b, b + n); return; }
+    if (fwrite(p, 1, n, f_) != n) throw IoError("write failed: " + path_);
+  }
+  void base_header(bool compressed = false) { put<uint64_t>(MAGIC_BASE); put<uint32_t>(0); put<uint8_t>(compressed ? 1 : 0); hdr_cpr_ = compressed; }
+  void begin_body() { cpr_ = hdr_cpr_; }          // everything after this call is body
+  void close() {
+    if (!f_) return;
+    if (cpr_) { cpr_ = false; const auto z = lz4_compress(body_.data(), body_.size()); if (fwrite(z.data(), 1, z.size(), f_) != z.size()) throw IoError("write failed: " + path_); }
+    if (fclose(f_) != 0) { f_ = nullptr; throw IoError("write failed: " + path_); }
+    f_ = nullptr;
+  }
  private:
-  FILE* f_; std::string path_;
+  FILE* f_; std::string path_; bool hdr_cpr_ = false, cpr_ = false; std::vector<uint8_t> body_;
 };
 
 inline std::vector<uint8_t> slurp(const std::string& path) {
-  std::ifstream in(path, std::ios::binary);
-  if (!in) throw IoError("Unable to read at " + path);
-  return std::vector<uint8_t>((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw IoError("Unable to read at " + path);
+  struct stat st; if (fstat(fd, &st) != 0) { close(fd); throw IoError("Unable to read at " + path); }
+  std::vector<uint8_t> v((size_t)st.st_size);
+  size_t got = 0;
+  while (got < v.size()) { const ssize_t r = read(fd, v.data() + got, v.size() - got); if (r <= 0) break; got += (size_t)r; }
+  close(fd);
+  if (got != v.size()) throw IoError("short read: " + path);
+  return v;
 }
 template <typename T> inline T rd(const uint8_t* p) { T v; memcpy(&v, p, sizeof(T)); return v; }
+// header check + the (decompressed) body of a kmtricks file whose header is hdr bytes long
+inline std::vector<uint8_t> body_of(std::vector<uint8_t>& raw, size_t hdr, uint64_t magic, const std::string& path) {
+  if (raw.size() < hdr || rd<uint64_t>(&raw[0]) != MAGIC_BASE || rd<uint64_t>(&raw[13]) != magic) throw IoError("Invalid file format: " + path);
+  if (raw[12]) return lz4_decompress(raw.data() + hdr, raw.size() - hdr, path);
+  return std::vector<uint8_t>(raw.begin() + hdr, raw.end());
+}
 
-// ---- counts/partition_<p>/<id>.kmer (io/kmer_file.hpp:31-40, 102-108) -----------------------------
+// ---- counts/partition_<p>/<id>.kmer[.lz4] (io/kmer_file.hpp:31-40, 102-108) -----------------------------
 inline void write_kmer_file(const std::string& path, uint32_t k, uint32_t id, uint32_t part,
-                            const uint64_t* keys, const uint32_t* counts, uint64_t n) {
+                            const uint64_t* keys, const uint32_t* counts, uint64_t n, bool cpr = false) {
   const uint32_t slots = (k + 31) / 32;
-  Out o(path); o.base_header();
+  Out o(path); o.base_header(cpr);
   o.put<uint64_t>(MAGIC_KMER); o.put<uint32_t>(k); o.put<uint32_t>(slots); o.put<uint32_t>(4); o.put<uint32_t>(id); o.put<uint32_t>(part);
+  o.begin_body();
   std::vector<uint8_t> rec((size_t)n * (slots * 8 + 4));
   for (uint64_t i = 0; i < n; i++) { memcpy(&rec[i * (slots * 8 + 4)], keys + i * slots, slots * 8); memcpy(&rec[i * (slots * 8 + 4) + slots * 8], counts + i, 4); }
   o.raw(rec.data(), rec.size());
+  o.close();
 }
 // -> packed records (key words + u32 count) = what kmx_merge takes; widens 1/2-byte counts
 inline std::vector<uint8_t> read_kmer_records(const std::string& path, uint32_t* k_out, uint32_t* slots_out) {
   std::vector<uint8_t> raw = slurp(path);
-  if (raw.size() < 41 || rd<uint64_t>(&raw[0]) != MAGIC_BASE || rd<uint64_t>(&raw[13]) != MAGIC_KMER) throw IoError("Invalid file format: " + path);
-  if (raw[12]) throw IoError("compressed count files (--cpr) are not supported: " + path);
+  std::vector<uint8_t> body = body_of(raw, 41, MAGIC_KMER, path);
   const uint32_t k = rd<uint32_t>(&raw[21]), slots = rd<uint32_t>(&raw[25]), cs = rd<uint32_t>(&raw[29]);
   if (k_out) *k_out = k;
   if (slots_out) *slots_out = slots;
-  const size_t rin = slots * 8 + cs, rout = slots * 8 + 4, n = (raw.size() - 41) / rin;
+  if (slots == 0 || slots > 16 || (cs != 1 && cs != 2 && cs != 4)) throw IoError("Invalid file format: " + path);
+  if (cs == 4) return body;
+  const size_t rin = slots * 8 + cs, rout = slots * 8 + 4, n = body.size() / rin;
   std::vector<uint8_t> out(n * rout, 0);
-  for (size_t i = 0; i < n; i++) { memcpy(&out[i * rout], &raw[41 + i * rin], slots * 8); memcpy(&out[i * rout + slots * 8], &raw[41 + i * rin + slots * 8], cs); }
+  for (size_t i = 0; i < n; i++) { memcpy(&out[i * rout], &body[i * rin], slots * 8); memcpy(&out[i * rout + slots * 8], &body[i * rin + slots * 8], cs); }
   return out;
 }
 
@@ -76,17 +149,19 @@ inline void write_hash_file(const std::string& path, uint32_t id, uint32_t part,
     const uint64_t m = std::min<uint64_t>(4096, n - i);
     o.put<uint64_t>(m); o.raw(h + i, m * 8); o.raw(c + i, m * 4);
   }
+  o.close();
 }
 inline std::vector<uint8_t> read_hash_records(const std::string& path, uint32_t* part_out) {
   std::vector<uint8_t> raw = slurp(path);
   if (raw.size() < 33 || rd<uint64_t>(&raw[0]) != MAGIC_BASE || rd<uint64_t>(&raw[13]) != MAGIC_HASH) throw IoError("Invalid file format: " + path);
-  if (raw[12]) throw IoError("TurboPFor-compressed hash files (--cpr) are not supported: " + path);
+  if (raw[12]) throw IoError("TurboPFor-compressed hash files (.hash.p4) are not supported: " + path);
   const uint32_t cs = rd<uint32_t>(&raw[21]);
+  if (cs != 1 && cs != 2 && cs != 4) throw IoError("Invalid file format: " + path);
   if (part_out) *part_out = rd<uint32_t>(&raw[29]);
   std::vector<uint8_t> out; size_t off = 33;
   while (off + 8 <= raw.size()) {
     const uint64_t n = rd<uint64_t>(&raw[off]); off += 8;
-    if (off + n * (8 + cs) > raw.size()) throw IoError("truncated hash file: " + path);
+    if (n > (raw.size() - off) / (8 + cs)) throw IoError("truncated hash file: " + path);
     const size_t base = out.size(); out.resize(base + n * 12, 0);
     for (uint64_t i = 0; i < n; i++) { memcpy(&out[base + i * 12], &raw[off + i * 8], 8); memcpy(&out[base + i * 12 + 8], &raw[off + n * 8 + i * cs], cs); }
     off += n * (8 + cs);
@@ -95,19 +170,23 @@ inline std::vector<uint8_t> read_hash_records(const std::string& path, uint32_t*
 }
 
 // ---- matrices (io/matrix_file.hpp:31-41, 199-207; pa_matrix_file.hpp:31-41, 178-186; vector_matrix_file.hpp:31-40) ----
-inline void matrix_count_header(Out& o, uint32_t k, uint32_t n, uint32_t part) {   // merge.hpp:264: count_slots is the literal 1, id 0
-  o.base_header(); o.put<uint64_t>(MAGIC_MATRIX); o.put<uint32_t>(k); o.put<uint32_t>((k + 31) / 32); o.put<uint32_t>(1); o.put<uint32_t>(n); o.put<uint32_t>(0); o.put<uint32_t>(part);
+inline void matrix_count_header(Out& o, uint32_t k, uint32_t n, uint32_t part, bool cpr = false) {   // merge.hpp:264: count_slots is the literal 1, id 0
+  o.base_header(cpr); o.put<uint64_t>(MAGIC_MATRIX); o.put<uint32_t>(k); o.put<uint32_t>((k + 31) / 32); o.put<uint32_t>(1); o.put<uint32_t>(n); o.put<uint32_t>(0); o.put<uint32_t>(part);
+  o.begin_body();
 }
-inline void matrix_count_hash_header(Out& o, uint32_t n, uint32_t part) {           // merge.hpp:521
-  o.base_header(); o.put<uint64_t>(MAGIC_MATRIX_HASH); o.put<uint32_t>(4); o.put<uint32_t>(n); o.put<uint32_t>(0); o.put<uint32_t>(part);
+inline void matrix_count_hash_header(Out& o, uint32_t n, uint32_t part, bool cpr = false) {           // merge.hpp:521
+  o.base_header(cpr); o.put<uint64_t>(MAGIC_MATRIX_HASH); o.put<uint32_t>(4); o.put<uint32_t>(n); o.put<uint32_t>(0); o.put<uint32_t>(part);
+  o.begin_body();
 }
-inline void matrix_pa_header(Out& o, uint32_t k, uint32_t n, uint32_t part) {
-  o.base_header(); o.put<uint64_t>(MAGIC_PA); o.put<uint32_t>(k); o.put<uint32_t>((k + 31) / 32); o.put<uint32_t>(n); o.put<uint32_t>((n + 7) / 8); o.put<uint32_t>(0); o.put<uint32_t>(part);
+inline void matrix_pa_header(Out& o, uint32_t k, uint32_t n, uint32_t part, bool cpr = false) {
+  o.base_header(cpr); o.put<uint64_t>(MAGIC_PA); o.put<uint32_t>(k); o.put<uint32_t>((k + 31) / 32); o.put<uint32_t>(n); o.put<uint32_t>((n + 7) / 8); o.put<uint32_t>(0); o.put<uint32_t>(part);
+  o.begin_body();
 }
-inline void matrix_pa_hash_header(Out& o, uint32_t n, uint32_t part) {
-  o.base_header(); o.put<uint64_t>(MAGIC_PA_HASH); o.put<uint32_t>(n); o.put<uint32_t>((n + 7) / 8); o.put<uint32_t>(0); o.put<uint32_t>(part);
+inline void matrix_pa_hash_header(Out& o, uint32_t n, uint32_t part, bool cpr = false) {
+  o.base_header(cpr); o.put<uint64_t>(MAGIC_PA_HASH); o.put<uint32_t>(n); o.put<uint32_t>((n + 7) / 8); o.put<uint32_t>(0); o.put<uint32_t>(part);
+  o.begin_body();
 }
-inline void matrix_bf_header(Out& o, uint32_t bits, uint64_t first, uint64_t window, uint32_t part) {
+inline void matrix_bf_header(Out& o, uint32_t bits, uint64_t first, uint64_t window, uint32_t part) {   // never compressed (task.hpp:828-834)
   o.base_header(); o.put<uint64_t>(MAGIC_BITMATRIX); o.put<uint32_t>(bits); o.put<uint64_t>(first); o.put<uint64_t>(window); o.put<uint32_t>(0); o.put<uint32_t>(part);
 }
 
@@ -115,11 +194,12 @@ inline void matrix_bf_header(Out& o, uint32_t bits, uint64_t first, uint64_t win
 // blocks of <= 32768 bytes of whole records, each preceded by its u32 size
 struct SuperkBlockWriter {
   Out out; std::vector<uint8_t> buf; uint64_t kmers = 0, bytes = 0;
-  SuperkBlockWriter(const std::string& path, uint32_t part) : out(path) { out.base_header(); out.put<uint64_t>(MAGIC_SUPERK); out.put<uint32_t>(part); buf.reserve(32768); }
+  SuperkBlockWriter(const std::string& path, uint32_t part, bool cpr = false) : out(path) { out.base_header(cpr); out.put<uint64_t>(MAGIC_SUPERK); out.put<uint32_t>(part); out.begin_body(); buf.reserve(32768); }
   void add_stream(const uint8_t* s, uint64_t len, uint32_t k) {   // concatenated records [u8 n][bytes]
     uint64_t pos = 0;
     while (pos < len) {
       const uint32_t n = s[pos]; const uint64_t nb = ((uint64_t)k + n - 1 + 3) / 4;   // payload bytes
+      if (pos + 1 + nb > len) throw IoError("malformed super-k-mer stream");
       if (buf.size() + nb + 1 > 32768) flush();
       buf.insert(buf.end(), s + pos, s + pos + 1 + nb);
       kmers += n; pos += 1 + nb;
@@ -129,9 +209,13 @@ struct SuperkBlockWriter {
 };
 inline std::vector<uint8_t> read_superk_stream(const std::string& path) {
   std::vector<uint8_t> raw = slurp(path);
-  if (raw.size() < 25 || rd<uint64_t>(&raw[0]) != MAGIC_BASE || rd<uint64_t>(&raw[13]) != MAGIC_SUPERK) throw IoError("Invalid file format: " + path);
-  std::vector<uint8_t> out; size_t off = 25;
-  while (off + 4 <= raw.size()) { const uint32_t n = rd<uint32_t>(&raw[off]); off += 4; out.insert(out.end(), raw.begin() + off, raw.begin() + off + n); off += n; }
+  std::vector<uint8_t> body = body_of(raw, 25, MAGIC_SUPERK, path);
+  std::vector<uint8_t> out; size_t off = 0;
+  while (off + 4 <= body.size()) {
+    const uint32_t n = rd<uint32_t>(&body[off]); off += 4;
+    if (n > body.size() - off) throw IoError("truncated super-k-mer file: " + path);
+    out.insert(out.end(), body.begin() + off, body.begin() + off + n); off += n;
+  }
   return out;
 }
 
@@ -145,27 +229,87 @@ struct HashWindow {
   }
   uint64_t lower(uint32_t p) const { return p * wbits; }
   uint64_t upper(uint32_t p) const { return (p + 1) * wbits - 1; }
-  void save(const std::string& path) const { Out o(path); o.put(bloom); o.put(parts); o.put(wbits); o.put(wbytes); o.put(msize); }
+  void save(const std::string& path) const { Out o(path); o.put(bloom); o.put(parts); o.put(wbits); o.put(wbytes); o.put(msize); o.close(); }
 };
 
 // ---- repartition_gatb/repartition.minimRepart (gatb PartiInfo.cpp:271-297, repartition.hpp:58-67) ----
 inline void write_repartition(const std::string& path, uint16_t nb_part, const std::vector<uint16_t>& table) {
   Out o(path); o.put<uint16_t>(nb_part); o.put<uint64_t>(table.size()); o.put<uint16_t>(1);
   o.raw(table.data(), table.size() * 2); o.put<uint8_t>(0); o.put<uint32_t>(0x12345678);
+  o.close();
 }
 inline std::vector<uint16_t> read_repartition(const std::string& path, uint16_t* nb_part) {
   std::vector<uint8_t> raw = slurp(path);
   if (raw.size() < 12) throw IoError("bad repartition file: " + path);
   *nb_part = rd<uint16_t>(&raw[0]); const uint64_t n = rd<uint64_t>(&raw[2]);
-  if (raw.size() < 12 + n * 2 + 5 || rd<uint32_t>(&raw[12 + n * 2 + 1]) != 0x12345678) throw IoError("bad repartition file: " + path);
+  if (n > raw.size() || raw.size() < 12 + n * 2 + 5 || rd<uint32_t>(&raw[12 + n * 2 + 1]) != 0x12345678) throw IoError("bad repartition file: " + path);
   std::vector<uint16_t> t(n); memcpy(t.data(), &raw[12], n * 2); return t;
+}
+
+// ---- config_gatb/gatb.config (gatb Configuration.cpp:145-178; members Configuration.hpp) ---------------------
+// size_t kmerSize, minim_size, repartitionType, minimizerType; u64 max_disk_space; u32 max_memory; size_t nbCores,
+// nb_partitions_in_parallel, abundanceUserNb, nbCores_per_partition; u64 estimateSeqNb, estimateSeqTotalSize,
+// estimateSeqMaxSize, available_space, volume, kmersNb; u32 nb_passes, nb_partitions; u16 nb_bits_per_kmer, nb_banks;
+// u32 nb_cached_items_per_core_per_part.  The sizing fields are system dependent in the reference (not byte-pinned):
+// the fields a later stage reads back (k, m, nb_partitions, nb_banks, nb_passes) are exact.
+struct GatbConfig {
+  uint64_t kmer_size = 0, minim_size = 0, nb_cores = 1, est_seq_nb = 0, est_seq_total = 0, est_seq_max = 0, kmers_nb = 0;
+  uint32_t nb_partitions = 0; uint16_t nb_banks = 0;
+  void save(const std::string& path) const {
+    Out o(path);
+    o.put<uint64_t>(kmer_size); o.put<uint64_t>(minim_size); o.put<uint64_t>(0); o.put<uint64_t>(0);
+    o.put<uint64_t>(0); o.put<uint32_t>(0); o.put<uint64_t>(nb_cores); o.put<uint64_t>(1); o.put<uint64_t>(1);
+    o.put<uint64_t>(1); o.put<uint64_t>(est_seq_nb); o.put<uint64_t>(est_seq_total); o.put<uint64_t>(est_seq_max);
+    o.put<uint64_t>(0); o.put<uint64_t>(0); o.put<uint64_t>(kmers_nb);
+    o.put<uint32_t>(1); o.put<uint32_t>(nb_partitions); o.put<uint16_t>((uint16_t)(2 * kmer_size)); o.put<uint16_t>(nb_banks); o.put<uint32_t>(1);
+    o.close();
+  }
+  static bool load(const std::string& path, GatbConfig& c) {
+    std::vector<uint8_t> raw;
+    try { raw = slurp(path); } catch (const IoError&) { return false; }
+    if (raw.size() < 136) return false;
+    c.kmer_size = rd<uint64_t>(&raw[0]); c.minim_size = rd<uint64_t>(&raw[8]); c.nb_partitions = rd<uint32_t>(&raw[128]);
+    return true;
+  }
+};
+
+// ---- superkmers/<id>/PartiInfoFile (gatb PartiInfo.hpp:266-287): one number per line -------------------------
+inline void write_parti_info(const std::string& path, uint32_t nb_parts, uint64_t nb_minims, uint64_t nb_superk_total, uint64_t nb_kmer_total,
+                             const uint64_t* part_counters /* nb_parts * (2 + 5*256) */, const uint64_t* minim_superks, const uint64_t* minim_kmers) {
+  std::string s; s.reserve((size_t)nb_parts * 1282 * 3 + nb_minims * 6 + 64);
+  char b[24];
+  auto num = [&](uint64_t v) { if (v == 0) { s += "0\n"; return; } int n = 0; while (v) { b[n++] = (char)('0' + v % 10); v /= 10; } while (n) s += b[--n]; s += '\n'; };
+  num(nb_parts); num(nb_minims); num(nb_superk_total); num(nb_kmer_total);
+  for (size_t i = 0; i < (size_t)nb_parts * 1282; i++) num(part_counters[i]);
+  for (uint64_t i = 0; i < nb_minims; i++) { num(minim_superks[i]); num(minim_kmers[i]); s += "0\n"; }   // nb_kxmers per minimizer stays 0 in this stage
+  Out o(path); o.raw(s.data(), s.size()); o.close();
 }
 
 // ---- merge_infos/partition<p>.merge_info (merge.hpp:72-83) -------------------------------------------
 inline void write_merge_info(const std::string& path, const uint64_t* stats, uint32_t n) {
   static const char* names[6] = {"NON_SOLID", "RESCUED", "UNIQUE_WO_RESCUE", "UNIQUE_W_RESCUE", "TOTAL_WO_RESCUE", "TOTAL_W_RESCUE"};
-  std::ofstream out(path); if (!out) throw IoError("Unable to write at " + path);
-  for (int r = 0; r < 6; r++) { out << names[r] << '\t'; for (uint32_t i = 0; i < n; i++) out << stats[(size_t)r * n + i] << '\t'; out << "\n"; }
+  std::string s;
+  for (int r = 0; r < 6; r++) { s += names[r]; s += '\t'; for (uint32_t i = 0; i < n; i++) { s += std::to_string(stats[(size_t)r * n + i]); s += '\t'; } s += "\n"; }
+  Out o(path); o.raw(s.data(), s.size()); o.close();
+}
+
+// ---- filters/<id>.bf : one sample's Bloom filter in HowDeSBT's file format (howde_utils.hpp:56-187) --------------
+// bffileheader (km_howdesbt bloom_filter_file.h -- that header is NOT in the reference snapshot, so this layout is
+// restated from HowDeSBT's published format and is UNPINNED): u64 magic, u32 headerSize, u32 version, u32 bfKind,
+// u32 padding, u32 smerSize, u32 numHashes, u64 hashSeed1, u64 hashSeed2, u64 hashModulus, u64 numBits,
+// u32 numVectors, u32 setSizeKnown(+padding), u64 setSize, then one bfvectorinfo {u32 compressor, u32 name, u64 offset,
+// u64 numBytes, u64 filterInfo}: 112 bytes (already a multiple of 16).  The vector itself is an uncompressed sdsl
+// bit_vector: u64 number of bits, then the bits -- for p = 0..P-1 the W/8 bytes of sample s in partition p's
+// transposed matrix (BloomBuilderFromHash::build, howde_utils.hpp:142-187: offset 49 + s * W/8 of matrix_<p>.cmbf).
+constexpr uint64_t BF_MAGIC = 0xD532006662544253ULL;     // "SBTbf\0" + version tag (HowDeSBT bffileheaderMagic)
+constexpr uint32_t BF_HEADER_BYTES = 112, BF_VERSION = 2, BF_KIND_SIMPLE = 1, BF_COMP_UNCOMPRESSED = 1;
+inline void bf_header(uint8_t* h /* BF_HEADER_BYTES */, uint32_t kmer_size, uint64_t bloom_bits) {
+  memset(h, 0, BF_HEADER_BYTES);
+  auto w32 = [&](size_t o, uint32_t v) { memcpy(h + o, &v, 4); };
+  auto w64 = [&](size_t o, uint64_t v) { memcpy(h + o, &v, 8); };
+  w64(0, BF_MAGIC); w32(8, BF_HEADER_BYTES); w32(12, BF_VERSION); w32(16, BF_KIND_SIMPLE); w32(24, kmer_size); w32(28, 1);
+  w64(32, 0); w64(40, 0); w64(48, bloom_bits); w64(56, bloom_bits); w32(64, 1); w32(68, 0); w64(72, 0);
+  w32(80, BF_COMP_UNCOMPRESSED); w32(84, 0); w64(88, BF_HEADER_BYTES); w64(96, bloom_bits / 8 + 8); w64(104, 0);
 }
 
 // ---- FASTA / FASTQ (plain or gz) reader: kseq-style records, sequence lines joined (gatb BankFasta.cpp:390-570) ----
@@ -175,10 +319,11 @@ class SeqReader {
     if (!gz_) throw IoError("Unable to read at " + path);
     gzbuffer(gz_, 1 << 20);
   }
+  SeqReader(const SeqReader&) = delete;
   ~SeqReader() { if (gz_) gzclose(gz_); }
   bool next(std::string& seq) {
     seq.clear();
-    std::string line;
+    std::string& line = line_;
     if (!have_hdr_) { while (getline(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { hdr_ = line[0]; have_hdr_ = true; break; } if (!have_hdr_) return false; }
     have_hdr_ = false;
     if (hdr_ == '>') {
@@ -192,18 +337,27 @@ class SeqReader {
     return true;
   }
  private:
-  static void append(std::string& s, const std::string& l) { for (char c : l) if (c != ' ' && c != '\t' && c != '\r') s.push_back(c); }
+  static void append(std::string& s, const std::string& l) {
+    const size_t o = s.size(); s.resize(o + l.size()); size_t n = o;
+    for (char c : l) if (c != ' ' && c != '\t' && c != '\r') s[n++] = c;
+    s.resize(n);
+  }
+  // own line buffering over gzread (gzgets costs a call per line)
   bool getline(std::string& line) {
     line.clear();
-    char buf[65536];
     for (;;) {
-      if (!gzgets(gz_, buf, sizeof(buf))) return !line.empty();
-      const size_t n = strlen(buf);
-      line.append(buf, n);
-      if (n && buf[n - 1] == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+      if (pos_ == end_) { const int r = gzread(gz_, buf_, sizeof(buf_)); if (r <= 0) return !line.empty(); pos_ = 0; end_ = (size_t)r; }
+      const char* nl = (const char*)memchr(buf_ + pos_, '\n', end_ - pos_);
+      if (nl) {
+        line.append(buf_ + pos_, (size_t)(nl - (buf_ + pos_))); pos_ = (size_t)(nl - buf_) + 1;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return true;
+      }
+      line.append(buf_ + pos_, end_ - pos_); pos_ = end_;
     }
   }
-  gzFile gz_; std::string path_; char hdr_ = 0; bool have_hdr_ = false;
+  gzFile gz_; std::string path_, line_; char hdr_ = 0; bool have_hdr_ = false;
+  char buf_[1 << 16]; size_t pos_ = 0, end_ = 0;
 };
 
 }  // namespace kmxio

@@ -1,54 +1,58 @@
 // kmx_pipeline.cpp -- `kmx pipeline ...`: the `kmtricks pipeline` command line, run-directory layout
 // and plugin loading over libkmx (the MI355X engine).  Mirrors reference src/cli.cpp:117-382 (flags and
 // defaults), include/kmtricks/kmdir.hpp:195-241 (directory tree), task.hpp:98-124, 170-225, 255-320,
-// 367-392, 447-481, 690-743, 787-863 (what each stage reads and writes), io/fof.hpp:39-43 (fof grammar),
-// plugin_manager.hpp:38-113 (plugin symbols).  All compute goes through the C ABI of include/kmx.h;
-// this file only parses, reads and writes files.  Errors: message on stderr + exit(EXIT_FAILURE)
-// (reference src/kmtricks.cpp:109-123).
+// 367-392, 447-481, 690-743, 787-863 (what each stage reads and writes), task_scheduler.hpp:115-160, 251-417
+// (stage order, --restrict-to), io/fof.hpp:39-43 (fof grammar), plugin_manager.hpp:38-113 (plugin symbols),
+// howde_utils.hpp:133-187 (per-sample Bloom filter files).  All compute goes through the C ABI of
+// include/kmx.h; this file parses, schedules, reads and writes files.
+//
+// Scheduling (the role of task_scheduler.hpp + task_pool.hpp): one worker thread per GPU (--gpus G) owns a
+// libkmx context; samples go to GPU s mod G for split + count, partitions to GPU (index mod G) for the merge --
+// no collective, the count files on disk are the exchange, as in the reference.  A pool of -t host threads
+// parses reads ahead of the devices, reads the count files of the NEXT merge batch into pinned memory while the
+// current one merges (kmx_merge_host uploads on its own stream), and compresses / writes outputs behind them.
+// Errors: message on stderr + exit(EXIT_FAILURE) (reference src/kmtricks.cpp:109-123).
 #include <kmx.h>
 #include <kmtricks/plugin.hpp>
 
 #include <dlfcn.h>
 #include <sys/resource.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <future>
-#include <mutex>
-#include <thread>
 #include <cmath>
 #include <filesystem>
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <random>
 #include <regex>
+#include <set>
 #include <sstream>
 
 #include "kmx_io.hpp"
+#include "kmx_pool.hpp"
+#include "kmx_repart.hpp"
 
 namespace fs = std::filesystem;
 using namespace kmxio;
+using clk = std::chrono::steady_clock;
 
 struct Sample { std::string id; std::vector<std::string> files; uint32_t hard_min; };
 
 struct Opt {
-  std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file;
-  uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 1, gpus = 1;
-  uint64_t bloom = 10000000;
-  bool static_repart = false, keep_tmp = false, cpr = false;
+  std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file, bf_format = "howdesbt";
+  uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1;
+  uint64_t bloom = 10000000, merge_batch_mb = 4096;
+  double restrict_to = 1.0, focus = 0.5;
+  std::vector<uint32_t> restrict_list;
+  bool static_repart = false, keep_tmp = false, cpr = false, skip_pinfo = false;
 };
 
-[[noreturn]] static void die(const std::string& msg) { std::cerr << "[error] " << msg << std::endl; std::exit(EXIT_FAILURE); }
-
-static uint64_t xxh64_u32(uint32_t v)
-{ // XXH64(&v, 4, seed 0) -- static repartition (reference include/kmtricks/repartition.hpp:45-56)
-  const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P5 = 0x27D4EB2F165667C5ULL;
-  uint64_t h = P5 + 4;
-  h ^= (uint64_t)v * P1; h = ((h << 23) | (h >> 41)) * P2 + P3;
-  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
-  return h;
-}
+// (a worker thread cannot unwind the others: print and leave without running destructors under them)
+[[noreturn]] static void die(const std::string& msg) { std::cerr << "[error] " << msg << std::endl; std::cerr.flush(); _exit(EXIT_FAILURE); }
+static double since(clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); }
 
 static std::vector<Sample> parse_fof(const std::string& path, uint32_t default_hard_min)
 { // grammar `ID : path[ ; path...][ ! hardmin]` (io/fof.hpp:39-43, 126-134)
@@ -82,30 +86,40 @@ static Opt parse_cli(int argc, char** argv)
   if (argc < 2 || std::string(argv[1]) != "pipeline") die("usage: kmx pipeline --file <fof> --run-dir <dir> [options]  (see INTEGRATION.md)");
   Opt o;
   auto need = [&](int& i) -> std::string { if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]); return argv[++i]; };
+  auto num = [&](int& i) -> unsigned long { const std::string v = need(i); try { size_t n = 0; const unsigned long x = std::stoul(v, &n); if (n != v.size()) throw 1; return x; } catch (...) { die(std::string("bad number for ") + argv[i - 1] + ": " + v); } };
+  auto real = [&](int& i) -> double { const std::string v = need(i); try { return std::stod(v); } catch (...) { die(std::string("bad number for ") + argv[i - 1] + ": " + v); } };
   for (int i = 2; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "--file") o.fof = need(i);
     else if (a == "--run-dir") o.dir = need(i);
-    else if (a == "--kmer-size") o.k = std::stoul(need(i));
-    else if (a == "--hard-min") o.hard_min = std::stoul(need(i));
+    else if (a == "--kmer-size") o.k = num(i);
+    else if (a == "--hard-min") o.hard_min = num(i);
     else if (a == "--mode") o.mode = need(i);
-    else if (a == "--soft-min") o.soft_min = std::stoul(need(i));
-    else if (a == "--recurrence-min") o.rec_min = std::stoul(need(i));
-    else if (a == "--share-min") o.share_min = std::stoul(need(i));
-    else if (a == "--nb-partitions") o.nb_parts = std::stoul(need(i));
-    else if (a == "--minimizer-size") o.msize = std::stoul(need(i));
-    else if (a == "--bloom-size") o.bloom = (uint64_t)std::stod(need(i));
-    else if (a == "--bitw") o.bitw = std::stoul(need(i));
+    else if (a == "--soft-min") o.soft_min = num(i);
+    else if (a == "--recurrence-min") o.rec_min = num(i);
+    else if (a == "--share-min") o.share_min = num(i);
+    else if (a == "--nb-partitions") o.nb_parts = num(i);
+    else if (a == "--minimizer-size") o.msize = num(i);
+    else if (a == "--minimizer-type") { if (num(i) != 0) die("--minimizer-type: only 0 (lexicographic) is supported"); }
+    else if (a == "--repartition-type") { if (num(i) != 0) die("--repartition-type: only 0 (unordered) is supported"); }
+    else if (a == "--bloom-size") o.bloom = (uint64_t)real(i);
+    else if (a == "--bf-format") o.bf_format = need(i);
+    else if (a == "--bitw") o.bitw = num(i);
     else if (a == "--until") o.until = need(i);
     else if (a == "--static-repart") o.static_repart = true;
     else if (a == "--repart-from") o.repart_from = need(i);
     else if (a == "--repart-file") o.repart_file = need(i);     // kmx extension: use this minimRepart table as is
+    else if (a == "--restrict-to") { o.restrict_to = real(i); if (o.restrict_to < 0.05 || o.restrict_to > 1.0) die("--restrict-to must be in [0.05, 1.0]"); }
+    else if (a == "--restrict-to-list") { std::stringstream ss(need(i)); std::string t; while (std::getline(ss, t, ',')) { try { o.restrict_list.push_back((uint32_t)std::stoul(t)); } catch (...) { die("--restrict-to-list: bad partition " + t); } } }
+    else if (a == "--focus") { o.focus = real(i); if (o.focus < 0.0 || o.focus > 1.0) die("--focus must be in [0.0, 1.0]"); }
     else if (a == "--keep-tmp") o.keep_tmp = true;
     else if (a == "--cpr") o.cpr = true;
     else if (a == "--plugin") o.plugin = need(i);
     else if (a == "--plugin-config") o.plugin_config = need(i);
-    else if (a == "-t" || a == "--threads") o.threads = std::stoul(need(i));
-    else if (a == "--gpus") o.gpus = std::stoul(need(i));       // kmx extension: partitions p -> GPU p % gpus
+    else if (a == "-t" || a == "--threads") o.threads = num(i);
+    else if (a == "--gpus") o.gpus = num(i);                    // kmx extension: samples / partitions shard round-robin over this many GPUs
+    else if (a == "--merge-batch-mb") o.merge_batch_mb = num(i); // kmx extension: count-file bytes per merge batch and GPU
+    else if (a == "--skip-partiinfo") o.skip_pinfo = true;      // kmx extension: do not write superkmers/<id>/PartiInfoFile (6 MB of text per sample)
     else if (a == "-v" || a == "--verbose") need(i);
     else die("unknown option " + a);
   }
@@ -113,24 +127,22 @@ static Opt parse_cli(int argc, char** argv)
   if (fs::exists(o.dir)) die("--run-dir already exists: " + o.dir);                  // src/cli.cpp:101-104
   if (o.k < 8 || o.k > 63) die("--kmer-size must be in [8, 63] for this build");
   if (o.msize < 4 || o.msize > 15 || o.msize >= o.k) die("--minimizer-size must be in [4, 15] and < k");
-  if (o.cpr) die("--cpr (lz4 / TurboPFor bodies) is not supported by this build");
-  static const char* modes[] = {"kmer:count:bin", "kmer:pa:bin", "hash:count:bin", "hash:pa:bin", "hash:bf:bin", "hash:bfc:bin"};
+  static const char* modes[] = {"kmer:count:bin", "kmer:pa:bin", "hash:count:bin", "hash:pa:bin", "hash:bf:bin", "hash:bfc:bin", "hash:bft:bin"};
   if (std::find_if(std::begin(modes), std::end(modes), [&](const char* m) { return o.mode == m; }) == std::end(modes))
-    die("--mode " + o.mode + " is not supported (kmer:{count,pa}:bin, hash:{count,pa,bf,bfc}:bin)");
+    die("--mode " + o.mode + " is not supported (kmer:{count,pa}:bin, hash:{count,pa,bf,bfc,bft}:bin)");
   static const char* untils[] = {"all", "repart", "superk", "count", "merge"};
   if (std::find_if(std::begin(untils), std::end(untils), [&](const char* m) { return o.until == m; }) == std::end(untils)) die("bad --until");
-  if (o.nb_parts == 0) o.nb_parts = 4;                                                // task.hpp:112-115 forces >= 4; auto-sizing is system dependent
+  if (o.bf_format != "howdesbt") die("--bf-format " + o.bf_format + " is not supported (howdesbt)");
   if (o.nb_parts > 65535) die("--nb-partitions too large");
-  if (!o.plugin.empty() && (o.mode == "hash:bf:bin" || o.mode == "hash:bfc:bin")) die("--plugin with Bloom modes is not supported by this build");
+  const bool bloom_mode = o.mode == "hash:bf:bin" || o.mode == "hash:bfc:bin" || o.mode == "hash:bft:bin";
+  if (!o.plugin.empty() && bloom_mode) die("--plugin with Bloom modes is not supported by this build");
+  if ((o.mode == "hash:bf:bin" || o.mode == "hash:bft:bin") && (o.restrict_to != 1.0 || !o.restrict_list.empty())) die("--mode bf|bft requires all partitions.");   // cmd/all.hpp:137-143
+  if (o.mode == "hash:bfc:bin" && (o.bitw < 1 || o.bitw > 32)) die("--bitw must be in [1, 32]");
+  if (o.threads == 0) o.threads = 1;
+  if (o.gpus == 0) o.gpus = 1;
   return o;
 }
 
-struct Ctx {
-  std::vector<kmx_ctx*> c;
-  explicit Ctx(uint32_t gpus) { for (uint32_t g = 0; g < gpus; g++) { kmx_ctx* x = nullptr; if (kmx_create((int)g, &x) != KMX_OK) die(kmx_last_error(nullptr)); c.push_back(x); } }
-  ~Ctx() { for (auto x : c) kmx_destroy(x); }
-  kmx_ctx* of_partition(uint32_t p) const { return c[p % c.size()]; }   // partitions shard round-robin, no collective
-};
 static void chk(kmx_ctx* c, int rc, const char* what) { if (rc != KMX_OK) die(std::string(what) + ": " + kmx_last_error(c)); }
 
 // ---- plugin (plugin_manager.hpp:38-113) --------------------------------------------------------------
@@ -145,14 +157,41 @@ struct Plugin {
   }
 };
 
-int main(int argc, char** argv)
+// what SuperKStorageWriter::SaveInfoFile reports for a partition stream (io/superk_storage.hpp:205-225, 328-340; Appendix B-4 of
+// SURVEY.md): the info file is saved before the final flush, so it holds the k-mers since the last full block and the bytes
+// of the blocks flushed so far
+static void superk_info_numbers(const uint8_t* s, uint64_t len, uint32_t k, uint64_t* kmers_pending, uint64_t* bytes_flushed)
 {
-  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t pos = 0, buf = 0, km = 0, flushed = 0, km_total_in_flushed_reset = 0;
+  (void)km_total_in_flushed_reset;
+  while (pos < len) {
+    const uint32_t n = s[pos]; const uint64_t nb = ((uint64_t)k + n - 1 + 3) / 4;
+    if (buf + nb + 1 > 32768) { flushed += buf + 4; buf = 0; km = 0; }
+    buf += nb + 1; km += n; pos += 1 + nb;
+  }
+  *kmers_pending = km; *bytes_flushed = flushed;
+}
+
+struct Stage { double read = 0, split = 0, count = 0, merge_io = 0, merge = 0, format = 0, repart = 0; std::atomic<uint64_t> bases{0}, kmers{0}, merge_recs{0}; };
+
+int run(int argc, char** argv)
+{
+  const auto t0 = clk::now();
   Opt o = parse_cli(argc, argv);
   std::vector<Sample> samples = parse_fof(o.fof, o.hard_min);
-  const uint32_t N = (uint32_t)samples.size(), P = o.nb_parts, kw = (o.k + 31) / 32;
+  const uint32_t N = (uint32_t)samples.size(), kw = (o.k + 31) / 32;
   const bool hash_mode = o.mode.rfind("hash:", 0) == 0;
-  const std::string what = o.mode.substr(o.mode.find(':') + 1, o.mode.rfind(':') - o.mode.find(':') - 1);   // count|pa|bf|bfc
+  const std::string what = o.mode.substr(o.mode.find(':') + 1, o.mode.rfind(':') - o.mode.find(':') - 1);   // count|pa|bf|bfc|bft
+  if (o.cpr && hash_mode && !getenv("KMX_QUIET")) std::cerr << "[kmx pipeline] --cpr: .hash count files stay uncompressed (their .p4 form needs TurboPFor); matrix bodies are lz4 frames\n";
+
+  // ---- number of partitions (task.hpp:108-115): 0 = gatb's ConfigurationAlgorithm sizes it from the estimated volume,
+  // memory and open-file limits of the host (system dependent); this build uses volume / 2^30 k-mers, at least 4 ----
+  std::vector<std::string> all_files; uint64_t in_bytes = 0;
+  for (auto& s : samples) for (auto& f : s.files) { all_files.push_back(f); std::error_code ec; const auto sz = fs::file_size(f, ec); if (ec) die("Unable to read at " + f); in_bytes += sz * (f.size() > 3 && f.substr(f.size() - 3) == ".gz" ? 4 : 1); }
+  if (o.nb_parts == 0) { uint64_t p = in_bytes / (1ull << 30) + 1; o.nb_parts = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(p, 4), 2000); }
+  if (o.nb_parts < 4) o.nb_parts = 4;                                                  // task.hpp:112-113
+  const uint32_t P = o.nb_parts;
+  for (uint32_t p : o.restrict_list) if (p >= P) die("Ask to process part " + std::to_string(p) + " but nb_partitions is " + std::to_string(P));   // task_scheduler.hpp:152-158
 
   // ---- run directory (kmdir.hpp:195-241) ----
   const std::string root = fs::absolute(o.dir).string();
@@ -161,211 +200,490 @@ int main(int argc, char** argv)
     fs::create_directories(root + d);
   fs::copy_file(o.fof, root + "/kmtricks.fof");
   { std::ofstream b(root + "/build_infos.txt"); b << "kmx (MI355X-native kmtricks pipeline), libkmx ABI " << kmx_version() << "\n"; }
-  { std::ofstream f(root + "/options.txt");
-    f << "Options: dir=" << root << ", nb_threads=" << o.threads << ", fof=" << o.fof << ", kmer_size=" << o.k << ", c_ab_min=" << o.hard_min
-      << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", save_if=" << o.share_min << ", minim_size=" << o.msize
-      << ", nb_parts=" << P << ", bloom_size=" << o.bloom << ", keep_tmp=" << o.keep_tmp << ", static_repart=" << o.static_repart
-      << ", bwidth=" << o.bitw << ", mode=" << o.mode << ", until=" << o.until << "\n"; }
+  { std::ofstream f(root + "/options.txt");   // cmd/all.hpp:85-125: `kmtricks combine` re-parses mode= from this line
+    f << "Options: dir=" << root << ", verbosity=info, nb_threads=" << o.threads << ", fof=" << o.fof << ", kmer_size=" << o.k << ", c_ab_min=" << o.hard_min
+      << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", m_ab_min_path=, m_ab_min_f=0, m_ab_float=0, save_if=" << o.share_min << ", minim_size=" << o.msize
+      << ", minim_type=0, repart_type=0, nb_parts=" << P << ", bloom_size=" << o.bloom << ", keep_tmp=" << o.keep_tmp << ", lz4=" << o.cpr << ", kff=0, hist=0, static_repart=" << o.static_repart
+      << ", focus=" << o.focus << ", restrict_to=" << o.restrict_to << ", bwidth=" << o.bitw << ", mode=" << o.mode.substr(0, o.mode.find(':')) << ":" << what << ":bin"
+      << ", format=bin, bf_format=" << o.bf_format << ", count_format=" << (hash_mode ? "hash" : "kmer") << ", until=" << o.until << "\n"; }
   for (uint32_t p = 0; p < P; p++) fs::create_directories(root + "/counts/partition_" + std::to_string(p));
   HashWindow hw(o.bloom, P, o.msize);
   hw.save(root + "/hash.info");                                                       // task.hpp:98-124
+  { GatbConfig gc; gc.kmer_size = o.k; gc.minim_size = o.msize; gc.nb_cores = o.threads; gc.nb_partitions = P; gc.nb_banks = (uint16_t)std::min<size_t>(all_files.size(), 65535);
+    gc.est_seq_total = in_bytes; gc.save(root + "/config_gatb/gatb.config"); }
+
+  // ---- devices and host threads ----
+  std::vector<kmx_ctx*> gpu;
+  // (--gpus beyond the devices present: the extra workers share the devices round-robin -- more contexts in flight per GPU)
+  const int ndev = std::max(1, kmx_device_count());
+  for (uint32_t g = 0; g < o.gpus; g++) { kmx_ctx* x = nullptr; if (kmx_create((int)(g % (uint32_t)ndev), &x) != KMX_OK) die(kmx_last_error(nullptr)); gpu.push_back(x); }
+  const uint32_t G = (uint32_t)gpu.size();
+  struct CtxGuard { std::vector<kmx_ctx*>& v; ~CtxGuard() { for (auto x : v) kmx_destroy(x); } } ctx_guard{gpu};
+  Pool pool(o.threads);
+  Stage st;
+  const char* trace = getenv("KMX_TRACE");
+  const auto t_start = clk::now();
+  auto tlog = [&](uint32_t g, const char* what_, uint64_t id) { if (trace) fprintf(stderr, "[kmx trace] %.6f gpu=%u %s %llu\n", since(t_start), g, what_, (unsigned long long)id); };
 
   // ---- repartition (task.hpp:170-225) ----
   std::vector<uint16_t> table;
   const std::string rpath = root + "/repartition_gatb/repartition.minimRepart";
-  if (!o.repart_file.empty() || !o.repart_from.empty()) {
-    uint16_t np = 0;
-    table = read_repartition(o.repart_file.empty() ? o.repart_from + "/repartition_gatb/repartition.minimRepart" : o.repart_file, &np);
-    if (np != P || table.size() != (1ULL << (2 * o.msize))) die("repartition table does not match --nb-partitions / --minimizer-size");   // task.hpp:136-147
-  } else if (o.static_repart) {
-    table.resize(1ULL << (2 * o.msize));
-    for (uint64_t m = 0; m < table.size(); m++) table[m] = (uint16_t)(xxh64_u32((uint32_t)m) % P);
-  } else die("the sampled repartition is not built yet: pass --static-repart (or --repart-from / --repart-file)");
-  write_repartition(rpath, (uint16_t)P, table);
-  if (o.msize <= 12) {   // minimizers/minimizers.<p>: every m-mer assigned to partition p, one per line (task.hpp:160-168, repartition.hpp:116-124)
-    fs::create_directories(root + "/minimizers");
-    std::vector<std::string> buf(P);
-    std::string mm(o.msize, 'A');
-    for (uint64_t v = 0; v < table.size(); v++) {
-      uint64_t t = v;
-      for (int i = (int)o.msize - 1; i >= 0; i--) { mm[i] = "ACTG"[t & 3]; t >>= 2; }   // Mmer::to_string (kmer.hpp:115-127)
-      std::string& b = buf[table[v]]; b += mm; b += '\n';
+  {
+    const auto t_rep = clk::now();
+    if (!o.repart_file.empty() || !o.repart_from.empty()) {
+      uint16_t np = 0;
+      if (!o.repart_from.empty()) {   // check_repart_compatibility (task.hpp:136-147)
+        GatbConfig fc;
+        if (GatbConfig::load(o.repart_from + "/config_gatb/gatb.config", fc)) {
+          if (fc.kmer_size != o.k) die("Unable to use repartition from " + o.repart_from + ", kmer sizes differ.");
+          if (fc.minim_size != o.msize) die("Unable to use repartition from " + o.repart_from + ", minimizer sizes differ.");
+          if (fc.nb_partitions != P) die("Unable to use repartition from " + o.repart_from + ", numbers of partitions differ.");
+        }
+      }
+      table = read_repartition(o.repart_file.empty() ? o.repart_from + "/repartition_gatb/repartition.minimRepart" : o.repart_file, &np);
+      if (np != P || table.size() != (1ULL << (2 * o.msize))) die("repartition table does not match --nb-partitions / --minimizer-size");
+    } else if (o.static_repart) {
+      table = repart_static(o.msize, P);
+    } else {
+      // sampled repartition (gatb RepartitionAlgorithm.cpp:395-496): from every bank (file), the reads up to the one that
+      // brings the super-k-mers seen past the sample size; their kx-mers per minimizer (counted on the GPU) are balanced
+      // over the partitions by Repartitor::computeDistrib.  Sample size: max(1 % of the bank's estimated reads, 100000)
+      // with several banks, max(5 %, 1000000) with one -- the estimate is gatb's, from file sizes, and only exceeds the
+      // floor for banks of more than 10 M reads; this build uses the floor.
+      const uint64_t nm = 1ULL << (2 * o.msize);
+      std::vector<uint64_t> kx(nm, 0);
+      std::vector<uint16_t> zero(nm, 0);
+      const uint64_t budget = all_files.size() > 1 ? 100000ULL : 1000000ULL;
+      kmx_superk_stats S{}; S.minim_kxmers = kx.data();
+      for (const std::string& f : all_files) {
+        SeqReader rd(f); std::string seq, bases; std::vector<uint64_t> offs(1, 0);
+        uint64_t seen = 0; bool done = false;
+        auto flush = [&]() {
+          if (offs.size() <= 1) return;
+          uint64_t used = 0, nsk = 0;
+          chk(gpu[0], kmx_superk_sample(gpu[0], bases.data(), offs.data(), offs.size() - 1, o.k, o.msize, budget - seen, &S, &used, &nsk), "kmx_superk_sample");
+          seen += nsk;
+          if (used < offs.size() - 1 || seen > budget) done = true;
+          bases.clear(); offs.assign(1, 0);
+        };
+        while (!done && rd.next(seq)) {
+          bases += seq; offs.push_back(bases.size()); st.bases += seq.size();
+          if (offs.size() > 20000 || bases.size() > (64u << 20)) flush();
+        }
+        if (!done) flush();
+      }
+      table = repart_from_kxmers(kx.data(), nm, P);
     }
-    for (uint32_t p = 0; p < P; p++) { std::ofstream f(root + "/minimizers/minimizers." + std::to_string(p)); f.write(buf[p].data(), (std::streamsize)buf[p].size()); }
+    write_repartition(rpath, (uint16_t)P, table);
+    if (o.msize <= 12) {   // minimizers/minimizers.<p>: every m-mer assigned to partition p, one per line (task.hpp:160-168, repartition.hpp:116-124)
+      fs::create_directories(root + "/minimizers");
+      std::vector<std::string> buf(P);
+      std::string mm(o.msize, 'A');
+      for (uint64_t v = 0; v < table.size(); v++) {
+        uint64_t t = v;
+        for (int i = (int)o.msize - 1; i >= 0; i--) { mm[i] = "ACTG"[t & 3]; t >>= 2; }   // Mmer::to_string (kmer.hpp:115-127)
+        if (table[v] >= P) die("repartition table names partition " + std::to_string(table[v]));
+        std::string& b = buf[table[v]]; b += mm; b += '\n';
+      }
+      pool.for_each(P, [&](size_t p) { Out f(root + "/minimizers/minimizers." + std::to_string(p)); f.raw(buf[p].data(), buf[p].size()); f.close(); });
+    }
+    st.repart = since(t_rep);
   }
   if (o.until == "repart") return 0;
 
-  // wall-clock per stage (one line on stderr at the end; parsed by scripts/bench_pipeline.py)
-  using clk = std::chrono::steady_clock;
-  const auto t_start = clk::now();
-  double s_read = 0, s_split = 0, s_count = 0, s_merge_io = 0, s_merge = 0;
-  uint64_t n_bases = 0, n_kmers = 0, n_merge_recs = 0;
-  auto since = [](clk::time_point t) { return std::chrono::duration<double>(clk::now() - t).count(); };
+  // ---- the partitions to process (task_scheduler.hpp:121-160) ----
+  std::vector<uint32_t> plist = o.restrict_list;
+  if (plist.empty()) {
+    for (uint32_t p = 0; p < P; p++) plist.push_back(p);
+    if (o.restrict_to != 1.0) {
+      std::random_device rdev; std::mt19937 gen(rdev()); std::shuffle(plist.begin(), plist.end(), gen);
+      size_t n = (size_t)(P * o.restrict_to); if (n == 0) n = 1;
+      plist.resize(n);
+    }
+  }
+  std::vector<uint8_t> selected(P, 0); for (uint32_t p : plist) selected[p] = 1;
+
   auto report = [&]() {
-    fprintf(stderr, "[kmx pipeline] {\"samples\": %u, \"partitions\": %u, \"bases\": %llu, \"kmers\": %llu, \"merge_records\": %llu, "
-                    "\"read_s\": %.4f, \"superk_s\": %.4f, \"count_s\": %.4f, \"merge_io_s\": %.4f, \"merge_s\": %.4f, \"total_s\": %.4f}\n",
-            N, P, (unsigned long long)n_bases, (unsigned long long)n_kmers, (unsigned long long)n_merge_recs,
-            s_read, s_split, s_count, s_merge_io, s_merge, since(t_start));
+    fprintf(stderr, "[kmx pipeline] {\"samples\": %u, \"partitions\": %u, \"gpus\": %u, \"threads\": %u, \"bases\": %llu, \"kmers\": %llu, \"merge_records\": %llu, "
+                    "\"repart_s\": %.4f, \"read_s\": %.4f, \"superk_s\": %.4f, \"count_s\": %.4f, \"merge_io_s\": %.4f, \"merge_s\": %.4f, \"format_s\": %.4f, \"total_s\": %.4f}\n",
+            N, P, G, o.threads, (unsigned long long)st.bases.load(), (unsigned long long)st.kmers.load(), (unsigned long long)st.merge_recs.load(),
+            st.repart, st.read, st.split, st.count, st.merge_io, st.merge, st.format, since(t_start));
   };
-  Ctx gpu(o.gpus);
-  // ---- superk + count, sample by sample (task_scheduler.hpp:251-348) ----
-  // A reader thread parses the FASTA/FASTQ files one batch ahead of the device (a sample's files are read one
-  // after another, io/fof.hpp:82-87); the main thread splits and counts.
-  struct ReadBatch { uint32_t si; bool last; std::string bases; std::vector<uint64_t> offs; };
-  std::mutex qm; std::condition_variable qcv; std::deque<ReadBatch> rq; bool reader_done = false;
-  std::thread reader([&]() {
-    auto push = [&](ReadBatch&& b) {
-      std::unique_lock<std::mutex> lk(qm);
-      qcv.wait(lk, [&]() { return rq.size() < 2; });
-      rq.push_back(std::move(b)); qcv.notify_all();
-    };
-    for (uint32_t si = 0; si < N; si++) {
-      ReadBatch b; b.si = si; b.last = false; b.offs.assign(1, 0);
-      for (const std::string& f : samples[si].files) {
-        SeqReader rd(f); std::string seq;
-        auto t0 = clk::now();
-        while (rd.next(seq)) {
-          b.bases += seq; b.offs.push_back(b.bases.size());
-          if (b.bases.size() > (256u << 20)) {
-            s_read += since(t0);
-            push(std::move(b));
-            b = ReadBatch(); b.si = si; b.last = false; b.offs.assign(1, 0);
-            t0 = clk::now();
+  auto count_path = [&](uint32_t p, uint32_t si) {
+    return root + "/counts/partition_" + std::to_string(p) + "/" + samples[si].id + (hash_mode ? ".hash" : (o.cpr ? ".kmer.lz4" : ".kmer"));
+  };
+
+  // ================= superk + count, sample by sample (task_scheduler.hpp:251-348) =================
+  // Readers (pool threads) parse a sample's files into batches of reads; the worker of GPU (sample mod G) splits every batch
+  // (kmx_superk_partition[_stats]) and, at the sample's last batch, counts all its partitions (kmx_count_batch) and hands the
+  // count files to the pool for writing.
+  {
+    struct ReadBatch { uint32_t si = 0; bool last = false; std::string bases; std::vector<uint64_t> offs; };
+    std::vector<std::unique_ptr<Channel<ReadBatch>>> chan;
+    for (uint32_t g = 0; g < G; g++) chan.emplace_back(new Channel<ReadBatch>(3));
+    std::mutex tm; double s_read = 0, s_split = 0, s_count = 0;
+    // readers: one pool task per sample, at most `readers` in flight per GPU queue (bounded by the channel)
+    const uint32_t readers = std::max<uint32_t>(1, std::min<uint32_t>(o.threads > 1 ? o.threads - 1 : 1, 8));
+    std::atomic<uint32_t> next_sample{0};
+    // A sample's batches must reach its worker in order; samples are taken in fof order by `readers` threads per round so the
+    // GPU workers see them nearly in order too.
+    auto reader_fn = [&]() {
+      for (uint32_t si; (si = next_sample++) < N;) {
+        Channel<ReadBatch>& ch = *chan[si % G];
+        ReadBatch b; b.si = si; b.offs.assign(1, 0);
+        double rs = 0;
+        try {
+          for (const std::string& f : samples[si].files) {
+            SeqReader rd(f); std::string seq;
+            auto t = clk::now();
+            while (rd.next(seq)) {
+              b.bases += seq; b.offs.push_back(b.bases.size());
+              if (b.bases.size() > (256u << 20)) {
+                rs += since(t);
+                ch.push(std::move(b));
+                b = ReadBatch(); b.si = si; b.offs.assign(1, 0);
+                t = clk::now();
+              }
+            }
+            rs += since(t);
           }
+        } catch (const std::exception& e) { die(e.what()); }
+        b.last = true; ch.push(std::move(b));
+        std::lock_guard<std::mutex> lk(tm); s_read += rs;
+      }
+    };
+    std::vector<std::thread> rthreads;
+    for (uint32_t r = 0; r < readers; r++) rthreads.emplace_back(reader_fn);
+
+    struct SampleState {
+      std::vector<std::vector<uint8_t>> streams; std::vector<uint64_t> nk;
+      std::vector<uint64_t> pc, ms, mk; uint64_t nb_superk = 0;
+    };
+    std::atomic<uint32_t> samples_left{N};
+    std::vector<uint32_t> per_gpu(G, 0); for (uint32_t si = 0; si < N; si++) per_gpu[si % G]++;
+    auto worker_fn = [&](uint32_t g) {
+      kmx_ctx* c = gpu[g];
+      std::map<uint32_t, SampleState> open;
+      std::deque<std::future<void>> writes;
+      uint32_t done = 0;
+      double w_split = 0, w_count = 0;
+      const uint64_t nm = 1ULL << (2 * o.msize);
+      while (done < per_gpu[g]) {
+        ReadBatch b;
+        if (!chan[g]->pop(b)) break;
+        SampleState& S = open[b.si];
+        if (S.streams.empty()) { S.streams.resize(P); S.nk.assign(P, 0); if (!o.skip_pinfo) { S.pc.assign((size_t)P * KMX_PINFO_STRIDE, 0); S.ms.assign(nm, 0); S.mk.assign(nm, 0); } }
+        if (b.offs.size() > 1) {
+          const auto t = clk::now();
+          tlog(g, "split_begin", b.si);
+          st.bases += b.bases.size();
+          std::vector<uint8_t*> ob(P); std::vector<uint64_t> ol(P), ok(P);
+          if (o.skip_pinfo) chk(c, kmx_superk_partition(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, ob.data(), ol.data(), ok.data()), "kmx_superk_partition");
+          else {
+            kmx_superk_stats ks{}; ks.part_counters = S.pc.data(); ks.minim_superks = S.ms.data(); ks.minim_kmers = S.mk.data();
+            chk(c, kmx_superk_partition_stats(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, ob.data(), ol.data(), ok.data(), &ks), "kmx_superk_partition_stats");
+            S.nb_superk += ks.nb_superk;
+          }
+          for (uint32_t p = 0; p < P; p++) {
+            if (selected[p]) { S.streams[p].insert(S.streams[p].end(), ob[p], ob[p] + ol[p]); S.nk[p] += ok[p]; }   // --restrict-to: other partitions are dropped (superk_storage.hpp:301)
+            kmx_free(ob[p]);
+          }
+          tlog(g, "split_end", b.si);
+          w_split += since(t);
         }
-        s_read += since(t0);
+        if (!b.last) continue;
+        // ---- the sample is complete ----
+        const uint32_t si = b.si; const Sample& smp = samples[si];
+        uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) nkt += S.nk[p];
+        st.kmers += nkt;
+        { std::string s; for (uint32_t p = 0; p < P; p++) { s += std::to_string(S.nk[p]); s += "\n"; }   // gatb_utils.hpp:46-51
+          Out pi(root + "/partition_infos/" + smp.id + ".pinfo"); pi.raw(s.data(), s.size()); pi.close(); }
+        const std::string sd = root + "/superkmers/" + smp.id; fs::create_directories(sd);
+        {
+          std::string info = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
+          const bool files = o.keep_tmp || o.until == "superk";
+          for (uint32_t p = 0; p < P; p++) {
+            uint64_t kmp = 0, bfl = 0;
+            if (files && selected[p]) {
+              SuperkBlockWriter w(sd + "/skp." + std::to_string(p), p, o.cpr);
+              w.add_stream(S.streams[p].data(), S.streams[p].size(), o.k);
+              kmp = w.kmers; bfl = w.bytes;
+              uint64_t a = 0, bb = 0; superk_info_numbers(S.streams[p].data(), S.streams[p].size(), o.k, &a, &bb);
+              kmp = a; bfl = bb;                      // saved before the final flush, like task.hpp:315-316 (Appendix B-4)
+              w.flush(); w.out.close();
+            } else if (selected[p]) superk_info_numbers(S.streams[p].data(), S.streams[p].size(), o.k, &kmp, &bfl);
+            info += std::to_string(kmp) + "\n" + std::to_string(bfl) + "\n";
+          }
+          Out f(sd + "/SuperKmerBinInfoFile"); f.raw(info.data(), info.size()); f.close();
+        }
+        if (!o.skip_pinfo) {
+          auto pc = std::make_shared<std::vector<uint64_t>>(std::move(S.pc)); auto ms = std::make_shared<std::vector<uint64_t>>(std::move(S.ms)); auto mk = std::make_shared<std::vector<uint64_t>>(std::move(S.mk));
+          const uint64_t nsk = S.nb_superk;
+          writes.push_back(pool.submit([=]() { try { write_parti_info(sd + "/PartiInfoFile", P, nm, nsk, nkt, pc->data(), ms->data(), mk->data()); } catch (const std::exception& e) { die(e.what()); } }));
+        }
+        if (o.until != "superk") {
+          const auto t = clk::now();
+          tlog(g, "count_begin", si);
+          // CountTask / HashCountTask over the sample's partitions (task.hpp:367-392, 447-481): groups of partitions whose
+          // k-mers and bytes stay below libkmx's 2^32 per-call limits; a partition beyond them by itself goes alone
+          std::vector<uint32_t> grp; uint64_t gk = 0, gb = 0;
+          auto run_group = [&]() {
+            if (grp.empty()) return;
+            const uint32_t n = (uint32_t)grp.size();
+            std::vector<const uint8_t*> sp(n); std::vector<uint64_t> sl(n), pid(n), cnt(n);
+            std::vector<uint64_t*> keys(n, nullptr); std::vector<uint32_t*> cnts(n, nullptr);
+            for (uint32_t i = 0; i < n; i++) { sp[i] = S.streams[grp[i]].data(); sl[i] = S.streams[grp[i]].size(); pid[i] = grp[i]; }
+            chk(c, kmx_count_batch(c, n, sp.data(), sl.data(), o.k, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, pid.data(), smp.hard_min,
+                                   keys.data(), cnts.data(), cnt.data()), "kmx_count_batch");
+            for (uint32_t i = 0; i < n; i++) {
+              const uint32_t p = grp[i]; uint64_t* kk = keys[i]; uint32_t* cc = cnts[i]; const uint64_t nn = cnt[i];
+              std::vector<uint8_t>().swap(S.streams[p]);
+              writes.push_back(pool.submit([=, &o]() {
+                try { if (hash_mode) write_hash_file(count_path(p, si), si, p, kk, cc, nn); else write_kmer_file(count_path(p, si), o.k, si, p, kk, cc, nn, o.cpr); }
+                catch (const std::exception& e) { die(e.what()); }
+                kmx_free(kk); kmx_free(cc);
+              }));
+            }
+            grp.clear(); gk = 0; gb = 0;
+          };
+          const uint64_t LIM = 0x7FFFFFFFULL;
+          for (uint32_t p : plist) {
+            const uint64_t nkp = S.nk[p], nbp = S.streams[p].size();
+            if (nkp >= 0xFFFFFF00ULL || nbp >= 0xFFFFFF00ULL) die("sample " + smp.id + ", partition " + std::to_string(p) + ": more than 2^32 k-mers in one partition; use more partitions");
+            if (!grp.empty() && (gk + nkp > LIM || gb + nbp > LIM)) run_group();
+            grp.push_back(p); gk += nkp; gb += nbp;
+          }
+          run_group();
+          tlog(g, "count_end", si);
+          w_count += since(t);
+        }
+        open.erase(si);
+        done++;
+        while (writes.size() > 4u * P) { writes.front().get(); writes.pop_front(); }
       }
-      b.last = true; push(std::move(b));
-    }
-    { std::lock_guard<std::mutex> lk(qm); reader_done = true; } qcv.notify_all();
-  });
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
-  for (uint32_t si = 0; si < N; si++) {
-    const Sample& S = samples[si];
-    kmx_ctx* c = gpu.c[si % gpu.c.size()];
-    std::vector<std::vector<uint8_t>> streams(P);
-    std::vector<uint64_t> nk(P, 0);
-    for (;;) {
-      ReadBatch b;
-      { std::unique_lock<std::mutex> lk(qm); qcv.wait(lk, [&]() { return !rq.empty(); }); b = std::move(rq.front()); rq.pop_front(); qcv.notify_all(); }
-      if (b.offs.size() > 1) {
-        const auto t0 = clk::now();
-        n_bases += b.bases.size();
-        std::vector<uint8_t*> ob(P); std::vector<uint64_t> ol(P), ok(P);
-        chk(c, kmx_superk_partition(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, ob.data(), ol.data(), ok.data()), "kmx_superk_partition");
-        for (uint32_t p = 0; p < P; p++) { streams[p].insert(streams[p].end(), ob[p], ob[p] + ol[p]); nk[p] += ok[p]; kmx_free(ob[p]); }
-        s_split += since(t0);
-      }
-      if (b.last) break;
-    }
-    for (uint32_t p = 0; p < P; p++) n_kmers += nk[p];
-    { std::ofstream pi(root + "/partition_infos/" + S.id + ".pinfo"); for (uint32_t p = 0; p < P; p++) pi << nk[p] << "\n"; }   // gatb_utils.hpp:46-51
-    if (o.keep_tmp || o.until == "superk") {
-      const std::string sd = root + "/superkmers/" + S.id; fs::create_directories(sd);
-      std::ofstream info(sd + "/SuperKmerBinInfoFile"); info << "skp\n" << sd << "\n" << P << "\n";
-      for (uint32_t p = 0; p < P; p++) {
-        SuperkBlockWriter w(sd + "/skp." + std::to_string(p), p);
-        w.add_stream(streams[p].data(), streams[p].size(), o.k);
-        info << w.kmers << "\n" << w.bytes << "\n";       // saved before the final flush, like task.hpp:315-316 (Appendix B-4)
-        w.flush();
-      }
-    }
-    if (o.until == "superk") continue;
-    const auto t_count = clk::now();
-    {   // every partition of the sample in one device pass (CountTask / HashCountTask, task.hpp:367-392, 447-481)
-      std::vector<const uint8_t*> sp(P); std::vector<uint64_t> sl(P), pid(P), n(P);
-      std::vector<uint64_t*> keys(P, nullptr); std::vector<uint32_t*> cnts(P, nullptr);
-      for (uint32_t p = 0; p < P; p++) { sp[p] = streams[p].data(); sl[p] = streams[p].size(); pid[p] = p; }
-      chk(c, kmx_count_batch(c, P, sp.data(), sl.data(), o.k, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, pid.data(), S.hard_min,
-                             keys.data(), cnts.data(), n.data()), "kmx_count_batch");
-      for (uint32_t p = 0; p < P; p++) {
-        const std::string cp = root + "/counts/partition_" + std::to_string(p) + "/" + S.id + (hash_mode ? ".hash" : ".kmer");
-        if (hash_mode) write_hash_file(cp, si, p, keys[p], cnts[p], n[p]);
-        else write_kmer_file(cp, o.k, si, p, keys[p], cnts[p], n[p]);
-        kmx_free(keys[p]); kmx_free(cnts[p]);
-      }
-    }
-    s_count += since(t_count);
+      for (auto& w : writes) w.get();
+      std::lock_guard<std::mutex> lk(tm); s_split += w_split; s_count += w_count;
+      (void)samples_left;
+    };
+    std::vector<std::thread> wthreads;
+    for (uint32_t g = 0; g < G; g++) wthreads.emplace_back(worker_fn, g);
+    for (auto& t : rthreads) t.join();
+    for (auto& t : wthreads) t.join();
+    st.read = s_read; st.split = s_split; st.count = s_count;
   }
   if (o.until == "superk" || o.until == "count") { report(); return 0; }
 
-  // ---- merge, one task per partition (task_scheduler.hpp:381-417) ----
+  // ================= merge, one task per partition (task_scheduler.hpp:381-417), batched per GPU =================
   Plugin plug; if (!o.plugin.empty()) plug.load(o.plugin, o.k);
   std::vector<uint32_t> soft(N, o.soft_min);
-  // the count files of partition p + 1 are read while partition p is merged
-  auto load_partition = [&](uint32_t p) {
-    std::vector<std::vector<uint8_t>> r(N);
-    for (uint32_t i = 0; i < N; i++) {
-      const std::string cp = root + "/counts/partition_" + std::to_string(p) + "/" + samples[i].id + (hash_mode ? ".hash" : ".kmer");
-      if (!fs::exists(cp)) die(cp + " is missing.");                                  // kmdir.hpp:69-70
-      r[i] = hash_mode ? read_hash_records(cp, nullptr) : read_kmer_records(cp, nullptr, nullptr);
-    }
-    return r;
-  };
-  std::future<std::vector<std::vector<uint8_t>>> next_recs;
-  if (P) next_recs = std::async(std::launch::async, load_partition, 0u);
-  for (uint32_t p = 0; p < P; p++) {
-    kmx_ctx* c = gpu.of_partition(p);
-    auto t_io = clk::now();
-    std::vector<std::vector<uint8_t>> recs = next_recs.get(); std::vector<kmx_list> lists(N);
-    if (p + 1 < P) next_recs = std::async(std::launch::async, load_partition, p + 1);
-    for (uint32_t i = 0; i < N; i++) {
-      lists[i].recs = recs[i].data(); lists[i].n = recs[i].size() / ((hash_mode ? 1 : kw) * 8 + 4);
-      n_merge_recs += lists[i].n;
-    }
-    s_merge_io += since(t_io);
-    kmx_merge_task t{};
-    t.n_lists = N; t.key_words = hash_mode ? 1 : kw; t.lists = lists.data(); t.soft_min = soft.data();
-    t.rec_min = o.rec_min; t.share_min = o.share_min; t.bitw = o.bitw;
-    t.mode = what == "count" ? KMX_MODE_COUNT : what == "pa" ? KMX_MODE_PA : what == "bf" ? KMX_MODE_BF : KMX_MODE_BFC;
-    if (what == "bf" || what == "bfc") { t.lower = hw.lower(p); t.upper = hw.upper(p); }
-    km::IMergePlugin* pl = nullptr;
-    if (plug.create) {   // the plugin's return value replaces the recurrence test: produce every row, filter on the host
-      pl = plug.create(); pl->configure(o.plugin_config);                              // plugin_manager.hpp:106-111
-      pl->set_out_dir(root + "/plugin_output"); pl->set_kmer_size(hash_mode ? 0 : o.k); pl->set_partition(p);   // task.hpp:701-712
-      t.rec_min = 0; t.mode = KMX_MODE_COUNT;
-    }
-    void* body = nullptr; uint64_t nbytes = 0, rows = 0; std::vector<uint64_t> stats((size_t)6 * N);
-    const auto t_m = clk::now();
-    chk(c, kmx_merge(c, &t, &body, &nbytes, &rows, stats.data()), "kmx_merge");
-    s_merge += since(t_m);
-    t_io = clk::now();
-    const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
-    Out out(root + "/matrices/matrix_" + std::to_string(p) + "." + ext);
-    if (what == "count") { if (hash_mode) matrix_count_hash_header(out, N, p); else matrix_count_header(out, o.k, N, p); }
-    else if (what == "pa") { if (hash_mode) matrix_pa_hash_header(out, N, p); else matrix_pa_header(out, o.k, N, p); }
-    else matrix_bf_header(out, what == "bf" ? N : N * o.bitw, t.lower, t.upper - t.lower + 1, p);
-    if (!pl) out.raw(body, nbytes);
-    else {
-      const uint32_t kb = t.key_words * 8; const size_t rb = kb + 4ull * N;
-      std::vector<km::IMergePlugin::count_type> cv(N); std::vector<uint8_t> pa((N + 7) / 8);
-      uint64_t last_key[2] = {0, 0};
-      for (uint64_t r = 0; r <= rows; r++) {   // r == rows: the reference's extra call after the last row (merge.hpp:185-259)
-        const uint8_t* row = (const uint8_t*)body + r * rb;
-        if (r < rows) { memcpy(last_key, row, kb); for (uint32_t i = 0; i < N; i++) { uint32_t v; memcpy(&v, row + kb + 4 * i, 4); cv[i] = (km::IMergePlugin::count_type)v; } }
-        else std::fill(cv.begin(), cv.end(), 0);
-        const bool keep = hash_mode ? pl->process_hash(last_key[0], cv) : pl->process_kmer(last_key, cv);
-        if (r == rows || !keep) continue;
-        out.raw(last_key, kb);
-        if (what == "count") for (uint32_t i = 0; i < N; i++) { const uint32_t v = (uint32_t)cv[i]; out.raw(&v, 4); }
-        else { std::fill(pa.begin(), pa.end(), 0); for (uint32_t i = 0; i < N; i++) if (cv[i]) pa[i >> 3] |= (uint8_t)(1u << (i & 7)); out.raw(pa.data(), pa.size()); }
+  const bool is_bloom = what == "bf" || what == "bfc" || what == "bft";
+  const uint32_t mkw = hash_mode ? 1 : kw;
+  const size_t rec_bytes = mkw * 8 + 4;
+  // per-sample Bloom filter files (hash:bft:bin): filters/<id>.bf = header + u64 number of bits + for p = 0..P-1 the sample's row of
+  // partition p's transposed matrix (howde_utils.hpp:133-187)
+  if (what == "bft") {
+    const auto t = clk::now();
+    uint8_t hdr[BF_HEADER_BYTES]; bf_header(hdr, o.k, hw.bloom);
+    pool.for_each(N, [&](size_t i) {
+      const std::string path = root + "/filters/" + samples[i].id + ".bf";
+      const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
+      if (fd < 0) die("Unable to write at " + path);
+      const uint64_t bits = hw.bloom;
+      if (pwrite(fd, hdr, BF_HEADER_BYTES, 0) != (ssize_t)BF_HEADER_BYTES || pwrite(fd, &bits, 8, BF_HEADER_BYTES) != 8 ||
+          ftruncate(fd, (off_t)(BF_HEADER_BYTES + 8 + hw.bloom / 8)) != 0) die("write failed: " + path);
+      close(fd);
+    });
+    st.format += since(t);
+  }
+  {
+    std::mutex tm; double s_io = 0, s_merge = 0, s_format = 0;
+    struct PartIn { uint32_t p = 0; std::vector<kmx_list> lists; };
+    struct Batch { std::vector<PartIn> parts; uint8_t* buf = nullptr; uint64_t bytes = 0; double io_s = 0; };
+    struct Pinned { uint8_t* p = nullptr; uint64_t cap = 0; void need(uint64_t n) { if (n <= cap) return; kmx_free_pinned(p); cap = n + n / 8 + (1u << 20); p = (uint8_t*)kmx_alloc_pinned(cap); if (!p) die("pinned host allocation failed"); } ~Pinned() { kmx_free_pinned(p); } };
+
+    auto worker_fn = [&](uint32_t g) {
+      kmx_ctx* c = gpu[g];
+      std::vector<uint32_t> mine;
+      for (size_t i = g; i < plist.size(); i += G) mine.push_back(plist[i]);       // partitions shard round-robin, no collective
+      if (mine.empty()) return;
+      // batches: count-file bytes (+ Bloom image bytes) up to the budget
+      const uint64_t budget = std::max<uint64_t>(o.merge_batch_mb, 16) << 20;
+      std::vector<std::vector<uint32_t>> batches; std::vector<std::vector<uint64_t>> fsize;   // per batch: partitions, file sizes [part][sample]
+      {
+        std::vector<uint32_t> cur; std::vector<uint64_t> cur_sz; uint64_t acc = 0;
+        for (uint32_t p : mine) {
+          uint64_t pb = 0; std::vector<uint64_t> sz(N);
+          for (uint32_t i = 0; i < N; i++) { std::error_code ec; sz[i] = fs::file_size(count_path(p, i), ec); if (ec) die(count_path(p, i) + " is missing."); pb += sz[i]; }   // kmdir.hpp:69-70
+          if (is_bloom) pb += hw.wbits * (uint64_t)(what == "bfc" ? ((uint64_t)N * o.bitw + 7) / 8 : (N + 7) / 8) * (what == "bft" ? 2 : 1);
+          if (!cur.empty() && (acc + pb > budget || cur.size() >= 64)) { batches.push_back(cur); fsize.push_back(cur_sz); cur.clear(); cur_sz.clear(); acc = 0; }
+          cur.push_back(p); cur_sz.insert(cur_sz.end(), sz.begin(), sz.end()); acc += pb;
+        }
+        if (!cur.empty()) { batches.push_back(cur); fsize.push_back(cur_sz); }
       }
-      plug.destroy(pl);
-    }
-    kmx_free(body);
-    write_merge_info(root + "/merge_infos/partition" + std::to_string(p) + ".merge_info", stats.data(), N);
-    if (what == "bf") {   // task.hpp:849-860 + utils.hpp:239-243
-      std::ofstream fp(root + "/fpr/partition_" + std::to_string(p) + ".txt");
-      for (uint32_t i = 0; i < N; i++) fp << std::fixed << std::pow(1.0 - std::pow(std::exp(1.0), -(double)stats[(size_t)3 * N + i] / (double)hw.wbits), 1.0) << "\n";
-    }
-    if (!o.keep_tmp)                                                                  // task.hpp:676-688
-      for (uint32_t i = 0; i < N; i++) fs::remove(root + "/counts/partition_" + std::to_string(p) + "/" + samples[i].id + (hash_mode ? ".hash" : ".kmer"));
-    s_merge_io += since(t_io);
+      Pinned pin[2];
+      // loader: the count files of a batch into one pinned buffer, lists back to back (kmx_merge_host then needs one copy)
+      auto load = [&](size_t bi, Batch& B) {
+        const auto t = clk::now();
+        const auto& parts = batches[bi]; const auto& sz = fsize[bi];
+        const bool direct = !hash_mode && !o.cpr;       // our own .kmer files: 41-byte header, then the records exactly as kmx_list wants them
+        B.parts.resize(parts.size());
+        if (direct) {
+          std::vector<uint64_t> off(parts.size() * N + 1, 0);
+          for (size_t j = 0; j < parts.size() * N; j++) { if (sz[j] < 41) die("Invalid file format: " + count_path(parts[j / N], (uint32_t)(j % N))); off[j + 1] = off[j] + (sz[j] - 41) / rec_bytes * rec_bytes; }
+          B.bytes = off.back(); pin[bi & 1].need(B.bytes + 64); B.buf = pin[bi & 1].p;
+          for (size_t a = 0; a < parts.size(); a++) { B.parts[a].p = parts[a]; B.parts[a].lists.resize(N); }
+          pool.for_each(parts.size() * N, [&](size_t j) {
+            const uint32_t p = parts[j / N], i = (uint32_t)(j % N);
+            const std::string path = count_path(p, i);
+            const int fd = open(path.c_str(), O_RDONLY); if (fd < 0) die("Unable to read at " + path);
+            uint8_t h[41]; if (pread(fd, h, 41, 0) != 41 || rd<uint64_t>(h) != MAGIC_BASE || rd<uint64_t>(h + 13) != MAGIC_KMER || h[12] != 0 || rd<uint32_t>(h + 29) != 4 || rd<uint32_t>(h + 25) != kw) { close(fd); die("Invalid file format: " + path); }
+            const uint64_t nb = off[j + 1] - off[j]; uint64_t got = 0;
+            while (got < nb) { const ssize_t r = pread(fd, B.buf + off[j] + got, nb - got, (off_t)(41 + got)); if (r <= 0) break; got += (uint64_t)r; }
+            close(fd);
+            if (got != nb) die("short read: " + path);
+            B.parts[j / N].lists[i].recs = B.buf + off[j]; B.parts[j / N].lists[i].n = nb / rec_bytes;
+          });
+        } else {
+          std::vector<std::vector<uint8_t>> recs(parts.size() * N);
+          pool.for_each(parts.size() * N, [&](size_t j) {
+            const std::string path = count_path(parts[j / N], (uint32_t)(j % N));
+            try { recs[j] = hash_mode ? read_hash_records(path, nullptr) : read_kmer_records(path, nullptr, nullptr); } catch (const std::exception& e) { die(e.what()); }
+          });
+          std::vector<uint64_t> off(recs.size() + 1, 0);
+          for (size_t j = 0; j < recs.size(); j++) off[j + 1] = off[j] + recs[j].size();
+          B.bytes = off.back(); pin[bi & 1].need(B.bytes + 64); B.buf = pin[bi & 1].p;
+          for (size_t a = 0; a < parts.size(); a++) { B.parts[a].p = parts[a]; B.parts[a].lists.resize(N); }
+          pool.for_each(recs.size(), [&](size_t j) {
+            if (!recs[j].empty()) memcpy(B.buf + off[j], recs[j].data(), recs[j].size());
+            B.parts[j / N].lists[j % N].recs = B.buf + off[j]; B.parts[j / N].lists[j % N].n = recs[j].size() / rec_bytes;
+          });
+        }
+        B.io_s = since(t);
+      };
+      struct Flight { kmx_merge_result* R = nullptr; Batch B; std::vector<kmx_merge_task> tasks; };
+      std::deque<std::future<void>> writes;
+      double w_io = 0, w_merge = 0, w_format = 0;
+      // output of a finished batch: bodies + statistics back, files written on the pool
+      auto finish = [&](Flight& F) {
+        auto t = clk::now();
+        chk(c, kmx_result_wait(F.R), "kmx_merge");
+        w_merge += since(t);
+        t = clk::now();
+        for (size_t a = 0; a < F.B.parts.size(); a++) {
+          const uint32_t p = F.B.parts[a].p;
+          const uint64_t nbytes = kmx_result_body_bytes(F.R, (uint32_t)a), rows = kmx_result_rows(F.R, (uint32_t)a);
+          auto body = std::make_shared<std::vector<uint8_t>>(nbytes);
+          auto stats = std::make_shared<std::vector<uint64_t>>((size_t)6 * N);
+          chk(c, kmx_result_copy_body(F.R, (uint32_t)a, body->data(), nbytes), "kmx_result_copy_body");
+          chk(c, kmx_result_copy_stats(F.R, (uint32_t)a, stats->data()), "kmx_result_copy_stats");
+          tlog(g, "merge_done", p);
+          const kmx_merge_task T = F.tasks[a];
+          writes.push_back(pool.submit([=, &o, &plug, &samples, &hw, &tm, &s_format]() {
+            try {
+              const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
+              const bool lz4_name = o.cpr && !hash_mode && !is_bloom;                       // hash-mode matrices never get the suffix (task.hpp:794-795)
+              const bool cpr_body = o.cpr && !is_bloom;
+              Out out(root + "/matrices/matrix_" + std::to_string(p) + "." + ext + (lz4_name ? ".lz4" : ""));
+              if (what == "count") { if (hash_mode) matrix_count_hash_header(out, N, p, cpr_body); else matrix_count_header(out, o.k, N, p, cpr_body); }
+              else if (what == "pa") { if (hash_mode) matrix_pa_hash_header(out, N, p, cpr_body); else matrix_pa_header(out, o.k, N, p, cpr_body); }
+              else matrix_bf_header(out, what == "bfc" ? N * o.bitw : N, T.lower, T.upper - T.lower + 1, p);
+              km::IMergePlugin* pl = nullptr;
+              if (plug.create) {
+                pl = plug.create(); pl->configure(o.plugin_config);                              // plugin_manager.hpp:106-111
+                pl->set_out_dir(root + "/plugin_output"); pl->set_kmer_size(hash_mode ? 0 : o.k); pl->set_partition(p);   // task.hpp:701-712
+              }
+              if (!pl) out.raw(body->data(), body->size());
+              else {   // the plugin's return value replaces the recurrence test: every row was produced, filter here
+                const uint32_t kb = T.key_words * 8; const size_t rb = kb + 4ull * N;
+                std::vector<km::IMergePlugin::count_type> cv(N); std::vector<uint8_t> pa((N + 7) / 8);
+                uint64_t last_key[2] = {0, 0};
+                for (uint64_t r = 0; r <= rows; r++) {   // r == rows: the reference's extra call after the last row (merge.hpp:185-259)
+                  const uint8_t* row = body->data() + r * rb;
+                  if (r < rows) { memcpy(last_key, row, kb); for (uint32_t i = 0; i < N; i++) { uint32_t v; memcpy(&v, row + kb + 4 * i, 4); cv[i] = (km::IMergePlugin::count_type)v; } }
+                  else std::fill(cv.begin(), cv.end(), 0);
+                  const bool keep = hash_mode ? pl->process_hash(last_key[0], cv) : pl->process_kmer(last_key, cv);
+                  if (r == rows || !keep) continue;
+                  out.raw(last_key, kb);
+                  if (what == "count") for (uint32_t i = 0; i < N; i++) { const uint32_t v = (uint32_t)cv[i]; out.raw(&v, 4); }
+                  else { std::fill(pa.begin(), pa.end(), 0); for (uint32_t i = 0; i < N; i++) if (cv[i]) pa[i >> 3] |= (uint8_t)(1u << (i & 7)); out.raw(pa.data(), pa.size()); }
+                }
+                plug.destroy(pl);
+              }
+              out.close();
+              write_merge_info(root + "/merge_infos/partition" + std::to_string(p) + ".merge_info", stats->data(), N);
+              if (what == "bf" || what == "bft") {   // task.hpp:849-860 + utils.hpp:239-243
+                std::ostringstream fp;
+                for (uint32_t i = 0; i < N; i++) fp << std::fixed << std::pow(1.0 - std::pow(std::exp(1.0), -(double)(*stats)[(size_t)3 * N + i] / (double)hw.wbits), 1.0) << "\n";
+                Out f(root + "/fpr/partition_" + std::to_string(p) + ".txt"); const std::string s = fp.str(); f.raw(s.data(), s.size()); f.close();
+              }
+              if (what == "bft") {   // sample i's row of this partition -> its place in filters/<id>.bf
+                const auto tf = clk::now();
+                const uint64_t rowb = hw.wbits / 8;
+                for (uint32_t i = 0; i < N; i++) {
+                  const std::string path = root + "/filters/" + samples[i].id + ".bf";
+                  const int fd = open(path.c_str(), O_WRONLY); if (fd < 0) die("Unable to write at " + path);
+                  const off_t at = (off_t)(BF_HEADER_BYTES + 8 + (uint64_t)p * rowb); uint64_t done = 0;
+                  while (done < rowb) { const ssize_t r = pwrite(fd, body->data() + (uint64_t)i * rowb + done, rowb - done, at + (off_t)done); if (r <= 0) break; done += (uint64_t)r; }
+                  close(fd);
+                  if (done != rowb) die("write failed: " + path);
+                }
+                std::lock_guard<std::mutex> lk(tm); s_format += since(tf);
+              }
+              if (!o.keep_tmp) for (uint32_t i = 0; i < N; i++) fs::remove(count_path(p, i));   // task.hpp:676-688
+            } catch (const std::exception& e) { die(e.what()); }
+          }));
+        }
+        kmx_result_free(F.R); F.R = nullptr;
+        w_io += since(t);
+        while (writes.size() > 128) { writes.front().get(); writes.pop_front(); }
+      };
+      Batch next; std::future<void> fut;
+      auto start_load = [&](size_t bi) { next = Batch(); fut = std::async(std::launch::async, [&, bi]() { load(bi, next); }); };
+      start_load(0);
+      std::unique_ptr<Flight> prev;
+      for (size_t bi = 0; bi < batches.size(); bi++) {
+        fut.get();
+        std::unique_ptr<Flight> F(new Flight()); F->B = std::move(next);
+        w_io += F->B.io_s;
+        F->tasks.resize(F->B.parts.size());
+        for (size_t a = 0; a < F->B.parts.size(); a++) {
+          kmx_merge_task& t = F->tasks[a]; t = kmx_merge_task{};
+          const uint32_t p = F->B.parts[a].p;
+          t.n_lists = N; t.key_words = mkw; t.lists = F->B.parts[a].lists.data(); t.soft_min = soft.data();
+          t.rec_min = o.rec_min; t.share_min = o.share_min; t.bitw = o.bitw;
+          t.mode = what == "count" ? KMX_MODE_COUNT : what == "pa" ? KMX_MODE_PA : what == "bf" ? KMX_MODE_BF : what == "bfc" ? KMX_MODE_BFC : KMX_MODE_BFT;
+          if (is_bloom) { t.lower = hw.lower(p); t.upper = hw.upper(p); }
+          if (plug.create) { t.rec_min = 0; t.mode = KMX_MODE_COUNT; }
+          for (uint32_t i = 0; i < N; i++) st.merge_recs += t.lists[i].n;
+        }
+        tlog(g, "merge_submit", F->B.parts[0].p);
+        const auto t = clk::now();
+        chk(c, kmx_merge_host(c, F->tasks.data(), (uint32_t)F->tasks.size(), &F->R), "kmx_merge_host");
+        w_merge += since(t);
+        if (prev) finish(*prev);                 // (its pinned buffer is free again: the next load may take it)
+        else if (bi + 1 < batches.size()) { /* the other buffer has never been used */ }
+        if (bi + 1 < batches.size()) start_load(bi + 1);
+        prev = std::move(F);
+      }
+      if (prev) finish(*prev);
+      for (auto& w : writes) w.get();
+      std::lock_guard<std::mutex> lk(tm); s_io += w_io; s_merge += w_merge; s_format += w_format;
+    };
+    std::vector<std::thread> wthreads;
+    for (uint32_t g = 0; g < G; g++) wthreads.emplace_back(worker_fn, g);
+    for (auto& t : wthreads) t.join();
+    st.merge_io = s_io; st.merge = s_merge; st.format += s_format;
   }
   report();
   struct rusage ru; getrusage(RUSAGE_SELF, &ru);
   { std::ofstream ri(root + "/run_infos.txt");                                         // task_scheduler.hpp:453-457
-    ri << "Time: " << std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() << " seconds\n"
+    ri << "Time: " << std::chrono::duration_cast<std::chrono::seconds>(clk::now() - t0).count() << " seconds\n"
        << "Memory: " << ru.ru_maxrss / 1024 << "MB\n"; }
   return 0;
+}
+
+int main(int argc, char** argv)
+{
+  try { return run(argc, argv); }
+  catch (const std::exception& e) { die(e.what()); }
 }

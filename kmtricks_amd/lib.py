@@ -74,7 +74,12 @@ _lib.kmx_superk_partition_stats.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.
                                             C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                             C.POINTER(KmxSuperkStats)]
 
-EXPORTS = ["kmx_version", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+_lib.kmx_merge_host.argtypes = [_vp, C.POINTER(KmxMergeTask), C.c_uint32, C.POINTER(_vp)]
+_lib.kmx_alloc_pinned.restype = _vp
+_lib.kmx_alloc_pinned.argtypes = [C.c_size_t]
+_lib.kmx_free_pinned.argtypes = [_vp]
+
+EXPORTS = ["kmx_version", "kmx_device_count", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -253,6 +258,16 @@ class Context:
         assert st.nb_superk == int(ms.sum())
         return out, pin.reshape(nb_parts, -1), ms, mk, mx
 
+    def superk_sample(self, reads, k, m, budget):
+        """kmx_superk_sample -> (reads used, their super-k-mers, kx-mers per minimizer)"""
+        blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
+        mx = np.zeros(4 ** m, dtype=np.uint64)
+        st = KmxSuperkStats(None, None, None, mx.ctypes.data, 0)
+        used, nsk = C.c_uint64(), C.c_uint64()
+        self._check(_lib.kmx_superk_sample(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, budget, C.byref(st),
+                                           C.byref(used), C.byref(nsk)), "kmx_superk_sample")
+        return used.value, nsk.value, mx
+
     def prepare(self, tasks):
         """Builds the kmx_merge_task array once (so a timed loop does no Python marshalling).
         tasks: list of dicts with keys lists=[(device_ptr, n)], key_words, soft_min, rec_min, share_min,
@@ -263,6 +278,13 @@ class Context:
             arr[i] = self._task(d["lists"], d["key_words"], d["soft_min"], d["rec_min"], d["share_min"], d["mode"],
                                 d.get("lower", 0), d.get("upper", 0), d.get("bitw", 2), d.get("rows_hint", 0), keep)
         return (arr, len(tasks), [len(d["lists"]) for d in tasks], keep)
+
+    def merge_host(self, tasks):
+        """kmx_merge_host: like merge_dev with HOST record pointers (uploaded by libkmx on its upload stream)"""
+        prep = tasks if isinstance(tasks, tuple) else self.prepare(tasks)
+        res = _vp()
+        self._check(_lib.kmx_merge_host(self._h, prep[0], prep[1], C.byref(res)), "kmx_merge_host")
+        return MergeResult(self, res, prep[2])
 
     def merge_dev(self, tasks):
         """Device-resident batch merge (kmx_merge_dev) of a task list or a prepare()d batch.

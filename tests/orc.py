@@ -6,6 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _lib = C.CDLL(os.path.join(ROOT, "oracle", "libkmx_oracle.so"))
 
+_lib2 = C.CDLL(os.path.join(ROOT, "oracle", "libkmx_oracle_repart.so"))
+_lib2.orc_repart_sampled.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
 u8p, u16p, u32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64))
 
 
@@ -125,6 +127,15 @@ def superk_stats(seqs, k, m, lut, repart, nb_parts):
     for p in range(nb_parts):
         _lib.orc_buf_free(C.byref(bufs[p]))
     return pinfo.reshape(nb_parts, -1), ms, mk, mx
+
+
+def repart_sampled(minim_kxmers, nb_parts):
+    """Repartitor::computeDistrib (gatb PartiInfo.cpp:48-103) on kx-mers per minimizer"""
+    mx = np.ascontiguousarray(minim_kxmers, dtype=np.uint64)
+    out = np.zeros(len(mx), dtype=np.uint16)
+    rc = _lib2.orc_repart_sampled(mx.ctypes.data, len(mx), nb_parts, out.ctypes.data)
+    assert rc == 0
+    return out
 
 
 def superk_decode(recs: bytes, k):

@@ -172,3 +172,15 @@ def test_transpose_roundtrip():
         bits = np.unpackbits(m.reshape(nr, nc // 8), axis=1, bitorder="little")
         tb = np.unpackbits(t.reshape(nc, nr // 8), axis=1, bitorder="little")
         assert np.array_equal(bits.T, tb)
+
+
+def test_sampled_repartition_reproduces_the_reference_table():
+    """gatb's sampled repartition (RepartitionAlgorithm.cpp:182-215 kx-mers per minimizer of the sampled reads, PartiInfo.cpp:48-103
+    computeDistrib) on the reference's two test samples (k = 31, m = 10, 4 partitions) == its committed
+    tests/data/repart_gatb/repartition.minimRepart, all 4^10 entries"""
+    lut = orc.minimizer_lut(10)
+    reads = read_fasta(os.path.join(GD, "1.fasta")) + read_fasta(os.path.join(GD, "2.fasta"))
+    pin, ms, mk, mx = orc.superk_stats(reads, 31, 10, lut, repart_table(), 4)
+    assert int(mk.sum()) == sum(G["task_main"]["superk_info_D1"][1::2]) + sum(G["task_main"]["superk_info_D2"][1::2])
+    assert [int(x) for x in pin[:, 0]] == [a + b for a, b in zip(G["task_main"]["superk_info_D1"][1::2], G["task_main"]["superk_info_D2"][1::2])]
+    assert np.array_equal(orc.repart_sampled(mx, 4), repart_table())

@@ -145,9 +145,166 @@ def test_plugin_pipeline(inputs, tmp_path):
 def test_cli_errors(inputs, tmp_path):
     r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 1 and "already exists" in r.stderr          # src/cli.cpp:101-104
-    r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "x"), "--mode", "hash:bft:bin"],
+    r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "x"), "--mode", "hash:bfx:bin"],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "not supported" in r.stderr
+    r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "y"), "--mode", "hash:bft:bin",
+                        "--restrict-to-list", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "requires all partitions" in r.stderr  # cmd/all.hpp:137-143
+    (tmp_path / "bad.fof").write_text(f"D1 : {tmp_path}/missing.fasta\n")
+    r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "bad.fof"), "--run-dir", str(tmp_path / "z"), "--static-repart"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "[error]" in r.stderr and "missing.fasta" in r.stderr   # an unreadable input is an error line, not an abort
+
+
+def test_bft_pipeline_and_filters(inputs, tmp_path):
+    """hash:bft:bin end to end (BASELINE configs[3] in small): matrix_<p>.cmbf = HashMerger::write_as_bft (merge.hpp:631-644) and
+    filters/<id>.bf = header + u64 bits + the sample's row of every partition (howde_utils.hpp:133-187)"""
+    out = run(inputs, tmp_path / "run", "--mode", "hash:bft:bin", "--bloom-size", "1000000", "--soft-min", "1", "--share-min", "1")
+    W = 250048
+    lists = oracle_lists(True, W)
+    rows_of = {0: [], 1: []}
+    for p in range(P):
+        raw = open(out / "matrices" / f"matrix_{p}.cmbf", "rb").read()
+        assert struct.unpack("<QIBQIQQII", raw[:49]) == (kmfiles.KM_MAGIC, 0, 0, 0x74616d746962, 2, W * p, W, 0, p)
+        body, rows, stats = orc.merge_matrix([(h, c) for h, c in lists[p]], 1, [1, 1], 1, 1, orc.MODE_BFT, W * p, W * (p + 1) - 1)
+        assert rows == 8 and raw[49:] == body
+        for s in (0, 1):
+            rows_of[s].append(body[s * (W // 8):(s + 1) * (W // 8)])
+        fpr = [float(x) for x in open(out / "fpr" / f"partition_{p}.txt").read().split()]
+        assert np.allclose(fpr, [1.0 - np.exp(-float(n) / W) for n in stats[3]], atol=1e-6)
+    for s, name in enumerate(("D1", "D2")):
+        bf = open(out / "filters" / f"{name}.bf", "rb").read()
+        assert len(bf) == 112 + 8 + 4 * W // 8
+        magic, hsize, version, kind, _pad, ksz, nh = struct.unpack("<QIIIIII", bf[:32])
+        assert (hsize, kind, ksz, nh) == (112, 1, 31, 1)
+        assert struct.unpack("<QQ", bf[48:64]) == (4 * W, 4 * W)             # hashModulus, numBits = bloom size
+        assert struct.unpack("<IIQQQ", bf[80:112]) == (1, 0, 112, 4 * W // 8 + 8, 0)
+        assert struct.unpack("<Q", bf[112:120]) == (4 * W,)
+        assert bf[120:] == b"".join(rows_of[s])
+        # the filter holds exactly the sample's window hashes (soft-min 1)
+        bits = np.unpackbits(np.frombuffer(bf[120:], np.uint8), bitorder="little")
+        hs = np.concatenate([lists[p][s][0] for p in range(P)]).astype(np.int64)
+        assert np.array_equal(np.nonzero(bits)[0], np.sort(hs))
+
+
+def test_sampled_repartition(tmp_path):
+    """the default `kmtricks pipeline` (no --static-repart): gatb's sampled repartition (RepartitionAlgorithm.cpp:395-496,
+    PartiInfo.cpp:48-103) on the reference's two test samples reproduces its committed tests/data/repart_gatb table"""
+    (tmp_path / "t.fof").write_text(f"D1 : {GD}/1.fasta\nD2 : {GD}/2.fasta\n")
+    out = tmp_path / "run"
+    r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "t.fof"), "--run-dir", str(out), "--kmer-size", "31", "--hard-min", "1",
+                        "--nb-partitions", "4", "--until", "repart"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(out / "repartition_gatb" / "repartition.minimRepart", "rb").read()
+    assert len(raw) == G["repartition_table"]["file_size"]
+    got = np.frombuffer(raw[12:12 + 2 * 4 ** 10], np.uint16)
+    assert np.array_equal(got, repart_table())
+    # the table of a cohort balances the kx-mers of the sampled reads: no partition is empty, loads within a few percent
+    reads = _synthetic_samples(tmp_path, 3, 60_000, 5)
+    out2 = tmp_path / "run2"
+    r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out2), "--kmer-size", "31", "--nb-partitions", "8",
+                        "--until", "repart"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tab = np.frombuffer(open(out2 / "repartition_gatb" / "repartition.minimRepart", "rb").read()[12:12 + 2 * 4 ** 10], np.uint16)
+    lut = orc.minimizer_lut(10)
+    _, _, _, mx = orc.superk_stats([x for rs in reads for x in rs], 31, 10, lut, np.zeros(4 ** 10, np.uint16), 1)
+    exp = orc.repart_sampled(mx, 8)
+    assert np.array_equal(tab, exp)
+    load = np.bincount(tab, weights=mx.astype(np.float64), minlength=8)
+    assert load.min() > 0.9 * load.mean()
+
+
+def test_cpr_and_restrict(inputs, tmp_path):
+    """--cpr: lz4-framed count files and matrix bodies decompress to the uncompressed run's bytes; --restrict-to-list"""
+    import ctypes
+    lz4 = ctypes.CDLL("liblz4.so.1")
+    def unlz4(b):
+        dctx = ctypes.c_void_p()
+        assert lz4.LZ4F_createDecompressionContext(ctypes.byref(dctx), 100) == 0
+        lz4.LZ4F_decompress.restype = ctypes.c_size_t
+        out = bytearray(); src = ctypes.create_string_buffer(b, len(b)); pos = 0
+        while pos < len(b):
+            dst = ctypes.create_string_buffer(1 << 16); dn = ctypes.c_size_t(1 << 16); sn = ctypes.c_size_t(len(b) - pos)
+            r = lz4.LZ4F_decompress(dctx, dst, ctypes.byref(dn), ctypes.byref(src, pos), ctypes.byref(sn), None)
+            assert not lz4.LZ4F_isError(ctypes.c_size_t(r))
+            out += dst.raw[:dn.value]; pos += sn.value
+            if r == 0 and dn.value == 0 and sn.value == 0: break
+        return bytes(out)
+    plain = run(inputs, tmp_path / "plain", "--mode", "kmer:count:bin", "--keep-tmp")
+    cpr = run(inputs, tmp_path / "cpr", "--mode", "kmer:count:bin", "--keep-tmp", "--cpr")
+    for p in range(P):
+        a = open(plain / "matrices" / f"matrix_{p}.count", "rb").read()
+        b = open(cpr / "matrices" / f"matrix_{p}.count.lz4", "rb").read()
+        assert b[12] == 1 and a[:12] == b[:12] and a[13:45] == b[13:45] and unlz4(b[45:]) == a[45:]
+        for s in ("D1", "D2"):
+            a = open(plain / "counts" / f"partition_{p}" / f"{s}.kmer", "rb").read()
+            b = open(cpr / "counts" / f"partition_{p}" / f"{s}.kmer.lz4", "rb").read()
+            assert b[12] == 1 and unlz4(b[41:]) == a[41:]
+            a = open(plain / "superkmers" / s / f"skp.{p}", "rb").read()
+            b = open(cpr / "superkmers" / s / f"skp.{p}", "rb").read()
+            assert b[12] == 1 and unlz4(b[25:]) == a[25:]
+    hc = run(inputs, tmp_path / "hcpr", "--mode", "hash:pa:bin", "--cpr", "--bloom-size", "1000000")
+    hp = run(inputs, tmp_path / "hplain", "--mode", "hash:pa:bin", "--bloom-size", "1000000")
+    for p in range(P):   # hash-mode matrices keep their name, the body is an lz4 frame (task.hpp:794-795, 817)
+        a = open(hp / "matrices" / f"matrix_{p}.pa_hash", "rb").read(); b = open(hc / "matrices" / f"matrix_{p}.pa_hash", "rb").read()
+        assert b[12] == 1 and unlz4(b[37:]) == a[37:]
+    sub = run(inputs, tmp_path / "sub", "--mode", "kmer:count:bin", "--restrict-to-list", "1,3")
+    assert sorted(os.listdir(sub / "matrices")) == ["matrix_1.count", "matrix_3.count"]
+    for p in (1, 3):
+        assert open(sub / "matrices" / f"matrix_{p}.count", "rb").read() == open(plain / "matrices" / f"matrix_{p}.count", "rb").read()
+
+
+def test_parti_info_file(inputs, tmp_path):
+    """superkmers/<id>/PartiInfoFile (gatb PartiInfo.hpp:266-287) from the HIP split's statistics == the oracle's PartiInfo<5>"""
+    out = run(inputs, tmp_path / "run", "--mode", "kmer:count:bin", "--until", "superk")
+    lut = orc.minimizer_lut(M); rep = repart_table()
+    for name, f in (("D1", "1.fasta"), ("D2", "2.fasta")):
+        pin, ms, mk, _ = orc.superk_stats(read_fasta(os.path.join(GD, f)), K, M, lut, rep, P)
+        lines = [int(x) for x in open(out / "superkmers" / name / "PartiInfoFile").read().split()]
+        assert len(lines) == 4 + P * 1282 + 3 * 4 ** M
+        assert lines[:4] == [P, 4 ** M, int(ms.sum()), int(mk.sum())]
+        assert lines[4:4 + P * 1282] == [int(x) for x in pin.reshape(-1)]
+        tail = np.array(lines[4 + P * 1282:], dtype=np.uint64).reshape(-1, 3)
+        assert np.array_equal(tail[:, 0], ms) and np.array_equal(tail[:, 1], mk) and not tail[:, 2].any()
+        assert (out / "superkmers" / name / "skp.0").is_file()
+    cfg = open(out / "config_gatb" / "gatb.config", "rb").read()
+    assert len(cfg) == 140 and struct.unpack("<QQ", cfg[:16]) == (31, 10) and struct.unpack("<I", cfg[128:132]) == (4,)
+
+
+def test_two_gpu_workers_same_output(tmp_path):
+    """--gpus 2 (two worker threads with a context each; on a one-GPU box both on device 0): samples and partitions shard
+    round-robin, both workers are in flight at once (KMX_TRACE time stamps overlap) and the run directory is the one --gpus 1 writes"""
+    reads = _synthetic_samples(tmp_path, 8, 200_000, 3)
+    outs = []
+    for gp in (1, 2):
+        out = tmp_path / f"run{gp}"
+        r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out), "--kmer-size", "31", "--nb-partitions", "16",
+                            "--static-repart", "--recurrence-min", "2", "--gpus", str(gp), "--merge-batch-mb", "16", "--keep-tmp"], capture_output=True, text=True,
+                           env=dict(os.environ, KMX_TRACE="1"))
+        assert r.returncode == 0, r.stderr
+        outs.append((out, r.stderr))
+    for sub in ("matrices", "merge_infos", "partition_infos"):
+        names = sorted(os.listdir(outs[0][0] / sub))
+        assert names == sorted(os.listdir(outs[1][0] / sub)) and names
+        for n in names:
+            assert open(outs[0][0] / sub / n, "rb").read() == open(outs[1][0] / sub / n, "rb").read(), (sub, n)
+    for p in range(16):
+        for s in range(8):
+            n = f"partition_{p}/S{s:04d}.kmer"
+            assert open(outs[0][0] / "counts" / n, "rb").read() == open(outs[1][0] / "counts" / n, "rb").read()
+    # overlap: some split/count interval of worker 0 intersects one of worker 1
+    ev = {0: [], 1: []}
+    open_at = {}
+    for line in outs[1][1].splitlines():
+        if not line.startswith("[kmx trace]"): continue
+        t, g, what_, ident = line.split()[2:6]
+        t = float(t); g = int(g.split("=")[1])
+        base = what_.rsplit("_", 1)[0]
+        if what_.endswith("_begin"): open_at[(g, base, ident)] = t
+        elif what_.endswith("_end"): ev[g].append((open_at.pop((g, base, ident)), t))
+    assert ev[0] and ev[1]
+    assert any(a0 < b1 and a1 < b0 for a0, b0 in ev[0] for a1, b1 in ev[1])
 
 
 def _synthetic_samples(d, n_samples, genome_len, seed):
