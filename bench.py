@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- k-mers merged/s of the MI355X-native kmtricks merge (libkmx, C ABI).
 
-Workload = BASELINE.json configs[2]: 1000 synthetic samples, k=31, kmer:count:bin
-(`--hard-min 2 --recurrence-min 2 --soft-min 1`), 256 minimizer partitions of a 5 Mbp
-ancestor genome with substitution rate 0.001.  Partitions are
-independent, so they shard over GPUs with no collective: every rank merges
-`--partitions-per-gpu` partitions per step (32 = the 8-GPU sharding of the 256-partition
-job; weak scaling).  A step = one kmx_merge_dev batch over this rank's partitions, inputs
-(sorted per-sample count lists = .kmer file bodies) already resident in HBM.
+Default workload = BASELINE.json configs[2]: 1000 synthetic samples, k=31, kmer:count:bin
+(`--hard-min 2 --recurrence-min 2 --soft-min 1`), 256 minimizer partitions (static repartition) of a
+5 Mbp ancestor genome with substitution rate 0.001.  Partitions are independent, so
+they shard over GPUs with no collective: every rank merges `--partitions-per-gpu` partitions per step
+(32 = the 8-GPU sharding of the 256-partition job; weak scaling).  A step = one kmx_merge_dev batch over
+this rank's partitions, inputs (sorted per-sample count lists = .kmer file bodies) resident in HBM.
 
-The per-partition count lists are generated directly (the FASTQ -> super-k-mer -> count
-stages are not part of the timed merge stage): each partition has G/P shared ancestor
-k-mers, present in a sample with probability (1-d)^k, plus the sample's private k-mers
-created by its substitutions; counts ~ 2 + Poisson-like coverage.  Random data, seeded.
+Where the lists come from (`--lists`):
+  counted (default)  the product's own count stage: every sample's genome (the ancestor with its substitutions) goes
+                     through kmx_superk_partition + kmx_count_batch, and the (k-mer, count) lists of this rank's
+                     partitions are what the merge is timed on -- the key distribution of real minimizer partitions
+                     (setup, not timed: about a minute for 1000 samples);
+  random             uniform random 62-bit keys with the same sharing model (G/P shared k-mers present with
+                     probability (1-d)^k, the rest private) -- the round-1 generator, seconds to set up.
+
+Other workloads (`--workload`), each with its own roofline line:
+  bf     configs[1]: 100 samples, hash:bf:bin, bloom 1e8, 32 partitions on one GPU
+  pa63   configs[4]: 500 samples, k=63 (128-bit keys), kmer:pa:bin, 64 of 256 partitions per GPU
+  bft    configs[3]: 2500 samples, hash:bft:bin --soft-min 2 --share-min 1 (merge + on-device transpose; with more than
+         one rank the per-sample Bloom rows are exchanged with one all-to-all over RCCL, kmtricks_amd/shard.py)
 
 Prints ONE JSON line on rank 0.
 """
@@ -22,8 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def gen_partition(torch, dev, seed, n_samples, shared, p_present, n_private):
-    """-> (records int32[R,3] on dev, offsets list[n_samples+1])  AoS: key lo, key hi, count"""
+# ---------------------------------------------------------------------------------------------- generators
+def gen_partition(torch, dev, seed, n_samples, shared, p_present, n_private, kw=1):
+    """random keys -> (records int32[R, 2*kw+1] on dev, offsets list[n_samples+1])  AoS: key words (low first), count"""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     INF = (1 << 62)
@@ -34,33 +43,107 @@ def gen_partition(torch, dev, seed, n_samples, shared, p_present, n_private):
     keys = torch.cat([keys, priv], dim=1)
     keys, _ = torch.sort(keys, dim=1)
     valid = keys < INF
-    # drop (astronomically unlikely) duplicates inside a list to keep lists strictly ascending
-    dup = torch.zeros_like(valid)
+    dup = torch.zeros_like(valid)                     # (astronomically unlikely) duplicates inside a list
     dup[:, 1:] = keys[:, 1:] == keys[:, :-1]
     valid &= ~dup
     n_i = valid.sum(dim=1)
     flat = keys[valid]
     R = flat.numel()
     counts = torch.randint(2, 12, (R,), generator=g, device=dev, dtype=torch.int32)
-    rec = torch.empty((R, 3), device=dev, dtype=torch.int32)
-    rec[:, :2] = flat.view(torch.int32).view(R, 2)
-    rec[:, 2] = counts
+    rec = torch.zeros((R, 2 * kw + 1), device=dev, dtype=torch.int32)
+    if kw == 1:
+        rec[:, :2] = flat.view(torch.int32).view(R, 2)
+    else:
+        # 128-bit keys that still ascend: the random value is the HIGH word (most significant first, kmer.hpp:262-268),
+        # the low word a mix of it
+        rec[:, 2:4] = flat.view(torch.int32).view(R, 2)
+        rec[:, :2] = (flat * 0x1E3779B97F4A7C15 + 12345).view(torch.int32).view(R, 2)
+    rec[:, 2 * kw] = counts
     offs = [0] + torch.cumsum(n_i, 0).tolist()
     return rec, offs
 
 
+def gen_hash_partition(torch, dev, g, N, per_list, lo, W, p_shared=0.969):
+    """hash-mode lists of one partition: window hashes are uniform in [lo, lo + W) whatever the k-mers are"""
+    pool = torch.randint(lo, lo + W, (per_list,), generator=g, device=dev, dtype=torch.int64)
+    recs, offs = [], [0]
+    for _ in range(N):
+        keep = torch.rand(per_list, generator=g, device=dev) < p_shared
+        priv = torch.randint(lo, lo + W, (int(per_list * (1 - p_shared)),), generator=g, device=dev, dtype=torch.int64)
+        h = torch.unique(torch.cat([pool[keep], priv]))                  # sorted, distinct (colliding k-mers are summed)
+        r = torch.empty((h.numel(), 3), device=dev, dtype=torch.int32)
+        r[:, :2] = h.view(torch.int32).view(-1, 2)
+        r[:, 2] = torch.randint(1, 12, (h.numel(),), generator=g, device=dev, dtype=torch.int32)
+        recs.append(r); offs.append(offs[-1] + h.numel())
+    return torch.cat(recs), offs
+
+
+def xxh64_u32(v):
+    """XXH64(&v, 4, seed 0) of a numpy uint32 array (static repartition, repartition.hpp:45-56)"""
+    import numpy as np
+    P1, P2, P3, P5 = (np.uint64(x) for x in (0x9E3779B185EBCA87, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0x27D4EB2F165667C5))
+    with np.errstate(over="ignore"):
+        h = P5 + np.uint64(4)
+        h = h ^ (v.astype(np.uint64) * P1)
+        h = ((h << np.uint64(23)) | (h >> np.uint64(41))) * P2 + P3
+        h ^= h >> np.uint64(33); h *= P2; h ^= h >> np.uint64(29); h *= P3; h ^= h >> np.uint64(32)
+    return h
+
+
+def gen_counted(ctx, torch, dev, N, k, genome, d, total_parts, my_parts, seed, log):
+    """Lists produced by the product's count stage: sample i = ancestor genome with i.i.d. substitutions at rate d (PCG64 seeds of
+    SURVEY 8d), given twice so that every k-mer passes --hard-min 2; split with the static repartition of `total_parts`
+    partitions, counted; only this rank's partitions are kept.  -> [(records tensor, offsets)] per partition of my_parts."""
+    import numpy as np
+    m = 10
+    table = (xxh64_u32(np.arange(4 ** m, dtype=np.uint32)) % np.uint64(total_parts)).astype(np.uint16)
+    anc = np.random.Generator(np.random.PCG64(seed)).integers(0, 4, genome, dtype=np.uint8)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    kw = (k + 31) // 32
+    per_part = [[] for _ in my_parts]
+    t0 = time.perf_counter()
+    for i in range(N):
+        rng = np.random.Generator(np.random.PCG64(seed + 1 + i))
+        gsm = anc.copy()
+        pos = np.nonzero(rng.random(genome) < d)[0]
+        gsm[pos] = (gsm[pos] + rng.integers(1, 4, len(pos), dtype=np.uint8)) & 3
+        seq = letters[gsm].tobytes()
+        offs = np.array([0, genome, 2 * genome], dtype=np.uint64)
+        streams = ctx.superk_partition((seq + seq, offs), k, m, table, total_parts)
+        res = ctx.count_batch([streams[p][0] for p in my_parts], k, 2)
+        for j, (keys, cnts) in enumerate(res):
+            n = len(cnts)
+            rec = np.empty((n, 2 * kw + 1), dtype=np.uint32)
+            rec[:, :2 * kw] = np.ascontiguousarray(keys, dtype=np.uint64).reshape(n, kw).view(np.uint32)
+            rec[:, 2 * kw] = cnts
+            per_part[j].append(rec)
+        if log and (i + 1) % 100 == 0:
+            print(f"[bench] counted lists: {i + 1}/{N} samples, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    parts = []
+    for lst in per_part:
+        offs = [0]
+        for r in lst:
+            offs.append(offs[-1] + len(r))
+        rec = torch.from_numpy(np.concatenate(lst).view(np.int32)).to(dev)
+        parts.append((rec, offs))
+    return parts
+
+
+# ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--samples", type=int, default=1000)
-    ap.add_argument("--partitions-per-gpu", type=int, default=32)
+    ap.add_argument("--workload", choices=["count", "bf", "pa63", "bft"], default="count")
+    ap.add_argument("--lists", choices=["counted", "random"], default="counted")
+    ap.add_argument("--samples", type=int, default=0)
+    ap.add_argument("--partitions-per-gpu", type=int, default=0)
     ap.add_argument("--total-partitions", type=int, default=256)
     ap.add_argument("--genome", type=float, default=5e6)
     ap.add_argument("--subst-rate", type=float, default=0.001)
-    ap.add_argument("--kmer-size", type=int, default=31)
-    ap.add_argument("--rec-min", type=int, default=2)
+    ap.add_argument("--rec-min", type=int, default=-1)
+    ap.add_argument("--bloom", type=float, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -68,6 +151,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -79,28 +163,52 @@ def main():
     ctx = lib.Context(local)
     ctx.set_profiling(True)
 
-    N, P = a.samples, a.partitions_per_gpu
-    shared = int(a.genome / a.total_partitions)
-    p_present = (1.0 - a.subst_rate) ** a.kmer_size
+    wl = a.workload
+    defaults = {"count": (1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 64, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
+    N = a.samples or defaults[0]
+    P = a.partitions_per_gpu or defaults[1]
+    k = defaults[2]
+    rec_min = a.rec_min if a.rec_min >= 0 else defaults[3]
+    kw = (k + 31) // 32
+    total_parts = a.total_partitions if wl != "bf" else 32
+    my_parts = shard.partitions_of_rank(P * world, world, rank)        # weak scaling: the job has P * world partitions
+    genome = int(a.genome)
+    shared = genome // total_parts
+    p_present = (1.0 - a.subst_rate) ** k
     n_private = int(round(shared * (1.0 - p_present)))
-    parts, total_recs = [], 0
-    # weak scaling: the job has P * world partitions, partition g belongs to rank g mod world
-    for g in shard.partitions_of_rank(P * world, world, rank):
-        rec, offs = gen_partition(torch, dev, 20240601 + g, N, shared, p_present, n_private)
-        parts.append((rec, offs))
-        total_recs += rec.shape[0]
-    torch.cuda.synchronize()
-
-    def make_tasks():
-        tasks = []
+    parts, tasks_d, label, mode = [], [], "", lib.MODE_COUNT
+    W = 0
+    if wl in ("count", "pa63"):
+        mode = lib.MODE_COUNT if wl == "count" else lib.MODE_PA
+        if a.lists == "counted":
+            parts = gen_counted(ctx, torch, dev, N, k, genome, a.subst_rate, total_parts, my_parts, 20240601, rank == 0)
+        else:
+            parts = [gen_partition(torch, dev, 20240601 + g, N, shared, p_present, n_private, kw) for g in my_parts]
+        rb = 8 * kw + 4
         for rec, offs in parts:
             base = rec.data_ptr()
-            lists = [(base + 12 * offs[i], offs[i + 1] - offs[i]) for i in range(N)]
-            tasks.append(dict(lists=lists, key_words=1, soft_min=[1] * N, rec_min=a.rec_min, share_min=0,
-                              mode=lib.MODE_COUNT, rows_hint=shared + 4096))
-        return tasks
-
-    tasks = ctx.prepare(make_tasks())
+            tasks_d.append(dict(lists=[(base + rb * offs[i], offs[i + 1] - offs[i]) for i in range(N)], key_words=kw, soft_min=[1] * N,
+                                rec_min=rec_min, share_min=0, mode=mode, rows_hint=(offs[-1] // N) * 5 // 4 + 4096))
+        label = (f"BASELINE configs[{2 if wl == 'count' else 4}]: {N} samples, k={k}, kmer:{'count' if wl == 'count' else 'pa'}:bin, recurrence-min {rec_min}, "
+                 f"{P} of {total_parts} partitions per GPU (G={genome} bp, d={a.subst_rate}), lists: "
+                 + ("count stage output (kmx_superk_partition + kmx_count_batch)" if a.lists == "counted" else "random 62-bit keys"))
+    else:
+        bloom = int(a.bloom) if a.bloom else (100_000_000 if wl == "bf" else 1_000_000_000)
+        W = ((bloom + total_parts - 1) // total_parts + 63) // 64 * 64      # hash.hpp:31-40
+        g = torch.Generator(device=dev); g.manual_seed(20240601 + rank)
+        mode = lib.MODE_BF if wl == "bf" else lib.MODE_BFT
+        smin, share = (1, 0) if wl == "bf" else (2, 1)
+        for p in my_parts:
+            rec, offs = gen_hash_partition(torch, dev, g, N, shared, W * p, W)
+            parts.append((rec, offs))
+            base = rec.data_ptr()
+            tasks_d.append(dict(lists=[(base + 12 * offs[i], offs[i + 1] - offs[i]) for i in range(N)], key_words=1, soft_min=[smin] * N,
+                                rec_min=rec_min, share_min=share, mode=mode, lower=W * p, upper=W * (p + 1) - 1))
+        label = (f"BASELINE configs[{1 if wl == 'bf' else 3}]: {N} samples, k=31, hash:{wl}:bin, bloom {bloom:.0e} / {total_parts} partitions "
+                 f"(window {W} bits), soft-min {smin}, share-min {share}, {P} partitions per GPU and step (G={genome} bp)")
+    total_recs = sum(rec.shape[0] for rec, _ in parts)
+    torch.cuda.synchronize()
+    tasks = ctx.prepare(tasks_d)
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,7 +216,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, algo_bytes, rows_out, kernel_name = [], 0, 0, ""
+    kernel_ms, tr_ms, algo_bytes, rows_out, kernel_name = [], [], 0, 0, ""
+    xbuf = None
+    if wl == "bft" and world > 1:
+        n8 = (N + 7) // 8 * 8
+        xbuf = [torch.empty((n8, W // 8), dtype=torch.uint8, device=dev) for _ in range(P)]
 
     def run(n, record):
         """n steps = n kmx_merge_dev batches; batch i+1 is submitted before batch i is waited for (the host
@@ -119,8 +231,14 @@ def main():
         def finish(res):
             nonlocal algo_bytes, rows_out, kernel_name
             res.wait()
+            if xbuf is not None:      # per-sample Bloom rows to their owners: the one collective of the path (RCCL all-to-all)
+                for t in range(P):
+                    res.body_to_device(t, xbuf[t].data_ptr(), xbuf[t].numel())
+                shard.bloom_exchange(dist, xbuf, N, P * world, world, rank)
             if record:
                 kernel_ms.append(res.kernel_ms())
+                if wl == "bft":
+                    tr_ms.append(res.transpose_ms())
                 algo_bytes = sum(res.algo_bytes(t) for t in range(P))
                 rows_out = sum(res.rows(t) for t in range(P))
                 kernel_name = res.kernel()
@@ -147,25 +265,27 @@ def main():
         ms_step = dt / a.steps * 1e3
         value = job_recs * a.steps / dt
         kms = sum(kernel_ms) / max(1, len(kernel_ms))
+        # BFT: the launch priced is merge + transposes (the roofline's algorithmic bytes are records in + transposed matrix out)
+        if wl == "bft" and tr_ms:
+            kms += sum(tr_ms) / len(tr_ms)
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else None
+        kname = kernel_name + ("<1>" if wl == "pa63" and kernel_name != "k_merge_rows" else "") + (" + k_bit_transpose" if wl == "bft" else "")
         out = {
             "metric": "k-mers merged/s (merge stage, sum over partitions of input records / time)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 keys / u32 counts (integer)", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: {N} samples, k={a.kmer_size}, kmer:count:bin, "
-                                   f"recurrence-min {a.rec_min}, {P} of {a.total_partitions} partitions per GPU "
-                                   f"(G={a.genome:.0f} bp, d={a.subst_rate})",
+            "dtype": ("u128" if kw == 2 else "u64") + " keys / u32 counts (integer)", "data": "synthetic",
+            "config": {"workload": label,
                        "records_per_step_per_gpu": total_recs, "rows_out_per_step_per_gpu": rows_out,
-                       "parallelism": f"partitions sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"partitions sharded over {world} GPU(s), " + ("per-sample Bloom rows exchanged by one RCCL all-to-all" if xbuf is not None else "no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(a, N, P, kernel_name),
-                         "kernel": kernel_name + ("" if kernel_name == "k_merge_cols" else "<1,0>"), "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(wl, a.lists, N, P, kernel_name),
+                         "kernel": kname, "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
                          # streaming read rate of this access pattern measured on an MI355X (profiles/r01_h_fetch_calibration.txt)
                          "measured_stream_peak": 5654.0, "frac_of_measured": (achieved / 5654.0) if achieved else None},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(parts, N, a.rec_min)
+            out["cpu_baseline"] = cpu_baseline(parts, N, kw, tasks_d, mode)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -173,45 +293,63 @@ def main():
     ctx.close()
 
 
-def pmc_traffic(a, N, P, kernel):
+def pmc_traffic(wl, lists, N, P, kernel):
     """HBM bytes per launch of the merge kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE + WRITE_SIZE, profiles/merge_pmc.json) -- only when they were taken on this workload."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "merge_pmc.json")))
     except Exception:
         return None
-    key = f"configs[2] {N}x{P} G={a.genome:.0e} d={a.subst_rate} rec_min={a.rec_min}".replace("e+0", "e")
-    d = d.get(kernel, {})
-    return d["fetch_bytes"] + d["write_bytes"] if d.get("workload") == key else None
+    d = d.get(f"{wl}:{lists if wl in ('count', 'pa63') else 'uniform'}:{N}x{P}", {}).get(kernel, {})
+    return d["fetch_bytes"] + d["write_bytes"] if d else None
 
 
-def cpu_baseline(parts, N, rec_min, budget_s=12.0):
-    """The oracle (a port of the reference's KmerMerger linear-scan merge, merge.hpp:183-260) timed on one
-    host core over a bounded sample: whole partitions of the workload until ~budget_s seconds of CPU work."""
+def cpu_baseline(parts, N, kw, tasks_d, mode, budget_s=20.0):
+    """The oracle (a port of the reference's KmerMerger / HashMerger linear-scan merge, merge.hpp:183-260, 441-517, 575-644) on ALL
+    host cores with the reference's task granularity -- one merge task per partition handed to a pool of nproc threads
+    (task_scheduler.hpp:381-417) -- over a bounded sample: whole partitions of the workload until ~budget_s seconds of summed CPU work.
+    The checker timed as a baseline; never part of the measured GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import subprocess
+    from concurrent.futures import ThreadPoolExecutor
     so = os.path.join(ROOT, "oracle", "libkmx_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     import orc
-    total_dt, total_n, total_rows, used = 0.0, 0, 0, 0
-    for rec, offs in parts:
-        h = rec.cpu().numpy()
-        lists = []
+    omode = {0: orc.MODE_COUNT, 1: orc.MODE_PA, 2: orc.MODE_BF, 3: orc.MODE_BFC, 4: orc.MODE_BFT}[mode]
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # one partition on one core first: sizes the sample
+    def host_lists(j):
+        rec, offs = parts[j]
+        h = rec.cpu().numpy().view(np.uint32)
+        out = []
         for i in range(N):
             r = h[offs[i]:offs[i + 1]]
-            keys = np.ascontiguousarray(r[:, :2]).view(np.uint64).reshape(-1)
-            lists.append((keys, np.ascontiguousarray(r[:, 2]).view(np.uint32)))
+            out.append((np.ascontiguousarray(r[:, :2 * kw]).view(np.uint64).reshape(-1), np.ascontiguousarray(r[:, 2 * kw])))
+        return out
+
+    def merge(j, lists):
+        d = tasks_d[j]
         t0 = time.perf_counter()
-        body, rows, stats = orc.merge_matrix(lists, 1, [1] * N, rec_min, 0, orc.MODE_COUNT)
-        total_dt += time.perf_counter() - t0
-        total_n += int(offs[-1]); total_rows += rows; used += 1
-        if total_dt >= budget_s:
-            break
-    return {"value": total_n / total_dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-            "sample": f"{used} of the {len(parts)} partitions of the workload ({total_n} input records, {total_rows} rows out), "
-                      f"oracle linear-scan merge, {total_dt:.1f} s"}
+        body, rows, stats = orc.merge_matrix(lists, kw, d["soft_min"], d["rec_min"], d["share_min"], omode, d.get("lower", 0), d.get("upper", 0))
+        return time.perf_counter() - t0, rows
+
+    l0 = host_lists(0)
+    one_s, _ = merge(0, l0)
+    n_tasks = int(max(1, min(len(parts), budget_s / max(one_s, 1e-3))))
+    n_thr = max(1, min(nproc, n_tasks))
+    all_lists = [l0] + [host_lists(j) for j in range(1, n_tasks)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(n_thr) as ex:          # (ctypes releases the GIL: the merges run in parallel)
+        res = list(ex.map(lambda j: merge(j, all_lists[j]), range(n_tasks)))
+    wall = time.perf_counter() - t0
+    recs = sum(int(parts[j][1][-1]) for j in range(n_tasks))
+    return {"value": recs / wall, "unit": "k-mers/s", "cores": n_thr, "kind": "port",
+            "host_cores": nproc, "per_core": recs / sum(r[0] for r in res),
+            "sample": f"{n_tasks} of the {len(parts)} partitions of the step ({recs} input records, {sum(r[1] for r in res)} rows out), one merge task per "
+                      f"partition on a pool of {n_thr} threads (host has {nproc} cores), oracle linear-scan merge, {wall:.1f} s wall, "
+                      f"{sum(r[0] for r in res):.1f} s of CPU"}
 
 
 if __name__ == "__main__":

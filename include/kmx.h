@@ -135,6 +135,8 @@ uint64_t kmx_result_algo_bytes(const kmx_merge_result* r, uint32_t task);
 /* copies the matrix file body (rows in ascending key order, exactly what the
  * reference's writer streams after its header) into host memory */
 int kmx_result_copy_body(kmx_merge_result* r, uint32_t task, void* host_dst, uint64_t dst_bytes);
+/* BF / BFC / BFT: the same body into DEVICE memory of the caller (e.g. a buffer an RCCL collective sends from) */
+int kmx_result_copy_body_dev(kmx_merge_result* r, uint32_t task, void* dev_dst, uint64_t dst_bytes);
 int kmx_result_copy_stats(kmx_merge_result* r, uint32_t task, uint64_t* host_stats /* 6 * n_lists */);
 void kmx_result_free(kmx_merge_result* r);
 

@@ -846,6 +846,22 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
   return KMX_OK;
 }
 
+extern "C" int kmx_result_copy_body_dev(kmx_merge_result* R, uint32_t t, void* dev_dst, uint64_t dst_bytes)
+{
+  if (!R || t >= R->tasks.size()) return KMX_E_INVAL;
+  kmx_ctx* ctx = R->ctx;
+  if (!R->is_bf) return ctx->fail(KMX_E_UNSUPPORTED, "kmx_result_copy_body_dev: COUNT / PA rows lie in segments (use kmx_result_copy_body)");
+  int rc = kmx_result_wait(R);
+  if (rc != KMX_OK) return rc;
+  const u64 body = kmx_result_body_bytes(R, t);
+  if (dst_bytes < body) return ctx->fail(KMX_E_INVAL, "destination too small");
+  if (!body) return KMX_OK;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  KMX_HIP(ctx, hipMemcpyAsync(dev_dst, R->tasks[t].d_out, body, hipMemcpyDeviceToDevice, ctx->copy));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+  return KMX_OK;
+}
+
 extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* st)
 {
   if (!R || t >= R->tasks.size() || !st) return KMX_E_INVAL;

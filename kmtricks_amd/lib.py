@@ -49,6 +49,7 @@ for _f in ("kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes", "
     getattr(_lib, _f).argtypes = [_vp, C.c_uint32]
 _lib.kmx_result_copy_body.argtypes = [_vp, C.c_uint32, _vp, C.c_uint64]
 _lib.kmx_result_copy_stats.argtypes = [_vp, C.c_uint32, _vp]
+_lib.kmx_result_copy_body_dev.argtypes = [_vp, C.c_uint32, _vp, C.c_uint64]
 _lib.kmx_result_free.argtypes = [_vp]
 _lib.kmx_merge.argtypes = [_vp, C.POINTER(KmxMergeTask), C.POINTER(_vp), C.POINTER(C.c_uint64),
                            C.POINTER(C.c_uint64), _vp]
@@ -79,7 +80,7 @@ _lib.kmx_alloc_pinned.restype = _vp
 _lib.kmx_alloc_pinned.argtypes = [C.c_size_t]
 _lib.kmx_free_pinned.argtypes = [_vp]
 
-EXPORTS = ["kmx_version", "kmx_device_count", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_version", "kmx_device_count", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -332,6 +333,10 @@ class MergeResult:
         buf = np.zeros(max(nb, 1), dtype=np.uint8)
         self._ctx._check(_lib.kmx_result_copy_body(self._h, t, buf.ctypes.data, nb), "kmx_result_copy_body")
         return buf[:nb].tobytes()
+
+    def body_to_device(self, t, dev_ptr, nbytes):
+        """BF / BFC / BFT body -> device memory of the caller (a torch tensor's data_ptr())"""
+        self._ctx._check(_lib.kmx_result_copy_body_dev(self._h, t, dev_ptr, nbytes), "kmx_result_copy_body_dev")
 
     def stats(self, t=0):
         st = np.zeros((STATS_ROWS, self._n[t]), dtype=np.uint64)

@@ -39,6 +39,50 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _bloom_worker(rank, world, port, q, N, P, RB):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # matrix of partition p: row s, byte b = a value every rank can recompute
+    def mat(p):
+        s = torch.arange((N + 7) // 8 * 8, dtype=torch.int64).view(-1, 1)
+        b = torch.arange(RB, dtype=torch.int64).view(1, -1)
+        return ((s * 131 + p * 17 + b * 7) % 251).to(torch.uint8)
+    mats = [mat(p) for p in shard.partitions_of_rank(P, world, rank)]
+    out = shard.bloom_exchange(dist, mats, N, P, world, rank)
+    mine = shard.samples_of_rank(N, world, rank)
+    ok = out.shape == (len(mine), P, RB)
+    for j, s in enumerate(mine):
+        for p in range(P):
+            ok = ok and bool(torch.equal(out[j, p], mat(p)[s]))
+    q.put((rank, ok, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,P,RB", [(5, 4, 24), (11, 7, 8), (2, 2, 16)])
+def test_two_rank_gloo_bloom_exchange(N, P, RB):
+    """the per-sample Bloom-row all-to-all of hash:bft:bin (howde_utils.hpp:133-187 layout): after the exchange rank
+    s mod 2 holds, for each of its samples, the rows of ALL partitions in partition order"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bloom_worker, args=(r, 2, port, q, N, P, RB)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(ok for _, ok, _ in res)
+    assert sorted(x for _, _, mine in res for x in mine) == list(range(N))
+
+
+def test_bloom_exchange_single_rank():
+    mats = [torch.full((8, 4), p, dtype=torch.uint8) for p in range(3)]
+    out = shard.bloom_exchange(None, mats, 5, 3, 1, 0)
+    assert out.shape == (5, 3, 4) and all(int(out[:, p].max()) == p and int(out[:, p].min()) == p for p in range(3))
+
+
 def test_two_rank_gloo_reduction():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
