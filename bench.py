@@ -101,14 +101,18 @@ def gen_counted(ctx, torch, dev, N, k, genome, d, total_parts, my_parts, seed, l
     letters = np.frombuffer(b"ACGT", np.uint8)
     kw = (k + 31) // 32
     per_part = [[] for _ in my_parts]
+    L = 2000
+    starts = np.arange(0, genome - k + 1, L)
+    win = starts[:, None] + np.arange(L + k - 1)[None, :]                # (the last window runs into a tail of N's: no k-mers there)
+    offs = (np.arange(2 * len(starts) + 1, dtype=np.uint64) * np.uint64(L + k - 1))
     t0 = time.perf_counter()
     for i in range(N):
         rng = np.random.Generator(np.random.PCG64(seed + 1 + i))
         gsm = anc.copy()
         pos = np.nonzero(rng.random(genome) < d)[0]
         gsm[pos] = (gsm[pos] + rng.integers(1, 4, len(pos), dtype=np.uint8)) & 3
-        seq = letters[gsm].tobytes()
-        offs = np.array([0, genome, 2 * genome], dtype=np.uint64)
+        # the genome as overlapping 2 kb windows (every k-mer exactly once; a wave per read in the split), twice
+        seq = np.concatenate([letters[gsm], np.full(L, ord("N"), np.uint8)])[win].tobytes()
         streams = ctx.superk_partition((seq + seq, offs), k, m, table, total_parts)
         res = ctx.count_batch([streams[p][0] for p in my_parts], k, 2)
         for j, (keys, cnts) in enumerate(res):
@@ -188,7 +192,7 @@ def main():
         for rec, offs in parts:
             base = rec.data_ptr()
             tasks_d.append(dict(lists=[(base + rb * offs[i], offs[i + 1] - offs[i]) for i in range(N)], key_words=kw, soft_min=[1] * N,
-                                rec_min=rec_min, share_min=0, mode=mode, rows_hint=(offs[-1] // N) * 5 // 4 + 4096))
+                                rec_min=rec_min, share_min=0, mode=mode))      # (no rows_hint: libkmx sizes the arenas from the batches it has seen)
         label = (f"BASELINE configs[{2 if wl == 'count' else 4}]: {N} samples, k={k}, kmer:{'count' if wl == 'count' else 'pa'}:bin, recurrence-min {rec_min}, "
                  f"{P} of {total_parts} partitions per GPU (G={genome} bp, d={a.subst_rate}), lists: "
                  + ("count stage output (kmx_superk_partition + kmx_count_batch)" if a.lists == "counted" else "random 62-bit keys"))
@@ -266,10 +270,10 @@ def main():
         value = job_recs * a.steps / dt
         kms = sum(kernel_ms) / max(1, len(kernel_ms))
         # BFT: the launch priced is merge + transposes (the roofline's algorithmic bytes are records in + transposed matrix out)
-        if wl == "bft" and tr_ms:
+        if wl == "bft" and tr_ms and min(tr_ms) >= 0:      # (builds that transpose in a second pass)
             kms += sum(tr_ms) / len(tr_ms)
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else None
-        kname = kernel_name + ("<1>" if wl == "pa63" and kernel_name != "k_merge_rows" else "") + (" + k_bit_transpose" if wl == "bft" else "")
+        kname = kernel_name + ("<1>" if wl == "pa63" and kernel_name != "k_merge_rows" else "") + (" (+ k_bf_rowrec)" if wl == "bft" else "")
         out = {
             "metric": "k-mers merged/s (merge stage, sum over partitions of input records / time)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

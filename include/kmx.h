@@ -118,10 +118,11 @@ int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, k
 int      kmx_result_wait(kmx_merge_result* r);
 /* duration in ms of the batch's merge kernel launch (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
 double   kmx_result_kernel_ms(kmx_merge_result* r);
-/* name of the device kernel that produced (most of) the result: "k_merge_cols", "k_merge_pivot", "k_merge_rows"
- * or "k_merge_bf"; valid after kmx_result_wait (tasks a cohort kernel handed back count for the kernel that
+/* name of the device kernel that produced (most of) the result: "k_merge_cols", "k_merge_pivot", "k_merge_rows",
+ * "k_merge_bf" or "k_merge_bft"; valid after kmx_result_wait (tasks a cohort kernel handed back count for the kernel that
  * completed them) */
-/* BFT: duration in ms of the batch's transposes (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
+/* duration in ms of a separate transpose pass behind the merge; < 0 when there is none (KMX_MODE_BFT results come out
+ * of k_merge_bft sample-major already: kmx_result_kernel_ms covers k_bf_rowrec + k_merge_bft) */
 double   kmx_result_transpose_ms(kmx_merge_result* r);
 /* BF / BFC / BFT: DEVICE pointer to the task's dense body (rows * row_bytes bytes), valid until kmx_result_free;
  * NULL for COUNT / PA results (their rows lie in segments: use kmx_result_copy_body) */

@@ -124,7 +124,8 @@ struct TaskHost {
   // offsets into the meta blob
   size_t o_recs = 0, o_len = 0, o_smin = 0, o_bounds = 0, o_stats = 0, o_ctrl = 0, o_segs = 0;
   u8* d_out = nullptr; size_t out_bytes = 0;
-  u8* d_img = nullptr; size_t img_bytes = 0;   // BFT: the hash-major Bloom image k_merge_bf writes, transposed into d_out
+  u16* d_rowrec = nullptr;                      // BFT: recurrence per hash row (k_bf_rowrec)
+  u8* d_img = nullptr; size_t img_bytes = 0;   // (unused since k_merge_bft writes the transposed matrix directly)
   u64 t_rows = 0, t_cols = 0;                   // BFT: rows / columns of that image rounded up to 8 (merge.hpp:634)
   Seg* d_segs = nullptr;        // directory in use (inside the meta blob, or d_segs_own after a retry)
   Seg* d_segs_own = nullptr;
@@ -210,16 +211,12 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   if (R->is_bf) {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    if (R->is_bft)   // rows W .. round_up8(W) - 1 of the image are not written by the merge
-      for (auto& H : R->tasks) { const u64 W = H.upper - H.lower + 1; if (H.t_rows > W) KMX_HIP(ctx, hipMemsetAsync(H.d_img + W * H.row_bytes, 0, (H.t_rows - W) * H.row_bytes, ctx->stream)); }
+    if (R->is_bft) {   // sample-major matrix straight from the merge (merge_bft.hip): the rows' recurrences first, where they matter
+      const uint2* d_citems = reinterpret_cast<const uint2*>(R->d_meta + R->o_citems);
+      KMX_HIP(ctx, launch_bf_rowrec(d_tasks, d_items, R->n_items, R->max_n, ctx->stream));
+      KMX_HIP(ctx, launch_merge_bft(d_tasks, d_citems, R->n_citems, d_ticket, std::min(R->n_citems, (u32)ctx->n_cu * 2u), ctx->stream));
+    } else
     KMX_HIP(ctx, launch_merge_bf(mode == KMX_MODE_BFC, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->bf_lds, ctx->stream));
-    if (R->is_bft) {
-      if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
-      if (ctx->profiling && !R->ev2) { KMX_HIP(ctx, hipEventCreate(&R->ev2)); }
-      for (auto& H : R->tasks) KMX_HIP(ctx, launch_bit_transpose(H.d_img, H.d_out, H.t_rows, H.t_cols, ctx->stream));
-      if (R->ev2) KMX_HIP(ctx, hipEventRecord(R->ev2, ctx->stream));
-      return mirror_and_mark(R);
-    }
   } else if (R->use_cols) {
     // row keys first (bounds + k_merge_rows over a few lists of every task, gathered by k_cols_prep), then the
     // column-blocked merge, then the check that no key outside the rows reaches the recurrence
@@ -326,12 +323,13 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       if (mode == KMX_MODE_BFC && (K.bitw == 0 || K.bitw > 32)) return ctx->fail(KMX_E_INVAL, "bitw must be in 1..32");
       H.row_bytes = mode != KMX_MODE_BFC ? (H.N + 7) / 8 : (u32)(((u64)H.N * K.bitw + 7) / 8);
       u32 rt = (40960u / H.row_bytes) & ~63u; if (rt < 64) rt = 64;
-      if ((u64)rt * H.row_bytes > 96 * 1024) return ctx->fail(KMX_E_UNSUPPORTED, "BF row too wide for one LDS tile");
-      H.rt = rt;
+      if (!is_bft && (u64)rt * H.row_bytes > 96 * 1024) return ctx->fail(KMX_E_UNSUPPORTED, "BF row too wide for one LDS tile");
+      H.rt = is_bft ? bft_tile_rows() : rt;
       H.out_bytes = (size_t)((K.upper - K.lower + 1) * H.row_bytes);
       if (is_bft) {   // write_as_bft (merge.hpp:631-644): BitMatrix(ROUND_UP(W, 8), ROUND_UP(N, 8) / 8), transposed, dumped whole
         H.t_rows = (K.upper - K.lower + 1 + 7) & ~7ULL; H.t_cols = (u64)H.row_bytes * 8;
-        H.img_bytes = (size_t)(H.t_rows * H.row_bytes);
+        H.img_bytes = 0;
+        H.nblk = (u32)((H.t_cols + bft_block_lists() - 1) / bft_block_lists());
         H.out_bytes = (size_t)(H.t_cols * (H.t_rows >> 3));
       }
     } else {
@@ -340,6 +338,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.wl = wl;
       if (H.row_bytes > rows_image_bytes((int)kw)) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
       u64 guess = K.rows_hint ? K.rows_hint : 2ULL * longest + 4096;
+      if (ctx->rows_per_longest > 0.0) guess = std::max<u64>(guess, (u64)(ctx->rows_per_longest * 1.125 * (double)longest) + 4096);
       if (guess > H.total_recs) guess = H.total_recs;
       H.rows_guess = std::max<u64>(guess, 1);   // arena = guess + chunk slack, sized once c is known
     }
@@ -495,6 +494,11 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     H.o_stats = off; off = align_up(off + 8ull * 6 * H.N, 256);
   };
   for (auto& H : R->tasks) lay_lists(H);
+  if (is_bft) {
+    u32 ncit = 0; for (auto& H : R->tasks) ncit += H.c * H.nblk;
+    R->n_citems = ncit;
+    R->o_citems = off; off = align_up(off + sizeof(uint2) * ncit, 256);
+  }
   if (cols) {
     R->o_subtasks = off; off = align_up(off + sizeof(TaskDev) * n_tasks, 256);
     R->o_subitems = off; off = align_up(off + sizeof(uint2) * R->n_subitems, 256);
@@ -523,7 +527,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->h_meta = (u8*)ctx->halloc(upload_bytes);
   if (!R->d_meta || !R->h_meta) { ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); return ctx->fail(KMX_E_NOMEM, "meta allocation failed"); }
   auto drop_blocks = [&]() {
-    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); }
+    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); ctx->dfree(G.d_rowrec); }
     for (auto& G : R->subs) ctx->dfree(G.d_out);
     ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
   };
@@ -531,9 +535,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
     if (H.d_out && cols) H.d_ov = (u8*)ctx->dalloc((size_t)(cols_scratch_keys(H.slots_cap, H.nblk) * 8 + cols_scratch_counts(H.slots_cap, H.nblk) * 4));
     if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
-    if (is_bft) {
-      H.d_img = (u8*)ctx->dalloc(H.img_bytes);
-      if (!H.d_img) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "Bloom image allocation failed"); }
+    if (is_bft && (H.rec_min > 1 || H.share_min > 0)) {
+      H.d_rowrec = (u16*)ctx->dalloc((size_t)(H.upper - H.lower + 1 + 2 * bft_tile_rows()) * 2);
+      if (!H.d_rowrec) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "row recurrence allocation failed"); }
     }
   }
   for (auto& Q : R->subs) {
@@ -549,7 +553,8 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     D.soft_min = reinterpret_cast<const u32*>(R->d_meta + H.o_smin);
     D.bounds = reinterpret_cast<u32*>(R->d_meta + H.o_bounds);
     D.stats = reinterpret_cast<u64*>(R->d_meta + H.o_stats);
-    D.out = H.d_img ? H.d_img : H.d_out;      // (BFT: k_merge_bf fills the hash-major image, the transpose fills d_out)
+    D.out = H.d_out;
+    D.rowrec = H.d_rowrec;
     D.ctrl = reinterpret_cast<u64*>(R->d_meta + H.o_ctrl);
     H.d_segs = reinterpret_cast<Seg*>(R->d_meta + H.o_segs);
     D.segs = H.d_segs;
@@ -569,6 +574,12 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     fill_dev(H, D);
     D.item0 = it;
     for (u32 j = 0; j < H.c; j++) items[it++] = make_uint2(t, j);
+  }
+  if (is_bft) {
+    uint2* citems = reinterpret_cast<uint2*>(R->h_meta + R->o_citems);
+    u32 ci = 0;
+    // (sample blocks of a range next to each other: the blocks of a tile share the rows' recurrences in the L2)
+    for (u32 t = 0; t < n_tasks; t++) for (u32 j = 0; j < R->tasks[t].c * R->tasks[t].nblk; j++) citems[ci++] = make_uint2(t, j);
   }
   if (cols) {
     TaskDev* sd = reinterpret_cast<TaskDev*>(R->h_meta + R->o_subtasks);
@@ -765,6 +776,11 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     if (rc == KMX_OK && overflow && attempt >= 2) rc = ctx->fail(KMX_E_HIP, "merge overflowed its exact-size arena (internal error)");
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
   }
+  {   // what the next batches' arenas are sized from
+    double ratio = 0.0;
+    for (auto& H : R->tasks) { u32 longest = 0; for (u32 l : H.len) longest = std::max(longest, l); if (longest) ratio = std::max(ratio, (double)H.rows / (double)longest); }
+    ctx->rows_per_longest = ctx->rows_per_longest > 0.0 ? std::max(ratio, 0.75 * ctx->rows_per_longest + 0.25 * ratio) : ratio;
+  }
   R->waited = true; R->status = KMX_OK;
   return KMX_OK;
 }
@@ -772,6 +788,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
 extern "C" const char* kmx_result_kernel(const kmx_merge_result* R)
 {
   if (!R) return "";
+  if (R->is_bft) return "k_merge_bft";
   if (R->is_bf) return "k_merge_bf";
   size_t n[3] = {0, 0, 0};            // the kernel that produced most of the result
   for (auto& H : R->tasks) n[H.kernel]++;
@@ -902,7 +919,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
 #ifdef KMX_PHASE_PROF
   if (!R->is_bf) { if (R->use_cols) kmx::cols_phase_prof_dump(); else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
-  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); }
+  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);

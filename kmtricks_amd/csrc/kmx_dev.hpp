@@ -31,6 +31,7 @@ struct TaskDev {
   u8* out;                 // COUNT/PA: row arena; BF/BFC: dense window image
   u64* ctrl;               // [0] rows allocated so far, [1] segments produced, [2] error bits
   Seg* segs;
+  u16* rowrec;             // BFT: recurrence of every hash row of the window (k_bf_rowrec), when recurrence-min > 1 or share-min
   u64 out_cap_rows;
   u64 lower, upper;        // BF window [lower, upper]
   u32 seg_cap;

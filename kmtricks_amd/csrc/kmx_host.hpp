@@ -36,6 +36,10 @@ int bf_lds_bytes(u32 rt, u32 nb, u32 n_lists);
 hipError_t launch_range_bounds_bf(const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);
 hipError_t launch_merge_bf(int bfc, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
                            u32 grid_x, int lds, hipStream_t st);
+u32 bft_tile_rows();
+u32 bft_block_lists();
+hipError_t launch_bf_rowrec(const TaskDev* tasks, const uint2* items, u32 n_items, u32 max_n, hipStream_t st);
+hipError_t launch_merge_bft(const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
 hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hipStream_t st);
 
 }  // namespace kmx
@@ -59,6 +63,10 @@ struct kmx_ctx {
   // (doubling back-off, reset by the first batch the pivot kernel completes)
   unsigned pivot_backoff = 0, pivot_skip = 0;
   unsigned cols_backoff = 0, cols_skip = 0;   // the same for the column-blocked kernel
+  // rows kept per record of a task's longest list, as the batches completed so far had it (COUNT/PA arenas are sized from it:
+  // a cohort whose samples share their private k-mers pairwise keeps several times more rows than a list is long, and an arena
+  // sized for 2 x the longest list would make every batch run twice)
+  double rows_per_longest = 0.0;
 
   void* dalloc(size_t bytes);
   void dfree(void* p);
