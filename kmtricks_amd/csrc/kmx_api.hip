@@ -136,7 +136,9 @@ struct TaskHost {
   // column-blocked kernel (merge_cols.hip)
   u32 nblk = 0, nb = 0, rt_cols = 0, slots_cap = 0;
   size_t o_skel = 0, o_nskel = 0, o_rbounds = 0;
-  u8* d_ov = nullptr;           // keys + counts of the records that are not row keys
+  u8* d_ov = nullptr;           // the records that are not row keys (key, list, count), the slices' counts, and the directory of their rows
+  size_t o_spdir = 0;           // ... offset of that directory in d_ov
+  u64 sparse_rows = 0;          // rows k_cols_sparse added behind the row keys' rows
   std::vector<u32> src;         // (row-key merge of a task: which of the task's lists it merges)
   int kernel = 0;               // the kernel that completed (or is to complete) the task: 0 rows, 1 pivot, 2 cols
 };
@@ -243,7 +245,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, launch_merge_cols(mode, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
     // (the check stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
-    KMX_HIP(ctx, launch_cols_check(d_tasks, d_cols, d_items, R->n_items, ctx->stream));
+    KMX_HIP(ctx, launch_cols_sparse(mode, d_tasks, d_cols, d_items, R->n_items, ctx->stream));
     return mirror_and_mark(R);
   } else {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
@@ -359,7 +361,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     }
     const char* force = getenv("KMX_MERGE_KERNEL");
     const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
-    bool can_cols = !is_bf && !rescue && kw == 1 && mx_n <= (u32)rows_cap() && min_rec >= 1;
+    bool can_cols = !is_bf && !rescue && kw == 1 && mx_n <= (u32)rows_cap();
     if (can_cols) {
       // k_merge_cols keeps worst-case room for the records it sets aside (a slice per half tile, block and wave: ~2.3 KB per
       // row at 1000 lists): not for batches where that would take more than KMX_COLS_SCRATCH_GB (default 32) of HBM
@@ -367,7 +369,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       for (auto& H : R->tasks) {
         const u32 nblk = (H.N + cols_block_lists() - 1) / cols_block_lists();
         const u32 sl = (u32)std::min<u64>(0x7FFFFFF0ULL, H.rows_guess / cols_tile_rows(cols_block_lists()) + 64);
-        scratch += cols_scratch_keys(sl, nblk) * 8 + cols_scratch_counts(sl, nblk) * 4;
+        scratch += cols_scratch_keys(sl, nblk) * 8 + cols_scratch_counts(sl, nblk) * 4 + cols_dir_bytes(sl);
       }
       const char* gb = getenv("KMX_COLS_SCRATCH_GB");
       can_cols = scratch <= (u64)(gb && atoi(gb) > 0 ? atoi(gb) : 32) << 30;
@@ -379,7 +381,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     else {
       // (cols: from 128 lists -- below, k_merge_rows' wide windows win -- and 1 M records per batch -- below, its seven
       //  launches cost more than they save; recurrence-min 2..21)
-      R->use_cols = can_cols && min_n >= 128 && grand_total >= (1ull << 20) && min_rec >= 2 && cols_row_lists(max_rec) != 0;
+      R->use_cols = can_cols && min_n >= 128 && grand_total >= (1ull << 20) && cols_row_lists(std::max(1u, max_rec)) != 0;
       if (R->use_cols && ctx->cols_skip) { ctx->cols_skip--; R->use_cols = false; }
       R->cols_auto = R->use_cols;
       R->use_pivot = !R->use_cols && can && min_n > 512;
@@ -434,7 +436,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     for (u32 t = 0; t < n_tasks; t++) {
       const TaskHost& H = R->tasks[t];
       TaskHost& Q = R->subs[t];
-      { const u32 S = cols_row_lists(H.rec_min); Q.N = std::min<u32>(S ? S : 32u, H.N); }
+      { const u32 S = cols_row_lists(std::max(1u, H.rec_min)); Q.N = std::min<u32>(S ? S : 32u, H.N); }
       Q.kw = kw; Q.mode = mode; Q.rec_min = H.rec_min; Q.share_min = 0;
       Q.len.resize(Q.N);
       u32 piv = 0;
@@ -533,7 +535,11 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   };
   for (auto& H : R->tasks) {
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
-    if (H.d_out && cols) H.d_ov = (u8*)ctx->dalloc((size_t)(cols_scratch_keys(H.slots_cap, H.nblk) * 8 + cols_scratch_counts(H.slots_cap, H.nblk) * 4));
+    if (H.d_out && cols) {
+      H.o_spdir = align_up((size_t)(cols_scratch_keys(H.slots_cap, H.nblk) * 8 + cols_scratch_counts(H.slots_cap, H.nblk) * 4), 256);
+      H.d_ov = (u8*)ctx->dalloc(H.o_spdir + (size_t)cols_dir_bytes(H.slots_cap));
+      if (H.d_ov && hipMemsetAsync(H.d_ov + H.o_spdir, 0, (size_t)cols_dir_bytes(H.slots_cap), ctx->aux) != hipSuccess) { ctx->dfree(H.d_ov); H.d_ov = nullptr; }
+    }
     if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
     if (is_bft && (H.rec_min > 1 || H.share_min > 0)) {
       H.d_rowrec = (u16*)ctx->dalloc((size_t)(H.upper - H.lower + 1 + 2 * bft_tile_rows()) * 2);
@@ -607,6 +613,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       C.rbounds = reinterpret_cast<u32*>(R->d_meta + H.o_rbounds);
       C.ovkeys = reinterpret_cast<u64*>(H.d_ov);
       C.ovcnt = reinterpret_cast<u32*>(H.d_ov + cols_scratch_keys(H.slots_cap, H.nblk) * 8);
+      C.spdir = H.d_ov + H.o_spdir;
       C.slots_cap = H.slots_cap; C.nblk = H.nblk; C.nb = H.nb; C.rt = H.rt_cols;
       for (u32 j = 0; j < H.c * H.nblk; j++) citems[ci++] = make_uint2(t, j);   // y = range * nblk + block
     }
@@ -644,7 +651,7 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
   for (size_t t = 0; t < nt; t++) {
     TaskHost& H = R->tasks[t];
     const u64* ctrl = hc + t * 8;
-    H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3];
+    H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3]; H.sparse_rows = ctrl[6];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
     H.handed_back = false;
     if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; if (ctrl[2] & ERR_DIVERGENT) R->divergent = true; }
@@ -840,6 +847,24 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
   if (R->is_bf) {
     KMX_HIP(ctx, hipMemcpyAsync(dst, H.d_out, body, hipMemcpyDeviceToHost, ctx->copy));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+    return KMX_OK;
+  }
+  if (H.kernel == 2 && H.sparse_rows) {
+    // k_merge_cols + k_cols_sparse: the row keys' rows and the rows of the keys outside them are interleaved by key on the
+    // device (k_cols_offsets + k_cols_gather), the body then comes back in one copy
+    const u32 ng = cols_groups(H.slots_cap);
+    u8* d_body = (u8*)ctx->dalloc(body);
+    u64* d_goff = (u64*)ctx->dalloc((size_t)ng * 8);
+    u8* stage = (u8*)ctx->halloc(body);
+    struct Rel2 { kmx_ctx* c; void* a; void* b; void* h; ~Rel2() { c->dfree(a); c->dfree(b); c->hfree(h); } } rel2{ctx, d_body, d_goff, stage};
+    if (!d_body || !d_goff || !stage) return ctx->fail(KMX_E_NOMEM, "body assembly allocation failed");
+    const TaskDev* d_tasks = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_tasks);
+    const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
+    KMX_HIP(ctx, launch_cols_offsets(d_cols, t, d_goff, ctx->copy));
+    KMX_HIP(ctx, launch_cols_gather(d_tasks, d_cols, t, ng, d_goff, d_body, ctx->copy));
+    KMX_HIP(ctx, hipMemcpyAsync(stage, d_body, body, hipMemcpyDeviceToHost, ctx->copy));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+    memcpy(dst, stage, body);
     return KMX_OK;
   }
   std::vector<Seg> segs(H.nsegs);

@@ -51,8 +51,9 @@ struct ColsDev {
   u64* skel;               // [out_cap_rows] ascending row keys (the keys kept by a merge of a few of the task's lists)
   u32* nskel;              // -> number of row keys
   u32* rbounds;            // [c + 1] first row key of each key range
-  u64* ovkeys;             // [slots_cap][nblk][16][CL_OVW] keys of solid records that are not row keys
-  u32* ovcnt;              // [slots_cap][nblk][16] how many of them
+  u64* ovkeys;             // [slots_cap][halves][nblk][16][CL_OVW][2] solid records that are not row keys: key, list << 32 | count
+  u32* ovcnt;              // [slots_cap][halves][nblk][16] how many of them
+  void* spdir;             // [slots_cap][halves][8] where k_cols_sparse put the rows of the keys outside the row keys
   u32 slots_cap;           // tile slots (tile q of range j: (rbounds[j] + q * rt) / rt + j)
   u32 nblk;                // column blocks
   u32 nb;                  // lists per column block (the last one may hold fewer)

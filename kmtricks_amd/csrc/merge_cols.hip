@@ -49,16 +49,10 @@ constexpr int CL_NT = (CL_KPL == 1 && CL_WGS == 1) ? 2 : 1;  // row tables: two 
 constexpr int CL_PT = CL_KPL == 1 ? 2048 : 4096;      // row-key table entries
 constexpr int CL_PTSHIFT = CL_PT == 2048 ? 21 : 20;
 constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 56 rows (k_cols_check takes a slice group at a time)
-constexpr int CL_SEEDS = 64;             // hash multipliers tried per tile for a collision-free table
+constexpr int CL_SEEDS = 256;            // hashes tried per tile for a collision-free table: 64 cheap ones, then 64-bit multiplicative ones
 constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
 constexpr int CL_NW = CL_TPB / 64;
-#ifndef KMX_CK_SPEC
-#define KMX_CK_SPEC 5
-#endif
-constexpr int CK_SPEC = KMX_CK_SPEC;     // k_cols_check: keys per thread requested together with the slice's count
-constexpr int CK_BITS = 1 << 18;         // k_cols_check: bits of the key map (32 KB of LDS)
-constexpr int CK_NSUSP = 32;             // ... suspects per pass (keys that found their bit set)
-constexpr int CK_PASS = 2048;            // ... keys per pass (~8 suspects expected at that many)
+constexpr int CK_BITS = 1 << 17;         // k_cols_sparse: bits of the key map (16 KB of LDS)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
 
 __device__ u32 kmx_cols_dbg[8];      // why tasks were handed back (KMX_TRACE=1 prints and clears them)
@@ -79,12 +73,23 @@ __device__ __forceinline__ void cl_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // distinct entries of the 1024, so a lookup is one LDS read and one compare -- no probing, no branch
 // (a hash = 24-bit multiplier | shift << 24: the shift picks which key bits are folded into the 24 that get multiplied,
 //  so two keys that agree in those 24 bits under one hash do not under the next)
+// Keys of real minimizer partitions are structured (the row keys of a tile share their leading nucleotides, neighbours in
+// the genome are shifted copies of each other): for a tile in a thousand none of the cheap hashes is collision free.  Those
+// tiles use a second family -- a 64-bit multiplicative hash of the whole key (bit 31 of the hash word set; a uniform branch).
 __device__ __forceinline__ u32 cl_thash(u64 k, u32 hf)
 {
+  if (hf & 0x80000000u) {
+    const u64 m = 0x9E3779B97F4A7C15ULL + 2ULL * (u64)(hf & 0xFFFFu) * 0xBF58476D1CE4E5B9ULL;      // odd
+    return (u32)((k * m) >> 40) & (u32)(CL_PT - 1);
+  }
   const u32 x = ((u32)k ^ (u32)(k >> (hf >> 24))) & 0xFFFFFFu;
   return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
 }
-__device__ __forceinline__ u32 cl_mult(u32 seed) { return ((0x9E3779u + seed * 0x5A6B2u) & 0xFFFFFFu) | ((13u + (seed * 7u) % 19u) << 24); }
+__device__ __forceinline__ u32 cl_mult(u32 seed)
+{
+  if (seed >= 64u) return 0x80000000u | (seed - 63u);
+  return ((0x9E3779u + seed * 0x5A6B2u) & 0xFFFFFFu) | ((13u + (seed * 7u) % 19u) << 24);
+}
 __device__ __forceinline__ u32 cl_mix(u64 k)
 {
   u32 x = (u32)k ^ ((u32)(k >> 32) * 0x9E3779B1u);
@@ -410,8 +415,10 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       const ClEnt* const tab = ptab + (q % CL_NT) * CL_PT;
       const u32 mult = cl_uni(sh[4 + (q % CL_NT)]);
       // the wave's slices of the tile's slice groups (records below / from the tile's middle row key)
-      gu64w* const ovk0 = (gu64w*)(uintptr_t)(C.ovkeys + (((((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave) * CL_OVW));
-      gu64w* const ovk1 = ovk0 + (u64)nblk * CL_NW * CL_OVW;
+      // (an entry = the key and (list << 32 | count): k_cols_sparse builds the rows of the keys that reach the recurrence from them)
+      gu64w* const ovk0 = (gu64w*)(uintptr_t)(C.ovkeys + (((((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave) * CL_OVW) * 2);
+      gu64w* const ovk1 = ovk0 + (u64)nblk * CL_NW * CL_OVW * 2;
+      const u64 li_hi = (u64)li << 32;
       u32 wov = 0, wov1 = 0;                        // records of this wave that are not row keys (uniform), per slice group
 
       for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
@@ -462,7 +469,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
               if (CL_HALVES == 1) {
                 if ((ovm >> j) & 1u) {
                   const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                  if (pos < (u32)CL_OVW) ovk0[pos] = kk;
+                  if (pos < (u32)CL_OVW) { ovk0[2 * pos] = kk; ovk0[2 * pos + 1] = li_hi | rec[g + j].z; }
                 }
                 wov += (u32)__popcll(bal);
               } else {
@@ -471,7 +478,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
                   const bool up = kk >= kmid;
                   const u64 m = up ? hi : lo;
                   const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                  if (pos < (u32)CL_OVW) (up ? ovk1 : ovk0)[pos] = kk;
+                  if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; o[2 * pos] = kk; o[2 * pos + 1] = li_hi | rec[g + j].z; }
                 }
                 wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
               }
@@ -506,7 +513,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       if (lane == 0) {
         C.ovcnt[(((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave] = wov;
         if (CL_HALVES > 1) C.ovcnt[(((u64)(slot0 + q) * CL_HALVES + 1) * nblk + blk) * CL_NW + wave] = wov1;
-        if (max(wov, wov1) > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); }
+        if (max(wov, wov1) > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); atomicMax(&kmx_cols_dbg[5], max(wov, wov1)); if (last) atomicAdd(&kmx_cols_dbg[6], 1u); if (q == 0) atomicAdd(&kmx_cols_dbg[7], 1u); }
       }
 
       // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
@@ -585,126 +592,192 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   }
 }
 
-// ---- after the merge: does any key outside the rows reach the recurrence?  One workgroup per (task, range), a tile
-//      at a time: the records the column blocks set aside for the tile are counted per key in an LDS hash set ----
+// ---- after the merge: the rows of the keys OUTSIDE the row keys.  A cohort's samples share most of their private k-mers with
+//      nobody, some with one or two other samples: those keys reach a small recurrence-min without being in the few lists the row
+//      keys were taken from (with recurrence-min 1 -- kmtricks' default -- every key set aside is a row).  One workgroup per
+//      (task, range), a slice group (the records the column blocks set aside for half a tile: the keys between two row keys 56
+//      rows apart) at a time:
+//        1. every entry sets its key's bit of a 256-Kbit LDS map; an entry that finds the bit set marks the key in a second, small
+//           map: the keys marked there occur at least twice (plus a few chance pairs) -- the CANDIDATES; for a recurrence-min of 1
+//           every entry is one;
+//        2. the candidates are gathered in LDS and sorted by key (bitonic); a run of >= recurrence-min equal keys is a row;
+//        3. the group's rows are claimed from the task's arena BEHIND the row keys' rows with one atomic; a wave per row writes the
+//           key, zeroes the counts and drops the run's counts in (PA: sets its bits);
+//        4. a directory entry per (group, pass) says where they are: the rows of a task are the row keys' rows (row r = row key r)
+//           and these, each list ascending; k_cols_gather interleaves them when the body is asked for.
+//      Groups with many entries are done in 2..8 passes split by hash bits (equal keys meet in the same pass). ----
 #ifndef KMX_CK_TPB
 #define KMX_CK_TPB 512
 #endif
 #ifndef KMX_CK_Z
 #define KMX_CK_Z 16
 #endif
-constexpr int CK_TPB = KMX_CK_TPB;       // k_cols_check: threads (3 workgroups per CU by LDS; 256 threads: step +1.7 %)
-constexpr int CK_Z = KMX_CK_Z;           // ... and workgroups sharing the tiles of a range
+constexpr int CK_TPB = KMX_CK_TPB;
+constexpr int CK_Z = KMX_CK_Z;           // workgroups sharing the slice groups of a range
+constexpr int CK_CAND = 2048;            // candidates per pass (32 KB of LDS)
+constexpr int CK_B2 = 1 << 15;           // bits of the candidate map
+constexpr int CK_NPASS = 8;              // directory entries per group
+
+struct SpDir { u32 base, n, dense_first, dense_n; };      // rows [base, base + n) of the arena: a pass's rows; dense_* filled in entry 0 of a group
+
+__device__ __forceinline__ bool ck_less(u64 ka, u64 pa, u64 kb, u64 pb) { return ka != kb ? ka < kb : pa < pb; }
+
+template <int MODE>
 __global__ __launch_bounds__(CK_TPB)
-void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
+void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
-  // Per slice group: (1) every key sets its bit of a 256 Kbit LDS map (one ds_or, no probing -- a hash set's probe chains,
-  // dependent LDS atomics with the wave waiting for its slowest lane, were this kernel's time); a key that finds its
-  // bit set is a SUSPECT (a handful per group: the second of two equal keys always, two different keys with one bit
-  // now and then); (2) the suspects are counted exactly over the group's keys.  A suspect in recurrence-min or more
-  // lists means the rows were incomplete.
   __shared__ u32 bits[CK_BITS / 32];
-  __shared__ u64 susp[CK_NSUSP];
-  __shared__ u32 scount[CK_NSUSP];
-  __shared__ u32 sbm[128];         // 4096 bits: where the suspects are (the exact count looks at a key only if its bit is set here)
-  __shared__ u32 flag, total, special, nsusp;
+  __shared__ u32 bits2[CK_B2 / 32];
+  __shared__ u64 ck[CK_CAND];            // candidate keys
+  __shared__ u64 cp[CK_CAND];            // ... and their (list << 32 | count)
+  __shared__ u32 runs[CK_CAND];          // kept runs: first entry | length << 16 ... as two words: see below
+  __shared__ u32 wsum[CK_TPB / 64];
+  __shared__ u32 flag, total, ncand, rowbase, sover;
+  __shared__ u32 parow[MODE == 1 ? (CK_TPB / 64) * 136 : 1];      // PA: a row per wave is assembled here (<= 4096 lists + key)
   const u32 item = blockIdx.x;
   if (item >= n_items) return;
   const TaskDev& T = tasks[items[item].x];
   const ColsDev& C = cols[items[item].x];
   if (T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) return;
-  const u32 range = items[item].y, rec_min = T.rec_min, rt = C.rt, nsl = C.nblk * CL_NW;
+  const u32 range = items[item].y, thr = max(1u, T.rec_min), rt = C.rt, nsl = C.nblk * CL_NW, row_bytes = T.row_bytes;
   const u32 s_lo = C.rbounds[range], s_hi = C.rbounds[range + 1];
   const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
   const u32 slot0 = (s_lo / rt + range) * CL_HALVES;
   const u32 ngroups = ntiles * CL_HALVES;
-  const u32 tid = threadIdx.x;
-  auto wipe = [&]() {
-    for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
-    if (tid < (u32)CK_NSUSP) scount[tid] = 0;
-    if (tid < 128) sbm[tid] = 0;
-    if (tid == 0) { special = 0; nsusp = 0; }
-  };
-  wipe();
-  if (tid == 0) { flag = 0; total = 0; }
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  SpDir* const dir = reinterpret_cast<SpDir*>(C.spdir);
+  if (tid == 0) { flag = 0; total = 0; sover = 0; }
   __syncthreads();
-  const bool single = nsl <= (u32)CK_TPB / 4;      // every slice of a group has its four threads at once
   for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) {
-    // four threads per (block, wave) slice of the group: every slice's count and first 20 keys (5 per thread -- the usual slice holds ~13; the
-    // slice's memory is there whatever the count) are requested together -- one memory round trip per group (a wave
-    // walking its slices one after the other pays two dependent round trips per slice).
-    // A group with many keys (cohorts with many sample-private k-mers) is counted in 2, 4 or 8 passes, a pass taking the
-    // keys whose hash has its bits (equal keys meet in the same pass): the suspects of a pass stay a handful.
     const u64 sbase = (u64)(slot0 + q) * nsl;
-    u32 n0 = 0; u64 kk0[CK_SPEC];
-    const u64* kp0 = C.ovkeys;
-    for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
-      const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
-      const bool ok = sl < nsl;
-      const u32 nraw = ok ? C.ovcnt[sbase + sl] : 0u;
-      if (single) {
-        kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW;
-#pragma unroll
-        for (int x = 0; x < CK_SPEC; x++) kk0[x] = kp0[sub + 4 * x];
-        n0 = min(nraw, (u32)CL_OVW);
-      }
-      if (sub == 0 && nraw) atomicAdd(&total, nraw);
+    const u32 gid = slot0 + q;
+    // the group's row keys: rows [d0, d0 + dn) (a tile's first half: 56 rows, second: the rest)
+    const u32 tq = q / CL_HALVES, hq = q % CL_HALVES;
+    const u32 t0 = s_lo + tq * rt, te = min(s_hi, t0 + rt);
+    u32 d0 = t0, dn = te - t0;
+    if (CL_HALVES > 1) { const u32 mid = min(te, t0 + 56u); d0 = hq ? mid : t0; dn = hq ? te - mid : mid - t0; }
+    if (s_hi == s_lo) { d0 = s_lo; dn = 0; }
+    for (u32 sl = tid; sl < nsl; sl += CK_TPB) {
+      const u32 nraw = C.ovcnt[sbase + sl];
+      if (nraw > (u32)CL_OVW) sover = 1;
+      if (nraw) atomicAdd(&total, nraw);
     }
     __syncthreads();
     const u32 tot = total;
+    const bool over = sover != 0;
     __syncthreads();
+    if (tid == 0) { total = 0; dir[(u64)gid * CK_NPASS].dense_first = d0; dir[(u64)gid * CK_NPASS].dense_n = dn; }
+    if (over) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[1], 1u); } break; }
     if (tot == 0) continue;
-    if (tid == 0) total = 0;      // (barriers follow before the next group adds to it)
-    if (rec_min <= 1) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); } break; }      // (every key set aside is a row then)
-    if (tot > (u32)CK_PASS * 8) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }     // (a slice over its capacity lands here too)
-    const u32 npass = tot <= (u32)CK_PASS ? 1u : tot <= (u32)CK_PASS * 2 ? 2u : tot <= (u32)CK_PASS * 4 ? 4u : 8u;
+    // passes: ~1400 entries each when every entry is a candidate, ~3000 when only the keys seen twice are
+    const u32 per = thr == 1 ? 1400u : 3000u;
+    u32 npass = 1; while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;
+    if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
+    // each of my entries through f(key, payload): four threads per slice
+    auto each = [&](u32 pass, auto&& f) {
+      for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
+        const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
+        if (sl >= nsl) continue;
+        const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
+        const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW * 2;
+        for (u32 e = sub; e < n; e += 4) {
+          const u64 k = kp[2 * e];
+          if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
+          f(k, kp[2 * e + 1]);
+        }
+      }
+    };
     for (u32 pass = 0; pass < npass; pass++) {
-      // each of my keys through f(key)
-      auto each = [&](auto&& f) {
-        if (single) {
-          const u32 sub = tid & 3u;
-#pragma unroll
-          for (int x = 0; x < CK_SPEC; x++) if (sub + 4 * x < n0) f(kk0[x]);
-          for (u32 e = sub + 4 * CK_SPEC; e < n0; e += 4) f(kp0[e]);
-        } else {
-          for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
-            const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
-            if (sl >= nsl) continue;
-            const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
-            const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW;
-            for (u32 e = sub; e < n; e += 4) f(kp[e]);
-          }
-        }
-      };
-      each([&](u64 k) {
-        if (k == ~0ULL) { if (pass == 0 && atomicAdd(&special, 1u) + 1 >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); } return; }
-        const u32 hx = cl_mix(k);
-        if (((hx >> 24) & (npass - 1)) != pass) return;
-        const u32 bit = hx & (CK_BITS - 1);
-        const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
-        if ((old >> (bit & 31u)) & 1u) {
-          const u32 ps = atomicAdd(&nsusp, 1u);
-          if (ps < (u32)CK_NSUSP) susp[ps] = k; else flag = 1;
-          const u32 b2 = (hx >> 6) & 4095u;
-          atomicOr(&sbm[b2 >> 5], 1u << (b2 & 31u));
-        }
-      });
+      for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
+      for (u32 t = tid; t < (u32)CK_B2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
+      if (tid == 0) ncand = 0;
       __syncthreads();
-      if (flag) break;
-      const u32 ns = min(nsusp, (u32)CK_NSUSP);
-      if (ns) {
-        each([&](u64 k) {
-          const u32 b2 = (cl_mix(k) >> 6) & 4095u;
-          if (!((sbm[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
-          for (u32 j = 0; j < ns; j++) if (k == susp[j]) atomicAdd(&scount[j], 1u);
+      if (thr > 1) {
+        each(pass, [&](u64 k, u64) {
+          const u32 hx = cl_mix(k);
+          const u32 bit = hx & (CK_BITS - 1);
+          const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
+          if ((old >> (bit & 31u)) & 1u) { const u32 b2 = (hx >> 7) & (CK_B2 - 1); atomicOr(&bits2[b2 >> 5], 1u << (b2 & 31u)); }
         });
         __syncthreads();
-        // (a key that is a suspect twice is counted twice in both entries: each holds the key's true count)
-        if (tid < ns && scount[tid] >= rec_min) { flag = 1; atomicAdd(&kmx_cols_dbg[2], 1u); }
-        __syncthreads();
-        if (flag) break;
       }
-      wipe();
+      each(pass, [&](u64 k, u64 pl) {
+        if (thr > 1) { const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return; }
+        const u32 ps = atomicAdd(&ncand, 1u);
+        if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; }
+      });
+      __syncthreads();
+      const u32 nc = ncand;
+      if (nc > (u32)CK_CAND) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
+      if (tid == 0) { dir[(u64)gid * CK_NPASS + pass].base = 0; dir[(u64)gid * CK_NPASS + pass].n = 0; }
+      if (nc == 0) { __syncthreads(); continue; }
+      u32 P = 2; while (P < nc) P <<= 1;
+      for (u32 t = nc + tid; t < P; t += CK_TPB) { ck[t] = ~0ULL; cp[t] = ~0ULL; }      // (pads: larger than any entry, the key of all ones included)
+      __syncthreads();
+      for (u32 k2 = 2; k2 <= P; k2 <<= 1) {
+        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+          for (u32 t = tid; t < P / 2; t += CK_TPB) {
+            const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
+            const u64 ka = ck[a], kb = ck[b], pa = cp[a], pb = cp[b];
+            const bool up = (a & k2) == 0;
+            if (ck_less(kb, pb, ka, pa) == up) { ck[a] = kb; ck[b] = ka; cp[a] = pb; cp[b] = pa; }
+          }
+          __syncthreads();
+        }
+      }
+      // kept runs: first entry of a run of >= thr equal keys (entries of one key come from different lists)
+      u32 mine = 0, km = 0;
+      const u32 pt = (P + CK_TPB - 1) / CK_TPB;      // consecutive entries per thread (<= 4)
+      for (u32 x = 0; x < pt; x++) {
+        const u32 i = tid * pt + x;
+        if (i < nc) {
+          const u64 k = ck[i];
+          const bool kept = (i == 0 || ck[i - 1] != k) && i + thr - 1 < nc && ck[i + thr - 1] == k;
+          km |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
+        }
+      }
+      const u32 incl = wave_incl_scan(mine, (int)lane);
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      u32 rank = incl - mine, nk = 0;
+      for (u32 w = 0; w < CK_TPB / 64; w++) { if (w < wave) rank += wsum[w]; nk += wsum[w]; }
+      for (u32 x = 0; x < pt; x++) if ((km >> x) & 1u) runs[rank++] = tid * pt + x;
+      if (tid == 0 && nk) {
+        const u64 at = atomicAdd(&T.ctrl[0], (u64)nk);      // rows of the arena: behind the row keys' rows
+        atomicAdd(&T.ctrl[3], (u64)nk); atomicAdd(&T.ctrl[6], (u64)nk);
+        if (at + nk > T.out_cap_rows) { atomicOr(&T.ctrl[2], (u64)ERR_ROWS_OVERFLOW); rowbase = 0xFFFFFFFFu; }
+        else { rowbase = (u32)at; dir[(u64)gid * CK_NPASS + pass].base = (u32)at; dir[(u64)gid * CK_NPASS + pass].n = nk; }
+      }
+      __syncthreads();
+      const u32 rb = rowbase;
+      if (nk && rb != 0xFFFFFFFFu) {
+        for (u32 j = wave; j < nk; j += CK_TPB / 64) {      // a wave per row
+          const u32 i0 = runs[j];
+          const u64 key = ck[i0];
+          u32 len = 1; while (i0 + len < nc && ck[i0 + len] == key) len++;
+          u8* const row = T.out + (u64)(rb + j) * row_bytes;
+          if (MODE == 0) {
+            // row = key + N counts: 8-byte stores (rows start at multiples of 8: row_bytes = 8 + 4N with N even, else 4-byte ones)
+            if ((row_bytes & 7u) == 0) {
+              u64* const r8 = reinterpret_cast<u64*>(row);
+              for (u32 t = lane; t < row_bytes / 8; t += 64) r8[t] = t == 0 ? key : 0ULL;
+            } else {
+              u32* const r4 = reinterpret_cast<u32*>(row);
+              for (u32 t = lane; t < row_bytes / 4; t += 64) r4[t] = t == 0 ? (u32)key : t == 1 ? (u32)(key >> 32) : 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (u32 e = lane; e < len; e += 64) { const u64 pl = cp[i0 + e]; reinterpret_cast<u32*>(row + 8)[(u32)(pl >> 32)] = (u32)pl; }
+          } else {
+            u32* const pr = parow + wave * 136;
+            const u32 nby = row_bytes - 8, nw = (nby + 3) / 4;
+            for (u32 t = lane; t < nw + 2; t += 64) pr[t] = t == 0 ? (u32)key : t == 1 ? (u32)(key >> 32) : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (u32 e = lane; e < len; e += 64) { const u32 li = (u32)(cp[i0 + e] >> 32); atomicOr(&pr[2 + (li >> 5)], 1u << (li & 31u)); }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (u32 t = lane; t < row_bytes; t += 64) row[t] = (u8)(pr[t >> 2] >> ((t & 3u) * 8));
+          }
+        }
+      }
       __syncthreads();
     }
     if (flag) break;
@@ -713,11 +786,73 @@ void k_cols_check(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   if (tid == 0 && flag) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
 }
 
+// ---- the body of a task the column-blocked merge completed: row keys' rows and the sparse rows, interleaved by key.
+//      k_cols_offsets: position of every slice group's first row in the body (a workgroup per task walks the directory);
+//      k_cols_gather: a workgroup per slice group ranks its (<= 9) ascending lists against each other and copies the rows. ----
+__global__ __launch_bounds__(1024)
+void k_cols_offsets(const ColsDev* __restrict__ cols, u32 task, u64* __restrict__ goff)
+{
+  const ColsDev& C = cols[task];
+  const SpDir* dir = reinterpret_cast<const SpDir*>(C.spdir);
+  __shared__ u64 part[1024];
+  const u32 ng = C.slots_cap * CL_HALVES, tid = threadIdx.x;
+  const u32 per = (ng + 1023) / 1024;
+  u64 sum = 0;
+  for (u32 g = tid * per; g < min(ng, (tid + 1) * per); g++) { sum += dir[(u64)g * CK_NPASS].dense_n; for (int p = 0; p < CK_NPASS; p++) sum += dir[(u64)g * CK_NPASS + p].n; }
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) { u64 a = 0; for (u32 t = 0; t < 1024; t++) { const u64 v = part[t]; part[t] = a; a += v; } }
+  __syncthreads();
+  u64 a = part[tid];
+  for (u32 g = tid * per; g < min(ng, (tid + 1) * per); g++) { goff[g] = a; a += dir[(u64)g * CK_NPASS].dense_n; for (int p = 0; p < CK_NPASS; p++) a += dir[(u64)g * CK_NPASS + p].n; }
+}
+
+constexpr int GA_TPB = 256;
+constexpr int GA_KEYS = 4096;      // keys of a group held in LDS (more: ranks come from global memory)
+__global__ __launch_bounds__(GA_TPB)
+void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, u32 task, const u64* __restrict__ goff, u8* __restrict__ body)
+{
+  const TaskDev& T = tasks[task];
+  const ColsDev& C = cols[task];
+  const SpDir* dir = reinterpret_cast<const SpDir*>(C.spdir) + (u64)blockIdx.x * CK_NPASS;
+  __shared__ u64 keys[GA_KEYS];
+  __shared__ u32 lo[CK_NPASS + 2];      // list l = keys [lo[l], lo[l + 1]): 0 the row keys, 1.. the passes
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row_bytes = T.row_bytes;
+  if (tid == 0) { u32 a = 0; lo[0] = 0; a += dir[0].dense_n; lo[1] = a; for (int p = 0; p < CK_NPASS; p++) { a += dir[p].n; lo[2 + p] = a; } }
+  __syncthreads();
+  const u32 n = lo[CK_NPASS + 1];
+  if (n == 0) return;
+  const u32 d0 = dir[0].dense_first, dn = dir[0].dense_n;
+  auto src_row = [&](u32 i) -> const u8* {      // i-th row of the group in list order
+    if (i < dn) return T.out + (u64)(d0 + i) * row_bytes;
+    int p = 0; while (i >= lo[2 + p]) p++;
+    return T.out + (u64)(dir[p].base + (i - lo[1 + p])) * row_bytes;
+  };
+  auto key_at = [&](u32 i) -> u64 { return i < (u32)GA_KEYS ? keys[i] : load_key<1>(src_row(i)).w[0]; };
+  for (u32 i = tid; i < min(n, (u32)GA_KEYS); i += GA_TPB) keys[i] = i < dn ? C.skel[d0 + i] : load_key<1>(src_row(i)).w[0];
+  __syncthreads();
+  u8* const dst0 = body + goff[blockIdx.x] * row_bytes;
+  for (u32 i = wave; i < n; i += GA_TPB / 64) {      // a wave per row: its rank = keys below it in every list
+    const u64 k = key_at(i);
+    u32 rank = 0;
+    for (int l = 0; l <= CK_NPASS; l++) {
+      u32 a = lo[l], b = lo[l + 1];
+      if (i >= a && i < b) { rank += i - a; continue; }
+      while (a < b) { const u32 m = (a + b) >> 1; if (key_at(m) < k) a = m + 1; else b = m; }
+      rank += a - lo[l];
+    }
+    const u8* s = src_row(i);
+    u8* d = dst0 + (u64)rank * row_bytes;
+    if ((row_bytes & 3u) == 0) for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(d)[t] = reinterpret_cast<const u32*>(s)[t];
+    else for (u32 t = lane; t < row_bytes; t += 64) d[t] = s[t];
+  }
+}
+
 void cols_dbg_dump()
 {
   u32 h[8];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_cols_dbg), sizeof(h)) != hipSuccess) return;
-  fprintf(stderr, "[kmx merge] k_merge_cols hand-back reasons: no collision-free row table %u, slice overflow %u (wave-tiles), kept key outside the row keys %u, check table full %u, lists too divergent %u (tasks)\n", h[0], h[1], h[2], h[3], h[4]);
+  fprintf(stderr, "[kmx merge] k_merge_cols hand-back reasons: no collision-free row table %u, slice overflow %u (wave-tiles; largest %u, in a range's last tile %u, first tile %u), kept key outside the row keys %u, check table full %u, lists too divergent %u (tasks)\n", h[0], h[1], h[5], h[6], h[7], h[2], h[3], h[4]);
   memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_dbg), h, sizeof(h));
 }
 #ifdef KMX_PHASE_PROF
@@ -739,7 +874,7 @@ u32 cols_halves() { return CL_HALVES; }
 u32 cols_wgs_per_cu() { return CL_WGS; }
 u32 cols_block_lists() { return CL_NB; }
 u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }      // (sized for count rows; PA rows need less)
-u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW; }
+u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW * 2; }      // (u64 words: two per entry)
 u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW; }
 
 u32 cols_skel_cap() { return SK_CAP; }
@@ -767,9 +902,22 @@ hipError_t launch_merge_cols(int mode, const TaskDev* tasks, const ColsDev* cols
   }
   return hipGetLastError();
 }
-hipError_t launch_cols_check(const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)
+hipError_t launch_cols_sparse(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_cols_check, dim3(n_items, CK_Z), dim3(CK_TPB), 0, st, tasks, cols, range_items, n_items);
+  if (mode == 0) hipLaunchKernelGGL(k_cols_sparse<0>, dim3(n_items, CK_Z), dim3(CK_TPB), 0, st, tasks, cols, range_items, n_items);
+  else hipLaunchKernelGGL(k_cols_sparse<1>, dim3(n_items, CK_Z), dim3(CK_TPB), 0, st, tasks, cols, range_items, n_items);
+  return hipGetLastError();
+}
+u64 cols_dir_bytes(u32 slots) { return (u64)slots * CL_HALVES * CK_NPASS * sizeof(SpDir); }
+u32 cols_groups(u32 slots) { return slots * CL_HALVES; }
+hipError_t launch_cols_offsets(const ColsDev* cols, u32 task, u64* goff, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cols_offsets, dim3(1), dim3(1024), 0, st, cols, task, goff);
+  return hipGetLastError();
+}
+hipError_t launch_cols_gather(const TaskDev* tasks, const ColsDev* cols, u32 task, u32 n_groups, const u64* goff, u8* body, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cols_gather, dim3(n_groups), dim3(GA_TPB), 0, st, tasks, cols, task, goff, body);
   return hipGetLastError();
 }
 
