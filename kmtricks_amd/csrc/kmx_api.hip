@@ -243,9 +243,9 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, launch_merge_cols(mode, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
-    if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
-    // (the check stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
+    // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
     KMX_HIP(ctx, launch_cols_sparse(mode, d_tasks, d_cols, d_items, R->n_items, ctx->stream));
+    if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));      // (the launch priced: the rows come out of both kernels)
     return mirror_and_mark(R);
   } else {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
@@ -368,7 +368,10 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       u64 scratch = 0;
       for (auto& H : R->tasks) {
         const u32 nblk = (H.N + cols_block_lists() - 1) / cols_block_lists();
-        const u32 sl = (u32)std::min<u64>(0x7FFFFFF0ULL, H.rows_guess / cols_tile_rows(cols_block_lists()) + 64);
+        // (tile slots count ROW KEYS -- the keys a merge of S of the lists keeps, at most the records of those lists -- not rows)
+        const u32 S_ = std::max(8u, cols_row_lists(std::max(1u, H.rec_min)));
+        const u64 skel_est = std::min<u64>(H.rows_guess, (u64)S_ * (H.total_recs / H.N + 1) * 5 / 4 + 4096);
+        const u32 sl = (u32)std::min<u64>(0x7FFFFFF0ULL, skel_est / cols_tile_rows(cols_block_lists()) + 64);
         scratch += cols_scratch_keys(sl, nblk) * 8 + cols_scratch_counts(sl, nblk) * 4 + cols_dir_bytes(sl);
       }
       const char* gb = getenv("KMX_COLS_SCRATCH_GB");
@@ -422,7 +425,11 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.out_cap_rows = H.rows_guess + (u64)(H.c + 1) * rows_chunk_rows(H.row_bytes);
       H.out_bytes = (size_t)(H.out_cap_rows * H.row_bytes);
     }
-    if (R->use_cols) H.slots_cap = (u32)std::min<u64>(0x7FFFFFF0ULL, H.out_cap_rows / H.rt_cols + H.c + 2);
+    if (R->use_cols) {
+      const u32 S_ = std::max(8u, cols_row_lists(std::max(1u, H.rec_min)));
+      const u64 skel_est = std::min<u64>(H.out_cap_rows, (u64)S_ * (H.total_recs / H.N + 1) * 5 / 4 + 4096);
+      H.slots_cap = (u32)std::min<u64>(0x7FFFFFF0ULL, skel_est / H.rt_cols + H.c + 2);
+    }
     n_items += H.c;
     max_n = std::max(max_n, H.N); max_c = std::max(max_c, H.c);
   }

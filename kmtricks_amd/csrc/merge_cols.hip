@@ -80,7 +80,8 @@ __device__ __forceinline__ u32 cl_thash(u64 k, u32 hf)
 {
   if (hf & 0x80000000u) {
     const u64 m = 0x9E3779B97F4A7C15ULL + 2ULL * (u64)(hf & 0xFFFFu) * 0xBF58476D1CE4E5B9ULL;      // odd
-    return (u32)((k * m) >> 40) & (u32)(CL_PT - 1);
+    return (u32)((k * m) >> (CL_PT == 2048 ? 53 : 52));      // the product's TOP bits: every key bit counts (a k-mer and its variant with one
+                                                             // substitution near the front differ in one high bit and sit in the same tile)
   }
   const u32 x = ((u32)k ^ (u32)(k >> (hf >> 24))) & 0xFFFFFFu;
   return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
@@ -389,6 +390,9 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         }
       }
       const u32 mult = cl_build(ptab, skn, have, (u32)tid, myslot);
+#ifdef KMX_DEBUG_TAB
+      if (mult == 0 && blk == 0 && range < 3) { for (int x = 0; x < CL_KPL; x++) printf("T%u r%u q0 lane %d x %d have %d key %016llx s_lo %u s_hi %u\n", items[item].x, range, tid, x, (int)have[x], skn[x], s_lo, s_hi); }
+#endif
       if (tid == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
     }
     u64 khi_n = ntiles > 1 ? skel[s_lo + rt] : ~0ULL;     // upper key of tile 0 (uniform address: scalar load)
@@ -531,6 +535,9 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             if (have[x] && blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes); kp[0] = (u32)skn[x]; kp[1] = (u32)(skn[x] >> 32); }
           }
           const u32 m2 = cl_build(ptab + ((q + 1) % CL_NT) * CL_PT, skn, have, (u32)lane, myslot);
+#ifdef KMX_DEBUG_TAB
+          if (m2 == 0 && blk == 0 && sn < 3000) { for (int x = 0; x < CL_KPL; x++) printf("T%u r%u sn %u lane %d x %d have %d key %016llx s_lo %u s_hi %u\n", items[item].x, range, sn, lane, x, (int)have[x], skn[x], s_lo, s_hi); }
+#endif
           if (lane == 0) { sh[4 + ((q + 1) % CL_NT)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
@@ -614,6 +621,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 #endif
 constexpr int CK_TPB = KMX_CK_TPB;
 constexpr int CK_Z = KMX_CK_Z;           // workgroups sharing the slice groups of a range
+constexpr int CK_SPEC = 5;               // entries per thread requested together with the slice's count
 constexpr int CK_CAND = 2048;            // candidates per pass (32 KB of LDS)
 constexpr int CK_B2 = 1 << 15;           // bits of the candidate map
 constexpr int CK_NPASS = 8;              // directory entries per group
@@ -648,6 +656,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
   SpDir* const dir = reinterpret_cast<SpDir*>(C.spdir);
   if (tid == 0) { flag = 0; total = 0; sover = 0; }
   __syncthreads();
+  const bool single = nsl <= (u32)CK_TPB / 4;
   for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) {
     const u64 sbase = (u64)(slot0 + q) * nsl;
     const u32 gid = slot0 + q;
@@ -657,10 +666,27 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     u32 d0 = t0, dn = te - t0;
     if (CL_HALVES > 1) { const u32 mid = min(te, t0 + 56u); d0 = hq ? mid : t0; dn = hq ? te - mid : mid - t0; }
     if (s_hi == s_lo) { d0 = s_lo; dn = 0; }
-    for (u32 sl = tid; sl < nsl; sl += CK_TPB) {
-      const u32 nraw = C.ovcnt[sbase + sl];
+    // four threads per (block, wave) slice; when every slice has its four threads at once (<= 1024 lists) a slice's count and its
+    // first 20 entries (5 per thread; the usual slice holds ~14; the slice's memory is there whatever the count) are requested
+    // together and kept in registers for both walks over the entries: one memory round trip per group
+    u32 n0 = 0; u64 kk0[CK_SPEC], pp0[CK_SPEC];
+    const u64* kp0 = C.ovkeys;
+    if (single) {
+      const u32 sl = tid >> 2, sub = tid & 3u;
+      const bool ok = sl < nsl;
+      const u32 nraw = ok ? C.ovcnt[sbase + sl] : 0u;
+      kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW * 2;
+#pragma unroll
+      for (int x = 0; x < CK_SPEC; x++) { kk0[x] = kp0[2 * (sub + 4 * x)]; pp0[x] = kp0[2 * (sub + 4 * x) + 1]; }
+      n0 = min(nraw, (u32)CL_OVW);
       if (nraw > (u32)CL_OVW) sover = 1;
-      if (nraw) atomicAdd(&total, nraw);
+      if (sub == 0 && nraw) atomicAdd(&total, nraw);
+    } else {
+      for (u32 sl = tid; sl < nsl; sl += CK_TPB) {
+        const u32 nraw = C.ovcnt[sbase + sl];
+        if (nraw > (u32)CL_OVW) sover = 1;
+        if (nraw) atomicAdd(&total, nraw);
+      }
     }
     __syncthreads();
     const u32 tot = total;
@@ -675,6 +701,18 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
     // each of my entries through f(key, payload): four threads per slice
     auto each = [&](u32 pass, auto&& f) {
+      if (single) {
+        const u32 sub = tid & 3u;
+#pragma unroll
+        for (int x = 0; x < CK_SPEC; x++)
+          if (sub + 4 * x < n0 && !(npass > 1 && ((cl_mix(kk0[x]) >> 24) & (npass - 1)) != pass)) f(kk0[x], pp0[x]);
+        for (u32 e = sub + 4 * CK_SPEC; e < n0; e += 4) {
+          const u64 k = kp0[2 * e];
+          if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
+          f(k, kp0[2 * e + 1]);
+        }
+        return;
+      }
       for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
         const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
         if (sl >= nsl) continue;
