@@ -212,6 +212,7 @@ def main():
                  f"(window {W} bits), soft-min {smin}, share-min {share}, {P} partitions per GPU and step (G={genome} bp)")
     total_recs = sum(rec.shape[0] for rec, _ in parts)
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()           # (the generators' scratch goes back to the device: libkmx allocates beside torch)
     tasks = ctx.prepare(tasks_d)
 
     def barrier():

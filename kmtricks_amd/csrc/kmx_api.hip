@@ -213,10 +213,8 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   if (R->is_bf) {
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    if (R->is_bft) {   // sample-major matrix straight from the merge (merge_bft.hip): the rows' recurrences first, where they matter
-      const uint2* d_citems = reinterpret_cast<const uint2*>(R->d_meta + R->o_citems);
-      KMX_HIP(ctx, launch_bf_rowrec(d_tasks, d_items, R->n_items, R->max_n, ctx->stream));
-      KMX_HIP(ctx, launch_merge_bft(d_tasks, d_citems, R->n_citems, d_ticket, std::min(R->n_citems, (u32)ctx->n_cu * 2u), ctx->stream));
+    if (R->is_bft) {   // sample-major matrix straight from the merge (merge_bft.hip)
+      KMX_HIP(ctx, launch_merge_bft(d_tasks, d_items, R->n_items, d_ticket, std::min(R->n_items, (u32)ctx->n_cu * 2u), R->max_n, ctx->stream));
     } else
     KMX_HIP(ctx, launch_merge_bf(mode == KMX_MODE_BFC, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->bf_lds, ctx->stream));
   } else if (R->use_cols) {
@@ -375,7 +373,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         scratch += cols_scratch_keys(sl, nblk) * 8 + cols_scratch_counts(sl, nblk) * 4 + cols_dir_bytes(sl);
       }
       const char* gb = getenv("KMX_COLS_SCRATCH_GB");
-      can_cols = scratch <= (u64)(gb && atoi(gb) > 0 ? atoi(gb) : 32) << 30;
+      const char* mb = getenv("KMX_COLS_SCRATCH_MB");
+      const u64 budget = mb && atoi(mb) > 0 ? (u64)atoi(mb) << 20 : (u64)(gb && atoi(gb) > 0 ? atoi(gb) : 32) << 30;
+      can_cols = scratch <= budget;
     }
     R->can_pivot = can && min_n > 512;      // (as the next kernel down from cols: below 512 lists k_merge_rows is the faster of the two)
     if (force && !strcmp(force, "cols")) { R->use_cols = can_cols; R->use_pivot = !can_cols && can; }
@@ -548,10 +548,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       if (H.d_ov && hipMemsetAsync(H.d_ov + H.o_spdir, 0, (size_t)cols_dir_bytes(H.slots_cap), ctx->aux) != hipSuccess) { ctx->dfree(H.d_ov); H.d_ov = nullptr; }
     }
     if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
-    if (is_bft && (H.rec_min > 1 || H.share_min > 0)) {
-      H.d_rowrec = (u16*)ctx->dalloc((size_t)(H.upper - H.lower + 1 + 2 * bft_tile_rows()) * 2);
-      if (!H.d_rowrec) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "row recurrence allocation failed"); }
-    }
+
   }
   for (auto& Q : R->subs) {
     Q.d_out = (u8*)ctx->dalloc(Q.out_bytes);

@@ -510,7 +510,7 @@ def test_default_kernel_from_128_lists(monkeypatch, similar):
 
 
 def test_cols_scratch_budget(monkeypatch):
-    """k_merge_cols is not chosen for a batch whose set-aside slices would exceed the scratch budget (KMX_COLS_SCRATCH_GB):
+    """k_merge_cols is not chosen for a batch whose set-aside slices would exceed the scratch budget (KMX_COLS_SCRATCH_GB / _MB):
     the batch goes to the next kernel, same result."""
     torch = pytest.importorskip("torch")
     from kmtricks_amd import lib
@@ -526,10 +526,10 @@ def test_cols_scratch_budget(monkeypatch):
     dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
     torch.cuda.synchronize()
     task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
-                soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT, rows_hint=1_500_000)      # (a hint that makes the slices ~2 GB)
+                soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT)      # (slices of ~100 MB: sized by the row keys, i.e. the lists' lengths)
     eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT)
-    for budget, kern in (("1", "k_merge_pivot"), ("8", "k_merge_cols")):
-        monkeypatch.setenv("KMX_COLS_SCRATCH_GB", budget)
+    for budget, kern in (("8", "k_merge_pivot"), ("8000", "k_merge_cols")):
+        monkeypatch.setenv("KMX_COLS_SCRATCH_MB", budget)
         res = ctx.merge_dev([task]); res.wait()
         assert res.kernel() == kern
         assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
