@@ -227,6 +227,19 @@ int kmx_superk_sample(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, 
                       uint32_t kmer_size, uint32_t minim_size, uint64_t budget, kmx_superk_stats* stats,
                       uint64_t* n_used, uint64_t* n_superk);
 
+/* One sample (or one batch of its reads) from reads to counts in ONE call: kmx_superk_partition[_stats] + kmx_count_batch
+ * with the super-k-mer streams never leaving HBM (what SuperKTask + CountTask / HashCountTask do through the skp files,
+ * task.hpp:255-320, 367-392, 447-481).  keys / counts / n_out / out_kmers: arrays of nb_parts entries as in kmx_count_batch
+ * (partition p's window index is p in hash mode); superk_bytes / superk_len: NULL, or arrays that receive the streams as
+ * kmx_superk_partition returns them (--keep-tmp); superk_info: NULL or 2 * nb_parts numbers, per partition what
+ * SuperKStorageWriter::SaveInfoFile reports for its skp file (io/superk_storage.hpp:205-225, 328-340: k-mers since the last
+ * full 32 KB block, bytes of the blocks flushed before it); stats: NULL or as in kmx_superk_partition_stats. */
+int kmx_count_reads(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                    uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart, uint32_t nb_parts,
+                    int hash_mode, uint64_t window, uint32_t hard_min,
+                    uint64_t** keys, uint32_t** counts, uint64_t* n_out, uint64_t* out_kmers,
+                    uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info, kmx_superk_stats* stats);
+
 void kmx_free(void* p);
 
 #ifdef __cplusplus

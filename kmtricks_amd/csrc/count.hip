@@ -543,3 +543,49 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
   if (rc != KMX_OK) for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
   return rc;
 }
+
+
+// ---- split -> count without the streams leaving HBM (kmx_count_reads; called from superk.hip) ---------------------------
+// record i of the partition-ordered stream: byte offset = low word of prefix[i], first k-mer index = high word
+__global__ void k_prefix_split(const u64* __restrict__ prefix, u32 n, u32* __restrict__ rec_off, u32* __restrict__ kmer_off)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const u64 v = prefix[i]; rec_off[i] = (u32)v; kmer_off[i] = (u32)(v >> 32); }
+}
+
+int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, const u16* d_part, u32 nr, u64 total, u32 n_parts, const kmx_count_req& rq)
+{
+  const u32 k = rq.k; const int hash_mode = rq.hash_mode; const u64 window = rq.window;
+  const int kw = (k + 31) / 32;
+  if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one batch: split it");
+  StageClock clk(ctx->stream, "count_reads");
+  if (total == 0) { for (u32 p = 0; p < n_parts; p++) { rq.keys[p] = (uint64_t*)malloc(8); rq.counts[p] = (uint32_t*)malloc(4); rq.n_out[p] = 0; } return KMX_OK; }
+  const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
+  u32* d_ro = (u32*)ctx->dalloc((size_t)nr * 4), *d_ko = (u32*)ctx->dalloc((size_t)nr * 4);
+  u64* d_pid = (u64*)ctx->dalloc((size_t)n_parts * 8);
+  void* d_keys = ctx->dalloc(total * key_bytes);
+  u16* d_kpart = (u16*)ctx->dalloc(total * 2);
+  std::vector<void*> blocks = {d_ro, d_ko, d_pid, d_keys, d_kpart};
+  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
+  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
+  hipStream_t st = ctx->stream; hipError_t e;
+  std::vector<u64> pid(n_parts); for (u32 p = 0; p < n_parts; p++) pid[p] = p;
+  if ((e = hipMemcpyAsync(d_pid, pid.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e)); }
+  dim3 grid((nr + 255) / 256), block(256);
+  hipLaunchKernelGGL(k_prefix_split, grid, block, 0, st, d_prefix, nr, d_ro, d_ko);
+  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<1, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_batch<1, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<2, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  else hipLaunchKernelGGL((k_superk_decode_batch<2, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
+  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode_batch: ") + hipGetErrorString(e)); }
+  // (pid is read by the kernels above: the stream is synchronised inside batch_sort_rle before this frame ends)
+  clk.mark("decode");
+  unsigned key_bits = 2 * k;
+  if (hash_mode) { key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * n_parts;
+    if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
+  int rc;
+  if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
+  else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
+  release();
+  return rc;
+}

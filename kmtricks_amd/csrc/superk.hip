@@ -245,6 +245,23 @@ __global__ void k_superk_part_bounds(const u16* __restrict__ part_sorted, u32 n,
   part_first[p] = lo;
 }
 
+// What SuperKStorageWriter::SaveInfoFile reports per partition (io/superk_storage.hpp:205-225, 328-340; the file is saved before
+// the final flush): k-mers since the last full 32 KB block, bytes of the blocks flushed so far.  A thread per partition walks
+// its records' sizes (prefix differences).
+__global__ void k_superk_info(const u32* __restrict__ part_first, const u64* __restrict__ prefix, u32 nb_parts, u64* __restrict__ info)
+{
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nb_parts) return;
+  u64 buf = 0, km = 0, flushed = 0;
+  for (u32 i = part_first[p]; i < part_first[p + 1]; i++) {
+    const u64 a = prefix[i], b = prefix[i + 1];
+    const u64 nb = (u32)b - (u32)a, n = (b >> 32) - (a >> 32);
+    if (buf + nb > 32768) { flushed += buf + 4; buf = 0; km = 0; }
+    buf += nb; km += n;
+  }
+  info[2 * p] = km; info[2 * p + 1] = flushed;
+}
+
 // four ASCII bases (one unaligned dword) -> four 2-bit codes in one byte, first base in the low bits
 __device__ __forceinline__ u32 pack4(u32 w)
 {
@@ -342,7 +359,8 @@ struct StatsDev {
 static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
                        uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
                        uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats,
-                       bool sampling = false, uint64_t budget = 0, uint64_t* n_used = nullptr, uint64_t* n_superk = nullptr)
+                       bool sampling = false, uint64_t budget = 0, uint64_t* n_used = nullptr, uint64_t* n_superk = nullptr,
+                       const kmx_count_req* creq = nullptr, bool streams_to_host = true, uint64_t* superk_info = nullptr)
 {
   if (!ctx) return KMX_E_INVAL;
   const bool want_streams = out_bytes != nullptr;
@@ -416,7 +434,15 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = hipMemcpyAsync(&nd, d_doff + n_seqs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   clk.mark("upload+scan");
-  if (nd == 0) { release(); for (u32 p = 0; p < nb_parts; p++) out_bytes[p] = (uint8_t*)malloc(1); return KMX_OK; }
+  if (nd == 0) {
+    release();
+    for (u32 p = 0; p < nb_parts; p++) {
+      if (streams_to_host) out_bytes[p] = (uint8_t*)malloc(1);
+      if (creq) { creq->keys[p] = (uint64_t*)malloc(8); creq->counts[p] = (uint32_t*)malloc(4); creq->n_out[p] = 0; }
+      if (superk_info) { superk_info[2 * p] = 0; superk_info[2 * p + 1] = 0; }
+    }
+    return KMX_OK;
+  }
 
   SkDesc* d_desc = (SkDesc*)ctx->dalloc((size_t)nd * sizeof(SkDesc));
   u16* d_keys = (u16*)ctx->dalloc((size_t)nd * 2), *d_keys2 = (u16*)ctx->dalloc((size_t)nd * 2);
@@ -460,6 +486,19 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   hipLaunchKernelGGL(k_superk_pack, g2, b2, 0, st, d_bases, d_desc, d_ids2, d_boff, nd, (int)k, d_out);
   if ((e = hipGetLastError()) != hipSuccess) { ctx->hfree(h_out); return fail(e, "k_superk_pack"); }
   clk.mark("pack");
+  for (u32 p = 0; p < nb_parts; p++) out_kmers[p] = (pp[p + 1] >> 32) - (pp[p] >> 32);
+  if (superk_info) {
+    u64* d_info = (u64*)ctx->dalloc((size_t)nb_parts * 16); blocks.push_back(d_info);
+    if (!d_info) { ctx->hfree(h_out); release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+    hipLaunchKernelGGL(k_superk_info, dim3((nb_parts + 63) / 64), dim3(64), 0, st, d_pf, d_boff, nb_parts, d_info);
+    if ((e = hipMemcpyAsync(superk_info, d_info, (size_t)nb_parts * 16, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) { ctx->hfree(h_out); return fail(e, "superk info"); }
+  }
+  if (creq) {   // count straight from the device-resident stream (kmx_count_reads)
+    const int rc = kmx_count_from_device(ctx, d_out, d_boff, d_keys2, nd, tot >> 32, nb_parts, *creq);
+    if (rc != KMX_OK) { ctx->hfree(h_out); release(); return rc; }
+    clk.mark("count");
+  }
+  if (!streams_to_host) { ctx->hfree(h_out); release(); return KMX_OK; }
   // the partition-ordered stream comes back in one copy; a few host threads cut it into the per-partition buffers
   if ((e = hipMemcpyAsync(h_out, d_out, total_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipStreamSynchronize(st)) != hipSuccess) { ctx->hfree(h_out); return fail(e, "download"); }
@@ -507,4 +546,23 @@ extern "C" int kmx_superk_sample(kmx_ctx* ctx, const char* bases, const uint64_t
 {
   if (ctx && (!stats || !n_used || !n_superk)) return ctx->fail(KMX_E_INVAL, "kmx_superk_sample: null argument");
   return superk_impl(ctx, bases, offsets, n_seqs, k, m, nullptr, 1, nullptr, nullptr, nullptr, stats, true, budget, n_used, n_superk);
+}
+
+extern "C" int kmx_count_reads(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                               uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
+                               int hash_mode, uint64_t window, uint32_t hard_min,
+                               uint64_t** keys, uint32_t** counts, uint64_t* n_out, uint64_t* out_kmers,
+                               uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info, kmx_superk_stats* stats)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!keys || !counts || !n_out || !out_kmers || (superk_bytes && !superk_len)) return ctx->fail(KMX_E_INVAL, "kmx_count_reads: null argument");
+  if (hash_mode && window == 0) return ctx->fail(KMX_E_INVAL, "hash window is 0");
+  for (u32 p = 0; p < nb_parts; p++) { keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
+  kmx_count_req rq{k, hash_mode, window, hard_min, keys, counts, n_out};
+  std::vector<uint8_t*> dummy_b; std::vector<uint64_t> dummy_l;
+  uint8_t** ob = superk_bytes; uint64_t* ol = superk_len;
+  if (!ob) { dummy_b.assign(nb_parts, nullptr); dummy_l.assign(nb_parts, 0); ob = dummy_b.data(); ol = dummy_l.data(); }
+  const int rc = superk_impl(ctx, bases, offsets, n_seqs, k, m, repart, nb_parts, ob, ol, out_kmers, stats, false, 0, nullptr, nullptr, &rq, superk_bytes != nullptr, superk_info);
+  if (rc != KMX_OK) for (u32 p = 0; p < nb_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
+  return rc;
 }

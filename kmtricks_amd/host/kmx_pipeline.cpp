@@ -371,6 +371,52 @@ int run(int argc, char** argv)
       while (done < per_gpu[g]) {
         ReadBatch b;
         if (!chan[g]->pop(b)) break;
+        if (b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk") {
+          // ---- the whole sample in one batch: split + count in one call, the super-k-mer streams stay in HBM (kmx_count_reads) ----
+          const auto t = clk::now();
+          const uint32_t si = b.si; const Sample& smp = samples[si];
+          tlog(g, "split_begin", si);
+          st.bases += b.bases.size();
+          std::vector<uint64_t*> keys(P, nullptr); std::vector<uint32_t*> cnts(P, nullptr); std::vector<uint64_t> cnt(P, 0), nkp(P, 0), info(2 * (size_t)P, 0);
+          std::vector<uint8_t*> ob(P, nullptr); std::vector<uint64_t> ol(P, 0);
+          auto pc = std::make_shared<std::vector<uint64_t>>(), ms = std::make_shared<std::vector<uint64_t>>(), mk = std::make_shared<std::vector<uint64_t>>();
+          kmx_superk_stats ks{};
+          if (!o.skip_pinfo) { pc->assign((size_t)P * KMX_PINFO_STRIDE, 0); ms->assign(nm, 0); mk->assign(nm, 0); ks.part_counters = pc->data(); ks.minim_superks = ms->data(); ks.minim_kmers = mk->data(); }
+          chk(c, kmx_count_reads(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, smp.hard_min,
+                                 keys.data(), cnts.data(), cnt.data(), nkp.data(), o.keep_tmp ? ob.data() : nullptr, o.keep_tmp ? ol.data() : nullptr, info.data(),
+                                 o.skip_pinfo ? nullptr : &ks), "kmx_count_reads");
+          uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
+          st.kmers += nkt;
+          { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string(selected[p] ? nkp[p] : 0); s2 += "\n"; }
+            Out pi(root + "/partition_infos/" + smp.id + ".pinfo"); pi.raw(s2.data(), s2.size()); pi.close(); }
+          const std::string sd = root + "/superkmers/" + smp.id; fs::create_directories(sd);
+          { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
+            for (uint32_t p = 0; p < P; p++) {
+              inf += std::to_string(selected[p] ? info[2 * p] : 0) + "\n" + std::to_string(selected[p] ? info[2 * p + 1] : 0) + "\n";
+              if (o.keep_tmp && selected[p]) { SuperkBlockWriter w(sd + "/skp." + std::to_string(p), p, o.cpr); w.add_stream(ob[p], ol[p], o.k); w.flush(); w.out.close(); }
+              if (o.keep_tmp) kmx_free(ob[p]);
+            }
+            Out f(sd + "/SuperKmerBinInfoFile"); f.raw(inf.data(), inf.size()); f.close(); }
+          if (!o.skip_pinfo) {
+            uint64_t nk_all = 0; for (uint32_t p = 0; p < P; p++) nk_all += nkp[p];
+            const uint64_t nsk = ks.nb_superk;
+            writes.push_back(pool.submit([=]() { try { write_parti_info(sd + "/PartiInfoFile", P, nm, nsk, nk_all, pc->data(), ms->data(), mk->data()); } catch (const std::exception& e) { die(e.what()); } }));
+          }
+          for (uint32_t p = 0; p < P; p++) {
+            uint64_t* kk = keys[p]; uint32_t* cc = cnts[p]; const uint64_t nn = cnt[p];
+            if (!selected[p]) { kmx_free(kk); kmx_free(cc); continue; }
+            writes.push_back(pool.submit([=, &o]() {
+              try { if (hash_mode) write_hash_file(count_path(p, si), si, p, kk, cc, nn); else write_kmer_file(count_path(p, si), o.k, si, p, kk, cc, nn, o.cpr); }
+              catch (const std::exception& e) { die(e.what()); }
+              kmx_free(kk); kmx_free(cc);
+            }));
+          }
+          tlog(g, "split_end", si);
+          w_count += since(t);
+          done++;
+          while (writes.size() > 4u * P) { writes.front().get(); writes.pop_front(); }
+          continue;
+        }
         SampleState& S = open[b.si];
         if (S.streams.empty()) { S.streams.resize(P); S.nk.assign(P, 0); if (!o.skip_pinfo) { S.pc.assign((size_t)P * KMX_PINFO_STRIDE, 0); S.ms.assign(nm, 0); S.mk.assign(nm, 0); } }
         if (b.offs.size() > 1) {

@@ -80,7 +80,11 @@ _lib.kmx_alloc_pinned.restype = _vp
 _lib.kmx_alloc_pinned.argtypes = [C.c_size_t]
 _lib.kmx_free_pinned.argtypes = [_vp]
 
-EXPORTS = ["kmx_version", "kmx_device_count", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+_lib.kmx_count_reads.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_int, C.c_uint64, C.c_uint32,
+                                 C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                 C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(KmxSuperkStats)]
+
+EXPORTS = ["kmx_version", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -258,6 +262,30 @@ class Context:
                 _lib.kmx_free(ob[p])
         assert st.nb_superk == int(ms.sum())
         return out, pin.reshape(nb_parts, -1), ms, mk, mx
+
+    def count_reads(self, reads, k, m, repart, nb_parts, hard_min, window=0, streams=False):
+        """kmx_count_reads: reads -> [(keys, counts)] per partition without the super-k-mer streams leaving HBM
+        -> (counts per partition, k-mers per partition, [(stream, ...)] or None, info numbers uint64[nb_parts, 2])"""
+        blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
+        rep = np.ascontiguousarray(repart, dtype=np.uint16)
+        kp, cp, no, nk = (_vp * nb_parts)(), (_vp * nb_parts)(), (C.c_uint64 * nb_parts)(), (C.c_uint64 * nb_parts)()
+        ob, ol = (_vp * nb_parts)(), (C.c_uint64 * nb_parts)()
+        info = (C.c_uint64 * (2 * nb_parts))()
+        self._check(_lib.kmx_count_reads(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
+                                         1 if window else 0, window, hard_min, kp, cp, no, nk, ob if streams else None,
+                                         ol if streams else None, info, None), "kmx_count_reads")
+        width = 1 if window else (k + 31) // 32
+        out = []
+        for p in range(nb_parts):
+            keys, cnts = self._take(_vp(kp[p]), _vp(cp[p]), no[p], width)
+            out.append((keys.reshape(-1) if window else keys, cnts))
+        st = None
+        if streams:
+            st = []
+            for p in range(nb_parts):
+                st.append(C.string_at(ob[p], ol[p]) if ol[p] else b"")
+                _lib.kmx_free(ob[p])
+        return out, [int(x) for x in nk], st, np.array(list(info), dtype=np.uint64).reshape(nb_parts, 2)
 
     def superk_sample(self, reads, k, m, budget):
         """kmx_superk_sample -> (reads used, their super-k-mers, kx-mers per minimizer)"""

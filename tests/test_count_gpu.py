@@ -142,6 +142,36 @@ def test_superk_statistics_vs_oracle(ctx, k, m, P):
     assert none is None and np.array_equal(ms2, ems) and np.array_equal(mk2, emk) and np.array_equal(mx2, emx)
 
 
+@pytest.mark.parametrize("k,m,P,hard_min,hashed", [(31, 10, 8, 1, False), (31, 10, 8, 2, True), (63, 10, 32, 2, False), (21, 8, 5, 3, False), (32, 10, 16, 1, True)])
+def test_count_reads_fused_vs_oracle(ctx, k, m, P, hard_min, hashed):
+    """kmx_count_reads (split + count with the streams resident in HBM) == oracle split, then oracle count of every partition;
+    the streams it can hand back are the split's, the info numbers those of the skp block framing"""
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    reads = random_reads(700 + k, 400, 150, n_rate=0.003) * 2 + ["ACGT" * 70, "A" * 300, "", "T" * k, "acgtacgtnnacgt" * 12]
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    W = 6400
+    got, nk, streams, info = ctx.count_reads(reads, k, m, rep, P, hard_min, window=W if hashed else 0, streams=True)
+    for p in range(P):
+        assert streams[p] == exp[p][0] and nk[p] == exp[p][1]
+        if hashed:
+            ek, ec = orc.count_hash(exp[p][0], k, W, p, hard_min)
+            assert np.array_equal(got[p][0], ek) and np.array_equal(got[p][1], ec)
+        else:
+            ek, ec = orc.count_kmer(exp[p][0], k, hard_min)
+            assert np.array_equal(got[p][0], ek) and np.array_equal(got[p][1], ec)
+        # block framing of the stream (<= 32768-byte blocks): k-mers since the last flush, bytes flushed
+        buf = km = fl = pos = 0
+        s = exp[p][0]
+        while pos < len(s):
+            n = s[pos]; nb = 1 + (k + n - 1 + 3) // 4
+            if buf + nb > 32768: fl += buf + 4; buf = 0; km = 0
+            buf += nb; km += n; pos += nb
+        assert (int(info[p, 0]), int(info[p, 1])) == (km, fl)
+    got2, nk2, none, _ = ctx.count_reads(reads, k, m, rep, P, hard_min, window=W if hashed else 0)
+    assert none is None and nk2 == nk and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got, got2))
+
+
 @pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4)])
 def test_superk_partition_random_reads_vs_oracle(ctx, k, m, P):
     lut = orc.minimizer_lut(m)
