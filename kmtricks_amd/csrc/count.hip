@@ -22,6 +22,7 @@
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include "count_sort.hpp"
 
 namespace kmx {
 
@@ -345,6 +346,97 @@ __global__ void k_part_bounds(const u16* __restrict__ part_sorted, u32 n, u32 n_
   bounds[p] = lo;
 }
 
+// ---- partition-local sample sort + run-length count (count_sort.hpp): keys grouped by partition in d_keys, partition p =
+//      keys [kmoff[p], kmoff[p + 1]).  Returns KMX_OK, a negative error, or 1 when a bucket would not fit the LDS (the caller
+//      then uses the library sort: d_keys is still untouched at that point). ----
+template <typename KeyT>
+static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, const std::vector<u64>& kmoff, u32 n_parts, u32 hard_min,
+                                uint64_t** keys, uint32_t** counts, uint64_t* n_out)
+{
+  const char* force = getenv("KMX_COUNT_SORT");
+  if (force && !strcmp(force, "library")) return 1;
+  const u64 total = kmoff[n_parts];
+  const u32 target = cs_target<KeyT>(), cap = (u32)CsCap<KeyT>::cap;
+  std::vector<CsPart> parts(n_parts); std::vector<CsChunk> chunks;
+  u32 TB = 0;
+  for (u32 p = 0; p < n_parts; p++) {
+    const u64 n = kmoff[p + 1] - kmoff[p];
+    const u64 nb = std::max<u64>(1, (n + target - 1) / target);
+    if (nb > (u64)CS_MAXB) return 1;                       // a partition beyond 256 buckets: the library sort takes the batch
+    parts[p] = CsPart{(u32)kmoff[p], (u32)n, TB, (u32)nb};
+    TB += (u32)nb;
+    for (u64 o = 0; o < n; o += CS_CHUNK) chunks.push_back(CsChunk{p, (u32)(kmoff[p] + o), (u32)std::min<u64>(CS_CHUNK, n - o), 0});
+  }
+  hipStream_t st = ctx->stream;
+  std::vector<void*> blocks;
+  auto dal = [&](size_t b) { void* p = ctx->dalloc(b); blocks.push_back(p); return p; };
+  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
+  CsPart* d_parts = (CsPart*)dal(sizeof(CsPart) * n_parts);
+  CsChunk* d_chunks = (CsChunk*)dal(sizeof(CsChunk) * std::max<size_t>(1, chunks.size()));
+  KeyT* d_spl = (KeyT*)dal(sizeof(KeyT) * (size_t)TB);
+  u32* d_cnt = (u32*)dal(4 * ((size_t)TB + 1)), *d_boff = (u32*)dal(4 * ((size_t)TB + 1)), *d_cur = (u32*)dal(4 * ((size_t)TB + 1));
+  u32* d_nkept = (u32*)dal(4 * ((size_t)TB + 1)), *d_koff = (u32*)dal(4 * ((size_t)TB + 1));
+  KeyT* d_bkeys = (KeyT*)dal(sizeof(KeyT) * total);
+  u32* d_tc = (u32*)dal(4 * total);
+  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count sort: device allocation failed"); }
+  auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+  hipError_t e;
+  if ((e = hipMemcpyAsync(d_parts, parts.data(), sizeof(CsPart) * n_parts, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_chunks, chunks.data(), sizeof(CsChunk) * chunks.size(), hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemsetAsync(d_cnt, 0, 4 * ((size_t)TB + 1), st)) != hipSuccess) return fail(e, "count sort upload");
+  hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(n_parts), dim3(CS_TPB), 0, st, d_keys, d_parts, d_spl);
+  hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cnt, (KeyT*)nullptr);
+  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_cnt, TB, d_boff);
+  std::vector<u32> boff((size_t)TB + 1);
+  if ((e = hipMemcpyAsync(boff.data(), d_boff, 4 * ((size_t)TB + 1), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort sizes");
+  for (u32 b = 0; b < TB; b++) if (boff[b + 1] - boff[b] > cap) { release(); return 1; }      // (parts / chunks were read by kernels that have finished)
+  clk.mark("buckets");
+  if ((e = hipMemcpyAsync(d_cur, d_boff, 4 * (size_t)TB, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e, "count sort cursors");
+  hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cur, d_bkeys);
+  KeyT* d_tk = d_keys;                     // (the grouped keys are dead behind the scatter: their room takes the kept pairs)
+  hipLaunchKernelGGL((k_cs_sort<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_bkeys, d_boff, hard_min, d_tk, d_tc, d_nkept);
+  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_nkept, TB, d_koff);
+  std::vector<u32> koff((size_t)TB + 1);
+  if ((e = hipMemcpyAsync(koff.data(), d_koff, 4 * ((size_t)TB + 1), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort kept");
+  clk.mark("sort+count");
+  const u32 kept = koff[TB];
+  KeyT* d_ok = d_bkeys;                    // (and the buckets are dead behind the sort)
+  u32* d_oc = (u32*)dal(4 * (size_t)std::max<u32>(kept, 1));
+  KeyT* h_k = kept ? (KeyT*)ctx->halloc((size_t)kept * sizeof(KeyT)) : nullptr;
+  u32* h_c = kept ? (u32*)ctx->halloc((size_t)kept * 4) : nullptr;
+  auto hrel = [&]() { ctx->hfree(h_k); ctx->hfree(h_c); };
+  if (!d_oc || (kept && (!h_k || !h_c))) { hrel(); release(); return ctx->fail(KMX_E_NOMEM, "count sort: allocation failed"); }
+  if (kept) {
+    hipLaunchKernelGGL((k_cs_compact<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_tk, d_tc, d_boff, d_koff, d_ok, d_oc);
+    if ((e = hipMemcpyAsync(h_k, d_ok, (size_t)kept * sizeof(KeyT), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(h_c, d_oc, (size_t)kept * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (e = hipStreamSynchronize(st)) != hipSuccess) { hrel(); return fail(e, "count sort download"); }
+  }
+  std::atomic<u32> next{0}; std::atomic<int> oom{0};
+  auto fill = [&]() {
+    for (u32 p; (p = next++) < n_parts;) {
+      const u32 lo = koff[parts[p].bucket0], hi = koff[parts[p].bucket0 + parts[p].nb];
+      const size_t n = hi - lo;
+      keys[p] = (uint64_t*)malloc(n ? n * sizeof(KeyT) : 8);
+      counts[p] = (uint32_t*)malloc(n ? n * 4 : 4);
+      if (!keys[p] || !counts[p]) { oom = 1; continue; }
+      n_out[p] = n;
+      if (n) { memcpy(keys[p], h_k + lo, n * sizeof(KeyT)); memcpy(counts[p], h_c + lo, n * 4); }
+    }
+  };
+  {
+    const unsigned nthr = std::max(1u, std::min({16u, std::thread::hardware_concurrency(), n_parts}));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthr; t++) th.emplace_back(fill);
+    fill();
+    for (auto& x : th) x.join();
+  }
+  hrel(); release();
+  if (oom) return ctx->fail(KMX_E_NOMEM, "count sort: host allocation failed");
+  clk.mark("download");
+  return KMX_OK;
+}
+
 // ---- batched count: every partition stream of one sample in one call ---------------------------------
 // One global radix sort of (key, partition) pairs, one run-length pass, then only the kept runs are
 // regrouped by partition (stable, so each partition's keys stay ascending).
@@ -537,8 +629,14 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
   if (hash_mode) { u64 top = 0; for (u32 p = 0; p < n_parts; p++) top = std::max(top, pid[p]); key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * (top + 1);
     if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
   int rc;
-  if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), hard_min, keys, counts, n_out);
-  else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), hard_min, keys, counts, n_out);
+  // partition-local sample sort first (count_sort.hpp); the library sort when a bucket would not fit the LDS
+  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, km_base, n_parts, hard_min, keys, counts, n_out);
+  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, km_base, n_parts, hard_min, keys, counts, n_out);
+  if (rc == 1) {
+    for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
+    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), hard_min, keys, counts, n_out);
+    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), hard_min, keys, counts, n_out);
+  }
   release();
   if (rc != KMX_OK) for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
   return rc;
@@ -553,7 +651,7 @@ __global__ void k_prefix_split(const u64* __restrict__ prefix, u32 n, u32* __res
   if (i < n) { const u64 v = prefix[i]; rec_off[i] = (u32)v; kmer_off[i] = (u32)(v >> 32); }
 }
 
-int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, const u16* d_part, u32 nr, u64 total, u32 n_parts, const kmx_count_req& rq)
+int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, const u16* d_part, u32 nr, u64 total, u32 n_parts, const u64* part_kmer_off, const kmx_count_req& rq)
 {
   const u32 k = rq.k; const int hash_mode = rq.hash_mode; const u64 window = rq.window;
   const int kw = (k + 31) / 32;
@@ -584,8 +682,14 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
   if (hash_mode) { key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * n_parts;
     if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
   int rc;
-  if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
-  else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
+  std::vector<u64> kmoff(part_kmer_off, part_kmer_off + n_parts + 1);
+  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, kmoff, n_parts, rq.hard_min, rq.keys, rq.counts, rq.n_out);
+  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, kmoff, n_parts, rq.hard_min, rq.keys, rq.counts, rq.n_out);
+  if (rc == 1) {
+    for (u32 p = 0; p < n_parts; p++) { free(rq.keys[p]); free(rq.counts[p]); rq.keys[p] = nullptr; rq.counts[p] = nullptr; rq.n_out[p] = 0; }
+    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
+    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
+  }
   release();
   return rc;
 }

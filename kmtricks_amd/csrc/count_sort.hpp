@@ -1,0 +1,189 @@
+// count_sort.hpp -- partition-local sort + run-length count of decoded k-mers (or window hashes) on gfx950: the device side of
+// km::KmerSort / HashSort + KmerPartCounter / HashPartCounter::executeDump (reference include/kmtricks/gatb/sorting_count.hpp:
+// 488-533 sort, 694-884 and 971-990 run-length dump; count_processor.hpp:61-70, 135-146 hard-min).  Included by count.hip.
+//
+// The decode kernel leaves the keys grouped by partition.  A partition (tens to hundreds of thousands of keys) does not fit the
+// LDS, a bucket of it does -- so it is a SAMPLE SORT per partition, every stage staged in LDS, no key ever compared in HBM:
+//   k_cs_splitters  a workgroup per partition sorts an even sample of its keys in LDS (bitonic) and keeps every (sample / buckets)-th
+//                   as a splitter: buckets of ~1500 keys whatever the key distribution (canonical k-mers of a minimizer partition
+//                   crowd a few prefixes -- a fixed radix digit would not balance);
+//   k_cs_count      a workgroup per chunk of 4096 keys: bucket of every key by binary search in the partition's splitters (LDS),
+//                   LDS histogram, one global add per bucket and chunk;
+//   k_cs_scan       exclusive scan of the bucket sizes (one workgroup);
+//   k_cs_scatter    the same walk again: a key goes to its bucket's place (rank inside the chunk from the LDS histogram, the
+//                   chunk's base from one global add per bucket);
+//   k_cs_sort       a workgroup per bucket: keys into LDS, bitonic sort, run starts by neighbour compare, run lengths = counts,
+//                   runs of at least hard-min kept (counts saturate at u32); the kept (key, count) pairs go to the bucket's own
+//                   place in a temporary, their number to a table;
+//   k_cs_scan + k_cs_compact  the kept pairs of all buckets, packed: partition p's result is one ascending run.
+// Equal keys always share a bucket (the splitter compare decides).  A bucket over the LDS capacity (a k-mer repeated thousands of
+// times, an unlucky sample) makes the call fall back to the library sort (rocPRIM radix sort + run-length encode) -- same result.
+// Traffic per k-mer: 8 B written by the decode, read 3 times and written once here (K + 4 per DISTINCT k-mer out): ~40 B against
+// the >= 128 B of an 8-pass LSD radix sort over the whole batch.
+#pragma once
+#include "kmx_dev.hpp"
+
+namespace kmx {
+
+constexpr int CS_TPB = 256;
+constexpr int CS_CHUNK = 4096;            // keys per workgroup in the count / scatter walks
+constexpr int CS_MAXB = 256;              // buckets per partition
+constexpr int CS_SAMPLE = 4096;           // keys sampled per partition (<= CS_SAMPLE, >= 16 per bucket)
+template <typename K> struct CsCap { static constexpr int cap = 4096; };            // keys of a bucket that fit the sort's LDS
+template <> struct CsCap<__uint128_t> { static constexpr int cap = 2048; };
+template <typename K> __host__ __device__ inline u32 cs_target() { return (u32)CsCap<K>::cap * 3 / 8; }      // aimed bucket size
+
+struct CsPart { u32 key0, nkeys, bucket0, nb; };      // a partition's keys [key0, key0 + nkeys), its buckets [bucket0, bucket0 + nb)
+struct CsChunk { u32 part, key0, nkeys, pad; };
+
+template <typename K> __device__ __forceinline__ K cs_max() { return ~(K)0; }
+
+template <typename K>
+__global__ __launch_bounds__(CS_TPB)
+void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, K* __restrict__ splitters)
+{
+  __shared__ K sm[CS_SAMPLE];
+  const CsPart P = parts[blockIdx.x];
+  if (P.nb <= 1) return;
+  const u32 tid = threadIdx.x;
+  u32 S = 16 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, (u32)CS_SAMPLE); }      // samples: a power of two
+  for (u32 i = tid; i < S; i += CS_TPB) sm[i] = keys[P.key0 + (u32)(((u64)i * P.nkeys) / S)];
+  __syncthreads();
+  for (u32 k2 = 2; k2 <= S; k2 <<= 1)
+    for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+      for (u32 t = tid; t < S / 2; t += CS_TPB) {
+        const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
+        const K x = sm[a], y = sm[b];
+        if ((x > y) == ((a & k2) == 0)) { sm[a] = y; sm[b] = x; }
+      }
+      __syncthreads();
+    }
+  // bucket b holds the keys k with splitter[b - 1] <= k < splitter[b]
+  for (u32 b = tid; b + 1 < P.nb; b += CS_TPB) splitters[(u64)P.bucket0 + b] = sm[(u32)(((u64)(b + 1) * S) / P.nb)];
+}
+
+template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32 nb, K k)
+{ // number of splitters <= k
+  u32 lo = 0, hi = nb - 1;
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (spl[mid] <= k) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// SCATTER = false: bucket sizes.  SCATTER = true: keys to their buckets (cursor[] starts at the buckets' offsets).
+template <typename K, bool SCATTER>
+__global__ __launch_bounds__(CS_TPB)
+void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, const CsChunk* __restrict__ chunks, const K* __restrict__ splitters,
+               u32* __restrict__ counts_or_cursor, K* __restrict__ out)
+{
+  __shared__ K spl[CS_MAXB];
+  __shared__ u32 hist[CS_MAXB];
+  __shared__ u32 base[CS_MAXB];
+  const CsChunk C = chunks[blockIdx.x];
+  const CsPart P = parts[C.part];
+  const u32 tid = threadIdx.x;
+  for (u32 b = tid; b < P.nb; b += CS_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
+  __syncthreads();
+  K k[CS_CHUNK / CS_TPB]; u32 bk[CS_CHUNK / CS_TPB], rk[CS_CHUNK / CS_TPB];
+#pragma unroll
+  for (int x = 0; x < CS_CHUNK / CS_TPB; x++) {
+    const u32 i = tid + x * CS_TPB;
+    bk[x] = 0xFFFFFFFFu;
+    if (i < C.nkeys) { k[x] = keys[C.key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<K>(spl, P.nb, k[x]) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
+  }
+  __syncthreads();
+  if (!SCATTER) { for (u32 b = tid; b < P.nb; b += CS_TPB) if (hist[b]) atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]); return; }
+  for (u32 b = tid; b < P.nb; b += CS_TPB) base[b] = hist[b] ? atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int x = 0; x < CS_CHUNK / CS_TPB; x++) if (bk[x] != 0xFFFFFFFFu) out[base[bk[x]] + rk[x]] = k[x];
+}
+
+// exclusive scan of n u32 values (n <= a few 100 k): one workgroup, 1024 threads; out[n] = total
+__global__ __launch_bounds__(1024)
+void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out)
+{
+  __shared__ u32 part[1024];
+  const u32 tid = threadIdx.x, per = (n + 1023) / 1024;
+  u32 s = 0;
+  for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) s += in[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) { u32 a = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = a; a += v; } out[n] = a; }
+  __syncthreads();
+  u32 a = part[tid];
+  for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) { const u32 v = in[i]; out[i] = a; a += v; }
+}
+
+// a workgroup per bucket: sort in LDS, run-length count, hard-min.  kept pairs -> tk / tc at the bucket's offset, their number -> nkept
+template <typename K>
+__global__ __launch_bounds__(CS_TPB)
+void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept)
+{
+  constexpr int CAP = CsCap<K>::cap;
+  __shared__ K sk[CAP];
+  __shared__ u32 starts[CAP];      // positions of the run starts, in order
+  __shared__ u32 wsum[CS_TPB / 64];
+  const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 o = boff[b], n = boff[b + 1] - o;
+  if (n == 0) { if (tid == 0) nkept[b] = 0; return; }
+  u32 Pn = 2; while (Pn < n) Pn <<= 1;
+  for (u32 i = tid; i < Pn; i += CS_TPB) sk[i] = i < n ? bkeys[o + i] : cs_max<K>();
+  __syncthreads();
+  for (u32 k2 = 2; k2 <= Pn; k2 <<= 1)
+    for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+      for (u32 t = tid; t < Pn / 2; t += CS_TPB) {
+        const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), c = a | j;
+        const K x = sk[a], y = sk[c];
+        if ((x > y) == ((a & k2) == 0)) { sk[a] = y; sk[c] = x; }
+      }
+      __syncthreads();
+    }
+  // run starts among the n real keys (pads sort last; a real key may equal the pad value: positions decide, not values)
+  constexpr int PT = CAP / CS_TPB;
+  u32 mine = 0, m = 0;
+#pragma unroll
+  for (int x = 0; x < PT; x++) {
+    const u32 i = tid * PT + x;
+    if (i < n) { const bool st = i == 0 || sk[i - 1] != sk[i]; m |= (st ? 1u : 0u) << x; mine += st ? 1u : 0u; }
+  }
+  const u32 incl = wave_incl_scan(mine, (int)lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 r = incl - mine, nruns = 0;
+  for (u32 w = 0; w < CS_TPB / 64; w++) { if (w < wave) r += wsum[w]; nruns += wsum[w]; }
+#pragma unroll
+  for (int x = 0; x < PT; x++) if ((m >> x) & 1u) starts[r++] = tid * PT + x;
+  __syncthreads();
+  // kept runs, in order
+  u32 kept = 0, km = 0;
+  const u32 per = (nruns + CS_TPB - 1) / CS_TPB;      // consecutive runs per thread
+  for (u32 x = 0; x < per; x++) {
+    const u32 j = tid * per + x;
+    if (j < nruns) { const u32 len = (j + 1 < nruns ? starts[j + 1] : n) - starts[j]; if (len >= hard_min) kept++; }
+  }
+  (void)km;
+  const u32 incl2 = wave_incl_scan(kept, (int)lane);
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl2;
+  __syncthreads();
+  u32 w0 = incl2 - kept, tot = 0;
+  for (u32 w = 0; w < CS_TPB / 64; w++) { if (w < wave) w0 += wsum[w]; tot += wsum[w]; }
+  for (u32 x = 0; x < per; x++) {
+    const u32 j = tid * per + x;
+    if (j < nruns) {
+      const u32 s = starts[j], len = (j + 1 < nruns ? starts[j + 1] : n) - s;
+      if (len >= hard_min) { tk[o + w0] = sk[s]; tc[o + w0] = len; w0++; }      // (a run is at most the bucket: no saturation below 2^32)
+    }
+  }
+  if (tid == 0) nkept[b] = tot;
+}
+
+template <typename K>
+__global__ __launch_bounds__(CS_TPB)
+void k_cs_compact(const K* __restrict__ tk, const u32* __restrict__ tc, const u32* __restrict__ boff, const u32* __restrict__ koff, K* __restrict__ ok, u32* __restrict__ oc)
+{
+  const u32 b = blockIdx.x, src = boff[b], dst = koff[b], n = koff[b + 1] - dst;
+  for (u32 i = threadIdx.x; i < n; i += CS_TPB) { ok[dst + i] = tk[src + i]; oc[dst + i] = tc[src + i]; }
+}
+
+}  // namespace kmx

@@ -51,7 +51,7 @@ hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hip
 //      record stream, every record's (k-mers << 32 | bytes) prefix and partition to count.hip ----
 struct kmx_count_req { kmx::u32 k; int hash_mode; kmx::u64 window; kmx::u32 hard_min; uint64_t** keys; uint32_t** counts; uint64_t* n_out; };
 int kmx_count_from_device(kmx_ctx* ctx, const kmx::u8* d_recs, const kmx::u64* d_prefix, const kmx::u16* d_part, kmx::u32 n_recs,
-                          kmx::u64 total_kmers, kmx::u32 n_parts, const kmx_count_req& rq);
+                          kmx::u64 total_kmers, kmx::u32 n_parts, const kmx::u64* part_kmer_off /* n_parts + 1, host */, const kmx_count_req& rq);
 
 // ---- context -------------------------------------------------------------------------------------
 struct kmx_pool_block { void* p; size_t bytes; bool used; };

@@ -494,7 +494,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     if ((e = hipMemcpyAsync(superk_info, d_info, (size_t)nb_parts * 16, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) { ctx->hfree(h_out); return fail(e, "superk info"); }
   }
   if (creq) {   // count straight from the device-resident stream (kmx_count_reads)
-    const int rc = kmx_count_from_device(ctx, d_out, d_boff, d_keys2, nd, tot >> 32, nb_parts, *creq);
+    std::vector<u64> pko((size_t)nb_parts + 1); for (u32 p = 0; p <= nb_parts; p++) pko[p] = pp[p] >> 32;
+    const int rc = kmx_count_from_device(ctx, d_out, d_boff, d_keys2, nd, tot >> 32, nb_parts, pko.data(), *creq);
     if (rc != KMX_OK) { ctx->hfree(h_out); release(); return rc; }
     clk.mark("count");
   }

@@ -142,6 +142,34 @@ def test_superk_statistics_vs_oracle(ctx, k, m, P):
     assert none is None and np.array_equal(ms2, ems) and np.array_equal(mk2, emk) and np.array_equal(mx2, emx)
 
 
+@pytest.mark.parametrize("path", ["sample-sort", "library", "overflow"])
+def test_count_sort_paths(ctx, monkeypatch, path):
+    """the partition-local sample sort (count_sort.hpp), the library sort it falls back to (forced, and taken by itself when a
+    k-mer repeated thousands of times overflows a bucket) -- same counts, large enough for several buckets per partition"""
+    if path == "library":
+        monkeypatch.setenv("KMX_COUNT_SORT", "library")
+    k, m, P = 31, 10, 4
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    reads = random_reads(4242, 1500, 150, n_rate=0.002) * 3
+    if path == "overflow":
+        reads = reads + ["ACGTTGCAAGGCTTAAGCCGATTACAGGCTAAGCTTAGGCATCG"] * 6000
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    got = ctx.count_batch([e[0] for e in exp], k, 2)
+    tot = 0
+    for p in range(P):
+        ek, ec = orc.count_kmer(exp[p][0], k, 2)
+        assert np.array_equal(got[p][0], ek) and np.array_equal(got[p][1], ec)
+        tot += len(ec)
+    assert tot > 150_000
+    if path == "overflow":
+        assert max(int(g[1].max()) for g in got if len(g[1])) >= 6000
+    goth = ctx.count_batch([e[0] for e in exp], k, 1, window=100003, partitions=[7, 3, 0, 9])
+    for p, wid in enumerate([7, 3, 0, 9]):
+        ek, ec = orc.count_hash(exp[p][0], k, 100003, wid, 1)
+        assert np.array_equal(goth[p][0], ek) and np.array_equal(goth[p][1], ec)
+
+
 @pytest.mark.parametrize("k,m,P,hard_min,hashed", [(31, 10, 8, 1, False), (31, 10, 8, 2, True), (63, 10, 32, 2, False), (21, 8, 5, 3, False), (32, 10, 16, 1, True)])
 def test_count_reads_fused_vs_oracle(ctx, k, m, P, hard_min, hashed):
     """kmx_count_reads (split + count with the streams resident in HBM) == oracle split, then oracle count of every partition;
