@@ -83,7 +83,7 @@ static std::vector<Sample> parse_fof(const std::string& path, uint32_t default_h
 
 static Opt parse_cli(int argc, char** argv)
 {
-  if (argc < 2 || std::string(argv[1]) != "pipeline") die("usage: kmx pipeline --file <fof> --run-dir <dir> [options]  (see INTEGRATION.md)");
+  if (argc < 2 || std::string(argv[1]) != "pipeline") die("usage: kmx pipeline --file <fof> --run-dir <dir> [options] | kmx dump --input <file> [-o out] | kmx aggregate --run-dir <dir> --matrix kmer|hash ...  (see INTEGRATION.md)");
   Opt o;
   auto need = [&](int& i) -> std::string { if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]); return argv[++i]; };
   auto num = [&](int& i) -> unsigned long { const std::string v = need(i); try { size_t n = 0; const unsigned long x = std::stoul(v, &n); if (n != v.size()) throw 1; return x; } catch (...) { die(std::string("bad number for ") + argv[i - 1] + ": " + v); } };
@@ -728,8 +728,11 @@ int run(int argc, char** argv)
   return 0;
 }
 
+int kmx_tools_main(int argc, char** argv);      // kmx_tools.cpp: dump, aggregate
+
 int main(int argc, char** argv)
 {
+  if (argc >= 2 && (std::string(argv[1]) == "dump" || std::string(argv[1]) == "aggregate")) return kmx_tools_main(argc, argv);
   try { return run(argc, argv); }
   catch (const std::exception& e) { die(e.what()); }
 }

@@ -1,0 +1,166 @@
+// kmx_tools.cpp -- `kmx dump` and `kmx aggregate`: the reader-side commands of kmtricks over a kmx run directory
+// (reference src/cli.cpp:648-776 flags; include/kmtricks/cmd.hpp:275-369 main_dump, 441-607 main_agg; text forms:
+// io/kmer_file.hpp:140-148, io/hash_file.hpp:211-219, io/matrix_file.hpp:169-180, 293-304, io/pa_matrix_file.hpp:134-152,
+// 267-285; sorted aggregation = a merge of the partitions' ascending files, io/kmer_file.hpp:171-290, matrix_file.hpp:307-460).
+// Host-only file conversion: no GPU work here (nothing data-parallel is timed on this path).
+#include <algorithm>
+#include <filesystem>
+#include <iostream>
+#include <queue>
+#include <sstream>
+#include "kmx_io.hpp"
+
+namespace fs = std::filesystem;
+using namespace kmxio;
+
+[[noreturn]] static void tdie(const std::string& msg) { std::cerr << "[error] " << msg << std::endl; std::exit(EXIT_FAILURE); }
+
+static std::string kmer_string(const uint8_t* key, uint32_t k)
+{ // Kmer::to_string: nucleotide i (from the first) = digit k-1-i, A0 C1 T2 G3 (kmer.hpp:797-810)
+  std::string s(k, 'A');
+  for (uint32_t i = 0; i < k; i++) { const uint32_t d = k - 1 - i; uint64_t w; memcpy(&w, key + 8 * (d >> 5), 8); s[i] = "ACTG"[(w >> ((d & 31) * 2)) & 3]; }
+  return s;
+}
+
+// one kmtricks file, decoded: rows of `key_bytes` key + payload
+struct KmFile {
+  enum Kind { KMER, HASH, MATRIX, MATRIX_HASH, PA, PA_HASH } kind;
+  uint32_t k = 0, key_bytes = 8, cols = 0, count_slots = 4, pa_bytes = 0, partition = 0;
+  std::vector<uint8_t> body;          // HASH files: re-packed to hash + count records
+  size_t row_bytes() const { return kind == KMER || kind == HASH ? key_bytes + count_slots : kind == MATRIX || kind == MATRIX_HASH ? key_bytes + (size_t)cols * count_slots : key_bytes + pa_bytes; }
+  size_t rows() const { return row_bytes() ? body.size() / row_bytes() : 0; }
+  bool hashed() const { return kind == HASH || kind == MATRIX_HASH || kind == PA_HASH; }
+};
+
+static KmFile load(const std::string& path)
+{
+  std::vector<uint8_t> raw = slurp(path);
+  if (raw.size() < 21 || rd<uint64_t>(&raw[0]) != MAGIC_BASE) tdie("Invalid file format: " + path);
+  const uint64_t magic = rd<uint64_t>(&raw[13]);
+  KmFile f;
+  if (magic == MAGIC_KMER) { f.kind = KmFile::KMER; f.k = rd<uint32_t>(&raw[21]); f.key_bytes = rd<uint32_t>(&raw[25]) * 8; f.count_slots = rd<uint32_t>(&raw[29]); f.partition = rd<uint32_t>(&raw[37]); f.body = body_of(raw, 41, magic, path); }
+  else if (magic == MAGIC_HASH) { f.kind = KmFile::HASH; f.count_slots = 4; f.partition = rd<uint32_t>(&raw[29]); f.body = read_hash_records(path, nullptr); }
+  else if (magic == MAGIC_MATRIX) { f.kind = KmFile::MATRIX; f.k = rd<uint32_t>(&raw[21]); f.key_bytes = rd<uint32_t>(&raw[25]) * 8; f.count_slots = 4; f.cols = rd<uint32_t>(&raw[33]); f.partition = rd<uint32_t>(&raw[41]); f.body = body_of(raw, 45, magic, path); }   // (count_slots is the literal 1 in the header, the counts are 4 bytes: merge.hpp:264)
+  else if (magic == MAGIC_MATRIX_HASH) { f.kind = KmFile::MATRIX_HASH; f.count_slots = rd<uint32_t>(&raw[21]); f.cols = rd<uint32_t>(&raw[25]); f.partition = rd<uint32_t>(&raw[33]); f.body = body_of(raw, 37, magic, path); }
+  else if (magic == MAGIC_PA) { f.kind = KmFile::PA; f.k = rd<uint32_t>(&raw[21]); f.key_bytes = rd<uint32_t>(&raw[25]) * 8; f.cols = rd<uint32_t>(&raw[29]); f.pa_bytes = rd<uint32_t>(&raw[33]); f.partition = rd<uint32_t>(&raw[41]); f.body = body_of(raw, 45, magic, path); }
+  else if (magic == MAGIC_PA_HASH) { f.kind = KmFile::PA_HASH; f.cols = rd<uint32_t>(&raw[21]); f.pa_bytes = rd<uint32_t>(&raw[25]); f.partition = rd<uint32_t>(&raw[33]); f.body = body_of(raw, 37, magic, path); }
+  else tdie("this file type doesn't support text conversion: " + path);
+  if (f.key_bytes == 0 || f.key_bytes > 128 || (f.count_slots != 1 && f.count_slots != 2 && f.count_slots != 4)) tdie("Invalid file format: " + path);
+  return f;
+}
+
+static void row_text(const KmFile& f, const uint8_t* row, bool no_count, std::string& out)
+{
+  if (f.hashed()) out += std::to_string(rd<uint64_t>(row)); else out += kmer_string(row, f.k);
+  if (!no_count) {
+    const uint8_t* p = row + f.key_bytes;
+    if (f.kind == KmFile::PA || f.kind == KmFile::PA_HASH) { for (uint32_t i = 0; i < f.cols; i++) { out += ' '; out += ((p[i >> 3] >> (i & 7)) & 1) ? '1' : '0'; } }
+    else {
+      const uint32_t n = f.kind == KmFile::KMER || f.kind == KmFile::HASH ? 1 : f.cols;
+      for (uint32_t i = 0; i < n; i++) { uint32_t c = 0; memcpy(&c, p + (size_t)i * f.count_slots, f.count_slots); out += ' '; out += std::to_string(c); }
+    }
+  }
+  out += '\n';
+}
+
+struct Sink {
+  std::ostream* os = &std::cout; std::ofstream file;
+  explicit Sink(const std::string& path) { if (path != "stdout") { file.open(path, std::ios::binary); if (!file) tdie("Unable to write at " + path); os = &file; } }
+  void put(const std::string& s) { os->write(s.data(), (std::streamsize)s.size()); }
+};
+
+static bool key_less(const uint8_t* a, const uint8_t* b, uint32_t key_bytes)
+{ // most significant word first (kmer.hpp:262-268)
+  for (int w = (int)key_bytes / 8 - 1; w >= 0; w--) { const uint64_t x = rd<uint64_t>(a + 8 * w), y = rd<uint64_t>(b + 8 * w); if (x != y) return x < y; }
+  return false;
+}
+
+static int cmd_dump(int argc, char** argv)
+{
+  std::string input, output = "stdout";
+  for (int i = 2; i < argc; i++) {
+    const std::string a = argv[i];
+    auto need = [&]() -> std::string { if (i + 1 >= argc) tdie("missing value for " + a); return argv[++i]; };
+    if (a == "--input") input = need(); else if (a == "-o" || a == "--output") output = need(); else if (a == "--run-dir") need(); else if (a == "-v" || a == "--verbose" || a == "-t" || a == "--threads") need();
+    else tdie("unknown option " + a);
+  }
+  if (input.empty()) tdie("--input is required");
+  const KmFile f = load(input);
+  Sink out(output); std::string buf;
+  for (size_t r = 0; r < f.rows(); r++) { row_text(f, f.body.data() + r * f.row_bytes(), false, buf); if (buf.size() > (1u << 20)) { out.put(buf); buf.clear(); } }
+  out.put(buf);
+  return 0;
+}
+
+static int cmd_aggregate(int argc, char** argv)
+{
+  std::string dir, count, matrix, pa, format = "text", output = "stdout";
+  bool sorted = false, cpr_in = false, cpr_out = false, no_count = false;
+  for (int i = 2; i < argc; i++) {
+    const std::string a = argv[i];
+    auto need = [&]() -> std::string { if (i + 1 >= argc) tdie("missing value for " + a); return argv[++i]; };
+    if (a == "--run-dir") dir = need(); else if (a == "--count") count = need(); else if (a == "--matrix") matrix = need(); else if (a == "--pa-matrix") pa = need();
+    else if (a == "--format") format = need(); else if (a == "--sorted") sorted = true; else if (a == "--cpr-in") cpr_in = true; else if (a == "--cpr-out") cpr_out = true;
+    else if (a == "--no-count") no_count = true; else if (a == "--output") output = need(); else if (a == "-v" || a == "--verbose" || a == "-t" || a == "--threads") need();
+    else tdie("unknown option " + a);
+  }
+  if (dir.empty()) tdie("--run-dir is required");
+  if (format != "text" && format != "bin") tdie("--format must be text or bin");
+  if ((int)!count.empty() + (int)!matrix.empty() + (int)!pa.empty() != 1) tdie("exactly one of --count, --matrix, --pa-matrix is required");
+  GatbConfig gc; if (!GatbConfig::load(dir + "/config_gatb/gatb.config", gc)) tdie("Unable to read at " + dir + "/config_gatb/gatb.config");
+  std::vector<std::string> paths;
+  for (uint32_t p = 0; p < gc.nb_partitions; p++) {
+    std::string f;
+    if (!count.empty()) {   // id:kmer|hash
+      const size_t c = count.find(':'); if (c == std::string::npos) tdie("--count takes id:kmer|hash");
+      const std::string id = count.substr(0, c), kind = count.substr(c + 1);
+      f = dir + "/counts/partition_" + std::to_string(p) + "/" + id + (kind == "hash" ? ".hash" : (cpr_in ? ".kmer.lz4" : ".kmer"));
+    } else if (!matrix.empty()) f = dir + "/matrices/matrix_" + std::to_string(p) + (matrix == "hash" ? ".count_hash" : (cpr_in ? ".count.lz4" : ".count"));
+    else f = dir + "/matrices/matrix_" + std::to_string(p) + (pa == "hash" ? ".pa_hash" : (cpr_in ? ".pa.lz4" : ".pa"));
+    if (fs::exists(f)) paths.push_back(f);
+  }
+  if (paths.empty()) tdie("No files found for these parameters.");
+  std::vector<KmFile> files; for (auto& p : paths) files.push_back(load(p));
+  const KmFile& f0 = files[0];
+  for (auto& f : files) if (f.kind != f0.kind || f.row_bytes() != f0.row_bytes()) tdie("partition files of different shapes");
+  if (sorted && f0.hashed()) sorted = false;            // (hash windows of the partitions are disjoint and ascending already)
+  // row order: partition after partition, or one ascending stream (a merge of the partitions' ascending files)
+  std::vector<std::pair<uint32_t, size_t>> order;
+  if (!sorted) { for (uint32_t i = 0; i < files.size(); i++) for (size_t r = 0; r < files[i].rows(); r++) order.push_back({i, r}); }
+  else {
+    auto cmp = [&](const std::pair<uint32_t, size_t>& a, const std::pair<uint32_t, size_t>& b) {
+      return key_less(files[b.first].body.data() + b.second * f0.row_bytes(), files[a.first].body.data() + a.second * f0.row_bytes(), f0.key_bytes); };
+    std::priority_queue<std::pair<uint32_t, size_t>, std::vector<std::pair<uint32_t, size_t>>, decltype(cmp)> pq(cmp);
+    for (uint32_t i = 0; i < files.size(); i++) if (files[i].rows()) pq.push({i, 0});
+    while (!pq.empty()) { auto t = pq.top(); pq.pop(); order.push_back(t); if (t.second + 1 < files[t.first].rows()) pq.push({t.first, t.second + 1}); }
+  }
+  if (format == "text") {
+    Sink out(output); std::string buf;
+    for (auto& o : order) { row_text(f0, files[o.first].body.data() + o.second * f0.row_bytes(), no_count, buf); if (buf.size() > (1u << 20)) { out.put(buf); buf.clear(); } }
+    out.put(buf);
+  } else {
+    if (output == "stdout") tdie("--format bin needs --output");
+    Out out(output);
+    switch (f0.kind) {   // the aggregated file carries partition 0 (KmerFileAggregator::write_as_bin and friends)
+      case KmFile::KMER: out.base_header(cpr_out); out.put<uint64_t>(MAGIC_KMER); out.put<uint32_t>(f0.k); out.put<uint32_t>(f0.key_bytes / 8); out.put<uint32_t>(f0.count_slots); out.put<uint32_t>(0); out.put<uint32_t>(0); out.begin_body(); break;
+      case KmFile::HASH: tdie("aggregated hash count files (--format bin) are not supported"); break;
+      case KmFile::MATRIX: matrix_count_header(out, f0.k, f0.cols, 0, cpr_out); break;
+      case KmFile::MATRIX_HASH: matrix_count_hash_header(out, f0.cols, 0, cpr_out); break;
+      case KmFile::PA: matrix_pa_header(out, f0.k, f0.cols, 0, cpr_out); break;
+      case KmFile::PA_HASH: matrix_pa_hash_header(out, f0.cols, 0, cpr_out); break;
+    }
+    for (auto& o : order) out.raw(files[o.first].body.data() + o.second * f0.row_bytes(), f0.row_bytes());
+    out.close();
+  }
+  return 0;
+}
+
+int kmx_tools_main(int argc, char** argv)
+{
+  try {
+    const std::string cmd = argv[1];
+    if (cmd == "dump") return cmd_dump(argc, argv);
+    if (cmd == "aggregate") return cmd_aggregate(argc, argv);
+  } catch (const std::exception& e) { tdie(e.what()); }
+  return -1;
+}

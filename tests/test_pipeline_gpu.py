@@ -370,3 +370,34 @@ def test_synthetic_multi_sample_pipeline(tmp_path, mode):
         for rix in range(6):
             assert [int(x) for x in mi[rix][1:1 + NS]] == [int(x) for x in stats[rix]]
     assert total_rows > 50_000
+
+
+def test_dump_and_aggregate(inputs, tmp_path):
+    """`kmx dump` / `kmx aggregate` (cmd.hpp:275-369, 441-607) on a run directory: matrix rows as text, partitions concatenated or merged
+    into one ascending stream, aggregated binary matrix"""
+    out = run(inputs, tmp_path / "run", "--mode", "kmer:count:bin", "--keep-tmp")
+    lists = oracle_lists(False)
+    rows_all = []
+    for p in range(P):
+        body, rows, _ = orc.merge_matrix(lists[p], 1, [1, 1], 1, 0, orc.MODE_COUNT)
+        a = np.frombuffer(body, np.uint8).reshape(rows, 16)
+        part = [(int(a[i, :8].view(np.uint64)[0]), int(a[i, 8:12].view(np.uint32)[0]), int(a[i, 12:16].view(np.uint32)[0])) for i in range(rows)]
+        r = subprocess.run([KMX, "dump", "--input", str(out / "matrices" / f"matrix_{p}.count")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == "".join(f"{orc.kmer_to_string(np.array([k], np.uint64), 31)} {c0} {c1}\n" for k, c0, c1 in part)
+        rows_all.append(part)
+    flat = [x for part in rows_all for x in part]
+    r = subprocess.run([KMX, "aggregate", "--run-dir", str(out), "--matrix", "kmer"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "".join(f"{orc.kmer_to_string(np.array([k], np.uint64), 31)} {c0} {c1}\n" for k, c0, c1 in flat)
+    r = subprocess.run([KMX, "aggregate", "--run-dir", str(out), "--matrix", "kmer", "--sorted", "--no-count"], capture_output=True, text=True)
+    assert r.stdout == "".join(f"{orc.kmer_to_string(np.array([k], np.uint64), 31)}\n" for k, _, _ in sorted(flat))
+    agg = tmp_path / "all.count"
+    r = subprocess.run([KMX, "aggregate", "--run-dir", str(out), "--matrix", "kmer", "--sorted", "--format", "bin", "--output", str(agg)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(agg, "rb").read()
+    assert len(raw) == 45 + 16 * len(flat)
+    got = np.frombuffer(raw[45:], np.uint8).reshape(-1, 16)
+    assert [int(x) for x in got[:, :8].copy().view(np.uint64).reshape(-1)] == [k for k, _, _ in sorted(flat)]
+    r = subprocess.run([KMX, "aggregate", "--run-dir", str(out), "--count", "D1:kmer", "--sorted"], capture_output=True, text=True)
+    assert r.returncode == 0 and len(r.stdout.splitlines()) == sum(G["task_main"]["superk_info_D1"][1::2])
