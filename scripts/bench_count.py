@@ -35,6 +35,11 @@ t0 = time.perf_counter(); bk = ctx.count_batch(streams, K, 2); t_bk = time.perf_
 t0 = time.perf_counter(); bh = ctx.count_batch(streams, K, 2, window=3125056); t_bh = time.perf_counter() - t0
 batch_ok = all(np.array_equal(bk[p][0], cnt[p][0]) and np.array_equal(bk[p][1], cnt[p][1]) and
                np.array_equal(bh[p][0], cnth[p][0]) and np.array_equal(bh[p][1], cnth[p][1]) for p in range(P))
+ctx.count_reads(packed, K, M, rep, P, 2); ctx.count_reads(packed, K, M, rep, P, 2, window=3125056)      # warm-up
+t0 = time.perf_counter(); fk, fnk, _, _ = ctx.count_reads(packed, K, M, rep, P, 2); t_fk = time.perf_counter() - t0
+t0 = time.perf_counter(); fh, _, _, _ = ctx.count_reads(packed, K, M, rep, P, 2, window=3125056); t_fh = time.perf_counter() - t0
+fused_ok = all(np.array_equal(fk[p][0], cnt[p][0]) and np.array_equal(fk[p][1], cnt[p][1]) and
+               np.array_equal(fh[p][0], cnth[p][0]) and np.array_equal(fh[p][1], cnth[p][1]) for p in range(P))
 # oracle on one core, bounded sample: 1/8 of the reads for the split, 4 partitions for the counts
 lut = orc.minimizer_lut(M)
 t0 = time.perf_counter(); osk = orc.superk_partition(reads[: n_reads // 8], K, M, lut, rep, P); t_osk = time.perf_counter() - t0
@@ -47,6 +52,9 @@ print(json.dumps({"reads": n_reads, "bases": n_reads * L, "kmers": nk, "superk_b
                   "gpu_count_batch_kmer_s": t_bk, "gpu_count_batch_kmer_Mkmers_per_s": nk / t_bk / 1e6,
                   "gpu_count_batch_hash_s": t_bh, "gpu_count_batch_hash_Mkmers_per_s": nk / t_bh / 1e6,
                   "batch_equals_per_partition": bool(batch_ok),
+                  "gpu_count_reads_kmer_s": t_fk, "gpu_count_reads_kmer_Mkmers_per_s": nk / t_fk / 1e6, "gpu_count_reads_kmer_Mbases_per_s": n_reads * L / t_fk / 1e6,
+                  "gpu_count_reads_hash_s": t_fh, "gpu_count_reads_hash_Mkmers_per_s": nk / t_fh / 1e6, "fused_equals_per_partition": bool(fused_ok),
+                  "count_algorithmic_bytes": nb + 12 * int(sum(len(c[1]) for c in cnt)),
                   "oracle_superk_Mbases_per_s_1core": (n_reads // 8) * L / t_osk / 1e6,
                   "oracle_count_kmer_Mkmers_per_s_1core": sum(sk[p][1] for p in range(4)) / t_ock / 1e6,
                   "count_bit_exact_vs_oracle_4_partitions": bool(ok)}))
