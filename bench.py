@@ -258,6 +258,10 @@ def main():
         if prev is not None:
             finish(prev)
 
+    # setup, not warm-up: libkmx sizes its row arenas from the batches it has completed (the first ones of a cohort run twice, and
+    # the first arenas of the final size are fresh hipMallocs): three batches, one at a time, before the W warm-up steps
+    for _ in range(3):
+        run(1, False)
     run(a.warmup, False)
     barrier()
     t0 = time.perf_counter()

@@ -252,12 +252,19 @@ __global__ void k_superk_info(const u32* __restrict__ part_first, const u64* __r
 {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nb_parts) return;
-  u64 buf = 0, km = 0, flushed = 0;
-  for (u32 i = part_first[p]; i < part_first[p + 1]; i++) {
-    const u64 a = prefix[i], b = prefix[i + 1];
-    const u64 nb = (u32)b - (u32)a, n = (b >> 32) - (a >> 32);
-    if (buf + nb > 32768) { flushed += buf + 4; buf = 0; km = 0; }
-    buf += nb; km += n;
+  // a block = the longest run of whole records of at most 32768 bytes: its end is a binary search in the byte prefix (a step per
+  // block, not per record); the last run is still in the writer's buffer when the info file is saved
+  const u32 i1 = part_first[p + 1];
+  u32 s = part_first[p];
+  u64 flushed = 0, km = 0;
+  while (s < i1) {
+    const u32 b0 = (u32)prefix[s];
+    u32 lo = s + 1, hi = i1;                       // largest e in (s, i1] with bytes[s, e) <= 32768
+    while (lo < hi) { const u32 mid = lo + ((hi - lo + 1) >> 1); if ((u32)prefix[mid] - b0 <= 32768u) lo = mid; else hi = mid - 1; }
+    const u32 e = lo;
+    if (e < i1) flushed += (u64)((u32)prefix[e] - b0) + 4;
+    else km = (prefix[e] >> 32) - (prefix[s] >> 32);
+    s = e;
   }
   info[2 * p] = km; info[2 * p + 1] = flushed;
 }
