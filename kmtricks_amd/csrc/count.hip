@@ -362,7 +362,7 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   for (u32 p = 0; p < n_parts; p++) {
     const u64 n = kmoff[p + 1] - kmoff[p];
     const u64 nb = std::max<u64>(1, (n + target - 1) / target);
-    if (nb > (u64)CS_MAXB) return 1;                       // a partition beyond 256 buckets: the library sort takes the batch
+    if (nb > (u64)CS_MAXB || nb * 4 > (u64)CsCap<KeyT>::sample) return 1;      // a partition beyond the bucket / sample limits: the library sort takes the batch
     parts[p] = CsPart{(u32)kmoff[p], (u32)n, TB, (u32)nb};
     TB += (u32)nb;
     for (u64 o = 0; o < n; o += CS_CHUNK) chunks.push_back(CsChunk{p, (u32)(kmoff[p] + o), (u32)std::min<u64>(CS_CHUNK, n - o), 0});

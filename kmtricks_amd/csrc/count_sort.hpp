@@ -5,7 +5,7 @@
 // The decode kernel leaves the keys grouped by partition.  A partition (tens to hundreds of thousands of keys) does not fit the
 // LDS, a bucket of it does -- so it is a SAMPLE SORT per partition, every stage staged in LDS, no key ever compared in HBM:
 //   k_cs_splitters  a workgroup per partition sorts an even sample of its keys in LDS (bitonic) and keeps every (sample / buckets)-th
-//                   as a splitter: buckets of ~1500 keys whatever the key distribution (canonical k-mers of a minimizer partition
+//                   as a splitter: buckets of ~1000 keys whatever the key distribution (canonical k-mers of a minimizer partition
 //                   crowd a few prefixes -- a fixed radix digit would not balance);
 //   k_cs_count      a workgroup per chunk of 4096 keys: bucket of every key by binary search in the partition's splitters (LDS),
 //                   LDS histogram, one global add per bucket and chunk;
@@ -27,11 +27,10 @@ namespace kmx {
 
 constexpr int CS_TPB = 256;
 constexpr int CS_CHUNK = 4096;            // keys per workgroup in the count / scatter walks
-constexpr int CS_MAXB = 256;              // buckets per partition
-constexpr int CS_SAMPLE = 4096;           // keys sampled per partition (<= CS_SAMPLE, >= 16 per bucket)
-template <typename K> struct CsCap { static constexpr int cap = 4096; };            // keys of a bucket that fit the sort's LDS
-template <> struct CsCap<__uint128_t> { static constexpr int cap = 2048; };
-template <typename K> __host__ __device__ inline u32 cs_target() { return (u32)CsCap<K>::cap * 3 / 8; }      // aimed bucket size
+constexpr int CS_MAXB = 1024;             // buckets per partition (partitions of up to ~1 M keys; beyond: the library sort)
+template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 8192; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (64 KB)
+template <> struct CsCap<__uint128_t> { static constexpr int cap = 2048, sample = 4096; };
+template <typename K> __host__ __device__ inline u32 cs_target() { return (u32)CsCap<K>::cap / 4; }      // aimed bucket size (a bucket may come out 4x that)
 
 struct CsPart { u32 key0, nkeys, bucket0, nb; };      // a partition's keys [key0, key0 + nkeys), its buckets [bucket0, bucket0 + nb)
 struct CsChunk { u32 part, key0, nkeys, pad; };
@@ -42,11 +41,12 @@ template <typename K>
 __global__ __launch_bounds__(CS_TPB)
 void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, K* __restrict__ splitters)
 {
-  __shared__ K sm[CS_SAMPLE];
+  constexpr u32 SMAX = (u32)CsCap<K>::sample;
+  __shared__ K sm[SMAX];
   const CsPart P = parts[blockIdx.x];
   if (P.nb <= 1) return;
   const u32 tid = threadIdx.x;
-  u32 S = 16 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, (u32)CS_SAMPLE); }      // samples: a power of two
+  u32 S = 16 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 16 per bucket (8 for the largest partitions)
   for (u32 i = tid; i < S; i += CS_TPB) sm[i] = keys[P.key0 + (u32)(((u64)i * P.nkeys) / S)];
   __syncthreads();
   for (u32 k2 = 2; k2 <= S; k2 <<= 1)
