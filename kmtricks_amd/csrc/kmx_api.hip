@@ -397,7 +397,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
   const u32 slots = (u32)ctx->n_cu * 2;
   const char* ipc = getenv("KMX_ITEMS_PER_SLOT");            // tuning knob (default 3): work items per resident workgroup slot
-  const u32 per_slot = ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : 3u;
+  // (3 for the general kernels; 6 for the column-blocked pair: on lists from the count stage -- uneven key density, k_cols_sparse's
+  //  groups -- finer items balance better: 5.2 -> 4.8 ms per step, +2 % on uniform random keys; scripts/r2_tune.sh)
+  const u32 per_slot = ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : (R->use_cols ? 6u : 3u);
   // (cols: one workgroup per CU, and a work item is a column block of a range.  Leaving a few CUs to the small kernels
   //  that prepare the NEXT batch on the second stream was tried: the merge then needs finer work items, net +5 %)
   const u32 cols_cus = (u32)ctx->n_cu * cols_wgs_per_cu();
