@@ -18,7 +18,7 @@ Where the lists come from (`--lists`):
 
 Other workloads (`--workload`), each with its own roofline line:
   bf     configs[1]: 100 samples, hash:bf:bin, bloom 1e8, 32 partitions on one GPU
-  pa63   configs[4]: 500 samples, k=63 (128-bit keys), kmer:pa:bin, 64 of 256 partitions per GPU
+  pa63   configs[4]: 500 samples, k=63 (128-bit keys), kmer:pa:bin, 32 of 256 partitions per GPU and step
   bft    configs[3]: 2500 samples, hash:bft:bin --soft-min 2 --share-min 1 (merge + on-device transpose; with more than
          one rank the per-sample Bloom rows are exchanged with one all-to-all over RCCL, kmtricks_amd/shard.py)
 
@@ -168,7 +168,7 @@ def main():
     ctx.set_profiling(True)
 
     wl = a.workload
-    defaults = {"count": (1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 64, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
+    defaults = {"count": (1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
     N = a.samples or defaults[0]
     P = a.partitions_per_gpu or defaults[1]
     k = defaults[2]

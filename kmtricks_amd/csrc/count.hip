@@ -265,7 +265,7 @@ static int count_impl(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_
   if (parse_records(superk, len, k, rec_off, kmer_off, &total)) return ctx->fail(KMX_E_INVAL, "malformed super-k-mer stream");
   if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one partition file: split it");
   if (total == 0) {   // header-only count file (task.hpp:466-476)
-    *keys = malloc(1); *counts = (uint32_t*)malloc(1);
+    *keys = malloc(8); *counts = (uint32_t*)malloc(8);
     return KMX_OK;
   }
   const u32 nr = (u32)rec_off.size();

@@ -10,7 +10,6 @@
 using namespace kmx;
 
 static thread_local std::string g_create_err;
-namespace kmx { void cols_dbg_dump(); }
 
 // ---- memory pools ----------------------------------------------------------------------------------
 void* kmx_ctx::dalloc(size_t bytes)
@@ -207,6 +206,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   const uint2* d_items = reinterpret_cast<const uint2*>(R->d_meta + R->o_items);
   u32* d_ticket = reinterpret_cast<u32*>(R->d_meta + R->o_ticket);
   const int kw = (int)R->tasks[0].kw, mode = (int)R->tasks[0].mode;
+  const ColsOps& CO = cols_ops(kw);
   const u32 nt = (u32)R->tasks.size();
   if (!R->use_cols) KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 16, ctx->stream));      // (cols runs once per result: the upload zeroed it)
   if (ctx->profiling && !R->ev0) { KMX_HIP(ctx, hipEventCreate(&R->ev0)); KMX_HIP(ctx, hipEventCreate(&R->ev1)); }
@@ -232,17 +232,17 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
       KMX_HIP(ctx, hipStreamWaitEvent(ctx->aux, R->ev_pre, 0));
     }
     KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ctx->aux));
-    KMX_HIP(ctx, launch_cols_skel(d_subs, d_subitems, R->n_subitems, ctx->aux));
-    KMX_HIP(ctx, launch_cols_prep(d_tasks, d_subs, d_cols, nt, ctx->aux));
+    KMX_HIP(ctx, CO.skel(d_subs, d_subitems, R->n_subitems, ctx->aux));
+    KMX_HIP(ctx, CO.prep(d_tasks, d_subs, d_cols, nt, ctx->aux));
     KMX_HIP(ctx, hipEventRecord(R->ev_pre, ctx->aux));
     // (the task's own range bounds need the upload only: on the main stream, beside the row-key kernels)
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_up, 0));
     KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    KMX_HIP(ctx, launch_merge_cols(mode, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
+    KMX_HIP(ctx, CO.merge(mode, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
-    KMX_HIP(ctx, launch_cols_sparse(mode, d_tasks, d_cols, d_items, R->n_items, ctx->stream));
+    KMX_HIP(ctx, CO.sparse(mode, d_tasks, d_cols, d_items, R->n_items, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));      // (the launch priced: the rows come out of both kernels)
     return mirror_and_mark(R);
   } else {
@@ -283,6 +283,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   if (mode > KMX_MODE_BFT) return ctx->fail(KMX_E_INVAL, "unknown mode");
   const bool is_bft = mode == KMX_MODE_BFT;
   const bool is_bf = mode == KMX_MODE_BF || mode == KMX_MODE_BFC || is_bft;
+  const ColsOps& CO = cols_ops((int)kw);
   if (is_bf && kw != 1) return ctx->fail(KMX_E_INVAL, "BF/BFC modes take hash keys (key_words = 1)");
 
   std::unique_ptr<kmx_merge_result> R(new kmx_merge_result());
@@ -359,18 +360,18 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     }
     const char* force = getenv("KMX_MERGE_KERNEL");
     const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
-    bool can_cols = !is_bf && !rescue && kw == 1 && mx_n <= (u32)rows_cap();
+    bool can_cols = !is_bf && !rescue && mx_n <= (u32)rows_cap();      // (both key widths: merge_cols.hip, merge_cols_k2.hip)
     if (can_cols) {
       // k_merge_cols keeps worst-case room for the records it sets aside (a slice per half tile, block and wave: ~2.3 KB per
       // row at 1000 lists): not for batches where that would take more than KMX_COLS_SCRATCH_GB (default 32) of HBM
       u64 scratch = 0;
       for (auto& H : R->tasks) {
-        const u32 nblk = (H.N + cols_block_lists() - 1) / cols_block_lists();
+        const u32 nblk = (H.N + CO.block_lists() - 1) / CO.block_lists();
         // (tile slots count ROW KEYS -- the keys a merge of S of the lists keeps, at most the records of those lists -- not rows)
         const u32 S_ = std::max(8u, cols_row_lists(std::max(1u, H.rec_min)));
         const u64 skel_est = std::min<u64>(H.rows_guess, (u64)S_ * (H.total_recs / H.N + 1) * 5 / 4 + 4096);
-        const u32 sl = (u32)std::min<u64>(0x7FFFFFF0ULL, skel_est / cols_tile_rows(cols_block_lists()) + 64);
-        scratch += cols_scratch_keys(sl, nblk) * 8 + cols_scratch_counts(sl, nblk) * 4 + cols_dir_bytes(sl);
+        const u32 sl = (u32)std::min<u64>(0x7FFFFFF0ULL, skel_est / CO.tile_rows(CO.block_lists()) + 64);
+        scratch += CO.scratch_keys(sl, nblk) * 8 + CO.scratch_counts(sl, nblk) * 4 + CO.dir_bytes(sl);
       }
       const char* gb = getenv("KMX_COLS_SCRATCH_GB");
       const char* mb = getenv("KMX_COLS_SCRATCH_MB");
@@ -402,16 +403,16 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   const u32 per_slot = ipc && atoi(ipc) > 0 ? (u32)atoi(ipc) : (R->use_cols ? 6u : 3u);
   // (cols: one workgroup per CU, and a work item is a column block of a range.  Leaving a few CUs to the small kernels
   //  that prepare the NEXT batch on the second stream was tried: the merge then needs finer work items, net +5 %)
-  const u32 cols_cus = (u32)ctx->n_cu * cols_wgs_per_cu();
+  const u32 cols_cus = (u32)ctx->n_cu * CO.wgs_per_cu();
   const u32 target_items = (R->use_cols ? cols_cus : slots) * per_slot;
   u32 n_items = 0, max_n = 0, max_c = 0;
   for (auto& H : R->tasks) {
     if (R->use_cols) {
-      H.nblk = (H.N + cols_block_lists() - 1) / cols_block_lists();
+      H.nblk = (H.N + CO.block_lists() - 1) / CO.block_lists();
       // (lists per block: even for count rows -- 8-byte stores --, a multiple of 8 for PA rows -- whole bytes per block)
-      H.nb = std::min<u32>(cols_block_lists(), mode == KMX_MODE_COUNT ? ((((H.N + H.nblk - 1) / H.nblk) + 1) & ~1u) : ((((H.N + H.nblk - 1) / H.nblk) + 7) & ~7u));
+      H.nb = std::min<u32>(CO.block_lists(), mode == KMX_MODE_COUNT ? ((((H.N + H.nblk - 1) / H.nblk) + 1) & ~1u) : ((((H.N + H.nblk - 1) / H.nblk) + 7) & ~7u));
       H.nblk = (H.N + H.nb - 1) / H.nb;
-      H.rt_cols = cols_tile_rows(H.nb);
+      H.rt_cols = CO.tile_rows(H.nb);
     }
     u64 c = grand_total ? (u64)target_items * H.total_recs / grand_total : 1;
     if (R->use_cols) c = (c + H.nblk / 2) / H.nblk;
@@ -464,7 +465,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         if (Q.len[i] > Q.len[piv]) piv = i;
       }
       Q.pivot = (Q.N >= 2 && Q.len[Q.N / 2] > 0) ? Q.N / 2 : piv;
-      Q.row_bytes = 8;                                   // k_cols_skel writes keys only
+      Q.row_bytes = 8 * kw;                              // k_cols_skel writes keys only
       u32 wl = 0; while (wl < 6 && (Q.N << (wl + 1)) <= (u32)rows_cap()) wl++;
       Q.wl = wl;
       Q.rows_guess = std::max<u64>(1, std::min<u64>(H.rows_guess, Q.total_recs));
@@ -473,7 +474,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       c = std::min<u64>(c, std::max<u32>(1, Q.len[Q.pivot]));
       Q.c = (u32)c;
       Q.seg_cap = Q.c;
-      Q.out_cap_rows = (u64)Q.c * cols_skel_cap();
+      Q.out_cap_rows = (u64)Q.c * CO.skel_cap();
       Q.out_bytes = (size_t)(Q.out_cap_rows * Q.row_bytes);
       nsub += Q.c; ncit += H.c * H.nblk;
       R->sub_max_c = std::max(R->sub_max_c, Q.c); R->sub_max_n = std::max(R->sub_max_n, Q.N);
@@ -528,7 +529,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   if (cols) {
     for (auto& Q : R->subs) lay_work(Q);
     for (auto& H : R->tasks) {
-      H.o_skel = off; off = align_up(off + 8ull * H.out_cap_rows, 256);
+      H.o_skel = off; off = align_up(off + 8ull * kw * H.out_cap_rows, 256);
       H.o_nskel = off; off += 256;
       H.o_rbounds = off; off = align_up(off + 4ull * (H.c + 1), 256);
     }
@@ -545,9 +546,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   for (auto& H : R->tasks) {
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
     if (H.d_out && cols) {
-      H.o_spdir = align_up((size_t)(cols_scratch_keys(H.slots_cap, H.nblk) * 8 + cols_scratch_counts(H.slots_cap, H.nblk) * 4), 256);
-      H.d_ov = (u8*)ctx->dalloc(H.o_spdir + (size_t)cols_dir_bytes(H.slots_cap));
-      if (H.d_ov && hipMemsetAsync(H.d_ov + H.o_spdir, 0, (size_t)cols_dir_bytes(H.slots_cap), ctx->aux) != hipSuccess) { ctx->dfree(H.d_ov); H.d_ov = nullptr; }
+      H.o_spdir = align_up((size_t)(CO.scratch_keys(H.slots_cap, H.nblk) * 8 + CO.scratch_counts(H.slots_cap, H.nblk) * 4), 256);
+      H.d_ov = (u8*)ctx->dalloc(H.o_spdir + (size_t)CO.dir_bytes(H.slots_cap));
+      if (H.d_ov && hipMemsetAsync(H.d_ov + H.o_spdir, 0, (size_t)CO.dir_bytes(H.slots_cap), ctx->aux) != hipSuccess) { ctx->dfree(H.d_ov); H.d_ov = nullptr; }
     }
     if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
 
@@ -618,7 +619,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       C.nskel = reinterpret_cast<u32*>(R->d_meta + H.o_nskel);
       C.rbounds = reinterpret_cast<u32*>(R->d_meta + H.o_rbounds);
       C.ovkeys = reinterpret_cast<u64*>(H.d_ov);
-      C.ovcnt = reinterpret_cast<u32*>(H.d_ov + cols_scratch_keys(H.slots_cap, H.nblk) * 8);
+      C.ovcnt = reinterpret_cast<u32*>(H.d_ov + CO.scratch_keys(H.slots_cap, H.nblk) * 8);
       C.spdir = H.d_ov + H.o_spdir;
       C.slots_cap = H.slots_cap; C.nblk = H.nblk; C.nb = H.nb; C.rt = H.rt_cols;
       for (u32 j = 0; j < H.c * H.nblk; j++) citems[ci++] = make_uint2(t, j);   // y = range * nblk + block
@@ -677,6 +678,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     R->waited = true; R->status = KMX_OK;
     return KMX_OK;
   }
+  const ColsOps& CO = cols_ops((int)R->tasks[0].kw);
   bool overflow = false, fallback = false;
   int rc = fetch_ctrl(R, &overflow, &fallback);
   if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
@@ -691,7 +693,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     u32 n_back = 0;
     for (auto& H : R->tasks) n_back += H.handed_back ? 1u : 0u;
     for (u32 i = 0; i < R->n_items; i++) if (R->tasks[all_items[i].x].handed_back) redo.push_back(all_items[i]);
-    if (getenv("KMX_TRACE") && from_cols) kmx::cols_dbg_dump();
+    if (getenv("KMX_TRACE") && from_cols) CO.dbg_dump();
     if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] %s handed back %u of %zu tasks: re-run with %s\n", from_cols ? "k_merge_cols" : "k_merge_pivot",
                                      n_back, R->tasks.size(), to_pivot ? "k_merge_pivot" : "k_merge_rows");
     if (from_cols) {
@@ -855,10 +857,11 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
     KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
     return KMX_OK;
   }
+  const ColsOps& CO = cols_ops((int)H.kw);
   if (H.kernel == 2 && H.sparse_rows) {
     // k_merge_cols + k_cols_sparse: the row keys' rows and the rows of the keys outside them are interleaved by key on the
     // device (k_cols_offsets + k_cols_gather), the body then comes back in one copy
-    const u32 ng = cols_groups(H.slots_cap);
+    const u32 ng = CO.groups(H.slots_cap);
     u8* d_body = (u8*)ctx->dalloc(body);
     u64* d_goff = (u64*)ctx->dalloc((size_t)ng * 8);
     u8* stage = (u8*)ctx->halloc(body);
@@ -866,8 +869,8 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
     if (!d_body || !d_goff || !stage) return ctx->fail(KMX_E_NOMEM, "body assembly allocation failed");
     const TaskDev* d_tasks = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_tasks);
     const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
-    KMX_HIP(ctx, launch_cols_offsets(d_cols, t, d_goff, ctx->copy));
-    KMX_HIP(ctx, launch_cols_gather(d_tasks, d_cols, t, ng, d_goff, d_body, ctx->copy));
+    KMX_HIP(ctx, CO.offsets(d_cols, t, d_goff, ctx->copy));
+    KMX_HIP(ctx, CO.gather(d_tasks, d_cols, t, ng, d_goff, d_body, ctx->copy));
     KMX_HIP(ctx, hipMemcpyAsync(stage, d_body, body, hipMemcpyDeviceToHost, ctx->copy));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
     memcpy(dst, stage, body);
@@ -938,7 +941,7 @@ extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* 
 }
 
 #ifdef KMX_PHASE_PROF
-namespace kmx { void rows_phase_prof_dump(); void pivot_phase_prof_dump(); void cols_phase_prof_dump(); }
+namespace kmx { void rows_phase_prof_dump(); void pivot_phase_prof_dump(); }
 #endif
 extern "C" void kmx_result_free(kmx_merge_result* R)
 {
@@ -948,7 +951,8 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   if (R->ev_done) (void)hipEventSynchronize(R->ev_done);      // (this result's work, not the stream: later batches are queued behind it)
   else (void)hipStreamSynchronize(ctx->stream);
 #ifdef KMX_PHASE_PROF
-  if (!R->is_bf) { if (R->use_cols) kmx::cols_phase_prof_dump(); else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
+  const ColsOps& CO = cols_ops((int)R->tasks[0].kw);
+  if (!R->is_bf) { if (R->use_cols) { if (CO.phase_prof_dump) CO.phase_prof_dump(); } else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
   for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);

@@ -21,21 +21,30 @@ int pivot_lds_bytes(int kw);
 u32 pivot_max_lists();
 hipError_t launch_merge_pivot(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
                               u32 grid_x, hipStream_t st);
-int cols_lds_bytes();
-u32 cols_block_lists();
-u32 cols_wgs_per_cu();
-u32 cols_tile_rows(u32 nb);
-u64 cols_scratch_keys(u32 slots, u32 nblk);
-u64 cols_scratch_counts(u32 slots, u32 nblk);
-u32 cols_skel_cap();
-hipError_t launch_cols_skel(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st);
-hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st);
-hipError_t launch_merge_cols(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
-hipError_t launch_cols_sparse(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st);
-u64 cols_dir_bytes(u32 slots);
-u32 cols_groups(u32 slots);
-hipError_t launch_cols_offsets(const ColsDev* cols, u32 task, u64* goff, hipStream_t st);
-hipError_t launch_cols_gather(const TaskDev* tasks, const ColsDev* cols, u32 task, u32 n_groups, const u64* goff, u8* body, hipStream_t st);
+// the column-blocked merge is compiled once per key width (merge_cols.hip, merge_cols_k2.hip): the entry points of a build
+struct ColsOps {
+  int (*lds_bytes)();
+  u32 (*block_lists)();
+  u32 (*wgs_per_cu)();
+  u32 (*tile_rows)(u32 nb);
+  u64 (*scratch_keys)(u32 slots, u32 nblk);       // u64 words of the set-aside entries
+  u64 (*scratch_counts)(u32 slots, u32 nblk);
+  u32 (*skel_cap)();
+  hipError_t (*skel)(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st);
+  hipError_t (*prep)(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st);
+  hipError_t (*merge)(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
+  hipError_t (*sparse)(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st);
+  u64 (*dir_bytes)(u32 slots);
+  u32 (*groups)(u32 slots);
+  hipError_t (*offsets)(const ColsDev* cols, u32 task, u64* goff, hipStream_t st);
+  hipError_t (*gather)(const TaskDev* tasks, const ColsDev* cols, u32 task, u32 n_groups, const u64* goff, u8* body, hipStream_t st);
+  void (*dbg_dump)();
+  void (*phase_prof_dump)();
+  u32 key_words;
+};
+const ColsOps& cols_ops_k1();
+const ColsOps& cols_ops_k2();
+inline const ColsOps& cols_ops(int kw) { return kw == 2 ? cols_ops_k2() : cols_ops_k1(); }
 int bf_lds_bytes(u32 rt, u32 nb, u32 n_lists);
 hipError_t launch_range_bounds_bf(const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);
 hipError_t launch_merge_bf(int bfc, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,

@@ -16,19 +16,32 @@
 //     refilled in place with the record one window further (one global_load_dwordx3), a record whose key
 //     is a row key (one read of a collision-free LDS table built per tile) is deposited into the block's LDS
 //     image of the tile, and the image leaves as rt slices of ~500 bytes;
-//   * a solid record whose key is NOT a row key (sample-private k-mers) is appended to a per-(half tile, block,
-//     wave) slice in HBM.  k_cols_check then counts, half tile by half tile and across the blocks, in how many
-//     lists each of those keys is solid: if one reaches the recurrence the rows were incomplete and the task is
-//     handed back (ERR_FALLBACK: the driver re-runs it with k_merge_pivot / k_merge_rows).  So are tasks whose
-//     slices overflow.  Results never depend on how well the row keys cover the lists.
-// Applicable to COUNT and PA rows, 64-bit keys, no share-min; chosen for > 512 lists and 2 <= recurrence-min <= 21
+//   * a solid record whose key is NOT a row key (sample-private k-mers, and the k-mers two or three samples share) is
+//     appended to a per-(half tile, block, wave) slice in HBM.  k_cols_sparse then takes those entries a slice group at a
+//     time across the blocks, sorts the keys that can reach the recurrence-min in LDS and writes THEIR rows behind the row
+//     keys' rows (with a directory: k_cols_gather interleaves the two when the body is asked for).  A task whose slices
+//     overflow, or with a tile no collision-free table was found for, is handed back (ERR_FALLBACK: the driver re-runs it
+//     with k_merge_pivot / k_merge_rows).  Results never depend on how well the row keys cover the lists.
+// Applicable to COUNT and PA rows, 64- and 128-bit keys, no share-min; chosen from 128 lists and recurrence-min <= 21
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
-#include "kmx_dev.hpp"
+#include "kmx_host.hpp"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 
-namespace kmx {
+// This file is compiled twice: as it is for 64-bit keys (k <= 31, hashes), and through merge_cols_k2.hip with KMX_CL_KW = 2 for
+// 128-bit keys (32 <= k <= 63: 5-dword records, 8-slot windows, one 32-byte-entry row table).  Each build lives in its own
+// namespace and hands kmx_api.hip its entry points through a ColsOps table.
+#ifndef KMX_CL_KW
+#define KMX_CL_KW 1
+#endif
+#if KMX_CL_KW == 1
+#define CLNS cols_k1
+#else
+#define CLNS cols_k2
+#endif
+
+namespace kmx { namespace CLNS {
 
 #ifndef KMX_CL_TPB
 #define KMX_CL_TPB 1024
@@ -39,16 +52,20 @@ constexpr int CL_WGS = 1024 / CL_TPB;
 #define KMX_CL_G 8
 #endif
 constexpr int CL_G = KMX_CL_G;           // adjacent lanes per list (4: 64-record windows, 256 lists per block; 8: 128 and 128)
-constexpr int CL_U = 16;                 // window slots per lane
+constexpr int KW = KMX_CL_KW;            // 64-bit words per key
+constexpr int RB = KW * 8 + 4;           // bytes per record (key words, u32 count)
+constexpr int RD = RB / 4;               // ... in dwords
+constexpr int EW = KW + 1;               // u64 words per set-aside entry: the key, then list << 32 | count
+constexpr int CL_U = KW == 1 ? 16 : 8;   // window slots per lane (a 128-bit record is 5 registers: 8 slots keep the kernel under 128 VGPRs)
 constexpr int CL_W = CL_G * CL_U;        // records per window
 constexpr int CL_NB = CL_TPB / CL_G;     // lists per column block
 constexpr int CL_IMG = 61440 / CL_WGS;   // LDS image bytes (rt rows x nb u32 counts)
 constexpr int CL_RT = CL_W * 7 / 8;      // row keys per tile (< window: a similar list needs no second round)
 constexpr int CL_KPL = (CL_RT + 63) / 64;   // row keys per lane of wave 0 (which builds the row table)
-constexpr int CL_NT = (CL_KPL == 1 && CL_WGS == 1) ? 2 : 1;  // row tables: two of 2048 entries (the next tile's is built beside this tile's), or one of 4096
+constexpr int CL_NT = (CL_KPL == 1 && CL_WGS == 1 && KW == 1) ? 2 : 1;  // row tables: two of 2048 entries (the next tile's is built beside this tile's), or one
 constexpr int CL_PT = CL_KPL == 1 ? 2048 : 4096;      // row-key table entries
 constexpr int CL_PTSHIFT = CL_PT == 2048 ? 21 : 20;
-constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 56 rows (k_cols_check takes a slice group at a time)
+constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 56 rows (k_cols_sparse takes a slice group at a time)
 constexpr int CL_SEEDS = 256;            // hashes tried per tile for a collision-free table: 64 cheap ones, then 64-bit multiplicative ones
 constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
 constexpr int CL_NW = CL_TPB / 64;
@@ -60,14 +77,57 @@ __device__ u32 kmx_cols_dbg[8];      // why tasks were handed back (KMX_TRACE=1 
 namespace {
 
 typedef u32 u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef __attribute__((address_space(1))) const u32x3 gu32x3;
+typedef __attribute__((address_space(1))) const u32x4 gu32x4;
 typedef __attribute__((address_space(1))) u64 gu64w;
-struct ClEnt { u32 klo, khi, idx, pad; };   // idx = row + 1, 0 = empty
-
-__device__ __forceinline__ u64 cl_key(const u32x3& v) { return (u64)v.x | ((u64)v.y << 32); }
-__device__ __forceinline__ u32x3 cl_none() { u32x3 v; v.x = ~0u; v.y = ~0u; v.z = 0; return v; }
 __device__ __forceinline__ u32 cl_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 cl_uni64(u64 v) { return (u64)cl_uni((u32)v) | ((u64)cl_uni((u32)(v >> 32)) << 32); }
+
+// ---- the key type of this build: u64, or two words compared most significant first (kmer.hpp:262-268) ----
+#if KMX_CL_KW == 1
+typedef u64 CKey;
+struct CRec { u32x3 v; };                                      // key low dword, key high dword, count
+struct ClEnt { u32 klo, khi, idx, pad; };                      // row table entry: idx = row + 1, 0 = empty
+__device__ __forceinline__ bool ck_lt(CKey a, CKey b) { return a < b; }
+__device__ __forceinline__ bool ck_eq(CKey a, CKey b) { return a == b; }
+__device__ __forceinline__ CKey ck_inf() { return ~0ULL; }
+__device__ __forceinline__ u64 ck_fold(CKey k) { return k; }    // the 64 bits the hashes work on
+__device__ __forceinline__ CKey ck_uni(CKey k) { return cl_uni64(k); }
+__device__ __forceinline__ CKey ck_load(const u8* p) { return load_key<1>(p).w[0]; }
+__device__ __forceinline__ void ck_store(u32* p, CKey k) { p[0] = (u32)k; p[1] = (u32)(k >> 32); }
+__device__ __forceinline__ CKey cl_key(const CRec& r) { return (u64)r.v.x | ((u64)r.v.y << 32); }
+__device__ __forceinline__ u32 cl_cnt(const CRec& r) { return r.v.z; }
+__device__ __forceinline__ CRec cl_none() { CRec r; r.v.x = ~0u; r.v.y = ~0u; r.v.z = 0; return r; }
+__device__ __forceinline__ CRec cl_load(gu32* p) { CRec r; r.v = *(gu32x3*)p; return r; }
+__device__ __forceinline__ bool ent_hit(const ClEnt& e, CKey k) { return e.klo == (u32)k && e.khi == (u32)(k >> 32) && e.idx != 0; }
+__device__ __forceinline__ void ent_set(ClEnt& e, CKey k) { e.klo = (u32)k; e.khi = (u32)(k >> 32); }
+__device__ __forceinline__ ClEnt ent_load(const ClEnt* tab, u32 h) { const uint4 v = reinterpret_cast<const uint4*>(tab)[h]; ClEnt e; e.klo = v.x; e.khi = v.y; e.idx = v.z; e.pad = v.w; return e; }      // one 16-byte LDS read
+#else
+struct CKey { u64 lo, hi; };
+struct CRec { u32x4 k; u32 c; };                               // key (low word first), count
+struct ClEnt { u64 lo, hi; u32 idx, pad[3]; };                 // 32 bytes
+__device__ __forceinline__ bool ck_lt(CKey a, CKey b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; }
+__device__ __forceinline__ bool ck_eq(CKey a, CKey b) { return a.lo == b.lo && a.hi == b.hi; }
+__device__ __forceinline__ CKey ck_inf() { CKey k; k.lo = ~0ULL; k.hi = ~0ULL; return k; }
+// (the product's high half folded down: a plain lo ^ hi * c cancels when the low word is itself a multiple of the high one)
+__device__ __forceinline__ u64 ck_fold(CKey k) { const u64 h = k.hi * 0x9E3779B97F4A7C15ULL; return k.lo ^ h ^ (h >> 32); }
+__device__ __forceinline__ CKey ck_uni(CKey k) { CKey r; r.lo = cl_uni64(k.lo); r.hi = cl_uni64(k.hi); return r; }
+__device__ __forceinline__ CKey ck_load(const u8* p) { const Key<2> k = load_key<2>(p); CKey r; r.lo = k.w[0]; r.hi = k.w[1]; return r; }
+__device__ __forceinline__ void ck_store(u32* p, CKey k) { p[0] = (u32)k.lo; p[1] = (u32)(k.lo >> 32); p[2] = (u32)k.hi; p[3] = (u32)(k.hi >> 32); }
+__device__ __forceinline__ CKey cl_key(const CRec& r) { CKey k; k.lo = (u64)r.k.x | ((u64)r.k.y << 32); k.hi = (u64)r.k.z | ((u64)r.k.w << 32); return k; }
+__device__ __forceinline__ u32 cl_cnt(const CRec& r) { return r.c; }
+__device__ __forceinline__ CRec cl_none() { CRec r; r.k.x = ~0u; r.k.y = ~0u; r.k.z = ~0u; r.k.w = ~0u; r.c = 0; return r; }
+__device__ __forceinline__ CRec cl_load(gu32* p) { CRec r; r.k = *(gu32x4*)p; r.c = p[4]; return r; }
+__device__ __forceinline__ bool ent_hit(const ClEnt& e, CKey k) { return e.lo == k.lo && e.hi == k.hi && e.idx != 0; }
+__device__ __forceinline__ void ent_set(ClEnt& e, CKey k) { e.lo = k.lo; e.hi = k.hi; }
+__device__ __forceinline__ ClEnt ent_load(const ClEnt* tab, u32 h)
+{ // the key and the row: 20 of the entry's 32 bytes
+  const uint4 v = reinterpret_cast<const uint4*>(tab)[2 * h]; const u32 ix = reinterpret_cast<const u32*>(tab)[8 * h + 4];
+  ClEnt e; e.lo = (u64)v.x | ((u64)v.y << 32); e.hi = (u64)v.z | ((u64)v.w << 32); e.idx = ix; return e;
+}
+#endif
+__device__ __forceinline__ bool ck_le(CKey a, CKey b) { return !ck_lt(b, a); }
 __device__ __forceinline__ void cl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // the row keys of a tile sit in a PERFECT hash table: wave 0 tries multipliers until the (<= 56) keys land in
 // distinct entries of the 1024, so a lookup is one LDS read and one compare -- no probing, no branch
@@ -76,8 +136,9 @@ __device__ __forceinline__ void cl_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // Keys of real minimizer partitions are structured (the row keys of a tile share their leading nucleotides, neighbours in
 // the genome are shifted copies of each other): for a tile in a thousand none of the cheap hashes is collision free.  Those
 // tiles use a second family -- a 64-bit multiplicative hash of the whole key (bit 31 of the hash word set; a uniform branch).
-__device__ __forceinline__ u32 cl_thash(u64 k, u32 hf)
+__device__ __forceinline__ u32 cl_thash(CKey key, u32 hf)
 {
+  const u64 k = ck_fold(key);
   if (hf & 0x80000000u) {
     const u64 m = 0x9E3779B97F4A7C15ULL + 2ULL * (u64)(hf & 0xFFFFu) * 0xBF58476D1CE4E5B9ULL;      // odd
     return (u32)((k * m) >> (CL_PT == 2048 ? 53 : 52));      // the product's TOP bits: every key bit counts (a k-mer and its variant with one
@@ -91,14 +152,15 @@ __device__ __forceinline__ u32 cl_mult(u32 seed)
   if (seed >= 64u) return 0x80000000u | (seed - 63u);
   return ((0x9E3779u + seed * 0x5A6B2u) & 0xFFFFFFu) | ((13u + (seed * 7u) % 19u) << 24);
 }
-__device__ __forceinline__ u32 cl_mix(u64 k)
+__device__ __forceinline__ u32 cl_mix(CKey key)
 {
+  const u64 k = ck_fold(key);
   u32 x = (u32)k ^ ((u32)(k >> 32) * 0x9E3779B1u);
   x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
   return x;
 }
 // wave 0: lane j holds row keys j, j + 64, ...  -> the hash, 0 when no try worked; slot[x] = entry of my key x
-__device__ __forceinline__ u32 cl_build(ClEnt* tab, const u64 (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL])
+__device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL])
 {
   for (u32 s = 0; s < (u32)CL_SEEDS; s++) {
     const u32 mult = cl_mult(s);
@@ -112,7 +174,7 @@ __device__ __forceinline__ u32 cl_build(ClEnt* tab, const u64 (&key)[CL_KPL], co
     }
     if (__ballot(clash) == 0) {
 #pragma unroll
-      for (int x = 0; x < CL_KPL; x++) { if (have[x]) { tab[h[x]].klo = (u32)key[x]; tab[h[x]].khi = (u32)(key[x] >> 32); } slot[x] = h[x]; }
+      for (int x = 0; x < CL_KPL; x++) { if (have[x]) ent_set(tab[h[x]], key[x]); slot[x] = h[x]; }
       return mult;
     }
 #pragma unroll
@@ -136,7 +198,7 @@ constexpr int SK_CAP = 2048;             // records per range (all lists), and t
 __global__ __launch_bounds__(SK_TPB)
 void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ items, u32 n_items)
 {
-  __shared__ u64 ks[SK_CAP];
+  __shared__ CKey ks[SK_CAP];
   __shared__ u32 wsum[SK_TPB / 64];
   const u32 item = blockIdx.x;
   if (item >= n_items) return;
@@ -163,7 +225,7 @@ void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ ite
   u32 P = 2;
   if (runs) P = max(2u, SP * L); else while (P < total) P <<= 1;
   if (tid == 0) irregular = 0;
-  if (runs) for (u32 t = tid; t < P; t += SK_TPB) ks[t] = ~0ULL;
+  if (runs) for (u32 t = tid; t < P; t += SK_TPB) ks[t] = ck_inf();
   __syncthreads();
   {   // SK_TPB / N threads per list, every list at once
     const u32 tpl = max(1u, (u32)SK_TPB / N);
@@ -171,26 +233,26 @@ void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ ite
       u32 off = 0;
       if (!runs) for (u32 j = 0; j < i; j++) off += S.bounds[(u64)(range + 1) * N + j] - S.bounds[(u64)range * N + j];
       const u32 lo = S.bounds[(u64)range * N + i], n = S.bounds[(u64)(range + 1) * N + i] - lo, smin = S.soft_min[i];
-      const u8* base = S.recs[i] + (u64)lo * 12;
+      const u8* base = S.recs[i] + (u64)lo * RB;
       for (u32 e = tid % tpl; e < n; e += tpl) {
-        const u32* rp = reinterpret_cast<const u32*>(base + (u64)e * 12);
-        const bool solid = rp[2] >= smin;
-        const u64 key = solid ? ((u64)rp[0] | ((u64)rp[1] << 32)) : ~0ULL;      // (a non-solid record counts for nothing)
+        const u32* rp = reinterpret_cast<const u32*>(base + (u64)e * RB);
+        const bool solid = rp[RD - 1] >= smin;
+        const CKey key = solid ? ck_load(reinterpret_cast<const u8*>(rp)) : ck_inf();      // (a non-solid record counts for nothing)
         if (!runs) ks[off + e] = key;
         else { ks[i * L + ((i & 1u) ? L - 1 - e : e)] = key; if (!solid) irregular = 1; }
       }
     }
   }
-  if (!runs) for (u32 t = total + tid; t < P; t += SK_TPB) ks[t] = ~0ULL;
+  if (!runs) for (u32 t = total + tid; t < P; t += SK_TPB) ks[t] = ck_inf();
   __syncthreads();
   const u32 k0 = (runs && !irregular) ? 2 * L : 2;      // runs of L are sorted, in the directions the network expects
   for (u32 k = k0; k <= P; k <<= 1) {
     for (u32 j = k >> 1; j > 0; j >>= 1) {
       for (u32 t = tid; t < P / 2; t += SK_TPB) {
         const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;      // the pair (a, a + j)
-        const u64 x = ks[a], y = ks[b];
+        const CKey x = ks[a], y = ks[b];
         const bool up = (a & k) == 0;
-        if ((x > y) == up) { ks[a] = y; ks[b] = x; }
+        if (ck_lt(y, x) == up) { ks[a] = y; ks[b] = x; }
       }
       __syncthreads();
     }
@@ -201,13 +263,14 @@ void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ ite
   for (u32 x = 0; x < per; x++) {
     const u32 i = tid * per + x;
     if (i < P) {
-      const u64 k = ks[i];
-      const bool kept = k != ~0ULL && (i == 0 || ks[i - 1] != k) && i + rec_min - 1 < P && ks[i + rec_min - 1] == k;
+      const CKey k = ks[i];
+      const bool real = !ck_eq(k, ck_inf());
+      const bool kept = real && (i == 0 || !ck_eq(ks[i - 1], k)) && i + rec_min - 1 < P && ck_eq(ks[i + rec_min - 1], k);
       keptm |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
-      if (k != ~0ULL && (range & 7u) == 0) {      // (an estimate: every eighth range)
+      if (real && (range & 7u) == 0) {      // (an estimate: every eighth range)
         nsolid++;
         bool cov = false;      // my record's run of equal keys is at least recurrence-min long
-        for (u32 j = 0; j < rec_min && !cov; j++) cov = i >= j && i - j + rec_min - 1 < P && ks[i - j] == k && ks[i - j + rec_min - 1] == k;
+        for (u32 j = 0; j < rec_min && !cov; j++) cov = i >= j && i - j + rec_min - 1 < P && ck_eq(ks[i - j], k) && ck_eq(ks[i - j + rec_min - 1], k);
         ncov += cov ? 1u : 0u;
       }
     }
@@ -222,7 +285,7 @@ void k_cols_skel(const TaskDev* __restrict__ subs, const uint2* __restrict__ ite
   __syncthreads();
   u32 base = incl - mine, nk = 0;
   for (u32 w = 0; w < SK_TPB / 64; w++) { if (w < wave) base += wsum[w]; nk += wsum[w]; }
-  u64* out = reinterpret_cast<u64*>(S.out) + (u64)range * SK_CAP;
+  CKey* out = reinterpret_cast<CKey*>(S.out) + (u64)range * SK_CAP;
   for (u32 x = 0; x < per; x++) if ((keptm >> x) & 1u) out[base++] = ks[tid * per + x];
   if (tid == 0) { sg.nrows = nk; S.segs[range] = sg; atomicAdd(&S.ctrl[1], 1ULL); atomicAdd(&S.ctrl[3], (u64)nk); }
 }
@@ -271,7 +334,7 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
   for (u32 i = tid >> 6; i < nseg; i += CP_TPB / 64) {   // a wave per segment
     const Seg a = S.segs[i];
     const u8* src = S.out + a.row_off * srb;
-    for (u32 r = tid & 63u; r < a.nrows; r += 64) C.skel[(u64)s_off[i] + r] = load_key<1>(src + (u64)r * srb).w[0];
+    for (u32 r = tid & 63u; r < a.nrows; r += 64) reinterpret_cast<CKey*>(C.skel)[(u64)s_off[i] + r] = ck_load(src + (u64)r * srb);
   }
   __syncthreads();
   const u32 np = T.len[T.pivot];
@@ -281,9 +344,9 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
     else if (j == T.c) res = (u32)rows;
     else {   // same boundary keys as k_range_bounds: Q_j = pivot[j * len_pivot / c]
       const u32 pos = (u32)(((u64)j * np) / T.c);
-      const u64 q = load_key<1>(T.recs[T.pivot] + (u64)pos * 12).w[0];
+      const CKey q = ck_load(T.recs[T.pivot] + (u64)pos * RB);
       u32 lo = 0, hi = (u32)rows;
-      while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (C.skel[mid] < q) lo = mid + 1; else hi = mid; }
+      while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (ck_lt(reinterpret_cast<const CKey*>(C.skel)[mid], q)) lo = mid + 1; else hi = mid; }
       res = lo;
     }
     C.rbounds[j] = res;
@@ -296,10 +359,11 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
   }
 }
 
-__device__ const u32 kmx_cols_sentinel[4] = {~0u, ~0u, 0u, 0u};      // the record "past the end of a list": largest key, count 0
+__device__ const u32 kmx_cols_sentinel[8] = {~0u, ~0u, KW == 1 ? 0u : ~0u, KW == 1 ? 0u : ~0u, 0u, 0u, 0u, 0u};      // the record "past the end of a list": largest key, count 0
 
 #ifdef KMX_PHASE_PROF
 __device__ u64 kmx_cols_prof[8];
+__device__ u64 kmx_sparse_prof[8];
 #ifndef KMX_PROF_TID
 #define KMX_PROF_TID 512
 #endif
@@ -352,7 +416,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const u32 s_lo = cl_uni(C.rbounds[range]), s_hi = cl_uni(C.rbounds[range + 1]);
     const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
     const u32 slot0 = s_lo / rt + range;
-    const u64* const skel = C.skel;
+    const CKey* const skel = reinterpret_cast<const CKey*>(C.skel);
 
     // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + CL_G * u
     // (mod CL_W) inside [cur, cur + CL_W)
@@ -364,20 +428,20 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const u32 smin = T.soft_min[li];
     gu32* const base = (gu32*)(uintptr_t)T.recs[li];
     gu32* const sentinel = (gu32*)(uintptr_t)kmx_cols_sentinel;
-    u32x3 rec[CL_U];
+    CRec rec[CL_U];
 #pragma unroll
     for (int u = 0; u < CL_U; u++) {
       const u32 ix = cur + ((r + CL_G * u - cur) & (CL_W - 1));
       rec[u] = cl_none();
-      if (ix < end) rec[u] = *(gu32x3*)(base + (u64)ix * 3);
+      if (ix < end) rec[u] = cl_load(base + (u64)ix * RD);
     }
     u64 tsum = 0; u32 tn = 0;            // TOTAL_WO / NON_SOLID of my share of my list
     // first tile: row keys, table, (block 0) the key column of the result
-    u64 skn[CL_KPL];
+    CKey skn[CL_KPL];
     u32 myslot[CL_KPL];                  // wave 0: the table entries of my row keys of the tile in hand
     bool failed = false;
 #pragma unroll
-    for (int x = 0; x < CL_KPL; x++) { skn[x] = ~0ULL; myslot[x] = 0; }
+    for (int x = 0; x < CL_KPL; x++) { skn[x] = ck_inf(); myslot[x] = 0; }
     if (tid < 64) {
       bool have[CL_KPL];
 #pragma unroll
@@ -386,17 +450,14 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         have[x] = j < rt && s_lo + j < s_hi;
         if (have[x]) {
           skn[x] = skel[s_lo + j];
-          if (blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes); kp[0] = (u32)skn[x]; kp[1] = (u32)(skn[x] >> 32); }
+          if (blk == 0) ck_store(reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes), skn[x]);
         }
       }
       const u32 mult = cl_build(ptab, skn, have, (u32)tid, myslot);
-#ifdef KMX_DEBUG_TAB
-      if (mult == 0 && blk == 0 && range < 3) { for (int x = 0; x < CL_KPL; x++) printf("T%u r%u q0 lane %d x %d have %d key %016llx s_lo %u s_hi %u\n", items[item].x, range, tid, x, (int)have[x], skn[x], s_lo, s_hi); }
-#endif
       if (tid == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
     }
-    u64 khi_n = ntiles > 1 ? skel[s_lo + rt] : ~0ULL;     // upper key of tile 0 (uniform address: scalar load)
-    u64 kmid_n = (CL_HALVES > 1 && s_lo + 56 < s_hi) ? skel[s_lo + 56] : ~0ULL;      // ... and the key its second slice group starts at
+    CKey khi_n = ntiles > 1 ? skel[s_lo + rt] : ck_inf();     // upper key of tile 0 (uniform address: scalar load)
+    CKey kmid_n = (CL_HALVES > 1 && s_lo + 56 < s_hi) ? skel[s_lo + 56] : ck_inf();      // ... and the key its second slice group starts at
     u32 rnd = 0;                         // round number mod 3
     cl_barrier();
     CLPH(0);
@@ -405,23 +466,23 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       const u32 s0 = s_lo + q * rt;
       const u32 rte = min(rt, s_hi - s0);
       const bool last = cl_uni(q + 1 == ntiles ? 1u : 0u) != 0;            // takes everything the lists have left in the range
-      const u64 khi = cl_uni64(khi_n);
-      const u64 kmid = cl_uni64(kmid_n);
+      const CKey khi = ck_uni(khi_n);
+      const CKey kmid = ck_uni(kmid_n);
       if (!last) {
         // the next tile's row keys are wave 0's business alone: nobody else ever waits for these loads
         if (tid < 64) {
 #pragma unroll
-          for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)tid + 64u * x; skn[x] = ~0ULL; if (j < rt && s0 + rt + j < s_hi) skn[x] = skel[s0 + rt + j]; }
+          for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)tid + 64u * x; skn[x] = ck_inf(); if (j < rt && s0 + rt + j < s_hi) skn[x] = skel[s0 + rt + j]; }
         }
-        khi_n = q + 2 < ntiles ? skel[s0 + 2 * rt] : ~0ULL;
-        kmid_n = (CL_HALVES > 1 && s0 + rt + 56 < s_hi) ? skel[s0 + rt + 56] : ~0ULL;
+        khi_n = q + 2 < ntiles ? skel[s0 + 2 * rt] : ck_inf();
+        kmid_n = (CL_HALVES > 1 && s0 + rt + 56 < s_hi) ? skel[s0 + rt + 56] : ck_inf();
       }
       const ClEnt* const tab = ptab + (q % CL_NT) * CL_PT;
       const u32 mult = cl_uni(sh[4 + (q % CL_NT)]);
       // the wave's slices of the tile's slice groups (records below / from the tile's middle row key)
       // (an entry = the key and (list << 32 | count): k_cols_sparse builds the rows of the keys that reach the recurrence from them)
-      gu64w* const ovk0 = (gu64w*)(uintptr_t)(C.ovkeys + (((((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave) * CL_OVW) * 2);
-      gu64w* const ovk1 = ovk0 + (u64)nblk * CL_NW * CL_OVW * 2;
+      gu64w* const ovk0 = (gu64w*)(uintptr_t)(C.ovkeys + (((((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave) * CL_OVW) * EW);
+      gu64w* const ovk1 = ovk0 + (u64)nblk * CL_NW * CL_OVW * EW;
       const u64 li_hi = (u64)li << 32;
       u32 wov = 0, wov1 = 0;                        // records of this wave that are not row keys (uniform), per slice group
 
@@ -436,7 +497,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           for (int u = 0; u < CL_U; u++) consm |= ((cur + ((r + CL_G * u - cur) & (CL_W - 1))) < end ? 1u : 0u) << u;
         } else {
 #pragma unroll
-          for (int u = 0; u < CL_U; u++) consm |= (cl_key(rec[u]) < khi ? 1u : 0u) << u;      // (an empty slot holds the largest key)
+          for (int u = 0; u < CL_U; u++) consm |= (ck_lt(cl_key(rec[u]), khi) ? 1u : 0u) << u;      // (an empty slot holds the largest key)
         }
         asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
         CLPH(1);
@@ -444,23 +505,23 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         for (int g = 0; g < CL_U; g += 4) {
           __builtin_amdgcn_sched_barrier(0);
           u32 curg = cur; asm volatile("" : "+v"(curg));      // (re-derived per group: 16 slot indices kept live get spilled)
-          uint4 pe[4];
+          ClEnt pe[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) pe[j] = reinterpret_cast<const uint4*>(tab)[cl_thash(cl_key(rec[g + j]), mult)];
+          for (int j = 0; j < 4; j++) pe[j] = ent_load(tab, cl_thash(cl_key(rec[g + j]), mult));
           u32 ovm = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             // straight-line: masks and selects, no branches (a deposit that is none goes to a scratch word)
             const int u = g + j;
             const bool cons = (consm >> u) & 1u;
-            const u64 k = cl_key(rec[u]);
-            const u32 c = rec[u].z;
+            const CKey k = cl_key(rec[u]);
+            const u32 c = cl_cnt(rec[u]);
             const bool solid = cons && c >= smin;
-            const bool hit = pe[j].x == (u32)k && pe[j].y == (u32)(k >> 32) && pe[j].z != 0;
+            const bool hit = ent_hit(pe[j], k);
             tsum += solid ? c : 0u;
             tn += (cons && !solid) ? 1u : 0u;
-            if (MODE == 0) img[(solid && hit) ? __umul24(pe[j].z - 1, iw) + lg : dummy] = c;
-            else if (solid && hit) atomicOr(&img[__umul24(pe[j].z - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
+            if (MODE == 0) img[(solid && hit) ? __umul24(pe[j].idx - 1, iw) + lg : dummy] = c;
+            else if (solid && hit) atomicOr(&img[__umul24(pe[j].idx - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
             ovm |= ((solid && !hit) ? 1u : 0u) << j;
           }
           asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
@@ -469,20 +530,25 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           for (int j = 0; j < 4; j++) {
             const u64 bal = __ballot((ovm >> j) & 1u);
             if (bal) {
-              const u64 kk = cl_key(rec[g + j]);
+              const CKey kk = cl_key(rec[g + j]);
+#if KMX_CL_KW == 1
+#define CL_PUT(o, pos) do { (o)[2 * (pos)] = kk; (o)[2 * (pos) + 1] = li_hi | cl_cnt(rec[g + j]); } while (0)
+#else
+#define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = li_hi | cl_cnt(rec[g + j]); } while (0)
+#endif
               if (CL_HALVES == 1) {
                 if ((ovm >> j) & 1u) {
                   const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                  if (pos < (u32)CL_OVW) { ovk0[2 * pos] = kk; ovk0[2 * pos + 1] = li_hi | rec[g + j].z; }
+                  if (pos < (u32)CL_OVW) CL_PUT(ovk0, pos);
                 }
                 wov += (u32)__popcll(bal);
               } else {
-                const u64 hi = __ballot(((ovm >> j) & 1u) && kk >= kmid), lo = bal & ~hi;
+                const u64 hi = __ballot(((ovm >> j) & 1u) && !ck_lt(kk, kmid)), lo = bal & ~hi;
                 if ((ovm >> j) & 1u) {
-                  const bool up = kk >= kmid;
+                  const bool up = !ck_lt(kk, kmid);
                   const u64 m = up ? hi : lo;
                   const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                  if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; o[2 * pos] = kk; o[2 * pos + 1] = li_hi | rec[g + j].z; }
+                  if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; CL_PUT(o, pos); }
                 }
                 wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
               }
@@ -496,8 +562,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             const int u = g + j;
             if ((consm >> u) & 1u) {
               const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + (u32)CL_W;
-              gu32* const src = ix < end ? base + (u64)ix * 3 : sentinel;
-              rec[u] = *(gu32x3*)src;
+              gu32* const src = ix < end ? base + (u64)ix * RD : sentinel;
+              rec[u] = cl_load(src);
             }
           }
         }
@@ -532,17 +598,14 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           for (int x = 0; x < CL_KPL; x++) {
             const u32 j = (u32)lane + 64u * x;
             have[x] = j < rt && sn + j < s_hi;
-            if (have[x] && blk == 0) { u32* kp = reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes); kp[0] = (u32)skn[x]; kp[1] = (u32)(skn[x] >> 32); }
+            if (have[x] && blk == 0) ck_store(reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes), skn[x]);
           }
           const u32 m2 = cl_build(ptab + ((q + 1) % CL_NT) * CL_PT, skn, have, (u32)lane, myslot);
-#ifdef KMX_DEBUG_TAB
-          if (m2 == 0 && blk == 0 && sn < 3000) { for (int x = 0; x < CL_KPL; x++) printf("T%u r%u sn %u lane %d x %d have %d key %016llx s_lo %u s_hi %u\n", items[item].x, range, sn, lane, x, (int)have[x], skn[x], s_lo, s_hi); }
-#endif
           if (lane == 0) { sh[4 + ((q + 1) % CL_NT)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
         if (MODE == 0) {
-          u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + 4ull * col0;
+          u8* const out0 = T.out + (u64)s0 * row_bytes + KW * 8 + 4ull * col0;
           const bool wide = ((row_bytes | (4u * col0) | (4u * nbs)) & 7u) == 0;
           for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
             u32* const src = img + j * nbs;
@@ -563,7 +626,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           }
         } else {
           // a row's slice is (lists of the block) / 8 bytes (the block starts at a multiple of 8 lists): a byte per lane
-          u8* const out0 = T.out + (u64)s0 * row_bytes + 8 + (col0 >> 3);
+          u8* const out0 = T.out + (u64)s0 * row_bytes + KW * 8 + (col0 >> 3);
           const u32 nby = (nbl + 7) >> 3;
           for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
             u32* const src = img + j * iw;
@@ -621,29 +684,100 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 #endif
 constexpr int CK_TPB = KMX_CK_TPB;
 constexpr int CK_Z = KMX_CK_Z;           // workgroups sharing the slice groups of a range
-constexpr int CK_SPEC = 5;               // entries per thread requested together with the slice's count
-constexpr int CK_CAND = 2048;            // candidates per pass (32 KB of LDS)
+constexpr int CK_SPEC = KW == 1 ? 5 : 4;               // entries per thread requested together with the slice's count
+constexpr int CK_CAND = KW == 1 ? 2048 : 1024;      // candidates per pass (24 KB of LDS with their payloads)
 constexpr int CK_B2 = 1 << 15;           // bits of the candidate map
 constexpr int CK_NPASS = 8;              // directory entries per group
 
 struct SpDir { u32 base, n, dense_first, dense_n; };      // rows [base, base + n) of the arena: a pass's rows; dense_* filled in entry 0 of a group
 
-__device__ __forceinline__ bool ck_less(u64 ka, u64 pa, u64 kb, u64 pb) { return ka != kb ? ka < kb : pa < pb; }
+__device__ __forceinline__ bool ck_less(CKey ka, u64 pa, CKey kb, u64 pb) { return !ck_eq(ka, kb) ? ck_lt(ka, kb) : pa < pb; }
+
+// ---- the candidates' sort: a bitonic network over P = 128 .. CK_CAND entries in LDS.  Steps between entries less than 128
+//      apart stay inside a wave -- a wave holds a chunk of 128 entries in registers (two per lane) and exchanges them with
+//      lane shuffles, no workgroup barrier -- so a sort of 1024 entries meets 10 barriers, not 55. ----
+__device__ __forceinline__ CKey ck_shfl_xor(CKey k, int m)
+{
+#if KMX_CL_KW == 1
+  return (u64)__shfl_xor((unsigned long long)k, m);
+#else
+  CKey r; r.lo = (u64)__shfl_xor((unsigned long long)k.lo, m); r.hi = (u64)__shfl_xor((unsigned long long)k.hi, m); return r;
+#endif
+}
+// steps j = jtop .. 1 of stage k2 on the chunk [base, base + 128) (jtop <= 64)
+__device__ __forceinline__ void ck_chunk_steps(CKey (&k)[2], u64 (&p)[2], u32 base, u32 lane, u32 k2, u32 jtop)
+{
+  if (jtop >= 64u) {
+    const bool asc = ((base + lane) & k2) == 0;      // (k2 >= 128 here: both of my entries sort the same way)
+    if (ck_less(k[1], p[1], k[0], p[0]) == asc) { const CKey tk = k[0]; k[0] = k[1]; k[1] = tk; const u64 tp = p[0]; p[0] = p[1]; p[1] = tp; }
+    jtop = 32;
+  }
+  for (u32 j = jtop; j > 0; j >>= 1) {
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      const CKey ok = ck_shfl_xor(k[x], (int)j); const u64 op = (u64)__shfl_xor((unsigned long long)p[x], (int)j);
+      const bool asc = ((base + 64u * x + lane) & k2) == 0;
+      const bool keep_min = ((lane & j) == 0) == asc;
+      const bool other_less = ck_less(ok, op, k[x], p[x]);
+      if (other_less == keep_min) { k[x] = ok; p[x] = op; }
+    }
+  }
+}
+__device__ __forceinline__ void ck_sort_block(CKey* ck, u64* cp, u32 P, u32 tid)      // P: a power of two >= 128, pads = ck_inf()
+{
+  const u32 lane = tid & 63u, wave = tid >> 6;
+  for (u32 base = wave * 128u; base < P; base += (CK_TPB / 64) * 128u) {
+    CKey k[2] = {ck[base + lane], ck[base + 64u + lane]}; u64 p[2] = {cp[base + lane], cp[base + 64u + lane]};
+    for (u32 k2 = 2; k2 <= 128u; k2 <<= 1) ck_chunk_steps(k, p, base, lane, k2, k2 >> 1);
+    ck[base + lane] = k[0]; ck[base + 64u + lane] = k[1]; cp[base + lane] = p[0]; cp[base + 64u + lane] = p[1];
+  }
+  __syncthreads();
+  for (u32 k2 = 256; k2 <= P; k2 <<= 1) {
+    for (u32 j = k2 >> 1; j >= 128u; j >>= 1) {
+      for (u32 t = tid; t < P / 2; t += CK_TPB) {
+        const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
+        const CKey ka = ck[a], kb = ck[b]; const u64 pa = cp[a], pb = cp[b];
+        const bool up = (a & k2) == 0;
+        if (ck_less(kb, pb, ka, pa) == up) { ck[a] = kb; ck[b] = ka; cp[a] = pb; cp[b] = pa; }
+      }
+      __syncthreads();
+    }
+    for (u32 base = wave * 128u; base < P; base += (CK_TPB / 64) * 128u) {
+      CKey k[2] = {ck[base + lane], ck[base + 64u + lane]}; u64 p[2] = {cp[base + lane], cp[base + 64u + lane]};
+      ck_chunk_steps(k, p, base, lane, k2, 64u);
+      ck[base + lane] = k[0]; ck[base + 64u + lane] = k[1]; cp[base + lane] = p[0]; cp[base + 64u + lane] = p[1];
+    }
+    __syncthreads();
+  }
+}
 
 template <int MODE>
-__global__ __launch_bounds__(CK_TPB)
+__global__ __launch_bounds__(CK_TPB, MODE == 1 ? 4 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores)
 void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
   __shared__ u32 bits[CK_BITS / 32];
   __shared__ u32 bits2[CK_B2 / 32];
-  __shared__ u64 ck[CK_CAND];            // candidate keys
+  __shared__ CKey ck[CK_CAND];           // candidate keys
   __shared__ u64 cp[CK_CAND];            // ... and their (list << 32 | count)
   __shared__ u32 runs[CK_CAND];          // kept runs: first entry | length << 16 ... as two words: see below
   __shared__ u32 wsum[CK_TPB / 64];
   __shared__ u32 flag, total, ncand, rowbase, sover;
-  __shared__ u32 parow[MODE == 1 ? (CK_TPB / 64) * 136 : 1];      // PA: a row per wave is assembled here (<= 4096 lists + key)
+  __shared__ u32 parow[MODE == 1 ? (CK_TPB / 16) * 136 : 1];      // PA: a row per lane group is assembled here (<= 4096 lists + key)
+  auto ent_key = [](const u64* kp, u32 e) -> CKey {
+#if KMX_CL_KW == 1
+    return kp[EW * e];
+#else
+    CKey k; k.lo = kp[EW * e]; k.hi = kp[EW * e + 1]; return k;
+#endif
+  };
   const u32 item = blockIdx.x;
   if (item >= n_items) return;
+#ifdef KMX_PHASE_PROF
+  long long spt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long spc = clock64();
+#define SPPH(i) do { const long long n_ = clock64(); spt[i] += n_ - spc; spc = n_; } while (0)
+#else
+#define SPPH(i) do {} while (0)
+#endif
   const TaskDev& T = tasks[items[item].x];
   const ColsDev& C = cols[items[item].x];
   if (T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) return;
@@ -669,15 +803,15 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     // four threads per (block, wave) slice; when every slice has its four threads at once (<= 1024 lists) a slice's count and its
     // first 20 entries (5 per thread; the usual slice holds ~14; the slice's memory is there whatever the count) are requested
     // together and kept in registers for both walks over the entries: one memory round trip per group
-    u32 n0 = 0; u64 kk0[CK_SPEC], pp0[CK_SPEC];
+    u32 n0 = 0; CKey kk0[CK_SPEC]; u64 pp0[CK_SPEC];
     const u64* kp0 = C.ovkeys;
     if (single) {
       const u32 sl = tid >> 2, sub = tid & 3u;
       const bool ok = sl < nsl;
       const u32 nraw = ok ? C.ovcnt[sbase + sl] : 0u;
-      kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW * 2;
+      kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW * EW;
 #pragma unroll
-      for (int x = 0; x < CK_SPEC; x++) { kk0[x] = kp0[2 * (sub + 4 * x)]; pp0[x] = kp0[2 * (sub + 4 * x) + 1]; }
+      for (int x = 0; x < CK_SPEC; x++) { kk0[x] = ent_key(kp0, sub + 4 * x); pp0[x] = kp0[EW * (sub + 4 * x) + KW]; }
       n0 = min(nraw, (u32)CL_OVW);
       if (nraw > (u32)CL_OVW) sover = 1;
       if (sub == 0 && nraw) atomicAdd(&total, nraw);
@@ -692,11 +826,12 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     const u32 tot = total;
     const bool over = sover != 0;
     __syncthreads();
+    SPPH(0);
     if (tid == 0) { total = 0; dir[(u64)gid * CK_NPASS].dense_first = d0; dir[(u64)gid * CK_NPASS].dense_n = dn; }
     if (over) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[1], 1u); } break; }
     if (tot == 0) continue;
     // passes: ~1400 entries each when every entry is a candidate, ~3000 when only the keys seen twice are
-    const u32 per = thr == 1 ? 1400u : 3000u;
+    const u32 per = (thr == 1 ? 1400u : 3000u) * (u32)CK_CAND / 2048u;
     u32 npass = 1; while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;
     if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
     // each of my entries through f(key, payload): four threads per slice
@@ -707,9 +842,9 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         for (int x = 0; x < CK_SPEC; x++)
           if (sub + 4 * x < n0 && !(npass > 1 && ((cl_mix(kk0[x]) >> 24) & (npass - 1)) != pass)) f(kk0[x], pp0[x]);
         for (u32 e = sub + 4 * CK_SPEC; e < n0; e += 4) {
-          const u64 k = kp0[2 * e];
+          const CKey k = ent_key(kp0, e);
           if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
-          f(k, kp0[2 * e + 1]);
+          f(k, kp0[EW * e + KW]);
         }
         return;
       }
@@ -717,11 +852,11 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
         if (sl >= nsl) continue;
         const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
-        const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW * 2;
+        const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW * EW;
         for (u32 e = sub; e < n; e += 4) {
-          const u64 k = kp[2 * e];
+          const CKey k = ent_key(kp, e);
           if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
-          f(k, kp[2 * e + 1]);
+          f(k, kp[EW * e + KW]);
         }
       }
     };
@@ -730,48 +865,44 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       for (u32 t = tid; t < (u32)CK_B2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
       if (tid == 0) ncand = 0;
       __syncthreads();
+      SPPH(1);
       if (thr > 1) {
-        each(pass, [&](u64 k, u64) {
+        each(pass, [&](CKey k, u64) {
           const u32 hx = cl_mix(k);
           const u32 bit = hx & (CK_BITS - 1);
           const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
           if ((old >> (bit & 31u)) & 1u) { const u32 b2 = (hx >> 7) & (CK_B2 - 1); atomicOr(&bits2[b2 >> 5], 1u << (b2 & 31u)); }
         });
         __syncthreads();
+        SPPH(2);
       }
-      each(pass, [&](u64 k, u64 pl) {
+      each(pass, [&](CKey k, u64 pl) {
         if (thr > 1) { const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return; }
         const u32 ps = atomicAdd(&ncand, 1u);
         if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; }
       });
       __syncthreads();
+      SPPH(3);
       const u32 nc = ncand;
       if (nc > (u32)CK_CAND) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
       if (tid == 0) { dir[(u64)gid * CK_NPASS + pass].base = 0; dir[(u64)gid * CK_NPASS + pass].n = 0; }
       if (nc == 0) { __syncthreads(); continue; }
-      u32 P = 2; while (P < nc) P <<= 1;
-      for (u32 t = nc + tid; t < P; t += CK_TPB) { ck[t] = ~0ULL; cp[t] = ~0ULL; }      // (pads: larger than any entry, the key of all ones included)
+      u32 P = 128; while (P < nc) P <<= 1;
+      for (u32 t = nc + tid; t < P; t += CK_TPB) { ck[t] = ck_inf(); cp[t] = ~0ULL; }      // (pads: larger than any entry, the key of all ones included)
       __syncthreads();
-      for (u32 k2 = 2; k2 <= P; k2 <<= 1) {
-        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
-          for (u32 t = tid; t < P / 2; t += CK_TPB) {
-            const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
-            const u64 ka = ck[a], kb = ck[b], pa = cp[a], pb = cp[b];
-            const bool up = (a & k2) == 0;
-            if (ck_less(kb, pb, ka, pa) == up) { ck[a] = kb; ck[b] = ka; cp[a] = pb; cp[b] = pa; }
-          }
-          __syncthreads();
-        }
-      }
+      ck_sort_block(ck, cp, P, tid);
+      SPPH(4);
       // kept runs: first entry of a run of >= thr equal keys (entries of one key come from different lists)
-      u32 mine = 0, km = 0;
+      u32 mine = 0, km = 0, rl[4] = {0, 0, 0, 0};
       const u32 pt = (P + CK_TPB - 1) / CK_TPB;      // consecutive entries per thread (<= 4)
-      for (u32 x = 0; x < pt; x++) {
+#pragma unroll
+      for (u32 x = 0; x < 4; x++) {
         const u32 i = tid * pt + x;
-        if (i < nc) {
-          const u64 k = ck[i];
-          const bool kept = (i == 0 || ck[i - 1] != k) && i + thr - 1 < nc && ck[i + thr - 1] == k;
+        if (x < pt && i < nc) {
+          const CKey k = ck[i];
+          const bool kept = (i == 0 || !ck_eq(ck[i - 1], k)) && i + thr - 1 < nc && ck_eq(ck[i + thr - 1], k);
           km |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
+          if (kept) { u32 len = 1; while (i + len < nc && ck_eq(ck[i + len], k)) len++; rl[x] = i | (len << 16); }      // (len <= lists <= 4096, i < 2048)
         }
       }
       const u32 incl = wave_incl_scan(mine, (int)lane);
@@ -779,7 +910,8 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       __syncthreads();
       u32 rank = incl - mine, nk = 0;
       for (u32 w = 0; w < CK_TPB / 64; w++) { if (w < wave) rank += wsum[w]; nk += wsum[w]; }
-      for (u32 x = 0; x < pt; x++) if ((km >> x) & 1u) runs[rank++] = tid * pt + x;
+#pragma unroll
+      for (u32 x = 0; x < 4; x++) if ((km >> x) & 1u) runs[rank++] = rl[x];
       if (tid == 0 && nk) {
         const u64 at = atomicAdd(&T.ctrl[0], (u64)nk);      // rows of the arena: behind the row keys' rows
         atomicAdd(&T.ctrl[3], (u64)nk); atomicAdd(&T.ctrl[6], (u64)nk);
@@ -788,39 +920,80 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       }
       __syncthreads();
       const u32 rb = rowbase;
+      SPPH(5);
       if (nk && rb != 0xFFFFFFFFu) {
-        for (u32 j = wave; j < nk; j += CK_TPB / 64) {      // a wave per row
-          const u32 i0 = runs[j];
-          const u64 key = ck[i0];
-          u32 len = 1; while (i0 + len < nc && ck[i0 + len] == key) len++;
+        // lanes per row: a wave for a count row (4 N bytes); 16 for a PA row (N / 8 bytes), 8 when that is at most 128 bytes
+        const u32 SG = MODE == 0 ? 64u : row_bytes <= 128u ? 8u : 16u;
+        const u32 sg = tid / SG, sl = tid % SG;      // my lane group, my lane in it
+        for (u32 j = sg; j < nk; j += CK_TPB / SG) {      // a lane group per row
+          const u32 i0 = runs[j] & 0xFFFFu, len = runs[j] >> 16;
+          const CKey key = ck[i0];
           u8* const row = T.out + (u64)(rb + j) * row_bytes;
+          u32 kw4[4] = {0, 0, 0, 0};
+          ck_store(kw4, key);                      // the key's dwords (2 or 4 of them)
+          auto kword = [&](u32 w) -> u32 { return w == 0 ? kw4[0] : w == 1 ? kw4[1] : w == 2 ? kw4[2] : kw4[3]; };
+          // a PA row starts at any byte (rows are row_bytes apart): the aligned dwords inside the row are stored whole, each taken
+          // from two words of the row as word(w) gives them, the <= 3 bytes before and after them one by one
+          auto put_bytes = [&](auto&& word) {
+            const u32 head = (4u - (u32)((uintptr_t)row & 3u)) & 3u;
+            const u32 nd = (row_bytes - head) / 4, tail0 = head + 4 * nd;
+            if (sl < head) row[sl] = (u8)(word(0) >> (sl * 8));
+            for (u32 t = sl; t < nd; t += SG) {
+              const u32 off = head + 4 * t, w = off >> 2;
+              const u64 two = (u64)word(w) | ((u64)word(w + 1) << 32);
+              reinterpret_cast<u32*>(row + off)[0] = (u32)(two >> ((off & 3u) * 8));
+            }
+            if (sl < row_bytes - tail0) { const u32 t = tail0 + sl; row[t] = (u8)(word(t >> 2) >> ((t & 3u) * 8)); }
+          };
+          if (len == 1) {
+            // the usual row here: a key one list holds (a private k-mer) -- every lane knows the whole row, no staging
+            const u64 pl = cp[i0];
+            const u32 li = (u32)(pl >> 32), cnt = (u32)pl;
+            if (MODE == 0) {
+              if ((row_bytes & 7u) == 0) {
+                u64* const r8 = reinterpret_cast<u64*>(row);
+                for (u32 t = sl; t < row_bytes / 8; t += SG)
+                  r8[t] = t < (u32)KW ? ((u64)kword(2 * t) | ((u64)kword(2 * t + 1) << 32)) : (t - KW == (li >> 1) ? (u64)cnt << ((li & 1u) * 32) : 0ULL);
+              } else {
+                u32* const r4 = reinterpret_cast<u32*>(row);
+                for (u32 t = sl; t < row_bytes / 4; t += SG) r4[t] = t < 2u * KW ? kword(t) : (t - 2u * KW == li ? cnt : 0u);
+              }
+            } else {
+              put_bytes([&](u32 w) -> u32 { return w < 2u * KW ? kword(w) : (w - 2u * KW == (li >> 5) ? 1u << (li & 31u) : 0u); });
+            }
+            continue;
+          }
           if (MODE == 0) {
-            // row = key + N counts: 8-byte stores (rows start at multiples of 8: row_bytes = 8 + 4N with N even, else 4-byte ones)
+            // row = key + N counts: 8-byte stores (rows start at multiples of 8 when row_bytes is one: N even), else 4-byte ones
             if ((row_bytes & 7u) == 0) {
               u64* const r8 = reinterpret_cast<u64*>(row);
-              for (u32 t = lane; t < row_bytes / 8; t += 64) r8[t] = t == 0 ? key : 0ULL;
+              for (u32 t = sl; t < row_bytes / 8; t += SG) r8[t] = t < (u32)KW ? ((u64)kword(2 * t) | ((u64)kword(2 * t + 1) << 32)) : 0ULL;
             } else {
               u32* const r4 = reinterpret_cast<u32*>(row);
-              for (u32 t = lane; t < row_bytes / 4; t += 64) r4[t] = t == 0 ? (u32)key : t == 1 ? (u32)(key >> 32) : 0u;
+              for (u32 t = sl; t < row_bytes / 4; t += SG) r4[t] = t < 2u * KW ? kword(t) : 0u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            for (u32 e = lane; e < len; e += 64) { const u64 pl = cp[i0 + e]; reinterpret_cast<u32*>(row + 8)[(u32)(pl >> 32)] = (u32)pl; }
+            for (u32 e = sl; e < len; e += SG) { const u64 pl = cp[i0 + e]; reinterpret_cast<u32*>(row + KW * 8)[(u32)(pl >> 32)] = (u32)pl; }
           } else {
-            u32* const pr = parow + wave * 136;
-            const u32 nby = row_bytes - 8, nw = (nby + 3) / 4;
-            for (u32 t = lane; t < nw + 2; t += 64) pr[t] = t == 0 ? (u32)key : t == 1 ? (u32)(key >> 32) : 0u;
+            u32* const pr = parow + sg * (SG == 8u ? 40u : 136u);
+            const u32 nby = row_bytes - KW * 8, nw = (nby + 3) / 4;
+            for (u32 t = sl; t < nw + 2 * KW + 1; t += SG) pr[t] = t < 2u * KW ? kword(t) : 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            for (u32 e = lane; e < len; e += 64) { const u32 li = (u32)(cp[i0 + e] >> 32); atomicOr(&pr[2 + (li >> 5)], 1u << (li & 31u)); }
+            for (u32 e = sl; e < len; e += SG) { const u32 li = (u32)(cp[i0 + e] >> 32); atomicOr(&pr[2 * KW + (li >> 5)], 1u << (li & 31u)); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            for (u32 t = lane; t < row_bytes; t += 64) row[t] = (u8)(pr[t >> 2] >> ((t & 3u) * 8));
+            put_bytes([&](u32 w) -> u32 { return pr[w]; });
           }
         }
       }
       __syncthreads();
+      SPPH(6);
     }
     if (flag) break;
   }
   __syncthreads();
+#ifdef KMX_PHASE_PROF
+  if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&kmx_sparse_prof[i], (u64)spt[i]);
+#endif
   if (tid == 0 && flag) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
 }
 
@@ -846,14 +1019,14 @@ void k_cols_offsets(const ColsDev* __restrict__ cols, u32 task, u64* __restrict_
 }
 
 constexpr int GA_TPB = 256;
-constexpr int GA_KEYS = 4096;      // keys of a group held in LDS (more: ranks come from global memory)
+constexpr int GA_KEYS = 4096 / KW;      // keys of a group held in LDS (more: ranks come from global memory)
 __global__ __launch_bounds__(GA_TPB)
 void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, u32 task, const u64* __restrict__ goff, u8* __restrict__ body)
 {
   const TaskDev& T = tasks[task];
   const ColsDev& C = cols[task];
   const SpDir* dir = reinterpret_cast<const SpDir*>(C.spdir) + (u64)blockIdx.x * CK_NPASS;
-  __shared__ u64 keys[GA_KEYS];
+  __shared__ CKey keys[GA_KEYS];
   __shared__ u32 lo[CK_NPASS + 2];      // list l = keys [lo[l], lo[l + 1]): 0 the row keys, 1.. the passes
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row_bytes = T.row_bytes;
   if (tid == 0) { u32 a = 0; lo[0] = 0; a += dir[0].dense_n; lo[1] = a; for (int p = 0; p < CK_NPASS; p++) { a += dir[p].n; lo[2 + p] = a; } }
@@ -866,17 +1039,17 @@ void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     int p = 0; while (i >= lo[2 + p]) p++;
     return T.out + (u64)(dir[p].base + (i - lo[1 + p])) * row_bytes;
   };
-  auto key_at = [&](u32 i) -> u64 { return i < (u32)GA_KEYS ? keys[i] : load_key<1>(src_row(i)).w[0]; };
-  for (u32 i = tid; i < min(n, (u32)GA_KEYS); i += GA_TPB) keys[i] = i < dn ? C.skel[d0 + i] : load_key<1>(src_row(i)).w[0];
+  auto key_at = [&](u32 i) -> CKey { return i < (u32)GA_KEYS ? keys[i] : ck_load(src_row(i)); };
+  for (u32 i = tid; i < min(n, (u32)GA_KEYS); i += GA_TPB) keys[i] = i < dn ? reinterpret_cast<const CKey*>(C.skel)[d0 + i] : ck_load(src_row(i));
   __syncthreads();
   u8* const dst0 = body + goff[blockIdx.x] * row_bytes;
   for (u32 i = wave; i < n; i += GA_TPB / 64) {      // a wave per row: its rank = keys below it in every list
-    const u64 k = key_at(i);
+    const CKey k = key_at(i);
     u32 rank = 0;
     for (int l = 0; l <= CK_NPASS; l++) {
       u32 a = lo[l], b = lo[l + 1];
       if (i >= a && i < b) { rank += i - a; continue; }
-      while (a < b) { const u32 m = (a + b) >> 1; if (key_at(m) < k) a = m + 1; else b = m; }
+      while (a < b) { const u32 m = (a + b) >> 1; if (ck_lt(key_at(m), k)) a = m + 1; else b = m; }
       rank += a - lo[l];
     }
     const u8* s = src_row(i);
@@ -903,6 +1076,12 @@ void cols_phase_prof_dump()
   for (int i = 0; i < 6; i++) fprintf(stderr, "[cols] %-12s %6.2f%%  %llu\n", nm[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
   memset(h, 0, sizeof(h));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_prof), h, sizeof(h));
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_sparse_prof), sizeof(h)) != hipSuccess) return;
+  tot = 0; for (int i = 0; i < 8; i++) tot += h[i];
+  static const char* sn[8] = {"group entries", "zero maps", "mark twice", "candidates", "sort", "runs + claim", "rows", "-"};
+  for (int i = 0; i < 7; i++) fprintf(stderr, "[sparse] %-14s %6.2f%%  %llu\n", sn[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
+  memset(h, 0, sizeof(h));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_sparse_prof), h, sizeof(h));
 }
 #endif
 
@@ -912,7 +1091,7 @@ u32 cols_halves() { return CL_HALVES; }
 u32 cols_wgs_per_cu() { return CL_WGS; }
 u32 cols_block_lists() { return CL_NB; }
 u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }      // (sized for count rows; PA rows need less)
-u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW * 2; }      // (u64 words: two per entry)
+u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW * EW; }      // (u64 words: key + payload per entry)
 u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW; }
 
 u32 cols_skel_cap() { return SK_CAP; }
@@ -959,4 +1138,19 @@ hipError_t launch_cols_gather(const TaskDev* tasks, const ColsDev* cols, u32 tas
   return hipGetLastError();
 }
 
+static const ColsOps g_ops = {cols_lds_bytes, cols_block_lists, cols_wgs_per_cu, cols_tile_rows, cols_scratch_keys, cols_scratch_counts, cols_skel_cap,
+                              launch_cols_skel, launch_cols_prep, launch_merge_cols, launch_cols_sparse, cols_dir_bytes, cols_groups, launch_cols_offsets,
+                              launch_cols_gather, cols_dbg_dump,
+#ifdef KMX_PHASE_PROF
+                              cols_phase_prof_dump,
+#else
+                              nullptr,
+#endif
+                              (u32)KMX_CL_KW};
+}  // namespace CLNS
+#if KMX_CL_KW == 1
+const ColsOps& cols_ops_k1() { return cols_k1::g_ops; }
+#else
+const ColsOps& cols_ops_k2() { return cols_k2::g_ops; }
+#endif
 }  // namespace kmx

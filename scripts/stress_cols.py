@@ -12,6 +12,7 @@ import orc
 if len(sys.argv) > 3 and sys.argv[3] == "auto": os.environ.pop("KMX_MERGE_KERNEL", None)      # libkmx chooses (and backs off)
 else: os.environ["KMX_MERGE_KERNEL"] = "cols"
 big = "big" in sys.argv[3:]
+KW = 2 if "kw2" in sys.argv[3:] else 1      # 128-bit keys (k >= 32): merge_cols_k2.hip
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = lib.Context(0)
@@ -25,8 +26,9 @@ for case in range(n_cases):
     rec_min = rng.choice([1, 2, 2, 2, 3, 5, 9])
     mode = rng.choice([lib.MODE_COUNT, lib.MODE_COUNT, lib.MODE_PA])
     os.environ["KMX_ITEMS_PER_SLOT"] = rng.choice(["1", "3"])
-    lists = synth_lists(rng.randrange(1 << 30), N, pool, p, priv, kw=1, count_max=rng.choice([2, 5, 50]), ragged=rng.random() < 0.2)
-    if rng.random() < 0.3:      # a list with a long run of keys nobody else has
+    lists = synth_lists(rng.randrange(1 << 30), N, pool, p, priv, kw=KW, key_bits=62 if KW == 1 else rng.choice([66, 72, 126]),
+                        count_max=rng.choice([2, 5, 50]), ragged=rng.random() < 0.2)
+    if KW == 1 and rng.random() < 0.3:      # a list with a long run of keys nobody else has
         i = rng.randrange(N); k, c = lists[i]
         if len(k):
             lo = int(k[len(k) // 2, 0]); run = (np.arange(1, 400, dtype=np.uint64) + np.uint64(lo)).reshape(-1, 1)
@@ -35,8 +37,8 @@ for case in range(n_cases):
             o = np.argsort(k2[:, 0]); lists[i] = (np.ascontiguousarray(k2[o]), np.ascontiguousarray(c2[o]))
     soft = [rng.choice([1, 1, 2, 3]) for _ in range(N)]
     print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} mode={mode} ...", flush=True)
-    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, soft, rec_min, 0, mode)
-    body, rows, stats = ctx.merge(lists, 1, soft, rec_min, 0, mode)
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], KW, soft, rec_min, 0, mode)
+    body, rows, stats = ctx.merge(lists, KW, soft, rec_min, 0, mode)
     ok = rows == er and body == eb and np.array_equal(stats, es)
     print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} mode={mode} rows={rows} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:

@@ -322,8 +322,8 @@ def test_partial_handback_in_a_batch(monkeypatch):
 
 def test_cols_kept_key_outside_the_row_keys():
     """k_merge_cols takes its row keys from a merge of 8 of the lists.  A key none of those 8 has, but two other lists
-    in DIFFERENT column blocks do, reaches recurrence-min 2: only k_cols_check (which counts the set-aside records
-    across the blocks) can see it, and the task must come back complete through the next kernel."""
+    in DIFFERENT column blocks do, reaches recurrence-min 2: only k_cols_sparse (which brings the set-aside records
+    of all blocks together) can see it, and the row must be in the result."""
     from kmtricks_amd import lib
     if os.environ.get("KMX_MERGE_KERNEL") != "cols":
         pytest.skip("column-blocked kernel only")
@@ -559,6 +559,42 @@ def test_cols_randomised_stress():
     env = dict(os.environ); env.pop("KMX_MERGE_KERNEL", None); env.pop("KMX_ITEMS_PER_SLOT", None)
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_cols.py"), "30", "23"], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "all 30 cases equal the oracle" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_cols_128bit_keys_randomised_stress():
+    """scripts/stress_cols.py ... kw2: 25 random cohorts of 128-bit keys (k >= 32; key widths 66, 72 and 126 bits, so that
+    both the low-word tie-break and the high word decide) through merge_cols_k2.hip and its hand-back chain."""
+    import subprocess, sys
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("one run is enough")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("KMX_MERGE_KERNEL", None); env.pop("KMX_ITEMS_PER_SLOT", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_cols.py"), "25", "5", "cols", "kw2"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "all 25 cases equal the oracle" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("mode,rec_min", [(orc.MODE_COUNT, 2), (orc.MODE_PA, 1), (orc.MODE_PA, 3)])
+def test_cols_128bit_keys_cohort(ctx, mode, rec_min):
+    """a cohort of 300 samples with k = 63 (BASELINE configs[4]'s shape): the column-blocked kernel runs it (no hand-back)
+    and every row equals the oracle's"""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("cols only")
+    dev = torch.device("cuda", 0)
+    n = 300
+    lists = synth_lists(4242, n, 12000, 0.97, 100, kw=2, key_bits=126)
+    recs = [lib.pack_records(k, c, 2) for k, c in lists]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+    dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+    task = dict(lists=[(dt.data_ptr() + 20 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(n)], key_words=2,
+                soft_min=[1] * n, rec_min=rec_min, share_min=0, mode=mode)
+    torch.cuda.synchronize()
+    res = ctx.merge_dev([task]); res.wait()
+    assert res.kernel() == "k_merge_cols"
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 2, [1] * n, rec_min, 0, mode)
+    assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
+    res.free()
 
 
 def test_batch_of_tasks_with_different_list_counts(monkeypatch):
