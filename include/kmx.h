@@ -240,6 +240,18 @@ int kmx_count_reads(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, ui
                     uint64_t** keys, uint32_t** counts, uint64_t* n_out, uint64_t* out_kmers,
                     uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info, kmx_superk_stats* stats);
 
+/* The abundance histogram of a sample (`--hist`): the reference's KHist (histogram.hpp:35-68) is fed EVERY distinct k-mer /
+ * hash of the sample with its count, before the hard-min filter (count_processor.hpp:61, 135), one clone per partition,
+ * summed (histogram.hpp:113-136).  kmx_hist_reset zeroes the context's device histogram and turns accumulation on: every
+ * kmx_count_kmer / _hash / _batch / _reads call after it adds its distinct keys (on the device, where the run lengths are).
+ * kmx_hist_read waits for them and fills uniq_bins / total_bins (upper - lower + 1 entries each: keys with count c, and c times
+ * that), oob[4] = {keys below lower, keys above upper, the sums of their counts: lower, upper} and sums[2] = {distinct keys,
+ * sum of counts} -- the fields of HistFileHeader + the two vectors of a .hist file (io/hist_file.hpp:30-116).
+ * lower <= upper <= 255 (the reference always builds KHist(id, k, 1, 255): task_scheduler.hpp:103).  kmx_hist_off stops it. */
+int kmx_hist_reset(kmx_ctx* ctx);
+int kmx_hist_read(kmx_ctx* ctx, uint32_t lower, uint32_t upper, uint64_t* uniq_bins, uint64_t* total_bins, uint64_t* oob, uint64_t* sums);
+int kmx_hist_off(kmx_ctx* ctx);
+
 void kmx_free(void* p);
 
 #ifdef __cplusplus

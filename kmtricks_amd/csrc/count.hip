@@ -197,6 +197,59 @@ static int parse_records(const uint8_t* s, uint64_t len, uint32_t k, std::vector
   return 0;
 }
 
+// abundance histogram of run counts (the library-sort paths; k_cs_sort adds its own runs): see kmx_ctx::d_hist
+__global__ __launch_bounds__(256) void k_hist_runs(const u32* __restrict__ cnt, u32 n, unsigned long long* __restrict__ hist)
+{
+  __shared__ u32 hh[257];
+  __shared__ unsigned long long big;
+  for (u32 i = threadIdx.x; i < 257; i += 256) hh[i] = 0;
+  if (threadIdx.x == 0) big = 0;
+  __syncthreads();
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const u32 c = cnt[i];
+    if (c <= 255u) atomicAdd(&hh[c], 1u); else { atomicAdd(&hh[256], 1u); atomicAdd(&big, (unsigned long long)c); }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < 257; i += 256) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
+  if (threadIdx.x == 0 && big) atomicAdd(&hist[257], big);
+}
+static void hist_runs(kmx_ctx* ctx, const u32* d_cnt, u32 runs)
+{
+  if (!ctx->hist_on || !runs) return;
+  hipLaunchKernelGGL(k_hist_runs, dim3(std::min<u32>((runs + 255) / 256, 1024u)), dim3(256), 0, ctx->stream, d_cnt, runs, ctx->d_hist);
+}
+
+extern "C" int kmx_hist_reset(kmx_ctx* ctx)
+{
+  if (!ctx) return KMX_E_INVAL;
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->d_hist) KMX_HIP(ctx, hipMalloc((void**)&ctx->d_hist, 258 * 8));
+  KMX_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, 258 * 8, ctx->stream));
+  ctx->hist_on = true;
+  return KMX_OK;
+}
+extern "C" int kmx_hist_off(kmx_ctx* ctx) { if (!ctx) return KMX_E_INVAL; ctx->hist_on = false; return KMX_OK; }
+extern "C" int kmx_hist_read(kmx_ctx* ctx, uint32_t lower, uint32_t upper, uint64_t* uniq_bins, uint64_t* total_bins, uint64_t* oob, uint64_t* sums)
+{
+  if (!ctx || !uniq_bins || !total_bins || !oob || !sums) return KMX_E_INVAL;
+  if (!ctx->d_hist) return ctx->fail(KMX_E_INVAL, "kmx_hist_read: no histogram (kmx_hist_reset first)");
+  if (upper > 255 || lower > upper) return ctx->fail(KMX_E_INVAL, "kmx_hist_read: bounds must satisfy lower <= upper <= 255");
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long h[258];
+  KMX_HIP(ctx, hipMemcpyAsync(h, ctx->d_hist, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t i = 0; i <= upper - lower; i++) uniq_bins[i] = total_bins[i] = 0;
+  oob[0] = oob[1] = oob[2] = oob[3] = 0; sums[0] = sums[1] = 0;
+  for (uint32_t c = 0; c <= 255; c++) {      // KHist::inc (histogram.hpp:48-68) over h[c] keys of count c
+    sums[0] += h[c]; sums[1] += (uint64_t)c * h[c];
+    if (c < lower) { oob[0] += h[c]; oob[2] += (uint64_t)c * h[c]; }
+    else if (c > upper) { oob[1] += h[c]; oob[3] += (uint64_t)c * h[c]; }
+    else { uniq_bins[c - lower] = h[c]; total_bins[c - lower] = (uint64_t)c * h[c]; }
+  }
+  sums[0] += h[256]; sums[1] += h[257]; oob[1] += h[256]; oob[3] += h[257];
+  return KMX_OK;
+}
+
 template <typename KeyT>
 static int sort_rle_filter(kmx_ctx* ctx, KeyT* d_keys, u64 n, u32 hard_min, void** out_keys, uint32_t** out_counts, uint64_t* n_out)
 {
@@ -226,6 +279,7 @@ static int sort_rle_filter(kmx_ctx* ctx, KeyT* d_keys, u64 n, u32 hard_min, void
   if ((e = hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   KeyT* res_k = d_uniq; u32* res_c = d_cnt; u32 kept = runs;
+  hist_runs(ctx, d_cnt, runs);
   if (hard_min > 1 && runs) {
     hipLaunchKernelGGL(k_keep_flags, dim3((runs + 255) / 256), dim3(256), 0, st, d_cnt, runs, hard_min, d_flags);
     t = tmax;
@@ -394,7 +448,8 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   if ((e = hipMemcpyAsync(d_cur, d_boff, 4 * (size_t)TB, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e, "count sort cursors");
   hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cur, d_bkeys);
   KeyT* d_tk = d_keys;                     // (the grouped keys are dead behind the scatter: their room takes the kept pairs)
-  hipLaunchKernelGGL((k_cs_sort<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_bkeys, d_boff, hard_min, d_tk, d_tc, d_nkept);
+  hipLaunchKernelGGL((k_cs_sort<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_bkeys, d_boff, hard_min, d_tk, d_tc, d_nkept,
+                     ctx->hist_on ? ctx->d_hist : (unsigned long long*)nullptr);
   hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_nkept, TB, d_koff);
   std::vector<u32> koff((size_t)TB + 1);
   if ((e = hipMemcpyAsync(koff.data(), d_koff, 4 * ((size_t)TB + 1), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort kept");
@@ -469,6 +524,7 @@ static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kp
   u32 runs = 0;
   if ((e = hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   clk.mark("rle");
+  hist_runs(ctx, d_cnt, runs);
   // per run: partition + keep flag; kept run indices regrouped by partition
   u32* d_start = (u32*)ctx->dalloc(((size_t)runs + 1) * 4);
   u16* d_rpart = (u16*)ctx->dalloc((size_t)runs * 2 + 2), *d_kp = (u16*)ctx->dalloc((size_t)runs * 2 + 2), *d_kp2 = (u16*)ctx->dalloc((size_t)runs * 2 + 2);

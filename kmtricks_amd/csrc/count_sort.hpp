@@ -117,15 +117,18 @@ void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out)
 // a workgroup per bucket: sort in LDS, run-length count, hard-min.  kept pairs -> tk / tc at the bucket's offset, their number -> nkept
 template <typename K>
 __global__ __launch_bounds__(CS_TPB)
-void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept)
+void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
+               unsigned long long* __restrict__ hist)
 {
   constexpr int CAP = CsCap<K>::cap;
   __shared__ K sk[CAP];
   __shared__ u32 starts[CAP];      // positions of the run starts, in order
   __shared__ u32 wsum[CS_TPB / 64];
+  __shared__ u32 hh[258];          // abundance histogram of the bucket's runs (hist != nullptr): see kmx_ctx::d_hist
   const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 o = boff[b], n = boff[b + 1] - o;
   if (n == 0) { if (tid == 0) nkept[b] = 0; return; }
+  if (hist) for (u32 i = tid; i < 258; i += CS_TPB) hh[i] = 0;
   u32 Pn = 2; while (Pn < n) Pn <<= 1;
   for (u32 i = tid; i < Pn; i += CS_TPB) sk[i] = i < n ? bkeys[o + i] : cs_max<K>();
   __syncthreads();
@@ -159,7 +162,11 @@ void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 ha
   const u32 per = (nruns + CS_TPB - 1) / CS_TPB;      // consecutive runs per thread
   for (u32 x = 0; x < per; x++) {
     const u32 j = tid * per + x;
-    if (j < nruns) { const u32 len = (j + 1 < nruns ? starts[j + 1] : n) - starts[j]; if (len >= hard_min) kept++; }
+    if (j < nruns) {
+      const u32 len = (j + 1 < nruns ? starts[j + 1] : n) - starts[j];
+      if (len >= hard_min) kept++;
+      if (hist) { if (len <= 255u) atomicAdd(&hh[len], 1u); else { atomicAdd(&hh[256], 1u); atomicAdd(&hh[257], len); } }      // (a bucket holds < 2^32 keys)
+    }
   }
   (void)km;
   const u32 incl2 = wave_incl_scan(kept, (int)lane);
@@ -176,6 +183,9 @@ void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 ha
     }
   }
   if (tid == 0) nkept[b] = tot;
+  if (hist) {      // (the barriers above separate the histogram's atomics from these reads)
+    for (u32 i = tid; i < 258; i += CS_TPB) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
+  }
 }
 
 template <typename K>

@@ -85,6 +85,10 @@ struct kmx_ctx {
   // a cohort whose samples share their private k-mers pairwise keeps several times more rows than a list is long, and an arena
   // sized for 2 x the longest list would make every batch run twice)
   double rows_per_longest = 0.0;
+  // abundance histogram (kmx_hist_reset / kmx_hist_read): distinct keys per count 0..255, [256] = keys counted more than 255
+  // times, [257] = the sum of those counts.  Every count call adds to it while it is on.
+  unsigned long long* d_hist = nullptr;
+  bool hist_on = false;
 
   void* dalloc(size_t bytes);
   void dfree(void* p);

@@ -142,6 +142,32 @@ inline std::vector<uint8_t> read_kmer_records(const std::string& path, uint32_t*
 }
 
 // ---- counts/partition_<p>/<id>.hash (io/hash_file.hpp:31-38, 91-131): blocks [u64 n][n x u64][n x count] ----
+// histograms/<id>.hist (io/hist_file.hpp:30-116): base header, then magic, k, sample index, lower, upper, unique, total,
+// oob lower total, oob lower unique, oob upper total, oob upper unique (the order HistFileHeader::serialize writes them),
+// then the unique bins and the total bins (u64 each, upper - lower + 1 of them).  oob = {lower unique, upper unique, lower total, upper total}.
+constexpr uint64_t MAGIC_HIST = 0x747369686bULL;      // "khist" (io/io_common.hpp:58)
+inline void write_hist_file(const std::string& path, uint32_t k, uint32_t idx, uint64_t lower, uint64_t upper,
+                            const uint64_t* uniq_bins, const uint64_t* total_bins, const uint64_t* oob, const uint64_t* sums) {
+  Out o(path); o.base_header(false);
+  o.put<uint64_t>(MAGIC_HIST); o.put<uint32_t>(k); o.put<uint32_t>(idx); o.put<uint64_t>(lower); o.put<uint64_t>(upper);
+  o.put<uint64_t>(sums[0]); o.put<uint64_t>(sums[1]); o.put<uint64_t>(oob[2]); o.put<uint64_t>(oob[0]); o.put<uint64_t>(oob[3]); o.put<uint64_t>(oob[1]);
+  o.begin_body();
+  o.raw(uniq_bins, (size_t)(upper - lower + 1) * 8); o.raw(total_bins, (size_t)(upper - lower + 1) * 8);
+  o.close();
+}
+struct HistFile { uint32_t k = 0, idx = 0; uint64_t lower = 0, upper = 0, uniq = 0, total = 0, oob_ln = 0, oob_lu = 0, oob_un = 0, oob_uu = 0; std::vector<uint64_t> u, n; };
+inline HistFile read_hist_file(const std::string& path) {
+  std::vector<uint8_t> raw = slurp(path);
+  std::vector<uint8_t> body = body_of(raw, 93, MAGIC_HIST, path);
+  HistFile h; h.k = rd<uint32_t>(&raw[21]); h.idx = rd<uint32_t>(&raw[25]); h.lower = rd<uint64_t>(&raw[29]); h.upper = rd<uint64_t>(&raw[37]);
+  h.uniq = rd<uint64_t>(&raw[45]); h.total = rd<uint64_t>(&raw[53]); h.oob_ln = rd<uint64_t>(&raw[61]); h.oob_lu = rd<uint64_t>(&raw[69]);
+  h.oob_un = rd<uint64_t>(&raw[77]); h.oob_uu = rd<uint64_t>(&raw[85]);
+  if (h.upper < h.lower || body.size() != (h.upper - h.lower + 1) * 16) throw IoError("Invalid file format: " + path);
+  const size_t nb = (size_t)(h.upper - h.lower + 1);
+  h.u.resize(nb); h.n.resize(nb);
+  memcpy(h.u.data(), body.data(), nb * 8); memcpy(h.n.data(), body.data() + nb * 8, nb * 8);
+  return h;
+}
 inline void write_hash_file(const std::string& path, uint32_t id, uint32_t part, const uint64_t* h, const uint32_t* c, uint64_t n) {
   Out o(path); o.base_header();
   o.put<uint64_t>(MAGIC_HASH); o.put<uint32_t>(4); o.put<uint32_t>(id); o.put<uint32_t>(part);

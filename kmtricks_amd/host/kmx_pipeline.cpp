@@ -47,7 +47,7 @@ struct Opt {
   uint64_t bloom = 10000000, merge_batch_mb = 4096;
   double restrict_to = 1.0, focus = 0.5;
   std::vector<uint32_t> restrict_list;
-  bool static_repart = false, keep_tmp = false, cpr = false, skip_pinfo = false;
+  bool static_repart = false, keep_tmp = false, cpr = false, skip_pinfo = false, hist = false;
 };
 
 // (a worker thread cannot unwind the others: print and leave without running destructors under them)
@@ -114,6 +114,7 @@ static Opt parse_cli(int argc, char** argv)
     else if (a == "--focus") { o.focus = real(i); if (o.focus < 0.0 || o.focus > 1.0) die("--focus must be in [0.0, 1.0]"); }
     else if (a == "--keep-tmp") o.keep_tmp = true;
     else if (a == "--cpr") o.cpr = true;
+    else if (a == "--hist") o.hist = true;                      // histograms/<id>.hist (src/cli.cpp:207-209)
     else if (a == "--plugin") o.plugin = need(i);
     else if (a == "--plugin-config") o.plugin_config = need(i);
     else if (a == "-t" || a == "--threads") o.threads = num(i);
@@ -203,8 +204,8 @@ int run(int argc, char** argv)
   { std::ofstream f(root + "/options.txt");   // cmd/all.hpp:85-125: `kmtricks combine` re-parses mode= from this line
     f << "Options: dir=" << root << ", verbosity=info, nb_threads=" << o.threads << ", fof=" << o.fof << ", kmer_size=" << o.k << ", c_ab_min=" << o.hard_min
       << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", m_ab_min_path=, m_ab_min_f=0, m_ab_float=0, save_if=" << o.share_min << ", minim_size=" << o.msize
-      << ", minim_type=0, repart_type=0, nb_parts=" << P << ", bloom_size=" << o.bloom << ", keep_tmp=" << o.keep_tmp << ", lz4=" << o.cpr << ", kff=0, hist=0, static_repart=" << o.static_repart
-      << ", focus=" << o.focus << ", restrict_to=" << o.restrict_to << ", bwidth=" << o.bitw << ", mode=" << o.mode.substr(0, o.mode.find(':')) << ":" << what << ":bin"
+      << ", minim_type=0, repart_type=0, nb_parts=" << P << ", bloom_size=" << o.bloom << ", keep_tmp=" << o.keep_tmp << ", lz4=" << o.cpr << ", kff=0, hist=" << o.hist << ", static_repart=" << o.static_repart
+      << ", focus=" << o.focus << ", restrict_to=" << o.restrict_to << ", bwidth=" << o.bitw << ", bam_exclude_refs=, bam_include_flags=0, bam_exclude_flags=0, mode=" << what      // (mode_to_str: count | pa | bf | bfc; cmd/all.hpp:119)
       << ", format=bin, bf_format=" << o.bf_format << ", count_format=" << (hash_mode ? "hash" : "kmer") << ", until=" << o.until << "\n"; }
   for (uint32_t p = 0; p < P; p++) fs::create_directories(root + "/counts/partition_" + std::to_string(p));
   HashWindow hw(o.bloom, P, o.msize);
@@ -302,6 +303,16 @@ int run(int argc, char** argv)
     }
   }
   std::vector<uint8_t> selected(P, 0); for (uint32_t p : plist) selected[p] = 1;
+  const bool restricted = plist.size() != P;
+  // --hist: the sample's abundance histogram comes off the device after its count calls (kmx_hist_reset / kmx_hist_read) and goes
+  // to histograms/<id>.hist as KHist(i, k, 1, 255) leaves it (task_scheduler.hpp:54-57, 103)
+  auto save_hist = [&](kmx_ctx* c, uint32_t si) {
+    auto ub = std::make_shared<std::vector<uint64_t>>(255), tb = std::make_shared<std::vector<uint64_t>>(255), ex = std::make_shared<std::vector<uint64_t>>(6);
+    chk(c, kmx_hist_read(c, 1, 255, ub->data(), tb->data(), ex->data(), ex->data() + 4), "kmx_hist_read");
+    chk(c, kmx_hist_off(c), "kmx_hist_off");
+    const std::string path = root + "/histograms/" + samples[si].id + ".hist"; const uint32_t k = o.k;
+    return pool.submit([=]() { try { write_hist_file(path, k, si, 1, 255, ub->data(), tb->data(), ex->data(), ex->data() + 4); } catch (const std::exception& e) { die(e.what()); } });
+  };
 
   auto report = [&]() {
     fprintf(stderr, "[kmx pipeline] {\"samples\": %u, \"partitions\": %u, \"gpus\": %u, \"threads\": %u, \"bases\": %llu, \"kmers\": %llu, \"merge_records\": %llu, "
@@ -371,7 +382,7 @@ int run(int argc, char** argv)
       while (done < per_gpu[g]) {
         ReadBatch b;
         if (!chan[g]->pop(b)) break;
-        if (b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk") {
+        if (b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk" && !(o.hist && restricted)) {      // (the fused call counts every partition: not what a histogram of the selected ones needs)
           // ---- the whole sample in one batch: split + count in one call, the super-k-mer streams stay in HBM (kmx_count_reads) ----
           const auto t = clk::now();
           const uint32_t si = b.si; const Sample& smp = samples[si];
@@ -382,9 +393,11 @@ int run(int argc, char** argv)
           auto pc = std::make_shared<std::vector<uint64_t>>(), ms = std::make_shared<std::vector<uint64_t>>(), mk = std::make_shared<std::vector<uint64_t>>();
           kmx_superk_stats ks{};
           if (!o.skip_pinfo) { pc->assign((size_t)P * KMX_PINFO_STRIDE, 0); ms->assign(nm, 0); mk->assign(nm, 0); ks.part_counters = pc->data(); ks.minim_superks = ms->data(); ks.minim_kmers = mk->data(); }
+          if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
           chk(c, kmx_count_reads(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, smp.hard_min,
                                  keys.data(), cnts.data(), cnt.data(), nkp.data(), o.keep_tmp ? ob.data() : nullptr, o.keep_tmp ? ol.data() : nullptr, info.data(),
                                  o.skip_pinfo ? nullptr : &ks), "kmx_count_reads");
+          if (o.hist) writes.push_back(save_hist(c, si));
           uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
           st.kmers += nkt;
           { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string(selected[p] ? nkp[p] : 0); s2 += "\n"; }
@@ -493,6 +506,7 @@ int run(int argc, char** argv)
             grp.clear(); gk = 0; gb = 0;
           };
           const uint64_t LIM = 0x7FFFFFFFULL;
+          if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
           for (uint32_t p : plist) {
             const uint64_t nkp = S.nk[p], nbp = S.streams[p].size();
             if (nkp >= 0xFFFFFF00ULL || nbp >= 0xFFFFFF00ULL) die("sample " + smp.id + ", partition " + std::to_string(p) + ": more than 2^32 k-mers in one partition; use more partitions");
@@ -500,6 +514,7 @@ int run(int argc, char** argv)
             grp.push_back(p); gk += nkp; gb += nbp;
           }
           run_group();
+          if (o.hist) writes.push_back(save_hist(c, si));
           tlog(g, "count_end", si);
           w_count += since(t);
         }
@@ -732,7 +747,7 @@ int kmx_tools_main(int argc, char** argv);      // kmx_tools.cpp: dump, aggregat
 
 int main(int argc, char** argv)
 {
-  if (argc >= 2 && (std::string(argv[1]) == "dump" || std::string(argv[1]) == "aggregate")) return kmx_tools_main(argc, argv);
+  if (argc >= 2 && (std::string(argv[1]) == "dump" || std::string(argv[1]) == "aggregate" || std::string(argv[1]) == "combine")) return kmx_tools_main(argc, argv);
   try { return run(argc, argv); }
   catch (const std::exception& e) { die(e.what()); }
 }

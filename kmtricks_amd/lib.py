@@ -84,7 +84,10 @@ _lib.kmx_count_reads.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C
                                  C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                  C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(KmxSuperkStats)]
 
-EXPORTS = ["kmx_version", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+_lib.kmx_hist_reset.argtypes = [_vp]
+_lib.kmx_hist_off.argtypes = [_vp]
+_lib.kmx_hist_read.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
+EXPORTS = ["kmx_version", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -286,6 +289,20 @@ class Context:
                 st.append(C.string_at(ob[p], ol[p]) if ol[p] else b"")
                 _lib.kmx_free(ob[p])
         return out, [int(x) for x in nk], st, np.array(list(info), dtype=np.uint64).reshape(nb_parts, 2)
+
+    def hist_reset(self):
+        """kmx_hist_reset: zero the abundance histogram; the count calls that follow add their distinct keys to it"""
+        self._check(_lib.kmx_hist_reset(self._h), "kmx_hist_reset")
+
+    def hist_off(self):
+        self._check(_lib.kmx_hist_off(self._h), "kmx_hist_off")
+
+    def hist_read(self, lower=1, upper=255):
+        """kmx_hist_read -> dict(unique, total (bins lower..upper), oob [lower unique, upper unique, lower total, upper total], sums [unique, total])"""
+        n = upper - lower + 1
+        h = dict(unique=np.zeros(n, np.uint64), total=np.zeros(n, np.uint64), oob=np.zeros(4, np.uint64), sums=np.zeros(2, np.uint64))
+        self._check(_lib.kmx_hist_read(self._h, lower, upper, h["unique"].ctypes.data, h["total"].ctypes.data, h["oob"].ctypes.data, h["sums"].ctypes.data), "kmx_hist_read")
+        return h
 
     def superk_sample(self, reads, k, m, budget):
         """kmx_superk_sample -> (reads used, their super-k-mers, kx-mers per minimizer)"""

@@ -672,4 +672,19 @@ void orc_transpose_bits(const uint8_t* in, uint8_t* out, uint64_t nrows, uint64_
     }
 }
 
+/* ---- the abundance histogram of a sample: KHist::inc (histogram.hpp:48-68), called for every distinct k-mer / hash before
+ *      the hard-min filter (count_processor.hpp:61, 135).  uniq_bins / total_bins hold upper - lower + 1 entries;
+ *      oob = {lower unique, upper unique, lower total, upper total}; sums = {unique, total}. ---- */
+void orc_khist(const uint32_t* counts, uint64_t n, uint64_t lower, uint64_t upper, uint64_t* uniq_bins, uint64_t* total_bins,
+               uint64_t* oob, uint64_t* sums)
+{
+  for (uint64_t i = 0; i < n; i++) {
+    const uint64_t c = counts[i];
+    sums[0]++; sums[1] += c;
+    if (c < lower) { oob[0]++; oob[2] += c; }
+    else if (c > upper) { oob[1]++; oob[3] += c; }
+    else { uniq_bins[c - lower]++; total_bins[c - lower] += c; }
+  }
+}
+
 void orc_free(void* p) { free(p); }

@@ -5,7 +5,7 @@ container only, where /root/reference exists; the outputs are committed).
 What is copied is DATA: the fixture files the reference's own tests read
 (tests/data/**) and the expected values its tests assert (parsed out of the
 EXPECT_/ASSERT_ lines of tests/task_main.cpp, tests/merge_test.cpp,
-tests/repartition_test.cpp, tests/packc_test.cpp).  No reference source text
+tests/repartition_test.cpp, tests/packc_test.cpp, tests/histogram_test.cpp).  No reference source text
 is stored.
 """
 import json, os, re, shutil, struct, sys
@@ -89,12 +89,20 @@ def packc_goldens():
             "to_n_b": [[int(a), int(b), int(c)] for a, b, c in tnb]}
 
 
+def histogram_goldens():
+    """tests/histogram_test.cpp: the counts fed to KHist(0, 20, 1, 10) and the unique / total bins it asserts"""
+    src = open(f"{REF}/tests/histogram_test.cpp").read().split("TEST(histogram, clones)")[0]
+    vec = lambda name: [int(x) for x in re.search(r'std::vector<uint64_t> %s \{([^}]*)\}' % name, src).group(1).split(",")]
+    lo, hi = re.search(r'KHist hist\(0, 20, (\d+), (\d+)\)', src).groups()
+    return {"counts": vec("v"), "unique": vec("r"), "total": vec("rn"), "lower": int(lo), "upper": int(hi), "kmer_size": 20}
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not mounted; goldens are already committed")
     copy_data()
     g = {"repartition_table": repart_sparse(), "task_main": task_main_goldens(),
          "merge_test": merge_goldens(), "repartition_test": repartition_goldens(),
-         "packc_test": packc_goldens()}
+         "packc_test": packc_goldens(), "histogram_test": histogram_goldens()}
     json.dump(g, open(f"{OUT}/reference_goldens.json", "w"), indent=1, sort_keys=True)
     print("wrote", f"{OUT}/reference_goldens.json")

@@ -172,6 +172,19 @@ def count_hash(recs: bytes, k, win, part, hard_min):
     return _take(kp, n.value, np.uint64), _take(cp, n.value, np.uint32)
 
 
+_lib.orc_khist.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.orc_khist.restype = None
+
+
+def khist(counts, lower=1, upper=255, acc=None):
+    """KHist::inc over `counts` -> dict(unique, total (bins lower..upper), oob [lu, uu, ln, un], sums [unique, total]); `acc` adds to a previous result"""
+    h = acc or dict(unique=np.zeros(upper - lower + 1, np.uint64), total=np.zeros(upper - lower + 1, np.uint64),
+                    oob=np.zeros(4, np.uint64), sums=np.zeros(2, np.uint64))
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    _lib.orc_khist(c.ctypes.data, len(c), lower, upper, h["unique"].ctypes.data, h["total"].ctypes.data, h["oob"].ctypes.data, h["sums"].ctypes.data)
+    return h
+
+
 def merge_matrix(lists, kw, soft_min, rec_min, share_min, mode, lower=0, upper=0, bitw=2):
     """lists: [(keys uint64[n*kw] or [n,kw], counts uint32[n])].  -> (body bytes, rows, stats[6,N])"""
     N = len(lists)

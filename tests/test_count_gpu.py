@@ -170,6 +170,56 @@ def test_count_sort_paths(ctx, monkeypatch, path):
         assert np.array_equal(goth[p][0], ek) and np.array_equal(goth[p][1], ec)
 
 
+def _same_hist(a, b):
+    return all(np.array_equal(a[f], b[f]) for f in ("unique", "total", "oob", "sums"))
+
+
+@pytest.mark.parametrize("path", ["sample-sort", "library", "overflow"])
+def test_abundance_histogram_vs_oracle(ctx, monkeypatch, path):
+    """--hist: KHist (histogram.hpp:48-68) over every distinct k-mer / hash of a sample BEFORE the hard-min filter
+    (count_processor.hpp:61, 135), accumulated on the device by each count call while the histogram is on: per-partition
+    calls, the batched call (both sorts; 'overflow' has a k-mer counted 6000 times -> the upper out-of-bounds fields) and
+    the fused kmx_count_reads; bounds (1, 255) as the reference builds it and a narrow (2, 10)."""
+    if path == "library":
+        monkeypatch.setenv("KMX_COUNT_SORT", "library")
+    k, m, P = 31, 10, 4
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    reads = random_reads(99, 700, 150, n_rate=0.002) * 3 + random_reads(98, 300, 150)
+    if path == "overflow":
+        reads = reads + ["ACGTTGCAAGGCTTAAGCCGATTACAGGCTAAGCTTAGGCATCG"] * 6000
+    streams = [e[0] for e in orc.superk_partition(reads, k, m, lut, rep, P)]
+    W = 100003
+    for hashed in (False, True):
+        exp, exp_n = None, None
+        for p in range(P):
+            c = orc.count_hash(streams[p], k, W, p, 1)[1] if hashed else orc.count_kmer(streams[p], k, 1)[1]
+            exp = orc.khist(c, 1, 255, acc=exp); exp_n = orc.khist(c, 2, 10, acc=exp_n)
+        assert int(exp["sums"][0]) > 50_000
+        if path == "overflow" and not hashed:
+            assert int(exp["oob"][1]) >= 1 and int(exp["oob"][3]) >= 6000
+        # batched call (hard-min 3 on purpose: the histogram sees the k-mers the filter drops)
+        ctx.hist_reset()
+        ctx.count_batch(streams, k, 3, window=W if hashed else 0)
+        assert _same_hist(ctx.hist_read(1, 255), exp) and _same_hist(ctx.hist_read(2, 10), exp_n)
+        # per-partition calls add up
+        ctx.hist_reset()
+        for p in range(P):
+            if hashed: ctx.count_hash(streams[p], k, W, p, 2)
+            else: ctx.count_kmer(streams[p], k, 2)
+        assert _same_hist(ctx.hist_read(1, 255), exp)
+        # fused split + count
+        ctx.hist_reset()
+        ctx.count_reads(reads, k, m, rep, P, 2, window=W if hashed else 0)
+        assert _same_hist(ctx.hist_read(1, 255), exp)
+        # off: later calls leave it alone
+        ctx.hist_off()
+        ctx.count_batch(streams, k, 1, window=W if hashed else 0)
+        assert _same_hist(ctx.hist_read(1, 255), exp)
+    with pytest.raises(Exception):
+        ctx.hist_read(1, 256)
+
+
 @pytest.mark.parametrize("k,m,P,hard_min,hashed", [(31, 10, 8, 1, False), (31, 10, 8, 2, True), (63, 10, 32, 2, False), (21, 8, 5, 3, False), (32, 10, 16, 1, True)])
 def test_count_reads_fused_vs_oracle(ctx, k, m, P, hard_min, hashed):
     """kmx_count_reads (split + count with the streams resident in HBM) == oracle split, then oracle count of every partition;

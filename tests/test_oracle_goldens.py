@@ -184,3 +184,13 @@ def test_sampled_repartition_reproduces_the_reference_table():
     assert int(mk.sum()) == sum(G["task_main"]["superk_info_D1"][1::2]) + sum(G["task_main"]["superk_info_D2"][1::2])
     assert [int(x) for x in pin[:, 0]] == [a + b for a, b in zip(G["task_main"]["superk_info_D1"][1::2], G["task_main"]["superk_info_D2"][1::2])]
     assert np.array_equal(orc.repart_sampled(mx, 4), repart_table())
+
+
+def test_histogram_reference_vector():
+    """tests/histogram_test.cpp: KHist(0, 20, 1, 10) fed {1, 1, 3, 9, 1, 2, 2, 2, 9, 5} -> the unique / total bins it asserts, nothing out of bounds"""
+    g = G["histogram_test"]
+    h = orc.khist(g["counts"], g["lower"], g["upper"])
+    assert h["unique"].tolist() == g["unique"] and h["total"].tolist() == g["total"]
+    assert h["oob"].tolist() == [0, 0, 0, 0] and h["sums"].tolist() == [len(g["counts"]), sum(g["counts"])]
+    h2 = orc.khist([0, 11, 300], 1, 10, acc=h)      # out of bounds on both sides
+    assert h2["oob"].tolist() == [1, 2, 0, 311]

@@ -255,6 +255,43 @@ def test_cpr_and_restrict(inputs, tmp_path):
         assert open(sub / "matrices" / f"matrix_{p}.count", "rb").read() == open(plain / "matrices" / f"matrix_{p}.count", "rb").read()
 
 
+def _hist_bytes(k, idx, counts_per_partition):
+    """a .hist file as HistWriter leaves it (io/hist_file.hpp:30-116) for KHist(idx, k, 1, 255) fed the given counts"""
+    h = None
+    for c in counts_per_partition: h = orc.khist(c, 1, 255, acc=h)
+    hdr = struct.pack("<QIB", 0x736b636972746d6b, 0, 0) + struct.pack("<QIIQQQQQQQQ", 0x747369686b, k, idx, 1, 255, int(h["sums"][0]), int(h["sums"][1]),
+                                                                int(h["oob"][2]), int(h["oob"][0]), int(h["oob"][3]), int(h["oob"][1]))
+    return hdr + h["unique"].tobytes() + h["total"].tobytes(), h
+
+
+@pytest.mark.parametrize("mode", ["kmer:count:bin", "hash:count:bin"])
+def test_hist_pipeline(inputs, tmp_path, mode):
+    """--hist: histograms/<id>.hist of every sample = KHist(i, k, 1, 255) over ALL its distinct k-mers / hashes (before --hard-min
+    3), as a file and through `kmx dump`; with --restrict-to-list only the selected partitions are counted"""
+    hashed = mode.startswith("hash")
+    extra = ["--bloom-size", "1000000"] if hashed else []
+    out = run(inputs, tmp_path / "run", "--mode", mode, "--hist", "--hard-min", "3", *extra)
+    W = None
+    if hashed:
+        W = struct.unpack_from("<QQQ", open(out / "hash.info", "rb").read(), 0)[2]
+    lists = oracle_lists(hashed, W)      # hard-min 1: every distinct key
+    assert "hist=1" in open(out / "options.txt").read()
+    for si, sid in enumerate(("D1", "D2")):
+        exp, h = _hist_bytes(K, si, [lists[p][si][1] for p in range(P)])
+        assert open(out / "histograms" / f"{sid}.hist", "rb").read() == exp
+        r = subprocess.run([KMX, "dump", "--input", str(out / "histograms" / f"{sid}.hist")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == f"@LOWER=1\n@UPPER=255\n@OOB_L=0\n@OOB_U={int(h['oob'][1])}\n" + "".join(f"{c} {int(v)}\n" for c, v in zip(range(1, 256), h["unique"]))
+        assert int(h["sums"][0]) > 100
+    if not hashed:
+        sub = run(inputs, tmp_path / "sub", "--mode", mode, "--hist", "--restrict-to-list", "1,3")
+        for si, sid in enumerate(("D1", "D2")):
+            exp, _ = _hist_bytes(K, si, [lists[p][si][1] for p in (1, 3)])
+            assert open(sub / "histograms" / f"{sid}.hist", "rb").read() == exp
+    plain = run(inputs, tmp_path / "nohist", "--mode", mode, *extra)
+    assert os.listdir(plain / "histograms") == []
+
+
 def test_parti_info_file(inputs, tmp_path):
     """superkmers/<id>/PartiInfoFile (gatb PartiInfo.hpp:266-287) from the HIP split's statistics == the oracle's PartiInfo<5>"""
     out = run(inputs, tmp_path / "run", "--mode", "kmer:count:bin", "--until", "superk")

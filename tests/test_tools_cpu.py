@@ -100,3 +100,159 @@ def _mmers(s, m):
         for c in s[i:i + m]:
             v = (v << 2) | code[c]
         yield v
+
+
+# ---- kmx combine (matrix.hpp:396-886) -------------------------------------------------------------------------------------------
+import struct
+
+KM_BASE = struct.pack("<QIB", 0x736b636972746d6b, 0, 0)
+
+
+def _magics():
+    """the type magics as the shipped headers' library writes them: read back from a file `kmx` wrote would be circular, so they
+    are taken from kmx_io.hpp's constants (which the pipeline tests pin against the reference's committed files)"""
+    import re
+    src = open(os.path.join(ROOT, "kmtricks_amd", "host", "kmx_io.hpp")).read()
+    return {n.lower(): int(v, 16) for n, v in re.findall(r"MAGIC_(\w+) = (0x[0-9a-fA-F]+)ULL", src)}
+
+
+def _write_matrix(path, kind, k, ncols, sid, part, keys, data):
+    """keys: uint64[n, slots] (hash: slots = 1); data: uint32[n, ncols] counts or uint8[n, ceil(ncols / 8)] PA bytes"""
+    M = _magics()
+    slots = (k + 31) // 32
+    if kind == "count": hdr = struct.pack("<QIIIIII", M["matrix"], k, slots, 1, ncols, sid, part)
+    elif kind == "count_hash": hdr = struct.pack("<QIIII", M["matrix_hash"], 4, ncols, sid, part)
+    elif kind == "pa": hdr = struct.pack("<QIIIIII", M["pa"], k, slots, ncols, (ncols + 7) // 8, sid, part)
+    else: hdr = struct.pack("<QIIII", M["pa_hash"], ncols, (ncols + 7) // 8, sid, part)
+    with open(path, "wb") as f:
+        f.write(KM_BASE + hdr)
+        for kk, d in zip(keys, data):
+            f.write(np.ascontiguousarray(kk, dtype=np.uint64).tobytes() + np.ascontiguousarray(d).tobytes())
+
+
+def _partition_merger(files, pa):
+    """PartitionMerger::next / write loop restated (matrix.hpp:534-583, 632-680): files = [(keys as tuples most significant word
+    first, rows of column values or bits, ncols)].  -> [(key, merged columns)].  The row whose first file empties the queue is
+    not handed out."""
+    import heapq
+    pos, total = [], 0
+    for _, _, n in files: pos.append(total); total += n
+    cur = [0] * len(files)
+    heap = [(f[0][0], i) for i, f in enumerate(files) if len(f[0])]
+    heapq.heapify(heap)
+    out = []
+    def adv(i):
+        cur[i] += 1
+        if cur[i] < len(files[i][0]): heapq.heappush(heap, (files[i][0][cur[i]], i))
+    while heap:
+        row = [0] * total
+        key, i = heapq.heappop(heap)
+        for c, v in enumerate(files[i][1][cur[i]]): row[pos[i] + c] = v
+        adv(i)
+        if not heap: break
+        while heap and heap[0][0] == key:
+            _, j = heapq.heappop(heap)
+            for c, v in enumerate(files[j][1][cur[j]]): row[pos[j] + c] = v
+            adv(j)
+        out.append((key, row))
+    return out
+
+
+def _make_run(root, kind, k, P, ncols, seed, ids, hashed, shared_pool):
+    rng = np.random.default_rng(seed)
+    os.makedirs(f"{root}/matrices"); os.makedirs(f"{root}/repartition_gatb"); os.makedirs(f"{root}/config_gatb"); os.makedirs(f"{root}/counts/partition_0")
+    open(f"{root}/repartition_gatb/repartition.minimRepart", "wb").write(b"same table" * 10)
+    open(f"{root}/config_gatb/gatb.config", "wb").write(b"cfg")
+    open(f"{root}/hash.info", "wb").write(struct.pack("<QQQQQ", 1000, P, 10, 2, 10))
+    mode = "pa" if kind.startswith("pa") else "count"
+    open(f"{root}/options.txt", "w").write(f"Options: dir={root}, verbosity=info, nb_threads=1, mode={mode}, format=bin, bf_format=howdesbt, count_format={'hash' if hashed else 'kmer'}, until=all\n")
+    open(f"{root}/kmtricks.fof", "w").write("".join(f"{i}: /x/{i}.fa\n" for i in ids))
+    slots = 1 if hashed else (k + 31) // 32
+    parts = []
+    for p in range(P):
+        pool = shared_pool[p]
+        take = np.sort(rng.choice(len(pool), size=rng.integers(0, len(pool) + 1), replace=False))
+        keys = [pool[i] for i in take]
+        if mode == "count": data = [rng.integers(0, 1000, ncols, dtype=np.uint32) for _ in keys]
+        else: data = [np.packbits(rng.integers(0, 2, ncols, dtype=np.uint8), bitorder="little") for _ in keys]
+        ext = {"count": "count", "count_hash": "count_hash", "pa": "pa", "pa_hash": "pa_hash"}[kind]
+        _write_matrix(f"{root}/matrices/matrix_{p}.{ext}", kind, k, ncols, 7, p, [np.array(kk[::-1], dtype=np.uint64) for kk in keys], data)
+        parts.append((keys, data))
+    return parts
+
+
+@pytest.mark.parametrize("kind,k", [("count", 31), ("pa", 40), ("count_hash", 31), ("pa_hash", 31)])
+def test_combine_matrices_of_three_runs(tmp_path, kind, k):
+    """`kmx combine`: per partition, the rows of the runs' matrices joined by key, a run's columns behind the previous run's,
+    zeros where a run lacks the key -- against a restatement of PartitionMerger, with its quirks: matrices/ entries are
+    taken in NAME order (12 partitions: matrix_10 comes third), the last key of a partition is lost unless two runs hold it,
+    header fields come from the last run's file."""
+    P, hashed, pa = 12, kind.endswith("hash"), kind.startswith("pa")
+    slots = 1 if hashed else (k + 31) // 32
+    rng = np.random.default_rng(17)
+    # per partition: a pool of ascending keys (tuples, most significant word first)
+    pools = []
+    for p in range(P):
+        # (two-word keys: few distinct high words, so that the low word decides often)
+        ks = {tuple(int(rng.integers(0, 1 << (4 if (slots == 2 and w == 0) else 40))) for w in range(slots)) for _ in range(25)}
+        pools.append(sorted(ks))
+    ncols = [3, 11, 6]
+    runs, parts = [], []
+    for r in range(3):
+        root = str(tmp_path / f"run{r}"); runs.append(root)
+        parts.append(_make_run(root, kind, k, P, ncols[r], 100 + r, [f"S{r}a", f"S{r}b"], hashed, pools))
+    fof = tmp_path / "runs.fof"; fof.write_text("\n".join(runs) + "\n\n")
+    out = str(tmp_path / "combined")
+    r = subprocess.run([KMX, "combine", "--fof", str(fof), "--output", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(f"{out}/kmtricks.fof").read() == "".join(f"S{r}{x}: /x/S{r}{x}.fa\n" for r in range(3) for x in "ab")
+    assert open(f"{out}/options.txt").read() == open(f"{runs[0]}/options.txt").read() and os.path.exists(f"{out}/hash.info")
+    assert open(f"{out}/repartition_gatb/repartition.minimRepart", "rb").read() == b"same table" * 10
+    names = sorted(os.listdir(f"{runs[0]}/matrices"))
+    total = sum(ncols)
+    M = _magics()
+    for p in range(P):
+        src_p = int(names[p].split("_")[1].split(".")[0])                 # the partition the p-th name holds
+        files = []
+        for rr in range(3):
+            keys, data = parts[rr][src_p]
+            rows = [([int(x) for x in d] if not pa else [int(b) for b in np.unpackbits(d, bitorder="little")[:ncols[rr]]]) for d in data]
+            files.append((keys, rows, ncols[rr]))
+        exp = _partition_merger(files, pa)
+        raw = open(f"{out}/matrices/matrix_{p}.{kind}", "rb").read()
+        assert raw[:13] == KM_BASE
+        if kind == "count": hdr = struct.pack("<QIIIIII", M["matrix"], k, slots, 1, total, 7, src_p); hl = 45
+        elif kind == "count_hash": hdr = struct.pack("<QIIII", M["matrix_hash"], 4, total, 7, src_p); hl = 37
+        elif kind == "pa": hdr = struct.pack("<QIIIIII", M["pa"], k, slots, total, (total + 7) // 8, 7, src_p); hl = 45
+        else: hdr = struct.pack("<QIIII", M["pa_hash"], total, (total + 7) // 8, 7, src_p); hl = 37
+        assert raw[13:hl] == hdr
+        body = b""
+        for key, row in exp:
+            body += np.array(key[::-1], dtype=np.uint64).tobytes()
+            body += (np.array(row, dtype=np.uint32).tobytes() if not pa else np.packbits(np.array(row, dtype=np.uint8), bitorder="little").tobytes())
+        assert raw[hl:] == body, (p, len(exp))
+        n_all = len({kk for f in files for kk in f[0]})
+        assert len(exp) in (n_all, n_all - 1)
+    # the text form of a combined matrix through `kmx dump`
+    r = subprocess.run([KMX, "dump", "--input", f"{out}/matrices/matrix_0.{kind}"], capture_output=True, text=True)
+    assert r.returncode == 0 and len(r.stdout.splitlines()) == len(_partition_merger(
+        [(parts[rr][int(names[0].split('_')[1].split('.')[0])][0], [[0] * ncols[rr]] * len(parts[rr][int(names[0].split('_')[1].split('.')[0])][0]), ncols[rr]) for rr in range(3)], pa))
+
+
+def test_combine_renames_duplicate_ids_and_checks_the_repartition(tmp_path):
+    pools = [sorted({(int(x),) for x in np.random.default_rng(3).integers(0, 1 << 40, 20)}) for _ in range(2)]
+    runs = []
+    for r in range(2):
+        root = str(tmp_path / f"run{r}"); runs.append(root)
+        _make_run(root, "count", 31, 2, 2, 5 + r, ["A", "B"], False, pools)
+    fof = tmp_path / "runs.fof"; fof.write_text("\n".join(runs) + "\n")
+    out = str(tmp_path / "c1")
+    r = subprocess.run([KMX, "combine", "--fof", str(fof), "--output", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(f"{out}/kmtricks.fof").read() == "A_0:  /x/A.fa\nB_0:  /x/B.fa\nA_1:  /x/A.fa\nB_1:  /x/B.fa\n"      # (cat_fof_and_rename, matrix.hpp:841-864)
+    open(f"{runs[1]}/repartition_gatb/repartition.minimRepart", "wb").write(b"another table")
+    r = subprocess.run([KMX, "combine", "--fof", str(fof), "--output", str(tmp_path / "c2")], capture_output=True, text=True)
+    assert r.returncode == 1 and "are not mergeable" in r.stderr
+    open(f"{runs[0]}/options.txt", "w").write("Options: mode=bf, count_format=hash\n")
+    r = subprocess.run([KMX, "combine", "--fof", str(fof), "--output", str(tmp_path / "c3")], capture_output=True, text=True)
+    assert r.returncode == 1 and "not supported by 'kmtricks combine'" in r.stderr
