@@ -798,6 +798,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     ctx->rows_per_longest = ctx->rows_per_longest > 0.0 ? std::max(ratio, 0.75 * ctx->rows_per_longest + 0.25 * ratio) : ratio;
   }
   R->waited = true; R->status = KMX_OK;
+  if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] batch of %zu tasks (%u-bit keys): %s\n", R->tasks.size(), 64u * R->tasks[0].kw, kmx_result_kernel(R));
   return KMX_OK;
 }
 

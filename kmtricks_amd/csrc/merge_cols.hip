@@ -831,7 +831,10 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     if (over) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[1], 1u); } break; }
     if (tot == 0) continue;
     // passes: ~1400 entries each when every entry is a candidate, ~3000 when only the keys seen twice are
-    const u32 per = (thr == 1 ? 1400u : 3000u) * (u32)CK_CAND / 2048u;
+#ifndef KMX_CK_PER1
+#define KMX_CK_PER1 1400
+#endif
+    const u32 per = (thr == 1 ? (u32)KMX_CK_PER1 : 3000u) * (u32)CK_CAND / 2048u;
     u32 npass = 1; while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;
     if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
     // each of my entries through f(key, payload): four threads per slice

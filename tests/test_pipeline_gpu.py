@@ -409,6 +409,33 @@ def test_synthetic_multi_sample_pipeline(tmp_path, mode):
     assert total_rows > 50_000
 
 
+def test_k63_pa_cohort_pipeline(tmp_path):
+    """BASELINE configs[4] in small (130 samples x 40 kbp, k = 63, `kmer:pa:bin`, recurrence-min 1, 4 partitions): the 128-bit-key
+    build of the column-blocked merge runs the batches (KMX_TRACE names the kernel), every PA matrix and merge_info equals the oracle's"""
+    NS, GL, PP, KK = 130, 40_000, 4, 63
+    reads = _synthetic_samples(tmp_path, NS, GL, 23)
+    out = tmp_path / "run"
+    args = [KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out), "--kmer-size", str(KK), "--hard-min", "2",
+            "--nb-partitions", str(PP), "--static-repart", "--mode", "kmer:pa:bin", "--recurrence-min", "1"]
+    r = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, KMX_TRACE="1"))
+    assert r.returncode == 0, r.stderr
+    ran = [l for l in r.stderr.splitlines() if l.startswith("[kmx merge] batch of")]
+    assert ran and all("128-bit keys" in l and l.endswith("k_merge_cols") for l in ran), ran
+    lut = orc.minimizer_lut(10); rep = orc.repart_static(10, PP)
+    sk = [orc.superk_partition(rs, KK, 10, lut, rep, PP) for rs in reads]
+    total_rows = 0
+    for p in range(PP):
+        lists = [tuple(x if i else x.reshape(-1) for i, x in enumerate(orc.count_kmer(s[p][0], KK, 2))) for s in sk]
+        body, rows, stats = orc.merge_matrix(lists, 2, [1] * NS, 1, 0, orc.MODE_PA)
+        raw = open(out / "matrices" / f"matrix_{p}.pa", "rb").read()
+        assert struct.unpack_from("<II", raw, 21) == (KK, 2) and raw[45:] == body
+        total_rows += rows
+        mi = [l.split("\t") for l in open(out / "merge_infos" / f"partition{p}.merge_info").read().splitlines()]
+        for rix in range(6):
+            assert [int(x) for x in mi[rix][1:1 + NS]] == [int(x) for x in stats[rix]]
+    assert total_rows > 100_000
+
+
 def test_dump_and_aggregate(inputs, tmp_path):
     """`kmx dump` / `kmx aggregate` (cmd.hpp:275-369, 441-607) on a run directory: matrix rows as text, partitions concatenated or merged
     into one ascending stream, aggregated binary matrix"""
