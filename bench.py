@@ -278,7 +278,7 @@ def main():
         if wl == "bft" and tr_ms and min(tr_ms) >= 0:      # (builds that transpose in a second pass)
             kms += sum(tr_ms) / len(tr_ms)
         achieved = algo_bytes / (kms * 1e-3) / 1e9 if kms > 0 else None
-        kname = kernel_name + (" + k_cols_sparse" if kernel_name == "k_merge_cols" else "") + (" (+ k_bf_rowrec)" if wl == "bft" else "")
+        kname = kernel_name + (" + k_cols_sparse" if kernel_name == "k_merge_cols" else "")
         out = {
             "metric": "k-mers merged/s (merge stage, sum over partitions of input records / time)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

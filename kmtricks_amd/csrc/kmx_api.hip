@@ -328,6 +328,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       if (!is_bft && (u64)rt * H.row_bytes > 96 * 1024) return ctx->fail(KMX_E_UNSUPPORTED, "BF row too wide for one LDS tile");
       H.rt = is_bft ? bft_tile_rows() : rt;
       H.out_bytes = (size_t)((K.upper - K.lower + 1) * H.row_bytes);
+      if (is_bft && H.N > bft_max_lists()) return ctx->fail(KMX_E_UNSUPPORTED, "more than " + std::to_string(bft_max_lists()) + " samples per hash:bft task not supported");
       if (is_bft) {   // write_as_bft (merge.hpp:631-644): BitMatrix(ROUND_UP(W, 8), ROUND_UP(N, 8) / 8), transposed, dumped whole
         H.t_rows = (K.upper - K.lower + 1 + 7) & ~7ULL; H.t_cols = (u64)H.row_bytes * 8;
         H.img_bytes = 0;

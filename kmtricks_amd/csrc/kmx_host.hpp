@@ -51,6 +51,7 @@ hipError_t launch_merge_bf(int bfc, const TaskDev* tasks, const uint2* items, u3
                            u32 grid_x, int lds, hipStream_t st);
 u32 bft_tile_rows();
 u32 bft_block_lists();
+u32 bft_max_lists();
 hipError_t launch_merge_bft(const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, u32 max_n, hipStream_t st);
 hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hipStream_t st);
 
