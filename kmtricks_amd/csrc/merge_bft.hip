@@ -59,6 +59,7 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
   __shared__ u32 bc;
   extern __shared__ u32 curs[];                                         // [2][N]: every sample's cursor, and its cursor behind the tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (u32 t = tid; t < BT_NB * BT_RW / 4; t += BT_TPB) reinterpret_cast<uint4*>(img)[t] = make_uint4(0, 0, 0, 0);      // (every block leaves it zero behind it)
   for (;;) {
     if (tid == 0) bc = atomicAdd(ticket, 1u);
     bt_barrier();
@@ -123,13 +124,14 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
             u32 next = st[x];
             bool stop = false;
             for (u32 idx0 = st[x] + r; ; ) {
+              // (a list ascends and a slot past its end holds ~0: once a record is beyond the tile, so are the lane's later ones)
 #pragma unroll
               for (int q = 0; q < BT_UNR; q++) {
-                if (stop) continue;
-                if (d[x].hh[q] >= thi) { stop = true; continue; }
-                next = idx0 + q * BT_G + 1;
-                if (d[x].cc[q] >= sm[x]) { const u32 row = (u32)(d[x].hh[q] - tlo); atomicAdd(&rec[row >> 1], 1u << ((row & 1u) * 16)); }
+                const bool in = d[x].hh[q] < thi;
+                if (in) next = idx0 + q * BT_G + 1;
+                if (in && d[x].cc[q] >= sm[x]) { const u32 row = (u32)(d[x].hh[q] - tlo); atomicAdd(&rec[row >> 1], 1u << ((row & 1u) * 16)); }
               }
+              stop = !(d[x].hh[BT_UNR - 1] < thi);
               idx0 += BT_UNR * BT_G;
               if (stop || idx0 >= e[x]) break;
               issue(base[x], idx0, e[x], d[x]);      // (a sample with more than a round of records in the tile)
@@ -150,28 +152,29 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
         const u32 li = col0 + (u32)tid / BT_G;
         const bool on = li < N;
         BtRound d = dn; const u8* const base = nbase; const u32 e = ne, sm = nsm, start = nst;
-        for (u32 t = tid; t < BT_NB * BT_RW / 4; t += BT_TPB) reinterpret_cast<uint4*>(img)[t] = make_uint4(0, 0, 0, 0);
         { const u32 ln = li + BT_NB; if (blk + 1 < nblk && ln < N) { sample_of(ln, nbase, ne, nsm, nst); issue(nbase, nst + r, ne, dn); } }
-        bt_barrier();
-        if (on) {
+        if (on) {      // (the image is zero: the previous block cleared it before its last barrier)
           u32 next = start, uwo = 0, nresc = 0; u64 two = 0, tresc = 0;
           bool stop = false;
           for (u32 idx0 = start + r; ; ) {
+            // (as above: in-tile records are a prefix of the lane's slots; the rows' recurrences are all requested before the first is used)
+            u32 rw[BT_UNR];
+#pragma unroll
+            for (int q = 0; q < BT_UNR; q++) { const bool in = d.hh[q] < thi; const u32 row = in ? (u32)(d.hh[q] - tlo) : 0u; rw[q] = two_pass ? rec[row >> 1] : 0u; }
 #pragma unroll
             for (int q = 0; q < BT_UNR; q++) {
-              if (stop) continue;
-              if (d.hh[q] >= thi) { stop = true; continue; }
+              if (!(d.hh[q] < thi)) continue;
               next = idx0 + q * BT_G + 1;
               const u32 c = d.cc[q], row = (u32)(d.hh[q] - tlo);
               const bool solid = c >= sm;
-              u32 rc = 0;
-              if (two_pass) rc = (rec[row >> 1] >> ((row & 1u) * 16)) & 0xFFFFu;
+              const u32 rc = (rw[q] >> ((row & 1u) * 16)) & 0xFFFFu;
               u32 outc = 0;
               if (solid) { outc = c; uwo++; two += c; }
               else if (share_min && rc >= share_min) { outc = c; nresc++; tresc += c; }      // rescued (merge.hpp:491-510)
               const bool keep = two_pass ? (rc >= rec_min) : (solid || rec_min == 0);
               if (keep && outc) atomicOr(&myrow[row >> 5], 1u << (row & 31u));
             }
+            stop = !(d.hh[BT_UNR - 1] < thi);
             idx0 += BT_UNR * BT_G;
             if (stop || idx0 >= e) break;
             issue(base, idx0, e, d);
@@ -199,6 +202,11 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
           } else {
             for (u32 t = lane; t < nby; t += 64) dst[t] = (u8)(src[t >> 2] >> ((t & 3u) * 8));
           }
+        }
+        // the image is zero again for the next block: a wave clears the rows it has just read (the padding rows of the last block too)
+        for (u32 j = wave; j < (u32)BT_NB; j += BT_TPB / 64) {
+          uint4* const z = reinterpret_cast<uint4*>(img + j * BT_RW);
+          for (u32 t = (u32)lane; t < (u32)BT_RW / 4; t += 64) z[t] = make_uint4(0, 0, 0, 0);
         }
         bt_barrier();
       }
