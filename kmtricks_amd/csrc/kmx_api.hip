@@ -225,17 +225,25 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     const uint2* d_subitems = reinterpret_cast<const uint2*>(R->d_meta + R->o_subitems);
     const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
     const uint2* d_citems = reinterpret_cast<const uint2*>(R->d_meta + R->o_citems);
-    // (the preparation -- small, latency-bound kernels -- goes to the second stream: it fills the CUs the previous
-    //  batch's merge leaves idle towards its end, and runs beside that batch's check)
+    // The preparation -- small, latency-bound kernels -- runs on the merge's own stream, behind the previous batch.  Round 1 put it on
+    // a second stream, to fill the CUs the previous batch's merge leaves idle towards its end.  But k_merge_cols holds every CU with
+    // one persistent workgroup; the row-key kernels then squeeze into what it leaves (a few wave slots, 34 KB of LDS), crawl
+    // (k_cols_skel: 0.16 ms alone, up to 4.4 ms there) and slow the merge down with them -- or not, depending on when the host
+    // happened to submit: configs[4] on lists from the count stage ran at 8.2 or 5.3 ms per launch with the same binary, and
+    // recurrence-min 1 count rows at 0.59-0.66 or 0.70 of the roofline.  In line they cost their own 0.25 ms per batch and nothing
+    // else (KMX_COLS_PREP_OVERLAP=1 brings the second stream back).
+    static const bool overlap = getenv("KMX_COLS_PREP_OVERLAP") != nullptr;
+    hipStream_t ps = overlap ? ctx->aux : ctx->stream;
     if (!R->ev_pre) KMX_HIP(ctx, hipEventCreateWithFlags(&R->ev_pre, hipEventDisableTiming));
-    if (ctx->stream_shared) {   // whatever the caller queued on the stream (producers of the lists) comes first
+    if (overlap && ctx->stream_shared) {   // whatever the caller queued on the stream (producers of the lists) comes first
       KMX_HIP(ctx, hipEventRecord(R->ev_pre, ctx->stream));
       KMX_HIP(ctx, hipStreamWaitEvent(ctx->aux, R->ev_pre, 0));
     }
-    KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ctx->aux));
-    KMX_HIP(ctx, CO.skel(d_subs, d_subitems, R->n_subitems, ctx->aux));
-    KMX_HIP(ctx, CO.prep(d_tasks, d_subs, d_cols, nt, ctx->aux));
-    KMX_HIP(ctx, hipEventRecord(R->ev_pre, ctx->aux));
+    if (!overlap) KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_up, 0));      // (the meta blob travels on the second stream)
+    KMX_HIP(ctx, launch_range_bounds(kw, d_subs, nt, R->sub_max_n, R->sub_max_c, ps));
+    KMX_HIP(ctx, CO.skel(d_subs, d_subitems, R->n_subitems, ps));
+    KMX_HIP(ctx, CO.prep(d_tasks, d_subs, d_cols, nt, ps));
+    KMX_HIP(ctx, hipEventRecord(R->ev_pre, ps));
     // (the task's own range bounds need the upload only: on the main stream, beside the row-key kernels)
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_up, 0));
     KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));

@@ -110,8 +110,9 @@ struct ClEnt { u64 lo, hi; u32 idx, pad[3]; };                 // 32 bytes
 __device__ __forceinline__ bool ck_lt(CKey a, CKey b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; }
 __device__ __forceinline__ bool ck_eq(CKey a, CKey b) { return a.lo == b.lo && a.hi == b.hi; }
 __device__ __forceinline__ CKey ck_inf() { CKey k; k.lo = ~0ULL; k.hi = ~0ULL; return k; }
-// (the product's high half folded down: a plain lo ^ hi * c cancels when the low word is itself a multiple of the high one)
-__device__ __forceinline__ u64 ck_fold(CKey k) { const u64 h = k.hi * 0x9E3779B97F4A7C15ULL; return k.lo ^ h ^ (h >> 32); }
+// (the product's high part folded down: a plain lo ^ hi * c cancels when the low word is itself a multiple of the high one.  By 29,
+//  not 32: a difference in the high word's upper half must not put the same bits into both halves of the fold -- cl_thash xors them)
+__device__ __forceinline__ u64 ck_fold(CKey k) { const u64 h = k.hi * 0x9E3779B97F4A7C15ULL; return k.lo ^ h ^ (h >> 29); }
 __device__ __forceinline__ CKey ck_uni(CKey k) { CKey r; r.lo = cl_uni64(k.lo); r.hi = cl_uni64(k.hi); return r; }
 __device__ __forceinline__ CKey ck_load(const u8* p) { const Key<2> k = load_key<2>(p); CKey r; r.lo = k.w[0]; r.hi = k.w[1]; return r; }
 __device__ __forceinline__ void ck_store(u32* p, CKey k) { p[0] = (u32)k.lo; p[1] = (u32)(k.lo >> 32); p[2] = (u32)k.hi; p[3] = (u32)(k.hi >> 32); }
@@ -144,11 +145,21 @@ __device__ __forceinline__ u32 cl_thash(CKey key, u32 hf)
     return (u32)((k * m) >> (CL_PT == 2048 ? 53 : 52));      // the product's TOP bits: every key bit counts (a k-mer and its variant with one
                                                              // substitution near the front differ in one high bit and sit in the same tile)
   }
+#if KMX_CL_KW == 1
   const u32 x = ((u32)k ^ (u32)(k >> (hf >> 24))) & 0xFFFFFFu;
+#else
+  // 128-bit keys of a partition are ~2^100 apart: a k-mer and its variant with ONE substitution anywhere in its low 50 nucleotides
+  // are neighbours in a tile, so every bit of the fold has to reach the 24 that get multiplied: f ^ f >> 8 takes bit i of either half
+  // to bit i or i - 8.  (With the 64-bit family's window of 48 bits three tiles in four of a real cohort went through all the cheap
+  // tries first, the workgroup waiting: 63 % of the kernel on configs[4]'s lists from the count stage.)
+  const u32 f = (u32)k ^ (u32)(k >> 32);
+  const u32 x = (f ^ (f >> 8)) & 0xFFFFFFu;
+#endif
   return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
 }
 __device__ __forceinline__ u32 cl_mult(u32 seed)
 {
+  if (KW == 2 && seed >= 16u) return 0x80000000u | (seed - 15u);      // (its cheap hashes differ in the multiplier only: 16 tries tell)
   if (seed >= 64u) return 0x80000000u | (seed - 63u);
   return ((0x9E3779u + seed * 0x5A6B2u) & 0xFFFFFFu) | ((13u + (seed * 7u) % 19u) << 24);
 }
