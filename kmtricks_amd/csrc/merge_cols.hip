@@ -875,11 +875,93 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       }
     };
     for (u32 pass = 0; pass < npass; pass++) {
-      for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
-      for (u32 t = tid; t < (u32)CK_B2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
+      constexpr bool BY_INTERVAL = MODE == 1;      // (count rows -- 4 N bytes each -- are bound by their stores: +-0 there, 20 more registers)
+      if (thr > 1) {
+        for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
+        for (u32 t = tid; t < (u32)CK_B2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
+      } else {
+        for (u32 t = tid; t < 512u; t += CK_TPB) bits[t] = 0;      // (the interval counters below live in the key map's room)
+      }
       if (tid == 0) ncand = 0;
       __syncthreads();
       SPPH(1);
+      bool sorted = false;
+      u32 nc1 = 0;
+      if (thr == 1 && !BY_INTERVAL) {
+        each(pass, [&](CKey k, u64 pl) { const u32 ps = atomicAdd(&ncand, 1u); if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; } });
+        __syncthreads();
+      }
+      if (thr == 1 && BY_INTERVAL) {
+        // recurrence-min 1: every entry is a row, the sort is all there is to do -- and the group's ROW KEYS (<= 56, ascending) cut its
+        // key range into intervals of ~20 entries.  An entry finds its interval by binary search, the intervals are laid out one after
+        // the other (count, scan, place) and an entry's place inside its interval is the number of the interval's entries below it.
+        CKey* const rk = reinterpret_cast<CKey*>(bits);            // [64] the group's row keys
+        u32* const ioff = bits + 256;                               // [66] entries per interval, then where each interval starts
+        const u32 nrk = min(dn, 64u);
+        for (u32 t = tid; t < nrk; t += CK_TPB) rk[t] = reinterpret_cast<const CKey*>(C.skel)[d0 + t];
+        __syncthreads();
+        // (the entries are gathered first, as they come: then every thread of the workgroup has its two or four to work on at once)
+        each(pass, [&](CKey k, u64 pl) { const u32 ps = atomicAdd(&ncand, 1u); if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; } });
+        __syncthreads();
+        nc1 = ncand;
+        if (nc1 <= (u32)CK_CAND) {
+          constexpr int PER = CK_CAND / CK_TPB;      // entries per thread
+          CKey mk[PER]; u64 mp[PER]; u32 mb[PER], mo[PER];
+#pragma unroll
+          for (int x = 0; x < PER; x++) {
+            const u32 i = tid + (u32)x * CK_TPB;
+            mk[x] = ck_inf(); mp[x] = 0; mb[x] = 0xFFFFFFFFu; mo[x] = 0;
+            if (i < nc1) { mk[x] = ck[i]; mp[x] = cp[i]; }
+          }
+          {   // the binary searches of my entries side by side (7 fixed steps cover 64 row keys: their LDS reads overlap)
+            u32 lo[PER], hi[PER];
+#pragma unroll
+            for (int x = 0; x < PER; x++) { lo[x] = 0; hi[x] = nrk; }
+#pragma unroll
+            for (int it = 0; it < 7; it++) {
+#pragma unroll
+              for (int x = 0; x < PER; x++) {
+                const u32 m = (lo[x] + hi[x]) >> 1;
+                const bool open = lo[x] < hi[x];
+                const bool below = open && ck_lt(rk[min(m, 63u)], mk[x]);
+                lo[x] = below ? m + 1 : lo[x];
+                hi[x] = (open && !below) ? m : hi[x];
+              }
+            }
+#pragma unroll
+            for (int x = 0; x < PER; x++) if (tid + (u32)x * CK_TPB < nc1) { mb[x] = lo[x]; mo[x] = atomicAdd(&ioff[lo[x]], 1u); }      // my number in my interval
+          }
+          __syncthreads();
+          if (tid < 64) {      // wave 0: sizes -> offsets (65 intervals: lane 0 takes the last one as well)
+            const u32 v = ioff[tid];
+            const u32 incl = wave_incl_scan(v, (int)tid);
+            const u32 t64 = (u32)__shfl((int)incl, 63);
+            const u32 last = ioff[64];
+            ioff[tid] = incl - v;
+            if (tid == 0) { ioff[64] = t64; ioff[65] = t64 + last; }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int x = 0; x < PER; x++) if (mb[x] != 0xFFFFFFFFu) { const u32 ps = ioff[mb[x]] + mo[x]; ck[ps] = mk[x]; cp[ps] = mp[x]; }      // interval after interval
+          __syncthreads();
+          u32 mr[PER];
+#pragma unroll
+          for (int x = 0; x < PER; x++) {
+            mr[x] = 0xFFFFFFFFu;
+            if (mb[x] != 0xFFFFFFFFu) {
+              const u32 lo = ioff[mb[x]], hi = ioff[mb[x] + 1];
+              u32 rr = lo;
+              for (u32 j = lo; j < hi; j++) rr += ck_less(ck[j], cp[j], mk[x], mp[x]) ? 1u : 0u;
+              mr[x] = rr;
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int x = 0; x < PER; x++) if (mr[x] != 0xFFFFFFFFu) { ck[mr[x]] = mk[x]; cp[mr[x]] = mp[x]; }
+          sorted = true;
+        }
+        __syncthreads();
+      }
       if (thr > 1) {
         each(pass, [&](CKey k, u64) {
           const u32 hx = cl_mix(k);
@@ -890,25 +972,29 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         __syncthreads();
         SPPH(2);
       }
-      each(pass, [&](CKey k, u64 pl) {
-        if (thr > 1) { const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return; }
-        const u32 ps = atomicAdd(&ncand, 1u);
-        if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; }
-      });
-      __syncthreads();
+      if (thr > 1) {
+        each(pass, [&](CKey k, u64 pl) {
+          const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
+          const u32 ps = atomicAdd(&ncand, 1u);
+          if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; }
+        });
+        __syncthreads();
+      }
       SPPH(3);
       const u32 nc = ncand;
       if (nc > (u32)CK_CAND) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
       if (tid == 0) { dir[(u64)gid * CK_NPASS + pass].base = 0; dir[(u64)gid * CK_NPASS + pass].n = 0; }
       if (nc == 0) { __syncthreads(); continue; }
-      u32 P = 128; while (P < nc) P <<= 1;
-      for (u32 t = nc + tid; t < P; t += CK_TPB) { ck[t] = ck_inf(); cp[t] = ~0ULL; }      // (pads: larger than any entry, the key of all ones included)
-      __syncthreads();
-      ck_sort_block(ck, cp, P, tid);
+      if (!sorted) {
+        u32 P = 128; while (P < nc) P <<= 1;
+        for (u32 t = nc + tid; t < P; t += CK_TPB) { ck[t] = ck_inf(); cp[t] = ~0ULL; }      // (pads: larger than any entry, the key of all ones included)
+        __syncthreads();
+        ck_sort_block(ck, cp, P, tid);
+      }
       SPPH(4);
       // kept runs: first entry of a run of >= thr equal keys (entries of one key come from different lists)
       u32 mine = 0, km = 0, rl[4] = {0, 0, 0, 0};
-      const u32 pt = (P + CK_TPB - 1) / CK_TPB;      // consecutive entries per thread (<= 4)
+      const u32 pt = (nc + CK_TPB - 1) / CK_TPB;     // consecutive entries per thread (<= 4)
 #pragma unroll
       for (u32 x = 0; x < 4; x++) {
         const u32 i = tid * pt + x;
