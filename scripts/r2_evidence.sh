@@ -8,6 +8,8 @@ python bench.py --lists random --no-cpu-baseline 2>/dev/null | line > $O/bench_c
 python bench.py --rec-min 1 --partitions-per-gpu 8 --no-cpu-baseline 2>/dev/null | line > $O/bench_count_recmin1.json
 python bench.py --workload bf 2>/dev/null | line > $O/bench_bf.json
 python bench.py --workload pa63 --no-cpu-baseline 2>/dev/null | line > $O/bench_pa63.json
+python bench.py --workload pa63 --lists random --partitions-per-gpu 16 --no-cpu-baseline 2>/dev/null | line > $O/bench_pa63_random16.json
+python bench.py --lists random --rec-min 1 --partitions-per-gpu 8 --no-cpu-baseline 2>/dev/null | line > $O/bench_count_random_recmin1.json
 python bench.py --workload bft --no-cpu-baseline 2>/dev/null | line > $O/bench_bft.json
 for K in pivot rows; do KMX_MERGE_KERNEL=$K python bench.py --no-cpu-baseline 2>/dev/null | line > $O/bench_count_counted_$K.json; done
 python scripts/bench_count.py > $O/bench_count_stage.json 2>$O/err_count.log
