@@ -34,11 +34,19 @@ __global__ void k_range_bounds_bf(const TaskDev* __restrict__ tasks, u32 max_c)
     const u64 tiles_per = (tiles + T.c - 1) / T.c;
     const u64 q = T.lower + (u64)j * tiles_per * T.rt;
     const u8* base = T.recs[i];
+    // window hashes are uniform in [lower, upper]: interpolate between the bracket's ends (log log n probes instead of log n
+    // dependent loads: 5 against 14 for configs[3]'s lists), every third probe a plain bisection so that no input costs more than 3 log n
     u32 lo = 0, hi = n;
-    while (lo < hi) {
-      u32 mid = lo + ((hi - lo) >> 1);
-      Key<1> k = load_key<1>(base + (u64)mid * 12);
-      if (k.w[0] < q) lo = mid + 1; else hi = mid;
+    u64 klo = T.lower, khi = T.upper + 1;      // keys below position lo are < q (>= klo), the key at hi (if any) is >= q (<= khi)
+    for (u32 step = 0; lo < hi; step++) {
+      u32 mid;
+      if (step % 3 == 2 || khi <= klo || q <= klo) mid = lo + ((hi - lo) >> 1);
+      else {
+        const double f = (double)(q - klo) / (double)(khi - klo);
+        mid = lo + (u32)min((double)(hi - lo - 1), f * (double)(hi - lo));
+      }
+      const u64 k = load_key<1>(base + (u64)mid * 12).w[0];
+      if (k < q) { lo = mid + 1; klo = k; } else { hi = mid; khi = k; }
     }
     res = lo;
   }
