@@ -436,6 +436,36 @@ def test_k63_pa_cohort_pipeline(tmp_path):
     assert total_rows > 100_000
 
 
+def test_combine_two_runs_equals_one_run(inputs, tmp_path):
+    """`kmx combine` over two `kmx pipeline` runs that share a repartition (one sample each) == the matrix of one run over both
+    samples (recurrence-min 1), up to MatrixMerger's dropped last key (matrix.hpp:534-583); also with a run that kept its count
+    files (taken as one-column matrices, matrix.hpp:756-771)."""
+    fofs = []
+    for i, line in enumerate((f"D1 : {GD}/1.fasta", f"D2 : {inputs}/2.fastq.gz")):
+        f = tmp_path / f"s{i}.fof"; f.write_text(line + "\n"); fofs.append(f)
+    def pipe(fof, out, *extra):
+        r = subprocess.run([KMX, "pipeline", "--file", str(fof), "--run-dir", str(out), "--kmer-size", "31", "--hard-min", "1", "--nb-partitions", "4",
+                            "--repart-file", str(inputs / "fixture.minimRepart"), "--mode", "kmer:count:bin", "--recurrence-min", "1", *extra], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return out
+    a = pipe(fofs[0], tmp_path / "runA"); b = pipe(fofs[1], tmp_path / "runB"); bk = pipe(fofs[1], tmp_path / "runBk", "--keep-tmp")
+    both = run(inputs, tmp_path / "both", "--mode", "kmer:count:bin", "--recurrence-min", "1")
+    for name, second in (("c1", b), ("c2", bk)):
+        lst = tmp_path / f"{name}.fof"; lst.write_text(f"{a}\n{second}\n")
+        out = tmp_path / name
+        r = subprocess.run([KMX, "combine", "--fof", str(lst), "--output", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(out / "kmtricks.fof").read().split() == open(both / "kmtricks.fof").read().split()
+        for p in range(P):
+            full = np.frombuffer(open(both / "matrices" / f"matrix_{p}.count", "rb").read()[45:], np.uint8).reshape(-1, 16)
+            raw = open(out / "matrices" / f"matrix_{p}.count", "rb").read()
+            got = np.frombuffer(raw[45:], np.uint8).reshape(-1, 16)
+            assert struct.unpack_from("<IIII", raw, 21)[3] == 2                      # two columns
+            last_in_one_run_only = int((full[-1, 8:12].view(np.uint32)[0] == 0) or (full[-1, 12:16].view(np.uint32)[0] == 0))
+            assert len(got) == len(full) - last_in_one_run_only
+            assert np.array_equal(got, full[:len(got)]), p
+
+
 def test_dump_and_aggregate(inputs, tmp_path):
     """`kmx dump` / `kmx aggregate` (cmd.hpp:275-369, 441-607) on a run directory: matrix rows as text, partitions concatenated or merged
     into one ascending stream, aggregated binary matrix"""
