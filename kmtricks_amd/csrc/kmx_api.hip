@@ -359,7 +359,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   // lists) is faster when MANY lists share most of their keys -- the cohort case the metric is quoted on --
   // and k_merge_cols (merge_cols.hip; a small recurrence-min) faster still there.  Both flag tasks
   // they do not suit, and those are re-run with the next kernel down (cols -> pivot -> rows, see
-  // kmx_result_wait; below 513 lists cols -> rows).  Default: from 128 lists per task and 2 <= recurrence-min <= 21
+  // kmx_result_wait; below 513 lists cols -> rows).  Default: from 192 lists per task and recurrence-min <= 21
   // cols; otherwise pivot above 512 lists (where k_merge_rows is down to 4-record windows), else rows.
   // KMX_MERGE_KERNEL=rows|pivot|cols forces one of them (where it is applicable).
   {
@@ -393,9 +393,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     else if (force && !strcmp(force, "pivot")) R->use_pivot = can;
     else if (force && !strcmp(force, "rows")) R->use_pivot = false;
     else {
-      // (cols: from 128 lists -- below, k_merge_rows' wide windows win -- and 1 M records per batch -- below, its seven
-      //  launches cost more than they save; recurrence-min 2..21)
-      R->use_cols = can_cols && min_n >= 128 && grand_total >= (1ull << 20) && cols_row_lists(std::max(1u, max_rec)) != 0;
+      // (cols: from 192 lists -- at 128, k_merge_rows' wide windows and single launch win by 0.15 ms per batch; at 200 cols does --
+      //  and 1 M records per batch -- below, its seven launches cost more than they save; recurrence-min up to 21)
+      R->use_cols = can_cols && min_n >= 192 && grand_total >= (1ull << 20) && cols_row_lists(std::max(1u, max_rec)) != 0;
       if (R->use_cols && ctx->cols_skip) { ctx->cols_skip--; R->use_cols = false; }
       R->cols_auto = R->use_cols;
       R->use_pivot = !R->use_cols && can && min_n > 512;

@@ -22,7 +22,7 @@
 //     keys' rows (with a directory: k_cols_gather interleaves the two when the body is asked for).  A task whose slices
 //     overflow, or with a tile no collision-free table was found for, is handed back (ERR_FALLBACK: the driver re-runs it
 //     with k_merge_pivot / k_merge_rows).  Results never depend on how well the row keys cover the lists.
-// Applicable to COUNT and PA rows, 64- and 128-bit keys, no share-min; chosen from 128 lists and recurrence-min <= 21
+// Applicable to COUNT and PA rows, 64- and 128-bit keys, no share-min; chosen from 192 lists and recurrence-min <= 21
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
 #include "kmx_host.hpp"
 #include <algorithm>

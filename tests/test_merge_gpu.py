@@ -485,7 +485,7 @@ def test_default_kernel_for_presence_absence_rows(monkeypatch, n):
 
 
 @pytest.mark.parametrize("similar", [True, False])
-def test_default_kernel_from_128_lists(monkeypatch, similar):
+def test_default_kernel_from_192_lists(monkeypatch, similar):
     """KMX_MERGE_KERNEL unset, 200 lists x 25k records: a cohort goes to k_merge_cols;
     unrelated lists are handed straight down to k_merge_rows (k_merge_pivot is not in the chain below 513 lists)."""
     torch = pytest.importorskip("torch")
@@ -603,7 +603,7 @@ def test_cols_128bit_keys_cohort(ctx, mode, rec_min):
 
 
 def test_batch_of_tasks_with_different_list_counts(monkeypatch):
-    """One kmx_merge_dev batch of four tasks with 130, 1000, 257 and 600 lists (different block counts, tile sizes and
+    """One kmx_merge_dev batch of four tasks with 200, 1000, 257 and 600 lists (different block counts, tile sizes and
     row widths side by side), count and PA, libkmx's own kernel choice: every task equals the oracle."""
     torch = pytest.importorskip("torch")
     from kmtricks_amd import lib
@@ -613,7 +613,7 @@ def test_batch_of_tasks_with_different_list_counts(monkeypatch):
     ctx = lib.Context(0)
     dev = torch.device("cuda", 0)
     for mode in (lib.MODE_COUNT, lib.MODE_PA):
-        sets = [synth_lists(9960 + i, n, pool, 0.97, pool // 40, kw=1) for i, (n, pool) in enumerate(((130, 9000), (1000, 2500), (257, 4000), (600, 3000)))]
+        sets = [synth_lists(9960 + i, n, pool, 0.97, pool // 40, kw=1) for i, (n, pool) in enumerate(((200, 9000), (1000, 2500), (257, 4000), (600, 3000)))]
         keep, tasks = [], []
         for lists in sets:
             n = len(lists)

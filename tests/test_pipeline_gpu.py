@@ -410,9 +410,9 @@ def test_synthetic_multi_sample_pipeline(tmp_path, mode):
 
 
 def test_k63_pa_cohort_pipeline(tmp_path):
-    """BASELINE configs[4] in small (130 samples x 40 kbp, k = 63, `kmer:pa:bin`, recurrence-min 1, 4 partitions): the 128-bit-key
+    """BASELINE configs[4] in small (200 samples x 40 kbp, k = 63, `kmer:pa:bin`, recurrence-min 1, 4 partitions): the 128-bit-key
     build of the column-blocked merge runs the batches (KMX_TRACE names the kernel), every PA matrix and merge_info equals the oracle's"""
-    NS, GL, PP, KK = 130, 40_000, 4, 63
+    NS, GL, PP, KK = 200, 40_000, 4, 63
     reads = _synthetic_samples(tmp_path, NS, GL, 23)
     out = tmp_path / "run"
     args = [KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out), "--kmer-size", str(KK), "--hard-min", "2",
