@@ -343,13 +343,16 @@ int run(int argc, char** argv)
         Channel<ReadBatch>& ch = *chan[si % G];
         ReadBatch b; b.si = si; b.offs.assign(1, 0);
         double rs = 0;
+        // (a sample's reads reach the GPU in batches of 256 MB of bases; KMX_READ_BATCH_BYTES lowers that -- for the tests of the
+        //  path that adds a sample's batches up)
+        static const size_t batch_bytes = getenv("KMX_READ_BATCH_BYTES") ? (size_t)std::max(1L, atol(getenv("KMX_READ_BATCH_BYTES"))) : (size_t)(256u << 20);
         try {
           for (const std::string& f : samples[si].files) {
             SeqReader rd(f); std::string seq;
             auto t = clk::now();
             while (rd.next(seq)) {
               b.bases += seq; b.offs.push_back(b.bases.size());
-              if (b.bases.size() > (256u << 20)) {
+              if (b.bases.size() > batch_bytes) {
                 rs += since(t);
                 ch.push(std::move(b));
                 b = ReadBatch(); b.si = si; b.offs.assign(1, 0);

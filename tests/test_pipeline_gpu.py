@@ -292,6 +292,31 @@ def test_hist_pipeline(inputs, tmp_path, mode):
     assert os.listdir(plain / "histograms") == []
 
 
+@pytest.mark.parametrize("mode", ["kmer:count:bin", "hash:count:bin"])
+def test_sample_in_several_read_batches(inputs, tmp_path, mode):
+    """a sample whose reads reach the GPU in several batches (256 MB of bases each in production; a few kb here): the streams,
+    k-mer totals, PartiInfo<5> counters and the histogram add up over the batches -- the run directory is the one-batch run's"""
+    extra = ["--bloom-size", "1000000"] if mode.startswith("hash") else []
+    one = run(inputs, tmp_path / "one", "--mode", mode, "--keep-tmp", "--hist", *extra)
+    env = dict(os.environ, KMX_READ_BATCH_BYTES="3000")
+    cmd = [KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "many"), "--kmer-size", "31", "--hard-min", "1",
+           "--nb-partitions", "4", "--repart-file", str(inputs / "fixture.minimRepart"), "--mode", mode, "--keep-tmp", "--hist", *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    many = tmp_path / "many"
+    checked = 0
+    for sub in ("matrices", "merge_infos", "partition_infos", "histograms", "counts", "superkmers"):
+        for root, _, files in os.walk(one / sub):
+            for f in files:
+                a = os.path.join(root, f); b = os.path.join(many, os.path.relpath(a, one))
+                da, db = open(a, "rb").read(), open(b, "rb").read()
+                if f == "SuperKmerBinInfoFile":      # (its second line is the directory)
+                    da, db = da.split(b"\n", 2)[2], db.split(b"\n", 2)[2]
+                assert da == db, os.path.relpath(a, one)
+                checked += 1
+    assert checked > 30
+
+
 def test_parti_info_file(inputs, tmp_path):
     """superkmers/<id>/PartiInfoFile (gatb PartiInfo.hpp:266-287) from the HIP split's statistics == the oracle's PartiInfo<5>"""
     out = run(inputs, tmp_path / "run", "--mode", "kmer:count:bin", "--until", "superk")
