@@ -508,7 +508,8 @@ int run(int argc, char** argv)
             }
             grp.clear(); gk = 0; gb = 0;
           };
-          const uint64_t LIM = 0x7FFFFFFFULL;
+          // (KMX_COUNT_GROUP_LIMIT lowers the limit for the test of the grouping)
+          static const uint64_t LIM = getenv("KMX_COUNT_GROUP_LIMIT") ? (uint64_t)std::max(1LL, atoll(getenv("KMX_COUNT_GROUP_LIMIT"))) : 0x7FFFFFFFULL;
           if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
           for (uint32_t p : plist) {
             const uint64_t nkp = S.nk[p], nbp = S.streams[p].size();

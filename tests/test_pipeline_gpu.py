@@ -298,7 +298,9 @@ def test_sample_in_several_read_batches(inputs, tmp_path, mode):
     k-mer totals, PartiInfo<5> counters and the histogram add up over the batches -- the run directory is the one-batch run's"""
     extra = ["--bloom-size", "1000000"] if mode.startswith("hash") else []
     one = run(inputs, tmp_path / "one", "--mode", mode, "--keep-tmp", "--hist", *extra)
-    env = dict(os.environ, KMX_READ_BATCH_BYTES="3000")
+    # (and the count of such a sample in groups of partitions: libkmx takes < 2^32 k-mers and bytes per call, the limit is lowered to
+    #  a few hundred here so that every partition goes alone or in pairs)
+    env = dict(os.environ, KMX_READ_BATCH_BYTES="3000", KMX_COUNT_GROUP_LIMIT="700")
     cmd = [KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "many"), "--kmer-size", "31", "--hard-min", "1",
            "--nb-partitions", "4", "--repart-file", str(inputs / "fixture.minimRepart"), "--mode", mode, "--keep-tmp", "--hist", *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
