@@ -153,6 +153,19 @@ def test_synthetic_bft(ctx, merge_kernel, n, dens, smin, rmin, share, W):
     assert rows == (n + 7) // 8 * 8
 
 
+def test_limits_fail_loudly(ctx, merge_kernel):
+    """what this build does not take is refused with a message, not computed wrongly: more samples per hash:bft task than cursors
+    fit the LDS, more than 4096 lists per COUNT / PA task"""
+    if merge_kernel != "rows":
+        pytest.skip("one run is enough")
+    empty = (np.zeros((0, 1), np.uint64), np.zeros(0, np.uint32))
+    with pytest.raises(Exception, match="hash:bft"):
+        ctx.merge([empty] * 9000, 1, [1] * 9000, 1, 0, orc.MODE_BFT, 0, 6399)
+    with pytest.raises(Exception, match="4096 lists"):
+        ctx.merge([empty] * 5000, 1, [1] * 5000, 1, 0, orc.MODE_COUNT)
+    check(ctx, [empty] * 3, 1, [1] * 3, 1, 0, orc.MODE_COUNT)      # (the context is still usable)
+
+
 def test_bft_rows_are_the_per_sample_filters(ctx, merge_kernel):
     """row s of the BFT body == column s of the BF body (what howde_utils.hpp:133-187 copies into sample s's filter)"""
     if merge_kernel != "rows":
