@@ -169,7 +169,7 @@ class Context:
         stats = np.zeros((STATS_ROWS, len(lists)), dtype=np.uint64)
         self._check(_lib.kmx_merge(self._h, C.byref(t), C.byref(body), C.byref(nb), C.byref(rows), stats.ctypes.data),
                     "kmx_merge")
-        data = C.string_at(body.value, nb.value) if nb.value else b""
+        data = (C.string_at(body.value, nb.value) if nb.value < (1 << 31) else bytes((C.c_ubyte * nb.value).from_address(body.value))) if nb.value else b""      # (string_at takes an int)
         _lib.kmx_free(body)
         return data, rows.value, stats
 

@@ -203,7 +203,8 @@ def merge_matrix(lists, kw, soft_min, rec_min, share_min, mode, lower=0, upper=0
     rc = _lib.orc_merge_matrix(arr, N, kw, sm.ctypes.data, rec_min, share_min, mode, lower, upper, bitw,
                                C.byref(body), C.byref(blen), C.byref(rows), stats.ctypes.data)
     assert rc == 0, rc
-    data = C.string_at(body.value, blen.value) if blen.value else b""
+    # (string_at takes an int: bodies of 2 GiB and more are copied through a ctypes array)
+    data = (C.string_at(body.value, blen.value) if blen.value < (1 << 31) else bytes((C.c_ubyte * blen.value).from_address(body.value))) if blen.value else b""
     _lib.orc_free(body)
     return data, rows.value, stats
 
