@@ -293,7 +293,7 @@ def main():
                          # streaming read rate of this access pattern measured on an MI355X (profiles/r01_h_fetch_calibration.txt)
                          "measured_stream_peak": 5654.0, "frac_of_measured": (achieved / 5654.0) if achieved else None},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # (the host baseline is a 1-GPU line: with more ranks the others would wait ~20 s at the barrier for it)
             out["cpu_baseline"] = cpu_baseline(parts, N, kw, tasks_d, mode)
         print(json.dumps(out))
     if world > 1:
