@@ -137,7 +137,8 @@ struct TaskHost {
   u32 nblk = 0, nb = 0, rt_cols = 0, slots_cap = 0;
   size_t o_skel = 0, o_nskel = 0, o_rbounds = 0;
   u8* d_ov = nullptr;           // the records that are not row keys (key, list, count), the slices' counts, and the directory of their rows
-  size_t o_spdir = 0;           // ... offset of that directory in d_ov
+  size_t o_spdir = 0;           // ... offset of (the extension pool's cursor and) that directory in d_ov
+  size_t o_ovx = 0; u32 xcap = 0;   // ... the pool the slices' extensions come from
   u64 sparse_rows = 0;          // rows k_cols_sparse added behind the row keys' rows
   std::vector<u32> src;         // (row-key merge of a task: which of the task's lists it merges)
   int kernel = 0;               // the kernel that completed (or is to complete) the task: 0 rows, 1 pivot, 2 cols
@@ -152,6 +153,7 @@ struct kmx_merge_result {
   u32 n_items = 0, grid = 0, max_n = 0, max_c = 0;
   int bf_lds = 0;
   bool is_bf = false, is_bft = false, waited = false;
+  bool cols_ext = false, slices_full = false;   // k_merge_cols with slice extensions; a task came back because a slice was full
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
@@ -249,7 +251,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    KMX_HIP(ctx, CO.merge(mode, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
+    KMX_HIP(ctx, CO.merge(mode, R->cols_ext ? 1 : 0, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
     KMX_HIP(ctx, CO.sparse(mode, d_tasks, d_cols, d_items, R->n_items, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));      // (the launch priced: the rows come out of both kernels)
@@ -381,7 +383,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         const u32 S_ = std::max(8u, cols_row_lists(std::max(1u, H.rec_min)));
         const u64 skel_est = std::min<u64>(H.rows_guess, (u64)S_ * (H.total_recs / H.N + 1) * 5 / 4 + 4096);
         const u32 sl = (u32)std::min<u64>(0x7FFFFFF0ULL, skel_est / CO.tile_rows(CO.block_lists()) + 64);
-        scratch += CO.scratch_keys(sl, nblk) * 8 + CO.scratch_counts(sl, nblk) * 4 + CO.dir_bytes(sl);
+        scratch += CO.scratch_keys(sl, nblk) * 8 + CO.scratch_counts(sl, nblk) * 8 + CO.ext_entries(sl, nblk) * (CO.key_words + 1) * 8 + CO.dir_bytes(sl);
       }
       const char* gb = getenv("KMX_COLS_SCRATCH_GB");
       const char* mb = getenv("KMX_COLS_SCRATCH_MB");
@@ -404,6 +406,10 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       R->auto_sel = true;
     }
     R->given = n_tasks;
+    // (an outlier by length is known up front: a list of more than 2.5 times the task's mean length)
+    bool long_list = false;
+    for (auto& H : R->tasks) { u32 longest = 0; for (u32 l : H.len) longest = std::max(longest, l); long_list |= (u64)longest * H.N * 2 > H.total_recs * 5; }
+    R->cols_ext = R->use_cols && (ctx->cols_ext || long_list);
   }
   // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
   const u32 slots = (u32)ctx->n_cu * 2;
@@ -556,9 +562,12 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   for (auto& H : R->tasks) {
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
     if (H.d_out && cols) {
-      H.o_spdir = align_up((size_t)(CO.scratch_keys(H.slots_cap, H.nblk) * 8 + CO.scratch_counts(H.slots_cap, H.nblk) * 4), 256);
-      H.d_ov = (u8*)ctx->dalloc(H.o_spdir + (size_t)CO.dir_bytes(H.slots_cap));
-      if (H.d_ov && hipMemsetAsync(H.d_ov + H.o_spdir, 0, (size_t)CO.dir_bytes(H.slots_cap), ctx->aux) != hipSuccess) { ctx->dfree(H.d_ov); H.d_ov = nullptr; }
+      // [set-aside slices][their counts][their extensions' places][the extension pool] | [the pool's cursor][the sparse rows' directory]
+      H.xcap = (u32)std::min<u64>(0x7FFFFF00ULL, CO.ext_entries(H.slots_cap, H.nblk));
+      H.o_ovx = align_up((size_t)(CO.scratch_keys(H.slots_cap, H.nblk) * 8 + CO.scratch_counts(H.slots_cap, H.nblk) * 8), 256);
+      H.o_spdir = align_up(H.o_ovx + (size_t)H.xcap * (CO.key_words + 1) * 8, 256);
+      H.d_ov = (u8*)ctx->dalloc(H.o_spdir + 256 + (size_t)CO.dir_bytes(H.slots_cap));
+      if (H.d_ov && hipMemsetAsync(H.d_ov + H.o_spdir, 0, 256 + (size_t)CO.dir_bytes(H.slots_cap), ctx->aux) != hipSuccess) { ctx->dfree(H.d_ov); H.d_ov = nullptr; }
     }
     if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
 
@@ -630,7 +639,10 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       C.rbounds = reinterpret_cast<u32*>(R->d_meta + H.o_rbounds);
       C.ovkeys = reinterpret_cast<u64*>(H.d_ov);
       C.ovcnt = reinterpret_cast<u32*>(H.d_ov + CO.scratch_keys(H.slots_cap, H.nblk) * 8);
-      C.spdir = H.d_ov + H.o_spdir;
+      C.ovx = reinterpret_cast<u64*>(H.d_ov + H.o_ovx);
+      C.xcur = reinterpret_cast<u32*>(H.d_ov + H.o_spdir);
+      C.xcap = H.xcap;
+      C.spdir = H.d_ov + H.o_spdir + 256;
       C.slots_cap = H.slots_cap; C.nblk = H.nblk; C.nb = H.nb; C.rt = H.rt_cols;
       for (u32 j = 0; j < H.c * H.nblk; j++) citems[ci++] = make_uint2(t, j);   // y = range * nblk + block
     }
@@ -671,7 +683,7 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
     H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3]; H.sparse_rows = ctrl[6];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
     H.handed_back = false;
-    if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; if (ctrl[2] & ERR_DIVERGENT) R->divergent = true; }
+    if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; if (ctrl[2] & ERR_DIVERGENT) R->divergent = true; if (ctrl[2] & ERR_SLICES) R->slices_full = true; }
   }
   return KMX_OK;
 }
@@ -707,7 +719,11 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] %s handed back %u of %zu tasks: re-run with %s\n", from_cols ? "k_merge_cols" : "k_merge_pivot",
                                      n_back, R->tasks.size(), to_pivot ? "k_merge_pivot" : "k_merge_rows");
     if (from_cols) {
-      if (R->cols_auto && n_back * 4 >= R->given) {   // a cohort it does not suit: back off for the next batches
+      // full set-aside slices (an outlier sample: several times the cohort's k-mers in one list): not a cohort the kernel does not
+      // suit -- the context's next batches run the build whose waves claim slice extensions; no pause
+      const bool retry_ext = R->slices_full && !R->cols_ext && !R->divergent;
+      if (retry_ext) ctx->cols_ext = true;
+      if (R->cols_auto && n_back * 4 >= R->given && !retry_ext) {   // a cohort it does not suit: back off for the next batches
         // (doubling; at once to the longest pause when three quarters of the batch came back: a try costs a whole merge)
         ctx->cols_backoff = n_back * 4 >= 3 * R->given ? 64u : std::min(64u, std::max(1u, ctx->cols_backoff * 2));
         ctx->cols_skip = ctx->cols_backoff;

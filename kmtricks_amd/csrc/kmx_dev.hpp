@@ -52,7 +52,10 @@ struct ColsDev {
   u32* nskel;              // -> number of row keys
   u32* rbounds;            // [c + 1] first row key of each key range
   u64* ovkeys;             // [slots_cap][halves][nblk][16][CL_OVW][2] solid records that are not row keys: key, list << 32 | count
-  u32* ovcnt;              // [slots_cap][halves][nblk][16] how many of them
+  u32* ovcnt;              // [slots_cap][halves][nblk][16][2] how many of them; 0, or 1 + where the slice goes on in ovx once its CL_OVW entries are full
+  u64* ovx;                // [xcap] entries: extensions of CL_XS entries, claimed from xcur by the wave that fills its slice (an outlier sample)
+  u32* xcur;               // -> entries of ovx claimed so far
+  u32 xcap;
   void* spdir;             // [slots_cap][halves][8] where k_cols_sparse put the rows of the keys outside the row keys
   u32 slots_cap;           // tile slots (tile q of range j: (rbounds[j] + q * rt) / rt + j)
   u32 nblk;                // column blocks
@@ -66,7 +69,8 @@ struct ColsDev {
 #endif
 
 enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2, ERR_FALLBACK = 4,
-       ERR_DIVERGENT = 8 };   // (with ERR_FALLBACK, from k_cols_prep: the lists share too few keys for the kernels built for cohorts)
+       ERR_DIVERGENT = 8,    // (with ERR_FALLBACK, from k_cols_prep: the lists share too few keys for the kernels built for cohorts)
+       ERR_SLICES = 16 };    // (with ERR_FALLBACK, from k_merge_cols: a wave's set-aside slice ran over -- the batches that follow use the build with extensions)
 
 // ---- keys -------------------------------------------------------------------------------------
 template <int KW> struct Key { u64 w[KW]; };

@@ -29,10 +29,11 @@ struct ColsOps {
   u32 (*tile_rows)(u32 nb);
   u64 (*scratch_keys)(u32 slots, u32 nblk);       // u64 words of the set-aside entries
   u64 (*scratch_counts)(u32 slots, u32 nblk);
+  u64 (*ext_entries)(u32 slots, u32 nblk);        // entries of the pool the slices' extensions come from
   u32 (*skel_cap)();
   hipError_t (*skel)(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st);
   hipError_t (*prep)(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st);
-  hipError_t (*merge)(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
+  hipError_t (*merge)(int mode, int ext, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
   hipError_t (*sparse)(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st);
   u64 (*dir_bytes)(u32 slots);
   u32 (*groups)(u32 slots);
@@ -86,6 +87,7 @@ struct kmx_ctx {
   // a cohort whose samples share their private k-mers pairwise keeps several times more rows than a list is long, and an arena
   // sized for 2 x the longest list would make every batch run twice)
   double rows_per_longest = 0.0;
+  bool cols_ext = false;                // a batch was handed back for full set-aside slices: k_merge_cols with slice extensions from here on
   // abundance histogram (kmx_hist_reset / kmx_hist_read): distinct keys per count 0..255, [256] = keys counted more than 255
   // times, [257] = the sum of those counts.  Every count call adds to it while it is on.
   unsigned long long* d_hist = nullptr;

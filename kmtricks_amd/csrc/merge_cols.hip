@@ -20,7 +20,7 @@
 //     appended to a per-(half tile, block, wave) slice in HBM.  k_cols_sparse then takes those entries a slice group at a
 //     time across the blocks, sorts the keys that can reach the recurrence-min in LDS and writes THEIR rows behind the row
 //     keys' rows (with a directory: k_cols_gather interleaves the two when the body is asked for).  A task whose slices
-//     overflow, or with a tile no collision-free table was found for, is handed back (ERR_FALLBACK: the driver re-runs it
+//     overflow (beyond the extension a wave can claim in the EXT build), or with a tile no collision-free table was found for, is handed back (ERR_FALLBACK: the driver re-runs it
 //     with k_merge_pivot / k_merge_rows).  Results never depend on how well the row keys cover the lists.
 // Applicable to COUNT and PA rows, 64- and 128-bit keys, no share-min; chosen from 192 lists and recurrence-min <= 21
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
@@ -68,6 +68,7 @@ constexpr int CL_PTSHIFT = CL_PT == 2048 ? 21 : 20;
 constexpr int CL_HALVES = CL_KPL;        // set-aside slices per tile: one per 56 rows (k_cols_sparse takes a slice group at a time)
 constexpr int CL_SEEDS = 256;            // hashes tried per tile for a collision-free table: 64 cheap ones, then 64-bit multiplicative ones
 constexpr int CL_OVW = 128;              // keys per (slice group, block, wave) of records that are not row keys
+constexpr int CL_XS = 3 * CL_OVW;        // ... and of the extension a wave claims when its slice is full (an outlier sample among its lists)
 constexpr int CL_NW = CL_TPB / 64;
 constexpr int CK_BITS = 1 << 17;         // k_cols_sparse: bits of the key map (16 KB of LDS)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
@@ -381,7 +382,9 @@ __device__ u64 kmx_sparse_prof[8];
 #endif
 
 // ---- the merge: work item = (task, key range, column block) ----------------------------------------------
-template <int MODE>      // 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
+// EXT: a wave whose set-aside slice is full claims an extension (cohorts with outlier samples; the plain build hands such a task
+// back and the context's next batches use this one: 1-2 % slower on cohorts that never need it)
+template <int MODE, bool EXT>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
 __global__ __launch_bounds__(CL_TPB, CL_WGS)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
                   u32 n_items, u32* ticket)
@@ -496,6 +499,15 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       gu64w* const ovk1 = ovk0 + (u64)nblk * CL_NW * CL_OVW * EW;
       const u64 li_hi = (u64)li << 32;
       u32 wov = 0, wov1 = 0;                        // records of this wave that are not row keys (uniform), per slice group
+      u32 xb0 = 0, xb1 = 0;                         // 0, or 1 + the first entry of the slice's extension in C.ovx (uniform)
+      // a slice about to run over claims an extension (rare: a sample with several times the cohort's k-mers among the wave's lists)
+      auto extend = [&](u32& xb) {
+        u32 b = 0;
+        if (lane == 0) b = atomicAdd(C.xcur, (u32)CL_XS);
+        b = cl_uni(b);
+        xb = (b + (u32)CL_XS <= C.xcap) ? b + 1u : 0xFFFFFFFFu;      // (pool exhausted: the task is handed back)
+      };
+      gu64w* const ovx = (gu64w*)(uintptr_t)C.ovx;
 
       for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
         // (three flags in turn: the one cleared here was last read two rounds ago, a barrier away)
@@ -548,18 +560,26 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 #define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = li_hi | cl_cnt(rec[g + j]); } while (0)
 #endif
               if (CL_HALVES == 1) {
+                if (EXT && __builtin_expect(wov + (u32)__popcll(bal) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
                 if ((ovm >> j) & 1u) {
                   const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
                   if (pos < (u32)CL_OVW) CL_PUT(ovk0, pos);
+                  else if (EXT && xb0 - 1u < 0xFFFFFFFEu && pos - (u32)CL_OVW < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb0 - 1u) * EW; const u32 px = pos - (u32)CL_OVW; CL_PUT(o, px); }
                 }
                 wov += (u32)__popcll(bal);
               } else {
                 const u64 hi = __ballot(((ovm >> j) & 1u) && !ck_lt(kk, kmid)), lo = bal & ~hi;
+                if (EXT && __builtin_expect(wov + (u32)__popcll(lo) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
+                if (EXT && __builtin_expect(wov1 + (u32)__popcll(hi) > (u32)CL_OVW && xb1 == 0, 0)) extend(xb1);
                 if ((ovm >> j) & 1u) {
                   const bool up = !ck_lt(kk, kmid);
                   const u64 m = up ? hi : lo;
                   const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
                   if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; CL_PUT(o, pos); }
+                  else if (EXT) {
+                    const u32 xb = up ? xb1 : xb0, px = pos - (u32)CL_OVW;
+                    if (xb - 1u < 0xFFFFFFFEu && px < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb - 1u) * EW; CL_PUT(o, px); }
+                  }
                 }
                 wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
               }
@@ -592,9 +612,14 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         if (!more) break;
       }
       if (lane == 0) {
-        C.ovcnt[(((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave] = wov;
-        if (CL_HALVES > 1) C.ovcnt[(((u64)(slot0 + q) * CL_HALVES + 1) * nblk + blk) * CL_NW + wave] = wov1;
-        if (max(wov, wov1) > (u32)CL_OVW) { failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); atomicMax(&kmx_cols_dbg[5], max(wov, wov1)); if (last) atomicAdd(&kmx_cols_dbg[6], 1u); if (q == 0) atomicAdd(&kmx_cols_dbg[7], 1u); }
+        const u64 s0i = (((u64)(slot0 + q) * CL_HALVES) * nblk + blk) * CL_NW + wave, s1i = (((u64)(slot0 + q) * CL_HALVES + 1) * nblk + blk) * CL_NW + wave;
+        // (a slice's count and its extension's place side by side: one load for k_cols_sparse)
+        reinterpret_cast<uint2*>(C.ovcnt)[s0i] = make_uint2(wov, xb0 == 0xFFFFFFFFu ? 0u : xb0);
+        if (CL_HALVES > 1) reinterpret_cast<uint2*>(C.ovcnt)[s1i] = make_uint2(wov1, xb1 == 0xFFFFFFFFu ? 0u : xb1);
+        const bool over0 = wov > (u32)CL_OVW && (xb0 - 1u >= 0xFFFFFFFEu || wov > (u32)(CL_OVW + CL_XS));
+        const bool over1 = wov1 > (u32)CL_OVW && (xb1 - 1u >= 0xFFFFFFFEu || wov1 > (u32)(CL_OVW + CL_XS));
+        if (over0 || over1) {
+          if (lane == 0) atomicOr(&T.ctrl[2], (u64)ERR_SLICES); failed = true; atomicAdd(&kmx_cols_dbg[1], 1u); atomicMax(&kmx_cols_dbg[5], max(wov, wov1)); if (last) atomicAdd(&kmx_cols_dbg[6], 1u); if (q == 0) atomicAdd(&kmx_cols_dbg[7], 1u); }
       }
 
       // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
@@ -815,21 +840,25 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     // first 20 entries (5 per thread; the usual slice holds ~14; the slice's memory is there whatever the count) are requested
     // together and kept in registers for both walks over the entries: one memory round trip per group
     u32 n0 = 0; CKey kk0[CK_SPEC]; u64 pp0[CK_SPEC];
-    const u64* kp0 = C.ovkeys;
+    const u64* kp0 = C.ovkeys; const u64* kpx0 = C.ovx;
     if (single) {
       const u32 sl = tid >> 2, sub = tid & 3u;
       const bool ok = sl < nsl;
-      const u32 nraw = ok ? C.ovcnt[sbase + sl] : 0u;
+      const uint2 ce = ok ? reinterpret_cast<const uint2*>(C.ovcnt)[sbase + sl] : make_uint2(0u, 0u);
+      const u32 nraw = ce.x, xb = ce.y;                                 // the slice's entries, and its extension if it has one
+      kpx0 = C.ovx + (u64)(xb ? xb - 1u : 0u) * EW;
+      const u32 lim0 = xb ? (u32)(CL_OVW + CL_XS) : (u32)CL_OVW;
       kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW * EW;
 #pragma unroll
       for (int x = 0; x < CK_SPEC; x++) { kk0[x] = ent_key(kp0, sub + 4 * x); pp0[x] = kp0[EW * (sub + 4 * x) + KW]; }
-      n0 = min(nraw, (u32)CL_OVW);
-      if (nraw > (u32)CL_OVW) sover = 1;
+      n0 = min(nraw, lim0);
+      if (nraw > lim0) sover = 1;
       if (sub == 0 && nraw) atomicAdd(&total, nraw);
     } else {
       for (u32 sl = tid; sl < nsl; sl += CK_TPB) {
-        const u32 nraw = C.ovcnt[sbase + sl];
-        if (nraw > (u32)CL_OVW) sover = 1;
+        const uint2 ce = reinterpret_cast<const uint2*>(C.ovcnt)[sbase + sl];
+        const u32 nraw = ce.x;
+        if (nraw > (ce.y ? (u32)(CL_OVW + CL_XS) : (u32)CL_OVW)) sover = 1;
         if (nraw) atomicAdd(&total, nraw);
       }
     }
@@ -856,21 +885,26 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         for (int x = 0; x < CK_SPEC; x++)
           if (sub + 4 * x < n0 && !(npass > 1 && ((cl_mix(kk0[x]) >> 24) & (npass - 1)) != pass)) f(kk0[x], pp0[x]);
         for (u32 e = sub + 4 * CK_SPEC; e < n0; e += 4) {
-          const CKey k = ent_key(kp0, e);
+          const u64* const kp = e < (u32)CL_OVW ? kp0 : kpx0; const u32 ee = e < (u32)CL_OVW ? e : e - (u32)CL_OVW;      // (the slice, then its extension)
+          const CKey k = ent_key(kp, ee);
           if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
-          f(k, kp0[EW * e + KW]);
+          f(k, kp[EW * ee + KW]);
         }
         return;
       }
       for (u32 sl0 = 0; sl0 < nsl; sl0 += CK_TPB / 4) {
         const u32 sl = sl0 + (tid >> 2), sub = tid & 3u;
         if (sl >= nsl) continue;
-        const u32 n = min(C.ovcnt[sbase + sl], (u32)CL_OVW);
-        const u64* kp = C.ovkeys + (sbase + sl) * CL_OVW * EW;
+        const uint2 ce = reinterpret_cast<const uint2*>(C.ovcnt)[sbase + sl];
+        const u32 xb = ce.y;
+        const u32 n = min(ce.x, xb ? (u32)(CL_OVW + CL_XS) : (u32)CL_OVW);
+        const u64* const kpb = C.ovkeys + (sbase + sl) * CL_OVW * EW;
+        const u64* const kpx = C.ovx + (u64)(xb ? xb - 1u : 0u) * EW;
         for (u32 e = sub; e < n; e += 4) {
-          const CKey k = ent_key(kp, e);
+          const u64* const kp = e < (u32)CL_OVW ? kpb : kpx; const u32 ee = e < (u32)CL_OVW ? e : e - (u32)CL_OVW;
+          const CKey k = ent_key(kp, ee);
           if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
-          f(k, kp[EW * e + KW]);
+          f(k, kp[EW * ee + KW]);
         }
       }
     };
@@ -1193,6 +1227,8 @@ u32 cols_block_lists() { return CL_NB; }
 u32 cols_tile_rows(u32 nb) { return std::max(1u, std::min<u32>((u32)CL_RT, (u32)CL_IMG / (4u * std::max(1u, nb)))); }      // (sized for count rows; PA rows need less)
 u64 cols_scratch_keys(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW * EW; }      // (u64 words: key + payload per entry)
 u64 cols_scratch_counts(u32 slots, u32 nblk) { return (u64)slots * CL_HALVES * nblk * CL_NW; }
+// the pool the slices' extensions come from: 1/16 of the slices' room (a sample in 300 of three times the cohort's size fills 1/50)
+u64 cols_ext_entries(u32 slots, u32 nblk) { return std::max<u64>(64 * 1024, (u64)slots * CL_HALVES * nblk * CL_NW * CL_OVW / 16); }
 
 u32 cols_skel_cap() { return SK_CAP; }
 hipError_t launch_cols_skel(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st)
@@ -1205,19 +1241,19 @@ hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const Col
   hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(CP_TPB), 0, st, tasks, subs, cols);
   return hipGetLastError();
 }
-hipError_t launch_merge_cols(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
+template <int MODE, bool EXT>
+static hipError_t launch_merge_cols_as(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
   const int lds = cols_lds_bytes();
-  if (mode == 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_merge_cols<0>, dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
-  } else {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_merge_cols<1>, dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
-  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<MODE, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_merge_cols<MODE, EXT>), dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
   return hipGetLastError();
+}
+hipError_t launch_merge_cols(int mode, int ext, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
+{
+  if (mode == 0) return ext ? launch_merge_cols_as<0, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<0, false>(tasks, cols, items, n_items, ticket, grid_x, st);
+  return ext ? launch_merge_cols_as<1, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<1, false>(tasks, cols, items, n_items, ticket, grid_x, st);
 }
 hipError_t launch_cols_sparse(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)
 {
@@ -1238,7 +1274,7 @@ hipError_t launch_cols_gather(const TaskDev* tasks, const ColsDev* cols, u32 tas
   return hipGetLastError();
 }
 
-static const ColsOps g_ops = {cols_lds_bytes, cols_block_lists, cols_wgs_per_cu, cols_tile_rows, cols_scratch_keys, cols_scratch_counts, cols_skel_cap,
+static const ColsOps g_ops = {cols_lds_bytes, cols_block_lists, cols_wgs_per_cu, cols_tile_rows, cols_scratch_keys, cols_scratch_counts, cols_ext_entries, cols_skel_cap,
                               launch_cols_skel, launch_cols_prep, launch_merge_cols, launch_cols_sparse, cols_dir_bytes, cols_groups, launch_cols_offsets,
                               launch_cols_gather, cols_dbg_dump,
 #ifdef KMX_PHASE_PROF

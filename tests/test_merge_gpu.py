@@ -615,6 +615,48 @@ def test_cols_128bit_keys_cohort(ctx, mode, rec_min):
     res.free()
 
 
+def test_cols_outlier_samples(monkeypatch):
+    """Outlier samples in a cohort (KMX_MERGE_KERNEL unset).  A list of three times the cohort's size fills its wave's set-aside slices:
+    libkmx sees the length and runs k_merge_cols with slice extensions.  Three unrelated lists of the cohort's size among the eight of
+    one wave do the same without a length to see: that batch is handed back (k_merge_rows), the context's next batch runs the build
+    with extensions -- not the back-off.  Results equal the oracle's every time."""
+    torch = pytest.importorskip("torch")
+    from kmtricks_amd import lib
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("one run is enough")
+    monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    dev = torch.device("cuda", 0)
+    N = 300
+    rng = np.random.default_rng(5)
+    def unrelated(n):
+        k = np.unique(rng.integers(0, 1 << 62, n, dtype=np.uint64)).reshape(-1, 1)
+        return (k, rng.integers(1, 9, len(k), dtype=np.uint32))
+    def run(ctx, lists):
+        recs = [lib.pack_records(k, c, 1) for k, c in lists]
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
+        dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+                    soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT)
+        res = ctx.merge_dev([task]); res.wait()
+        eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT)
+        ok = res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
+        kern = res.kernel(); res.free()
+        assert ok
+        return kern
+    ctx = lib.Context(0)
+    long_one = synth_lists(11, N, 20000, 0.97, 200, kw=1); long_one[137] = unrelated(60000)
+    assert run(ctx, long_one) == "k_merge_cols"
+    ctx.close()
+    ctx = lib.Context(0)
+    three = synth_lists(12, N, 20000, 0.97, 200, kw=1)
+    for i in (136, 137, 138): three[i] = unrelated(20000)
+    assert run(ctx, three) == "k_merge_rows"          # handed back: slices full, nothing to see beforehand
+    assert run(ctx, three) == "k_merge_cols"          # ... and the next batch of the context takes the extensions
+    assert run(ctx, synth_lists(13, N, 20000, 0.97, 200, kw=1)) == "k_merge_cols"
+    ctx.close()
+
+
 def test_batch_of_tasks_with_different_list_counts(monkeypatch):
     """One kmx_merge_dev batch of four tasks with 200, 1000, 257 and 600 lists (different block counts, tile sizes and
     row widths side by side), count and PA, libkmx's own kernel choice: every task equals the oracle."""
