@@ -615,7 +615,8 @@ def test_cols_128bit_keys_cohort(ctx, mode, rec_min):
     res.free()
 
 
-def test_cols_outlier_samples(monkeypatch):
+@pytest.mark.parametrize("kw", [1, 2])
+def test_cols_outlier_samples(monkeypatch, kw):
     """Outlier samples in a cohort (KMX_MERGE_KERNEL unset).  A list of three times the cohort's size fills its wave's set-aside slices:
     libkmx sees the length and runs k_merge_cols with slice extensions.  Three unrelated lists of the cohort's size among the eight of
     one wave do the same without a length to see: that batch is handed back (k_merge_rows), the context's next batch runs the build
@@ -630,30 +631,32 @@ def test_cols_outlier_samples(monkeypatch):
     rng = np.random.default_rng(5)
     def unrelated(n):
         k = np.unique(rng.integers(0, 1 << 62, n, dtype=np.uint64)).reshape(-1, 1)
-        return (k, rng.integers(1, 9, len(k), dtype=np.uint32))
+        if kw == 2: k = np.concatenate([rng.integers(0, 1 << 62, (len(k), 1), dtype=np.uint64), k], axis=1)      # (low word first; the high one ascends)
+        return (np.ascontiguousarray(k), rng.integers(1, 9, len(k), dtype=np.uint32))
     def run(ctx, lists):
-        recs = [lib.pack_records(k, c, 1) for k, c in lists]
+        recs = [lib.pack_records(k, c, kw) for k, c in lists]
         offs = np.concatenate([[0], np.cumsum([len(r) for r in recs])])
         dt = torch.from_numpy(np.concatenate(recs).view(np.int32)).to(dev)
         torch.cuda.synchronize()
-        task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
+        task = dict(lists=[(dt.data_ptr() + (8 * kw + 4) * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=kw,
                     soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT)
         res = ctx.merge_dev([task]); res.wait()
-        eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT)
+        eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], kw, [1] * N, 2, 0, orc.MODE_COUNT)
         ok = res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
         kern = res.kernel(); res.free()
         assert ok
         return kern
     ctx = lib.Context(0)
-    long_one = synth_lists(11, N, 20000, 0.97, 200, kw=1); long_one[137] = unrelated(60000)
+    kb = dict(kw=kw, key_bits=62 if kw == 1 else 126)
+    long_one = synth_lists(11, N, 20000, 0.97, 200, **kb); long_one[137] = unrelated(60000)
     assert run(ctx, long_one) == "k_merge_cols"
     ctx.close()
     ctx = lib.Context(0)
-    three = synth_lists(12, N, 20000, 0.97, 200, kw=1)
+    three = synth_lists(12, N, 20000, 0.97, 200, **kb)
     for i in (136, 137, 138): three[i] = unrelated(20000)
     assert run(ctx, three) == "k_merge_rows"          # handed back: slices full, nothing to see beforehand
     assert run(ctx, three) == "k_merge_cols"          # ... and the next batch of the context takes the extensions
-    assert run(ctx, synth_lists(13, N, 20000, 0.97, 200, kw=1)) == "k_merge_cols"
+    assert run(ctx, synth_lists(13, N, 20000, 0.97, 200, **kb)) == "k_merge_cols"
     ctx.close()
 
 
