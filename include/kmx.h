@@ -99,6 +99,9 @@ typedef struct {
   uint32_t        bitw;        /* BFC bits per count (--bitw), else ignored */
   uint64_t        lower, upper;/* BF/BFC: first and last hash of the window (hash.hpp:77-85) */
   uint64_t        rows_hint;   /* COUNT/PA: expected kept rows (0 = let the engine guess) */
+  const uint8_t*  list_on_device; /* kmx_merge_host only: NULL = every lists[i].recs is a host pointer; else [n_lists],
+                                     non-zero = lists[i].recs is a DEVICE pointer already (a list of a kmx_store) and is
+                                     merged where it lies.  Ignored by kmx_merge_dev / kmx_merge. */
 } kmx_merge_task;
 
 /* statistics layout: 6 * n_lists u64, rows in the order of merge.hpp:72-83:
@@ -124,8 +127,10 @@ double   kmx_result_kernel_ms(kmx_merge_result* r);
 /* duration in ms of a separate transpose pass behind the merge; < 0 when there is none (KMX_MODE_BFT results come out
  * of k_merge_bft sample-major already: kmx_result_kernel_ms covers k_bf_rowrec + k_merge_bft) */
 double   kmx_result_transpose_ms(kmx_merge_result* r);
-/* BF / BFC / BFT: DEVICE pointer to the task's dense body (rows * row_bytes bytes), valid until kmx_result_free;
- * NULL for COUNT / PA results (their rows lie in segments: use kmx_result_copy_body) */
+/* DEVICE pointer to the task's body in file order (rows * row_bytes bytes), valid until kmx_result_free.  BF / BFC / BFT
+ * bodies are dense as the kernel leaves them; COUNT / PA rows are put in ascending key order on the device the first time
+ * the body is asked for (rows of k_merge_rows / k_merge_pivot lie in arena segments, those of k_merge_cols in two ascending
+ * lists): a caller can then bring it to the host in pieces (kmx_copy_to_host) or send it from where it lies. */
 const void* kmx_result_body_dev(kmx_merge_result* r, uint32_t task);
 const char* kmx_result_kernel(const kmx_merge_result* r);
 uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA), window rows (BF/BFC), round_up8(N) (BFT) */
@@ -134,9 +139,10 @@ uint64_t kmx_result_body_bytes(const kmx_merge_result* r, uint32_t task);  /* ro
 /* algorithmic bytes moved for this task: input records + output rows (DESIGN.md roofline) */
 uint64_t kmx_result_algo_bytes(const kmx_merge_result* r, uint32_t task);
 /* copies the matrix file body (rows in ascending key order, exactly what the
- * reference's writer streams after its header) into host memory */
+ * reference's writer streams after its header) into host memory -- by DMA straight into host_dst when that is
+ * page-locked (kmx_alloc_pinned), through a pinned staging buffer otherwise */
 int kmx_result_copy_body(kmx_merge_result* r, uint32_t task, void* host_dst, uint64_t dst_bytes);
-/* BF / BFC / BFT: the same body into DEVICE memory of the caller (e.g. a buffer an RCCL collective sends from) */
+/* the same body into DEVICE memory of the caller (e.g. a buffer an RCCL collective sends from) */
 int kmx_result_copy_body_dev(kmx_merge_result* r, uint32_t task, void* dev_dst, uint64_t dst_bytes);
 int kmx_result_copy_stats(kmx_merge_result* r, uint32_t task, uint64_t* host_stats /* 6 * n_lists */);
 void kmx_result_free(kmx_merge_result* r);
@@ -239,6 +245,43 @@ int kmx_count_reads(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, ui
                     int hash_mode, uint64_t window, uint32_t hard_min,
                     uint64_t** keys, uint32_t** counts, uint64_t* n_out, uint64_t* out_kmers,
                     uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info, kmx_superk_stats* stats);
+
+/* ---- count lists that stay in HBM between the count and the merge stage ------------------------------------------
+ * The reference's CountTask writes counts/partition_<p>/<id>.kmer and its merge task reads them back
+ * (task.hpp:367-392, 690-743), erasing them afterwards unless --keep-tmp (task.hpp:676-688).  On a GPU with 288 GB of
+ * HBM the lists of a whole cohort fit: a kmx_store is an arena of device memory on one GPU that holds packed
+ * (key, count) records -- exactly a .kmer file body, what kmx_merge_dev takes -- until the store is destroyed.
+ * Thread-safe (the contexts of several host threads append to one store); limit_bytes = 0: 60 % of the device's
+ * memory.  A store on another GPU than the counting context is filled with a peer copy over xGMI. */
+typedef struct kmx_store kmx_store;
+int      kmx_store_create(int device, uint64_t limit_bytes, kmx_store** out);
+void     kmx_store_destroy(kmx_store* s);
+uint64_t kmx_store_used(const kmx_store* s);
+uint64_t kmx_store_limit(const kmx_store* s);
+
+/* kmx_superk_stats without the host arithmetic: the device's own u32 tables of ONE call, copied (not added) into the
+ * caller's buffers -- best pinned (kmx_alloc_pinned).  part_radix: [nb_parts][5][256] kx-mers of x + 1 k-mers per radix
+ * (PartiInfoFile's nbk_per_radix; nb_kmers / nb_kxmers of a partition are sums over it); minim_superks / minim_kmers:
+ * [4^m].  Any pointer may be NULL.  nb_superk: super-k-mers of the call. */
+typedef struct {
+  uint32_t* part_radix;
+  uint32_t* minim_superks;
+  uint32_t* minim_kmers;
+  uint64_t  nb_superk;
+} kmx_superk_raw;
+
+/* kmx_count_reads with the results left on the device: partition p's (key, count) records -- ascending, packed as a
+ * .kmer body with 4-byte counts -- go to stores[p % n_stores] (the merge stage shards partitions round-robin over the
+ * GPUs: the list already lies where it will be merged), lists[p] = {device pointer, records}.  stats (added to, u64)
+ * or raw (copied, u32) or neither.  KMX_E_NOMEM when a store is full (nothing is left allocated for this call). */
+int kmx_count_reads_dev(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                        uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart, uint32_t nb_parts,
+                        int hash_mode, uint64_t window, uint32_t hard_min,
+                        kmx_store* const* stores, uint32_t n_stores, kmx_list* lists, uint64_t* out_kmers,
+                        uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info,
+                        kmx_superk_stats* stats, kmx_superk_raw* raw);
+/* device memory (a list of a store, a result body) into host memory; blocks until it is there */
+int kmx_copy_to_host(kmx_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
 
 /* The abundance histogram of a sample (`--hist`): the reference's KHist (histogram.hpp:35-68) is fed EVERY distinct k-mer /
  * hash of the sample with its count, before the hard-min filter (count_processor.hpp:61, 135), one clone per partition,

@@ -400,13 +400,82 @@ __global__ void k_part_bounds(const u16* __restrict__ part_sorted, u32 n, u32 n_
   bounds[p] = lo;
 }
 
+// ---- results left on the device (kmx_count_reads_dev): the kept (key, count) pairs -- two arrays, partition after partition --
+//      become packed records, the body of a .kmer file with 4-byte counts (io/kmer_file.hpp:102-108), in the stores of the GPUs
+//      that will merge them: partition p -> stores[p % G], the partitions of one store back to back (one copy per GPU) ----
+struct CountOut {
+  uint64_t** keys = nullptr; uint32_t** counts = nullptr; uint64_t* n_out = nullptr;          // host arrays, or
+  kmx_store* const* stores = nullptr; u32 n_stores = 0; kmx_list* lists = nullptr;           // device stores
+  bool dev() const { return lists != nullptr; }
+};
+
+template <typename KeyT>
+__global__ __launch_bounds__(256)
+void k_pack_recs(const KeyT* __restrict__ keys, const u32* __restrict__ cnt, u32 n, const u32* __restrict__ bounds, u32 n_parts,
+                 const u64* __restrict__ pdst, u8* __restrict__ out)
+{
+  constexpr u32 KWD = sizeof(KeyT) / 4;      // key dwords
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 lo = 0, hi = n_parts;                  // the last partition that starts at or before i (empty ones in front of it share its start)
+  while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (bounds[mid] <= i) lo = mid; else hi = mid; }
+  u32* o = reinterpret_cast<u32*>(out + (pdst[lo] + (i - bounds[lo])) * (u64)(sizeof(KeyT) + 4));
+  const KeyT k = keys[i];
+#pragma unroll
+  for (u32 w = 0; w < KWD; w++) o[w] = (u32)(k >> (32 * w));
+  o[KWD] = cnt[i];
+}
+
+template <typename KeyT>
+static int pack_to_stores(kmx_ctx* ctx, const KeyT* d_k, const u32* d_c, const std::vector<u32>& bounds /* n_parts + 1 */, u32 n_parts, const CountOut& out)
+{
+  const u32 kept = bounds[n_parts], G = out.n_stores;
+  const size_t RB = sizeof(KeyT) + 4;
+  for (u32 p = 0; p < n_parts; p++) { out.lists[p].recs = nullptr; out.lists[p].n = bounds[p + 1] - bounds[p]; }
+  if (!kept) return KMX_OK;
+  std::vector<u64> pdst(n_parts), doff((size_t)G + 1, 0);
+  { u64 at = 0; for (u32 d = 0; d < G; d++) { doff[d] = at; for (u32 p = d; p < n_parts; p += G) { pdst[p] = at; at += bounds[p + 1] - bounds[p]; } } doff[G] = at; }
+  hipStream_t st = ctx->stream;
+  const bool direct = G == 1 && out.stores[0]->device == ctx->device;      // one GPU: packed straight into the store
+  u8* d_pack = direct ? (u8*)out.stores[0]->alloc((size_t)kept * RB) : (u8*)ctx->dalloc((size_t)kept * RB);
+  u32* d_bounds = (u32*)ctx->dalloc(((size_t)n_parts + 1) * 4);
+  u64* d_pdst = (u64*)ctx->dalloc((size_t)n_parts * 8);
+  auto release = [&]() { if (!direct) ctx->dfree(d_pack); ctx->dfree(d_bounds); ctx->dfree(d_pdst); };
+  if (!d_pack || !d_bounds || !d_pdst) { release(); return ctx->fail(KMX_E_NOMEM, direct && !d_pack ? "count store is full" : "count: device allocation failed"); }
+  hipError_t e;
+  if ((e = hipMemcpyAsync(d_bounds, bounds.data(), ((size_t)n_parts + 1) * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(d_pdst, pdst.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count pack upload: ") + hipGetErrorString(e)); }
+  hipLaunchKernelGGL((k_pack_recs<KeyT>), dim3((kept + 255) / 256), dim3(256), 0, st, d_k, d_c, kept, d_bounds, n_parts, d_pdst, d_pack);
+  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_pack_recs: ") + hipGetErrorString(e)); }
+  int rc = KMX_OK;
+  for (u32 d = 0; d < G && rc == KMX_OK; d++) {
+    const size_t nb = (size_t)(doff[d + 1] - doff[d]) * RB;
+    if (!nb) continue;
+    u8* dst = d_pack;
+    if (!direct) {
+      kmx_store* S = out.stores[d];
+      dst = (u8*)S->alloc(nb);
+      if (!dst) { rc = ctx->fail(KMX_E_NOMEM, "count store is full"); break; }
+      // the store of another GPU is filled over xGMI (hipMemcpyPeerAsync stages through the host when the two have no peer access)
+      e = S->device == ctx->device ? hipMemcpyAsync(dst, d_pack + doff[d] * RB, nb, hipMemcpyDeviceToDevice, st)
+                                   : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
+      if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }
+    }
+    for (u32 p = d; p < n_parts; p += G) if (out.lists[p].n) out.lists[p].recs = dst + (pdst[p] - doff[d]) * RB;
+  }
+  if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == KMX_OK) rc = ctx->fail(KMX_E_HIP, std::string("count pack: ") + hipGetErrorString(e));
+  release();
+  return rc;
+}
+
 // ---- partition-local sample sort + run-length count (count_sort.hpp): keys grouped by partition in d_keys, partition p =
 //      keys [kmoff[p], kmoff[p + 1]).  Returns KMX_OK, a negative error, or 1 when a bucket would not fit the LDS (the caller
 //      then uses the library sort: d_keys is still untouched at that point). ----
 template <typename KeyT>
 static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, const std::vector<u64>& kmoff, u32 n_parts, u32 hard_min,
-                                uint64_t** keys, uint32_t** counts, uint64_t* n_out)
+                                const CountOut& out)
 {
+  uint64_t** keys = out.keys; uint32_t** counts = out.counts; uint64_t* n_out = out.n_out;
   const char* force = getenv("KMX_COUNT_SORT");
   if (force && !strcmp(force, "library")) return 1;
   const u64 total = kmoff[n_parts];
@@ -457,6 +526,17 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   const u32 kept = koff[TB];
   KeyT* d_ok = d_bkeys;                    // (and the buckets are dead behind the sort)
   u32* d_oc = (u32*)dal(4 * (size_t)std::max<u32>(kept, 1));
+  if (out.dev()) {      // the pairs stay on the device, packed as records in the stores of the GPUs that merge them
+    if (!d_oc) { release(); return ctx->fail(KMX_E_NOMEM, "count sort: allocation failed"); }
+    if (kept) hipLaunchKernelGGL((k_cs_compact<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_tk, d_tc, d_boff, d_koff, d_ok, d_oc);
+    std::vector<u32> bounds((size_t)n_parts + 1);
+    for (u32 p = 0; p < n_parts; p++) bounds[p] = koff[parts[p].bucket0];
+    bounds[n_parts] = kept;
+    const int rc = pack_to_stores<KeyT>(ctx, d_ok, d_oc, bounds, n_parts, out);
+    release();
+    clk.mark("pack");
+    return rc;
+  }
   KeyT* h_k = kept ? (KeyT*)ctx->halloc((size_t)kept * sizeof(KeyT)) : nullptr;
   u32* h_c = kept ? (u32*)ctx->halloc((size_t)kept * 4) : nullptr;
   auto hrel = [&]() { ctx->hfree(h_k); ctx->hfree(h_c); };
@@ -497,8 +577,9 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
 // regrouped by partition (stable, so each partition's keys stay ascending).
 template <typename KeyT>
 static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kpart, u32 total, u32 n_parts, unsigned key_bits, u32 hard_min,
-                          uint64_t** keys, uint32_t** counts, uint64_t* n_out)
+                          const CountOut& out)
 {
+  uint64_t** keys = out.keys; uint32_t** counts = out.counts; uint64_t* n_out = out.n_out;
   hipStream_t st = ctx->stream;
   KeyT* d_sorted = (KeyT*)ctx->dalloc((size_t)total * sizeof(KeyT));
   u16* d_spart = (u16*)ctx->dalloc((size_t)total * 2);
@@ -562,6 +643,11 @@ static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kp
     if ((e = hipMemcpyAsync(bounds.data(), d_bounds, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   }
   clk.mark("regroup");
+  if (out.dev()) {
+    const int rc = pack_to_stores<KeyT>(ctx, d_ok, d_oc, bounds, n_parts, out);
+    release();
+    return rc;
+  }
   // one D2H into pinned staging, then the per-partition output arrays are filled by a few host threads
   // (first-touch page faults of fresh allocations dominate a single-threaded copy)
   KeyT* h_k = kept ? (KeyT*)ctx->halloc((size_t)kept * sizeof(KeyT)) : nullptr;
@@ -686,12 +772,13 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
     if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
   int rc;
   // partition-local sample sort first (count_sort.hpp); the library sort when a bucket would not fit the LDS
-  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, km_base, n_parts, hard_min, keys, counts, n_out);
-  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, km_base, n_parts, hard_min, keys, counts, n_out);
+  CountOut co; co.keys = keys; co.counts = counts; co.n_out = n_out;
+  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, km_base, n_parts, hard_min, co);
+  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, km_base, n_parts, hard_min, co);
   if (rc == 1) {
     for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
-    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), hard_min, keys, counts, n_out);
-    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), hard_min, keys, counts, n_out);
+    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), hard_min, co);
+    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), hard_min, co);
   }
   release();
   if (rc != KMX_OK) for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
@@ -713,7 +800,11 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
   const int kw = (k + 31) / 32;
   if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one batch: split it");
   StageClock clk(ctx->stream, "count_reads");
-  if (total == 0) { for (u32 p = 0; p < n_parts; p++) { rq.keys[p] = (uint64_t*)malloc(8); rq.counts[p] = (uint32_t*)malloc(4); rq.n_out[p] = 0; } return KMX_OK; }
+  CountOut co; co.keys = rq.keys; co.counts = rq.counts; co.n_out = rq.n_out; co.stores = rq.stores; co.n_stores = rq.n_stores; co.lists = rq.lists;
+  if (total == 0) {
+    for (u32 p = 0; p < n_parts; p++) { if (co.dev()) { co.lists[p].recs = nullptr; co.lists[p].n = 0; } else { rq.keys[p] = (uint64_t*)malloc(8); rq.counts[p] = (uint32_t*)malloc(4); rq.n_out[p] = 0; } }
+    return KMX_OK;
+  }
   const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
   u32* d_ro = (u32*)ctx->dalloc((size_t)nr * 4), *d_ko = (u32*)ctx->dalloc((size_t)nr * 4);
   u64* d_pid = (u64*)ctx->dalloc((size_t)n_parts * 8);
@@ -739,12 +830,12 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
     if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
   int rc;
   std::vector<u64> kmoff(part_kmer_off, part_kmer_off + n_parts + 1);
-  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, kmoff, n_parts, rq.hard_min, rq.keys, rq.counts, rq.n_out);
-  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, kmoff, n_parts, rq.hard_min, rq.keys, rq.counts, rq.n_out);
+  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, kmoff, n_parts, rq.hard_min, co);
+  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, kmoff, n_parts, rq.hard_min, co);
   if (rc == 1) {
-    for (u32 p = 0; p < n_parts; p++) { free(rq.keys[p]); free(rq.counts[p]); rq.keys[p] = nullptr; rq.counts[p] = nullptr; rq.n_out[p] = 0; }
-    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
-    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), rq.hard_min, rq.keys, rq.counts, rq.n_out);
+    if (!co.dev()) for (u32 p = 0; p < n_parts; p++) { free(rq.keys[p]); free(rq.counts[p]); rq.keys[p] = nullptr; rq.counts[p] = nullptr; rq.n_out[p] = 0; }
+    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), rq.hard_min, co);
+    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), rq.hard_min, co);
   }
   release();
   return rc;

@@ -112,6 +112,68 @@ extern "C" void* kmx_alloc_pinned(size_t bytes)
   return p;
 }
 extern "C" void kmx_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+// ---- kmx_store: count lists resident in HBM between the count and the merge stage ---------------------------------
+void* kmx_store::alloc(size_t bytes)
+{
+  bytes = (bytes + 255) / 256 * 256;
+  if (bytes == 0) bytes = 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (limit && used + bytes > limit) return nullptr;
+  for (auto& c : chunks) if (c.cap - c.fill >= bytes) { void* p = c.p + c.fill; c.fill += bytes; used += bytes; return p; }
+  int cur = -1; (void)hipGetDevice(&cur);
+  if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
+  size_t cap = std::max(bytes, chunk_bytes);
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cap);
+  if (e != hipSuccess && cap > bytes) { cap = bytes; e = hipMalloc(&p, cap); }      // (the device is nearly full: an exact block)
+  if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+  if (e != hipSuccess) return nullptr;
+  chunks.push_back({(u8*)p, cap, bytes});
+  used += bytes;
+  return p;
+}
+extern "C" int kmx_store_create(int device, uint64_t limit_bytes, kmx_store** out)
+{
+  if (!out) return KMX_E_INVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_err = "kmx_store_create: no HIP device; libkmx has no CPU fallback"; return KMX_E_NODEVICE; }
+  if (device < 0 || device >= n) { g_create_err = "kmx_store_create: device index out of range"; return KMX_E_INVAL; }
+  int cur = -1; (void)hipGetDevice(&cur);
+  if (hipSetDevice(device) != hipSuccess) { g_create_err = "kmx_store_create: hipSetDevice failed"; return KMX_E_NODEVICE; }
+  size_t fr = 0, tot = 0;
+  (void)hipMemGetInfo(&fr, &tot);
+  if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+  kmx_store* s = new kmx_store();
+  s->device = device;
+  s->limit = limit_bytes ? (size_t)limit_bytes : (size_t)(tot / 10 * 6);
+  s->chunk_bytes = (size_t)256 << 20;
+  *out = s;
+  return KMX_OK;
+}
+extern "C" void kmx_store_destroy(kmx_store* s)
+{
+  if (!s) return;
+  int cur = -1; (void)hipGetDevice(&cur);
+  (void)hipSetDevice(s->device);
+  (void)hipDeviceSynchronize();
+  for (auto& c : s->chunks) (void)hipFree(c.p);
+  if (cur >= 0 && cur != s->device) (void)hipSetDevice(cur);
+  delete s;
+}
+extern "C" uint64_t kmx_store_used(const kmx_store* s) { return s ? s->used : 0; }
+extern "C" uint64_t kmx_store_limit(const kmx_store* s) { return s ? s->limit : 0; }
+extern "C" int kmx_copy_to_host(kmx_ctx* ctx, void* dst, const void* src, uint64_t bytes)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!bytes) return KMX_OK;
+  if (!dst || !src) return ctx->fail(KMX_E_INVAL, "kmx_copy_to_host: null pointer");
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  KMX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->copy));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+  return KMX_OK;
+}
+
 extern "C" int kmx_set_profiling(kmx_ctx* ctx, int on) { if (!ctx) return KMX_E_INVAL; ctx->profiling = on != 0; return KMX_OK; }
 
 // ---- merge ---------------------------------------------------------------------------------------------
@@ -140,6 +202,8 @@ struct TaskHost {
   size_t o_spdir = 0;           // ... offset of (the extension pool's cursor and) that directory in d_ov
   size_t o_ovx = 0; u32 xcap = 0;   // ... the pool the slices' extensions come from
   u64 sparse_rows = 0;          // rows k_cols_sparse added behind the row keys' rows
+  u8* d_body = nullptr;         // COUNT/PA: the body assembled in file order on the device (kmx_result_body_dev), when it is not d_out itself
+  bool body_ready = false;
   std::vector<u32> src;         // (row-key merge of a task: which of the task's lists it merges)
   int kernel = 0;               // the kernel that completed (or is to complete) the task: 0 rows, 1 pivot, 2 cols
 };
@@ -862,10 +926,79 @@ extern "C" double kmx_result_transpose_ms(kmx_merge_result* R)
   if (hipEventElapsedTime(&ms, R->ev1, R->ev2) != hipSuccess) return -1.0;
   return (double)ms;
 }
+// COUNT/PA rows of k_merge_rows / k_merge_pivot lie in arena segments (one per chunk a range claimed); the file order is the
+// directory sorted by (range, sequence).  One workgroup per segment copies its rows to their place in the body.
+struct SegCopy { u64 src, dst, bytes; };
+__global__ __launch_bounds__(256) void k_segs_gather(const SegCopy* __restrict__ sc, const u8* __restrict__ arena, u8* __restrict__ body)
+{
+  const SegCopy c = sc[blockIdx.x];
+  const u8* s = arena + c.src; u8* d = body + c.dst;
+  // rows are 4-byte aligned at both ends (row_bytes is a multiple of 4 for COUNT rows; PA rows may not be: bytes then)
+  if ((((uintptr_t)s | (uintptr_t)d | c.bytes) & 3u) == 0) {
+    const u32* s4 = reinterpret_cast<const u32*>(s); u32* d4 = reinterpret_cast<u32*>(d);
+    for (u64 i = threadIdx.x; i < c.bytes / 4; i += 256) d4[i] = s4[i];
+  } else for (u64 i = threadIdx.x; i < c.bytes; i += 256) d[i] = s[i];
+}
+
+// the body of a COUNT/PA task in file order, on the device: d_out itself when the rows already lie that way (one segment from
+// row 0: k_merge_cols without rows outside the row keys), else assembled once into d_body (k_cols_gather / k_segs_gather)
+static int assemble_body(kmx_merge_result* R, uint32_t t)
+{
+  kmx_ctx* ctx = R->ctx;
+  TaskHost& H = R->tasks[t];
+  if (H.body_ready) return KMX_OK;
+  const u64 body = H.rows * H.row_bytes;
+  if (body == 0) { H.body_ready = true; return KMX_OK; }
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  const ColsOps& CO = cols_ops((int)H.kw);
+  if (H.kernel == 2 && H.sparse_rows) {
+    const u32 ng = CO.groups(H.slots_cap);
+    u8* d_body = (u8*)ctx->dalloc(body);
+    u64* d_goff = (u64*)ctx->dalloc((size_t)ng * 8);
+    if (!d_body || !d_goff) { ctx->dfree(d_body); ctx->dfree(d_goff); return ctx->fail(KMX_E_NOMEM, "body assembly allocation failed"); }
+    const TaskDev* d_tasks = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_tasks);
+    const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
+    hipError_t e = CO.offsets(d_cols, t, d_goff, ctx->copy);
+    if (e == hipSuccess) e = CO.gather(d_tasks, d_cols, t, ng, d_goff, d_body, ctx->copy);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy);
+    ctx->dfree(d_goff);
+    if (e != hipSuccess) { ctx->dfree(d_body); return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); }
+    H.d_body = d_body; H.body_ready = true;
+    return KMX_OK;
+  }
+  std::vector<Seg> segs(H.nsegs);
+  KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->copy));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.range != b.range ? a.range < b.range : a.seq < b.seq; });
+  const u64 arena = H.arena_rows * H.row_bytes;
+  std::vector<SegCopy> sc; sc.reserve(segs.size());
+  u64 done = 0; bool in_place = true;
+  for (const Seg& g : segs) {
+    const u64 nb = (u64)g.nrows * H.row_bytes;
+    if (g.row_off * H.row_bytes + nb > arena || done + nb > body) return ctx->fail(KMX_E_HIP, "corrupt segment directory");
+    if (nb) { in_place = in_place && g.row_off * H.row_bytes == done; sc.push_back({g.row_off * H.row_bytes, done, nb}); }
+    done += nb;
+  }
+  if (done != body) return ctx->fail(KMX_E_HIP, "segment directory does not cover the arena");
+  if (in_place) { H.body_ready = true; return KMX_OK; }      // (d_out is the body)
+  u8* d_body = (u8*)ctx->dalloc(body);
+  SegCopy* d_sc = (SegCopy*)ctx->dalloc(sc.size() * sizeof(SegCopy));
+  if (!d_body || !d_sc) { ctx->dfree(d_body); ctx->dfree(d_sc); return ctx->fail(KMX_E_NOMEM, "body assembly allocation failed"); }
+  hipError_t e = hipMemcpyAsync(d_sc, sc.data(), sc.size() * sizeof(SegCopy), hipMemcpyHostToDevice, ctx->copy);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_segs_gather, dim3((unsigned)sc.size()), dim3(256), 0, ctx->copy, d_sc, H.d_out, d_body); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy);
+  ctx->dfree(d_sc);
+  if (e != hipSuccess) { ctx->dfree(d_body); return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); }
+  H.d_body = d_body; H.body_ready = true;
+  return KMX_OK;
+}
+
 extern "C" const void* kmx_result_body_dev(kmx_merge_result* R, uint32_t t)
 {
-  if (!R || t >= R->tasks.size() || !R->is_bf || kmx_result_wait(R) != KMX_OK) return nullptr;
-  return R->tasks[t].d_out;
+  if (!R || t >= R->tasks.size() || kmx_result_wait(R) != KMX_OK) return nullptr;
+  if (R->is_bf) return R->tasks[t].d_out;
+  if (assemble_body(R, t) != KMX_OK) return nullptr;
+  return R->tasks[t].d_body ? R->tasks[t].d_body : R->tasks[t].d_out;
 }
 
 extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, uint64_t dst_bytes)
@@ -884,43 +1017,24 @@ extern "C" int kmx_result_copy_body(kmx_merge_result* R, uint32_t t, void* dst, 
     KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
     return KMX_OK;
   }
-  const ColsOps& CO = cols_ops((int)H.kw);
-  if (H.kernel == 2 && H.sparse_rows) {
-    // k_merge_cols + k_cols_sparse: the row keys' rows and the rows of the keys outside them are interleaved by key on the
-    // device (k_cols_offsets + k_cols_gather), the body then comes back in one copy
-    const u32 ng = CO.groups(H.slots_cap);
-    u8* d_body = (u8*)ctx->dalloc(body);
-    u64* d_goff = (u64*)ctx->dalloc((size_t)ng * 8);
-    u8* stage = (u8*)ctx->halloc(body);
-    struct Rel2 { kmx_ctx* c; void* a; void* b; void* h; ~Rel2() { c->dfree(a); c->dfree(b); c->hfree(h); } } rel2{ctx, d_body, d_goff, stage};
-    if (!d_body || !d_goff || !stage) return ctx->fail(KMX_E_NOMEM, "body assembly allocation failed");
-    const TaskDev* d_tasks = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_tasks);
-    const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
-    KMX_HIP(ctx, CO.offsets(d_cols, t, d_goff, ctx->copy));
-    KMX_HIP(ctx, CO.gather(d_tasks, d_cols, t, ng, d_goff, d_body, ctx->copy));
-    KMX_HIP(ctx, hipMemcpyAsync(stage, d_body, body, hipMemcpyDeviceToHost, ctx->copy));
+  // COUNT/PA: the body is put in file order on the device (assemble_body), then comes back in one copy -- straight into the
+  // caller's buffer when that is page-locked (kmx_alloc_pinned), through pinned staging otherwise
+  if ((rc = assemble_body(R, t)) != KMX_OK) return rc;
+  const u8* src = H.d_body ? H.d_body : H.d_out;
+  hipPointerAttribute_t at;
+  const bool pinned = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();
+  if (pinned) {
+    KMX_HIP(ctx, hipMemcpyAsync(dst, src, body, hipMemcpyDeviceToHost, ctx->copy));
     KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
-    memcpy(dst, stage, body);
     return KMX_OK;
   }
-  std::vector<Seg> segs(H.nsegs);
-  KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->copy));
-  const u64 arena = H.arena_rows * H.row_bytes;
-  u8* tmp = (u8*)ctx->halloc(arena);          // pinned staging (pooled): the arena comes back at PCIe speed
-  if (!tmp) return ctx->fail(KMX_E_NOMEM, "host staging allocation failed");
-  struct Rel { kmx_ctx* c; u8* p; ~Rel() { c->hfree(p); } } rel{ctx, tmp};
-  KMX_HIP(ctx, hipMemcpyAsync(tmp, H.d_out, arena, hipMemcpyDeviceToHost, ctx->copy));
+  u8* stage = (u8*)ctx->halloc(body);
+  if (!stage) return ctx->fail(KMX_E_NOMEM, "host staging allocation failed");
+  struct Rel { kmx_ctx* c; u8* p; ~Rel() { c->hfree(p); } } rel{ctx, stage};
+  KMX_HIP(ctx, hipMemcpyAsync(stage, src, body, hipMemcpyDeviceToHost, ctx->copy));
   KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
-  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.range != b.range ? a.range < b.range : a.seq < b.seq; });
-  u8* d = (u8*)dst;
-  u64 done = 0;
-  for (const Seg& s : segs) {
-    const u64 nb = (u64)s.nrows * H.row_bytes;
-    if (s.row_off * H.row_bytes + nb > arena || done + nb > body) return ctx->fail(KMX_E_HIP, "corrupt segment directory");
-    memcpy(d + done, tmp + s.row_off * H.row_bytes, nb);
-    done += nb;
-  }
-  if (done != body) return ctx->fail(KMX_E_HIP, "segment directory does not cover the arena");
+  memcpy(dst, stage, body);
   return KMX_OK;
 }
 
@@ -928,14 +1042,14 @@ extern "C" int kmx_result_copy_body_dev(kmx_merge_result* R, uint32_t t, void* d
 {
   if (!R || t >= R->tasks.size()) return KMX_E_INVAL;
   kmx_ctx* ctx = R->ctx;
-  if (!R->is_bf) return ctx->fail(KMX_E_UNSUPPORTED, "kmx_result_copy_body_dev: COUNT / PA rows lie in segments (use kmx_result_copy_body)");
   int rc = kmx_result_wait(R);
   if (rc != KMX_OK) return rc;
   const u64 body = kmx_result_body_bytes(R, t);
   if (dst_bytes < body) return ctx->fail(KMX_E_INVAL, "destination too small");
   if (!body) return KMX_OK;
   KMX_HIP(ctx, hipSetDevice(ctx->device));
-  KMX_HIP(ctx, hipMemcpyAsync(dev_dst, R->tasks[t].d_out, body, hipMemcpyDeviceToDevice, ctx->copy));
+  if (!R->is_bf && (rc = assemble_body(R, t)) != KMX_OK) return rc;
+  KMX_HIP(ctx, hipMemcpyAsync(dev_dst, R->tasks[t].d_body ? R->tasks[t].d_body : R->tasks[t].d_out, body, hipMemcpyDeviceToDevice, ctx->copy));
   KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
   return KMX_OK;
 }
@@ -981,7 +1095,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   const ColsOps& CO = cols_ops((int)R->tasks[0].kw);
   if (!R->is_bf) { if (R->use_cols) { if (CO.phase_prof_dump) CO.phase_prof_dump(); } else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
-  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); }
+  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); ctx->dfree(H.d_body); }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);
@@ -1014,13 +1128,15 @@ extern "C" int kmx_merge_host(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_
       if (!K.lists[i].recs) return ctx->fail(KMX_E_INVAL, "null record pointer");
       const uintptr_t a = (uintptr_t)K.lists[i].recs;
       if (a & 3u) return ctx->fail(KMX_E_INVAL, "record pointers must be 4-byte aligned");
+      if (K.list_on_device && K.list_on_device[i]) continue;      // (resident already: a kmx_store list)
       lo = std::min(lo, a); hi = std::max(hi, (uintptr_t)(a + nb)); sum += nb; nl++;
     }
   }
   const bool one_span = nl && (u64)(hi - lo) <= sum + sum / 4 + 4096;
   u64 total = 0;
   if (one_span) total = hi - lo;
-  else for (u32 t = 0; t < n_tasks; t++) for (u32 i = 0; i < tasks[t].n_lists; i++) total += align_up(tasks[t].lists[i].n * (tasks[t].key_words * 8 + 4), 256);
+  else for (u32 t = 0; t < n_tasks; t++) for (u32 i = 0; i < tasks[t].n_lists; i++)
+    if (!(tasks[t].list_on_device && tasks[t].list_on_device[i])) total += align_up(tasks[t].lists[i].n * (tasks[t].key_words * 8 + 4), 256);
   u8* d_in = (u8*)ctx->dalloc(total ? total : 256);
   if (!d_in) return ctx->fail(KMX_E_NOMEM, "input upload allocation failed");
   std::vector<kmx_merge_task> dt(tasks, tasks + n_tasks);
@@ -1035,14 +1151,15 @@ extern "C" int kmx_merge_host(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_
     for (u32 i = 0; i < K.n_lists && e == hipSuccess; i++) {
       const u64 nb = K.lists[i].n * rb;
       dl[t][i].n = K.lists[i].n;
-      if (one_span) dl[t][i].recs = nb ? d_in + ((uintptr_t)K.lists[i].recs - lo) : d_in;
+      if (K.list_on_device && K.list_on_device[i]) dl[t][i].recs = K.lists[i].recs;
+      else if (one_span) dl[t][i].recs = nb ? d_in + ((uintptr_t)K.lists[i].recs - lo) : d_in;
       else {
         dl[t][i].recs = d_in + off;
         if (nb) e = hipMemcpyAsync(d_in + off, K.lists[i].recs, nb, hipMemcpyHostToDevice, ctx->up);
         off += align_up(nb, 256);
       }
     }
-    dt[t].lists = dl[t].data();
+    dt[t].lists = dl[t].data(); dt[t].list_on_device = nullptr;
   }
   hipEvent_t ev = nullptr;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);

@@ -60,12 +60,25 @@ hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hip
 
 // ---- split -> count without the super-k-mer streams leaving HBM (kmx_count_reads): superk.hip hands the packed, partition-ordered
 //      record stream, every record's (k-mers << 32 | bytes) prefix and partition to count.hip ----
-struct kmx_count_req { kmx::u32 k; int hash_mode; kmx::u64 window; kmx::u32 hard_min; uint64_t** keys; uint32_t** counts; uint64_t* n_out; };
+//      Results: host arrays (keys / counts / n_out, kmx_count_reads) or packed records in device stores (lists, kmx_count_reads_dev).
+struct kmx_count_req { kmx::u32 k; int hash_mode; kmx::u64 window; kmx::u32 hard_min; uint64_t** keys; uint32_t** counts; uint64_t* n_out;
+                       kmx_store* const* stores = nullptr; kmx::u32 n_stores = 0; kmx_list* lists = nullptr; };
 int kmx_count_from_device(kmx_ctx* ctx, const kmx::u8* d_recs, const kmx::u64* d_prefix, const kmx::u16* d_part, kmx::u32 n_recs,
                           kmx::u64 total_kmers, kmx::u32 n_parts, const kmx::u64* part_kmer_off /* n_parts + 1, host */, const kmx_count_req& rq);
 
 // ---- context -------------------------------------------------------------------------------------
 struct kmx_pool_block { void* p; size_t bytes; bool used; };
+
+// ---- device arena of count lists (kmx_store_*): chunks of HBM on one GPU, bump-allocated, freed together ----
+#include <mutex>
+struct kmx_store {
+  int device = 0;
+  size_t limit = 0, used = 0, chunk_bytes = 0;
+  struct Chunk { kmx::u8* p; size_t cap, fill; };
+  std::vector<Chunk> chunks;
+  std::mutex mu;
+  void* alloc(size_t bytes);      // 256-byte aligned; nullptr: over the limit or out of device memory
+};
 
 struct kmx_ctx {
   int device = 0;

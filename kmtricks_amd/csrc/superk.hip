@@ -312,40 +312,53 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
 
 using namespace kmx;
 
-// stats tables of one call (u32 on the device, added to the caller's u64 arrays)
+// stats tables of one call (u32 on the device): added to the caller's u64 arrays (kmx_superk_stats), or copied as they are into
+// the caller's u32 buffers (kmx_superk_raw: no host arithmetic, one synchronisation)
 struct StatsDev {
   SkStats S{nullptr, nullptr, nullptr, nullptr};
-  kmx_superk_stats* dst = nullptr; u32 nb_parts = 0; u64 nm = 0;
-  int alloc(kmx_ctx* ctx, kmx_superk_stats* st, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s) {
-    dst = st; nb_parts = P; nm = nminim;
-    if (!st) return KMX_OK;
+  kmx_superk_stats* dst = nullptr; kmx_superk_raw* raw = nullptr; u32 nb_parts = 0; u64 nm = 0;
+  int alloc(kmx_ctx* ctx, kmx_superk_stats* st, kmx_superk_raw* rw, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s) {
+    dst = st; raw = rw; nb_parts = P; nm = nminim;
+    if (!st && !rw) return KMX_OK;
     auto get = [&](bool want, size_t n) -> u32* {
       if (!want) return nullptr;
       u32* p = (u32*)ctx->dalloc(n * 4); blocks.push_back(p);
       if (p) (void)hipMemsetAsync(p, 0, n * 4, s);
       return p;
     };
-    S.pc = get(st->part_counters != nullptr, (size_t)P * 1280);
-    S.ms = get(st->minim_superks != nullptr, nminim);
-    S.mk = get(st->minim_kmers != nullptr, nminim);
-    S.mx = get(st->minim_kxmers != nullptr, nminim);
-    if ((st->part_counters && !S.pc) || (st->minim_superks && !S.ms) || (st->minim_kmers && !S.mk) || (st->minim_kxmers && !S.mx))
+    const bool w_pc = (st && st->part_counters) || (rw && rw->part_radix), w_ms = (st && st->minim_superks) || (rw && rw->minim_superks),
+               w_mk = (st && st->minim_kmers) || (rw && rw->minim_kmers), w_mx = st && st->minim_kxmers;
+    S.pc = get(w_pc, (size_t)P * 1280);
+    S.ms = get(w_ms, nminim);
+    S.mk = get(w_mk, nminim);
+    S.mx = get(w_mx, nminim);
+    if ((w_pc && !S.pc) || (w_ms && !S.ms) || (w_mk && !S.mk) || (w_mx && !S.mx))
       return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
     return KMX_OK;
   }
   bool any() const { return S.pc || S.ms || S.mk || S.mx; }
   // after the kernel: download and accumulate (PartiInfo::incKmer_and_rad / incSuperKmer_per_minimBin / incKxmer_per_minimBin)
   int collect(kmx_ctx* ctx, hipStream_t s) {
-    if (!dst || !any()) return KMX_OK;
-    std::vector<u32> h;
+    if ((!dst && !raw) || !any()) return KMX_OK;
+    if (raw) {
+      hipError_t e = hipSuccess;
+      if (raw->part_radix) e = hipMemcpyAsync(raw->part_radix, S.pc, (size_t)nb_parts * 1280 * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess && raw->minim_superks) e = hipMemcpyAsync(raw->minim_superks, S.ms, nm * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess && raw->minim_kmers) e = hipMemcpyAsync(raw->minim_kmers, S.mk, nm * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
+      if (!dst) return KMX_OK;
+    }
+    u32* h = (u32*)ctx->halloc(std::max<size_t>((size_t)nb_parts * 1280, nm) * 4);      // pinned staging: the tables come back at PCIe speed
+    if (!h) return ctx->fail(KMX_E_NOMEM, "superk statistics: host staging allocation failed");
+    struct Rel { kmx_ctx* c; void* p; ~Rel() { c->hfree(p); } } rel{ctx, h};
     auto pull = [&](const u32* d, size_t n) -> int {
-      h.resize(n);
-      hipError_t e = hipMemcpyAsync(h.data(), d, n * 4, hipMemcpyDeviceToHost, s);
+      hipError_t e = hipMemcpyAsync(h, d, n * 4, hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipStreamSynchronize(s);
       return e == hipSuccess ? KMX_OK : ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
     };
     int rc;
-    if (S.pc) {
+    if (S.pc && dst->part_counters) {
       if ((rc = pull(S.pc, (size_t)nb_parts * 1280)) != KMX_OK) return rc;
       for (u32 p = 0; p < nb_parts; p++) {
         uint64_t* o = dst->part_counters + (size_t)p * KMX_PINFO_STRIDE;
@@ -356,9 +369,9 @@ struct StatsDev {
         }
       }
     }
-    if (S.ms) { if ((rc = pull(S.ms, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) { dst->minim_superks[i] += h[i]; dst->nb_superk += h[i]; } }
-    if (S.mk) { if ((rc = pull(S.mk, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) dst->minim_kmers[i] += h[i]; }
-    if (S.mx) { if ((rc = pull(S.mx, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) dst->minim_kxmers[i] += h[i]; }
+    if (S.ms && dst->minim_superks) { if ((rc = pull(S.ms, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) { dst->minim_superks[i] += h[i]; dst->nb_superk += h[i]; } }
+    if (S.mk && dst->minim_kmers) { if ((rc = pull(S.mk, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) dst->minim_kmers[i] += h[i]; }
+    if (S.mx && dst->minim_kxmers) { if ((rc = pull(S.mx, nm)) != KMX_OK) return rc; for (u64 i = 0; i < nm; i++) dst->minim_kxmers[i] += h[i]; }
     return KMX_OK;
   }
 };
@@ -367,7 +380,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
                        uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
                        uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats,
                        bool sampling = false, uint64_t budget = 0, uint64_t* n_used = nullptr, uint64_t* n_superk = nullptr,
-                       const kmx_count_req* creq = nullptr, bool streams_to_host = true, uint64_t* superk_info = nullptr)
+                       const kmx_count_req* creq = nullptr, bool streams_to_host = true, uint64_t* superk_info = nullptr, kmx_superk_raw* raw = nullptr)
 {
   if (!ctx) return KMX_E_INVAL;
   const bool want_streams = out_bytes != nullptr;
@@ -406,7 +419,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
   if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
   StatsDev sd;
-  { const int rc = sd.alloc(ctx, stats, nb_parts, nm, blocks, st); if (rc != KMX_OK) { release(); return rc; } }
+  { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st); if (rc != KMX_OK) { release(); return rc; } }
+  if (raw) raw->nb_superk = 0;
   const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
   if (!want_streams) {   // statistics only (the sampling pass of the repartition): one walk, nothing emitted
     u64 use = n_seqs;
@@ -442,10 +456,16 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   clk.mark("upload+scan");
   if (nd == 0) {
+    if (raw) {      // nothing counted: the caller's tables are all zeros
+      if (raw->part_radix) memset(raw->part_radix, 0, (size_t)nb_parts * 1280 * 4);
+      if (raw->minim_superks) memset(raw->minim_superks, 0, nm * 4);
+      if (raw->minim_kmers) memset(raw->minim_kmers, 0, nm * 4);
+    }
     release();
     for (u32 p = 0; p < nb_parts; p++) {
       if (streams_to_host) out_bytes[p] = (uint8_t*)malloc(1);
-      if (creq) { creq->keys[p] = (uint64_t*)malloc(8); creq->counts[p] = (uint32_t*)malloc(4); creq->n_out[p] = 0; }
+      if (creq && creq->lists) { creq->lists[p].recs = nullptr; creq->lists[p].n = 0; }
+      else if (creq) { creq->keys[p] = (uint64_t*)malloc(8); creq->counts[p] = (uint32_t*)malloc(4); creq->n_out[p] = 0; }
       if (superk_info) { superk_info[2 * p] = 0; superk_info[2 * p + 1] = 0; }
     }
     return KMX_OK;
@@ -484,6 +504,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       (e = hipMemcpyAsync(pf.data(), d_pf, ((size_t)nb_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   clk.mark("emit+sort");
+  if (raw) raw->nb_superk = nd;                 // (one descriptor per super-k-mer)
   { const int rc = sd.collect(ctx, st); if (rc != KMX_OK) { release(); return rc; } }
   if (pf[nb_parts] != nd) { release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
   const u64 total_bytes = tot & 0xFFFFFFFFULL;
@@ -572,5 +593,26 @@ extern "C" int kmx_count_reads(kmx_ctx* ctx, const char* bases, const uint64_t* 
   if (!ob) { dummy_b.assign(nb_parts, nullptr); dummy_l.assign(nb_parts, 0); ob = dummy_b.data(); ol = dummy_l.data(); }
   const int rc = superk_impl(ctx, bases, offsets, n_seqs, k, m, repart, nb_parts, ob, ol, out_kmers, stats, false, 0, nullptr, nullptr, &rq, superk_bytes != nullptr, superk_info);
   if (rc != KMX_OK) for (u32 p = 0; p < nb_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
+  return rc;
+}
+
+extern "C" int kmx_count_reads_dev(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
+                                   uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
+                                   int hash_mode, uint64_t window, uint32_t hard_min,
+                                   kmx_store* const* stores, uint32_t n_stores, kmx_list* lists, uint64_t* out_kmers,
+                                   uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info,
+                                   kmx_superk_stats* stats, kmx_superk_raw* raw)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!stores || !n_stores || !lists || !out_kmers || (superk_bytes && !superk_len)) return ctx->fail(KMX_E_INVAL, "kmx_count_reads_dev: null argument");
+  for (u32 d = 0; d < n_stores; d++) if (!stores[d]) return ctx->fail(KMX_E_INVAL, "kmx_count_reads_dev: null store");
+  if (hash_mode && window == 0) return ctx->fail(KMX_E_INVAL, "hash window is 0");
+  for (u32 p = 0; p < nb_parts; p++) { lists[p].recs = nullptr; lists[p].n = 0; }
+  kmx_count_req rq{k, hash_mode, window, hard_min, nullptr, nullptr, nullptr, stores, n_stores, lists};
+  std::vector<uint8_t*> dummy_b; std::vector<uint64_t> dummy_l;
+  uint8_t** ob = superk_bytes; uint64_t* ol = superk_len;
+  if (!ob) { dummy_b.assign(nb_parts, nullptr); dummy_l.assign(nb_parts, 0); ob = dummy_b.data(); ol = dummy_l.data(); }
+  const int rc = superk_impl(ctx, bases, offsets, n_seqs, k, m, repart, nb_parts, ob, ol, out_kmers, stats, false, 0, nullptr, nullptr, &rq, superk_bytes != nullptr, superk_info, raw);
+  if (rc != KMX_OK) for (u32 p = 0; p < nb_parts; p++) { lists[p].recs = nullptr; lists[p].n = 0; }
   return rc;
 }

@@ -55,15 +55,17 @@ inline std::vector<uint8_t> lz4_decompress(const uint8_t* src, size_t n, const s
   if (LZ4F_isError(LZ4F_createDecompressionContext(&d, KMX_LZ4F_VERSION))) throw IoError("lz4: no decompression context");
   std::vector<uint8_t> out; std::vector<uint8_t> buf(1 << 20);
   size_t pos = 0;
+  size_t r = 0;
   while (pos < n) {
     size_t dn = buf.size(), sn = n - pos;
-    const size_t r = LZ4F_decompress(d, buf.data(), &dn, src + pos, &sn, nullptr);
+    r = LZ4F_decompress(d, buf.data(), &dn, src + pos, &sn, nullptr);
     if (LZ4F_isError(r)) { LZ4F_freeDecompressionContext(d); throw IoError("corrupt lz4 body: " + what); }
     out.insert(out.end(), buf.begin(), buf.begin() + dn);
     pos += sn;
     if (r == 0 && sn == 0 && dn == 0) break;
   }
   LZ4F_freeDecompressionContext(d);
+  if (n && r != 0) throw IoError("truncated lz4 body (the frame does not end): " + what);      // (a disk that filled up, a crashed writer)
   return out;
 }
 
@@ -134,6 +136,7 @@ inline std::vector<uint8_t> read_kmer_records(const std::string& path, uint32_t*
   if (k_out) *k_out = k;
   if (slots_out) *slots_out = slots;
   if (slots == 0 || slots > 16 || (cs != 1 && cs != 2 && cs != 4)) throw IoError("Invalid file format: " + path);
+  if (body.size() % (slots * 8 + cs) != 0) throw IoError("truncated count file (its body is no whole number of records): " + path);
   if (cs == 4) return body;
   const size_t rin = slots * 8 + cs, rout = slots * 8 + 4, n = body.size() / rin;
   std::vector<uint8_t> out(n * rout, 0);
@@ -309,6 +312,35 @@ inline void write_parti_info(const std::string& path, uint32_t nb_parts, uint64_
   for (size_t i = 0; i < (size_t)nb_parts * 1282; i++) num(part_counters[i]);
   for (uint64_t i = 0; i < nb_minims; i++) { num(minim_superks[i]); num(minim_kmers[i]); s += "0\n"; }   // nb_kxmers per minimizer stays 0 in this stage
   Out o(path); o.raw(s.data(), s.size()); o.close();
+}
+
+// the same file from the device's own u32 tables of one sample (kmx_superk_raw): part_radix[p][x][radix] = kx-mers of x + 1 k-mers;
+// a partition's nb_kmers / nb_kxmers are sums over its 1280 counters (PartiInfo::incKmer_and_rad)
+inline void write_parti_info_raw(const std::string& path, uint32_t nb_parts, uint64_t nb_minims, uint64_t nb_superk_total,
+                                 const uint32_t* part_radix, const uint32_t* minim_superks, const uint32_t* minim_kmers) {
+  std::vector<char> s((size_t)nb_parts * 1282 * 11 + nb_minims * 24 + 128);      // (a u32 is at most 10 digits + the newline)
+  char* w = s.data();
+  auto num = [&](uint64_t v) {
+    if (v < 10) { *w++ = (char)('0' + v); *w++ = '\n'; return; }
+    char b[24]; int n = 0; while (v) { b[n++] = (char)('0' + v % 10); v /= 10; } while (n) *w++ = b[--n]; *w++ = '\n';
+  };
+  uint64_t nk_total = 0;
+  for (uint32_t p = 0; p < nb_parts; p++) for (uint32_t x = 0; x < 5; x++) { uint64_t c = 0; const uint32_t* r = part_radix + ((size_t)p * 5 + x) * 256; for (int i = 0; i < 256; i++) c += r[i]; nk_total += c * (x + 1); }
+  num(nb_parts); num(nb_minims); num(nb_superk_total); num(nk_total);
+  for (uint32_t p = 0; p < nb_parts; p++) {
+    const uint32_t* r = part_radix + (size_t)p * 1280;
+    uint64_t nk = 0, nx = 0;
+    for (uint32_t x = 0; x < 5; x++) { uint64_t c = 0; for (int i = 0; i < 256; i++) c += r[x * 256 + i]; nx += c; nk += c * (x + 1); }
+    num(nk); num(nx);
+    for (int i = 0; i < 1280; i++) num(r[i]);
+  }
+  for (uint64_t i = 0; i < nb_minims; i++) { num(minim_superks[i]); num(minim_kmers[i]); *w++ = '0'; *w++ = '\n'; }
+  const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
+  if (fd < 0) throw IoError("Unable to write at " + path);
+  const size_t n = (size_t)(w - s.data()); size_t done = 0;
+  while (done < n) { const ssize_t r = write(fd, s.data() + done, n - done); if (r <= 0) break; done += (size_t)r; }
+  close(fd);
+  if (done != n) throw IoError("write failed: " + path);
 }
 
 // ---- merge_infos/partition<p>.merge_info (merge.hpp:72-83) -------------------------------------------

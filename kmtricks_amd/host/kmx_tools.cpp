@@ -48,6 +48,7 @@ static KmFile load(const std::string& path)
   else if (magic == MAGIC_PA_HASH) { f.kind = KmFile::PA_HASH; f.cols = rd<uint32_t>(&raw[21]); f.pa_bytes = rd<uint32_t>(&raw[25]); f.id = rd<uint32_t>(&raw[29]); f.partition = rd<uint32_t>(&raw[33]); f.body = body_of(raw, 37, magic, path); }
   else tdie("this file type doesn't support text conversion: " + path);
   if (f.key_bytes == 0 || f.key_bytes > 128 || (f.count_slots != 1 && f.count_slots != 2 && f.count_slots != 4)) tdie("Invalid file format: " + path);
+  if (f.row_bytes() && f.body.size() % f.row_bytes() != 0) tdie("truncated file (its body is no whole number of rows): " + path);
   return f;
 }
 
@@ -173,11 +174,12 @@ static std::string trim(const std::string& s) { const size_t a = s.find_first_no
 
 static int cmd_combine(int argc, char** argv)
 {
-  std::string fof, output; bool cpr = false;
+  std::string fof, output; bool cpr = false, compat = false;
   for (int i = 2; i < argc; i++) {
     const std::string a = argv[i];
     auto need = [&]() -> std::string { if (i + 1 >= argc) tdie("missing value for " + a); return argv[++i]; };
     if (a == "--fof") fof = need(); else if (a == "--output") output = need(); else if (a == "--cpr") cpr = true;
+    else if (a == "--reference-compat") compat = true;      // kmx extension: reproduce PartitionMerger::next's dropped last row (below)
     else if (a == "-v" || a == "--verbose" || a == "-t" || a == "--threads") need(); else tdie("unknown option " + a);
   }
   if (fof.empty() || output.empty()) tdie("--fof and --output are required");
@@ -252,9 +254,11 @@ static int cmd_combine(int argc, char** argv)
     else if (!hashed) { out.put<uint64_t>(MAGIC_PA); out.put<uint32_t>(last.k); out.put<uint32_t>((last.k + 31) / 32); out.put<uint32_t>((uint32_t)total); out.put<uint32_t>((uint32_t)((total + 7) / 8)); out.put<uint32_t>(h_id); out.put<uint32_t>(h_part); }
     else { out.put<uint64_t>(MAGIC_PA_HASH); out.put<uint32_t>((uint32_t)total); out.put<uint32_t>((uint32_t)((total + 7) / 8)); out.put<uint32_t>(h_id); out.put<uint32_t>(h_part); }
     out.begin_body();
-    // PartitionMerger::next (matrix.hpp:534-583), as it is: the smallest key of the queue starts a row, every file at that key adds
-    // its columns.  A row whose first file leaves the queue EMPTY is not written (`if (m_queue.empty()) return false` sits before
-    // the row is handed out): the last key of a partition is dropped unless two files hold it.
+    // PartitionMerger::next (matrix.hpp:534-583): the smallest key of the queue starts a row, every file at that key adds its
+    // columns.  In the reference a row whose first file leaves the queue EMPTY is not written (`if (m_queue.empty()) return
+    // false` sits before the row is handed out): the last key of a partition is lost unless two files hold it.  kmx writes that
+    // row -- combine(runA, runB) then equals one run over both sample sets -- and reproduces the reference's bytes only with
+    // --reference-compat.
     const uint32_t kb = files[0].key_bytes;
     std::vector<size_t> cur(files.size(), 0);
     auto key_of = [&](size_t i) { return files[i].body.data() + cur[i] * files[i].row_bytes(); };
@@ -274,7 +278,7 @@ static int cmd_combine(int argc, char** argv)
       size_t e = q.top();
       memcpy(row.data(), key_of(e), kb);
       add(e); advance(e);
-      if (q.empty()) break;                                        // (this row is lost: see above)
+      if (q.empty() && compat) break;                              // (this row is lost in the reference: see above)
       while (!q.empty() && memcmp(key_of(q.top()), row.data(), kb) == 0) { e = q.top(); add(e); advance(e); }
       obuf.insert(obuf.end(), row.begin(), row.end());
       if (obuf.size() > (4u << 20)) { out.raw(obuf.data(), obuf.size()); obuf.clear(); }

@@ -22,7 +22,7 @@ class KmxMergeTask(C.Structure):
     _fields_ = [("n_lists", C.c_uint32), ("key_words", C.c_uint32), ("lists", C.POINTER(KmxList)),
                 ("soft_min", C.POINTER(C.c_uint32)), ("rec_min", C.c_uint32), ("share_min", C.c_uint32),
                 ("mode", C.c_uint32), ("bitw", C.c_uint32), ("lower", C.c_uint64), ("upper", C.c_uint64),
-                ("rows_hint", C.c_uint64)]
+                ("rows_hint", C.c_uint64), ("list_on_device", C.c_void_p)]
 
 
 _vp = C.c_void_p
@@ -84,10 +84,29 @@ _lib.kmx_count_reads.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C
                                  C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                  C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(KmxSuperkStats)]
 
+_lib.kmx_superk_sample.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(KmxSuperkStats),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+
+
+class KmxSuperkRaw(C.Structure):
+    _fields_ = [("part_radix", _vp), ("minim_superks", _vp), ("minim_kmers", _vp), ("nb_superk", C.c_uint64)]
+
+
+_lib.kmx_store_create.argtypes = [C.c_int, C.c_uint64, C.POINTER(_vp)]
+_lib.kmx_store_destroy.argtypes = [_vp]
+_lib.kmx_store_used.restype = C.c_uint64
+_lib.kmx_store_used.argtypes = [_vp]
+_lib.kmx_store_limit.restype = C.c_uint64
+_lib.kmx_store_limit.argtypes = [_vp]
+_lib.kmx_copy_to_host.argtypes = [_vp, _vp, _vp, C.c_uint64]
+_lib.kmx_count_reads_dev.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_int, C.c_uint64, C.c_uint32,
+                                     C.POINTER(_vp), C.c_uint32, C.POINTER(KmxList), C.POINTER(C.c_uint64),
+                                     C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(KmxSuperkStats),
+                                     C.POINTER(KmxSuperkRaw)]
 _lib.kmx_hist_reset.argtypes = [_vp]
 _lib.kmx_hist_off.argtypes = [_vp]
 _lib.kmx_hist_read.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
-EXPORTS = ["kmx_version", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_version", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -290,6 +309,31 @@ class Context:
                 _lib.kmx_free(ob[p])
         return out, [int(x) for x in nk], st, np.array(list(info), dtype=np.uint64).reshape(nb_parts, 2)
 
+    def count_reads_dev(self, reads, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False):
+        """kmx_count_reads_dev: as count_reads, the results left on the device as packed records in `stores` (partition p ->
+        stores[p % len(stores)]) -> ([(device pointer, records)] per partition, k-mers per partition, raw tables or None)"""
+        blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
+        rep = np.ascontiguousarray(repart, dtype=np.uint16)
+        sp = (_vp * len(stores))(*[s._h for s in stores])
+        lists, nk = (KmxList * nb_parts)(), (C.c_uint64 * nb_parts)()
+        rw, tabs = None, None
+        if raw:
+            tabs = (np.zeros(nb_parts * 1280, np.uint32), np.zeros(4 ** m, np.uint32), np.zeros(4 ** m, np.uint32))
+            rw = KmxSuperkRaw(tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data, 0)
+        self._check(_lib.kmx_count_reads_dev(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
+                                             1 if window else 0, window, hard_min, sp, len(stores), lists, nk, None, None, None, None,
+                                             C.byref(rw) if raw else None), "kmx_count_reads_dev")
+        return [(lists[p].recs, int(lists[p].n)) for p in range(nb_parts)], [int(x) for x in nk], (tabs + (int(rw.nb_superk),)) if raw else None
+
+    def read_list(self, dev_ptr, n, key_words=1):
+        """a device-resident count list -> (keys uint64[n, key_words], counts uint32[n])"""
+        w = key_words * 2 + 1
+        rec = np.zeros((n, w), np.uint32)
+        if n:
+            self._check(_lib.kmx_copy_to_host(self._h, rec.ctypes.data, dev_ptr, n * w * 4), "kmx_copy_to_host")
+        keys = np.ascontiguousarray(rec[:, :key_words * 2]).view(np.uint64).reshape(n, key_words)
+        return keys, rec[:, key_words * 2].copy()
+
     def hist_reset(self):
         """kmx_hist_reset: zero the abundance histogram; the count calls that follow add their distinct keys to it"""
         self._check(_lib.kmx_hist_reset(self._h), "kmx_hist_reset")
@@ -396,5 +440,33 @@ class MergeResult:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class Store:
+    """kmx_store: count lists resident in HBM between the count and the merge stage"""
+
+    def __init__(self, device=0, limit_bytes=0):
+        h = _vp()
+        rc = _lib.kmx_store_create(device, limit_bytes, C.byref(h))
+        if rc != 0:
+            raise KmxError(f"kmx_store_create failed ({rc}): {_lib.kmx_last_error(None).decode()}")
+        self._h = h
+
+    def used(self):
+        return _lib.kmx_store_used(self._h)
+
+    def limit(self):
+        return _lib.kmx_store_limit(self._h)
+
+    def close(self):
+        if self._h:
+            _lib.kmx_store_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass

@@ -262,3 +262,111 @@ def test_superk_partition_random_reads_vs_oracle(ctx, k, m, P):
     for p in range(P):
         assert got[p][1] == exp[p][1]
         assert got[p][0] == exp[p][0]
+
+
+@pytest.mark.parametrize("k,m,P,hard_min,hashed,G", [(31, 10, 8, 1, False, 1), (31, 10, 8, 2, True, 2), (63, 10, 32, 2, False, 3), (21, 8, 5, 3, False, 2), (32, 10, 16, 1, True, 1)])
+def test_count_reads_dev_vs_oracle(ctx, k, m, P, hard_min, hashed, G):
+    """kmx_count_reads_dev: the counts stay in HBM as packed .kmer-body records, partition p in store p % G (what the merge stage
+    of GPU p % G reads); read back they are the oracle's counts, merged where they lie (kmx_merge_dev) they give the oracle's
+    matrix; the raw PartiInfo<5> tables are the oracle's counters"""
+    from kmtricks_amd import lib
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    reads = random_reads(900 + k, 400, 150, n_rate=0.003) * 2 + ["ACGT" * 70, "A" * 300, "", "T" * k, "acgtacgtnnacgt" * 12]
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    epin, ems, emk, _ = orc.superk_stats(reads, k, m, lut, rep, P)
+    W = 6400
+    kw = 1 if hashed else (k + 31) // 32
+    stores = [lib.Store(0) for _ in range(G)]
+    try:
+        lists, nk, raw = ctx.count_reads_dev(reads, k, m, rep, P, hard_min, stores, window=W if hashed else 0, raw=True)
+        # a second sample (the reads reversed) in the same stores: lists of both must stay valid
+        reads2 = reads[::-1][:300]
+        lists2, nk2, _ = ctx.count_reads_dev(reads2, k, m, rep, P, hard_min, stores, window=W if hashed else 0)
+        exp2 = orc.superk_partition(reads2, k, m, lut, rep, P)
+        assert all(s.used() > 0 for s in stores[:min(G, P)])
+        pr, ms, mk, nsk = raw
+        pr = pr.reshape(P, 5, 256).astype(np.uint64)
+        assert np.array_equal(pr.reshape(P, 1280), epin[:, 2:]) and np.array_equal(pr.sum(axis=(1, 2)), epin[:, 1])
+        assert np.array_equal((pr.sum(axis=2) * np.arange(1, 6, dtype=np.uint64)).sum(axis=1), epin[:, 0])
+        assert np.array_equal(ms, ems) and np.array_equal(mk, emk) and nsk == int(ems.sum())
+        for (ll, nn, ee) in ((lists, nk, exp), (lists2, nk2, exp2)):
+            for p in range(P):
+                assert nn[p] == ee[p][1]
+                gk, gc = ctx.read_list(ll[p][0], ll[p][1], kw)
+                ek, ec = orc.count_hash(ee[p][0], k, W, p, hard_min) if hashed else orc.count_kmer(ee[p][0], k, hard_min)
+                assert np.array_equal(gk.reshape(ek.shape), ek) and np.array_equal(gc, ec)
+        # merge straight from the stores: two samples per partition
+        for p in range(P):
+            e1 = orc.count_hash(exp[p][0], k, W, p, hard_min) if hashed else orc.count_kmer(exp[p][0], k, hard_min)
+            e2 = orc.count_hash(exp2[p][0], k, W, p, hard_min) if hashed else orc.count_kmer(exp2[p][0], k, hard_min)
+            res = ctx.merge_dev([dict(lists=[lists[p], lists2[p]], key_words=kw, soft_min=[1, 1], rec_min=1, share_min=0, mode=lib.MODE_COUNT)])
+            res.wait()
+            eb, er, es = orc.merge_matrix([(e1[0].reshape(-1), e1[1]), (e2[0].reshape(-1), e2[1])], kw, [1, 1], 1, 0, orc.MODE_COUNT)
+            assert res.rows() == er and res.body() == eb and np.array_equal(res.stats(), es)
+            res.free()
+    finally:
+        for s in stores:
+            s.close()
+
+
+def test_count_store_limit(ctx):
+    """a store refuses what does not fit its limit (the pipeline then writes that sample's count files instead)"""
+    from kmtricks_amd import lib
+    rep = orc.repart_static(10, 4)
+    reads = random_reads(5, 300, 150)
+    st = lib.Store(0, limit_bytes=4096)
+    try:
+        assert st.limit() == 4096
+        with pytest.raises(lib.KmxError, match="store is full"):
+            ctx.count_reads_dev(reads * 2, 31, 10, rep, 4, 1, [st])
+    finally:
+        st.close()
+
+
+def test_merge_host_mixed_lists(ctx):
+    """kmx_merge_host with list_on_device: resident lists (a store) and host lists (count files just read) in one task"""
+    import ctypes as C
+    from kmtricks_amd import lib
+    lut = orc.minimizer_lut(10)
+    rep = orc.repart_static(10, 4)
+    r1, r2, r3 = random_reads(11, 300, 150), random_reads(12, 300, 150), random_reads(11, 200, 150)
+    st = lib.Store(0)
+    try:
+        l1, _, _ = ctx.count_reads_dev(r1, 31, 10, rep, 4, 1, [st])
+        l3, _, _ = ctx.count_reads_dev(r3, 31, 10, rep, 4, 1, [st])
+        e = [[orc.count_kmer(s[0], 31, 1) for s in orc.superk_partition(r, 31, 10, lut, rep, 4)] for r in (r1, r2, r3)]
+        for p in range(4):
+            host = lib.pack_records(e[1][p][0], e[1][p][1], 1)
+            keep = []
+            t = ctx._task([l1[p], (host.ctypes.data if len(host) else None, len(host)), l3[p]], 1, [1, 1, 1], 2, 0, lib.MODE_COUNT, 0, 0, 2, 0, keep)
+            flags = (C.c_uint8 * 3)(1, 0, 1)
+            t.list_on_device = C.cast(flags, C.c_void_p)
+            arr = (lib.KmxMergeTask * 1)(t)
+            res = ctx.merge_host((arr, 1, [3], keep))
+            res.wait()
+            eb, er, es = orc.merge_matrix([(x[0].reshape(-1), x[1]) for x in (e[0][p], e[1][p], e[2][p])], 1, [1, 1, 1], 2, 0, orc.MODE_COUNT)
+            assert res.rows() == er and res.body() == eb and np.array_equal(res.stats(), es)
+            res.free()
+    finally:
+        st.close()
+
+
+def test_superk_sample_vs_oracle(ctx):
+    """kmx_superk_sample (the sampling pass of the sampled repartition, gatb RepartitionAlgorithm.cpp:182-215): the shortest
+    prefix of the reads that holds more than the budget of super-k-mers, its kx-mers per minimizer -> the oracle's table"""
+    k, m, P = 31, 10, 8
+    lut = orc.minimizer_lut(m)
+    rep0 = np.zeros(4 ** m, np.uint16)
+    reads = random_reads(31, 500, 150, n_rate=0.002)
+    per_read = [sum(x[2] for x in orc.superk_partition([r], k, m, lut, rep0, 1)) for r in reads]
+    for budget in (10, 1000, 10 ** 9):
+        acc = used = 0
+        while used < len(reads):
+            acc += per_read[used]; used += 1
+            if acc > budget: break
+        g_used, g_nsk, g_mx = ctx.superk_sample(reads, k, m, budget)
+        assert (g_used, g_nsk) == (used, acc)
+        _, _, _, emx = orc.superk_stats(reads[:used], k, m, lut, rep0, 1)
+        assert np.array_equal(g_mx, emx)
+        assert np.array_equal(orc.repart_sampled(g_mx, P), orc.repart_sampled(emx, P))

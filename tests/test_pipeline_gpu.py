@@ -465,8 +465,8 @@ def test_k63_pa_cohort_pipeline(tmp_path):
 
 def test_combine_two_runs_equals_one_run(inputs, tmp_path):
     """`kmx combine` over two `kmx pipeline` runs that share a repartition (one sample each) == the matrix of one run over both
-    samples (recurrence-min 1), up to MatrixMerger's dropped last key (matrix.hpp:534-583); also with a run that kept its count
-    files (taken as one-column matrices, matrix.hpp:756-771)."""
+    samples (recurrence-min 1) -- with --reference-compat up to MatrixMerger's dropped last key (matrix.hpp:534-583); also with
+    a run that kept its count files (taken as one-column matrices, matrix.hpp:756-771)."""
     fofs = []
     for i, line in enumerate((f"D1 : {GD}/1.fasta", f"D2 : {inputs}/2.fastq.gz")):
         f = tmp_path / f"s{i}.fof"; f.write_text(line + "\n"); fofs.append(f)
@@ -477,10 +477,10 @@ def test_combine_two_runs_equals_one_run(inputs, tmp_path):
         return out
     a = pipe(fofs[0], tmp_path / "runA"); b = pipe(fofs[1], tmp_path / "runB"); bk = pipe(fofs[1], tmp_path / "runBk", "--keep-tmp")
     both = run(inputs, tmp_path / "both", "--mode", "kmer:count:bin", "--recurrence-min", "1")
-    for name, second in (("c1", b), ("c2", bk)):
+    for name, second, compat in (("c1", b, False), ("c2", bk, False), ("c3", b, True)):
         lst = tmp_path / f"{name}.fof"; lst.write_text(f"{a}\n{second}\n")
         out = tmp_path / name
-        r = subprocess.run([KMX, "combine", "--fof", str(lst), "--output", str(out)], capture_output=True, text=True)
+        r = subprocess.run([KMX, "combine", "--fof", str(lst), "--output", str(out)] + (["--reference-compat"] if compat else []), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert open(out / "kmtricks.fof").read().split() == open(both / "kmtricks.fof").read().split()
         for p in range(P):
@@ -489,7 +489,7 @@ def test_combine_two_runs_equals_one_run(inputs, tmp_path):
             got = np.frombuffer(raw[45:], np.uint8).reshape(-1, 16)
             assert struct.unpack_from("<IIII", raw, 21)[3] == 2                      # two columns
             last_in_one_run_only = int((full[-1, 8:12].view(np.uint32)[0] == 0) or (full[-1, 12:16].view(np.uint32)[0] == 0))
-            assert len(got) == len(full) - last_in_one_run_only
+            assert len(got) == len(full) - (last_in_one_run_only if compat else 0)
             assert np.array_equal(got, full[:len(got)]), p
 
 

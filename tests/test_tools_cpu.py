@@ -130,7 +130,7 @@ def _write_matrix(path, kind, k, ncols, sid, part, keys, data):
             f.write(np.ascontiguousarray(kk, dtype=np.uint64).tobytes() + np.ascontiguousarray(d).tobytes())
 
 
-def _partition_merger(files, pa):
+def _partition_merger(files, pa, compat=True):
     """PartitionMerger::next / write loop restated (matrix.hpp:534-583, 632-680): files = [(keys as tuples most significant word
     first, rows of column values or bits, ncols)].  -> [(key, merged columns)].  The row whose first file empties the queue is
     not handed out."""
@@ -149,7 +149,7 @@ def _partition_merger(files, pa):
         key, i = heapq.heappop(heap)
         for c, v in enumerate(files[i][1][cur[i]]): row[pos[i] + c] = v
         adv(i)
-        if not heap: break
+        if not heap and compat: break
         while heap and heap[0][0] == key:
             _, j = heapq.heappop(heap)
             for c, v in enumerate(files[j][1][cur[j]]): row[pos[j] + c] = v
@@ -181,12 +181,12 @@ def _make_run(root, kind, k, P, ncols, seed, ids, hashed, shared_pool):
     return parts
 
 
-@pytest.mark.parametrize("kind,k", [("count", 31), ("pa", 40), ("count_hash", 31), ("pa_hash", 31)])
-def test_combine_matrices_of_three_runs(tmp_path, kind, k):
+@pytest.mark.parametrize("kind,k,compat", [("count", 31, True), ("pa", 40, True), ("count_hash", 31, True), ("pa_hash", 31, True), ("count", 31, False), ("pa", 40, False)])
+def test_combine_matrices_of_three_runs(tmp_path, kind, k, compat):
     """`kmx combine`: per partition, the rows of the runs' matrices joined by key, a run's columns behind the previous run's,
     zeros where a run lacks the key -- against a restatement of PartitionMerger, with its quirks: matrices/ entries are
-    taken in NAME order (12 partitions: matrix_10 comes third), the last key of a partition is lost unless two runs hold it,
-    header fields come from the last run's file."""
+    taken in NAME order (12 partitions: matrix_10 comes third), header fields come from the last run's file, and -- with
+    --reference-compat only -- the last key of a partition is lost unless two runs hold it (kmx keeps it by default)."""
     P, hashed, pa = 12, kind.endswith("hash"), kind.startswith("pa")
     slots = 1 if hashed else (k + 31) // 32
     rng = np.random.default_rng(17)
@@ -203,7 +203,7 @@ def test_combine_matrices_of_three_runs(tmp_path, kind, k):
         parts.append(_make_run(root, kind, k, P, ncols[r], 100 + r, [f"S{r}a", f"S{r}b"], hashed, pools))
     fof = tmp_path / "runs.fof"; fof.write_text("\n".join(runs) + "\n\n")
     out = str(tmp_path / "combined")
-    r = subprocess.run([KMX, "combine", "--fof", str(fof), "--output", out], capture_output=True, text=True)
+    r = subprocess.run([KMX, "combine", "--fof", str(fof), "--output", out] + (["--reference-compat"] if compat else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(f"{out}/kmtricks.fof").read() == "".join(f"S{r}{x}: /x/S{r}{x}.fa\n" for r in range(3) for x in "ab")
     assert open(f"{out}/options.txt").read() == open(f"{runs[0]}/options.txt").read() and os.path.exists(f"{out}/hash.info")
@@ -218,7 +218,7 @@ def test_combine_matrices_of_three_runs(tmp_path, kind, k):
             keys, data = parts[rr][src_p]
             rows = [([int(x) for x in d] if not pa else [int(b) for b in np.unpackbits(d, bitorder="little")[:ncols[rr]]]) for d in data]
             files.append((keys, rows, ncols[rr]))
-        exp = _partition_merger(files, pa)
+        exp = _partition_merger(files, pa, compat)
         raw = open(f"{out}/matrices/matrix_{p}.{kind}", "rb").read()
         assert raw[:13] == KM_BASE
         if kind == "count": hdr = struct.pack("<QIIIIII", M["matrix"], k, slots, 1, total, 7, src_p); hl = 45
@@ -232,11 +232,11 @@ def test_combine_matrices_of_three_runs(tmp_path, kind, k):
             body += (np.array(row, dtype=np.uint32).tobytes() if not pa else np.packbits(np.array(row, dtype=np.uint8), bitorder="little").tobytes())
         assert raw[hl:] == body, (p, len(exp))
         n_all = len({kk for f in files for kk in f[0]})
-        assert len(exp) in (n_all, n_all - 1)
+        assert len(exp) in ((n_all, n_all - 1) if compat else (n_all,))
     # the text form of a combined matrix through `kmx dump`
     r = subprocess.run([KMX, "dump", "--input", f"{out}/matrices/matrix_0.{kind}"], capture_output=True, text=True)
     assert r.returncode == 0 and len(r.stdout.splitlines()) == len(_partition_merger(
-        [(parts[rr][int(names[0].split('_')[1].split('.')[0])][0], [[0] * ncols[rr]] * len(parts[rr][int(names[0].split('_')[1].split('.')[0])][0]), ncols[rr]) for rr in range(3)], pa))
+        [(parts[rr][int(names[0].split('_')[1].split('.')[0])][0], [[0] * ncols[rr]] * len(parts[rr][int(names[0].split('_')[1].split('.')[0])][0]), ncols[rr]) for rr in range(3)], pa, compat))
 
 
 def test_combine_renames_duplicate_ids_and_checks_the_repartition(tmp_path):
