@@ -65,6 +65,8 @@ typedef struct kmx_ctx kmx_ctx;
 
 int  kmx_version(void);
 int  kmx_device_count(void);   /* HIP devices visible to this process (0: none -- libkmx has no CPU fallback) */
+/* free and total bytes of a device's memory (hipMemGetInfo) */
+int  kmx_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 int  kmx_create(int device, kmx_ctx** out);
 void kmx_destroy(kmx_ctx* ctx);
 /* last error message of this ctx (or of the failed kmx_create when ctx == NULL) */

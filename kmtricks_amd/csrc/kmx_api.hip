@@ -58,6 +58,21 @@ void kmx_ctx::hfree(void* p)
 extern "C" int kmx_version(void) { return KMX_VERSION; }
 extern "C" int kmx_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 
+extern "C" int kmx_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return KMX_E_NODEVICE;
+  int cur = -1; (void)hipGetDevice(&cur);
+  if (hipSetDevice(device) != hipSuccess) return KMX_E_NODEVICE;
+  size_t fr = 0, tot = 0;
+  const hipError_t e = hipMemGetInfo(&fr, &tot);
+  if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+  if (e != hipSuccess) return KMX_E_HIP;
+  if (free_bytes) *free_bytes = fr;
+  if (total_bytes) *total_bytes = tot;
+  return KMX_OK;
+}
+
 extern "C" int kmx_create(int device, kmx_ctx** out)
 {
   if (!out) { g_create_err = "kmx_create: out is NULL"; return KMX_E_INVAL; }

@@ -6,11 +6,15 @@
 // howde_utils.hpp:133-187 (per-sample Bloom filter files).  All compute goes through the C ABI of
 // include/kmx.h; this file parses, schedules, reads and writes files.
 //
-// Scheduling (the role of task_scheduler.hpp + task_pool.hpp): one worker thread per GPU (--gpus G) owns a
-// libkmx context; samples go to GPU s mod G for split + count, partitions to GPU (index mod G) for the merge --
-// no collective, the count files on disk are the exchange, as in the reference.  A pool of -t host threads
+// Scheduling (the role of task_scheduler.hpp + task_pool.hpp): --gpus G shards, each with --gpu-workers count workers
+// (a host thread + a libkmx context each: one worker's host work overlaps the other's kernels); samples go round-robin
+// over the workers for split + count, partitions to shard (index mod G) for the merge.  The count lists stay in HBM
+// between the two stages (a kmx_store per shard; partition p's list is written into the store of the shard that merges
+// it, over xGMI when that is another GPU) -- the reference's count files exist only with --keep-tmp / --until count, or
+// for the samples a full store turns away (the merge then takes both kinds in one batch).  A pool of -t host threads
 // parses reads ahead of the devices, reads the count files of the NEXT merge batch into pinned memory while the
-// current one merges (kmx_merge_host uploads on its own stream), and compresses / writes outputs behind them.
+// current one merges (kmx_merge_host uploads on its own stream), and writes outputs behind them: matrix bodies come
+// off the device in pieces into a ring of pinned buffers and go to their files with pwrite.
 // Errors: message on stderr + exit(EXIT_FAILURE) (reference src/kmtricks.cpp:109-123).
 #include <kmx.h>
 #include <kmtricks/plugin.hpp>
@@ -43,11 +47,11 @@ struct Sample { std::string id; std::vector<std::string> files; uint32_t hard_mi
 
 struct Opt {
   std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file, bf_format = "howdesbt";
-  uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1;
+  uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1, gpu_workers = 2;
   uint64_t bloom = 10000000, merge_batch_mb = 4096;
   double restrict_to = 1.0, focus = 0.5;
   std::vector<uint32_t> restrict_list;
-  bool static_repart = false, keep_tmp = false, cpr = false, skip_pinfo = false, hist = false;
+  bool static_repart = false, keep_tmp = false, cpr = false, skip_pinfo = false, hist = false, no_resident = false;
 };
 
 // (a worker thread cannot unwind the others: print and leave without running destructors under them)
@@ -119,7 +123,9 @@ static Opt parse_cli(int argc, char** argv)
     else if (a == "--plugin-config") o.plugin_config = need(i);
     else if (a == "-t" || a == "--threads") o.threads = num(i);
     else if (a == "--gpus") o.gpus = num(i);                    // kmx extension: samples / partitions shard round-robin over this many GPUs
-    else if (a == "--merge-batch-mb") o.merge_batch_mb = num(i); // kmx extension: count-file bytes per merge batch and GPU
+    else if (a == "--gpu-workers") o.gpu_workers = num(i);      // kmx extension: count workers (host thread + context) per shard
+    else if (a == "--no-resident") o.no_resident = true;        // kmx extension: count lists go through count files (as with --keep-tmp) instead of staying in HBM
+    else if (a == "--merge-batch-mb") o.merge_batch_mb = num(i); // kmx extension: count-list bytes per merge batch and GPU
     else if (a == "--skip-partiinfo") o.skip_pinfo = true;      // kmx extension: do not write superkmers/<id>/PartiInfoFile (6 MB of text per sample)
     else if (a == "-v" || a == "--verbose") need(i);
     else die("unknown option " + a);
@@ -141,6 +147,8 @@ static Opt parse_cli(int argc, char** argv)
   if (o.mode == "hash:bfc:bin" && (o.bitw < 1 || o.bitw > 32)) die("--bitw must be in [1, 32]");
   if (o.threads == 0) o.threads = 1;
   if (o.gpus == 0) o.gpus = 1;
+  if (o.gpu_workers == 0) o.gpu_workers = 1;
+  if (o.gpu_workers > 16) o.gpu_workers = 16;
   return o;
 }
 
@@ -173,7 +181,7 @@ static void superk_info_numbers(const uint8_t* s, uint64_t len, uint32_t k, uint
   *kmers_pending = km; *bytes_flushed = flushed;
 }
 
-struct Stage { double read = 0, split = 0, count = 0, merge_io = 0, merge = 0, format = 0, repart = 0; std::atomic<uint64_t> bases{0}, kmers{0}, merge_recs{0}; };
+struct Stage { double read = 0, split = 0, count = 0, merge_io = 0, merge = 0, format = 0, repart = 0, setup_wall = 0, count_wall = 0, merge_wall = 0; std::atomic<uint64_t> bases{0}, kmers{0}, merge_recs{0}; };
 
 int run(int argc, char** argv)
 {
@@ -215,11 +223,31 @@ int run(int argc, char** argv)
 
   // ---- devices and host threads ----
   std::vector<kmx_ctx*> gpu;
-  // (--gpus beyond the devices present: the extra workers share the devices round-robin -- more contexts in flight per GPU)
+  // G shards (--gpus beyond the devices present: the extra shards share the devices round-robin), NW = G x --gpu-workers count
+  // workers: worker w belongs to shard w mod G and runs on that shard's device; the merge of shard g runs on worker g's context
   const int ndev = std::max(1, kmx_device_count());
-  for (uint32_t g = 0; g < o.gpus; g++) { kmx_ctx* x = nullptr; if (kmx_create((int)(g % (uint32_t)ndev), &x) != KMX_OK) die(kmx_last_error(nullptr)); gpu.push_back(x); }
-  const uint32_t G = (uint32_t)gpu.size();
-  struct CtxGuard { std::vector<kmx_ctx*>& v; ~CtxGuard() { for (auto x : v) kmx_destroy(x); } } ctx_guard{gpu};
+  const uint32_t G = o.gpus, NW = G * o.gpu_workers;
+  for (uint32_t w = 0; w < NW; w++) { kmx_ctx* x = nullptr; if (kmx_create((int)((w % G) % (uint32_t)ndev), &x) != KMX_OK) die(kmx_last_error(nullptr)); gpu.push_back(x); }
+  // count lists resident in HBM between count and merge: one store per shard.  Not with --keep-tmp / --until count (the count
+  // files are the product then) nor with --no-resident.
+  const bool resident_mode = !o.keep_tmp && !o.no_resident && (o.until == "all" || o.until == "merge");
+  std::vector<kmx_store*> stores;
+  if (resident_mode) {
+    for (uint32_t g = 0; g < G; g++) {
+      const int dev = (int)(g % (uint32_t)ndev);
+      uint64_t fr = 0, tot = 0; kmx_device_memory(dev, &fr, &tot);
+      const uint32_t on_dev = (G - (uint32_t)dev + (uint32_t)ndev - 1) / (uint32_t)ndev;      // shards that share this device
+      uint64_t lim = tot / 10 * 6 / std::max(1u, on_dev);
+      if (const char* e = getenv("KMX_STORE_LIMIT_MB")) lim = (uint64_t)std::max(0L, atol(e)) << 20;      // (for the tests of the mixed merge: lists + count files)
+      kmx_store* st_ = nullptr;
+      if (kmx_store_create(dev, std::max<uint64_t>(lim, 1), &st_) != KMX_OK) die(kmx_last_error(nullptr));
+      stores.push_back(st_);
+    }
+  }
+  struct CtxGuard { std::vector<kmx_ctx*>& v; std::vector<kmx_store*>& s; ~CtxGuard() { for (auto x : s) kmx_store_destroy(x); for (auto x : v) kmx_destroy(x); } } ctx_guard{gpu, stores};
+  // where sample i's count list of partition p is: resident (res_flag[i]) -> res_lists[i * P + p], else its count file
+  std::vector<kmx_list> res_lists(resident_mode ? (size_t)samples.size() * o.nb_parts : 0, kmx_list{nullptr, 0});
+  std::vector<uint8_t> res_flag(samples.size(), 0);
   Pool pool(o.threads);
   Stage st;
   const char* trace = getenv("KMX_TRACE");
@@ -316,14 +344,18 @@ int run(int argc, char** argv)
 
   auto report = [&]() {
     fprintf(stderr, "[kmx pipeline] {\"samples\": %u, \"partitions\": %u, \"gpus\": %u, \"threads\": %u, \"bases\": %llu, \"kmers\": %llu, \"merge_records\": %llu, "
-                    "\"repart_s\": %.4f, \"read_s\": %.4f, \"superk_s\": %.4f, \"count_s\": %.4f, \"merge_io_s\": %.4f, \"merge_s\": %.4f, \"format_s\": %.4f, \"total_s\": %.4f}\n",
+                    "\"repart_s\": %.4f, \"read_s\": %.4f, \"superk_s\": %.4f, \"count_s\": %.4f, \"merge_io_s\": %.4f, \"merge_s\": %.4f, \"format_s\": %.4f, "
+                    "\"gpu_workers\": %u, \"resident_samples\": %u, \"setup_wall_s\": %.4f, \"count_wall_s\": %.4f, \"merge_wall_s\": %.4f, \"total_s\": %.4f}\n",
             N, P, G, o.threads, (unsigned long long)st.bases.load(), (unsigned long long)st.kmers.load(), (unsigned long long)st.merge_recs.load(),
-            st.repart, st.read, st.split, st.count, st.merge_io, st.merge, st.format, since(t_start));
+            st.repart, st.read, st.split, st.count, st.merge_io, st.merge, st.format,
+            o.gpu_workers, (unsigned)std::count(res_flag.begin(), res_flag.end(), (uint8_t)1), st.setup_wall, st.count_wall, st.merge_wall, since(t0));
   };
   auto count_path = [&](uint32_t p, uint32_t si) {
     return root + "/counts/partition_" + std::to_string(p) + "/" + samples[si].id + (hash_mode ? ".hash" : (o.cpr ? ".kmer.lz4" : ".kmer"));
   };
 
+  st.setup_wall = since(t0);
+  const auto t_count_stage = clk::now();
   // ================= superk + count, sample by sample (task_scheduler.hpp:251-348) =================
   // Readers (pool threads) parse a sample's files into batches of reads; the worker of GPU (sample mod G) splits every batch
   // (kmx_superk_partition[_stats]) and, at the sample's last batch, counts all its partitions (kmx_count_batch) and hands the
@@ -331,16 +363,34 @@ int run(int argc, char** argv)
   {
     struct ReadBatch { uint32_t si = 0; bool last = false; std::string bases; std::vector<uint64_t> offs; };
     std::vector<std::unique_ptr<Channel<ReadBatch>>> chan;
-    for (uint32_t g = 0; g < G; g++) chan.emplace_back(new Channel<ReadBatch>(3));
+    for (uint32_t w = 0; w < NW; w++) chan.emplace_back(new Channel<ReadBatch>(3));
     std::mutex tm; double s_read = 0, s_split = 0, s_count = 0;
-    // readers: one pool task per sample, at most `readers` in flight per GPU queue (bounded by the channel)
-    const uint32_t readers = std::max<uint32_t>(1, std::min<uint32_t>(o.threads > 1 ? o.threads - 1 : 1, 8));
+    // readers: threads that parse samples in fof order, each into the queue of the sample's worker (bounded by the channel)
+    const uint32_t readers = std::max<uint32_t>(1, std::min<uint32_t>(o.threads > 1 ? o.threads / 2 : 1, 24));
+    // pinned blocks for the statistics tables of a sample (kmx_superk_raw: P * 1280 + 2 * 4^m u32), handed back by the task that
+    // has written the sample's PartiInfoFile
+    const uint64_t nm_ = 1ULL << (2 * o.msize);
+    const size_t raw_words = (size_t)P * 1280 + 2 * nm_;
+    struct RawPool {
+      std::mutex m; std::condition_variable cv; std::vector<uint32_t*> free_; size_t made = 0, cap, words;
+      uint32_t* get() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          if (!free_.empty()) { uint32_t* p = free_.back(); free_.pop_back(); return p; }
+          if (made < cap) { made++; lk.unlock(); uint32_t* p = (uint32_t*)kmx_alloc_pinned(words * 4); if (!p) die("pinned host allocation failed"); return p; }
+          cv.wait(lk);
+        }
+      }
+      void put(uint32_t* p) { { std::lock_guard<std::mutex> lk(m); free_.push_back(p); } cv.notify_one(); }
+      ~RawPool() { for (auto p : free_) kmx_free_pinned(p); }
+    } rawpool;
+    rawpool.cap = 3 * (size_t)NW + 2; rawpool.words = raw_words;
     std::atomic<uint32_t> next_sample{0};
     // A sample's batches must reach its worker in order; samples are taken in fof order by `readers` threads per round so the
     // GPU workers see them nearly in order too.
     auto reader_fn = [&]() {
       for (uint32_t si; (si = next_sample++) < N;) {
-        Channel<ReadBatch>& ch = *chan[si % G];
+        Channel<ReadBatch>& ch = *chan[si % NW];
         ReadBatch b; b.si = si; b.offs.assign(1, 0);
         double rs = 0;
         // (a sample's reads reach the GPU in batches of 256 MB of bases; KMX_READ_BATCH_BYTES lowers that -- for the tests of the
@@ -370,11 +420,12 @@ int run(int argc, char** argv)
     for (uint32_t r = 0; r < readers; r++) rthreads.emplace_back(reader_fn);
 
     struct SampleState {
-      std::vector<std::vector<uint8_t>> streams; std::vector<uint64_t> nk;
+      std::vector<std::vector<uint8_t>> streams; std::vector<uint64_t> nk, nk_all;      // k-mers per selected partition / per partition
       std::vector<uint64_t> pc, ms, mk; uint64_t nb_superk = 0;
     };
     std::atomic<uint32_t> samples_left{N};
-    std::vector<uint32_t> per_gpu(G, 0); for (uint32_t si = 0; si < N; si++) per_gpu[si % G]++;
+    std::vector<uint32_t> per_gpu(NW, 0); for (uint32_t si = 0; si < N; si++) per_gpu[si % NW]++;
+    const size_t list_rec_bytes = (hash_mode ? 1 : kw) * 8 + 4;
     auto worker_fn = [&](uint32_t g) {
       kmx_ctx* c = gpu[g];
       std::map<uint32_t, SampleState> open;
@@ -385,7 +436,54 @@ int run(int argc, char** argv)
       while (done < per_gpu[g]) {
         ReadBatch b;
         if (!chan[g]->pop(b)) break;
-        if (b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk" && !(o.hist && restricted)) {      // (the fused call counts every partition: not what a histogram of the selected ones needs)
+        const bool whole_sample = b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk" && !(o.hist && restricted);      // (the fused calls count every partition: not what a histogram of the selected ones needs)
+        bool fits = resident_mode && whole_sample;
+        if (fits) {   // a k-mer per base at most, a record per k-mer at most: room for that in every store (its share of the partitions)
+          const uint64_t worst = (uint64_t)b.bases.size() * list_rec_bytes / G + (1u << 20);
+          for (uint32_t d = 0; d < G; d++) if (kmx_store_used(stores[d]) + worst > kmx_store_limit(stores[d])) fits = false;
+        }
+        if (fits) {
+          // ---- the whole sample in one batch, its counts stay in HBM: split + count in one call (kmx_count_reads_dev), partition
+          //      p's list lands in the store of shard p mod G; only numbers and the statistics tables come back ----
+          const auto t = clk::now();
+          const uint32_t si = b.si; const Sample& smp = samples[si];
+          tlog(g, "split_begin", si);
+          st.bases += b.bases.size();
+          std::vector<kmx_list> ls(P); std::vector<uint64_t> nkp(P, 0);
+          auto info = std::make_shared<std::vector<uint64_t>>(2 * (size_t)P, 0);
+          uint32_t* rawbuf = o.skip_pinfo ? nullptr : rawpool.get();
+          kmx_superk_raw raw{};
+          if (rawbuf) { raw.part_radix = rawbuf; raw.minim_superks = rawbuf + (size_t)P * 1280; raw.minim_kmers = raw.minim_superks + nm; }
+          if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
+          chk(c, kmx_count_reads_dev(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, smp.hard_min,
+                                     stores.data(), G, ls.data(), nkp.data(), nullptr, nullptr, info->data(), nullptr, rawbuf ? &raw : nullptr), "kmx_count_reads_dev");
+          if (o.hist) writes.push_back(save_hist(c, si));
+          for (uint32_t p = 0; p < P; p++) res_lists[(size_t)si * P + p] = selected[p] ? ls[p] : kmx_list{nullptr, 0};
+          res_flag[si] = 1;
+          uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
+          st.kmers += nkt;
+          const uint64_t nsk = raw.nb_superk;
+          auto nkp_s = std::make_shared<std::vector<uint64_t>>(std::move(nkp));
+          const std::string sid = smp.id;
+          writes.push_back(pool.submit([=, &rawpool, &selected]() {
+            try {
+              { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string((*nkp_s)[p]); s2 += "\n"; }      // every partition, as dump_pinfo does (gatb_utils.hpp:46-51)
+                Out pi(root + "/partition_infos/" + sid + ".pinfo"); pi.raw(s2.data(), s2.size()); pi.close(); }
+              const std::string sd = root + "/superkmers/" + sid; fs::create_directories(sd);
+              { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
+                for (uint32_t p = 0; p < P; p++) inf += std::to_string(selected[p] ? (*info)[2 * p] : 0) + "\n" + std::to_string(selected[p] ? (*info)[2 * p + 1] : 0) + "\n";
+                Out f(sd + "/SuperKmerBinInfoFile"); f.raw(inf.data(), inf.size()); f.close(); }
+              if (rawbuf) write_parti_info_raw(sd + "/PartiInfoFile", P, nm, nsk, rawbuf, rawbuf + (size_t)P * 1280, rawbuf + (size_t)P * 1280 + nm);
+            } catch (const std::exception& e) { die(e.what()); }
+            if (rawbuf) rawpool.put(rawbuf);
+          }));
+          tlog(g, "split_end", si);
+          w_count += since(t);
+          done++;
+          while (writes.size() > 64) { writes.front().get(); writes.pop_front(); }
+          continue;
+        }
+        if (whole_sample) {
           // ---- the whole sample in one batch: split + count in one call, the super-k-mer streams stay in HBM (kmx_count_reads) ----
           const auto t = clk::now();
           const uint32_t si = b.si; const Sample& smp = samples[si];
@@ -403,7 +501,7 @@ int run(int argc, char** argv)
           if (o.hist) writes.push_back(save_hist(c, si));
           uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
           st.kmers += nkt;
-          { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string(selected[p] ? nkp[p] : 0); s2 += "\n"; }
+          { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string(nkp[p]); s2 += "\n"; }      // every partition, as dump_pinfo does (gatb_utils.hpp:46-51; the split counts them all, fill_partitions.hpp:59-105)
             Out pi(root + "/partition_infos/" + smp.id + ".pinfo"); pi.raw(s2.data(), s2.size()); pi.close(); }
           const std::string sd = root + "/superkmers/" + smp.id; fs::create_directories(sd);
           { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
@@ -434,7 +532,7 @@ int run(int argc, char** argv)
           continue;
         }
         SampleState& S = open[b.si];
-        if (S.streams.empty()) { S.streams.resize(P); S.nk.assign(P, 0); if (!o.skip_pinfo) { S.pc.assign((size_t)P * KMX_PINFO_STRIDE, 0); S.ms.assign(nm, 0); S.mk.assign(nm, 0); } }
+        if (S.streams.empty()) { S.streams.resize(P); S.nk.assign(P, 0); S.nk_all.assign(P, 0); if (!o.skip_pinfo) { S.pc.assign((size_t)P * KMX_PINFO_STRIDE, 0); S.ms.assign(nm, 0); S.mk.assign(nm, 0); } }
         if (b.offs.size() > 1) {
           const auto t = clk::now();
           tlog(g, "split_begin", b.si);
@@ -447,6 +545,7 @@ int run(int argc, char** argv)
             S.nb_superk += ks.nb_superk;
           }
           for (uint32_t p = 0; p < P; p++) {
+            S.nk_all[p] += ok[p];
             if (selected[p]) { S.streams[p].insert(S.streams[p].end(), ob[p], ob[p] + ol[p]); S.nk[p] += ok[p]; }   // --restrict-to: other partitions are dropped (superk_storage.hpp:301)
             kmx_free(ob[p]);
           }
@@ -456,9 +555,9 @@ int run(int argc, char** argv)
         if (!b.last) continue;
         // ---- the sample is complete ----
         const uint32_t si = b.si; const Sample& smp = samples[si];
-        uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) nkt += S.nk[p];
+        uint64_t nkt = 0, nkt_all = 0; for (uint32_t p = 0; p < P; p++) { nkt += S.nk[p]; nkt_all += S.nk_all[p]; }
         st.kmers += nkt;
-        { std::string s; for (uint32_t p = 0; p < P; p++) { s += std::to_string(S.nk[p]); s += "\n"; }   // gatb_utils.hpp:46-51
+        { std::string s; for (uint32_t p = 0; p < P; p++) { s += std::to_string(S.nk_all[p]); s += "\n"; }   // gatb_utils.hpp:46-51 (every partition: the split counts them all)
           Out pi(root + "/partition_infos/" + smp.id + ".pinfo"); pi.raw(s.data(), s.size()); pi.close(); }
         const std::string sd = root + "/superkmers/" + smp.id; fs::create_directories(sd);
         {
@@ -481,7 +580,7 @@ int run(int argc, char** argv)
         if (!o.skip_pinfo) {
           auto pc = std::make_shared<std::vector<uint64_t>>(std::move(S.pc)); auto ms = std::make_shared<std::vector<uint64_t>>(std::move(S.ms)); auto mk = std::make_shared<std::vector<uint64_t>>(std::move(S.mk));
           const uint64_t nsk = S.nb_superk;
-          writes.push_back(pool.submit([=]() { try { write_parti_info(sd + "/PartiInfoFile", P, nm, nsk, nkt, pc->data(), ms->data(), mk->data()); } catch (const std::exception& e) { die(e.what()); } }));
+          writes.push_back(pool.submit([=]() { try { write_parti_info(sd + "/PartiInfoFile", P, nm, nsk, nkt_all, pc->data(), ms->data(), mk->data()); } catch (const std::exception& e) { die(e.what()); } }));
         }
         if (o.until != "superk") {
           const auto t = clk::now();
@@ -531,11 +630,13 @@ int run(int argc, char** argv)
       (void)samples_left;
     };
     std::vector<std::thread> wthreads;
-    for (uint32_t g = 0; g < G; g++) wthreads.emplace_back(worker_fn, g);
+    for (uint32_t w = 0; w < NW; w++) wthreads.emplace_back(worker_fn, w);
     for (auto& t : rthreads) t.join();
     for (auto& t : wthreads) t.join();
     st.read = s_read; st.split = s_split; st.count = s_count;
   }
+  st.count_wall = since(t_count_stage);
+  const auto t_merge_stage = clk::now();
   if (o.until == "superk" || o.until == "count") { report(); return 0; }
 
   // ================= merge, one task per partition (task_scheduler.hpp:381-417), batched per GPU =================
@@ -562,8 +663,26 @@ int run(int argc, char** argv)
   }
   {
     std::mutex tm; double s_io = 0, s_merge = 0, s_format = 0;
-    struct PartIn { uint32_t p = 0; std::vector<kmx_list> lists; };
+    struct PartIn { uint32_t p = 0; std::vector<kmx_list> lists; std::vector<uint8_t> on_dev; };
     struct Batch { std::vector<PartIn> parts; uint8_t* buf = nullptr; uint64_t bytes = 0; double io_s = 0; };
+    // matrix bodies leave the device in pieces: a ring of pinned buffers shared by the shards (KMX_OUT_RING_MB, default 2048, in
+    // pieces of 32 MB); a piece is handed to the pool (pwrite at its place in the file) and comes back to the ring when written --
+    // what is pending is bounded in bytes, whatever the cohort
+    struct Ring {
+      std::mutex m; std::condition_variable cv; std::vector<uint8_t*> free_; size_t made = 0, cap = 64, bytes = (size_t)32 << 20;
+      uint8_t* get() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          if (!free_.empty()) { uint8_t* p = free_.back(); free_.pop_back(); return p; }
+          if (made < cap) { made++; lk.unlock(); uint8_t* p = (uint8_t*)kmx_alloc_pinned(bytes); if (!p) die("pinned host allocation failed"); return p; }
+          cv.wait(lk);
+        }
+      }
+      void put(uint8_t* p) { { std::lock_guard<std::mutex> lk(m); free_.push_back(p); } cv.notify_one(); }
+      ~Ring() { for (auto p : free_) kmx_free_pinned(p); }
+    } ring;
+    if (const char* e = getenv("KMX_OUT_RING_MB")) ring.cap = std::max<size_t>(2, (size_t)atol(e) / 32);
+    if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(4096, (size_t)atol(e) << 10); ring.cap = std::max<size_t>(ring.cap, 4); }      // (small pieces: for the tests)
     struct Pinned { uint8_t* p = nullptr; uint64_t cap = 0; void need(uint64_t n) { if (n <= cap) return; kmx_free_pinned(p); cap = n + n / 8 + (1u << 20); p = (uint8_t*)kmx_alloc_pinned(cap); if (!p) die("pinned host allocation failed"); } ~Pinned() { kmx_free_pinned(p); } };
 
     auto worker_fn = [&](uint32_t g) {
@@ -571,16 +690,23 @@ int run(int argc, char** argv)
       std::vector<uint32_t> mine;
       for (size_t i = g; i < plist.size(); i += G) mine.push_back(plist[i]);       // partitions shard round-robin, no collective
       if (mine.empty()) return;
-      // batches: count-file bytes (+ Bloom image bytes) up to the budget
+      // batches: count-list bytes (+ Bloom image bytes) up to the budget.  A list is resident (kmx_store) or a count file.
+      // COUNT / PA: libkmx sizes its row arenas from the rows-per-record ratio of the batches a context has completed, and a first
+      // batch of full size would run twice if the default guess is too small (a cohort keeps several rows per record of a list):
+      // the first batch is ONE partition and is waited for before the second is submitted.
       const uint64_t budget = std::max<uint64_t>(o.merge_batch_mb, 16) << 20;
-      std::vector<std::vector<uint32_t>> batches; std::vector<std::vector<uint64_t>> fsize;   // per batch: partitions, file sizes [part][sample]
+      std::vector<std::vector<uint32_t>> batches; std::vector<std::vector<uint64_t>> fsize;   // per batch: partitions, file sizes [part][sample] (0: resident)
+      const bool calibrate = !is_bloom && mine.size() > 2;
       {
         std::vector<uint32_t> cur; std::vector<uint64_t> cur_sz; uint64_t acc = 0;
         for (uint32_t p : mine) {
-          uint64_t pb = 0; std::vector<uint64_t> sz(N);
-          for (uint32_t i = 0; i < N; i++) { std::error_code ec; sz[i] = fs::file_size(count_path(p, i), ec); if (ec) die(count_path(p, i) + " is missing."); pb += sz[i]; }   // kmdir.hpp:69-70
+          uint64_t pb = 0; std::vector<uint64_t> sz(N, 0);
+          for (uint32_t i = 0; i < N; i++) {
+            if (res_flag[i]) { pb += res_lists[(size_t)i * P + p].n * rec_bytes; continue; }
+            std::error_code ec; sz[i] = fs::file_size(count_path(p, i), ec); if (ec) die(count_path(p, i) + " is missing."); pb += sz[i];   // kmdir.hpp:69-70
+          }
           if (is_bloom) pb += hw.wbits * (uint64_t)(what == "bfc" ? ((uint64_t)N * o.bitw + 7) / 8 : (N + 7) / 8) * (what == "bft" ? 2 : 1);
-          if (!cur.empty() && (acc + pb > budget || cur.size() >= 64)) { batches.push_back(cur); fsize.push_back(cur_sz); cur.clear(); cur_sz.clear(); acc = 0; }
+          if (!cur.empty() && (acc + pb > budget || cur.size() >= 64 || (calibrate && batches.empty()))) { batches.push_back(cur); fsize.push_back(cur_sz); cur.clear(); cur_sz.clear(); acc = 0; }
           cur.push_back(p); cur_sz.insert(cur_sz.end(), sz.begin(), sz.end()); acc += pb;
         }
         if (!cur.empty()) { batches.push_back(cur); fsize.push_back(cur_sz); }
@@ -592,13 +718,24 @@ int run(int argc, char** argv)
         const auto& parts = batches[bi]; const auto& sz = fsize[bi];
         const bool direct = !hash_mode && !o.cpr;       // our own .kmer files: 41-byte header, then the records exactly as kmx_list wants them
         B.parts.resize(parts.size());
-        if (direct) {
+        for (size_t a = 0; a < parts.size(); a++) {      // the resident lists: merged where they lie
+          B.parts[a].p = parts[a]; B.parts[a].lists.assign(N, kmx_list{nullptr, 0}); B.parts[a].on_dev.assign(N, 0);
+          for (uint32_t i = 0; i < N; i++) if (res_flag[i]) { B.parts[a].lists[i] = res_lists[(size_t)i * P + parts[a]]; B.parts[a].on_dev[i] = 1; }
+        }
+        bool any_file = false; for (uint32_t i = 0; i < N; i++) any_file |= !res_flag[i];
+        if (!any_file) { B.bytes = 0; B.buf = nullptr; }
+        else if (direct) {
           std::vector<uint64_t> off(parts.size() * N + 1, 0);
-          for (size_t j = 0; j < parts.size() * N; j++) { if (sz[j] < 41) die("Invalid file format: " + count_path(parts[j / N], (uint32_t)(j % N))); off[j + 1] = off[j] + (sz[j] - 41) / rec_bytes * rec_bytes; }
+          for (size_t j = 0; j < parts.size() * N; j++) {
+            if (res_flag[j % N]) { off[j + 1] = off[j]; continue; }
+            if (sz[j] < 41) die("Invalid file format: " + count_path(parts[j / N], (uint32_t)(j % N)));
+            if ((sz[j] - 41) % rec_bytes) die("truncated count file (its body is no whole number of records): " + count_path(parts[j / N], (uint32_t)(j % N)));
+            off[j + 1] = off[j] + (sz[j] - 41);
+          }
           B.bytes = off.back(); pin[bi & 1].need(B.bytes + 64); B.buf = pin[bi & 1].p;
-          for (size_t a = 0; a < parts.size(); a++) { B.parts[a].p = parts[a]; B.parts[a].lists.resize(N); }
           pool.for_each(parts.size() * N, [&](size_t j) {
             const uint32_t p = parts[j / N], i = (uint32_t)(j % N);
+            if (res_flag[i]) return;
             const std::string path = count_path(p, i);
             const int fd = open(path.c_str(), O_RDONLY); if (fd < 0) die("Unable to read at " + path);
             uint8_t h[41]; if (pread(fd, h, 41, 0) != 41 || rd<uint64_t>(h) != MAGIC_BASE || rd<uint64_t>(h + 13) != MAGIC_KMER || h[12] != 0 || rd<uint32_t>(h + 29) != 4 || rd<uint32_t>(h + 25) != kw) { close(fd); die("Invalid file format: " + path); }
@@ -611,14 +748,15 @@ int run(int argc, char** argv)
         } else {
           std::vector<std::vector<uint8_t>> recs(parts.size() * N);
           pool.for_each(parts.size() * N, [&](size_t j) {
+            if (res_flag[j % N]) return;
             const std::string path = count_path(parts[j / N], (uint32_t)(j % N));
             try { recs[j] = hash_mode ? read_hash_records(path, nullptr) : read_kmer_records(path, nullptr, nullptr); } catch (const std::exception& e) { die(e.what()); }
           });
           std::vector<uint64_t> off(recs.size() + 1, 0);
           for (size_t j = 0; j < recs.size(); j++) off[j + 1] = off[j] + recs[j].size();
           B.bytes = off.back(); pin[bi & 1].need(B.bytes + 64); B.buf = pin[bi & 1].p;
-          for (size_t a = 0; a < parts.size(); a++) { B.parts[a].p = parts[a]; B.parts[a].lists.resize(N); }
           pool.for_each(recs.size(), [&](size_t j) {
+            if (res_flag[j % N]) return;
             if (!recs[j].empty()) memcpy(B.buf + off[j], recs[j].data(), recs[j].size());
             B.parts[j / N].lists[j % N].recs = B.buf + off[j]; B.parts[j / N].lists[j % N].n = recs[j].size() / rec_bytes;
           });
@@ -634,16 +772,62 @@ int run(int argc, char** argv)
         chk(c, kmx_result_wait(F.R), "kmx_merge");
         w_merge += since(t);
         t = clk::now();
+        // the plain case -- no plugin, no lz4 body, not the per-sample filters -- streams the body from the device to its file
+        const bool stream_out = !plug.create && !(o.cpr && !is_bloom) && what != "bft";
         for (size_t a = 0; a < F.B.parts.size(); a++) {
           const uint32_t p = F.B.parts[a].p;
           const uint64_t nbytes = kmx_result_body_bytes(F.R, (uint32_t)a), rows = kmx_result_rows(F.R, (uint32_t)a);
-          auto body = std::make_shared<std::vector<uint8_t>>(nbytes);
           auto stats = std::make_shared<std::vector<uint64_t>>((size_t)6 * N);
-          chk(c, kmx_result_copy_body(F.R, (uint32_t)a, body->data(), nbytes), "kmx_result_copy_body");
           chk(c, kmx_result_copy_stats(F.R, (uint32_t)a, stats->data()), "kmx_result_copy_stats");
-          tlog(g, "merge_done", p);
           const kmx_merge_task T = F.tasks[a];
-          writes.push_back(pool.submit([=, &o, &plug, &samples, &hw, &tm, &s_format]() {
+          if (stream_out) {
+            const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
+            const std::string path = root + "/matrices/matrix_" + std::to_string(p) + "." + ext;
+            uint64_t hl = 0;
+            try {
+              Out out(path);
+              if (what == "count") { if (hash_mode) matrix_count_hash_header(out, N, p, false); else matrix_count_header(out, o.k, N, p, false); hl = hash_mode ? 37 : 45; }
+              else if (what == "pa") { if (hash_mode) matrix_pa_hash_header(out, N, p, false); else matrix_pa_header(out, o.k, N, p, false); hl = hash_mode ? 37 : 45; }
+              else { matrix_bf_header(out, what == "bfc" ? N * o.bitw : N, T.lower, T.upper - T.lower + 1, p); hl = 49; }
+              out.close();
+            } catch (const std::exception& e) { die(e.what()); }
+            const uint8_t* dbody = (const uint8_t*)kmx_result_body_dev(F.R, (uint32_t)a);
+            if (nbytes && !dbody) die(std::string("kmx_result_body_dev: ") + kmx_last_error(c));
+            tlog(g, "merge_done", p);
+            if (nbytes) {
+              const int fd = open(path.c_str(), O_WRONLY); if (fd < 0) die("Unable to write at " + path);
+              auto left = std::make_shared<std::atomic<uint64_t>>((nbytes + ring.bytes - 1) / ring.bytes);
+              for (uint64_t off = 0; off < nbytes; off += ring.bytes) {
+                const uint64_t n = std::min<uint64_t>(ring.bytes, nbytes - off);
+                uint8_t* piece = ring.get();
+                chk(c, kmx_copy_to_host(c, piece, dbody + off, n), "kmx_copy_to_host");
+                writes.push_back(pool.submit([=, &ring]() {
+                  uint64_t done = 0;
+                  while (done < n) { const ssize_t r = pwrite(fd, piece + done, n - done, (off_t)(hl + off + done)); if (r <= 0) break; done += (uint64_t)r; }
+                  ring.put(piece);
+                  if (done != n) die("write failed: " + path);
+                  if (--*left == 0) close(fd);
+                }));
+              }
+            }
+            writes.push_back(pool.submit([=, &o, &hw, &res_flag]() {
+              try {
+                write_merge_info(root + "/merge_infos/partition" + std::to_string(p) + ".merge_info", stats->data(), N);
+                if (what == "bf") {   // task.hpp:849-860 + utils.hpp:239-243
+                  std::ostringstream fp;
+                  for (uint32_t i = 0; i < N; i++) fp << std::fixed << std::pow(1.0 - std::pow(std::exp(1.0), -(double)(*stats)[(size_t)3 * N + i] / (double)hw.wbits), 1.0) << "\n";
+                  Out f(root + "/fpr/partition_" + std::to_string(p) + ".txt"); const std::string s2 = fp.str(); f.raw(s2.data(), s2.size()); f.close();
+                }
+                if (!o.keep_tmp) for (uint32_t i = 0; i < N; i++) if (!res_flag[i]) fs::remove(count_path(p, i));   // task.hpp:676-688
+              } catch (const std::exception& e) { die(e.what()); }
+            }));
+            while (writes.size() > 512) { writes.front().get(); writes.pop_front(); }
+            continue;
+          }
+          auto body = std::make_shared<std::vector<uint8_t>>(nbytes);
+          chk(c, kmx_result_copy_body(F.R, (uint32_t)a, body->data(), nbytes), "kmx_result_copy_body");
+          tlog(g, "merge_done", p);
+          writes.push_back(pool.submit([=, &o, &plug, &samples, &hw, &tm, &s_format, &res_flag]() {
             try {
               const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
               const bool lz4_name = o.cpr && !hash_mode && !is_bloom;                       // hash-mode matrices never get the suffix (task.hpp:794-795)
@@ -694,7 +878,7 @@ int run(int argc, char** argv)
                 }
                 std::lock_guard<std::mutex> lk(tm); s_format += since(tf);
               }
-              if (!o.keep_tmp) for (uint32_t i = 0; i < N; i++) fs::remove(count_path(p, i));   // task.hpp:676-688
+              if (!o.keep_tmp) for (uint32_t i = 0; i < N; i++) if (!res_flag[i]) fs::remove(count_path(p, i));   // task.hpp:676-688
             } catch (const std::exception& e) { die(e.what()); }
           }));
         }
@@ -719,6 +903,7 @@ int run(int argc, char** argv)
           t.mode = what == "count" ? KMX_MODE_COUNT : what == "pa" ? KMX_MODE_PA : what == "bf" ? KMX_MODE_BF : what == "bfc" ? KMX_MODE_BFC : KMX_MODE_BFT;
           if (is_bloom) { t.lower = hw.lower(p); t.upper = hw.upper(p); }
           if (plug.create) { t.rec_min = 0; t.mode = KMX_MODE_COUNT; }
+          t.list_on_device = F->B.parts[a].on_dev.data();
           for (uint32_t i = 0; i < N; i++) st.merge_recs += t.lists[i].n;
         }
         tlog(g, "merge_submit", F->B.parts[0].p);
@@ -726,9 +911,9 @@ int run(int argc, char** argv)
         chk(c, kmx_merge_host(c, F->tasks.data(), (uint32_t)F->tasks.size(), &F->R), "kmx_merge_host");
         w_merge += since(t);
         if (prev) finish(*prev);                 // (its pinned buffer is free again: the next load may take it)
-        else if (bi + 1 < batches.size()) { /* the other buffer has never been used */ }
         if (bi + 1 < batches.size()) start_load(bi + 1);
         prev = std::move(F);
+        if (bi == 0 && calibrate && batches.size() > 1) { finish(*prev); prev.reset(); }      // (the one-partition batch the arenas of the others are sized from)
       }
       if (prev) finish(*prev);
       for (auto& w : writes) w.get();
@@ -739,6 +924,7 @@ int run(int argc, char** argv)
     for (auto& t : wthreads) t.join();
     st.merge_io = s_io; st.merge = s_merge; st.format += s_format;
   }
+  st.merge_wall = since(t_merge_stage);
   report();
   struct rusage ru; getrusage(RUSAGE_SELF, &ru);
   { std::ofstream ri(root + "/run_infos.txt");                                         // task_scheduler.hpp:453-457

@@ -337,38 +337,56 @@ def test_parti_info_file(inputs, tmp_path):
 
 
 def test_two_gpu_workers_same_output(tmp_path):
-    """--gpus 2 (two worker threads with a context each; on a one-GPU box both on device 0): samples and partitions shard
-    round-robin, both workers are in flight at once (KMX_TRACE time stamps overlap) and the run directory is the one --gpus 1 writes"""
+    """--gpus G shards x --gpu-workers W count workers (a host thread and a context each; on a one-GPU box all on device 0):
+    samples go round-robin over the workers, partitions over the shards, workers are in flight at once (KMX_TRACE time stamps
+    overlap), and the run directory is the one --gpus 1 writes -- with the count lists going through count files (--keep-tmp)
+    or staying in HBM (a store per shard, kmx_count_reads_dev), with 8 shards (the shape of an 8-GPU node), and with stores so
+    small that most samples are turned away and the merge takes resident lists and count files in one batch"""
     reads = _synthetic_samples(tmp_path, 8, 200_000, 3)
-    outs = []
-    for gp in (1, 2):
-        out = tmp_path / f"run{gp}"
-        r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out), "--kmer-size", "31", "--nb-partitions", "16",
-                            "--static-repart", "--recurrence-min", "2", "--gpus", str(gp), "--merge-batch-mb", "16", "--keep-tmp"], capture_output=True, text=True,
-                           env=dict(os.environ, KMX_TRACE="1"))
+    base_cmd = [KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--kmer-size", "31", "--nb-partitions", "16",
+                "--static-repart", "--recurrence-min", "2", "--merge-batch-mb", "16"]
+    runs = {"g1_files": (["--gpus", "1", "--gpu-workers", "1", "--keep-tmp"], {}),
+            "g2_files": (["--gpus", "2", "--gpu-workers", "1", "--keep-tmp"], {}),
+            "g1_resident": (["--gpus", "1", "--gpu-workers", "2"], {}),
+            "g2_resident": (["--gpus", "2", "--gpu-workers", "2"], {"KMX_OUT_PIECE_KB": "64"}),
+            "g8_resident": (["--gpus", "8", "--gpu-workers", "1"], {}),
+            "g3_mixed": (["--gpus", "3", "--gpu-workers", "1"], {"KMX_STORE_LIMIT_MB": "8"})}
+    outs = {}
+    for name, (flags, env) in runs.items():
+        out = tmp_path / name
+        r = subprocess.run(base_cmd + ["--run-dir", str(out)] + flags, capture_output=True, text=True, env=dict(os.environ, KMX_TRACE="1", **env))
         assert r.returncode == 0, r.stderr
-        outs.append((out, r.stderr))
-    for sub in ("matrices", "merge_infos", "partition_infos"):
-        names = sorted(os.listdir(outs[0][0] / sub))
-        assert names == sorted(os.listdir(outs[1][0] / sub)) and names
-        for n in names:
-            assert open(outs[0][0] / sub / n, "rb").read() == open(outs[1][0] / sub / n, "rb").read(), (sub, n)
+        outs[name] = (out, r.stderr)
+    ref = outs["g1_files"][0]
+    for name, (out, err) in outs.items():
+        for sub in ("matrices", "merge_infos", "partition_infos"):
+            names = sorted(os.listdir(ref / sub))
+            assert names == sorted(os.listdir(out / sub)) and names, (name, sub)
+            for n in names:
+                assert open(ref / sub / n, "rb").read() == open(out / sub / n, "rb").read(), (name, sub, n)
+        rep = json.loads([l for l in err.splitlines() if l.startswith("[kmx pipeline]")][-1][len("[kmx pipeline] "):])
+        if name.endswith("_files"): assert rep["resident_samples"] == 0
+        elif name.endswith("_resident"): assert rep["resident_samples"] == 8
+        else: assert 0 < rep["resident_samples"] < 8, rep      # (some samples fitted the 8 MB stores, the others left count files)
+        if not name.endswith("_files"):   # no count file survives a run without --keep-tmp
+            assert all(not os.listdir(out / "counts" / f"partition_{p}") for p in range(16)), name
     for p in range(16):
-        for s in range(8):
-            n = f"partition_{p}/S{s:04d}.kmer"
-            assert open(outs[0][0] / "counts" / n, "rb").read() == open(outs[1][0] / "counts" / n, "rb").read()
-    # overlap: some split/count interval of worker 0 intersects one of worker 1
-    ev = {0: [], 1: []}
-    open_at = {}
-    for line in outs[1][1].splitlines():
-        if not line.startswith("[kmx trace]"): continue
-        t, g, what_, ident = line.split()[2:6]
-        t = float(t); g = int(g.split("=")[1])
-        base = what_.rsplit("_", 1)[0]
-        if what_.endswith("_begin"): open_at[(g, base, ident)] = t
-        elif what_.endswith("_end"): ev[g].append((open_at.pop((g, base, ident)), t))
-    assert ev[0] and ev[1]
-    assert any(a0 < b1 and a1 < b0 for a0, b0 in ev[0] for a1, b1 in ev[1])
+        for s_ in range(8):
+            n = f"partition_{p}/S{s_:04d}.kmer"
+            assert open(ref / "counts" / n, "rb").read() == open(outs["g2_files"][0] / "counts" / n, "rb").read()
+    # overlap: some split/count interval of one worker intersects one of another
+    for name in ("g2_files", "g2_resident"):
+        ev, open_at = {}, {}
+        for line in outs[name][1].splitlines():
+            if not line.startswith("[kmx trace]"): continue
+            t, g, what_, ident = line.split()[2:6]
+            t = float(t); g = int(g.split("=")[1])
+            base = what_.rsplit("_", 1)[0]
+            if what_.endswith("_begin"): open_at[(g, base, ident)] = t
+            elif what_.endswith("_end"): ev.setdefault(g, []).append((open_at.pop((g, base, ident)), t))
+        assert len(ev) >= 2, name
+        ws = sorted(ev)
+        assert any(a0 < b1 and a1 < b0 for i in ws for j in ws if i < j for a0, b0 in ev[i] for a1, b1 in ev[j]), name
 
 
 def _synthetic_samples(d, n_samples, genome_len, seed):
