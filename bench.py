@@ -22,6 +22,12 @@ Other workloads (`--workload`), each with its own roofline line:
   bft    configs[3]: 2500 samples, hash:bft:bin --soft-min 2 --share-min 1 (merge + on-device transpose; with more than
          one rank the per-sample Bloom rows are exchanged with one all-to-all over RCCL, kmtricks_amd/shard.py)
 
+  pipeline  the metric's second half: `kmx pipeline` end to end (FASTA files in, matrix files out) on configs[2]'s cohort at the
+         size the GPU box's disk takes (1000 samples x 1 Mbp, 256 partitions), wall clock and k-mers merged/s end to end, with
+         the oracle's split + count + merge on the host cores over a bounded sample of the same files beside it
+  all    (default on one GPU) bf, bft, pa63 and pipeline first -- their lines go into "workloads" / "pipeline" of the ONE JSON
+         line -- then the headline count workload, whose fields are the line's own
+
 Prints ONE JSON line on rank 0.
 """
 import argparse, json, os, sys, time
@@ -90,17 +96,18 @@ def xxh64_u32(v):
     return h
 
 
-def gen_counted(ctx, torch, dev, N, k, genome, d, total_parts, my_parts, seed, log):
+def gen_counted(ctx, lib, N, k, genome, d, total_parts, my_parts, seed, log):
     """Lists produced by the product's count stage: sample i = ancestor genome with i.i.d. substitutions at rate d (PCG64 seeds of
     SURVEY 8d), given twice so that every k-mer passes --hard-min 2; split with the static repartition of `total_parts`
-    partitions, counted; only this rank's partitions are kept.  -> [(records tensor, offsets)] per partition of my_parts."""
+    partitions and counted in one call with the results left in HBM (kmx_count_reads_dev into a kmx_store: what `kmx pipeline`
+    does); only this rank's partitions are used.  -> (store, lists[j][i] = (device pointer, records) for partition my_parts[j])"""
     import numpy as np
     m = 10
     table = (xxh64_u32(np.arange(4 ** m, dtype=np.uint32)) % np.uint64(total_parts)).astype(np.uint16)
     anc = np.random.Generator(np.random.PCG64(seed)).integers(0, 4, genome, dtype=np.uint8)
     letters = np.frombuffer(b"ACGT", np.uint8)
-    kw = (k + 31) // 32
-    per_part = [[] for _ in my_parts]
+    store = lib.Store(ctx.device, limit_bytes=200 << 30)
+    lists = [[] for _ in my_parts]
     L = 2000
     starts = np.arange(0, genome - k + 1, L)
     win = starts[:, None] + np.arange(L + k - 1)[None, :]                # (the last window runs into a tail of N's: no k-mers there)
@@ -113,61 +120,23 @@ def gen_counted(ctx, torch, dev, N, k, genome, d, total_parts, my_parts, seed, l
         gsm[pos] = (gsm[pos] + rng.integers(1, 4, len(pos), dtype=np.uint8)) & 3
         # the genome as overlapping 2 kb windows (every k-mer exactly once; a wave per read in the split), twice
         seq = np.concatenate([letters[gsm], np.full(L, ord("N"), np.uint8)])[win].tobytes()
-        streams = ctx.superk_partition((seq + seq, offs), k, m, table, total_parts)
-        res = ctx.count_batch([streams[p][0] for p in my_parts], k, 2)
-        for j, (keys, cnts) in enumerate(res):
-            n = len(cnts)
-            rec = np.empty((n, 2 * kw + 1), dtype=np.uint32)
-            rec[:, :2 * kw] = np.ascontiguousarray(keys, dtype=np.uint64).reshape(n, kw).view(np.uint32)
-            rec[:, 2 * kw] = cnts
-            per_part[j].append(rec)
+        ls, _, _ = ctx.count_reads_dev((seq + seq, offs), k, m, table, total_parts, 2, [store])
+        for j, p in enumerate(my_parts):
+            lists[j].append(ls[p])
         if log and (i + 1) % 100 == 0:
-            print(f"[bench] counted lists: {i + 1}/{N} samples, {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
-    parts = []
-    for lst in per_part:
-        offs = [0]
-        for r in lst:
-            offs.append(offs[-1] + len(r))
-        rec = torch.from_numpy(np.concatenate(lst).view(np.int32)).to(dev)
-        parts.append((rec, offs))
-    return parts
+            print(f"[bench] counted lists: {i + 1}/{N} samples, {time.perf_counter() - t0:.1f} s, {store.used() / 1e9:.1f} GB resident", file=sys.stderr, flush=True)
+    return store, lists
 
 
-# ---------------------------------------------------------------------------------------------- main
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["count", "bf", "pa63", "bft"], default="count")
-    ap.add_argument("--lists", choices=["counted", "random"], default="counted")
-    ap.add_argument("--samples", type=int, default=0)
-    ap.add_argument("--partitions-per-gpu", type=int, default=0)
-    ap.add_argument("--total-partitions", type=int, default=256)
-    ap.add_argument("--genome", type=float, default=5e6)
-    ap.add_argument("--subst-rate", type=float, default=0.001)
-    ap.add_argument("--rec-min", type=int, default=-1)
-    ap.add_argument("--bloom", type=float, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    from kmtricks_amd import lib, shard
+# ---------------------------------------------------------------------------------------------- merge workloads
+def merge_workload(env, a, wl, lists_kind, want_cpu):
+    """One `--workload` of the merge stage: builds its lists on this rank's GPU, times a.steps batches, returns the JSON fields
+    (on rank 0; None elsewhere)."""
+    torch, dist, lib, shard = env["torch"], env["dist"], env["lib"], env["shard"]
+    rank, world, local, dev = env["rank"], env["world"], env["local"], env["dev"]
+    import numpy as np
     ctx = lib.Context(local)
     ctx.set_profiling(True)
-
-    wl = a.workload
     defaults = {"count": (1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
     N = a.samples or defaults[0]
     P = a.partitions_per_gpu or defaults[1]
@@ -180,48 +149,66 @@ def main():
     shared = genome // total_parts
     p_present = (1.0 - a.subst_rate) ** k
     n_private = int(round(shared * (1.0 - p_present)))
-    parts, tasks_d, label, mode = [], [], "", lib.MODE_COUNT
+    keep, tasks_d, label, mode = [], [], "", lib.MODE_COUNT      # keep: whatever owns the lists' device memory
+    host_lists = None                                             # j -> [(keys, counts)] of partition my_parts[j] on the host (cpu_baseline)
     W = 0
+    rb = 8 * kw + 4
     if wl in ("count", "pa63"):
         mode = lib.MODE_COUNT if wl == "count" else lib.MODE_PA
-        if a.lists == "counted":
-            parts = gen_counted(ctx, torch, dev, N, k, genome, a.subst_rate, total_parts, my_parts, 20240601, rank == 0)
+        if lists_kind == "counted":
+            store, lists = gen_counted(ctx, lib, N, k, genome, a.subst_rate, total_parts, my_parts, 20240601, rank == 0)
+            keep.append(store)
+            def host_lists(j):
+                return [ctx.read_list(ptr, n, kw) for ptr, n in lists[j]]
         else:
             parts = [gen_partition(torch, dev, 20240601 + g, N, shared, p_present, n_private, kw) for g in my_parts]
-        rb = 8 * kw + 4
-        for rec, offs in parts:
-            base = rec.data_ptr()
-            tasks_d.append(dict(lists=[(base + rb * offs[i], offs[i + 1] - offs[i]) for i in range(N)], key_words=kw, soft_min=[1] * N,
-                                rec_min=rec_min, share_min=0, mode=mode))      # (no rows_hint: libkmx sizes the arenas from the batches it has seen)
+            keep.append(parts)
+            lists = [[(rec.data_ptr() + rb * offs[i], offs[i + 1] - offs[i]) for i in range(N)] for rec, offs in parts]
+            def host_lists(j):
+                rec, offs = parts[j]
+                h = rec.cpu().numpy().view(np.uint32)
+                return [(np.ascontiguousarray(h[offs[i]:offs[i + 1], :2 * kw]).view(np.uint64).reshape(-1, kw), np.ascontiguousarray(h[offs[i]:offs[i + 1], 2 * kw])) for i in range(N)]
+        for ls in lists:
+            tasks_d.append(dict(lists=ls, key_words=kw, soft_min=[1] * N, rec_min=rec_min, share_min=a.share_min, mode=mode))      # (no rows_hint: libkmx sizes the arenas from the batches it has seen)
         label = (f"BASELINE configs[{2 if wl == 'count' else 4}]: {N} samples, k={k}, kmer:{'count' if wl == 'count' else 'pa'}:bin, recurrence-min {rec_min}, "
-                 f"{P} of {total_parts} partitions per GPU (G={genome} bp, d={a.subst_rate}), lists: "
-                 + ("count stage output (kmx_superk_partition + kmx_count_batch)" if a.lists == "counted" else "random 62-bit keys"))
+                 + (f"share-min {a.share_min}, " if a.share_min else "")
+                 + f"{P} of {total_parts} partitions per GPU (G={genome} bp, d={a.subst_rate}), lists: "
+                 + ("count stage output resident in HBM (kmx_count_reads_dev)" if lists_kind == "counted" else "random 62-bit keys"))
     else:
         bloom = int(a.bloom) if a.bloom else (100_000_000 if wl == "bf" else 1_000_000_000)
         W = ((bloom + total_parts - 1) // total_parts + 63) // 64 * 64      # hash.hpp:31-40
         g = torch.Generator(device=dev); g.manual_seed(20240601 + rank)
         mode = lib.MODE_BF if wl == "bf" else lib.MODE_BFT
         smin, share = (1, 0) if wl == "bf" else (2, 1)
+        parts = []
         for p in my_parts:
             rec, offs = gen_hash_partition(torch, dev, g, N, shared, W * p, W)
             parts.append((rec, offs))
             base = rec.data_ptr()
             tasks_d.append(dict(lists=[(base + 12 * offs[i], offs[i + 1] - offs[i]) for i in range(N)], key_words=1, soft_min=[smin] * N,
                                 rec_min=rec_min, share_min=share, mode=mode, lower=W * p, upper=W * (p + 1) - 1))
+        keep.append(parts)
+        def host_lists(j):
+            rec, offs = parts[j]
+            h = rec.cpu().numpy().view(np.uint32)
+            return [(np.ascontiguousarray(h[offs[i]:offs[i + 1], :2]).view(np.uint64).reshape(-1), np.ascontiguousarray(h[offs[i]:offs[i + 1], 2])) for i in range(N)]
         label = (f"BASELINE configs[{1 if wl == 'bf' else 3}]: {N} samples, k=31, hash:{wl}:bin, bloom {bloom:.0e} / {total_parts} partitions "
                  f"(window {W} bits), soft-min {smin}, share-min {share}, {P} partitions per GPU and step (G={genome} bp)")
-    total_recs = sum(rec.shape[0] for rec, _ in parts)
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()           # (the generators' scratch goes back to the device: libkmx allocates beside torch)
+    total_recs = sum(n for d_ in tasks_d for _, n in d_["lists"])
+    sync = env.get("sync", torch.cuda.synchronize)
+    empty_cache = env.get("empty_cache", torch.cuda.empty_cache)
+    sync()
+    empty_cache()           # (the generators' scratch goes back to the device: libkmx allocates beside torch)
     tasks = ctx.prepare(tasks_d)
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    kernel_ms, tr_ms, algo_bytes, rows_out, kernel_name = [], [], 0, 0, ""
+    kernel_ms, tr_ms, kernel_name = [], [], ""
+    algo_bytes = rows_out = 0
     xbuf = None
     if wl == "bft" and world > 1:
         n8 = (N + 7) // 8 * 8
@@ -270,6 +257,7 @@ def main():
     dt = time.perf_counter() - t0
     dt, job_recs = shard.reduce_job(dist if world > 1 else None, dev, dt, float(total_recs))
 
+    out = None
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = job_recs * a.steps / dt
@@ -288,18 +276,223 @@ def main():
                        "records_per_step_per_gpu": total_recs, "rows_out_per_step_per_gpu": rows_out,
                        "parallelism": f"partitions sharded over {world} GPU(s), " + ("per-sample Bloom rows exchanged by one RCCL all-to-all" if xbuf is not None else "no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(wl, a.lists, N, P, kernel_name),
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name),
                          "kernel": kname, "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
                          # streaming read rate of this access pattern measured on an MI355X (profiles/r01_h_fetch_calibration.txt)
                          "measured_stream_peak": 5654.0, "frac_of_measured": (achieved / 5654.0) if achieved else None},
         }
-        if not a.no_cpu_baseline and world == 1:      # (the host baseline is a 1-GPU line: with more ranks the others would wait ~20 s at the barrier for it)
-            out["cpu_baseline"] = cpu_baseline(parts, N, kw, tasks_d, mode)
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(host_lists, len(tasks_d), N, kw, tasks_d, mode, with_io=(wl == "count"))
+    ctx.close()
+    for x in keep:
+        if hasattr(x, "close"):
+            x.close()
+    del keep, tasks, tasks_d
+    empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- end to end
+def _pipeline_make_sample(args):
+    """one sample of SURVEY 8d's cohort as a FASTA file of error-free 150-bp reads at the given coverage, random strands"""
+    import numpy as np
+    s, G, d, cov, tmp = args
+    L = 150
+    ref = np.random.Generator(np.random.PCG64(20240601)).integers(0, 4, G, dtype=np.uint8)
+    rng = np.random.Generator(np.random.PCG64(20240601 + 1 + s))
+    g = ref
+    pos = np.nonzero(rng.random(G) < d)[0]
+    g[pos] = (g[pos] + rng.integers(1, 4, len(pos), dtype=np.uint8)) & 3
+    n_reads = G * cov // L
+    starts = rng.integers(0, G - L, n_reads)
+    reads = g[starts[:, None] + np.arange(L)[None, :]]
+    rc = rng.random(n_reads) < 0.5
+    comp = np.array([2, 3, 0, 1], np.uint8)           # A0 C1 T2 G3 -> T G A C
+    reads[rc] = comp[reads[rc]][:, ::-1]
+    letters = np.frombuffer(b"ACTG", np.uint8)
+    path = os.path.join(tmp, f"S{s:04d}.fa")
+    lines = np.empty((n_reads, L + 4), np.uint8)
+    lines[:, 0] = ord(">"); lines[:, 1] = ord("r"); lines[:, 2] = ord("\n"); lines[:, 3:3 + L] = letters[reads]; lines[:, 3 + L] = ord("\n")
+    lines.tofile(path)
+    return path
+
+
+def _pipeline_cpu_sample(args):
+    """the oracle's split + count of one sample's FASTA file (every partition) -> [(keys, counts)] per partition"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    path, k, m, P, hard_min = args
+    raw = np.fromfile(path, np.uint8)
+    reads = [bytes(r) for r in raw.reshape(-1, 154)[:, 3:153]]      # (the generator's fixed-width records)
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    sk = orc.superk_partition(reads, k, m, lut, rep, P)
+    out = []
+    for p in range(P):
+        keys, cnts = orc.count_kmer(sk[p][0], k, hard_min)
+        out.append((np.ascontiguousarray(keys).reshape(-1), cnts))
+    return out
+
+
+def pipeline_workload(a, n_gpus=1):
+    """`kmx pipeline` end to end on SURVEY 8d's cohort: FASTA files on local disk in, the run directory (matrices) out; wall clock
+    around the process.  Then the oracle (split + count + merge, a port of the reference's CPU path) over a bounded sample of the
+    same files on the host cores."""
+    import shutil, subprocess, tempfile
+    from multiprocessing import Pool
+    S, G, P, k = a.pipeline_samples, int(a.pipeline_genome), a.total_partitions, 31
+    tmp = tempfile.mkdtemp(prefix="kmx_bench_", dir=a.tmp)
+    try:
+        nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        with Pool(min(64, nproc)) as pool:
+            paths = pool.map(_pipeline_make_sample, [(s, G, a.subst_rate, 6, tmp) for s in range(S)], chunksize=4)
+        gen_s = time.perf_counter() - t0
+        with open(os.path.join(tmp, "in.fof"), "w") as fof:
+            for s, pth in enumerate(paths):
+                fof.write(f"S{s:04d}: {pth}\n")
+        run = os.path.join(tmp, "run")
+        threads = min(64, nproc)
+        cmd = [os.path.join(ROOT, "kmtricks_amd", "kmx"), "pipeline", "--file", os.path.join(tmp, "in.fof"), "--run-dir", run, "--kmer-size", str(k),
+               "--mode", "kmer:count:bin", "--hard-min", "2", "--recurrence-min", "2", "--nb-partitions", str(P), "--static-repart",
+               "-t", str(threads), "--gpus", str(n_gpus)]
+        os.sync()
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        line = [l for l in r.stderr.splitlines() if l.startswith("[kmx pipeline]")]
+        if r.returncode != 0 or not line:
+            return {"error": r.stderr[-1500:]}
+        d = json.loads(line[-1][len("[kmx pipeline] "):])
+        out_bytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(run, "matrices")) for f in fs)
+        shutil.rmtree(run, ignore_errors=True)
+        out = {"metric": "end-to-end wall-clock of kmx pipeline (FASTA in, matrices out)", "value": wall, "unit": "s", "higher_is_better": False,
+               "kmers_merged_per_s_end_to_end": d["merge_records"] / wall, "Mbases_per_s_end_to_end": d["bases"] / wall / 1e6,
+               "n_gpus": n_gpus, "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[2] end to end: {S} samples x {G} bp (d={a.subst_rate}, 150-bp reads at 6x, plain FASTA on local disk), k=31, "
+                                      f"kmer:count:bin --hard-min 2 --recurrence-min 2, {P} partitions, static repartition, {threads} host threads",
+                          "command": " ".join(cmd[1:]), "bases": d["bases"], "kmers": d["kmers"], "merge_records": d["merge_records"], "matrix_bytes": out_bytes},
+               "stages": {kk: d[kk] for kk in ("setup_wall_s", "count_wall_s", "merge_wall_s", "total_s", "read_s", "count_s", "merge_io_s", "merge_s", "gpu_workers", "resident_samples") if kk in d},
+               "fasta_generation_s": gen_s}
+        if not a.no_cpu_baseline:
+            # the host's share: the oracle over a bounded sample of the same files (whole samples through split + count on one core
+            # each, then one merge task per partition over those samples), as the reference's task pool would run them
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc
+            from concurrent.futures import ThreadPoolExecutor
+            so = os.path.join(ROOT, "oracle", "libkmx_oracle.so")
+            if not os.path.exists(so):
+                subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+            Sc = min(S, a.pipeline_cpu_samples, nproc)
+            t0 = time.perf_counter()
+            with Pool(min(Sc, nproc)) as pool:
+                counted = pool.map(_pipeline_cpu_sample, [(paths[s], k, 10, P, 2) for s in range(Sc)])
+            t_count = time.perf_counter() - t0
+            def merge_p(p):
+                _, rows, _ = orc.merge_matrix([counted[s][p] for s in range(Sc)], 1, [1] * Sc, 2, 0, orc.MODE_COUNT)
+                return rows
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(min(nproc, P)) as ex:
+                rows = list(ex.map(merge_p, range(P)))
+            t_merge = time.perf_counter() - t1
+            recs = sum(len(counted[s][p][1]) for s in range(Sc) for p in range(P))
+            cw = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": recs / cw, "unit": "k-mers merged/s end to end", "cores": min(Sc, nproc), "kind": "port", "host_cores": nproc,
+                                   "wall_s_per_sample_set": cw, "split_count_s": t_count, "merge_s": t_merge,
+                                   "sample": f"{Sc} of the {S} samples' FASTA files: oracle split + count of a whole sample per process ({min(Sc, nproc)} processes), "
+                                             f"then one oracle merge task per partition ({P}) on a thread pool; {recs} records merged, {sum(rows)} rows; in memory, no "
+                                             f"intermediate files (the reference writes and re-reads super-k-mer and count files)"}
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------- main
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["auto", "all", "count", "bf", "pa63", "bft", "pipeline"], default="auto")
+    ap.add_argument("--lists", choices=["counted", "random"], default="counted")
+    ap.add_argument("--samples", type=int, default=0)
+    ap.add_argument("--partitions-per-gpu", type=int, default=0)
+    ap.add_argument("--total-partitions", type=int, default=256)
+    ap.add_argument("--genome", type=float, default=5e6)
+    ap.add_argument("--subst-rate", type=float, default=0.001)
+    ap.add_argument("--rec-min", type=int, default=-1)
+    ap.add_argument("--share-min", type=int, default=0)
+    ap.add_argument("--bloom", type=float, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-samples", type=int, default=1000)
+    ap.add_argument("--pipeline-genome", type=float, default=1e6)
+    ap.add_argument("--pipeline-cpu-samples", type=int, default=64)
+    ap.add_argument("--tmp", default=None, help="directory for the end-to-end workload's files (default: the system's temporary directory)")
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    wl = a.workload
+    if wl == "auto":      # one GPU: every workload in one invocation; several ranks (the scaling runs): the headline workload
+        wl = "all" if world == 1 else "count"
+    if wl == "pipeline":
+        if rank == 0:
+            print(json.dumps(pipeline_workload(a, a.gpus if world == 1 else 1)))
+        return
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from kmtricks_amd import lib, shard
+    env = dict(torch=torch, dist=dist, lib=lib, shard=shard, rank=rank, world=world, local=local, dev=dev)
+    out = run_workloads(a, wl, env)
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+
+
+def run_workloads(a, wl, env):
+    """the merge workloads of one invocation on this rank; -> the JSON line's fields on rank 0 (None elsewhere).  env: torch, dist
+    (None on one rank), lib (the ctypes binding of libkmx), shard, rank, world, local, dev (+ sync / empty_cache overrides: the CPU
+    test of this plumbing runs it under a two-rank gloo group with a stand-in for lib)"""
+    rank, world = env["rank"], env["world"]
+    want_cpu = not a.no_cpu_baseline and world == 1      # (the host baseline is a 1-GPU line: with more ranks the others would wait at the barrier for it)
+    extras, pipe = {}, None
+    if wl == "all":
+        t_all = time.perf_counter()
+        for w in ("bf", "bft", "pa63"):
+            try:
+                extras[w] = merge_workload(env, a, w, "counted", want_cpu)
+            except Exception as e:      # (a side line must not cost the headline one)
+                extras[w] = {"error": repr(e)}
+            if rank == 0:
+                print(f"[bench] workload {w} done, {time.perf_counter() - t_all:.0f} s", file=sys.stderr, flush=True)
+        if rank == 0:
+            try:
+                pipe = pipeline_workload(a)
+            except Exception as e:
+                pipe = {"error": repr(e)}
+            print(f"[bench] workload pipeline done, {time.perf_counter() - t_all:.0f} s", file=sys.stderr, flush=True)
+        wl = "count"
+    out = merge_workload(env, a, wl, a.lists, want_cpu)
+    if rank == 0:
+        if extras:
+            out["workloads"] = extras
+        if pipe is not None:
+            out["pipeline"] = pipe
+    return out
 
 
 def pmc_traffic(wl, lists, N, P, kernel):
@@ -313,14 +506,15 @@ def pmc_traffic(wl, lists, N, P, kernel):
     return d["fetch_bytes"] + d["write_bytes"] if d else None
 
 
-def cpu_baseline(parts, N, kw, tasks_d, mode, budget_s=20.0):
-    """The oracle (a port of the reference's KmerMerger / HashMerger linear-scan merge, merge.hpp:183-260, 441-517, 575-644) on ALL
-    host cores with the reference's task granularity -- one merge task per partition handed to a pool of nproc threads
-    (task_scheduler.hpp:381-417) -- over a bounded sample: whole partitions of the workload until ~budget_s seconds of summed CPU work.
-    The checker timed as a baseline; never part of the measured GPU path."""
+def cpu_baseline(host_lists, n_parts, N, kw, tasks_d, mode, with_io=False):
+    """The oracle (a port of the reference's KmerMerger / HashMerger linear-scan merge, merge.hpp:183-260, 441-517, 575-644) on the
+    host cores with the reference's task granularity -- one merge task per partition handed to a pool of threads
+    (task_scheduler.hpp:381-417) -- over ALL partitions of the step, on min(partitions, cores) threads.  with_io: a second figure
+    with the files around it, as KmerMergeTask::exec has them (task.hpp:690-743): every task reads its N count files
+    (counts/partition_<p>/<id>.kmer) and writes its matrix file.  The checker timed as a baseline; never part of the measured GPU path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    import subprocess
+    import shutil, subprocess, tempfile
     from concurrent.futures import ThreadPoolExecutor
     so = os.path.join(ROOT, "oracle", "libkmx_oracle.so")
     if not os.path.exists(so):
@@ -328,37 +522,59 @@ def cpu_baseline(parts, N, kw, tasks_d, mode, budget_s=20.0):
     import orc
     omode = {0: orc.MODE_COUNT, 1: orc.MODE_PA, 2: orc.MODE_BF, 3: orc.MODE_BFC, 4: orc.MODE_BFT}[mode]
     nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # one partition on one core first: sizes the sample
-    def host_lists(j):
-        rec, offs = parts[j]
-        h = rec.cpu().numpy().view(np.uint32)
-        out = []
-        for i in range(N):
-            r = h[offs[i]:offs[i + 1]]
-            out.append((np.ascontiguousarray(r[:, :2 * kw]).view(np.uint64).reshape(-1), np.ascontiguousarray(r[:, 2 * kw])))
-        return out
+    n_thr = max(1, min(nproc, n_parts))
 
     def merge(j, lists):
         d = tasks_d[j]
         t0 = time.perf_counter()
         body, rows, stats = orc.merge_matrix(lists, kw, d["soft_min"], d["rec_min"], d["share_min"], omode, d.get("lower", 0), d.get("upper", 0))
-        return time.perf_counter() - t0, rows
+        return time.perf_counter() - t0, rows, body
 
-    l0 = host_lists(0)
-    one_s, _ = merge(0, l0)
-    n_tasks = int(max(1, min(len(parts), budget_s / max(one_s, 1e-3))))
-    n_thr = max(1, min(nproc, n_tasks))
-    all_lists = [l0] + [host_lists(j) for j in range(1, n_tasks)]
+    all_lists = [host_lists(j) for j in range(n_parts)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(n_thr) as ex:          # (ctypes releases the GIL: the merges run in parallel)
-        res = list(ex.map(lambda j: merge(j, all_lists[j]), range(n_tasks)))
+        res = list(ex.map(lambda j: merge(j, all_lists[j])[:2], range(n_parts)))
     wall = time.perf_counter() - t0
-    recs = sum(int(parts[j][1][-1]) for j in range(n_tasks))
-    return {"value": recs / wall, "unit": "k-mers/s", "cores": n_thr, "kind": "port",
-            "host_cores": nproc, "per_core": recs / sum(r[0] for r in res),
-            "sample": f"{n_tasks} of the {len(parts)} partitions of the step ({recs} input records, {sum(r[1] for r in res)} rows out), one merge task per "
-                      f"partition on a pool of {n_thr} threads (host has {nproc} cores), oracle linear-scan merge, {wall:.1f} s wall, "
-                      f"{sum(r[0] for r in res):.1f} s of CPU"}
+    recs = sum(len(c) for ls in all_lists for _, c in ls)
+    out = {"value": recs / wall, "unit": "k-mers/s", "cores": n_thr, "kind": "port",
+           "host_cores": nproc, "per_core": recs / sum(r[0] for r in res),
+           "sample": f"all {n_parts} partitions of the step ({recs} input records, {sum(r[1] for r in res)} rows out), one merge task per "
+                     f"partition on a pool of {n_thr} threads (host has {nproc} cores), oracle linear-scan merge in memory, {wall:.1f} s wall, "
+                     f"{sum(r[0] for r in res):.1f} s of CPU"}
+    if with_io:
+        tmp = tempfile.mkdtemp(prefix="kmx_cpu_")
+        try:
+            rbw = 2 * kw + 1
+            def write_part(j):
+                os.makedirs(os.path.join(tmp, f"partition_{j}"))
+                for i, (kk, cc) in enumerate(all_lists[j]):
+                    rec = np.empty((len(cc), rbw), np.uint32)
+                    rec[:, :2 * kw] = np.ascontiguousarray(kk, dtype=np.uint64).reshape(len(cc), kw).view(np.uint32)
+                    rec[:, 2 * kw] = cc
+                    with open(os.path.join(tmp, f"partition_{j}", f"{i}.kmer"), "wb") as f:
+                        f.write(b"\0" * 41); rec.tofile(f)
+            with ThreadPoolExecutor(n_thr) as ex:
+                list(ex.map(write_part, range(n_parts)))
+            del all_lists
+            os.sync()
+            def task(j):      # KmerMergeTask::exec: count files in, matrix file out
+                lists = []
+                for i in range(N):
+                    rec = np.fromfile(os.path.join(tmp, f"partition_{j}", f"{i}.kmer"), np.uint32, offset=41).reshape(-1, rbw)
+                    lists.append((np.ascontiguousarray(rec[:, :2 * kw]).view(np.uint64).reshape(-1, kw), np.ascontiguousarray(rec[:, 2 * kw])))
+                _, rows, body = merge(j, lists)
+                with open(os.path.join(tmp, f"matrix_{j}.count"), "wb") as f:
+                    f.write(b"\0" * 45); f.write(body)
+                return rows
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(n_thr) as ex:
+                rows = list(ex.map(task, range(n_parts)))
+            wall_io = time.perf_counter() - t0
+            out["with_io"] = {"value": recs / wall_io, "unit": "k-mers/s", "wall_s": wall_io,
+                              "sample": f"the same {n_parts} tasks, each reading its {N} count files and writing its matrix file ({sum(rows)} rows) on the box's local disk"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":

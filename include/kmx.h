@@ -136,6 +136,9 @@ double   kmx_result_transpose_ms(kmx_merge_result* r);
 const void* kmx_result_body_dev(kmx_merge_result* r, uint32_t task);
 const char* kmx_result_kernel(const kmx_merge_result* r);
 uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA), window rows (BF/BFC), round_up8(N) (BFT) */
+/* COUNT/PA results of k_merge_cols: how many of the task's rows came out of k_cols_sparse (keys outside the row keys the
+ * column blocks are built on: sample-private k-mers, k-mers a few samples share); 0 for the other kernels */
+uint64_t kmx_result_sparse_rows(const kmx_merge_result* r, uint32_t task);
 uint64_t kmx_result_row_bytes(const kmx_merge_result* r, uint32_t task);
 uint64_t kmx_result_body_bytes(const kmx_merge_result* r, uint32_t task);  /* rows * row_bytes */
 /* algorithmic bytes moved for this task: input records + output rows (DESIGN.md roofline) */

@@ -924,6 +924,7 @@ extern "C" double kmx_result_kernel_ms(kmx_merge_result* R)
   return (double)ms;
 }
 extern "C" uint64_t kmx_result_rows(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].rows : 0; }
+extern "C" uint64_t kmx_result_sparse_rows(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size() && R->tasks[t].kernel == 2) ? R->tasks[t].sparse_rows : 0; }
 extern "C" uint64_t kmx_result_row_bytes(const kmx_merge_result* R, uint32_t t)
 { return (R && t < R->tasks.size()) ? (R->is_bft ? R->tasks[t].t_rows >> 3 : R->tasks[t].row_bytes) : 0; }
 extern "C" uint64_t kmx_result_body_bytes(const kmx_merge_result* R, uint32_t t)

@@ -689,3 +689,16 @@ def test_batch_of_tasks_with_different_list_counts(monkeypatch):
             assert res.rows(t) == er and res.body(t) == eb and np.array_equal(res.stats(t), es), (mode, t)
         res.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("workload", ["count", "pa63"])
+def test_bench_workload_full_size_parity(workload):
+    """The workload the bench line is quoted on, at its full size, on the lists the bench times (the product's count stage, 32
+    partitions of the 1000 x 5 Mbp cohort / the 500-sample k = 63 cohort): k_merge_cols + k_cols_sparse == k_merge_pivot ==
+    k_merge_rows by sha256 of every partition's body and statistics, rows ascending, rows out of k_cols_sparse present, partition
+    0 == the oracle (scripts/verify_bench_parity.py)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import verify_bench_parity
+    rep = verify_bench_parity.verify(workload, "counted")
+    assert rep["all_kernels_equal_sha256"] and rep["rows_from_k_cols_sparse"] > 0 and rep["rows_total"] > 1_000_000
