@@ -256,6 +256,19 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     barrier()
     dt = time.perf_counter() - t0
     dt, job_recs = shard.reduce_job(dist if world > 1 else None, dev, dt, float(total_recs))
+    # the timed step leaves COUNT / PA rows in HBM as the kernels produce them (k_merge_cols: the row keys' rows and the rows out of
+    # k_cols_sparse, each list ascending); a consumer that wants the body in file order ON THE DEVICE (kmx_result_body_dev: the
+    # pipeline's writer, an RCCL send) pays a device-to-device pass once per result: timed here, outside the step, and reported
+    gather_ms = None
+    if wl in ("count", "pa63") and hasattr(lib, "_lib"):
+        res = ctx.merge_dev(tasks); res.wait()
+        sync()
+        tg = time.perf_counter()
+        for t in range(P):
+            res.body_dev(t)
+        sync()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        res.free()
 
     out = None
     if rank == 0:
@@ -278,6 +291,8 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name),
                          "kernel": kname, "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
+                         "file_order_gather_ms": gather_ms,
+                         "frac_with_file_order_gather": (algo_bytes / ((kms + gather_ms) * 1e-3) / 1e9 / 8000.0) if (gather_ms is not None and kms > 0) else None,
                          # streaming read rate of this access pattern measured on an MI355X (profiles/r01_h_fetch_calibration.txt)
                          "measured_stream_peak": 5654.0, "frac_of_measured": (achieved / 5654.0) if achieved else None},
         }
@@ -340,7 +355,8 @@ def pipeline_workload(a, n_gpus=1):
     around the process.  Then the oracle (split + count + merge, a port of the reference's CPU path) over a bounded sample of the
     same files on the host cores."""
     import shutil, subprocess, tempfile
-    from multiprocessing import Pool
+    import multiprocessing
+    Pool = multiprocessing.get_context("spawn").Pool      # (not fork: this process may hold a HIP runtime and tens of GB of mappings)
     S, G, P, k = a.pipeline_samples, int(a.pipeline_genome), a.total_partitions, 31
     tmp = tempfile.mkdtemp(prefix="kmx_bench_", dir=a.tmp)
     try:
@@ -384,7 +400,7 @@ def pipeline_workload(a, n_gpus=1):
             so = os.path.join(ROOT, "oracle", "libkmx_oracle.so")
             if not os.path.exists(so):
                 subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
-            Sc = min(S, a.pipeline_cpu_samples, nproc)
+            Sc = min(S, a.pipeline_cpu_samples or nproc, nproc)
             t0 = time.perf_counter()
             with Pool(min(Sc, nproc)) as pool:
                 counted = pool.map(_pipeline_cpu_sample, [(paths[s], k, 10, P, 2) for s in range(Sc)])
@@ -427,7 +443,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-samples", type=int, default=1000)
     ap.add_argument("--pipeline-genome", type=float, default=1e6)
-    ap.add_argument("--pipeline-cpu-samples", type=int, default=64)
+    ap.add_argument("--pipeline-cpu-samples", type=int, default=0, help="samples of the end-to-end cpu_baseline (0: one per host core)")
     ap.add_argument("--tmp", default=None, help="directory for the end-to-end workload's files (default: the system's temporary directory)")
     return ap.parse_args(argv)
 

@@ -930,6 +930,9 @@ int run(int argc, char** argv)
   { std::ofstream ri(root + "/run_infos.txt");                                         // task_scheduler.hpp:453-457
     ri << "Time: " << std::chrono::duration_cast<std::chrono::seconds>(clk::now() - t0).count() << " seconds\n"
        << "Memory: " << ru.ru_maxrss / 1024 << "MB\n"; }
+  // every file is written and closed, every worker joined: leave without giving tens of GB of device and pinned memory back
+  // block by block (the driver and the OS take them back with the process; KMX_SLOW_EXIT=1 runs the destructors, for leak checks)
+  if (!getenv("KMX_SLOW_EXIT")) { fflush(stdout); fflush(stderr); _exit(0); }
   return 0;
 }
 
