@@ -63,139 +63,100 @@ __device__ __forceinline__ u64 xxh64_words(const u64* w, int nw)
   return h;
 }
 
-// one thread per super-k-mer record: [u8 n][ceil((k+n-1)/4) bytes]; with S the record bytes as a
-// little-endian integer, seed = S mod 4^k and the j-th following nucleotide is (S >> 2(k+j-1)) & 3
-// (gatb Model.hpp:1388-1433; decoder sorting_count.hpp:153-275).
-template <int KW, int HASH>
-__global__ void k_superk_decode(const u8* __restrict__ recs, const u32* __restrict__ rec_off,
-                                const u32* __restrict__ kmer_off, u32 n_recs, int k,
-                                u64 win, u64 part, void* __restrict__ out)
-{
-  const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_recs) return;
-  const u8* p = recs + rec_off[r];
-  const u32 n = p[0];
-  p++;
-  u64 o = kmer_off[r];
-  if (KW == 1) {
-    const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-    u64 fwd = 0;
-    const int nbytes = (k + 3) / 4;
-    for (int b = 0; b < nbytes; b++) fwd |= (u64)p[b] << (8 * b);
-    fwd &= mask;
-    u64 rev = revcomp64(fwd, k);
-    for (u32 j = 0;; j++) {
-      const u64 c = fwd < rev ? fwd : rev;
-      if (HASH) reinterpret_cast<u64*>(out)[o + j] = xxh64_words(&c, 1) % win + win * part;
-      else reinterpret_cast<u64*>(out)[o + j] = c;
-      if (j + 1 >= n) break;
-      const int d = k + (int)j;                          // digit index of the next nucleotide
-      const u64 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
-      fwd = ((fwd << 2) | nt) & mask;
-      rev = (rev >> 2) | ((nt ^ 2ULL) << (2 * (k - 1)));
-    }
-  } else {
-    const u128 mask = (k == 64) ? ~(u128)0 : ((((u128)1) << (2 * k)) - 1);
-    u128 fwd = 0;
-    const int nbytes = (k + 3) / 4;
-    for (int b = 0; b < nbytes; b++) fwd |= (u128)p[b] << (8 * b);
-    fwd &= mask;
-    u128 rev = revcomp128(fwd, k);
-    for (u32 j = 0;; j++) {
-      const u128 c = fwd < rev ? fwd : rev;
-      if (HASH) {
-        u64 w[2] = {(u64)c, (u64)(c >> 64)};
-        reinterpret_cast<u64*>(out)[o + j] = xxh64_words(w, 2) % win + win * part;
-      } else reinterpret_cast<u128*>(out)[o + j] = c;
-      if (j + 1 >= n) break;
-      const int d = k + (int)j;
-      const u128 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
-      fwd = ((fwd << 2) | nt) & mask;
-      rev = (rev >> 2) | ((nt ^ (u128)2) << (2 * (k - 1)));
-    }
-  }
-}
-
-// batch variant: records of several partition streams; rec_part gives each record's partition
-template <int KW, int HASH>
-__global__ void k_superk_decode_batch(const u8* __restrict__ recs, const u32* __restrict__ rec_off,
-                                      const u32* __restrict__ kmer_off, const u16* __restrict__ rec_part,
-                                      const u64* __restrict__ part_ids, u32 n_recs, int k, u64 win, void* __restrict__ out,
-                                      u16* __restrict__ out_part)
-{
-  const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_recs) return;
-  const u8* p = recs + rec_off[r];
-  const u32 n = p[0];
-  p++;
-  const u64 o = kmer_off[r];
-  const u16 pidx = rec_part[r];
-  const u64 part = HASH ? part_ids[pidx] : 0;
-  for (u32 j = 0; j < n; j++) out_part[o + j] = pidx;
-  if (KW == 1) {
-    const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-    u64 fwd = 0;
-    const int nbytes = (k + 3) / 4;
-    for (int b = 0; b < nbytes; b++) fwd |= (u64)p[b] << (8 * b);
-    fwd &= mask;
-    u64 rev = revcomp64(fwd, k);
-    for (u32 j = 0;; j++) {
-      const u64 c = fwd < rev ? fwd : rev;
-      if (HASH) reinterpret_cast<u64*>(out)[o + j] = xxh64_words(&c, 1) % win + win * part;
-      else reinterpret_cast<u64*>(out)[o + j] = c;
-      if (j + 1 >= n) break;
-      const int d = k + (int)j;
-      const u64 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
-      fwd = ((fwd << 2) | nt) & mask;
-      rev = (rev >> 2) | ((nt ^ 2ULL) << (2 * (k - 1)));
-    }
-  } else {
-    const u128 mask = (k == 64) ? ~(u128)0 : ((((u128)1) << (2 * k)) - 1);
-    u128 fwd = 0;
-    const int nbytes = (k + 3) / 4;
-    for (int b = 0; b < nbytes; b++) fwd |= (u128)p[b] << (8 * b);
-    fwd &= mask;
-    u128 rev = revcomp128(fwd, k);
-    for (u32 j = 0;; j++) {
-      const u128 c = fwd < rev ? fwd : rev;
-      if (HASH) { u64 w[2] = {(u64)c, (u64)(c >> 64)}; reinterpret_cast<u64*>(out)[o + j] = xxh64_words(w, 2) % win + win * part; }
-      else reinterpret_cast<u128*>(out)[o + j] = c;
-      if (j + 1 >= n) break;
-      const int d = k + (int)j;
-      const u128 nt = (p[d >> 2] >> ((d & 3) * 2)) & 3u;
-      fwd = ((fwd << 2) | nt) & mask;
-      rev = (rev >> 2) | ((nt ^ (u128)2) << (2 * (k - 1)));
-    }
-  }
-}
-
-__global__ void k_keep_flags(const u32* __restrict__ cnt, u32 n, u32 hard_min, u8* __restrict__ flags)
+// ---- decode, one LANE per k-mer (round 3; rounds 1-2 walked a record per thread with byte loads and strided stores) ----------
+// Record [u8 n][ceil((k+n-1)/4) bytes]: with S the record bytes as a little-endian integer, seed = S mod 4^k and the j-th following
+// nucleotide is (S >> 2(k+j-1)) & 3 (gatb Model.hpp:1388-1433; decoder sorting_count.hpp:153-275).
+// Record i of the stream starts at byte lo(prefix[i]) and its first k-mer is number hi(prefix[i]) of the batch (prefix has one more
+// entry than there are records: the totals).  K-mer j of a record: the seed's digits shifted up by j, the j nucleotides that follow
+// it below them in reverse order (the record appends the following nucleotides at digits k, k + 1, ...; a k-mer's lowest digit is its
+// LAST nucleotide) -- two unaligned 8-byte loads (four for 128-bit keys), no loop over the record.  A workgroup takes DK consecutive
+// k-mers: the prefix entries of the records that hold them go to LDS (k_decode_block_starts found the first one), a lane finds its
+// record with a binary search there, and the keys leave as one coalesced store per wave.
+constexpr int DK = 1024;            // k-mers per workgroup (4 per thread)
+__global__ void k_decode_block_starts(const u64* __restrict__ prefix, u32 n_recs, u32* __restrict__ blk_first)
 {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flags[i] = cnt[i] >= hard_min;
+  if (i >= n_recs) return;
+  const u64 ko = prefix[i] >> 32, ke = prefix[i + 1] >> 32;
+  const u64 B = (ko + DK - 1) / DK;
+  if (B * DK < ke) blk_first[B] = i;      // (a record holds at most 60 k-mers: at most one block starts inside it)
+}
+
+__device__ __forceinline__ u64 load8u(const u8* p) { u64 w; __builtin_memcpy(&w, p, 8); return w; }
+
+template <int KW, int HASH>
+__global__ __launch_bounds__(256)
+void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ prefix, const u32* __restrict__ blk_first, const u16* __restrict__ rec_part,
+                           const u64* __restrict__ part_ids, u32 n_recs, u32 total, int k, u64 win, void* __restrict__ out)
+{
+  __shared__ u64 pk[DK + 1];
+  __shared__ u32 nrec_s;
+  const u32 tid = threadIdx.x;
+  const u32 g0 = blockIdx.x * DK;
+  const u32 r0 = blk_first[blockIdx.x];
+  const u32 avail = min((u32)DK + 1u, n_recs + 1u - r0);
+  for (u32 t = tid; t < avail; t += 256) pk[t] = prefix[r0 + t];
+  if (tid == 0) nrec_s = avail;
+  __syncthreads();
+#pragma unroll
+  for (int x = 0; x < DK / 256; x++) {
+    const u32 g = g0 + tid + x * 256;
+    if (g >= total) break;
+    // the last entry t with hi(pk[t]) <= g  (entry 0 qualifies: the block's first k-mer lies in record r0)
+    u32 lo = 0, hi = avail - 1;
+    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if ((u32)(pk[mid] >> 32) <= g) lo = mid; else hi = mid - 1; }
+    const u64 pe = pk[lo];
+    const u32 j = g - (u32)(pe >> 32);
+    const u8* p = recs + (u32)pe + 1;                  // behind the record's length byte
+    const u32 r = r0 + lo;
+    const u64 part = HASH ? part_ids[rec_part[r]] : 0;
+    const u32 eb = (u32)k >> 2, es = ((u32)k & 3u) * 2;   // the following nucleotides start at digit k: byte eb, bit es
+    if (KW == 1) {
+      const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+      u64 fwd = load8u(p) & mask;
+      if (j && k < 32) {      // (super-k-mers of at most 28 k-mers: j <= 27, the 54 bits wanted lie in one shifted word)
+        const u64 ex = load8u(p + eb) >> es;                                           // digits k, k + 1, ...
+        fwd = ((fwd << (2 * j)) | (rev_digits64(ex) >> (64 - 2 * j))) & mask;
+      } else if (j) {         // k = 32: a 64-bit key, but super-k-mers of up to 60 k-mers (the reference runs it as Kmer<64>): es = 0
+        const u128 ex = ((u128)load8u(p + eb + 8) << 64) | load8u(p + eb);
+        const u128 rv = ((u128)rev_digits64((u64)ex) << 64) | (u128)rev_digits64((u64)(ex >> 64));
+        fwd = (u64)((((u128)fwd << (2 * j)) | (rv >> (128 - 2 * j))));                 // (mask is all ones)
+      }
+      const u64 rev = revcomp64(fwd, k);
+      const u64 c = fwd < rev ? fwd : rev;
+      reinterpret_cast<u64*>(out)[g] = HASH ? (xxh64_words(&c, 1) % win + win * part) : c;
+    } else {
+      const u128 mask = (k == 64) ? ~(u128)0 : ((((u128)1) << (2 * k)) - 1);
+      u128 fwd = (((u128)load8u(p + 8) << 64) | load8u(p)) & mask;
+      if (j) {
+        const u64 a = load8u(p + eb), b2 = load8u(p + eb + 8);
+        u128 ex = (((u128)b2 << 64) | a) >> es;
+        if (es) ex |= (u128)p[eb + 16] << (128 - es);                                  // (j <= 59: 118 bits)
+        const u128 rv = ((u128)rev_digits64((u64)ex) << 64) | (u128)rev_digits64((u64)(ex >> 64));   // the 64 digits reversed
+        fwd = ((fwd << (2 * j)) | (rv >> (128 - 2 * j))) & mask;
+      }
+      const u128 rev = revcomp128(fwd, k);
+      const u128 c = fwd < rev ? fwd : rev;
+      if (HASH) { u64 w[2] = {(u64)c, (u64)(c >> 64)}; reinterpret_cast<u64*>(out)[g] = xxh64_words(w, 2) % win + win * part; }
+      else reinterpret_cast<u128*>(out)[g] = c;
+    }
+  }
+  (void)nrec_s;
+}
+
+// the partition of every k-mer (the library sort's second key): only the fallback asks for it
+__global__ void k_fill_kpart(const u32* __restrict__ part_kmer_off, u32 n_parts, u32 total, u16* __restrict__ out)
+{
+  const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  u32 lo = 0, hi = n_parts;                          // the last partition that starts at or before g
+  while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (part_kmer_off[mid] <= g) lo = mid; else hi = mid; }
+  out[g] = (u16)lo;
 }
 
 }  // namespace kmx
 
 using namespace kmx;
-
-// host: record offsets (each record's length depends on its first byte only)
-static int parse_records(const uint8_t* s, uint64_t len, uint32_t k, std::vector<u32>& rec_off, std::vector<u32>& kmer_off, u64* total)
-{
-  u64 pos = 0, nk = 0;
-  while (pos < len) {
-    const u32 n = s[pos];
-    if (n == 0) return -1;
-    const u64 nbytes = ((u64)k + n - 1 + 3) / 4;
-    if (pos + 1 + nbytes > len) return -1;
-    rec_off.push_back((u32)pos);
-    kmer_off.push_back((u32)nk);
-    nk += n;
-    pos += 1 + nbytes;
-  }
-  *total = nk;
-  return 0;
-}
 
 // abundance histogram of run counts (the library-sort paths; k_cs_sort adds its own runs): see kmx_ctx::d_hist
 __global__ __launch_bounds__(256) void k_hist_runs(const u32* __restrict__ cnt, u32 n, unsigned long long* __restrict__ hist)
@@ -250,103 +211,18 @@ extern "C" int kmx_hist_read(kmx_ctx* ctx, uint32_t lower, uint32_t upper, uint6
   return KMX_OK;
 }
 
-template <typename KeyT>
-static int sort_rle_filter(kmx_ctx* ctx, KeyT* d_keys, u64 n, u32 hard_min, void** out_keys, uint32_t** out_counts, uint64_t* n_out)
-{
-  hipStream_t st = ctx->stream;
-  KeyT* d_sorted = (KeyT*)ctx->dalloc(n * sizeof(KeyT));
-  KeyT* d_uniq = (KeyT*)ctx->dalloc(n * sizeof(KeyT));
-  u32* d_cnt = (u32*)ctx->dalloc(n * 4);
-  u32* d_runs = (u32*)ctx->dalloc(256);
-  u8* d_flags = (u8*)ctx->dalloc(n);
-  KeyT* d_k2 = (KeyT*)ctx->dalloc(n * sizeof(KeyT));
-  u32* d_c2 = (u32*)ctx->dalloc(n * 4);
-  auto release = [&]() { ctx->dfree(d_sorted); ctx->dfree(d_uniq); ctx->dfree(d_cnt); ctx->dfree(d_runs); ctx->dfree(d_flags); ctx->dfree(d_k2); ctx->dfree(d_c2); };
-  if (!d_sorted || !d_uniq || !d_cnt || !d_runs || !d_flags || !d_k2 || !d_c2) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
-  size_t tb = 0, tb2 = 0, tb3 = 0;
-  hipError_t e = rocprim::radix_sort_keys(nullptr, tb, d_keys, d_sorted, (size_t)n, 0, (unsigned)(sizeof(KeyT) * 8), st);
-  if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, tb2, d_sorted, (unsigned)n, d_uniq, d_cnt, d_runs, st);
-  if (e == hipSuccess) e = rocprim::select(nullptr, tb3, d_uniq, d_flags, d_k2, d_runs, (size_t)n, st);
-  size_t tmax = std::max(tb, std::max(tb2, tb3));
-  void* d_tmp = ctx->dalloc(tmax ? tmax : 256);
-  if (e != hipSuccess || !d_tmp) { release(); ctx->dfree(d_tmp); return ctx->fail(KMX_E_HIP, "count: rocPRIM temp sizing failed"); }
-  auto fail = [&](hipError_t er, const char* what) { release(); ctx->dfree(d_tmp); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(er)); };
-  size_t t = tmax;
-  if ((e = rocprim::radix_sort_keys(d_tmp, t, d_keys, d_sorted, (size_t)n, 0, (unsigned)(sizeof(KeyT) * 8), st)) != hipSuccess) return fail(e, "radix_sort_keys");
-  t = tmax;
-  if ((e = rocprim::run_length_encode(d_tmp, t, d_sorted, (unsigned)n, d_uniq, d_cnt, d_runs, st)) != hipSuccess) return fail(e, "run_length_encode");
-  u32 runs = 0;
-  if ((e = hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
-  KeyT* res_k = d_uniq; u32* res_c = d_cnt; u32 kept = runs;
-  hist_runs(ctx, d_cnt, runs);
-  if (hard_min > 1 && runs) {
-    hipLaunchKernelGGL(k_keep_flags, dim3((runs + 255) / 256), dim3(256), 0, st, d_cnt, runs, hard_min, d_flags);
-    t = tmax;
-    if ((e = rocprim::select(d_tmp, t, d_uniq, d_flags, d_k2, d_runs, (size_t)runs, st)) != hipSuccess) return fail(e, "select keys");
-    t = tmax;
-    if ((e = rocprim::select(d_tmp, t, d_cnt, d_flags, d_c2, d_runs, (size_t)runs, st)) != hipSuccess) return fail(e, "select counts");
-    if ((e = hipMemcpyAsync(&kept, d_runs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
-    res_k = d_k2; res_c = d_c2;
-  }
-  void* hk = malloc(kept ? (size_t)kept * sizeof(KeyT) : 1);
-  uint32_t* hc = (uint32_t*)malloc(kept ? (size_t)kept * 4 : 1);
-  if (!hk || !hc) { free(hk); free(hc); release(); ctx->dfree(d_tmp); return ctx->fail(KMX_E_NOMEM, "count: host allocation failed"); }
-  if (kept) {
-    if ((e = hipMemcpyAsync(hk, res_k, (size_t)kept * sizeof(KeyT), hipMemcpyDeviceToHost, st)) != hipSuccess) { free(hk); free(hc); return fail(e, "memcpy"); }
-    if ((e = hipMemcpyAsync(hc, res_c, (size_t)kept * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) { free(hk); free(hc); return fail(e, "memcpy"); }
-    if ((e = hipStreamSynchronize(st)) != hipSuccess) { free(hk); free(hc); return fail(e, "sync"); }
-  }
-  release(); ctx->dfree(d_tmp);
-  *out_keys = hk; *out_counts = hc; *n_out = kept;
-  return KMX_OK;
-}
-
+// one (sample, partition) stream: the batched path with one partition (rounds 1-2 had a library sort + run-length encode + select
+// of their own here)
 static int count_impl(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t k, int hash, uint64_t win, uint64_t part,
                       uint32_t hard_min, void** keys, uint32_t** counts, uint64_t* n_out)
 {
   if (!ctx) return KMX_E_INVAL;
   if (!keys || !counts || !n_out || (len && !superk)) return ctx->fail(KMX_E_INVAL, "count: null argument");
-  if (k < 8 || k > 63) return ctx->fail(KMX_E_UNSUPPORTED, "k-mer size outside 8..63");
-  if (hash && win == 0) return ctx->fail(KMX_E_INVAL, "hash window is 0");
   if (len >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "super-k-mer stream of 4 GiB or more: split it");
   *keys = nullptr; *counts = nullptr; *n_out = 0;
-  KMX_HIP(ctx, hipSetDevice(ctx->device));
-  const int kw = (k + 31) / 32;
-  std::vector<u32> rec_off, kmer_off;
-  u64 total = 0;
-  if (parse_records(superk, len, k, rec_off, kmer_off, &total)) return ctx->fail(KMX_E_INVAL, "malformed super-k-mer stream");
-  if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one partition file: split it");
-  if (total == 0) {   // header-only count file (task.hpp:466-476)
-    *keys = malloc(8); *counts = (uint32_t*)malloc(8);
-    return KMX_OK;
-  }
-  const u32 nr = (u32)rec_off.size();
-  u8* d_recs = (u8*)ctx->dalloc(len + 16);
-  u32* d_ro = (u32*)ctx->dalloc((size_t)nr * 4);
-  u32* d_ko = (u32*)ctx->dalloc((size_t)nr * 4);
-  const size_t key_bytes = hash ? 8 : (size_t)kw * 8;
-  void* d_keys = ctx->dalloc(total * key_bytes);
-  auto release = [&]() { ctx->dfree(d_recs); ctx->dfree(d_ro); ctx->dfree(d_ko); ctx->dfree(d_keys); };
-  if (!d_recs || !d_ro || !d_ko || !d_keys) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
-  hipStream_t st = ctx->stream;
-  hipError_t e;
-  if ((e = hipMemcpyAsync(d_recs, superk, len, hipMemcpyHostToDevice, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(d_ro, rec_off.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(d_ko, kmer_off.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st)) != hipSuccess) {
-    release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e));
-  }
-  dim3 grid((nr + 255) / 256), block(256);
-  if (kw == 1 && !hash) hipLaunchKernelGGL((k_superk_decode<1, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
-  else if (kw == 1 && hash) hipLaunchKernelGGL((k_superk_decode<1, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
-  else if (kw == 2 && !hash) hipLaunchKernelGGL((k_superk_decode<2, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
-  else hipLaunchKernelGGL((k_superk_decode<2, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, nr, (int)k, win, part, d_keys);
-  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode: ") + hipGetErrorString(e)); }
-  int rc;
-  if (hash || kw == 1) rc = sort_rle_filter<u64>(ctx, (u64*)d_keys, total, hard_min, keys, counts, n_out);
-  else rc = sort_rle_filter<__uint128_t>(ctx, (__uint128_t*)d_keys, total, hard_min, keys, counts, n_out);
-  release();
+  uint64_t* kp = nullptr;
+  const int rc = kmx_count_batch(ctx, 1, &superk, &len, k, hash, win, &part, hard_min, &kp, counts, n_out);
+  *keys = kp;
   return rc;
 }
 
@@ -471,6 +347,26 @@ static int pack_to_stores(kmx_ctx* ctx, const KeyT* d_k, const u32* d_c, const s
 // ---- partition-local sample sort + run-length count (count_sort.hpp): keys grouped by partition in d_keys, partition p =
 //      keys [kmoff[p], kmoff[p + 1]).  Returns KMX_OK, a negative error, or 1 when a bucket would not fit the LDS (the caller
 //      then uses the library sort: d_keys is still untouched at that point). ----
+// the bucket kernel of a key width: 64-bit keys count by hashing first (k_cs_count_hash), 128-bit keys by sorting (k_cs_sort)
+template <typename KeyT> static void cs_launch_bucket_count(u32 TB, hipStream_t st, const KeyT* bkeys, const u32* boff, u32 hard_min, KeyT* tk, u32* tc, u32* nkept,
+                                                            unsigned long long* hist, u32* overflow);
+template <> void cs_launch_bucket_count<u64>(u32 TB, hipStream_t st, const u64* bkeys, const u32* boff, u32 hard_min, u64* tk, u32* tc, u32* nkept,
+                                             unsigned long long* hist, u32* overflow)
+{
+  static const bool by_sort = getenv("KMX_COUNT_BUCKETS") && !strcmp(getenv("KMX_COUNT_BUCKETS"), "sort");      // (the round-2 kernel, for comparison)
+  if (by_sort) hipLaunchKernelGGL((k_cs_sort<u64>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow);
+  else hipLaunchKernelGGL(k_cs_count_hash, dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow);
+}
+template <> void cs_launch_bucket_count<__uint128_t>(u32 TB, hipStream_t st, const __uint128_t* bkeys, const u32* boff, u32 hard_min, __uint128_t* tk, u32* tc, u32* nkept,
+                                                     unsigned long long* hist, u32* overflow)
+{
+  hipLaunchKernelGGL((k_cs_sort<__uint128_t>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow);
+}
+__global__ void k_hist_add(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst)
+{
+  if (threadIdx.x < 258 && src[threadIdx.x]) atomicAdd(&dst[threadIdx.x], src[threadIdx.x]);
+}
+
 template <typename KeyT>
 static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, const std::vector<u64>& kmoff, u32 n_parts, u32 hard_min,
                                 const CountOut& out)
@@ -507,22 +403,29 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   if ((e = hipMemcpyAsync(d_parts, parts.data(), sizeof(CsPart) * n_parts, hipMemcpyHostToDevice, st)) != hipSuccess ||
       (e = hipMemcpyAsync(d_chunks, chunks.data(), sizeof(CsChunk) * chunks.size(), hipMemcpyHostToDevice, st)) != hipSuccess ||
       (e = hipMemsetAsync(d_cnt, 0, 4 * ((size_t)TB + 1), st)) != hipSuccess) return fail(e, "count sort upload");
+  (void)cap;
   hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(n_parts), dim3(CS_TPB), 0, st, d_keys, d_parts, d_spl);
   hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cnt, (KeyT*)nullptr);
   hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_cnt, TB, d_boff);
-  std::vector<u32> boff((size_t)TB + 1);
-  if ((e = hipMemcpyAsync(boff.data(), d_boff, 4 * ((size_t)TB + 1), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort sizes");
-  for (u32 b = 0; b < TB; b++) if (boff[b + 1] - boff[b] > cap) { release(); return 1; }      // (parts / chunks were read by kernels that have finished)
-  clk.mark("buckets");
   if ((e = hipMemcpyAsync(d_cur, d_boff, 4 * (size_t)TB, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e, "count sort cursors");
   hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cur, d_bkeys);
-  KeyT* d_tk = d_keys;                     // (the grouped keys are dead behind the scatter: their room takes the kept pairs)
-  hipLaunchKernelGGL((k_cs_sort<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_bkeys, d_boff, hard_min, d_tk, d_tc, d_nkept,
-                     ctx->hist_on ? ctx->d_hist : (unsigned long long*)nullptr);
+  // (a bucket beyond what the count kernel takes is found by the kernel itself and reported with the kept sizes: one round trip to
+  //  the host per call, not two.  The grouped keys stay as they are until then -- the library sort needs them -- and the abundance
+  //  histogram of this call is kept apart until the call is known to stand.)
+  KeyT* d_tk = (KeyT*)dal(sizeof(KeyT) * total);
+  u32* d_flag = d_cnt + TB;                // (d_cnt has TB + 1 entries; the last one is free behind the scan: the overflow word)
+  unsigned long long* d_htmp = ctx->hist_on ? (unsigned long long*)dal(258 * 8) : nullptr;
+  if (!d_tk || (ctx->hist_on && !d_htmp)) { release(); return ctx->fail(KMX_E_NOMEM, "count sort: device allocation failed"); }
+  if ((e = hipMemsetAsync(d_flag, 0, 4, st)) != hipSuccess || (d_htmp && (e = hipMemsetAsync(d_htmp, 0, 258 * 8, st)) != hipSuccess)) return fail(e, "count sort clear");
+  cs_launch_bucket_count<KeyT>(TB, st, d_bkeys, d_boff, hard_min, d_tk, d_tc, d_nkept, d_htmp, d_flag);
   hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_nkept, TB, d_koff);
   std::vector<u32> koff((size_t)TB + 1);
-  if ((e = hipMemcpyAsync(koff.data(), d_koff, 4 * ((size_t)TB + 1), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort kept");
-  clk.mark("sort+count");
+  u32 overflow = 0;
+  if ((e = hipMemcpyAsync(koff.data(), d_koff, 4 * ((size_t)TB + 1), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(&overflow, d_flag, 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort kept");
+  if (overflow) { release(); return 1; }      // (d_keys is untouched: the caller takes the library sort)
+  if (d_htmp) hipLaunchKernelGGL(k_hist_add, dim3(1), dim3(258), 0, st, d_htmp, ctx->d_hist);
+  clk.mark("buckets+sort+count");
   const u32 kept = koff[TB];
   KeyT* d_ok = d_bkeys;                    // (and the buckets are dead behind the sort)
   u32* d_oc = (u32*)dal(4 * (size_t)std::max<u32>(kept, 1));
@@ -684,6 +587,55 @@ static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kp
   return KMX_OK;
 }
 
+// ---- a batch from its record stream to its counts: decode (one lane per k-mer), partition-local count, the library sort if a
+//      bucket is beyond the count kernel.  d_prefix: u64[nr + 1], record i starts at byte lo(d_prefix[i]), its first k-mer is number
+//      hi(d_prefix[i]); d_rpart[i]: the record's partition (index into pid / kmoff); kmoff: first k-mer of every partition ----
+static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, const u64* d_prefix, const u16* d_rpart, u32 nr, u64 total, u32 n_parts,
+                            const std::vector<u64>& kmoff, const std::vector<u64>& pid, u32 k, int hash_mode, u64 window, u32 hard_min, const CountOut& co)
+{
+  const int kw = (k + 31) / 32;
+  const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
+  const u32 NB = (u32)((total + DK - 1) / DK);
+  u64* d_pid = (u64*)ctx->dalloc((size_t)n_parts * 8);
+  u32* d_blk = (u32*)ctx->dalloc((size_t)NB * 4);
+  void* d_keys = ctx->dalloc(total * key_bytes);
+  std::vector<void*> blocks = {d_pid, d_blk, d_keys};
+  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
+  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
+  hipStream_t st = ctx->stream; hipError_t e;
+  if ((e = hipMemcpyAsync(d_pid, pid.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e)); }
+  hipLaunchKernelGGL(k_decode_block_starts, dim3((nr + 255) / 256), dim3(256), 0, st, d_prefix, nr, d_blk);
+  const dim3 grid(NB), block(256);
+  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<1, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
+  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_kmers<1, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
+  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<2, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
+  else hipLaunchKernelGGL((k_superk_decode_kmers<2, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
+  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode_kmers: ") + hipGetErrorString(e)); }
+  clk.mark("decode");
+  int rc;
+  // partition-local sample sort / hash count first (count_sort.hpp); the library sort when a bucket is beyond it
+  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, kmoff, n_parts, hard_min, co);
+  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, kmoff, n_parts, hard_min, co);
+  if (rc == 1) {
+    if (!co.dev()) for (u32 p = 0; p < n_parts; p++) { free(co.keys[p]); free(co.counts[p]); co.keys[p] = nullptr; co.counts[p] = nullptr; co.n_out[p] = 0; }
+    unsigned key_bits = 2 * k;
+    if (hash_mode) { u64 top = 0; for (u32 p = 0; p < n_parts; p++) top = std::max(top, pid[p]); key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * (top + 1);
+      if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
+    // the partition of every k-mer: the library sort's second key
+    u16* d_kpart = (u16*)ctx->dalloc(total * 2); u32* d_kmo = (u32*)ctx->dalloc(((size_t)n_parts + 1) * 4);
+    blocks.push_back(d_kpart); blocks.push_back(d_kmo);
+    if (!d_kpart || !d_kmo) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
+    std::vector<u32> kmo32(kmoff.begin(), kmoff.end());
+    if ((e = hipMemcpyAsync(d_kmo, kmo32.data(), ((size_t)n_parts + 1) * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_fill_kpart, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_kmo, n_parts, (u32)total, d_kpart);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_fill_kpart: ") + hipGetErrorString(e)); }      // (kmo32 is this frame's)
+    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), hard_min, co);
+    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), hard_min, co);
+  }
+  release();
+  return rc;
+}
+
 extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* const* superk, const uint64_t* len,
                                uint32_t k, int hash_mode, uint64_t window, const uint64_t* partition_ids, uint32_t hard_min,
                                uint64_t** keys, uint32_t** counts, uint64_t* n_out)
@@ -695,7 +647,7 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
   if (n_parts > 65535) return ctx->fail(KMX_E_UNSUPPORTED, "more than 65535 partitions in one batch");
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   for (u32 p = 0; p < n_parts; p++) { keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
-  const int kw = (k + 31) / 32;
+
   // host: record offsets of every stream (a record's length depends on its first byte only).  Streams are
   // independent, so they are walked by a few threads: once to size the tables, once to fill them.
   StageClock clk(ctx->stream);
@@ -726,60 +678,37 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
   const u64 bytes = byte_base[n_parts], total = km_base[n_parts];
   if (total >= 0xFFFFFF00ULL || bytes >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers or bytes in one batch: split it");
   const u32 nr = (u32)rec_base[n_parts];
-  u32* rec_off = (u32*)ctx->halloc((size_t)nr * 4 + 4), *kmer_off = (u32*)ctx->halloc((size_t)nr * 4 + 4);
+  u64* prefix = (u64*)ctx->halloc(((size_t)nr + 1) * 8);
   u16* rec_part = (u16*)ctx->halloc((size_t)nr * 2 + 2);
-  auto hrelease = [&]() { ctx->hfree(rec_off); ctx->hfree(kmer_off); ctx->hfree(rec_part); };
-  if (!rec_off || !kmer_off || !rec_part) { hrelease(); return ctx->fail(KMX_E_NOMEM, "count batch: host allocation failed"); }
+  auto hrelease = [&]() { ctx->hfree(prefix); ctx->hfree(rec_part); };
+  if (!prefix || !rec_part) { hrelease(); return ctx->fail(KMX_E_NOMEM, "count batch: host allocation failed"); }
   run_threads([&](u32 p) {
     const uint8_t* s = superk[p]; u64 pos = 0, r = rec_base[p], o = km_base[p];
     while (pos < len[p]) {
       const u32 n = s[pos];
-      rec_off[r] = (u32)(byte_base[p] + pos); kmer_off[r] = (u32)o; rec_part[r] = (u16)p;
+      prefix[r] = (o << 32) | (byte_base[p] + pos); rec_part[r] = (u16)p;
       r++; o += n; pos += 1 + ((u64)k + n - 1 + 3) / 4;
     }
   });
+  prefix[nr] = (total << 32) | bytes;
   clk.mark("parse");
   auto empty_out = [&]() { for (u32 p = 0; p < n_parts; p++) { if (!keys[p]) { keys[p] = (uint64_t*)malloc(8); counts[p] = (uint32_t*)malloc(4); n_out[p] = 0; } } };
   if (total == 0) { hrelease(); empty_out(); return KMX_OK; }
-  const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
-  u8* d_recs = (u8*)ctx->dalloc(bytes + 16);
-  u32* d_ro = (u32*)ctx->dalloc((size_t)nr * 4), *d_ko = (u32*)ctx->dalloc((size_t)nr * 4);
+  u8* d_recs = (u8*)ctx->dalloc(bytes + 32);
+  u64* d_prefix = (u64*)ctx->dalloc(((size_t)nr + 1) * 8);
   u16* d_rp = (u16*)ctx->dalloc((size_t)nr * 2);
-  u64* d_pid = (u64*)ctx->dalloc((size_t)n_parts * 8);
-  void* d_keys = ctx->dalloc(total * key_bytes);
-  u16* d_kpart = (u16*)ctx->dalloc(total * 2);
-  std::vector<void*> blocks = {d_recs, d_ro, d_ko, d_rp, d_pid, d_keys, d_kpart};
+  std::vector<void*> blocks = {d_recs, d_prefix, d_rp};
   auto release = [&]() { for (void* b : blocks) ctx->dfree(b); hrelease(); };
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count batch: device allocation failed"); }
   hipStream_t st = ctx->stream; hipError_t e = hipSuccess;
   u64 off = 0;
   for (u32 p = 0; p < n_parts && e == hipSuccess; p++) { if (len[p]) e = hipMemcpyAsync(d_recs + off, superk[p], len[p], hipMemcpyHostToDevice, st); off += len[p]; }
   std::vector<u64> pid(n_parts, 0); if (hash_mode) for (u32 p = 0; p < n_parts; p++) pid[p] = partition_ids[p];
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ro, rec_off, (size_t)nr * 4, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ko, kmer_off, (size_t)nr * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_prefix, prefix, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_rp, rec_part, (size_t)nr * 2, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_pid, pid.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count batch upload: ") + hipGetErrorString(e)); }
-  dim3 grid((nr + 255) / 256), block(256);
-  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<1, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_batch<1, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<2, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  else hipLaunchKernelGGL((k_superk_decode_batch<2, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_rp, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode_batch: ") + hipGetErrorString(e)); }
-  clk.mark("upload+decode");
-  unsigned key_bits = 2 * k;
-  if (hash_mode) { u64 top = 0; for (u32 p = 0; p < n_parts; p++) top = std::max(top, pid[p]); key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * (top + 1);
-    if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
-  int rc;
-  // partition-local sample sort first (count_sort.hpp); the library sort when a bucket would not fit the LDS
   CountOut co; co.keys = keys; co.counts = counts; co.n_out = n_out;
-  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, km_base, n_parts, hard_min, co);
-  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, km_base, n_parts, hard_min, co);
-  if (rc == 1) {
-    for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
-    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), hard_min, co);
-    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), hard_min, co);
-  }
+  const int rc = decode_and_count(ctx, clk, d_recs, d_prefix, d_rp, nr, total, n_parts, km_base, pid, k, hash_mode, window, hard_min, co);
   release();
   if (rc != KMX_OK) for (u32 p = 0; p < n_parts; p++) { free(keys[p]); free(counts[p]); keys[p] = nullptr; counts[p] = nullptr; n_out[p] = 0; }
   return rc;
@@ -787,17 +716,10 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
 
 
 // ---- split -> count without the streams leaving HBM (kmx_count_reads; called from superk.hip) ---------------------------
-// record i of the partition-ordered stream: byte offset = low word of prefix[i], first k-mer index = high word
-__global__ void k_prefix_split(const u64* __restrict__ prefix, u32 n, u32* __restrict__ rec_off, u32* __restrict__ kmer_off)
-{
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const u64 v = prefix[i]; rec_off[i] = (u32)v; kmer_off[i] = (u32)(v >> 32); }
-}
-
+// record i of the partition-ordered stream: byte offset = low word of d_prefix[i], first k-mer index = high word (d_prefix has one
+// more entry than there are records: the totals) -- exactly what the decode takes
 int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, const u16* d_part, u32 nr, u64 total, u32 n_parts, const u64* part_kmer_off, const kmx_count_req& rq)
 {
-  const u32 k = rq.k; const int hash_mode = rq.hash_mode; const u64 window = rq.window;
-  const int kw = (k + 31) / 32;
   if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one batch: split it");
   StageClock clk(ctx->stream, "count_reads");
   CountOut co; co.keys = rq.keys; co.counts = rq.counts; co.n_out = rq.n_out; co.stores = rq.stores; co.n_stores = rq.n_stores; co.lists = rq.lists;
@@ -805,38 +727,7 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
     for (u32 p = 0; p < n_parts; p++) { if (co.dev()) { co.lists[p].recs = nullptr; co.lists[p].n = 0; } else { rq.keys[p] = (uint64_t*)malloc(8); rq.counts[p] = (uint32_t*)malloc(4); rq.n_out[p] = 0; } }
     return KMX_OK;
   }
-  const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
-  u32* d_ro = (u32*)ctx->dalloc((size_t)nr * 4), *d_ko = (u32*)ctx->dalloc((size_t)nr * 4);
-  u64* d_pid = (u64*)ctx->dalloc((size_t)n_parts * 8);
-  void* d_keys = ctx->dalloc(total * key_bytes);
-  u16* d_kpart = (u16*)ctx->dalloc(total * 2);
-  std::vector<void*> blocks = {d_ro, d_ko, d_pid, d_keys, d_kpart};
-  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
-  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
-  hipStream_t st = ctx->stream; hipError_t e;
   std::vector<u64> pid(n_parts); for (u32 p = 0; p < n_parts; p++) pid[p] = p;
-  if ((e = hipMemcpyAsync(d_pid, pid.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e)); }
-  dim3 grid((nr + 255) / 256), block(256);
-  hipLaunchKernelGGL(k_prefix_split, grid, block, 0, st, d_prefix, nr, d_ro, d_ko);
-  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<1, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_batch<1, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_batch<2, 0>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  else hipLaunchKernelGGL((k_superk_decode_batch<2, 1>), grid, block, 0, st, d_recs, d_ro, d_ko, d_part, d_pid, nr, (int)k, window, d_keys, d_kpart);
-  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode_batch: ") + hipGetErrorString(e)); }
-  // (pid is read by the kernels above: the stream is synchronised inside batch_sort_rle before this frame ends)
-  clk.mark("decode");
-  unsigned key_bits = 2 * k;
-  if (hash_mode) { key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * n_parts;
-    if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
-  int rc;
   std::vector<u64> kmoff(part_kmer_off, part_kmer_off + n_parts + 1);
-  if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, kmoff, n_parts, rq.hard_min, co);
-  else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, kmoff, n_parts, rq.hard_min, co);
-  if (rc == 1) {
-    if (!co.dev()) for (u32 p = 0; p < n_parts; p++) { free(rq.keys[p]); free(rq.counts[p]); rq.keys[p] = nullptr; rq.counts[p] = nullptr; rq.n_out[p] = 0; }
-    if (hash_mode || kw == 1) rc = batch_sort_rle<u64>(ctx, clk, (u64*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 64u), rq.hard_min, co);
-    else rc = batch_sort_rle<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, d_kpart, (u32)total, n_parts, std::min(key_bits, 128u), rq.hard_min, co);
-  }
-  release();
-  return rc;
+  return decode_and_count(ctx, clk, d_recs, d_prefix, d_part, nr, total, n_parts, kmoff, pid, rq.k, rq.hash_mode, rq.window, rq.hard_min, co);
 }

@@ -174,20 +174,14 @@ void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out)
   for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) { const u32 v = in[i]; out[i] = a; a += v; }
 }
 
-// a workgroup per bucket: sort in LDS, run-length count, hard-min.  kept pairs -> tk / tc at the bucket's offset, their number -> nkept
+// ---- a bucket by sorting: keys into LDS, bitonic sort, run starts by neighbour compare, run lengths = counts (n <= CsCap<K>::cap).
+//      LDS arrays are the caller's: sk[cap], starts[cap], wsum[CS_TPB / 64], hh[258] ----
 template <typename K>
-__global__ __launch_bounds__(CS_TPB)
-void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
-               unsigned long long* __restrict__ hist)
+__device__ __forceinline__ void cs_bucket_by_sort(K* sk, u32* starts, u32* wsum, u32* hh, const K* __restrict__ bkeys, u32 o, u32 n, u32 b, u32 hard_min,
+                                                  K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept, unsigned long long* __restrict__ hist)
 {
   constexpr int CAP = CsCap<K>::cap;
-  __shared__ K sk[CAP];
-  __shared__ u32 starts[CAP];      // positions of the run starts, in order
-  __shared__ u32 wsum[CS_TPB / 64];
-  __shared__ u32 hh[258];          // abundance histogram of the bucket's runs (hist != nullptr): see kmx_ctx::d_hist
-  const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u32 o = boff[b], n = boff[b + 1] - o;
-  if (n == 0) { if (tid == 0) nkept[b] = 0; return; }
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (hist) for (u32 i = tid; i < 258; i += CS_TPB) hh[i] = 0;
   u32 Pn = 2; while (Pn < n) Pn <<= 1;
   for (u32 i = tid; i < Pn; i += CS_TPB) sk[i] = i < n ? bkeys[o + i] : cs_max<K>();
@@ -210,7 +204,7 @@ void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 ha
   for (int x = 0; x < PT; x++) if ((m >> x) & 1u) starts[r++] = tid * PT + x;
   __syncthreads();
   // kept runs, in order
-  u32 kept = 0, km = 0;
+  u32 kept = 0;
   const u32 per = (nruns + CS_TPB - 1) / CS_TPB;      // consecutive runs per thread
   for (u32 x = 0; x < per; x++) {
     const u32 j = tid * per + x;
@@ -220,7 +214,6 @@ void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 ha
       if (hist) { if (len <= 255u) atomicAdd(&hh[len], 1u); else { atomicAdd(&hh[256], 1u); atomicAdd(&hh[257], len); } }      // (a bucket holds < 2^32 keys)
     }
   }
-  (void)km;
   const u32 incl2 = wave_incl_scan(kept, (int)lane);
   __syncthreads();
   if (lane == 63) wsum[wave] = incl2;
@@ -236,6 +229,135 @@ void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 ha
   }
   if (tid == 0) nkept[b] = tot;
   if (hist) {      // (the barriers above separate the histogram's atomics from these reads)
+    for (u32 i = tid; i < 258; i += CS_TPB) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
+  }
+}
+
+// a workgroup per bucket: sort in LDS, run-length count, hard-min.  kept pairs -> tk / tc at the bucket's offset, their number -> nkept.
+// A bucket over the LDS capacity raises *overflow (the caller then takes the library sort for the batch).
+template <typename K>
+__global__ __launch_bounds__(CS_TPB)
+void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
+               unsigned long long* __restrict__ hist, u32* __restrict__ overflow)
+{
+  constexpr int CAP = CsCap<K>::cap;
+  __shared__ K sk[CAP];
+  __shared__ u32 starts[CAP];      // positions of the run starts, in order
+  __shared__ u32 wsum[CS_TPB / 64];
+  __shared__ u32 hh[258];          // abundance histogram of the bucket's runs (hist != nullptr): see kmx_ctx::d_hist
+  const u32 b = blockIdx.x;
+  const u32 o = boff[b], n = boff[b + 1] - o;
+  if (n == 0) { if (threadIdx.x == 0) nkept[b] = 0; return; }
+  if (n > (u32)CAP) { if (threadIdx.x == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } return; }
+  cs_bucket_by_sort<K>(sk, starts, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
+}
+
+// ---- 64-bit keys: a bucket by HASHING first.  The keys of a bucket are mostly repeats (a k-mer is seen once per read that covers it:
+//      6 times at 6x), and sorting repeats is the expensive way to count them.  Every key goes into an LDS hash set (key claimed with
+//      one ds_cmpst_b64, count with one ds_add -- the keys are STREAMED from HBM, so a k-mer repeated 100 000 times is no overflow any
+//      more), then only the DISTINCT keys are compacted and sorted (a bitonic network over a few hundred keys instead of a few
+//      thousand) and each looks its count up.  More than CS_HT_LIMIT distinct keys: the bucket is sorted as before when it fits the
+//      LDS, else *overflow is raised. ----
+constexpr int CS_HT = 2048;                 // hash set entries (keys 16 KB + counts 8 KB; the distinct keys' dense copy: 16 KB)
+constexpr int CS_HT_LIMIT = CS_HT - 256;    // distinct keys it takes (load 0.875)
+__device__ __forceinline__ u32 cs_hash(u64 k) { return (u32)((k * 0x9E3779B97F4A7C15ULL) >> (64 - 11)); }
+static_assert(CS_HT == (1 << 11), "cs_hash takes the top 11 bits of the product");
+
+__global__ __launch_bounds__(CS_TPB)
+void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, u64* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
+                     unsigned long long* __restrict__ hist, u32* __restrict__ overflow)
+{
+  constexpr int CAP = CsCap<u64>::cap;
+  __shared__ u64 la[CAP];          // hash set keys [0, CS_HT) + the distinct keys' dense copy [CS_HT, 2 * CS_HT)  |  the sort path's keys
+  __shared__ u32 lb[CAP];          // hash set counts [0, CS_HT)                                                 |  the sort path's run starts
+  __shared__ u32 wsum[CS_TPB / 64];
+  __shared__ u32 hh[258];
+  __shared__ u32 ndist;
+  __shared__ volatile u32 full;
+  static_assert(2 * CS_HT <= CAP, "the dense copy lies behind the hash set");
+  const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 o = boff[b], n = boff[b + 1] - o;
+  if (n == 0) { if (tid == 0) nkept[b] = 0; return; }
+  const u64 EMPTY = ~0ULL;           // (no canonical k-mer and no window hash is all ones)
+  for (u32 i = tid; i < (u32)CS_HT; i += CS_TPB) { la[i] = EMPTY; lb[i] = 0; }
+  if (tid == 0) { ndist = 0; full = 0; }
+  if (hist) for (u32 i = tid; i < 258; i += CS_TPB) hh[i] = 0;
+  __syncthreads();
+  for (u32 i0 = 0; i0 < n; i0 += CS_TPB) {
+    const u32 i = i0 + tid;
+    if (i < n) {
+      const u64 k = bkeys[o + i];
+      u32 h = cs_hash(k);
+      for (u32 probe = 0; probe < (u32)CS_HT; probe++) {
+        u64 cur = ((volatile u64*)la)[h];
+        if (cur == EMPTY) {
+          cur = (u64)atomicCAS((unsigned long long*)&la[h], (unsigned long long)EMPTY, (unsigned long long)k);
+          if (cur == EMPTY) { if (atomicAdd(&ndist, 1u) + 1u > (u32)CS_HT_LIMIT) full = 1; cur = k; }
+        }
+        if (cur == k) { atomicAdd(&lb[h], 1u); break; }
+        h = (h + 1) & (CS_HT - 1);
+        if (full) break;
+      }
+    }
+    if (full) break;                 // (uniform enough: every thread leaves at its next look)
+  }
+  __syncthreads();
+  if (full) {                        // too many distinct keys for the hash set
+    if (n > (u32)CAP) { if (tid == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } return; }
+    __syncthreads();
+    cs_bucket_by_sort<u64>(la, lb, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
+    return;
+  }
+  // the distinct keys, dense: every thread's CS_HT / CS_TPB slots
+  constexpr int SPT = CS_HT / CS_TPB;
+  u64* const dk = la + CS_HT;
+  u32 mine = 0;
+#pragma unroll
+  for (int x = 0; x < SPT; x++) mine += la[tid * SPT + x] != EMPTY ? 1u : 0u;
+  const u32 incl = wave_incl_scan(mine, (int)lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 r = incl - mine, nd = 0;
+  for (u32 w = 0; w < CS_TPB / 64; w++) { if (w < wave) r += wsum[w]; nd += wsum[w]; }
+#pragma unroll
+  for (int x = 0; x < SPT; x++) { const u64 k = la[tid * SPT + x]; if (k != EMPTY) dk[r++] = k; }
+  u32 Pn = 2; while (Pn < nd) Pn <<= 1;
+  __syncthreads();
+  for (u32 i = nd + tid; i < Pn; i += CS_TPB) dk[i] = EMPTY;
+  __syncthreads();
+  cs_sort_lds<u64>(dk, Pn, tid);
+  // counts of the sorted keys from the hash set; kept ones out in order
+  const u32 per = (nd + CS_TPB - 1) / CS_TPB;          // consecutive keys per thread
+  u32 kept = 0;
+  for (u32 x = 0; x < per; x++) {
+    const u32 j = tid * per + x;
+    if (j < nd) {
+      const u64 k = dk[j];
+      u32 h = cs_hash(k);
+      while (la[h] != k) h = (h + 1) & (CS_HT - 1);
+      const u32 len = lb[h];
+      if (len >= hard_min) kept++;
+      if (hist) { if (len <= 255u) atomicAdd(&hh[len], 1u); else { atomicAdd(&hh[256], 1u); atomicAdd(&hh[257], len); } }
+    }
+  }
+  const u32 incl2 = wave_incl_scan(kept, (int)lane);
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl2;
+  __syncthreads();
+  u32 w0 = incl2 - kept, tot = 0;
+  for (u32 w = 0; w < CS_TPB / 64; w++) { if (w < wave) w0 += wsum[w]; tot += wsum[w]; }
+  for (u32 x = 0; x < per; x++) {
+    const u32 j = tid * per + x;
+    if (j < nd) {
+      const u64 k = dk[j];
+      u32 h = cs_hash(k);
+      while (la[h] != k) h = (h + 1) & (CS_HT - 1);
+      const u32 len = lb[h];
+      if (len >= hard_min) { tk[o + w0] = k; tc[o + w0] = len; w0++; }
+    }
+  }
+  if (tid == 0) nkept[b] = tot;
+  if (hist) {
     for (u32 i = tid; i < 258; i += CS_TPB) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
   }
 }
