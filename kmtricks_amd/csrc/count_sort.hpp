@@ -114,8 +114,7 @@ void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts
   const CsPart P = parts[blockIdx.x];
   if (P.nb <= 1) return;
   const u32 tid = threadIdx.x;
-  u32 S = 8 * P.nb; { u32 p2 = 64; while (p2 * 2 <= S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 4 to 8 per bucket (a bucket has no hard size
-                                                                                           // limit any more: the count kernel streams its keys)
+  u32 S = 16 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 16 per bucket (8 for the largest partitions)
   for (u32 i = tid; i < S; i += CS_TPB) sm[i] = keys[P.key0 + (u32)(((u64)i * P.nkeys) / S)];
   __syncthreads();
   cs_sort_lds<K>(sm, S, tid);
