@@ -233,6 +233,7 @@ struct kmx_merge_result {
   int bf_lds = 0;
   bool is_bf = false, is_bft = false, waited = false;
   bool cols_ext = false, slices_full = false;   // k_merge_cols with slice extensions; a task came back because a slice was full
+  bool cols_resc = false;                        // the RESC builds of the column-blocked pair (share-min, recurrence-min 0)
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
@@ -330,9 +331,9 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    KMX_HIP(ctx, CO.merge(mode, R->cols_ext ? 1 : 0, d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
+    KMX_HIP(ctx, CO.merge(mode, (R->cols_ext ? 1 : 0) | (R->cols_resc ? 2 : 0), d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
-    KMX_HIP(ctx, CO.sparse(mode, d_tasks, d_cols, d_items, R->n_items, ctx->stream));
+    KMX_HIP(ctx, CO.sparse(mode | (R->cols_resc ? 2 : 0), d_tasks, d_cols, d_items, R->n_items, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));      // (the launch priced: the rows come out of both kernels)
     return mirror_and_mark(R);
   } else {
@@ -451,7 +452,12 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     }
     const char* force = getenv("KMX_MERGE_KERNEL");
     const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
-    bool can_cols = !is_bf && !rescue && mx_n <= (u32)rows_cap();      // (both key widths: merge_cols.hip, merge_cols_k2.hip)
+    // (both key widths: merge_cols.hip, merge_cols_k2.hip; share-min up to max(1, recurrence-min): the RESC builds, which also take
+    //  recurrence-min 0 -- there a key only non-solid records hold is a row)
+    bool resc_ok = true, need_resc = false;
+    for (auto& H : R->tasks) { resc_ok = resc_ok && H.share_min <= std::max(1u, H.rec_min); need_resc = need_resc || H.share_min > 0 || H.rec_min == 0; }
+    bool can_cols = !is_bf && resc_ok && mx_n <= (u32)rows_cap();
+    R->cols_resc = need_resc;
     if (can_cols) {
       // k_merge_cols keeps worst-case room for the records it sets aside (a slice per half tile, block and wave: ~2.3 KB per
       // row at 1000 lists): not for batches where that would take more than KMX_COLS_SCRATCH_GB (default 32) of HBM

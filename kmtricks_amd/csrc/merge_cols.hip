@@ -22,7 +22,13 @@
 //     keys' rows (with a directory: k_cols_gather interleaves the two when the body is asked for).  A task whose slices
 //     overflow (beyond the extension a wave can claim in the EXT build), or with a tile no collision-free table was found for, is handed back (ERR_FALLBACK: the driver re-runs it
 //     with k_merge_pivot / k_merge_rows).  Results never depend on how well the row keys cover the lists.
-// Applicable to COUNT and PA rows, 64- and 128-bit keys, no share-min; chosen from 192 lists and recurrence-min <= 21
+// Share-min (rescue, merge.hpp:210-247; round 3): the RESC builds.  A row key has at least recurrence-min solid records, so with
+// share-min <= recurrence-min EVERY record of a row key's row is written (a non-solid one is rescued); the records that are no row
+// keys are set aside solid or not (a flag in the entry), and k_cols_sparse, which sees all records of such a key together, counts
+// the solid ones: the run is a row from recurrence-min of them, its non-solid records are rescued from share-min of them (statistics
+// for every key, kept or not, as the reference accumulates them).  Recurrence-min 0 takes the same builds: a key only non-solid
+// records hold is a row of zeros there.
+// Applicable to COUNT and PA rows, 64- and 128-bit keys, share-min <= max(1, recurrence-min); chosen from 192 lists and recurrence-min <= 21
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
 #include "kmx_host.hpp"
 #include <algorithm>
@@ -384,7 +390,8 @@ __device__ u64 kmx_sparse_prof[8];
 // ---- the merge: work item = (task, key range, column block) ----------------------------------------------
 // EXT: a wave whose set-aside slice is full claims an extension (cohorts with outlier samples; the plain build hands such a task
 // back and the context's next batches use this one: 1-2 % slower on cohorts that never need it)
-template <int MODE, bool EXT>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
+constexpr u64 CL_NONSOLID = 1ULL << 63;      // set-aside entry of a RESC build: the record is below its list's soft-min
+template <int MODE, bool EXT, bool RESC>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
 __global__ __launch_bounds__(CL_TPB, CL_WGS)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
                   u32 n_items, u32* ticket)
@@ -450,6 +457,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       if (ix < end) rec[u] = cl_load(base + (u64)ix * RD);
     }
     u64 tsum = 0; u32 tn = 0;            // TOTAL_WO / NON_SOLID of my share of my list
+    u64 rsum = 0; u32 rn = 0;            // RESC: the rescued records of the row keys' rows (their counts, their number)
+    const bool rescue = RESC && cl_uni(T.share_min) != 0;      // (a RESC build with share-min 0: recurrence-min 0 -- nothing is rescued, everything is set aside)
     // first tile: row keys, table, (block 0) the key column of the result
     CKey skn[CL_KPL];
     u32 myslot[CL_KPL];                  // wave 0: the table entries of my row keys of the tile in hand
@@ -543,21 +552,26 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             const bool hit = ent_hit(pe[j], k);
             tsum += solid ? c : 0u;
             tn += (cons && !solid) ? 1u : 0u;
-            if (MODE == 0) img[(solid && hit) ? __umul24(pe[j].idx - 1, iw) + lg : dummy] = c;
-            else if (solid && hit) atomicOr(&img[__umul24(pe[j].idx - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
-            ovm |= ((solid && !hit) ? 1u : 0u) << j;
+            // (RESC: a row key's row has recurrence-min >= share-min solid records: its non-solid records are rescued, written like the others)
+            const bool dep = RESC ? (cons && hit && (solid || rescue)) : (solid && hit);
+            if (RESC) { const bool rs = cons && hit && !solid && rescue; rsum += rs ? c : 0u; rn += rs ? 1u : 0u; }
+            if (MODE == 0) img[dep ? __umul24(pe[j].idx - 1, iw) + lg : dummy] = c;
+            else if (dep) atomicOr(&img[__umul24(pe[j].idx - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
+            ovm |= (((RESC ? cons : solid) && !hit) ? 1u : 0u) << j;
           }
           asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
+          if (RESC) asm volatile("" : "+v"(rsum), "+v"(rn));
           // solid records that are not row keys: appended to the wave's slice of the tile (positions from ballots)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const u64 bal = __ballot((ovm >> j) & 1u);
             if (bal) {
               const CKey kk = cl_key(rec[g + j]);
+              const u64 pay = li_hi | cl_cnt(rec[g + j]) | ((RESC && cl_cnt(rec[g + j]) < smin) ? CL_NONSOLID : 0ULL);
 #if KMX_CL_KW == 1
-#define CL_PUT(o, pos) do { (o)[2 * (pos)] = kk; (o)[2 * (pos) + 1] = li_hi | cl_cnt(rec[g + j]); } while (0)
+#define CL_PUT(o, pos) do { (o)[2 * (pos)] = kk; (o)[2 * (pos) + 1] = pay; } while (0)
 #else
-#define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = li_hi | cl_cnt(rec[g + j]); } while (0)
+#define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = pay; } while (0)
 #endif
               if (CL_HALVES == 1) {
                 if (EXT && __builtin_expect(wov + (u32)__popcll(bal) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
@@ -692,6 +706,18 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         if (tn) atomicAdd(&T.stats[0 * (u64)N + li], (u64)tn);
         if (ts) atomicAdd(&T.stats[4 * (u64)N + li], ts);
       }
+      if (RESC) {
+        u32 rlo = (u32)rsum, rhi = (u32)(rsum >> 32);
+        u64 rs = rsum;
+#pragma unroll
+        for (int off = 1; off < CL_G; off <<= 1) {
+          const u32 olo = __shfl_xor(rlo, off), ohi = __shfl_xor(rhi, off);
+          rs += (u64)olo | ((u64)ohi << 32);
+          rlo = (u32)rs; rhi = (u32)(rs >> 32);
+          rn += __shfl_xor(rn, off);
+        }
+        if (on && r == 0 && rn) { atomicAdd(&T.stats[1 * (u64)N + li], (u64)rn); atomicAdd(&T.stats[5 * (u64)N + li], rs); }
+      }
     }
     if (failed) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
     __syncthreads();
@@ -787,7 +813,7 @@ __device__ __forceinline__ void ck_sort_block(CKey* ck, u64* cp, u32 P, u32 tid)
   }
 }
 
-template <int MODE>
+template <int MODE, bool RESC>
 __global__ __launch_bounds__(CK_TPB, MODE == 1 ? 4 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores)
 void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
@@ -817,7 +843,11 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
   const TaskDev& T = tasks[items[item].x];
   const ColsDev& C = cols[items[item].x];
   if (T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) return;
-  const u32 range = items[item].y, thr = max(1u, T.rec_min), rt = C.rt, nsl = C.nblk * CL_NW, row_bytes = T.row_bytes;
+  // thr: solid records that make a key a row (RESC: 0 is taken literally -- a key only non-solid records hold is a row of zeros);
+  // share: solid records from which a key's non-solid records are rescued (0: never)
+  const u32 range = items[item].y, thr = RESC ? T.rec_min : max(1u, T.rec_min), share = RESC ? T.share_min : 0u, rt = C.rt, nsl = C.nblk * CL_NW, row_bytes = T.row_bytes;
+  auto pl_list = [](u64 pl) -> u32 { return (u32)(pl >> 32) & 0x7FFFFFFFu; };
+  auto pl_solid = [](u64 pl) -> bool { return !RESC || !(pl & CL_NONSOLID); };
   const u32 s_lo = C.rbounds[range], s_hi = C.rbounds[range + 1];
   const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
   const u32 slot0 = (s_lo / rt + range) * CL_HALVES;
@@ -874,7 +904,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
 #ifndef KMX_CK_PER1
 #define KMX_CK_PER1 1400
 #endif
-    const u32 per = (thr == 1 ? (u32)KMX_CK_PER1 : 3000u) * (u32)CK_CAND / 2048u;
+    const u32 per = (thr <= 1 ? (u32)KMX_CK_PER1 : 3000u) * (u32)CK_CAND / 2048u;
     u32 npass = 1; while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;
     if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
     // each of my entries through f(key, payload): four threads per slice
@@ -921,11 +951,11 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       SPPH(1);
       bool sorted = false;
       u32 nc1 = 0;
-      if (thr == 1 && !BY_INTERVAL) {
+      if (thr <= 1 && !BY_INTERVAL) {
         each(pass, [&](CKey k, u64 pl) { const u32 ps = atomicAdd(&ncand, 1u); if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; } });
         __syncthreads();
       }
-      if (thr == 1 && BY_INTERVAL) {
+      if (thr <= 1 && BY_INTERVAL) {
         // recurrence-min 1: every entry is a row, the sort is all there is to do -- and the group's ROW KEYS (<= 56, ascending) cut its
         // key range into intervals of ~20 entries.  An entry finds its interval by binary search, the intervals are laid out one after
         // the other (count, scan, place) and an entry's place inside its interval is the number of the interval's entries below it.
@@ -1026,7 +1056,10 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         ck_sort_block(ck, cp, P, tid);
       }
       SPPH(4);
-      // kept runs: first entry of a run of >= thr equal keys (entries of one key come from different lists)
+      // kept runs: first entry of a run of >= thr equal keys (entries of one key come from different lists).  RESC: of >= thr SOLID
+      // entries -- the payload sorts a key's non-solid entries behind its solid ones, so entry i + thr - 1 of the run decides; and a
+      // run with at least `share` solid entries has its non-solid ones rescued: their statistics here, for every run, kept or not
+      // (merge.hpp:234-247), their counts in the row below
       u32 mine = 0, km = 0, rl[4] = {0, 0, 0, 0};
       const u32 pt = (nc + CK_TPB - 1) / CK_TPB;     // consecutive entries per thread (<= 4)
 #pragma unroll
@@ -1034,9 +1067,18 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         const u32 i = tid * pt + x;
         if (x < pt && i < nc) {
           const CKey k = ck[i];
-          const bool kept = (i == 0 || !ck_eq(ck[i - 1], k)) && i + thr - 1 < nc && ck_eq(ck[i + thr - 1], k);
+          const bool first = i == 0 || !ck_eq(ck[i - 1], k);
+          bool kept = first && (thr == 0 || (i + thr - 1 < nc && ck_eq(ck[i + thr - 1], k) && pl_solid(cp[i + thr - 1])));
+          if (RESC && first) {
+            u32 len = 1; while (i + len < nc && ck_eq(ck[i + len], k)) len++;
+            u32 ns = 0; while (ns < len && pl_solid(cp[i + ns])) ns++;
+            if (share && ns >= share) for (u32 e = ns; e < len; e++) { const u64 pl = cp[i + e]; atomicAdd(&T.stats[1 * (u64)T.N + pl_list(pl)], 1ULL); atomicAdd(&T.stats[5 * (u64)T.N + pl_list(pl)], (u64)(u32)pl); }
+            if (kept) rl[x] = i | (len << 16);
+            // the row's entries: the solid ones, and all of them when the rescue applies -- marked by clearing / keeping the flags:
+            // a non-solid entry that is NOT rescued gets count 0 (it must not reach the row)
+            if (kept && !(share && ns >= share)) for (u32 e = ns; e < len; e++) cp[i + e] &= ~0xFFFFFFFFULL;
+          } else if (kept) { u32 len = 1; while (i + len < nc && ck_eq(ck[i + len], k)) len++; rl[x] = i | (len << 16); }      // (len <= lists <= 4096, i < 2048)
           km |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
-          if (kept) { u32 len = 1; while (i + len < nc && ck_eq(ck[i + len], k)) len++; rl[x] = i | (len << 16); }      // (len <= lists <= 4096, i < 2048)
         }
       }
       const u32 incl = wave_incl_scan(mine, (int)lane);
@@ -1082,7 +1124,8 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           if (len == 1) {
             // the usual row here: a key one list holds (a private k-mer) -- every lane knows the whole row, no staging
             const u64 pl = cp[i0];
-            const u32 li = (u32)(pl >> 32), cnt = (u32)pl;
+            const u32 li = pl_list(pl), cnt = (u32)pl;
+            const u32 bitv = (MODE == 1 && RESC && cnt == 0) ? 0u : 1u;      // (RESC, recurrence-min 0: a lone non-solid record is a row of zeros)
             if (MODE == 0) {
               if ((row_bytes & 7u) == 0) {
                 u64* const r8 = reinterpret_cast<u64*>(row);
@@ -1093,7 +1136,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
                 for (u32 t = sl; t < row_bytes / 4; t += SG) r4[t] = t < 2u * KW ? kword(t) : (t - 2u * KW == li ? cnt : 0u);
               }
             } else {
-              put_bytes([&](u32 w) -> u32 { return w < 2u * KW ? kword(w) : (w - 2u * KW == (li >> 5) ? 1u << (li & 31u) : 0u); });
+              put_bytes([&](u32 w) -> u32 { return w < 2u * KW ? kword(w) : (w - 2u * KW == (li >> 5) ? bitv << (li & 31u) : 0u); });
             }
             continue;
           }
@@ -1107,13 +1150,13 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
               for (u32 t = sl; t < row_bytes / 4; t += SG) r4[t] = t < 2u * KW ? kword(t) : 0u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            for (u32 e = sl; e < len; e += SG) { const u64 pl = cp[i0 + e]; reinterpret_cast<u32*>(row + KW * 8)[(u32)(pl >> 32)] = (u32)pl; }
+            for (u32 e = sl; e < len; e += SG) { const u64 pl = cp[i0 + e]; reinterpret_cast<u32*>(row + KW * 8)[pl_list(pl)] = (u32)pl; }
           } else {
             u32* const pr = parow + sg * (SG == 8u ? 40u : 136u);
             const u32 nby = row_bytes - KW * 8, nw = (nby + 3) / 4;
             for (u32 t = sl; t < nw + 2 * KW + 1; t += SG) pr[t] = t < 2u * KW ? kword(t) : 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            for (u32 e = sl; e < len; e += SG) { const u32 li = (u32)(cp[i0 + e] >> 32); atomicOr(&pr[2 * KW + (li >> 5)], 1u << (li & 31u)); }
+            for (u32 e = sl; e < len; e += SG) { const u64 pl = cp[i0 + e]; const u32 li = pl_list(pl); if (!RESC || (u32)pl) atomicOr(&pr[2 * KW + (li >> 5)], 1u << (li & 31u)); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             put_bytes([&](u32 w) -> u32 { return pr[w]; });
           }
@@ -1241,24 +1284,34 @@ hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const Col
   hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(CP_TPB), 0, st, tasks, subs, cols);
   return hipGetLastError();
 }
-template <int MODE, bool EXT>
+template <int MODE, bool EXT, bool RESC>
 static hipError_t launch_merge_cols_as(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
   const int lds = cols_lds_bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<MODE, EXT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<MODE, EXT, RESC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_merge_cols<MODE, EXT>), dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
+  hipLaunchKernelGGL((k_merge_cols<MODE, EXT, RESC>), dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
   return hipGetLastError();
 }
+// ext: bit 0 = slice extensions (outlier samples), bit 1 = the RESC build (share-min, recurrence-min 0)
 hipError_t launch_merge_cols(int mode, int ext, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
-  if (mode == 0) return ext ? launch_merge_cols_as<0, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<0, false>(tasks, cols, items, n_items, ticket, grid_x, st);
-  return ext ? launch_merge_cols_as<1, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<1, false>(tasks, cols, items, n_items, ticket, grid_x, st);
+  const bool x = ext & 1, r = (ext & 2) != 0;
+#define KMX_CL_LAUNCH(M) (r ? (x ? launch_merge_cols_as<M, true, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<M, false, true>(tasks, cols, items, n_items, ticket, grid_x, st)) \
+                            : (x ? launch_merge_cols_as<M, true, false>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<M, false, false>(tasks, cols, items, n_items, ticket, grid_x, st)))
+  return mode == 0 ? KMX_CL_LAUNCH(0) : KMX_CL_LAUNCH(1);
+#undef KMX_CL_LAUNCH
 }
+// mode: bit 0 = PA rows, bit 1 = the RESC build
 hipError_t launch_cols_sparse(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)
 {
-  if (mode == 0) hipLaunchKernelGGL(k_cols_sparse<0>, dim3(n_items, CK_Z), dim3(CK_TPB), 0, st, tasks, cols, range_items, n_items);
-  else hipLaunchKernelGGL(k_cols_sparse<1>, dim3(n_items, CK_Z), dim3(CK_TPB), 0, st, tasks, cols, range_items, n_items);
+  const dim3 grid(n_items, CK_Z), block(CK_TPB);
+  switch (mode & 3) {
+    case 0: hipLaunchKernelGGL((k_cols_sparse<0, false>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
+    case 1: hipLaunchKernelGGL((k_cols_sparse<1, false>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
+    case 2: hipLaunchKernelGGL((k_cols_sparse<0, true>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
+    default: hipLaunchKernelGGL((k_cols_sparse<1, true>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
+  }
   return hipGetLastError();
 }
 u64 cols_dir_bytes(u32 slots) { return (u64)slots * CL_HALVES * CK_NPASS * sizeof(SpDir); }

@@ -289,20 +289,6 @@ def test_pivot_list_count_edges(ctx, n, mode):
     check(ctx, lists, 1, soft, 3, 0, mode)
 
 
-def test_bench_workload_full_size_parity():
-    """The bench workload at full size (32 partitions x 1000 samples, 625 M records): k_merge_pivot and k_merge_rows give
-    byte-identical bodies and statistics on every partition, keys ascend, partition 0 equals the oracle
-    (scripts/verify_bench_parity.py).  Runs once (not per kernel parameter)."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if os.environ.get("KMX_MERGE_KERNEL") != "rows":      # the autouse fixture runs every test twice: do the work once
-        pytest.skip("covered by the other parameter")
-    env = dict(os.environ); env.pop("KMX_MERGE_KERNEL", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "verify_bench_parity.py")], capture_output=True, text=True, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert '"pivot_equals_rows_sha256": true' in r.stdout and '"cols_equals_rows_sha256": true' in r.stdout
-
-
 def test_partial_handback_in_a_batch(monkeypatch):
     """A batch of three tasks of 600 lists: two cohorts the pivot / column-blocked kernel suits and one set of unrelated
     lists.  The kernel hands the second task back, libkmx re-runs that task alone with the next kernel down (cols ->
@@ -698,7 +684,41 @@ def test_bench_workload_full_size_parity(workload):
     k_merge_rows by sha256 of every partition's body and statistics, rows ascending, rows out of k_cols_sparse present, partition
     0 == the oracle (scripts/verify_bench_parity.py)"""
     import sys
+    if os.environ.get("KMX_MERGE_KERNEL") != "rows":      # (the autouse fixture runs every test once per kernel; verify() forces the kernels itself)
+        pytest.skip("one run is enough")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import verify_bench_parity
     rep = verify_bench_parity.verify(workload, "counted")
     assert rep["all_kernels_equal_sha256"] and rep["rows_from_k_cols_sparse"] > 0 and rep["rows_total"] > 1_000_000
+
+
+@pytest.mark.parametrize("n,kw,smin,rmin,share", [(300, 1, 10, 2, 1), (300, 1, 10, 2, 2), (600, 1, 25, 1, 1), (257, 2, 10, 3, 2), (300, 1, 10, 0, 0), (300, 1, 10, 0, 1), (200, 2, 12, 0, 0)])
+@pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
+def test_cols_share_min_and_recurrence_min_0(n, kw, smin, rmin, share, mode):
+    """share-min (rescue, merge.hpp:210-247) and recurrence-min 0 in the column-blocked pair (the RESC builds): cohorts with many
+    non-solid records (counts 1..49 against soft-mins of 10..30) -- a row key's non-solid records are rescued in k_merge_cols, the
+    keys outside the row keys have their solid records counted in k_cols_sparse (rows from recurrence-min, rescue from share-min,
+    statistics for every key); with recurrence-min 0 a key only non-solid records hold is a row of zeros.  The result must be the
+    oracle's, and must have come from k_merge_cols."""
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("column-blocked kernel only")
+    from kmtricks_amd import lib
+    torch = pytest.importorskip("torch")
+    lists = synth_lists(4000 + n + 7 * rmin + share, n, 3000, 0.95, 40, kw=kw, key_bits=62 if kw == 1 else 100)
+    # a few keys that only two or three samples hold, solid in some, not in others (the rows k_cols_sparse decides)
+    soft = [smin + (i % 5) for i in range(n)]
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], kw, soft, rmin, share, mode)
+    ctx = lib.Context(0)
+    try:
+        recs = [torch.from_numpy(lib.pack_records(k, c, kw).view(np.int32)).cuda() for k, c in lists]
+        task = dict(lists=[(r.data_ptr(), r.shape[0]) for r in recs], key_words=kw, soft_min=soft, rec_min=rmin, share_min=share, mode=mode)
+        res = ctx.merge_dev([task]); res.wait()
+        assert res.kernel() == "k_merge_cols", res.kernel()
+        assert res.rows() == er
+        body = res.body()
+        assert body == eb, "body differs"
+        assert np.array_equal(res.stats(), es)
+        assert int(es[1].sum()) > 0 or share == 0          # (something was rescued)
+        res.free()
+    finally:
+        ctx.close()
