@@ -46,7 +46,7 @@ using clk = std::chrono::steady_clock;
 struct Sample { std::string id; std::vector<std::string> files; uint32_t hard_min; };
 
 struct Opt {
-  std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file, bf_format = "howdesbt";
+  std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file, bf_format = "howdesbt", soft_min_path;
   uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1, gpu_workers = 2;
   uint64_t bloom = 10000000, merge_batch_mb = 4096;
   double restrict_to = 1.0, focus = 0.5;
@@ -99,7 +99,14 @@ static Opt parse_cli(int argc, char** argv)
     else if (a == "--kmer-size") o.k = num(i);
     else if (a == "--hard-min") o.hard_min = num(i);
     else if (a == "--mode") o.mode = need(i);
-    else if (a == "--soft-min") o.soft_min = num(i);
+    else if (a == "--soft-min") {      // INT / STR / FLOAT (src/cli.cpp:228-248): an integer, a file with one threshold per sample, or a fraction
+      const std::string v = need(i);
+      if (fs::is_regular_file(v)) o.soft_min_path = v;
+      else if (v.find('.') != std::string::npos)
+        die("--soft-min " + v + ": thresholds derived from the abundance histograms (a fraction) are not supported by this build -- the reference's own "
+            "computation is broken (histogram.hpp:221-234 pushes onto a pre-sized vector); give an integer, or a file with one threshold per sample");
+      else { try { size_t n = 0; o.soft_min = (uint32_t)std::stoul(v, &n); if (n != v.size()) throw 1; } catch (...) { die("bad number for --soft-min: " + v); } }
+    }
     else if (a == "--recurrence-min") o.rec_min = num(i);
     else if (a == "--share-min") o.share_min = num(i);
     else if (a == "--nb-partitions") o.nb_parts = num(i);
@@ -141,8 +148,6 @@ static Opt parse_cli(int argc, char** argv)
   if (std::find_if(std::begin(untils), std::end(untils), [&](const char* m) { return o.until == m; }) == std::end(untils)) die("bad --until");
   if (o.bf_format != "howdesbt") die("--bf-format " + o.bf_format + " is not supported (howdesbt)");
   if (o.nb_parts > 65535) die("--nb-partitions too large");
-  const bool bloom_mode = o.mode == "hash:bf:bin" || o.mode == "hash:bfc:bin" || o.mode == "hash:bft:bin";
-  if (!o.plugin.empty() && bloom_mode) die("--plugin with Bloom modes is not supported by this build");
   if ((o.mode == "hash:bf:bin" || o.mode == "hash:bft:bin") && (o.restrict_to != 1.0 || !o.restrict_list.empty())) die("--mode bf|bft requires all partitions.");   // cmd/all.hpp:137-143
   if (o.mode == "hash:bfc:bin" && (o.bitw < 1 || o.bitw > 32)) die("--bitw must be in [1, 32]");
   if (o.threads == 0) o.threads = 1;
@@ -211,7 +216,7 @@ int run(int argc, char** argv)
   { std::ofstream b(root + "/build_infos.txt"); b << "kmx (MI355X-native kmtricks pipeline), libkmx ABI " << kmx_version() << "\n"; }
   { std::ofstream f(root + "/options.txt");   // cmd/all.hpp:85-125: `kmtricks combine` re-parses mode= from this line
     f << "Options: dir=" << root << ", verbosity=info, nb_threads=" << o.threads << ", fof=" << o.fof << ", kmer_size=" << o.k << ", c_ab_min=" << o.hard_min
-      << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", m_ab_min_path=, m_ab_min_f=0, m_ab_float=0, save_if=" << o.share_min << ", minim_size=" << o.msize
+      << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", m_ab_min_path=" << o.soft_min_path << ", m_ab_min_f=0, m_ab_float=0, save_if=" << o.share_min << ", minim_size=" << o.msize
       << ", minim_type=0, repart_type=0, nb_parts=" << P << ", bloom_size=" << o.bloom << ", keep_tmp=" << o.keep_tmp << ", lz4=" << o.cpr << ", kff=0, hist=" << o.hist << ", static_repart=" << o.static_repart
       << ", focus=" << o.focus << ", restrict_to=" << o.restrict_to << ", bwidth=" << o.bitw << ", bam_exclude_refs=, bam_include_flags=0, bam_exclude_flags=0, mode=" << what      // (mode_to_str: count | pa | bf | bfc; cmd/all.hpp:119)
       << ", format=bin, bf_format=" << o.bf_format << ", count_format=" << (hash_mode ? "hash" : "kmer") << ", until=" << o.until << "\n"; }
@@ -642,6 +647,12 @@ int run(int argc, char** argv)
   // ================= merge, one task per partition (task_scheduler.hpp:381-417), batched per GPU =================
   Plugin plug; if (!o.plugin.empty()) plug.load(o.plugin, o.k);
   std::vector<uint32_t> soft(N, o.soft_min);
+  if (!o.soft_min_path.empty()) {      // one threshold per sample, in fof order (cmd/all.hpp:150-162)
+    soft.clear();
+    std::ifstream in(o.soft_min_path); if (!in) die("Unable to read at " + o.soft_min_path);
+    for (std::string line; std::getline(in, line);) { if (line.empty()) continue; try { soft.push_back((uint32_t)std::stol(line)); } catch (...) { die("bad threshold in " + o.soft_min_path + ": " + line); } }
+    if (soft.size() != N) die("The number of thresholds in " + o.soft_min_path + " is different from the number of samples.");
+  }
   const bool is_bloom = what == "bf" || what == "bfc" || what == "bft";
   const uint32_t mkw = hash_mode ? 1 : kw;
   const size_t rec_bytes = mkw * 8 + 4;
@@ -827,6 +838,45 @@ int run(int argc, char** argv)
           auto body = std::make_shared<std::vector<uint8_t>>(nbytes);
           chk(c, kmx_result_copy_body(F.R, (uint32_t)a, body->data(), nbytes), "kmx_result_copy_body");
           tlog(g, "merge_done", p);
+          bool plugin_done = false;
+          if (plug.create && is_bloom) {
+            // A plugin in a Bloom mode (merge.hpp:509-514: process_hash sees EVERY hash of the window's lists, in ascending order, with
+            // the counts the soft-min / rescue rules left; its answer replaces the recurrence test, write_as_bf / bfc / bft then pack
+            // what it left in the counts, merge.hpp:575-644).  The batch ran as count rows with recurrence-min 0 (every hash is a
+            // row); here, on the worker's thread (the context is this thread's): the plugin over the rows, the Bloom rows packed
+            // into the window's dense image, and for hash:bft:bin the transpose (kmx_transpose_bits).
+            const uint64_t W = T.upper - T.lower + 1;
+            const size_t rb_in = 8 + 4ull * N, rb_out = what == "bfc" ? ((size_t)N * o.bitw + 7) / 8 : (N + 7) / 8;
+            auto img = std::make_shared<std::vector<uint8_t>>((size_t)((W + 7) & ~7ULL) * rb_out, 0);
+            km::IMergePlugin* pl = plug.create(); pl->configure(o.plugin_config);
+            pl->set_out_dir(root + "/plugin_output"); pl->set_kmer_size(0); pl->set_partition(p);
+            std::vector<km::IMergePlugin::count_type> cv(N);
+            uint64_t last = T.lower;
+            for (uint64_t r = 0; r <= rows; r++) {      // r == rows: the reference's extra call after the last row
+              const uint8_t* row = body->data() + r * rb_in;
+              if (r < rows) { memcpy(&last, row, 8); for (uint32_t i = 0; i < N; i++) { uint32_t v; memcpy(&v, row + 8 + 4 * i, 4); cv[i] = (km::IMergePlugin::count_type)v; } }
+              else std::fill(cv.begin(), cv.end(), 0);
+              const bool keep = pl->process_hash(last, cv);
+              if (r == rows || !keep || last < T.lower || last > T.upper) continue;
+              uint8_t* out_row = img->data() + (last - T.lower) * rb_out;
+              if (what == "bfc") {      // pack_v: to_n_b(c, w) = min(bit_length(c), 2^w - 1), MSB first at bit i * w (packc.hpp:26-43)
+                for (uint32_t i = 0; i < N; i++) {
+                  uint32_t cc = (uint32_t)cv[i], bl = 0; while (cc) { bl++; cc >>= 1; }
+                  const uint32_t v = std::min<uint32_t>(bl, o.bitw >= 32 ? 0xFFFFFFFFu : (1u << o.bitw) - 1);
+                  for (uint32_t b = 0; b < o.bitw; b++) if ((v >> (o.bitw - 1 - b)) & 1u) { const uint64_t bit = (uint64_t)i * o.bitw + b; out_row[bit >> 3] |= (uint8_t)(0x80u >> (bit & 7)); }
+                }
+              } else for (uint32_t i = 0; i < N; i++) if (cv[i]) out_row[i >> 3] |= (uint8_t)(1u << (i & 7));
+            }
+            plug.destroy(pl);
+            if (what == "bft") {      // write_as_bft: BitMatrix(ROUND_UP(W, 8), ROUND_UP(N, 8) / 8) transposed (merge.hpp:631-644)
+              const uint64_t W8 = (W + 7) & ~7ULL, N8 = (uint64_t)rb_out * 8;
+              auto tr = std::make_shared<std::vector<uint8_t>>((size_t)(N8 * (W8 / 8)), 0);
+              chk(c, kmx_transpose_bits(c, img->data(), W8, N8, tr->data()), "kmx_transpose_bits");
+              img = tr;
+            } else img->resize((size_t)W * rb_out);
+            body = img;
+            plugin_done = true;
+          }
           writes.push_back(pool.submit([=, &o, &plug, &samples, &hw, &tm, &s_format, &res_flag]() {
             try {
               const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
@@ -837,7 +887,7 @@ int run(int argc, char** argv)
               else if (what == "pa") { if (hash_mode) matrix_pa_hash_header(out, N, p, cpr_body); else matrix_pa_header(out, o.k, N, p, cpr_body); }
               else matrix_bf_header(out, what == "bfc" ? N * o.bitw : N, T.lower, T.upper - T.lower + 1, p);
               km::IMergePlugin* pl = nullptr;
-              if (plug.create) {
+              if (plug.create && !plugin_done) {
                 pl = plug.create(); pl->configure(o.plugin_config);                              // plugin_manager.hpp:106-111
                 pl->set_out_dir(root + "/plugin_output"); pl->set_kmer_size(hash_mode ? 0 : o.k); pl->set_partition(p);   // task.hpp:701-712
               }

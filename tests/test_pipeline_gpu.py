@@ -95,6 +95,20 @@ def test_kmer_count_pipeline(inputs, tmp_path):
     assert pin == G["task_main"]["superk_info_D1"][1::2]
 
 
+def test_soft_min_file(inputs, tmp_path):
+    """--soft-min <file>: one threshold per sample in fof order (src/cli.cpp:228-248, cmd/all.hpp:150-162)"""
+    (tmp_path / "soft.txt").write_text("1\n2\n")
+    out = run(inputs, tmp_path / "run", "--mode", "kmer:count:bin", "--soft-min", str(tmp_path / "soft.txt"), "--recurrence-min", "1", "--share-min", "1")
+    lists = oracle_lists(False)
+    for p in range(P):
+        raw = open(out / "matrices" / f"matrix_{p}.count", "rb").read()
+        body, rows, _ = orc.merge_matrix(lists[p], 1, [1, 2], 1, 1, orc.MODE_COUNT)
+        assert raw[45:] == body
+    (tmp_path / "soft1.txt").write_text("1\n")
+    r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "r2"), "--soft-min", str(tmp_path / "soft1.txt")], capture_output=True, text=True)
+    assert r.returncode == 1 and "different from the number of samples" in r.stderr
+
+
 def test_pa_and_recurrence_pipeline(inputs, tmp_path):
     out = run(inputs, tmp_path / "run", "--mode", "kmer:pa:bin", "--recurrence-min", "1")
     lists = oracle_lists(False)
@@ -142,6 +156,46 @@ def test_plugin_pipeline(inputs, tmp_path):
     assert all(os.path.getsize(out2 / "matrices" / f"matrix_{p}.count") == 45 for p in range(P))
 
 
+@pytest.mark.parametrize("what", ["bf", "bfc", "bft"])
+@pytest.mark.parametrize("threshold", [0, 1])
+def test_plugin_in_bloom_modes(inputs, tmp_path, what, threshold):
+    """--plugin with hash:bf|bfc|bft:bin (merge.hpp:509-514, 575-644): process_hash sees every hash of the window's lists in ascending
+    order with the counts the soft-min rule left, its answer replaces the recurrence test, and the Bloom rows are packed from the
+    counts it left (the test plugin keeps a row when every sample's count reaches the threshold and doubles sample 0's count)."""
+    plug = os.path.join(ROOT, "kmtricks_amd", "libkmx_test_plugin.so")
+    out = run(inputs, tmp_path / "run", "--mode", f"hash:{what}:bin", "--bloom-size", "1000000", "--bitw", "3", "--plugin", plug, "--plugin-config", str(threshold))
+    W = struct.unpack("<QQQQI", open(out / "hash.info", "rb").read())[2]
+    lists = oracle_lists(True, W)
+    any_kept = False
+    for p in range(P):
+        body, rows, _ = orc.merge_matrix([(h, c) for h, c in lists[p]], 1, [1, 1], 0, 0, orc.MODE_COUNT)
+        m = np.frombuffer(body, np.uint8).reshape(rows, 16)
+        hs = m[:, :8].copy().view(np.uint64).ravel(); cs = m[:, 8:].copy().view(np.uint32).reshape(rows, 2).astype(np.uint64)
+        keep = (cs >= threshold).all(axis=1)
+        cs[:, 0] *= 2
+        any_kept |= bool(keep.any())
+        rb = 1 if what != "bfc" else (2 * 3 + 7) // 8
+        exp = np.zeros((W, rb), np.uint8)
+        for h, c, k_ in zip(hs, cs, keep):
+            if not k_: continue
+            r = int(h) - W * p
+            if what == "bfc":
+                for i in range(2):
+                    v = min(int(c[i]).bit_length(), 7)
+                    for b in range(3):
+                        if (v >> (2 - b)) & 1:
+                            bit = i * 3 + b; exp[r, bit >> 3] |= 0x80 >> (bit & 7)
+            else:
+                for i in range(2):
+                    if c[i]: exp[r, 0] |= 1 << i
+        raw = open(out / "matrices" / f"matrix_{p}.cmbf", "rb").read()
+        assert struct.unpack("<QIBQIQQII", raw[:49])[4:7] == (2 * 3 if what == "bfc" else 2, W * p, W)
+        if what == "bft":
+            exp = orc.transpose_bits(exp.reshape(-1), W, 8).reshape(8, W // 8)
+        assert raw[49:] == exp.tobytes(), (what, threshold, p)
+    assert any_kept == (threshold == 0)      # (the two fixtures share no 31-mer: with threshold 1 nothing survives)
+
+
 def test_cli_errors(inputs, tmp_path):
     r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 1 and "already exists" in r.stderr          # src/cli.cpp:101-104
@@ -151,6 +205,8 @@ def test_cli_errors(inputs, tmp_path):
     r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "y"), "--mode", "hash:bft:bin",
                         "--restrict-to-list", "0"], capture_output=True, text=True)
     assert r.returncode == 1 and "requires all partitions" in r.stderr  # cmd/all.hpp:137-143
+    r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "w"), "--soft-min", "0.5"], capture_output=True, text=True)
+    assert r.returncode == 1 and "not supported by this build" in r.stderr and "histogram.hpp:221-234" in r.stderr
     (tmp_path / "bad.fof").write_text(f"D1 : {tmp_path}/missing.fasta\n")
     r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "bad.fof"), "--run-dir", str(tmp_path / "z"), "--static-repart"],
                        capture_output=True, text=True)
