@@ -259,8 +259,9 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     # the timed step leaves COUNT / PA rows in HBM as the kernels produce them (k_merge_cols: the row keys' rows and the rows out of
     # k_cols_sparse, each list ascending); a consumer that wants the body in file order ON THE DEVICE (kmx_result_body_dev: the
     # pipeline's writer, an RCCL send) pays a device-to-device pass once per result: timed here, outside the step, and reported
-    gather_ms = None
+    gather_ms = order_ms = None
     if wl in ("count", "pa63") and hasattr(lib, "_lib"):
+        import numpy as _np
         res = ctx.merge_dev(tasks); res.wait()
         sync()
         tg = time.perf_counter()
@@ -268,6 +269,16 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
             res.body_dev(t)
         sync()
         gather_ms = (time.perf_counter() - tg) * 1e3
+        res.free()
+        # ... a consumer that writes the rows to a file does not need that pass: the order of the arena's rows is enough
+        # (kmx_result_copy_order: ranks from the keys only, 4 bytes per row back to the host) -- what `kmx pipeline` uses
+        res = ctx.merge_dev(tasks); res.wait()
+        bufs = [_np.zeros(max(1, res.rows(t)), _np.uint32) for t in range(P)]
+        sync()
+        tg = time.perf_counter()
+        for t in range(P):
+            ctx._check(lib._lib.kmx_result_copy_order(res._h, t, bufs[t].ctypes.data), "kmx_result_copy_order")
+        order_ms = (time.perf_counter() - tg) * 1e3
         res.free()
 
     out = None
@@ -291,7 +302,8 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name),
                          "kernel": kname, "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
-                         "file_order_gather_ms": gather_ms,
+                         "file_order_gather_ms": gather_ms, "row_order_ms": order_ms,
+                         "frac_with_row_order": (algo_bytes / ((kms + order_ms) * 1e-3) / 1e9 / 8000.0) if (order_ms is not None and kms > 0) else None,
                          "frac_with_file_order_gather": (algo_bytes / ((kms + gather_ms) * 1e-3) / 1e9 / 8000.0) if (gather_ms is not None and kms > 0) else None,
                          # streaming read rate of this access pattern measured on an MI355X (profiles/r01_h_fetch_calibration.txt)
                          "measured_stream_peak": 5654.0, "frac_of_measured": (achieved / 5654.0) if achieved else None},

@@ -147,6 +147,12 @@ uint64_t kmx_result_algo_bytes(const kmx_merge_result* r, uint32_t task);
  * reference's writer streams after its header) into host memory -- by DMA straight into host_dst when that is
  * page-locked (kmx_alloc_pinned), through a pinned staging buffer otherwise */
 int kmx_result_copy_body(kmx_merge_result* r, uint32_t task, void* host_dst, uint64_t dst_bytes);
+/* COUNT / PA results WITHOUT any device-side pass over the rows: the arena as the kernels left it (arena_rows rows of row_bytes,
+ * some unused) and the order of its rows -- host_order[d] (kmx_result_rows entries) = the arena row that is row d of the body.
+ * What a file writer takes: it brings the arena to the host in pieces (kmx_copy_to_host) and writes every run of rows at its
+ * place (pwrite at d * row_bytes): the file order comes to exist in the file, never as a second copy of the matrix in HBM. */
+int kmx_result_arena(kmx_merge_result* r, uint32_t task, const void** dev_arena, uint64_t* arena_rows);
+int kmx_result_copy_order(kmx_merge_result* r, uint32_t task, uint32_t* host_order);
 /* the same body into DEVICE memory of the caller (e.g. a buffer an RCCL collective sends from) */
 int kmx_result_copy_body_dev(kmx_merge_result* r, uint32_t task, void* dev_dst, uint64_t dst_bytes);
 int kmx_result_copy_stats(kmx_merge_result* r, uint32_t task, uint64_t* host_stats /* 6 * n_lists */);

@@ -1015,6 +1015,58 @@ static int assemble_body(kmx_merge_result* R, uint32_t t)
   return KMX_OK;
 }
 
+// ---- COUNT/PA rows where the kernels left them + their order: what a consumer takes that puts the rows in place itself (a file
+//      writer: pwrite of row d at d * row_bytes).  No device-side pass over the rows, no second copy of the matrix in HBM. ----
+extern "C" int kmx_result_arena(kmx_merge_result* R, uint32_t t, const void** dev_arena, uint64_t* arena_rows)
+{
+  if (!R || t >= R->tasks.size() || !dev_arena || !arena_rows) return KMX_E_INVAL;
+  kmx_ctx* ctx = R->ctx;
+  int rc = kmx_result_wait(R);
+  if (rc != KMX_OK) return rc;
+  if (R->is_bf) return ctx->fail(KMX_E_UNSUPPORTED, "kmx_result_arena: Bloom results are dense (kmx_result_body_dev)");
+  *dev_arena = R->tasks[t].d_out; *arena_rows = R->tasks[t].arena_rows;
+  return KMX_OK;
+}
+extern "C" int kmx_result_copy_order(kmx_merge_result* R, uint32_t t, uint32_t* host_order)
+{
+  if (!R || t >= R->tasks.size() || !host_order) return KMX_E_INVAL;
+  kmx_ctx* ctx = R->ctx;
+  int rc = kmx_result_wait(R);
+  if (rc != KMX_OK) return rc;
+  if (R->is_bf) return ctx->fail(KMX_E_UNSUPPORTED, "kmx_result_copy_order: Bloom results are dense (kmx_result_body_dev)");
+  TaskHost& H = R->tasks[t];
+  if (H.rows == 0) return KMX_OK;
+  if (H.rows > 0xFFFFFFFFULL || H.arena_rows > 0xFFFFFFFFULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 rows in one task");
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  const ColsOps& CO = cols_ops((int)H.kw);
+  if (H.kernel == 2 && H.sparse_rows) {
+    const u32 ng = CO.groups(H.slots_cap);
+    u32* d_order = (u32*)ctx->dalloc((size_t)H.rows * 4);
+    u64* d_goff = (u64*)ctx->dalloc((size_t)ng * 8);
+    struct Rel { kmx_ctx* c; void* a; void* b; ~Rel() { c->dfree(a); c->dfree(b); } } rel{ctx, d_order, d_goff};
+    if (!d_order || !d_goff) return ctx->fail(KMX_E_NOMEM, "row order allocation failed");
+    const TaskDev* d_tasks = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_tasks);
+    const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
+    KMX_HIP(ctx, CO.offsets(d_cols, t, d_goff, ctx->copy));
+    KMX_HIP(ctx, CO.order(d_tasks, d_cols, t, ng, d_goff, d_order, ctx->copy));
+    KMX_HIP(ctx, hipMemcpyAsync(host_order, d_order, (size_t)H.rows * 4, hipMemcpyDeviceToHost, ctx->copy));
+    KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+    return KMX_OK;
+  }
+  std::vector<Seg> segs(H.nsegs);
+  KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->copy));
+  KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.range != b.range ? a.range < b.range : a.seq < b.seq; });
+  u64 done = 0;
+  for (const Seg& g : segs) {
+    if (g.row_off + g.nrows > H.arena_rows || done + g.nrows > H.rows) return ctx->fail(KMX_E_HIP, "corrupt segment directory");
+    for (u32 r = 0; r < g.nrows; r++) host_order[done + r] = (u32)(g.row_off + r);
+    done += g.nrows;
+  }
+  if (done != H.rows) return ctx->fail(KMX_E_HIP, "segment directory does not cover the arena");
+  return KMX_OK;
+}
+
 extern "C" const void* kmx_result_body_dev(kmx_merge_result* R, uint32_t t)
 {
   if (!R || t >= R->tasks.size() || kmx_result_wait(R) != KMX_OK) return nullptr;

@@ -39,6 +39,7 @@ struct ColsOps {
   u32 (*groups)(u32 slots);
   hipError_t (*offsets)(const ColsDev* cols, u32 task, u64* goff, hipStream_t st);
   hipError_t (*gather)(const TaskDev* tasks, const ColsDev* cols, u32 task, u32 n_groups, const u64* goff, u8* body, hipStream_t st);
+  hipError_t (*order)(const TaskDev* tasks, const ColsDev* cols, u32 task, u32 n_groups, const u64* goff, u32* order, hipStream_t st);
   void (*dbg_dump)();
   void (*phase_prof_dump)();
   u32 key_words;

@@ -1197,6 +1197,10 @@ void k_cols_offsets(const ColsDev* __restrict__ cols, u32 task, u64* __restrict_
 
 constexpr int GA_TPB = 256;
 constexpr int GA_KEYS = 4096 / KW;      // keys of a group held in LDS (more: ranks come from global memory)
+// COPY: the rows go to their places in `body`.  !COPY: only the ORDER is written -- order[d] = the arena row that is row d of the body
+// (body then points at a u32 array): a consumer that writes the rows to a file anyway puts them in order there (pwrite at d * row
+// bytes), and no second copy of the matrix ever exists in HBM.
+template <bool COPY>
 __global__ __launch_bounds__(GA_TPB)
 void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, u32 task, const u64* __restrict__ goff, u8* __restrict__ body)
 {
@@ -1219,6 +1223,21 @@ void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
   auto key_at = [&](u32 i) -> CKey { return i < (u32)GA_KEYS ? keys[i] : ck_load(src_row(i)); };
   for (u32 i = tid; i < min(n, (u32)GA_KEYS); i += GA_TPB) keys[i] = i < dn ? reinterpret_cast<const CKey*>(C.skel)[d0 + i] : ck_load(src_row(i));
   __syncthreads();
+  if (!COPY) {      // a thread per row: its rank, and where it lies in the arena
+    u32* const order = reinterpret_cast<u32*>(body) + goff[blockIdx.x];
+    for (u32 i = tid; i < n; i += GA_TPB) {
+      const CKey k = key_at(i);
+      u32 rank = 0;
+      for (int l = 0; l <= CK_NPASS; l++) {
+        u32 a = lo[l], b = lo[l + 1];
+        if (i >= a && i < b) { rank += i - a; continue; }
+        while (a < b) { const u32 m = (a + b) >> 1; if (ck_lt(key_at(m), k)) a = m + 1; else b = m; }
+        rank += a - lo[l];
+      }
+      order[rank] = (u32)((u64)(src_row(i) - T.out) / row_bytes);
+    }
+    return;
+  }
   u8* const dst0 = body + goff[blockIdx.x] * row_bytes;
   for (u32 i = wave; i < n; i += GA_TPB / 64) {      // a wave per row: its rank = keys below it in every list
     const CKey k = key_at(i);
@@ -1323,13 +1342,18 @@ hipError_t launch_cols_offsets(const ColsDev* cols, u32 task, u64* goff, hipStre
 }
 hipError_t launch_cols_gather(const TaskDev* tasks, const ColsDev* cols, u32 task, u32 n_groups, const u64* goff, u8* body, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_cols_gather, dim3(n_groups), dim3(GA_TPB), 0, st, tasks, cols, task, goff, body);
+  hipLaunchKernelGGL(k_cols_gather<true>, dim3(n_groups), dim3(GA_TPB), 0, st, tasks, cols, task, goff, body);
+  return hipGetLastError();
+}
+hipError_t launch_cols_order(const TaskDev* tasks, const ColsDev* cols, u32 task, u32 n_groups, const u64* goff, u32* order, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cols_gather<false>, dim3(n_groups), dim3(GA_TPB), 0, st, tasks, cols, task, goff, reinterpret_cast<u8*>(order));
   return hipGetLastError();
 }
 
 static const ColsOps g_ops = {cols_lds_bytes, cols_block_lists, cols_wgs_per_cu, cols_tile_rows, cols_scratch_keys, cols_scratch_counts, cols_ext_entries, cols_skel_cap,
                               launch_cols_skel, launch_cols_prep, launch_merge_cols, launch_cols_sparse, cols_dir_bytes, cols_groups, launch_cols_offsets,
-                              launch_cols_gather, cols_dbg_dump,
+                              launch_cols_gather, launch_cols_order, cols_dbg_dump,
 #ifdef KMX_PHASE_PROF
                               cols_phase_prof_dump,
 #else

@@ -693,7 +693,7 @@ int run(int argc, char** argv)
       ~Ring() { for (auto p : free_) kmx_free_pinned(p); }
     } ring;
     if (const char* e = getenv("KMX_OUT_RING_MB")) ring.cap = std::max<size_t>(2, (size_t)atol(e) / 32);
-    if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(4096, (size_t)atol(e) << 10); ring.cap = std::max<size_t>(ring.cap, 4); }      // (small pieces: for the tests)
+    if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(32768, (size_t)atol(e) << 10); ring.cap = std::max<size_t>(ring.cap, 4); }      // (small pieces: for the tests)
     struct Pinned { uint8_t* p = nullptr; uint64_t cap = 0; void need(uint64_t n) { if (n <= cap) return; kmx_free_pinned(p); cap = n + n / 8 + (1u << 20); p = (uint8_t*)kmx_alloc_pinned(cap); if (!p) die("pinned host allocation failed"); } ~Pinned() { kmx_free_pinned(p); } };
 
     auto worker_fn = [&](uint32_t g) {
@@ -802,10 +802,10 @@ int run(int argc, char** argv)
               else { matrix_bf_header(out, what == "bfc" ? N * o.bitw : N, T.lower, T.upper - T.lower + 1, p); hl = 49; }
               out.close();
             } catch (const std::exception& e) { die(e.what()); }
-            const uint8_t* dbody = (const uint8_t*)kmx_result_body_dev(F.R, (uint32_t)a);
-            if (nbytes && !dbody) die(std::string("kmx_result_body_dev: ") + kmx_last_error(c));
             tlog(g, "merge_done", p);
-            if (nbytes) {
+            if (nbytes && is_bloom) {      // a dense window image: pieces of it straight to their place in the file
+              const uint8_t* dbody = (const uint8_t*)kmx_result_body_dev(F.R, (uint32_t)a);
+              if (!dbody) die(std::string("kmx_result_body_dev: ") + kmx_last_error(c));
               const int fd = open(path.c_str(), O_WRONLY); if (fd < 0) die("Unable to write at " + path);
               auto left = std::make_shared<std::atomic<uint64_t>>((nbytes + ring.bytes - 1) / ring.bytes);
               for (uint64_t off = 0; off < nbytes; off += ring.bytes) {
@@ -817,6 +817,39 @@ int run(int argc, char** argv)
                   while (done < n) { const ssize_t r = pwrite(fd, piece + done, n - done, (off_t)(hl + off + done)); if (r <= 0) break; done += (uint64_t)r; }
                   ring.put(piece);
                   if (done != n) die("write failed: " + path);
+                  if (--*left == 0) close(fd);
+                }));
+              }
+            } else if (nbytes) {
+              // count / pa rows: the arena as the kernels left it (k_merge_cols: the row keys' rows, then the rows out of k_cols_sparse;
+              // the other kernels: row segments) comes to the host piece by piece, and every run of rows that is a run of the body
+              // too goes to its place in the file with one pwrite -- the file order comes to exist in the file; no pass over the
+              // matrix on the device, no second copy of it in HBM
+              const uint64_t rb = kmx_result_row_bytes(F.R, (uint32_t)a);
+              const void* dar = nullptr; uint64_t arows = 0;
+              chk(c, kmx_result_arena(F.R, (uint32_t)a, &dar, &arows), "kmx_result_arena");
+              std::vector<uint32_t> order(rows);
+              chk(c, kmx_result_copy_order(F.R, (uint32_t)a, order.data()), "kmx_result_copy_order");
+              auto inv = std::make_shared<std::vector<uint32_t>>(arows, 0xFFFFFFFFu);      // arena row -> row of the body (unused arena rows: none)
+              for (uint64_t d = 0; d < rows; d++) { if (order[d] >= arows) die("corrupt row order"); (*inv)[order[d]] = (uint32_t)d; }
+              const int fd = open(path.c_str(), O_WRONLY); if (fd < 0) die("Unable to write at " + path);
+              const uint64_t prow = std::max<uint64_t>(1, ring.bytes / rb);               // arena rows per piece
+              auto left = std::make_shared<std::atomic<uint64_t>>((arows + prow - 1) / prow);
+              for (uint64_t r0 = 0; r0 < arows; r0 += prow) {
+                const uint64_t nr = std::min<uint64_t>(prow, arows - r0);
+                uint8_t* piece = ring.get();
+                chk(c, kmx_copy_to_host(c, piece, (const uint8_t*)dar + r0 * rb, nr * rb), "kmx_copy_to_host");
+                writes.push_back(pool.submit([=, &ring]() {
+                  const uint32_t* iv = inv->data();
+                  for (uint64_t r = r0; r < r0 + nr;) {
+                    if (iv[r] == 0xFFFFFFFFu) { r++; continue; }
+                    uint64_t e = r + 1; while (e < r0 + nr && iv[e] == iv[e - 1] + 1) e++;      // rows r .. e - 1 are rows iv[r] .. of the body
+                    const uint64_t n = (e - r) * rb; uint64_t done = 0;
+                    while (done < n) { const ssize_t w = pwrite(fd, piece + (r - r0) * rb + done, n - done, (off_t)(hl + (uint64_t)iv[r] * rb + done)); if (w <= 0) break; done += (uint64_t)w; }
+                    if (done != n) die("write failed: " + path);
+                    r = e;
+                  }
+                  ring.put(piece);
                   if (--*left == 0) close(fd);
                 }));
               }

@@ -51,6 +51,8 @@ def verify(workload="count", lists_kind="counted", N=None, P=32, genome=5e6, d=0
                     keys = m[:, :8 * kw].copy().view(np.uint64).reshape(-1, kw)
                     hi, lo = keys[:, kw - 1], keys[:, 0]
                     assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1]))), "rows not ascending"
+                if t < 2 and res.body_from_arena(t) != body:      # (the arena and the order of its rows: what the pipeline's writer works from)
+                    raise AssertionError(f"{kern}: partition {t}: arena + row order do not give the body")
                 if t < oracle_parts and kern != "rows":
                     hl = [ctx.read_list(ptr, n, kw) for ptr, n in lists[t]]
                     eb, er, es = orc.merge_matrix(hl, kw, [1] * N, rec_min, 0, omode)

@@ -717,8 +717,31 @@ def test_cols_share_min_and_recurrence_min_0(n, kw, smin, rmin, share, mode):
         assert res.rows() == er
         body = res.body()
         assert body == eb, "body differs"
+        assert res.body_from_arena() == eb, "arena + order differ"
         assert np.array_equal(res.stats(), es)
         assert int(es[1].sum()) > 0 or share == 0          # (something was rescued)
+        res.free()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
+@pytest.mark.parametrize("n,kw", [(40, 1), (300, 1), (260, 2)])
+def test_arena_and_row_order(n, kw, mode):
+    """kmx_result_arena + kmx_result_copy_order (the rows where the kernels left them and the order of the body's rows: what the
+    pipeline's file writer turns into pwrites) give the body kmx_result_copy_body gives, for every kernel (segments of
+    k_merge_rows / k_merge_pivot, the two lists of k_merge_cols + k_cols_sparse) -- and that body is the oracle's"""
+    from kmtricks_amd import lib
+    torch = pytest.importorskip("torch")
+    lists = synth_lists(7000 + n, n, 2500, 0.93, 60, kw=kw, key_bits=62 if kw == 1 else 100)
+    soft = [1 + (i % 3) for i in range(n)]
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], kw, soft, 2, 0, mode)
+    ctx = lib.Context(0)
+    try:
+        recs = [torch.from_numpy(lib.pack_records(k, c, kw).view(np.int32)).cuda() for k, c in lists]
+        res = ctx.merge_dev([dict(lists=[(r.data_ptr(), r.shape[0]) for r in recs], key_words=kw, soft_min=soft, rec_min=2, share_min=0, mode=mode)])
+        res.wait()
+        assert res.rows() == er and res.body_from_arena() == eb and res.body() == eb
         res.free()
     finally:
         ctx.close()
