@@ -279,6 +279,13 @@ typedef struct {
   uint32_t* minim_superks;
   uint32_t* minim_kmers;
   uint64_t  nb_superk;
+  /* the per-minimizer records in SPARSE form instead (most of the 4^m minimizers never occur in a sample: 8 MB of tables for
+   * ~10^5 entries at m = 10): minim_sparse != NULL (room for 3 * minim_sparse_cap u32; minim_superks / minim_kmers are then
+   * ignored) receives minim_sparse_n triples {minimizer, super-k-mers, k-mers} in no particular order.  More minimizers
+   * than minim_sparse_cap: KMX_E_INVAL (4^m entries always suffice). */
+  uint32_t* minim_sparse;
+  uint64_t  minim_sparse_cap;
+  uint64_t  minim_sparse_n;
 } kmx_superk_raw;
 
 /* kmx_count_reads with the results left on the device: partition p's (key, count) records -- ascending, packed as a

@@ -312,6 +312,24 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
 
 using namespace kmx;
 
+// the minimizers that occur: {minimizer, super-k-mers, k-mers} triples, in no particular order (kmx_superk_raw::minim_sparse)
+__global__ void k_minim_sparse(const u32* __restrict__ ms, const u32* __restrict__ mk, u64 nm, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out)
+{
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 a = i < nm ? ms[i] : 0u;
+  const bool have = a != 0;
+  const u64 bal = __ballot(have);
+  if (!bal) return;
+  u32 base = 0;
+  const u32 lane = threadIdx.x & 63u;
+  if (lane == 0) base = atomicAdd(n_out, (u32)__popcll(bal));
+  base = (u32)__shfl((int)base, 0);
+  if (have) {
+    const u32 pos = base + (u32)__popcll(bal & ((1ULL << lane) - 1));
+    if (pos < cap) { out[3 * (u64)pos] = (u32)i; out[3 * (u64)pos + 1] = a; out[3 * (u64)pos + 2] = mk[i]; }
+  }
+}
+
 // stats tables of one call (u32 on the device): added to the caller's u64 arrays (kmx_superk_stats), or copied as they are into
 // the caller's u32 buffers (kmx_superk_raw: no host arithmetic, one synchronisation)
 struct StatsDev {
@@ -326,8 +344,8 @@ struct StatsDev {
       if (p) (void)hipMemsetAsync(p, 0, n * 4, s);
       return p;
     };
-    const bool w_pc = (st && st->part_counters) || (rw && rw->part_radix), w_ms = (st && st->minim_superks) || (rw && rw->minim_superks),
-               w_mk = (st && st->minim_kmers) || (rw && rw->minim_kmers), w_mx = st && st->minim_kxmers;
+    const bool w_pc = (st && st->part_counters) || (rw && rw->part_radix), w_ms = (st && st->minim_superks) || (rw && (rw->minim_superks || rw->minim_sparse)),
+               w_mk = (st && st->minim_kmers) || (rw && (rw->minim_kmers || rw->minim_sparse)), w_mx = st && st->minim_kxmers;
     S.pc = get(w_pc, (size_t)P * 1280);
     S.ms = get(w_ms, nminim);
     S.mk = get(w_mk, nminim);
@@ -343,8 +361,27 @@ struct StatsDev {
     if (raw) {
       hipError_t e = hipSuccess;
       if (raw->part_radix) e = hipMemcpyAsync(raw->part_radix, S.pc, (size_t)nb_parts * 1280 * 4, hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess && raw->minim_superks) e = hipMemcpyAsync(raw->minim_superks, S.ms, nm * 4, hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess && raw->minim_kmers) e = hipMemcpyAsync(raw->minim_kmers, S.mk, nm * 4, hipMemcpyDeviceToHost, s);
+      if (raw->minim_sparse) {      // the minimizers that occur, compacted on the device: their number first, then that many triples
+        const u32 cap = (u32)std::min<u64>(raw->minim_sparse_cap, 0xFFFFFFF0ULL);
+        u32* d_sp = (u32*)ctx->dalloc((size_t)std::min<u64>(cap, nm) * 12 + 16);
+        u32* d_n = (u32*)ctx->dalloc(256);
+        struct Rel { kmx_ctx* c; void* a; void* b; ~Rel() { c->dfree(a); c->dfree(b); } } rel{ctx, d_sp, d_n};
+        if (!d_sp || !d_n) return ctx->fail(KMX_E_NOMEM, "superk statistics: device allocation failed");
+        u32 n = 0;
+        if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, 4, s);
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, S.ms, S.mk, nm, d_sp, (u32)std::min<u64>(cap, nm), d_n); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
+        if (n > cap) return ctx->fail(KMX_E_INVAL, "kmx_superk_raw: more minimizers occur than minim_sparse_cap");
+        raw->minim_sparse_n = n;
+        if (n) e = hipMemcpyAsync(raw->minim_sparse, d_sp, (size_t)n * 12, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
+        if (!dst) return KMX_OK;
+      }
+      if (e == hipSuccess && !raw->minim_sparse && raw->minim_superks) e = hipMemcpyAsync(raw->minim_superks, S.ms, nm * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess && !raw->minim_sparse && raw->minim_kmers) e = hipMemcpyAsync(raw->minim_kmers, S.mk, nm * 4, hipMemcpyDeviceToHost, s);
       if (e == hipSuccess) e = hipStreamSynchronize(s);
       if (e != hipSuccess) return ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
       if (!dst) return KMX_OK;
@@ -420,7 +457,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
   StatsDev sd;
   { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st); if (rc != KMX_OK) { release(); return rc; } }
-  if (raw) raw->nb_superk = 0;
+  if (raw) { raw->nb_superk = 0; raw->minim_sparse_n = 0; }
   const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
   if (!want_streams) {   // statistics only (the sampling pass of the repartition): one walk, nothing emitted
     u64 use = n_seqs;
@@ -458,8 +495,11 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if (nd == 0) {
     if (raw) {      // nothing counted: the caller's tables are all zeros
       if (raw->part_radix) memset(raw->part_radix, 0, (size_t)nb_parts * 1280 * 4);
-      if (raw->minim_superks) memset(raw->minim_superks, 0, nm * 4);
-      if (raw->minim_kmers) memset(raw->minim_kmers, 0, nm * 4);
+      if (raw->minim_sparse) raw->minim_sparse_n = 0;
+      else {
+        if (raw->minim_superks) memset(raw->minim_superks, 0, nm * 4);
+        if (raw->minim_kmers) memset(raw->minim_kmers, 0, nm * 4);
+      }
     }
     release();
     for (u32 p = 0; p < nb_parts; p++) {

@@ -6,6 +6,7 @@
 // as the reference's serialize() methods do.  Bodies are raw, or one lz4 frame with --cpr
 // (io/lz4_stream.hpp:89-159: any LZ4F reader reads it; the compressed bytes themselves are not pinned).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -335,6 +336,46 @@ inline void write_parti_info_raw(const std::string& path, uint32_t nb_parts, uin
     for (int i = 0; i < 1280; i++) num(r[i]);
   }
   for (uint64_t i = 0; i < nb_minims; i++) { num(minim_superks[i]); num(minim_kmers[i]); *w++ = '0'; *w++ = '\n'; }
+  const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
+  if (fd < 0) throw IoError("Unable to write at " + path);
+  const size_t n = (size_t)(w - s.data()); size_t done = 0;
+  while (done < n) { const ssize_t r = write(fd, s.data() + done, n - done); if (r <= 0) break; done += (size_t)r; }
+  close(fd);
+  if (done != n) throw IoError("write failed: " + path);
+}
+
+// ... and with the per-minimizer records in sparse form ({minimizer, super-k-mers, k-mers} triples in any order,
+// kmx_superk_raw::minim_sparse): the minimizers that do not occur are runs of "0\n0\n0\n"
+inline void write_parti_info_sparse(const std::string& path, uint32_t nb_parts, uint64_t nb_minims, uint64_t nb_superk_total,
+                                    const uint32_t* part_radix, const uint32_t* triples, uint64_t n_triples) {
+  std::vector<std::pair<uint32_t, uint64_t>> idx(n_triples);      // minimizer, position
+  for (uint64_t i = 0; i < n_triples; i++) idx[i] = {triples[3 * i], i};
+  std::sort(idx.begin(), idx.end());
+  std::vector<char> s((size_t)nb_parts * 1282 * 11 + nb_minims * 6 + n_triples * 24 + 128);
+  char* w = s.data();
+  auto num = [&](uint64_t v) {
+    if (v < 10) { *w++ = (char)('0' + v); *w++ = '\n'; return; }
+    char b[24]; int n = 0; while (v) { b[n++] = (char)('0' + v % 10); v /= 10; } while (n) *w++ = b[--n]; *w++ = '\n';
+  };
+  uint64_t nk_total = 0;
+  for (uint32_t p = 0; p < nb_parts; p++) for (uint32_t x = 0; x < 5; x++) { uint64_t c = 0; const uint32_t* r = part_radix + ((size_t)p * 5 + x) * 256; for (int i = 0; i < 256; i++) c += r[i]; nk_total += c * (x + 1); }
+  num(nb_parts); num(nb_minims); num(nb_superk_total); num(nk_total);
+  for (uint32_t p = 0; p < nb_parts; p++) {
+    const uint32_t* r = part_radix + (size_t)p * 1280;
+    uint64_t nk = 0, nx = 0;
+    for (uint32_t x = 0; x < 5; x++) { uint64_t c = 0; for (int i = 0; i < 256; i++) c += r[x * 256 + i]; nx += c; nk += c * (x + 1); }
+    num(nk); num(nx);
+    for (int i = 0; i < 1280; i++) num(r[i]);
+  }
+  auto zeros = [&](uint64_t n) { for (uint64_t i = 0; i < n; i++) { memcpy(w, "0\n0\n0\n", 6); w += 6; } };
+  uint64_t at = 0;
+  for (auto& e : idx) {
+    if (e.first >= nb_minims) throw IoError("minimizer out of range in the statistics");
+    zeros(e.first - at);
+    num(triples[3 * e.second + 1]); num(triples[3 * e.second + 2]); *w++ = '0'; *w++ = '\n';
+    at = (uint64_t)e.first + 1;
+  }
+  zeros(nb_minims - at);
   const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0666);
   if (fd < 0) throw IoError("Unable to write at " + path);
   const size_t n = (size_t)(w - s.data()); size_t done = 0;

@@ -366,7 +366,26 @@ int run(int argc, char** argv)
   // (kmx_superk_partition[_stats]) and, at the sample's last batch, counts all its partitions (kmx_count_batch) and hands the
   // count files to the pool for writing.
   {
-    struct ReadBatch { uint32_t si = 0; bool last = false; std::string bases; std::vector<uint64_t> offs; };
+    // a batch of reads: the bases lie in page-locked memory (the upload is a DMA at the link's rate and does not hold the worker's
+    // thread; from a std::string the runtime stages it through its own pinned block, synchronously), blocks from a pool
+    struct PinStr { char* p = nullptr; size_t cap = 0, len = 0; const char* data() const { return p; } size_t size() const { return len; } };
+    struct PinPool {
+      std::mutex m; std::vector<PinStr> free_;
+      PinStr get(size_t want) {
+        {
+          std::lock_guard<std::mutex> lk(m);
+          int best = -1;
+          for (size_t i = 0; i < free_.size(); i++) if (free_[i].cap >= want && (best < 0 || free_[i].cap < free_[best].cap)) best = (int)i;
+          if (best >= 0) { PinStr r = free_[best]; free_.erase(free_.begin() + best); r.len = 0; return r; }
+        }
+        PinStr r; r.cap = want + want / 8 + (1u << 16); r.p = (char*)kmx_alloc_pinned(r.cap);
+        if (!r.p) die("pinned host allocation failed");
+        return r;
+      }
+      void put(PinStr b) { if (!b.p) return; std::lock_guard<std::mutex> lk(m); free_.push_back(b); }
+      ~PinPool() { for (auto& b : free_) kmx_free_pinned(b.p); }
+    } pinpool;
+    struct ReadBatch { uint32_t si = 0; bool last = false; PinStr bases; std::vector<uint64_t> offs; };
     std::vector<std::unique_ptr<Channel<ReadBatch>>> chan;
     for (uint32_t w = 0; w < NW; w++) chan.emplace_back(new Channel<ReadBatch>(3));
     std::mutex tm; double s_read = 0, s_split = 0, s_count = 0;
@@ -375,7 +394,7 @@ int run(int argc, char** argv)
     // pinned blocks for the statistics tables of a sample (kmx_superk_raw: P * 1280 + 2 * 4^m u32), handed back by the task that
     // has written the sample's PartiInfoFile
     const uint64_t nm_ = 1ULL << (2 * o.msize);
-    const size_t raw_words = (size_t)P * 1280 + 2 * nm_;
+    const size_t raw_words = (size_t)P * 1280 + 3 * nm_;      // the partitions' radix counters + {minimizer, super-k-mers, k-mers} triples (as many as occur)
     struct RawPool {
       std::mutex m; std::condition_variable cv; std::vector<uint32_t*> free_; size_t made = 0, cap, words;
       uint32_t* get() {
@@ -401,18 +420,23 @@ int run(int argc, char** argv)
         // (a sample's reads reach the GPU in batches of 256 MB of bases; KMX_READ_BATCH_BYTES lowers that -- for the tests of the
         //  path that adds a sample's batches up)
         static const size_t batch_bytes = getenv("KMX_READ_BATCH_BYTES") ? (size_t)std::max(1L, atol(getenv("KMX_READ_BATCH_BYTES"))) : (size_t)(256u << 20);
+        // room for the sample in one block when it fits a batch (its files' sizes bound its bases; 8x for gzip)
+        uint64_t est = 4096;
+        for (const std::string& f : samples[si].files) { std::error_code ec; const uint64_t sz = fs::file_size(f, ec); est += ec ? 0 : sz * (f.size() > 3 && f.substr(f.size() - 3) == ".gz" ? 8 : 1); }
+        const size_t want = (size_t)std::min<uint64_t>(batch_bytes, est);
+        b.bases = pinpool.get(want);
         try {
           for (const std::string& f : samples[si].files) {
             SeqReader rd(f); std::string seq;
             auto t = clk::now();
             while (rd.next(seq)) {
-              b.bases += seq; b.offs.push_back(b.bases.size());
-              if (b.bases.size() > batch_bytes) {
+              if (b.bases.len + seq.size() > b.bases.cap || (b.bases.len + seq.size() > batch_bytes && b.offs.size() > 1)) {
                 rs += since(t);
                 ch.push(std::move(b));
-                b = ReadBatch(); b.si = si; b.offs.assign(1, 0);
+                b = ReadBatch(); b.si = si; b.offs.assign(1, 0); b.bases = pinpool.get(std::max(want, seq.size()));
                 t = clk::now();
               }
+              memcpy(b.bases.p + b.bases.len, seq.data(), seq.size()); b.bases.len += seq.size(); b.offs.push_back(b.bases.len);
             }
             rs += since(t);
           }
@@ -441,6 +465,7 @@ int run(int argc, char** argv)
       while (done < per_gpu[g]) {
         ReadBatch b;
         if (!chan[g]->pop(b)) break;
+        struct Back { PinPool& pp; PinStr s; ~Back() { pp.put(s); } } back{pinpool, b.bases};      // (the block goes back to the pool when this batch is done with)
         const bool whole_sample = b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk" && !(o.hist && restricted);      // (the fused calls count every partition: not what a histogram of the selected ones needs)
         bool fits = resident_mode && whole_sample;
         if (fits) {   // a k-mer per base at most, a record per k-mer at most: room for that in every store (its share of the partitions)
@@ -458,7 +483,7 @@ int run(int argc, char** argv)
           auto info = std::make_shared<std::vector<uint64_t>>(2 * (size_t)P, 0);
           uint32_t* rawbuf = o.skip_pinfo ? nullptr : rawpool.get();
           kmx_superk_raw raw{};
-          if (rawbuf) { raw.part_radix = rawbuf; raw.minim_superks = rawbuf + (size_t)P * 1280; raw.minim_kmers = raw.minim_superks + nm; }
+          if (rawbuf) { raw.part_radix = rawbuf; raw.minim_sparse = rawbuf + (size_t)P * 1280; raw.minim_sparse_cap = nm; }      // (sparse: ~10^5 of the 4^m minimizers occur in a sample)
           if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
           chk(c, kmx_count_reads_dev(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, smp.hard_min,
                                      stores.data(), G, ls.data(), nkp.data(), nullptr, nullptr, info->data(), nullptr, rawbuf ? &raw : nullptr), "kmx_count_reads_dev");
@@ -467,7 +492,7 @@ int run(int argc, char** argv)
           res_flag[si] = 1;
           uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
           st.kmers += nkt;
-          const uint64_t nsk = raw.nb_superk;
+          const uint64_t nsk = raw.nb_superk, n_sparse = raw.minim_sparse_n;
           auto nkp_s = std::make_shared<std::vector<uint64_t>>(std::move(nkp));
           const std::string sid = smp.id;
           writes.push_back(pool.submit([=, &rawpool, &selected]() {
@@ -478,7 +503,7 @@ int run(int argc, char** argv)
               { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
                 for (uint32_t p = 0; p < P; p++) inf += std::to_string(selected[p] ? (*info)[2 * p] : 0) + "\n" + std::to_string(selected[p] ? (*info)[2 * p + 1] : 0) + "\n";
                 Out f(sd + "/SuperKmerBinInfoFile"); f.raw(inf.data(), inf.size()); f.close(); }
-              if (rawbuf) write_parti_info_raw(sd + "/PartiInfoFile", P, nm, nsk, rawbuf, rawbuf + (size_t)P * 1280, rawbuf + (size_t)P * 1280 + nm);
+              if (rawbuf) write_parti_info_sparse(sd + "/PartiInfoFile", P, nm, nsk, rawbuf, rawbuf + (size_t)P * 1280, n_sparse);
             } catch (const std::exception& e) { die(e.what()); }
             if (rawbuf) rawpool.put(rawbuf);
           }));

@@ -91,7 +91,8 @@ _lib.kmx_superk_sample.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32,
 
 
 class KmxSuperkRaw(C.Structure):
-    _fields_ = [("part_radix", _vp), ("minim_superks", _vp), ("minim_kmers", _vp), ("nb_superk", C.c_uint64)]
+    _fields_ = [("part_radix", _vp), ("minim_superks", _vp), ("minim_kmers", _vp), ("nb_superk", C.c_uint64),
+                ("minim_sparse", _vp), ("minim_sparse_cap", C.c_uint64), ("minim_sparse_n", C.c_uint64)]
 
 
 _lib.kmx_device_memory.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -313,7 +314,7 @@ class Context:
                 _lib.kmx_free(ob[p])
         return out, [int(x) for x in nk], st, np.array(list(info), dtype=np.uint64).reshape(nb_parts, 2)
 
-    def count_reads_dev(self, reads, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False):
+    def count_reads_dev(self, reads, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False, sparse=False):
         """kmx_count_reads_dev: as count_reads, the results left on the device as packed records in `stores` (partition p ->
         stores[p % len(stores)]) -> ([(device pointer, records)] per partition, k-mers per partition, raw tables or None)"""
         blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
@@ -321,12 +322,20 @@ class Context:
         sp = (_vp * len(stores))(*[s._h for s in stores])
         lists, nk = (KmxList * nb_parts)(), (C.c_uint64 * nb_parts)()
         rw, tabs = None, None
+        sp = None
         if raw:
             tabs = (np.zeros(nb_parts * 1280, np.uint32), np.zeros(4 ** m, np.uint32), np.zeros(4 ** m, np.uint32))
-            rw = KmxSuperkRaw(tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data, 0)
+            rw = KmxSuperkRaw(tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data, 0, None, 0, 0)
+            if sparse:      # the per-minimizer records as {minimizer, super-k-mers, k-mers} triples: turned back into the tables here
+                sp = np.zeros((4 ** m, 3), np.uint32)
+                rw = KmxSuperkRaw(tabs[0].ctypes.data, None, None, 0, sp.ctypes.data, 4 ** m, 0)
         self._check(_lib.kmx_count_reads_dev(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
                                              1 if window else 0, window, hard_min, sp, len(stores), lists, nk, None, None, None, None,
                                              C.byref(rw) if raw else None), "kmx_count_reads_dev")
+        if sp is not None:
+            t = sp[:int(rw.minim_sparse_n)]
+            assert len(np.unique(t[:, 0])) == len(t)
+            tabs[1][t[:, 0]] = t[:, 1]; tabs[2][t[:, 0]] = t[:, 2]
         return [(lists[p].recs, int(lists[p].n)) for p in range(nb_parts)], [int(x) for x in nk], (tabs + (int(rw.nb_superk),)) if raw else None
 
     def read_list(self, dev_ptr, n, key_words=1):
