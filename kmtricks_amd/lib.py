@@ -322,18 +322,18 @@ class Context:
         sp = (_vp * len(stores))(*[s._h for s in stores])
         lists, nk = (KmxList * nb_parts)(), (C.c_uint64 * nb_parts)()
         rw, tabs = None, None
-        sp = None
+        spt = None
         if raw:
             tabs = (np.zeros(nb_parts * 1280, np.uint32), np.zeros(4 ** m, np.uint32), np.zeros(4 ** m, np.uint32))
             rw = KmxSuperkRaw(tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data, 0, None, 0, 0)
             if sparse:      # the per-minimizer records as {minimizer, super-k-mers, k-mers} triples: turned back into the tables here
-                sp = np.zeros((4 ** m, 3), np.uint32)
-                rw = KmxSuperkRaw(tabs[0].ctypes.data, None, None, 0, sp.ctypes.data, 4 ** m, 0)
+                spt = np.zeros((4 ** m, 3), np.uint32)
+                rw = KmxSuperkRaw(tabs[0].ctypes.data, None, None, 0, spt.ctypes.data, 4 ** m, 0)
         self._check(_lib.kmx_count_reads_dev(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
                                              1 if window else 0, window, hard_min, sp, len(stores), lists, nk, None, None, None, None,
                                              C.byref(rw) if raw else None), "kmx_count_reads_dev")
-        if sp is not None:
-            t = sp[:int(rw.minim_sparse_n)]
+        if spt is not None:
+            t = spt[:int(rw.minim_sparse_n)]
             assert len(np.unique(t[:, 0])) == len(t)
             tabs[1][t[:, 0]] = t[:, 1]; tabs[2][t[:, 0]] = t[:, 2]
         return [(lists[p].recs, int(lists[p].n)) for p in range(nb_parts)], [int(x) for x in nk], (tabs + (int(rw.nb_superk),)) if raw else None
