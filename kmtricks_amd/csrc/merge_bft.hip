@@ -191,10 +191,16 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
             if (nresc) { atomicAdd(&T.stats[1 * (u64)N + li], (u64)nresc); atomicAdd(&T.stats[5 * (u64)N + li], tresc); }
           }
         }
-        bt_barrier();
-        // out: sample s = col0 + j gets bytes [(tlo - lower) / 8, ...) of its row -- a wave per sample, 8 bytes per lane
+        // (round 3) A sample's image row is written by the 16 lanes that walk the sample -- lanes of ONE wave: the wave's own rows
+        // (64 / BT_G samples of the block) need no workgroup barrier between the walk and the way out, only the wave's own LDS
+        // operations in order.  The waves drift apart over a tile's blocks instead of meeting twice per block (158 barriers per
+        // tile before), and a wave that drew long lists no longer holds the other seven.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // out: sample s = col0 + j gets bytes [(tlo - lower) / 8, ...) of its row -- the wave writes its samples' rows, 8 bytes per lane
         const u32 nby = (u32)((min(tlo + (u64)BT_RT, T.lower + W8) - tlo) >> 3);      // (the last tile carries the pad bits of ceil8(W))
-        for (u32 j = wave; j < nrows_out; j += BT_TPB / 64) {
+        constexpr u32 SPW = 64 / BT_G;                                                  // samples per wave
+        for (u32 j = wave * SPW; j < min(nrows_out, (wave + 1) * SPW); j++) {
           u8* dst = T.out + (u64)(col0 + j) * (W8 >> 3) + ((tlo - T.lower) >> 3);
           const u32* src = img + j * BT_RW;
           if ((W8 & 63u) == 0) {
@@ -203,13 +209,15 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
             for (u32 t = lane; t < nby; t += 64) dst[t] = (u8)(src[t >> 2] >> ((t & 3u) * 8));
           }
         }
-        // the image is zero again for the next block: a wave clears the rows it has just read (the padding rows of the last block too)
-        for (u32 j = wave; j < (u32)BT_NB; j += BT_TPB / 64) {
+        // the wave's rows are zero again for its next block (the padding rows of the last block too)
+        for (u32 j = wave * SPW; j < (wave + 1) * SPW; j++) {
           uint4* const z = reinterpret_cast<uint4*>(img + j * BT_RW);
           for (u32 t = (u32)lane; t < (u32)BT_RW / 4; t += 64) z[t] = make_uint4(0, 0, 0, 0);
         }
-        bt_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
       }
+      bt_barrier();      // (every wave is through the tile: the cursors below, and the recurrences of the next tile, are the workgroup's)
       for (u32 i = tid; i < N; i += BT_TPB) cur[i] = nxt[i];
       bt_barrier();
     }
