@@ -106,6 +106,9 @@ struct kmx_ctx {
   // times, [257] = the sum of those counts.  Every count call adds to it while it is on.
   unsigned long long* d_hist = nullptr;
   bool hist_on = false;
+  // the minimizer -> partition table of the split stays on the device between calls: a sample after a sample hands the same table
+  // (2 MB at m = 10) -- re-uploaded only when its address, size or digest (every entry folded: kmx_rep_digest) changes
+  kmx::u16* d_rep = nullptr; const void* rep_host = nullptr; size_t rep_n = 0; kmx::u64 rep_digest = 0;
 
   void* dalloc(size_t bytes);
   void dfree(void* p);

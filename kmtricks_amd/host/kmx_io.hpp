@@ -30,6 +30,13 @@ const char* LZ4F_getErrorName(size_t code);
 size_t LZ4F_createDecompressionContext(LZ4F_dctx** dctx, unsigned version);
 size_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx);
 size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dst, size_t* dstSize, const void* src, size_t* srcSize, const void* options);
+typedef struct LZ4F_cctx_s LZ4F_cctx;
+size_t LZ4F_createCompressionContext(LZ4F_cctx** cctx, unsigned version);
+size_t LZ4F_freeCompressionContext(LZ4F_cctx* cctx);
+size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const void* preferences);
+size_t LZ4F_compressBound(size_t srcSize, const void* preferences);
+size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* options);
+size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dst, size_t dstCapacity, const void* options);
 }
 #define KMX_LZ4F_VERSION 100
 
@@ -70,8 +77,9 @@ inline std::vector<uint8_t> lz4_decompress(const uint8_t* src, size_t n, const s
   return out;
 }
 
-// A kmtricks file being written: raw header (first layer), then the body -- streamed as is, or gathered and
-// written as one lz4 frame when the file is compressed.
+// A kmtricks file being written: raw header (first layer), then the body -- streamed as is, or, when the file is compressed, as
+// ONE lz4 frame fed piece by piece (LZ4F_compressBegin / Update / End with bounded buffers, as the reference's lz4 stream feeds 8 KB
+// blocks into its frame, io/lz4_stream.hpp:89-159): nothing the size of the body is ever held.
 class Out {
  public:
   explicit Out(const std::string& path) : f_(fopen(path.c_str(), "wb")), path_(path) {
@@ -79,23 +87,47 @@ class Out {
     setvbuf(f_, nullptr, _IOFBF, 1 << 20);
   }
   Out(const Out&) = delete;
-  ~Out() { try { close(); } catch (...) {} }
+  ~Out() { try { close(); } catch (...) {} if (cctx_) LZ4F_freeCompressionContext(cctx_); }
   template <typename T> void put(T v) { raw(&v, sizeof(T)); }
   void raw(const void* p, size_t n) {
     if (!n) return;
-    if (cpr_) { const uint8_t* b = (const uint8_t*)p; body_.insert(body_.end(), b, b + n); return; }
+    if (cpr_) {
+      const uint8_t* b = (const uint8_t*)p;
+      while (n) {      // pieces of at most 4 MB into the frame
+        const size_t m = std::min<size_t>(n, PIECE);
+        const size_t r = LZ4F_compressUpdate(cctx_, zbuf_.data(), zbuf_.size(), b, m, nullptr);
+        if (LZ4F_isError(r)) throw IoError(std::string("lz4 compression failed: ") + LZ4F_getErrorName(r));
+        if (r && fwrite(zbuf_.data(), 1, r, f_) != r) throw IoError("write failed: " + path_);
+        b += m; n -= m;
+      }
+      return;
+    }
     if (fwrite(p, 1, n, f_) != n) throw IoError("write failed: " + path_);
   }
   void base_header(bool compressed = false) { put<uint64_t>(MAGIC_BASE); put<uint32_t>(0); put<uint8_t>(compressed ? 1 : 0); hdr_cpr_ = compressed; }
-  void begin_body() { cpr_ = hdr_cpr_; }          // everything after this call is body
+  void begin_body() {          // everything after this call is body
+    if (!hdr_cpr_ || cpr_) return;
+    if (LZ4F_isError(LZ4F_createCompressionContext(&cctx_, KMX_LZ4F_VERSION))) throw IoError("lz4: no compression context");
+    zbuf_.resize(std::max<size_t>(LZ4F_compressBound(PIECE, nullptr), 64) + 64);
+    const size_t r = LZ4F_compressBegin(cctx_, zbuf_.data(), zbuf_.size(), nullptr);
+    if (LZ4F_isError(r)) throw IoError(std::string("lz4 compression failed: ") + LZ4F_getErrorName(r));
+    if (fwrite(zbuf_.data(), 1, r, f_) != r) throw IoError("write failed: " + path_);
+    cpr_ = true;
+  }
   void close() {
     if (!f_) return;
-    if (cpr_) { cpr_ = false; const auto z = lz4_compress(body_.data(), body_.size()); if (fwrite(z.data(), 1, z.size(), f_) != z.size()) throw IoError("write failed: " + path_); }
+    if (cpr_) {
+      cpr_ = false;
+      const size_t r = LZ4F_compressEnd(cctx_, zbuf_.data(), zbuf_.size(), nullptr);
+      if (LZ4F_isError(r)) throw IoError(std::string("lz4 compression failed: ") + LZ4F_getErrorName(r));
+      if (fwrite(zbuf_.data(), 1, r, f_) != r) throw IoError("write failed: " + path_);
+    }
     if (fclose(f_) != 0) { f_ = nullptr; throw IoError("write failed: " + path_); }
     f_ = nullptr;
   }
  private:
-  FILE* f_; std::string path_; bool hdr_cpr_ = false, cpr_ = false; std::vector<uint8_t> body_;
+  static constexpr size_t PIECE = (size_t)4 << 20;
+  FILE* f_; std::string path_; bool hdr_cpr_ = false, cpr_ = false; LZ4F_cctx* cctx_ = nullptr; std::vector<uint8_t> zbuf_;
 };
 
 inline std::vector<uint8_t> slurp(const std::string& path) {

@@ -800,6 +800,7 @@ int run(int argc, char** argv)
         B.io_s = since(t);
       };
       struct Flight { kmx_merge_result* R = nullptr; Batch B; std::vector<kmx_merge_task> tasks; };
+      std::atomic<uint64_t> pending_bytes{0};
       std::deque<std::future<void>> writes;
       double w_io = 0, w_merge = 0, w_format = 0;
       // output of a finished batch: bodies + statistics back, files written on the pool
@@ -941,7 +942,9 @@ int run(int argc, char** argv)
             body = img;
             plugin_done = true;
           }
-          writes.push_back(pool.submit([=, &o, &plug, &samples, &hw, &tm, &s_format, &res_flag]() {
+          pending_bytes += body->size();
+          writes.push_back(pool.submit([=, &o, &plug, &samples, &hw, &tm, &s_format, &res_flag, &pending_bytes]() {
+            struct Done { std::atomic<uint64_t>& p; uint64_t n; ~Done() { p -= n; } } done_{pending_bytes, (uint64_t)body->size()};
             try {
               const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
               const bool lz4_name = o.cpr && !hash_mode && !is_bloom;                       // hash-mode matrices never get the suffix (task.hpp:794-795)
@@ -998,7 +1001,8 @@ int run(int argc, char** argv)
         }
         kmx_result_free(F.R); F.R = nullptr;
         w_io += since(t);
-        while (writes.size() > 128) { writes.front().get(); writes.pop_front(); }
+        // (bodies handed to the pool whole -- plugin, lz4, per-sample filters -- are bounded in BYTES: at most ~8 GB wait to be written)
+        while (!writes.empty() && (writes.size() > 512 || pending_bytes.load() > ((uint64_t)8 << 30))) { writes.front().get(); writes.pop_front(); }
       };
       Batch next; std::future<void> fut;
       auto start_load = [&](size_t bi) { next = Batch(); fut = std::async(std::launch::async, [&, bi]() { load(bi, next); }); };
