@@ -71,9 +71,14 @@ int  kmx_create(int device, kmx_ctx** out);
 void kmx_destroy(kmx_ctx* ctx);
 /* last error message of this ctx (or of the failed kmx_create when ctx == NULL) */
 const char* kmx_last_error(const kmx_ctx* ctx);
-/* When on, the merge driver brackets its dominant kernel (k_merge_cols / k_merge_pivot / k_merge_rows /
- * k_merge_bf, whichever the batch runs) with HIP events on the ctx stream so that bench.py can report
- * the kernel's launch duration. */
+/* When on, the merge driver brackets its dominant kernel with HIP events on the ctx stream so that bench.py can report
+ * the kernel's launch duration.  Which kernel a batch runs (libkmx chooses; KMX_MERGE_KERNEL=rows|pivot|cols forces one):
+ *   COUNT / PA   k_merge_cols + k_cols_sparse  every task has >= 192 lists, recurrence-min <= 21, share-min <= max(1,
+ *                                              recurrence-min), >= 1 M records in the batch; 64- and 128-bit keys
+ *                k_merge_pivot                 otherwise, tasks of more than 512 lists, 64-bit keys, no share-min
+ *                k_merge_rows                  everything else -- and the tasks the two above hand back (lists that do not
+ *                                              resemble each other): results never depend on the choice
+ *   BF / BFC     k_merge_bf;   BFT  k_merge_bft */
 int  kmx_set_profiling(kmx_ctx* ctx, int on);
 /* HIP stream the ctx launches on (a hipStream_t), so callers can order their own work after it */
 void* kmx_stream(kmx_ctx* ctx);
@@ -124,8 +129,9 @@ int      kmx_result_wait(kmx_merge_result* r);
 /* duration in ms of the batch's merge kernel launch (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
 double   kmx_result_kernel_ms(kmx_merge_result* r);
 /* name of the device kernel that produced (most of) the result: "k_merge_cols", "k_merge_pivot", "k_merge_rows",
- * "k_merge_bf" or "k_merge_bft"; valid after kmx_result_wait (tasks a cohort kernel handed back count for the kernel that
- * completed them) */
+ * "k_merge_bf" or "k_merge_bft" (see kmx_set_profiling for when each is chosen); valid after kmx_result_wait (tasks a cohort
+ * kernel handed back count for the kernel that completed them) */
+const char* kmx_result_kernel(const kmx_merge_result* r);
 /* duration in ms of a separate transpose pass behind the merge; < 0 when there is none (KMX_MODE_BFT results come out
  * of k_merge_bft sample-major already: kmx_result_kernel_ms covers k_bf_rowrec + k_merge_bft) */
 double   kmx_result_transpose_ms(kmx_merge_result* r);
@@ -134,7 +140,6 @@ double   kmx_result_transpose_ms(kmx_merge_result* r);
  * the body is asked for (rows of k_merge_rows / k_merge_pivot lie in arena segments, those of k_merge_cols in two ascending
  * lists): a caller can then bring it to the host in pieces (kmx_copy_to_host) or send it from where it lies. */
 const void* kmx_result_body_dev(kmx_merge_result* r, uint32_t task);
-const char* kmx_result_kernel(const kmx_merge_result* r);
 uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA), window rows (BF/BFC), round_up8(N) (BFT) */
 /* COUNT/PA results of k_merge_cols: how many of the task's rows came out of k_cols_sparse (keys outside the row keys the
  * column blocks are built on: sample-private k-mers, k-mers a few samples share); 0 for the other kernels */

@@ -139,7 +139,8 @@ static Opt parse_cli(int argc, char** argv)
   }
   if (o.fof.empty() || o.dir.empty()) die("--file and --run-dir are required");
   if (fs::exists(o.dir)) die("--run-dir already exists: " + o.dir);                  // src/cli.cpp:101-104
-  if (o.k < 8 || o.k > 63) die("--kmer-size must be in [8, 63] for this build");
+  if (o.k < 8 || o.k > 63) die("--kmer-size must be in [8, 63]: this build is the reference built with KMER_LIST=\"32 64\" (keys of one or two 64-bit words; "
+                                "the reference's default list also has 96 and 128, loop_executor.hpp:47-63)");
   if (o.msize < 4 || o.msize > 15 || o.msize >= o.k) die("--minimizer-size must be in [4, 15] and < k");
   static const char* modes[] = {"kmer:count:bin", "kmer:pa:bin", "hash:count:bin", "hash:pa:bin", "hash:bf:bin", "hash:bfc:bin", "hash:bft:bin"};
   if (std::find_if(std::begin(modes), std::end(modes), [&](const char* m) { return o.mode == m; }) == std::end(modes))
