@@ -375,6 +375,27 @@ def test_sample_in_several_read_batches(inputs, tmp_path, mode):
     assert checked > 30
 
 
+def test_restricted_run_statistics_cover_every_partition(inputs, tmp_path):
+    """--restrict-to-list: the split counts EVERY partition (KmFillPartitions feeds PartiInfo before the writer drops the
+    super-k-mers of unselected partitions, fill_partitions.hpp:59-105, io/superk_storage.hpp:301), so <id>.pinfo and PartiInfoFile
+    are the full run's -- whichever way the sample reached the GPU: in one batch with its counts left in HBM, in one batch through
+    count files, or in several read batches."""
+    full = run(inputs, tmp_path / "full", "--mode", "kmer:count:bin", "--keep-tmp")
+    variants = {"resident": ([], {}), "files": (["--keep-tmp"], {}), "batches": (["--keep-tmp"], {"KMX_READ_BATCH_BYTES": "3000"})}
+    for name, (flags, env) in variants.items():
+        cmd = [KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / name), "--kmer-size", "31", "--hard-min", "1",
+               "--nb-partitions", "4", "--repart-file", str(inputs / "fixture.minimRepart"), "--mode", "kmer:count:bin", "--restrict-to-list", "1,3"] + flags
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        out = tmp_path / name
+        assert sorted(os.listdir(out / "matrices")) == ["matrix_1.count", "matrix_3.count"]
+        for s_ in ("D1", "D2"):
+            assert open(out / "partition_infos" / f"{s_}.pinfo").read() == open(full / "partition_infos" / f"{s_}.pinfo").read(), (name, s_)
+            assert open(out / "superkmers" / s_ / "PartiInfoFile").read() == open(full / "superkmers" / s_ / "PartiInfoFile").read(), (name, s_)
+        for p in (1, 3):
+            assert open(out / "matrices" / f"matrix_{p}.count", "rb").read() == open(full / "matrices" / f"matrix_{p}.count", "rb").read()
+
+
 def test_parti_info_file(inputs, tmp_path):
     """superkmers/<id>/PartiInfoFile (gatb PartiInfo.hpp:266-287) from the HIP split's statistics == the oracle's PartiInfo<5>"""
     out = run(inputs, tmp_path / "run", "--mode", "kmer:count:bin", "--until", "superk")
