@@ -140,6 +140,9 @@ double   kmx_result_transpose_ms(kmx_merge_result* r);
  * the body is asked for (rows of k_merge_rows / k_merge_pivot lie in arena segments, those of k_merge_cols in two ascending
  * lists): a caller can then bring it to the host in pieces (kmx_copy_to_host) or send it from where it lies. */
 const void* kmx_result_body_dev(kmx_merge_result* r, uint32_t task);
+/* queues that ordering for a COUNT / PA task without waiting for it (a writer asks for task i + 1 before it brings task i's body
+ * over: the pass hides behind the copies); kmx_result_body_dev / kmx_result_copy_body wait for it.  No-op for Bloom results. */
+int kmx_result_prepare_body(kmx_merge_result* r, uint32_t task);
 uint64_t kmx_result_rows(const kmx_merge_result* r, uint32_t task);        /* kept rows (COUNT/PA), window rows (BF/BFC), round_up8(N) (BFT) */
 /* COUNT/PA results of k_merge_cols: how many of the task's rows came out of k_cols_sparse (keys outside the row keys the
  * column blocks are built on: sample-private k-mers, k-mers a few samples share); 0 for the other kernels */

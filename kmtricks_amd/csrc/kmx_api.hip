@@ -220,6 +220,8 @@ struct TaskHost {
   u64 sparse_rows = 0;          // rows k_cols_sparse added behind the row keys' rows
   u8* d_body = nullptr;         // COUNT/PA: the body assembled in file order on the device (kmx_result_body_dev), when it is not d_out itself
   bool body_ready = false;
+  hipEvent_t ev_body = nullptr; // ... queued on the assembly stream by kmx_result_prepare_body: body_dev waits for it
+  void* d_body_tmp = nullptr;   // ... its scratch (group offsets / segment copies), freed with the result
   std::vector<u32> src;         // (row-key merge of a task: which of the task's lists it merges)
   int kernel = 0;               // the kernel that completed (or is to complete) the task: 0 rows, 1 pivot, 2 cols
 };
@@ -965,11 +967,30 @@ __global__ __launch_bounds__(256) void k_segs_gather(const SegCopy* __restrict__
 
 // the body of a COUNT/PA task in file order, on the device: d_out itself when the rows already lie that way (one segment from
 // row 0: k_merge_cols without rows outside the row keys), else assembled once into d_body (k_cols_gather / k_segs_gather)
-static int assemble_body(kmx_merge_result* R, uint32_t t)
+static int assemble_body(kmx_merge_result* R, uint32_t t, bool async = false)
 {
   kmx_ctx* ctx = R->ctx;
   TaskHost& H = R->tasks[t];
+  if (H.ev_body) {      // queued earlier (kmx_result_prepare_body): wait for it
+    if (async) return KMX_OK;
+    KMX_HIP(ctx, hipEventSynchronize(H.ev_body));
+    (void)hipEventDestroy(H.ev_body); H.ev_body = nullptr;
+    ctx->dfree(H.d_body_tmp); H.d_body_tmp = nullptr;
+    H.body_ready = true;
+    return KMX_OK;
+  }
   if (H.body_ready) return KMX_OK;
+  // (the assembly runs on the context's second stream -- not the copy stream, where the caller's device-to-host pieces of the
+  //  PREVIOUS task's body are queued: queued ahead of time it hides behind them)
+  hipStream_t as = async ? ctx->aux : ctx->copy;
+  auto finish = [&](u8* d_body, void* tmp) -> int {
+    if (!async) { hipError_t e = hipStreamSynchronize(as); ctx->dfree(tmp); if (e != hipSuccess) { ctx->dfree(d_body); return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); } H.d_body = d_body; H.body_ready = true; return KMX_OK; }
+    hipError_t e = hipEventCreateWithFlags(&H.ev_body, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(H.ev_body, as);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(as); ctx->dfree(tmp); ctx->dfree(d_body); if (H.ev_body) { (void)hipEventDestroy(H.ev_body); H.ev_body = nullptr; } return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); }
+    H.d_body = d_body; H.d_body_tmp = tmp;
+    return KMX_OK;
+  };
   const u64 body = H.rows * H.row_bytes;
   if (body == 0) { H.body_ready = true; return KMX_OK; }
   KMX_HIP(ctx, hipSetDevice(ctx->device));
@@ -981,13 +1002,10 @@ static int assemble_body(kmx_merge_result* R, uint32_t t)
     if (!d_body || !d_goff) { ctx->dfree(d_body); ctx->dfree(d_goff); return ctx->fail(KMX_E_NOMEM, "body assembly allocation failed"); }
     const TaskDev* d_tasks = reinterpret_cast<const TaskDev*>(R->d_meta + R->o_tasks);
     const ColsDev* d_cols = reinterpret_cast<const ColsDev*>(R->d_meta + R->o_cols);
-    hipError_t e = CO.offsets(d_cols, t, d_goff, ctx->copy);
-    if (e == hipSuccess) e = CO.gather(d_tasks, d_cols, t, ng, d_goff, d_body, ctx->copy);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy);
-    ctx->dfree(d_goff);
-    if (e != hipSuccess) { ctx->dfree(d_body); return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); }
-    H.d_body = d_body; H.body_ready = true;
-    return KMX_OK;
+    hipError_t e = CO.offsets(d_cols, t, d_goff, as);
+    if (e == hipSuccess) e = CO.gather(d_tasks, d_cols, t, ng, d_goff, d_body, as);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(as); ctx->dfree(d_goff); ctx->dfree(d_body); return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); }
+    return finish(d_body, d_goff);
   }
   std::vector<Seg> segs(H.nsegs);
   KMX_HIP(ctx, hipMemcpyAsync(segs.data(), H.d_segs, sizeof(Seg) * H.nsegs, hipMemcpyDeviceToHost, ctx->copy));
@@ -1008,12 +1026,19 @@ static int assemble_body(kmx_merge_result* R, uint32_t t)
   SegCopy* d_sc = (SegCopy*)ctx->dalloc(sc.size() * sizeof(SegCopy));
   if (!d_body || !d_sc) { ctx->dfree(d_body); ctx->dfree(d_sc); return ctx->fail(KMX_E_NOMEM, "body assembly allocation failed"); }
   hipError_t e = hipMemcpyAsync(d_sc, sc.data(), sc.size() * sizeof(SegCopy), hipMemcpyHostToDevice, ctx->copy);
-  if (e == hipSuccess) { hipLaunchKernelGGL(k_segs_gather, dim3((unsigned)sc.size()), dim3(256), 0, ctx->copy, d_sc, H.d_out, d_body); e = hipGetLastError(); }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy);
-  ctx->dfree(d_sc);
-  if (e != hipSuccess) { ctx->dfree(d_body); return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); }
-  H.d_body = d_body; H.body_ready = true;
-  return KMX_OK;
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy);      // (sc is this frame's)
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_segs_gather, dim3((unsigned)sc.size()), dim3(256), 0, as, d_sc, H.d_out, d_body); e = hipGetLastError(); }
+  if (e != hipSuccess) { (void)hipStreamSynchronize(as); ctx->dfree(d_sc); ctx->dfree(d_body); return ctx->fail(KMX_E_HIP, std::string("body assembly: ") + hipGetErrorString(e)); }
+  return finish(d_body, d_sc);
+}
+
+// queue the assembly of a COUNT/PA body without waiting for it (kmx_result_body_dev / kmx_result_copy_body then do)
+extern "C" int kmx_result_prepare_body(kmx_merge_result* R, uint32_t t)
+{
+  if (!R || t >= R->tasks.size()) return KMX_E_INVAL;
+  int rc = kmx_result_wait(R);
+  if (rc != KMX_OK || R->is_bf) return rc;
+  return assemble_body(R, t, true);
 }
 
 // ---- COUNT/PA rows where the kernels left them + their order: what a consumer takes that puts the rows in place itself (a file
@@ -1170,7 +1195,10 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   const ColsOps& CO = cols_ops((int)R->tasks[0].kw);
   if (!R->is_bf) { if (R->use_cols) { if (CO.phase_prof_dump) CO.phase_prof_dump(); } else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
-  for (auto& H : R->tasks) { ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); ctx->dfree(H.d_body); }
+  for (auto& H : R->tasks) {
+    if (H.ev_body) { (void)hipEventSynchronize(H.ev_body); (void)hipEventDestroy(H.ev_body); }
+    ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); ctx->dfree(H.d_body); ctx->dfree(H.d_body_tmp);
+  }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);

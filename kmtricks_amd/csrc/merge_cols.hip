@@ -1250,7 +1250,16 @@ void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     }
     const u8* s = src_row(i);
     u8* d = dst0 + (u64)rank * row_bytes;
-    if ((row_bytes & 3u) == 0) for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(d)[t] = reinterpret_cast<const u32*>(s)[t];
+    if ((row_bytes & 7u) == 0) {      // (count rows of an even number of lists: 8-byte pieces, four loads in flight per lane)
+      const u32 n8 = row_bytes / 8;
+      for (u32 t0 = 0; t0 < n8; t0 += 256) {
+        u64 w[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; w[x] = t < n8 ? reinterpret_cast<const u64*>(s)[t] : 0ULL; }
+#pragma unroll
+        for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; if (t < n8) reinterpret_cast<u64*>(d)[t] = w[x]; }
+      }
+    } else if ((row_bytes & 3u) == 0) for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(d)[t] = reinterpret_cast<const u32*>(s)[t];
     else for (u32 t = lane; t < row_bytes; t += 64) d[t] = s[t];
   }
 }

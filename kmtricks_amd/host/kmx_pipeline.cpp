@@ -837,6 +837,7 @@ int run(int argc, char** argv)
             // the merge stage, the price of ~10^6 small pwrites instead of 600 large ones.
             static const bool by_order = getenv("KMX_OUT_ORDER") != nullptr;
             if (nbytes && (is_bloom || !by_order)) {      // a dense image: pieces of it straight to their place in the file
+              if (!is_bloom && a + 1 < F.B.parts.size()) chk(c, kmx_result_prepare_body(F.R, (uint32_t)a + 1), "kmx_result_prepare_body");      // (the next task's ordering pass runs behind this task's copies)
               const uint8_t* dbody = (const uint8_t*)kmx_result_body_dev(F.R, (uint32_t)a);
               if (!dbody) die(std::string("kmx_result_body_dev: ") + kmx_last_error(c));
               const int fd = open(path.c_str(), O_WRONLY); if (fd < 0) die("Unable to write at " + path);
