@@ -265,6 +265,8 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
         res = ctx.merge_dev(tasks); res.wait()
         sync()
         tg = time.perf_counter()
+        for t in range(P):      # (queued for every task first, as a writer does: the passes run back to back)
+            ctx._check(lib._lib.kmx_result_prepare_body(res._h, t), "kmx_result_prepare_body")
         for t in range(P):
             res.body_dev(t)
         sync()

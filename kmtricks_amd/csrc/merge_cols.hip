@@ -1195,7 +1195,7 @@ void k_cols_offsets(const ColsDev* __restrict__ cols, u32 task, u64* __restrict_
   for (u32 g = tid * per; g < min(ng, (tid + 1) * per); g++) { goff[g] = a; a += dir[(u64)g * CK_NPASS].dense_n; for (int p = 0; p < CK_NPASS; p++) a += dir[(u64)g * CK_NPASS + p].n; }
 }
 
-constexpr int GA_TPB = 256;
+constexpr int GA_TPB = 512;
 constexpr int GA_KEYS = 4096 / KW;      // keys of a group held in LDS (more: ranks come from global memory)
 // COPY: the rows go to their places in `body`.  !COPY: only the ORDER is written -- order[d] = the arena row that is row d of the body
 // (body then points at a u32 array): a consumer that writes the rows to a file anyway puts them in order there (pwrite at d * row
@@ -1239,7 +1239,10 @@ void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     return;
   }
   u8* const dst0 = body + goff[blockIdx.x] * row_bytes;
-  for (u32 i = wave; i < n; i += GA_TPB / 64) {      // a wave per row: its rank = keys below it in every list
+  // (round 3) the ranks of the group's rows first, a THREAD per row (round 2: every lane of a wave repeated its row's binary searches),
+  // kept in LDS for the rows whose keys are there; then the rows are copied, a wave per row
+  __shared__ u32 rnk[GA_KEYS];
+  auto rank_of = [&](u32 i) -> u32 {
     const CKey k = key_at(i);
     u32 rank = 0;
     for (int l = 0; l <= CK_NPASS; l++) {
@@ -1248,16 +1251,22 @@ void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       while (a < b) { const u32 m = (a + b) >> 1; if (ck_lt(key_at(m), k)) a = m + 1; else b = m; }
       rank += a - lo[l];
     }
+    return rank;
+  };
+  for (u32 i = tid; i < min(n, (u32)GA_KEYS); i += GA_TPB) rnk[i] = rank_of(i);
+  __syncthreads();
+  for (u32 i = wave; i < n; i += GA_TPB / 64) {
+    const u32 rank = i < (u32)GA_KEYS ? rnk[i] : rank_of(i);
     const u8* s = src_row(i);
     u8* d = dst0 + (u64)rank * row_bytes;
     if ((row_bytes & 7u) == 0) {      // (count rows of an even number of lists: 8-byte pieces, four loads in flight per lane)
       const u32 n8 = row_bytes / 8;
-      for (u32 t0 = 0; t0 < n8; t0 += 256) {
-        u64 w[4];
+      for (u32 t0 = 0; t0 < n8; t0 += 512) {      // (a row of 1000 counts is 501 words: all of it requested before the first store)
+        u64 w[8];
 #pragma unroll
-        for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; w[x] = t < n8 ? reinterpret_cast<const u64*>(s)[t] : 0ULL; }
+        for (int x = 0; x < 8; x++) { const u32 t = t0 + 64 * x + lane; w[x] = t < n8 ? reinterpret_cast<const u64*>(s)[t] : 0ULL; }
 #pragma unroll
-        for (int x = 0; x < 4; x++) { const u32 t = t0 + 64 * x + lane; if (t < n8) reinterpret_cast<u64*>(d)[t] = w[x]; }
+        for (int x = 0; x < 8; x++) { const u32 t = t0 + 64 * x + lane; if (t < n8) reinterpret_cast<u64*>(d)[t] = w[x]; }
       }
     } else if ((row_bytes & 3u) == 0) for (u32 t = lane; t < row_bytes / 4; t += 64) reinterpret_cast<u32*>(d)[t] = reinterpret_cast<const u32*>(s)[t];
     else for (u32 t = lane; t < row_bytes; t += 64) d[t] = s[t];
