@@ -109,7 +109,7 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
     const u32 j = g - (u32)(pe >> 32);
     const u8* p = recs + (u32)pe + 1;                  // behind the record's length byte
     const u32 r = r0 + lo;
-    const u64 part = HASH ? part_ids[rec_part[r]] : 0;
+    const u64 part = HASH ? (part_ids ? part_ids[rec_part[r]] : (u64)rec_part[r]) : 0;      // (no table: the partition's index is its id)
     const u32 eb = (u32)k >> 2, es = ((u32)k & 3u) * 2;   // the following nucleotides start at digit k: byte eb, bit es
     if (KW == 1) {
       const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
@@ -344,6 +344,55 @@ static int pack_to_stores(kmx_ctx* ctx, const KeyT* d_k, const u32* d_c, const s
   return rc;
 }
 
+// the same from the partition-local count: the kept pairs of every bucket still lie in the bucket's own place (d_tk / d_tc at
+// boff[b]); one kernel writes them as records where they belong -- straight into the store when one GPU holds everything
+template <typename KeyT>
+static int compact_to_stores(kmx_ctx* ctx, const KeyT* d_tk, const u32* d_tc, const u32* d_boff, const u32* d_koff, const u32* koff /* host, TB + 1 */,
+                             const std::vector<CsPart>& parts, u32 TB, const CountOut& out)
+{
+  const u32 n_parts = (u32)parts.size(), kept = koff[TB], G = out.n_stores;
+  const size_t RB = sizeof(KeyT) + 4;
+  auto plen = [&](u32 p) { return koff[parts[p].bucket0 + parts[p].nb] - koff[parts[p].bucket0]; };
+  for (u32 p = 0; p < n_parts; p++) { out.lists[p].recs = nullptr; out.lists[p].n = plen(p); }
+  if (!kept) return KMX_OK;
+  std::vector<u64> pdst(n_parts), doff((size_t)G + 1, 0);
+  { u64 at = 0; for (u32 d = 0; d < G; d++) { doff[d] = at; for (u32 p = d; p < n_parts; p += G) { pdst[p] = at; at += plen(p); } } doff[G] = at; }
+  hipStream_t st = ctx->stream;
+  const bool direct = G == 1 && out.stores[0]->device == ctx->device;      // one GPU: packed straight into the store
+  u8* d_pack = direct ? (u8*)out.stores[0]->alloc((size_t)kept * RB) : (u8*)ctx->dalloc((size_t)kept * RB);
+  // where bucket b's records go: with one store the partitions lie in their own order (= the kept offsets, already on the device)
+  u32* d_bdst = G > 1 ? (u32*)ctx->dalloc((size_t)TB * 4) : nullptr;
+  u32* h_bdst = G > 1 ? (u32*)ctx->halloc((size_t)TB * 4) : nullptr;
+  auto release = [&]() { if (!direct) ctx->dfree(d_pack); ctx->dfree(d_bdst); ctx->hfree(h_bdst); };
+  if (!d_pack || (G > 1 && (!d_bdst || !h_bdst))) { release(); return ctx->fail(KMX_E_NOMEM, direct && !d_pack ? "count store is full" : "count: device allocation failed"); }
+  hipError_t e;
+  if (G > 1) {
+    for (u32 p = 0; p < n_parts; p++) for (u32 b = parts[p].bucket0; b < parts[p].bucket0 + parts[p].nb; b++) h_bdst[b] = (u32)(pdst[p] + (koff[b] - koff[parts[p].bucket0]));
+    if ((e = hipMemcpyAsync(d_bdst, h_bdst, (size_t)TB * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count pack upload: ") + hipGetErrorString(e)); }
+  }
+  hipLaunchKernelGGL((k_cs_compact_recs<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_tk, d_tc, d_boff, d_koff, G > 1 ? (const u32*)d_bdst : d_koff, d_pack);
+  if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_cs_compact_recs: ") + hipGetErrorString(e)); }
+  int rc = KMX_OK;
+  for (u32 d = 0; d < G && rc == KMX_OK; d++) {
+    const size_t nb = (size_t)(doff[d + 1] - doff[d]) * RB;
+    if (!nb) continue;
+    u8* dst = d_pack;
+    if (!direct) {
+      kmx_store* S = out.stores[d];
+      dst = (u8*)S->alloc(nb);
+      if (!dst) { rc = ctx->fail(KMX_E_NOMEM, "count store is full"); break; }
+      // the store of another GPU is filled over xGMI (hipMemcpyPeerAsync stages through the host when the two have no peer access)
+      e = S->device == ctx->device ? hipMemcpyAsync(dst, d_pack + doff[d] * RB, nb, hipMemcpyDeviceToDevice, st)
+                                   : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
+      if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }
+    }
+    for (u32 p = d; p < n_parts; p += G) if (out.lists[p].n) out.lists[p].recs = dst + (pdst[p] - doff[d]) * RB;
+  }
+  if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == KMX_OK) rc = ctx->fail(KMX_E_HIP, std::string("count pack: ") + hipGetErrorString(e));
+  release();
+  return rc;
+}
+
 // ---- partition-local sample sort + run-length count (count_sort.hpp): keys grouped by partition in d_keys, partition p =
 //      keys [kmoff[p], kmoff[p + 1]).  Returns KMX_OK, a negative error, or 1 when a bucket would not fit the LDS (the caller
 //      then uses the library sort: d_keys is still untouched at that point). ----
@@ -390,24 +439,31 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   std::vector<void*> blocks;
   auto dal = [&](size_t b) { void* p = ctx->dalloc(b); blocks.push_back(p); return p; };
   auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
-  CsPart* d_parts = (CsPart*)dal(sizeof(CsPart) * n_parts);
-  CsChunk* d_chunks = (CsChunk*)dal(sizeof(CsChunk) * std::max<size_t>(1, chunks.size()));
+  // the two tables go up in one copy, out of one page-locked block that also takes the kept sizes on their way back
+  static_assert(sizeof(CsPart) == 16 && sizeof(CsChunk) == 16, "the tables share one block");
+  const size_t tab_bytes = sizeof(CsPart) * n_parts + sizeof(CsChunk) * chunks.size();
+  u8* h_tab = (u8*)ctx->halloc(tab_bytes + 4 * ((size_t)TB + 2));
+  struct HRel { kmx_ctx* c; void* p; ~HRel() { c->hfree(p); } } h_tab_rel{ctx, h_tab};
+  if (!h_tab) return ctx->fail(KMX_E_NOMEM, "count sort: host staging allocation failed");
+  memcpy(h_tab, parts.data(), sizeof(CsPart) * n_parts);
+  if (!chunks.empty()) memcpy(h_tab + sizeof(CsPart) * n_parts, chunks.data(), sizeof(CsChunk) * chunks.size());
+  u8* d_tab = (u8*)dal(tab_bytes + 16);
+  CsPart* d_parts = (CsPart*)d_tab;
+  CsChunk* d_chunks = (CsChunk*)(d_tab + sizeof(CsPart) * n_parts);
   KeyT* d_spl = (KeyT*)dal(sizeof(KeyT) * (size_t)TB);
   u32* d_cnt = (u32*)dal(4 * ((size_t)TB + 1)), *d_boff = (u32*)dal(4 * ((size_t)TB + 1)), *d_cur = (u32*)dal(4 * ((size_t)TB + 1));
-  u32* d_nkept = (u32*)dal(4 * ((size_t)TB + 1)), *d_koff = (u32*)dal(4 * ((size_t)TB + 1));
+  u32* d_nkept = (u32*)dal(4 * ((size_t)TB + 1)), *d_koff = (u32*)dal(4 * ((size_t)TB + 2));
   KeyT* d_bkeys = (KeyT*)dal(sizeof(KeyT) * total);
   u32* d_tc = (u32*)dal(4 * total);
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count sort: device allocation failed"); }
   auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
   hipError_t e;
-  if ((e = hipMemcpyAsync(d_parts, parts.data(), sizeof(CsPart) * n_parts, hipMemcpyHostToDevice, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(d_chunks, chunks.data(), sizeof(CsChunk) * chunks.size(), hipMemcpyHostToDevice, st)) != hipSuccess ||
-      (e = hipMemsetAsync(d_cnt, 0, 4 * ((size_t)TB + 1), st)) != hipSuccess) return fail(e, "count sort upload");
+  if ((e = hipMemcpyAsync(d_tab, h_tab, tab_bytes, hipMemcpyHostToDevice, st)) != hipSuccess ||
+      (e = hipMemsetAsync(d_cnt, 0, 4 * ((size_t)TB + 1), st)) != hipSuccess) return fail(e, "count sort upload");      // (d_cnt[TB]: the overflow word, cleared with the rest)
   (void)cap;
   hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(n_parts), dim3(CS_TPB), 0, st, d_keys, d_parts, d_spl);
   hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cnt, (KeyT*)nullptr);
-  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_cnt, TB, d_boff);
-  if ((e = hipMemcpyAsync(d_cur, d_boff, 4 * (size_t)TB, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e, "count sort cursors");
+  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_cnt, TB, d_boff, d_cur, (const u32*)nullptr);      // (d_cur: the scatter's cursors)
   hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cur, d_bkeys);
   // (a bucket beyond what the count kernel takes is found by the kernel itself and reported with the kept sizes: one round trip to
   //  the host per call, not two.  The grouped keys stay as they are until then -- the library sort needs them -- and the abundance
@@ -416,30 +472,23 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   u32* d_flag = d_cnt + TB;                // (d_cnt has TB + 1 entries; the last one is free behind the scan: the overflow word)
   unsigned long long* d_htmp = ctx->hist_on ? (unsigned long long*)dal(258 * 8) : nullptr;
   if (!d_tk || (ctx->hist_on && !d_htmp)) { release(); return ctx->fail(KMX_E_NOMEM, "count sort: device allocation failed"); }
-  if ((e = hipMemsetAsync(d_flag, 0, 4, st)) != hipSuccess || (d_htmp && (e = hipMemsetAsync(d_htmp, 0, 258 * 8, st)) != hipSuccess)) return fail(e, "count sort clear");
+  if (d_htmp && (e = hipMemsetAsync(d_htmp, 0, 258 * 8, st)) != hipSuccess) return fail(e, "count sort clear");
   cs_launch_bucket_count<KeyT>(TB, st, d_bkeys, d_boff, hard_min, d_tk, d_tc, d_nkept, d_htmp, d_flag);
-  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_nkept, TB, d_koff);
-  std::vector<u32> koff((size_t)TB + 1);
-  u32 overflow = 0;
-  if ((e = hipMemcpyAsync(koff.data(), d_koff, 4 * ((size_t)TB + 1), hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(&overflow, d_flag, 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort kept");
-  if (overflow) { release(); return 1; }      // (d_keys is untouched: the caller takes the library sort)
+  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_nkept, TB, d_koff, (u32*)nullptr, (const u32*)d_flag);      // (d_koff[TB + 1] = the overflow word)
+  const u32* koff = reinterpret_cast<const u32*>(h_tab + tab_bytes);
+  if ((e = hipMemcpyAsync(h_tab + tab_bytes, d_koff, 4 * ((size_t)TB + 2), hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count sort kept");
+  if (koff[TB + 1]) { release(); return 1; }      // (d_keys is untouched: the caller takes the library sort)
   if (d_htmp) hipLaunchKernelGGL(k_hist_add, dim3(1), dim3(258), 0, st, d_htmp, ctx->d_hist);
   clk.mark("buckets+sort+count");
   const u32 kept = koff[TB];
-  KeyT* d_ok = d_bkeys;                    // (and the buckets are dead behind the sort)
-  u32* d_oc = (u32*)dal(4 * (size_t)std::max<u32>(kept, 1));
   if (out.dev()) {      // the pairs stay on the device, packed as records in the stores of the GPUs that merge them
-    if (!d_oc) { release(); return ctx->fail(KMX_E_NOMEM, "count sort: allocation failed"); }
-    if (kept) hipLaunchKernelGGL((k_cs_compact<KeyT>), dim3(TB), dim3(CS_TPB), 0, st, d_tk, d_tc, d_boff, d_koff, d_ok, d_oc);
-    std::vector<u32> bounds((size_t)n_parts + 1);
-    for (u32 p = 0; p < n_parts; p++) bounds[p] = koff[parts[p].bucket0];
-    bounds[n_parts] = kept;
-    const int rc = pack_to_stores<KeyT>(ctx, d_ok, d_oc, bounds, n_parts, out);
+    const int rc = compact_to_stores<KeyT>(ctx, d_tk, d_tc, d_boff, d_koff, koff, parts, TB, out);
     release();
     clk.mark("pack");
     return rc;
   }
+  KeyT* d_ok = d_bkeys;                    // (and the buckets are dead behind the sort)
+  u32* d_oc = (u32*)dal(4 * (size_t)std::max<u32>(kept, 1));
   KeyT* h_k = kept ? (KeyT*)ctx->halloc((size_t)kept * sizeof(KeyT)) : nullptr;
   u32* h_c = kept ? (u32*)ctx->halloc((size_t)kept * 4) : nullptr;
   auto hrel = [&]() { ctx->hfree(h_k); ctx->hfree(h_c); };
@@ -596,20 +645,24 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
   const int kw = (k + 31) / 32;
   const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
   const u32 NB = (u32)((total + DK - 1) / DK);
-  u64* d_pid = (u64*)ctx->dalloc((size_t)n_parts * 8);
+  u64* d_pid = (u64*)ctx->dalloc(pid.empty() ? 8 : (size_t)n_parts * 8);      // (pid empty: partition p has id p, nothing to upload)
   u32* d_blk = (u32*)ctx->dalloc((size_t)NB * 4);
   void* d_keys = ctx->dalloc(total * key_bytes);
   std::vector<void*> blocks = {d_pid, d_blk, d_keys};
   auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
   hipStream_t st = ctx->stream; hipError_t e;
-  if ((e = hipMemcpyAsync(d_pid, pid.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e)); }
+  const u64* d_pid_arg = nullptr;
+  if (hash_mode && !pid.empty()) {
+    if ((e = hipMemcpyAsync(d_pid, pid.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("count upload: ") + hipGetErrorString(e)); }
+    d_pid_arg = d_pid;
+  }
   hipLaunchKernelGGL(k_decode_block_starts, dim3((nr + 255) / 256), dim3(256), 0, st, d_prefix, nr, d_blk);
   const dim3 grid(NB), block(256);
-  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<1, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
-  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_kmers<1, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
-  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<2, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
-  else hipLaunchKernelGGL((k_superk_decode_kmers<2, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid, nr, (u32)total, (int)k, window, d_keys);
+  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<1, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
+  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_kmers<1, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
+  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<2, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
+  else hipLaunchKernelGGL((k_superk_decode_kmers<2, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
   if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode_kmers: ") + hipGetErrorString(e)); }
   clk.mark("decode");
   int rc;
@@ -619,7 +672,7 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
   if (rc == 1) {
     if (!co.dev()) for (u32 p = 0; p < n_parts; p++) { free(co.keys[p]); free(co.counts[p]); co.keys[p] = nullptr; co.counts[p] = nullptr; co.n_out[p] = 0; }
     unsigned key_bits = 2 * k;
-    if (hash_mode) { u64 top = 0; for (u32 p = 0; p < n_parts; p++) top = std::max(top, pid[p]); key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * (top + 1);
+    if (hash_mode) { u64 top = pid.empty() ? (u64)n_parts - 1 : 0; for (u32 p = 0; p < n_parts && !pid.empty(); p++) top = std::max(top, pid[p]); key_bits = 64; const unsigned __int128 span = (unsigned __int128)window * (top + 1);
       if (span < ((unsigned __int128)1 << 63)) { key_bits = 1; while ((((u64)1) << key_bits) < (u64)span) key_bits++; } }
     // the partition of every k-mer: the library sort's second key
     u16* d_kpart = (u16*)ctx->dalloc(total * 2); u32* d_kmo = (u32*)ctx->dalloc(((size_t)n_parts + 1) * 4);
@@ -727,7 +780,7 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
     for (u32 p = 0; p < n_parts; p++) { if (co.dev()) { co.lists[p].recs = nullptr; co.lists[p].n = 0; } else { rq.keys[p] = (uint64_t*)malloc(8); rq.counts[p] = (uint32_t*)malloc(4); rq.n_out[p] = 0; } }
     return KMX_OK;
   }
-  std::vector<u64> pid(n_parts); for (u32 p = 0; p < n_parts; p++) pid[p] = p;
+  const std::vector<u64> pid;      // (partition p of the stream has id p)
   std::vector<u64> kmoff(part_kmer_off, part_kmer_off + n_parts + 1);
   return decode_and_count(ctx, clk, d_recs, d_prefix, d_part, nr, total, n_parts, kmoff, pid, rq.k, rq.hash_mode, rq.window, rq.hard_min, co);
 }

@@ -160,9 +160,11 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   for (int x = 0; x < CS_CHUNK / CS_TPB; x++) if (bk[x] != 0xFFFFFFFFu) out[base[bk[x]] + rk[x]] = k[x];
 }
 
-// exclusive scan of n u32 values (n <= a few 100 k): one workgroup, 1024 threads; out[n] = total
+// exclusive scan of n u32 values (n <= a few 100 k): one workgroup, 1024 threads; out[n] = total.  What the caller would otherwise
+// queue as calls of their own rides along: a second copy of out[0, n) (the scatter's cursors), and a word brought next to the
+// result (out[n + 1] = *flag: one download for both)
 __global__ __launch_bounds__(1024)
-void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out)
+void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __restrict__ out2, const u32* __restrict__ flag)
 {
   __shared__ u32 part[1024];
   const u32 tid = threadIdx.x, per = (n + 1023) / 1024;
@@ -170,10 +172,10 @@ void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out)
   for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) s += in[i];
   part[tid] = s;
   __syncthreads();
-  if (tid == 0) { u32 a = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = a; a += v; } out[n] = a; }
+  if (tid == 0) { u32 a = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = a; a += v; } out[n] = a; if (flag) out[n + 1] = *flag; }
   __syncthreads();
   u32 a = part[tid];
-  for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) { const u32 v = in[i]; out[i] = a; a += v; }
+  for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) { const u32 v = in[i]; out[i] = a; if (out2) out2[i] = a; a += v; }
 }
 
 // ---- a bucket by sorting: keys into LDS, bitonic sort, run starts by neighbour compare, run lengths = counts (n <= CsCap<K>::cap).
@@ -370,6 +372,25 @@ void k_cs_compact(const K* __restrict__ tk, const u32* __restrict__ tc, const u3
 {
   const u32 b = blockIdx.x, src = boff[b], dst = koff[b], n = koff[b + 1] - dst;
   for (u32 i = threadIdx.x; i < n; i += CS_TPB) { ok[dst + i] = tk[src + i]; oc[dst + i] = tc[src + i]; }
+}
+
+// the same, the pairs written as packed records (key words + u32 count: the body of a .kmer file with 4-byte counts) -- bucket b's
+// kept pairs become records [bdst[b], bdst[b] + kept) of `out`
+template <typename K>
+__global__ __launch_bounds__(CS_TPB)
+void k_cs_compact_recs(const K* __restrict__ tk, const u32* __restrict__ tc, const u32* __restrict__ boff, const u32* __restrict__ koff,
+                       const u32* __restrict__ bdst, u8* __restrict__ out)
+{
+  constexpr u32 KWD = sizeof(K) / 4;      // key dwords
+  const u32 b = blockIdx.x, src = boff[b], n = koff[b + 1] - koff[b];
+  const u64 dst = bdst[b];
+  for (u32 i = threadIdx.x; i < n; i += CS_TPB) {
+    u32* o = reinterpret_cast<u32*>(out + (dst + i) * (u64)(sizeof(K) + 4));
+    const K k = tk[src + i];
+#pragma unroll
+    for (u32 w = 0; w < KWD; w++) o[w] = (u32)(k >> (32 * w));
+    o[KWD] = tc[src + i];
+  }
 }
 
 }  // namespace kmx

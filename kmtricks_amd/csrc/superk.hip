@@ -77,6 +77,11 @@ __device__ __forceinline__ u32 spread16(u32 y)
 //     most 5 k-mers of one strand inside a super-k-mer -- start / end flags are ballots again --, the lane that ends
 //     one adds 1 to the (partition, run length, radix) counter, radix = top 4 nucleotides of the run's first
 //     canonical k-mer (forward run) or of its last one (reverse run).
+struct SkSort {           // what the partition sort of the descriptors takes, written with the descriptors (EMIT); all null or all set
+  u16* keys;              // [n] partition of descriptor i
+  u32* ids;               // [n] i
+  u32* sizes;             // [n] bytes of its record: 1 + ceil((k + n - 1) / 4)
+};
 struct SkStats {          // device tables, zeroed by the caller; any of them may be null
   u32* pc;                // [nb_parts][5][256] kx-mers per (partition, x, radix)
   u32* ms;                // [4^m] super-k-mers per minimizer
@@ -88,7 +93,7 @@ template <bool EMIT, bool STATS>
 __global__ __launch_bounds__(256)
 void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
                    int k, int m, int maxs, const u16* __restrict__ repart,
-                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S)
+                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so)
 {
   const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -150,7 +155,9 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
       }
       if (EMIT && endf) {
         SkDesc d; d.base = (u32)(b0 + ps); d.part = repart[mini]; d.n = (u8)(pk - ps + 1); d.pad = 0;
-        desc[out + __popcll(Em & ((1ULL << lane) - 1))] = d;
+        const u32 di = out + __popcll(Em & ((1ULL << lane) - 1));
+        desc[di] = d;
+        if (so.keys) { so.keys[di] = d.part; so.ids[di] = di; so.sizes[di] = 1u + ((u32)k + d.n - 1u + 3u) / 4u; }
       }
       int w = 0; u64 ts = 0, xs = 0; u32 rf_s = 0;
       if (STATS) {
@@ -214,13 +221,6 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
   if (!EMIT && lane == 0) counts[r] = nsk;
 }
 
-__global__ void k_superk_sizes(const SkDesc* __restrict__ desc, u32 n, int k, u16* __restrict__ keys, u32* __restrict__ ids, u32* __restrict__ sizes_unsorted)
-{
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  keys[i] = desc[i].part; ids[i] = i;
-  sizes_unsorted[i] = 1u + ((u32)k + desc[i].n - 1u + 3u) / 4u;
-}
 __global__ void k_superk_gather_sizes(const u32* __restrict__ ids, const u32* __restrict__ sizes_unsorted, u32 n, u64* __restrict__ sizes_sorted)
 {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,13 +232,15 @@ __global__ void k_superk_gather_sizes2(const u32* __restrict__ ids, const u32* _
 {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const u32 j = ids[i]; sizes_sorted[i] = ((u64)desc[j].n << 32) | sizes_unsorted[j]; }
+  else if (i == n) sizes_sorted[n] = 0;      // (the scan runs over n + 1 entries: launch with more than n threads)
 }
 // prefix (k-mers << 32 | bytes) at the first record of every partition (nb_parts + 1 entries) + that record's index
 __global__ void k_superk_part_bounds(const u16* __restrict__ part_sorted, u32 n, u32 nb_parts, const u64* __restrict__ prefix,
-                                     u64* __restrict__ part_prefix, u32* __restrict__ part_first)
+                                     u64* __restrict__ part_prefix, u32* __restrict__ part_first, u64* __restrict__ zeroed)
 {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > nb_parts) return;
+  if (p == 0) *zeroed = 0;      // (the counter of k_minim_sparse, which runs behind this kernel)
   u32 lo = 0, hi = n;
   while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (part_sorted[mid] < p) lo = mid + 1; else hi = mid; }
   part_prefix[p] = prefix[lo];
@@ -335,57 +337,55 @@ __global__ void k_minim_sparse(const u32* __restrict__ ms, const u32* __restrict
 struct StatsDev {
   SkStats S{nullptr, nullptr, nullptr, nullptr};
   kmx_superk_stats* dst = nullptr; kmx_superk_raw* raw = nullptr; u32 nb_parts = 0; u64 nm = 0;
+  u32* d_sp = nullptr; u32 sp_cap = 0;      // kmx_superk_raw::minim_sparse: the triples on the device, and how many fit
   int alloc(kmx_ctx* ctx, kmx_superk_stats* st, kmx_superk_raw* rw, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s) {
     dst = st; raw = rw; nb_parts = P; nm = nminim;
     if (!st && !rw) return KMX_OK;
-    auto get = [&](bool want, size_t n) -> u32* {
-      if (!want) return nullptr;
-      u32* p = (u32*)ctx->dalloc(n * 4); blocks.push_back(p);
-      if (p) (void)hipMemsetAsync(p, 0, n * 4, s);
-      return p;
-    };
     const bool w_pc = (st && st->part_counters) || (rw && rw->part_radix), w_ms = (st && st->minim_superks) || (rw && (rw->minim_superks || rw->minim_sparse)),
                w_mk = (st && st->minim_kmers) || (rw && (rw->minim_kmers || rw->minim_sparse)), w_mx = st && st->minim_kxmers;
-    S.pc = get(w_pc, (size_t)P * 1280);
-    S.ms = get(w_ms, nminim);
-    S.mk = get(w_mk, nminim);
-    S.mx = get(w_mx, nminim);
-    if ((w_pc && !S.pc) || (w_ms && !S.ms) || (w_mk && !S.mk) || (w_mx && !S.mx))
-      return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
+    // the tables lie in one block, cleared with one call
+    const size_t n_pc = w_pc ? (size_t)P * 1280 : 0, n_m = nminim, words = n_pc + ((size_t)w_ms + w_mk + w_mx) * n_m;
+    if (!words) return KMX_OK;
+    u32* blk = (u32*)ctx->dalloc(words * 4); blocks.push_back(blk);
+    if (!blk) return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
+    if (hipMemsetAsync(blk, 0, words * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
+    u32* at = blk;
+    if (w_pc) { S.pc = at; at += n_pc; }
+    if (w_ms) { S.ms = at; at += n_m; }
+    if (w_mk) { S.mk = at; at += n_m; }
+    if (w_mx) { S.mx = at; at += n_m; }
+    if (rw && rw->minim_sparse) {
+      sp_cap = (u32)std::min<u64>(std::min<u64>(rw->minim_sparse_cap, 0xFFFFFFF0ULL), nminim);
+      d_sp = (u32*)ctx->dalloc((size_t)sp_cap * 12 + 16); blocks.push_back(d_sp);
+      if (!d_sp) return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
+    }
     return KMX_OK;
   }
   bool any() const { return S.pc || S.ms || S.mk || S.mx; }
+  // kmx_superk_raw, behind the kernel that fills the tables: the minimizers that occur are compacted on the device (their number
+  // lands in *d_n, which the caller has zeroed on the stream and downloads with its own results) ...
+  void launch_sparse(u32* d_n, hipStream_t s) const {
+    if (d_sp) hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, S.ms, S.mk, nm, d_sp, sp_cap, d_n);
+  }
+  // ... and once that number is on the host, the copies into the caller's (page-locked) buffers are queued: no synchronisation
+  // here, the caller's next one covers them
+  int finish_raw(kmx_ctx* ctx, u32 n_sparse, hipStream_t s) {
+    if (!raw) return KMX_OK;
+    hipError_t e = hipSuccess;
+    if (raw->part_radix) e = hipMemcpyAsync(raw->part_radix, S.pc, (size_t)nb_parts * 1280 * 4, hipMemcpyDeviceToHost, s);
+    if (raw->minim_sparse) {
+      if (n_sparse > sp_cap) return ctx->fail(KMX_E_INVAL, "kmx_superk_raw: more minimizers occur than minim_sparse_cap");
+      raw->minim_sparse_n = n_sparse;
+      if (n_sparse && e == hipSuccess) e = hipMemcpyAsync(raw->minim_sparse, d_sp, (size_t)n_sparse * 12, hipMemcpyDeviceToHost, s);
+    } else {
+      if (e == hipSuccess && raw->minim_superks) e = hipMemcpyAsync(raw->minim_superks, S.ms, nm * 4, hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess && raw->minim_kmers) e = hipMemcpyAsync(raw->minim_kmers, S.mk, nm * 4, hipMemcpyDeviceToHost, s);
+    }
+    return e == hipSuccess ? KMX_OK : ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
+  }
   // after the kernel: download and accumulate (PartiInfo::incKmer_and_rad / incSuperKmer_per_minimBin / incKxmer_per_minimBin)
   int collect(kmx_ctx* ctx, hipStream_t s) {
-    if ((!dst && !raw) || !any()) return KMX_OK;
-    if (raw) {
-      hipError_t e = hipSuccess;
-      if (raw->part_radix) e = hipMemcpyAsync(raw->part_radix, S.pc, (size_t)nb_parts * 1280 * 4, hipMemcpyDeviceToHost, s);
-      if (raw->minim_sparse) {      // the minimizers that occur, compacted on the device: their number first, then that many triples
-        const u32 cap = (u32)std::min<u64>(raw->minim_sparse_cap, 0xFFFFFFF0ULL);
-        u32* d_sp = (u32*)ctx->dalloc((size_t)std::min<u64>(cap, nm) * 12 + 16);
-        u32* d_n = (u32*)ctx->dalloc(256);
-        struct Rel { kmx_ctx* c; void* a; void* b; ~Rel() { c->dfree(a); c->dfree(b); } } rel{ctx, d_sp, d_n};
-        if (!d_sp || !d_n) return ctx->fail(KMX_E_NOMEM, "superk statistics: device allocation failed");
-        u32 n = 0;
-        if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, 4, s);
-        if (e == hipSuccess) { hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, S.ms, S.mk, nm, d_sp, (u32)std::min<u64>(cap, nm), d_n); e = hipGetLastError(); }
-        if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
-        if (n > cap) return ctx->fail(KMX_E_INVAL, "kmx_superk_raw: more minimizers occur than minim_sparse_cap");
-        raw->minim_sparse_n = n;
-        if (n) e = hipMemcpyAsync(raw->minim_sparse, d_sp, (size_t)n * 12, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
-        if (!dst) return KMX_OK;
-      }
-      if (e == hipSuccess && !raw->minim_sparse && raw->minim_superks) e = hipMemcpyAsync(raw->minim_superks, S.ms, nm * 4, hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess && !raw->minim_sparse && raw->minim_kmers) e = hipMemcpyAsync(raw->minim_kmers, S.mk, nm * 4, hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
-      if (e != hipSuccess) return ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
-      if (!dst) return KMX_OK;
-    }
+    if (!dst || !any()) return KMX_OK;
     u32* h = (u32*)ctx->halloc(std::max<size_t>((size_t)nb_parts * 1280, nm) * 4);      // pinned staging: the tables come back at PCIe speed
     if (!h) return ctx->fail(KMX_E_NOMEM, "superk statistics: host staging allocation failed");
     struct Rel { kmx_ctx* c; void* p; ~Rel() { c->hfree(p); } } rel{ctx, h};
@@ -486,7 +486,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       // the shortest prefix of the reads that holds more than `budget` super-k-mers (the reference's iterator is cancelled by the
       // super-k-mer that brings the count past the sample size, and stops before the next read; RepartitionAlgorithm.cpp:205-211)
       hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                         (const u32*)nullptr, (SkDesc*)nullptr, sd.S);
+                         (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
       std::vector<u32> cnt(n_seqs);
       if ((e = hipMemcpyAsync(cnt.data(), d_cnt, n_seqs * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sample counts");
       u64 acc = 0; use = 0;
@@ -496,22 +496,28 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     if (n_used) *n_used = use;
     const dim3 gs((unsigned)((use + 3) / 4));
     hipLaunchKernelGGL((k_superk_wave<false, true>), gs, b1, 0, st, d_bases, d_offs, (u64)use, (int)k, (int)m, maxs, d_rep, d_cnt,
-                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S);
+                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_superk_wave");
     const int rc = sd.collect(ctx, st);
     release();
     return rc;
   }
   hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                     (const u32*)nullptr, (SkDesc*)nullptr, sd.S);
+                     (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
   size_t tb = 0;
   if ((e = rocprim::exclusive_scan(nullptr, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan size");
   void* d_tmp = ctx->dalloc(tb ? tb : 256); blocks.push_back(d_tmp);
   if (!d_tmp) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   if ((e = rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan");
-  u32 nd = 0;
-  if ((e = hipMemcpyAsync(&nd, d_doff + n_seqs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
+  // what the host reads back between the steps lands in one page-locked block (a copy into pageable memory is staged by the
+  // runtime and waited for): [super-k-mers u64] [pp (P + 1) u64] [info 2P u64] [minimizers that occur u64] [pf (P + 1) u32]
+  const size_t P1 = (size_t)nb_parts + 1, sum_bytes = (P1 + 2 * (size_t)nb_parts + 1) * 8 + P1 * 4;
+  u8* h_sum = (u8*)ctx->halloc(8 + sum_bytes);
+  struct HRel { kmx_ctx* c; void* p; ~HRel() { c->hfree(p); } } h_sum_rel{ctx, h_sum};
+  if (!h_sum) { release(); return ctx->fail(KMX_E_NOMEM, "superk: host staging allocation failed"); }
+  if ((e = hipMemcpyAsync(h_sum, d_doff + n_seqs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  const u32 nd = *reinterpret_cast<const u32*>(h_sum);
   clk.mark("upload+scan");
   if (nd == 0) {
     if (raw) {      // nothing counted: the caller's tables are all zeros
@@ -537,58 +543,58 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   u32* d_ids = (u32*)ctx->dalloc((size_t)nd * 4), *d_ids2 = (u32*)ctx->dalloc((size_t)nd * 4);
   u32* d_sz = (u32*)ctx->dalloc((size_t)nd * 4);
   u64* d_szs = (u64*)ctx->dalloc(((size_t)nd + 1) * 8), *d_boff = (u64*)ctx->dalloc(((size_t)nd + 1) * 8);
-  for (void* b : {(void*)d_desc, (void*)d_keys, (void*)d_keys2, (void*)d_ids, (void*)d_ids2, (void*)d_sz, (void*)d_szs, (void*)d_boff}) blocks.push_back(b);
+  u8* d_sum = (u8*)ctx->dalloc(sum_bytes);
+  for (void* b : {(void*)d_desc, (void*)d_keys, (void*)d_keys2, (void*)d_ids, (void*)d_ids2, (void*)d_sz, (void*)d_szs, (void*)d_boff, (void*)d_sum}) blocks.push_back(b);
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                                    (const u32*)d_doff, d_desc, sd.S);
+                                    (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz});
   else hipLaunchKernelGGL((k_superk_wave<true, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                          (const u32*)d_doff, d_desc, sd.S);
+                          (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz});
   const dim3 g2((nd + 255) / 256), b2(256);
-  hipLaunchKernelGGL(k_superk_sizes, g2, b2, 0, st, d_desc, nd, (int)k, d_keys, d_ids, d_sz);
   size_t tb2 = 0, tb3 = 0;
   if ((e = rocprim::radix_sort_pairs(nullptr, tb2, d_keys, d_keys2, d_ids, d_ids2, (size_t)nd, 0, 16, st)) != hipSuccess) return fail(e, "sort size");
   if ((e = rocprim::exclusive_scan(nullptr, tb3, d_szs, d_boff, (u64)0, (size_t)nd + 1, rocprim::plus<u64>(), st)) != hipSuccess) return fail(e, "scan size");
   void* d_tmp2 = ctx->dalloc(std::max(tb2, tb3) + 256); blocks.push_back(d_tmp2);
   if (!d_tmp2) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   if ((e = rocprim::radix_sort_pairs(d_tmp2, tb2, d_keys, d_keys2, d_ids, d_ids2, (size_t)nd, 0, 16, st)) != hipSuccess) return fail(e, "sort");
-  if ((e = hipMemsetAsync(d_szs + nd, 0, 8, st)) != hipSuccess) return fail(e, "memset");
-  hipLaunchKernelGGL(k_superk_gather_sizes2, g2, b2, 0, st, d_ids2, d_sz, d_desc, nd, d_szs);
+  hipLaunchKernelGGL(k_superk_gather_sizes2, dim3((nd + 256) / 256), b2, 0, st, d_ids2, d_sz, d_desc, nd, d_szs);
   if ((e = rocprim::exclusive_scan(d_tmp2, tb3, d_szs, d_boff, (u64)0, (size_t)nd + 1, rocprim::plus<u64>(), st)) != hipSuccess) return fail(e, "scan");
-  u64* d_pp = (u64*)ctx->dalloc(((size_t)nb_parts + 1) * 8); u32* d_pf = (u32*)ctx->dalloc(((size_t)nb_parts + 1) * 4);
-  blocks.push_back(d_pp); blocks.push_back(d_pf);
-  if (!d_pp || !d_pf) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-  hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf);
-  std::vector<u64> pp((size_t)nb_parts + 1); std::vector<u32> pf((size_t)nb_parts + 1);
-  u64 tot = 0;
-  if ((e = hipMemcpyAsync(&tot, d_boff + nd, 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(pp.data(), d_pp, ((size_t)nb_parts + 1) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(pf.data(), d_pf, ((size_t)nb_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  u64* d_pp = (u64*)d_sum, *d_info = d_pp + P1, *d_nsp = d_info + 2 * (size_t)nb_parts; u32* d_pf = (u32*)(d_nsp + 1);
+  hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf, d_nsp);
+  if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((nb_parts + 63) / 64), dim3(64), 0, st, d_pf, d_boff, nb_parts, d_info);
+  sd.launch_sparse((u32*)d_nsp, st);
+  if ((e = hipMemcpyAsync(h_sum + 8, d_sum, sum_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  const u64* pp = reinterpret_cast<const u64*>(h_sum + 8);
+  const u32* pf = reinterpret_cast<const u32*>(h_sum + 8 + (P1 + 2 * (size_t)nb_parts + 1) * 8);
+  const u64 tot = pp[nb_parts];                 // (the prefix at the end of the last partition: all k-mers << 32 | all bytes)
   clk.mark("emit+sort");
-  if (raw) raw->nb_superk = nd;                 // (one descriptor per super-k-mer)
+  if (superk_info) memcpy(superk_info, pp + P1, (size_t)nb_parts * 16);
+  if (raw) {
+    raw->nb_superk = nd;                        // (one descriptor per super-k-mer)
+    const int rc = sd.finish_raw(ctx, (u32)pp[P1 + 2 * (size_t)nb_parts], st);      // (queued; the synchronisation of the steps below covers it)
+    if (rc != KMX_OK) { release(); return rc; }
+  }
   { const int rc = sd.collect(ctx, st); if (rc != KMX_OK) { release(); return rc; } }
   if (pf[nb_parts] != nd) { release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
   const u64 total_bytes = tot & 0xFFFFFFFFULL;
   u8* d_out = (u8*)ctx->dalloc(total_bytes + 16); blocks.push_back(d_out);
-  u8* h_out = (u8*)ctx->halloc(total_bytes + 16);
-  if (!d_out || !h_out) { ctx->hfree(h_out); release(); return ctx->fail(KMX_E_NOMEM, "superk: allocation failed"); }
+  u8* h_out = streams_to_host ? (u8*)ctx->halloc(total_bytes + 16) : nullptr;
+  if (!d_out || (streams_to_host && !h_out)) { ctx->hfree(h_out); release(); return ctx->fail(KMX_E_NOMEM, "superk: allocation failed"); }
   hipLaunchKernelGGL(k_superk_pack, g2, b2, 0, st, d_bases, d_desc, d_ids2, d_boff, nd, (int)k, d_out);
   if ((e = hipGetLastError()) != hipSuccess) { ctx->hfree(h_out); return fail(e, "k_superk_pack"); }
   clk.mark("pack");
   for (u32 p = 0; p < nb_parts; p++) out_kmers[p] = (pp[p + 1] >> 32) - (pp[p] >> 32);
-  if (superk_info) {
-    u64* d_info = (u64*)ctx->dalloc((size_t)nb_parts * 16); blocks.push_back(d_info);
-    if (!d_info) { ctx->hfree(h_out); release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-    hipLaunchKernelGGL(k_superk_info, dim3((nb_parts + 63) / 64), dim3(64), 0, st, d_pf, d_boff, nb_parts, d_info);
-    if ((e = hipMemcpyAsync(superk_info, d_info, (size_t)nb_parts * 16, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) { ctx->hfree(h_out); return fail(e, "superk info"); }
-  }
   if (creq) {   // count straight from the device-resident stream (kmx_count_reads)
     std::vector<u64> pko((size_t)nb_parts + 1); for (u32 p = 0; p <= nb_parts; p++) pko[p] = pp[p] >> 32;
     const int rc = kmx_count_from_device(ctx, d_out, d_boff, d_keys2, nd, tot >> 32, nb_parts, pko.data(), *creq);
     if (rc != KMX_OK) { ctx->hfree(h_out); release(); return rc; }
     clk.mark("count");
   }
-  if (!streams_to_host) { ctx->hfree(h_out); release(); return KMX_OK; }
+  if (!streams_to_host) {
+    // (kmx_superk_raw's copies are queued on the stream: normally the count above has waited for it already)
+    if ((raw || !creq) && (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+    release(); return KMX_OK;
+  }
   // the partition-ordered stream comes back in one copy; a few host threads cut it into the per-partition buffers
   if ((e = hipMemcpyAsync(h_out, d_out, total_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipStreamSynchronize(st)) != hipSuccess) { ctx->hfree(h_out); return fail(e, "download"); }

@@ -360,6 +360,45 @@ int run(int argc, char** argv)
     return root + "/counts/partition_" + std::to_string(p) + "/" + samples[si].id + (hash_mode ? ".hash" : (o.cpr ? ".kmer.lz4" : ".kmer"));
   };
 
+  // matrix bodies leave the device in pieces: a ring of pinned buffers shared by the shards (KMX_OUT_RING_MB, default 2048, in
+  // pieces of 32 MB); a piece is handed to the pool (pwrite at its place in the file) and comes back to the ring when written --
+  // what is pending is bounded in bytes, whatever the cohort.  Page-locking memory is slow (~10 ms per piece, 0.6 s for the ring:
+  // the whole merge stage of the 1000 x 1 Mbp cohort, as the first runs of round 3 showed): a thread of its own fills the ring
+  // while the samples are counted.
+  struct Ring {
+    std::mutex m; std::condition_variable cv; std::vector<uint8_t*> free_; size_t made = 0, cap = 64, bytes = (size_t)32 << 20;
+    uint8_t* get() {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        if (!free_.empty()) { uint8_t* p = free_.back(); free_.pop_back(); return p; }
+        if (made < cap) { made++; lk.unlock(); uint8_t* p = (uint8_t*)kmx_alloc_pinned(bytes); if (!p) die("pinned host allocation failed"); return p; }
+        cv.wait(lk);
+      }
+    }
+    void put(uint8_t* p) { { std::lock_guard<std::mutex> lk(m); free_.push_back(p); } cv.notify_one(); }
+    void prefill(const std::atomic<bool>& stop) {      // (pieces the writers will want, made ahead of them)
+      for (;;) {
+        { std::lock_guard<std::mutex> lk(m); if (made >= cap || stop.load()) return; made++; }
+        uint8_t* p = (uint8_t*)kmx_alloc_pinned(bytes);
+        if (!p) { std::lock_guard<std::mutex> lk(m); made--; return; }
+        put(p);
+      }
+    }
+    ~Ring() { for (auto p : free_) kmx_free_pinned(p); }
+  } ring;
+  if (const char* e = getenv("KMX_OUT_RING_MB")) ring.cap = std::max<size_t>(2, (size_t)atol(e) / 32);
+  if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(32768, (size_t)atol(e) << 10); ring.cap = std::max<size_t>(ring.cap, 4); }      // (small pieces: for the tests)
+  std::atomic<bool> ring_stop{false};
+  std::thread ring_filler;
+  {
+    const bool will_merge = o.until == "all" || o.until == "merge";
+    const bool streams = will_merge && o.plugin.empty() && !(o.cpr && !(o.mode == "hash:bf:bin" || o.mode == "hash:bfc:bin")) && o.mode != "hash:bft:bin";
+    // (as many pieces as the matrices can fill: input bytes bound them loosely; small runs do not pin 2 GB for nothing)
+    // KMX_RING_PREFILL: a thread pins the pieces while the samples are counted.  Measured on 1000 x 1 Mbp: the merge stage gains
+    // 0.1 s, the count stage loses 0.3 s (page pinning and the workers' HIP calls share the runtime's locks) -- off by default.
+    if (streams) { ring.cap = std::max<size_t>(4, std::min<size_t>(ring.cap, (size_t)(in_bytes * 4 / ring.bytes) + 4)); if (getenv("KMX_RING_PREFILL")) ring_filler = std::thread([&]() { ring.prefill(ring_stop); }); }
+  }
+  struct RingJoin { std::atomic<bool>& stop; std::thread& t; ~RingJoin() { stop = true; if (t.joinable()) t.join(); } } ring_join{ring_stop, ring_filler};
   st.setup_wall = since(t0);
   const auto t_count_stage = clk::now();
   // ================= superk + count, sample by sample (task_scheduler.hpp:251-348) =================
@@ -702,24 +741,6 @@ int run(int argc, char** argv)
     std::mutex tm; double s_io = 0, s_merge = 0, s_format = 0;
     struct PartIn { uint32_t p = 0; std::vector<kmx_list> lists; std::vector<uint8_t> on_dev; };
     struct Batch { std::vector<PartIn> parts; uint8_t* buf = nullptr; uint64_t bytes = 0; double io_s = 0; };
-    // matrix bodies leave the device in pieces: a ring of pinned buffers shared by the shards (KMX_OUT_RING_MB, default 2048, in
-    // pieces of 32 MB); a piece is handed to the pool (pwrite at its place in the file) and comes back to the ring when written --
-    // what is pending is bounded in bytes, whatever the cohort
-    struct Ring {
-      std::mutex m; std::condition_variable cv; std::vector<uint8_t*> free_; size_t made = 0, cap = 64, bytes = (size_t)32 << 20;
-      uint8_t* get() {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-          if (!free_.empty()) { uint8_t* p = free_.back(); free_.pop_back(); return p; }
-          if (made < cap) { made++; lk.unlock(); uint8_t* p = (uint8_t*)kmx_alloc_pinned(bytes); if (!p) die("pinned host allocation failed"); return p; }
-          cv.wait(lk);
-        }
-      }
-      void put(uint8_t* p) { { std::lock_guard<std::mutex> lk(m); free_.push_back(p); } cv.notify_one(); }
-      ~Ring() { for (auto p : free_) kmx_free_pinned(p); }
-    } ring;
-    if (const char* e = getenv("KMX_OUT_RING_MB")) ring.cap = std::max<size_t>(2, (size_t)atol(e) / 32);
-    if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(32768, (size_t)atol(e) << 10); ring.cap = std::max<size_t>(ring.cap, 4); }      // (small pieces: for the tests)
     struct Pinned { uint8_t* p = nullptr; uint64_t cap = 0; void need(uint64_t n) { if (n <= cap) return; kmx_free_pinned(p); cap = n + n / 8 + (1u << 20); p = (uint8_t*)kmx_alloc_pinned(cap); if (!p) die("pinned host allocation failed"); } ~Pinned() { kmx_free_pinned(p); } };
 
     auto worker_fn = [&](uint32_t g) {
