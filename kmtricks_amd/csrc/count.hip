@@ -84,10 +84,13 @@ __global__ void k_decode_block_starts(const u64* __restrict__ prefix, u32 n_recs
 
 __device__ __forceinline__ u64 load8u(const u8* p) { u64 w; __builtin_memcpy(&w, p, 8); return w; }
 
-template <int KW, int HASH>
+// DIRECT (kmx_count_reads_dev without the super-k-mer files): no record stream is written at all.  `recs` is then the batch's
+// bases, 2 bits each, 32 to a 64-bit word, the first base in the top bits (k_pack_bases), and sbase[i] the position of record i's
+// first base: k-mer j of the record is the 2k bits at base sbase[i] + j -- two (three) aligned word loads and a funnel shift.
+template <int KW, int HASH, bool DIRECT>
 __global__ __launch_bounds__(256)
 void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ prefix, const u32* __restrict__ blk_first, const u16* __restrict__ rec_part,
-                           const u64* __restrict__ part_ids, u32 n_recs, u32 total, int k, u64 win, void* __restrict__ out)
+                           const u64* __restrict__ part_ids, u32 n_recs, u32 total, int k, u64 win, void* __restrict__ out, const u32* __restrict__ sbase)
 {
   __shared__ u64 pk[DK + 1];
   __shared__ u32 nrec_s;
@@ -95,7 +98,10 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
   const u32 g0 = blockIdx.x * DK;
   const u32 r0 = blk_first[blockIdx.x];
   const u32 avail = min((u32)DK + 1u, n_recs + 1u - r0);
-  for (u32 t = tid; t < avail; t += 256) pk[t] = prefix[r0 + t];
+  for (u32 t = tid; t < avail; t += 256) {
+    const u64 e = prefix[r0 + t];
+    pk[t] = DIRECT ? ((e & 0xFFFFFFFF00000000ULL) | (r0 + t < n_recs ? sbase[r0 + t] : 0u)) : e;      // (low word: the record's byte offset, or its first base)
+  }
   if (tid == 0) nrec_s = avail;
   __syncthreads();
 #pragma unroll
@@ -111,7 +117,25 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
     const u32 r = r0 + lo;
     const u64 part = HASH ? (part_ids ? part_ids[rec_part[r]] : (u64)rec_part[r]) : 0;      // (no table: the partition's index is its id)
     const u32 eb = (u32)k >> 2, es = ((u32)k & 3u) * 2;   // the following nucleotides start at digit k: byte eb, bit es
-    if (KW == 1) {
+    if (DIRECT) {
+      const u64* W = reinterpret_cast<const u64*>(recs);
+      const u32 q = (u32)pe + j, w = q >> 5, o = (q & 31u) * 2u;
+      if (KW == 1) {
+        const u64 h = W[w], l = W[w + 1];
+        const u64 fwd = (o ? (h << o) | (l >> (64 - o)) : h) >> (64 - 2 * k);
+        const u64 rev = revcomp64(fwd, k);
+        const u64 c = fwd < rev ? fwd : rev;
+        reinterpret_cast<u64*>(out)[g] = HASH ? (xxh64_words(&c, 1) % win + win * part) : c;
+      } else {
+        const u128 a = ((u128)W[w] << 64) | W[w + 1];
+        const u64 l = W[w + 2];
+        const u128 fwd = (o ? (a << o) | (u128)(l >> (64 - o)) : a) >> (128 - 2 * k);
+        const u128 rev = revcomp128(fwd, k);
+        const u128 c = fwd < rev ? fwd : rev;
+        if (HASH) { u64 x[2] = {(u64)c, (u64)(c >> 64)}; reinterpret_cast<u64*>(out)[g] = xxh64_words(x, 2) % win + win * part; }
+        else reinterpret_cast<u128*>(out)[g] = c;
+      }
+    } else if (KW == 1) {
       const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
       u64 fwd = load8u(p) & mask;
       if (j && k < 32) {      // (super-k-mers of at most 28 k-mers: j <= 27, the 54 bits wanted lie in one shifted word)
@@ -142,6 +166,32 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
     }
   }
   (void)nrec_s;
+}
+
+// ASCII bases -> 2 bits each ((c >> 1) & 3: A 0, C 1, T 2, G 3), 32 to a word, the first one in the top bits; a thread per word.
+// `n` bases, the array behind them readable for 16 more bytes; words [0, ceil(n / 32) + 2) are written (the decode reads up to two
+// words past a k-mer's first one)
+__global__ void k_pack_bases(const char* __restrict__ bases, u64 n, u64* __restrict__ out)
+{
+  const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x, nw = (n + 31) / 32 + 2;
+  if (w >= nw) return;
+  u64 v = 0;
+  const u64 b0 = w * 32;
+  if (b0 + 32 <= n) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      u64 x = load8u(reinterpret_cast<const u8*>(bases) + b0 + 8 * q);
+      x = (x >> 1) & 0x0303030303030303ULL;                      // a code per byte, the first base in the low byte
+      x = (x | (x >> 6)) & 0x000F000F000F000FULL;                // two codes per 16 bits (first one low) ...
+      x = (x | (x >> 12)) & 0x000000FF000000FFULL;               // ... four per 32 ...
+      x = (x | (x >> 24)) & 0xFFFFULL;                           // ... eight in 16 bits, first base in bits 0-1
+      v |= x << (16 * q);                                        // 32 codes, first base lowest: reversed below
+    }
+    v = rev_digits64(v);
+  } else {
+    for (u32 i = 0; i < 32 && b0 + i < n; i++) v |= (u64)(((u32)(u8)bases[b0 + i] >> 1) & 3u) << (62 - 2 * i);
+  }
+  out[w] = v;
 }
 
 // the partition of every k-mer (the library sort's second key): only the fallback asks for it
@@ -396,20 +446,33 @@ static int compact_to_stores(kmx_ctx* ctx, const KeyT* d_tk, const u32* d_tc, co
 // ---- partition-local sample sort + run-length count (count_sort.hpp): keys grouped by partition in d_keys, partition p =
 //      keys [kmoff[p], kmoff[p + 1]).  Returns KMX_OK, a negative error, or 1 when a bucket would not fit the LDS (the caller
 //      then uses the library sort: d_keys is still untouched at that point). ----
-// the bucket kernel of a key width: 64-bit keys count by hashing first (k_cs_count_hash), 128-bit keys by sorting (k_cs_sort)
+// the bucket kernels: a wave per bucket with the keys in registers (k_cs_wave_sort, two launches for the two size classes); the LDS
+// kernels of before -- hash first (64-bit keys) or bitonic sort per workgroup -- stay behind KMX_COUNT_BUCKETS=hash|sort for comparison
 template <typename KeyT> static void cs_launch_bucket_count(u32 TB, hipStream_t st, const KeyT* bkeys, const u32* boff, u32 hard_min, KeyT* tk, u32* tc, u32* nkept,
                                                             unsigned long long* hist, u32* overflow);
+static int cs_bucket_kernel()      // 0: a wave per bucket, keys in registers (k_cs_wave_sort), the LDS kernels for the buckets beyond it; 1: hash first in LDS (64-bit keys); 2: bitonic sort in LDS
+{
+  static const int v = []() { const char* e = getenv("KMX_COUNT_BUCKETS"); return !e ? 0 : !strcmp(e, "hash") ? 1 : !strcmp(e, "sort") ? 2 : 0; }();
+  return v;
+}
 template <> void cs_launch_bucket_count<u64>(u32 TB, hipStream_t st, const u64* bkeys, const u32* boff, u32 hard_min, u64* tk, u32* tc, u32* nkept,
                                              unsigned long long* hist, u32* overflow)
 {
-  static const bool by_sort = getenv("KMX_COUNT_BUCKETS") && !strcmp(getenv("KMX_COUNT_BUCKETS"), "sort");      // (the round-2 kernel, for comparison)
-  if (by_sort) hipLaunchKernelGGL((k_cs_sort<u64>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow);
-  else hipLaunchKernelGGL(k_cs_count_hash, dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow);
+  const int which = cs_bucket_kernel();
+  const u32 lo = which == 0 ? CS_WAVE_MAX : 0u;
+  if (which == 0) hipLaunchKernelGGL((k_cs_wave_sort<u64, 8, 16>), dim3((TB + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, bkeys, boff, TB, 0u, (u32)CsCap<u64>::cap,
+                                     hard_min, tk, tc, nkept, hist, overflow);
+  if (which == 2) hipLaunchKernelGGL((k_cs_sort<u64>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, lo);
+  else hipLaunchKernelGGL(k_cs_count_hash, dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, lo);
 }
 template <> void cs_launch_bucket_count<__uint128_t>(u32 TB, hipStream_t st, const __uint128_t* bkeys, const u32* boff, u32 hard_min, __uint128_t* tk, u32* tc, u32* nkept,
                                                      unsigned long long* hist, u32* overflow)
 {
-  hipLaunchKernelGGL((k_cs_sort<__uint128_t>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow);
+  const int which = cs_bucket_kernel();
+  const u32 lo = which == 0 ? CS_WAVE_MAX : 0u;
+  if (which == 0) hipLaunchKernelGGL((k_cs_wave_sort<__uint128_t, 8, 16>), dim3((TB + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, bkeys, boff, TB, 0u,
+                                     (u32)CsCap<__uint128_t>::cap, hard_min, tk, tc, nkept, hist, overflow);
+  hipLaunchKernelGGL((k_cs_sort<__uint128_t>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, lo);
 }
 __global__ void k_hist_add(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst)
 {
@@ -461,10 +524,10 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   if ((e = hipMemcpyAsync(d_tab, h_tab, tab_bytes, hipMemcpyHostToDevice, st)) != hipSuccess ||
       (e = hipMemsetAsync(d_cnt, 0, 4 * ((size_t)TB + 1), st)) != hipSuccess) return fail(e, "count sort upload");      // (d_cnt[TB]: the overflow word, cleared with the rest)
   (void)cap;
-  hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(n_parts), dim3(CS_TPB), 0, st, d_keys, d_parts, d_spl);
-  hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cnt, (KeyT*)nullptr);
+  hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(n_parts), dim3(CS_SPL_TPB), 0, st, d_keys, d_parts, d_spl);
+  hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3((unsigned)chunks.size()), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cnt, (KeyT*)nullptr);
   hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_cnt, TB, d_boff, d_cur, (const u32*)nullptr);      // (d_cur: the scatter's cursors)
-  hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3((unsigned)chunks.size()), dim3(CS_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cur, d_bkeys);
+  hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3((unsigned)chunks.size()), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, d_chunks, d_spl, d_cur, d_bkeys);
   // (a bucket beyond what the count kernel takes is found by the kernel itself and reported with the kept sizes: one round trip to
   //  the host per call, not two.  The grouped keys stay as they are until then -- the library sort needs them -- and the abundance
   //  histogram of this call is kept apart until the call is known to stand.)
@@ -640,7 +703,8 @@ static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kp
 //      bucket is beyond the count kernel.  d_prefix: u64[nr + 1], record i starts at byte lo(d_prefix[i]), its first k-mer is number
 //      hi(d_prefix[i]); d_rpart[i]: the record's partition (index into pid / kmoff); kmoff: first k-mer of every partition ----
 static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, const u64* d_prefix, const u16* d_rpart, u32 nr, u64 total, u32 n_parts,
-                            const std::vector<u64>& kmoff, const std::vector<u64>& pid, u32 k, int hash_mode, u64 window, u32 hard_min, const CountOut& co)
+                            const std::vector<u64>& kmoff, const std::vector<u64>& pid, u32 k, int hash_mode, u64 window, u32 hard_min, const CountOut& co,
+                            const u32* d_sbase = nullptr /* set: d_recs are packed bases (k_pack_bases), record i starts at base d_sbase[i] */)
 {
   const int kw = (k + 31) / 32;
   const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
@@ -659,10 +723,13 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
   }
   hipLaunchKernelGGL(k_decode_block_starts, dim3((nr + 255) / 256), dim3(256), 0, st, d_prefix, nr, d_blk);
   const dim3 grid(NB), block(256);
-  if (kw == 1 && !hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<1, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
-  else if (kw == 1) hipLaunchKernelGGL((k_superk_decode_kmers<1, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
-  else if (!hash_mode) hipLaunchKernelGGL((k_superk_decode_kmers<2, 0>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
-  else hipLaunchKernelGGL((k_superk_decode_kmers<2, 1>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys);
+#define KMX_DECODE(KW_, H_, D_) hipLaunchKernelGGL((k_superk_decode_kmers<KW_, H_, D_>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys, d_sbase)
+  if (d_sbase) {
+    if (kw == 1 && !hash_mode) KMX_DECODE(1, 0, true); else if (kw == 1) KMX_DECODE(1, 1, true); else if (!hash_mode) KMX_DECODE(2, 0, true); else KMX_DECODE(2, 1, true);
+  } else {
+    if (kw == 1 && !hash_mode) KMX_DECODE(1, 0, false); else if (kw == 1) KMX_DECODE(1, 1, false); else if (!hash_mode) KMX_DECODE(2, 0, false); else KMX_DECODE(2, 1, false);
+  }
+#undef KMX_DECODE
   if ((e = hipGetLastError()) != hipSuccess) { release(); return ctx->fail(KMX_E_HIP, std::string("k_superk_decode_kmers: ") + hipGetErrorString(e)); }
   clk.mark("decode");
   int rc;
@@ -771,7 +838,8 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
 // ---- split -> count without the streams leaving HBM (kmx_count_reads; called from superk.hip) ---------------------------
 // record i of the partition-ordered stream: byte offset = low word of d_prefix[i], first k-mer index = high word (d_prefix has one
 // more entry than there are records: the totals) -- exactly what the decode takes
-int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, const u16* d_part, u32 nr, u64 total, u32 n_parts, const u64* part_kmer_off, const kmx_count_req& rq)
+int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, const u16* d_part, u32 nr, u64 total, u32 n_parts, const u64* part_kmer_off, const kmx_count_req& rq,
+                          const u32* d_sbase)
 {
   if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one batch: split it");
   StageClock clk(ctx->stream, "count_reads");
@@ -782,5 +850,12 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
   }
   const std::vector<u64> pid;      // (partition p of the stream has id p)
   std::vector<u64> kmoff(part_kmer_off, part_kmer_off + n_parts + 1);
-  return decode_and_count(ctx, clk, d_recs, d_prefix, d_part, nr, total, n_parts, kmoff, pid, rq.k, rq.hash_mode, rq.window, rq.hard_min, co);
+  return decode_and_count(ctx, clk, d_recs, d_prefix, d_part, nr, total, n_parts, kmoff, pid, rq.k, rq.hash_mode, rq.window, rq.hard_min, co, d_sbase);
+}
+
+// the bases of a batch, 2 bits each (see k_pack_bases); `out` holds (n + 31) / 32 + 2 words
+void kmx_launch_pack_bases(const char* d_bases, u64 n, u64* out, hipStream_t st)
+{
+  const u64 nw = (n + 31) / 32 + 2;
+  hipLaunchKernelGGL(k_pack_bases, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, d_bases, n, out);
 }

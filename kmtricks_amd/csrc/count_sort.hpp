@@ -26,11 +26,13 @@
 namespace kmx {
 
 constexpr int CS_TPB = 256;
-constexpr int CS_CHUNK = 4096;            // keys per workgroup in the count / scatter walks
-constexpr int CS_MAXB = 1024;             // buckets per partition (partitions of up to ~1 M keys; beyond: the library sort)
-template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 8192; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (64 KB)
-template <> struct CsCap<__uint128_t> { static constexpr int cap = 2048, sample = 4096; };
-template <typename K> __host__ __device__ inline u32 cs_target() { return (u32)CsCap<K>::cap / 4; }      // aimed bucket size (a bucket may come out 4x that)
+constexpr int CS_WALK_TPB = 1024;
+constexpr int CS_CHUNK = 16 * CS_WALK_TPB;  // keys per workgroup in the count / scatter walks (a chunk holds ~11 keys per bucket of a partition cut into 1500: the pieces the scatter writes)
+constexpr int CS_MAXB = 2048;             // buckets per partition (partitions of up to ~1 M keys; beyond: the library sort)
+template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 16384; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (64 KB)
+template <> struct CsCap<__uint128_t> { static constexpr int cap = 2048, sample = 8192; };
+constexpr u32 CS_WAVE_MAX = 1024;         // keys of a bucket that one wave sorts in registers (16 per lane)
+template <typename K> __host__ __device__ inline u32 cs_target() { return CS_WAVE_MAX / 2; }      // aimed bucket size (a bucket may come out twice that and stay with the wave kernel, 4-8x and stay in LDS)
 
 struct CsPart { u32 key0, nkeys, bucket0, nb; };      // a partition's keys [key0, key0 + nkeys), its buckets [bucket0, bucket0 + nb)
 struct CsChunk { u32 part, key0, nkeys, pad; };
@@ -47,6 +49,25 @@ template <> __device__ __forceinline__ __uint128_t cs_shfl_xor<__uint128_t>(__ui
   const u64 lo = (u64)__shfl_xor((unsigned long long)(u64)k, m), hi = (u64)__shfl_xor((unsigned long long)(u64)(k >> 64), m);
   return ((__uint128_t)hi << 64) | lo;
 }
+// the key of lane ^ M, M a constant (kmx_dev.hpp: DPP moves and permlane swaps instead of ds_bpermute)
+template <typename K, int M> __device__ __forceinline__ K cs_xor(K k);
+template <typename K, int M> struct CsXor;
+template <int M> struct CsXor<u64, M> { static __device__ __forceinline__ u64 get(u64 k) { return xor_lane_u64<M>(k); } };
+template <int M> struct CsXor<__uint128_t, M> {
+  static __device__ __forceinline__ __uint128_t get(__uint128_t k) { return ((__uint128_t)xor_lane_u64<M>((u64)(k >> 64)) << 64) | xor_lane_u64<M>((u64)k); }
+};
+template <typename K, int J>
+__device__ __forceinline__ void cs_chunk_step(K (&k)[2], u32 base, u32 lane, u32 k2)      // steps J .. 1
+{
+#pragma unroll
+  for (int x = 0; x < 2; x++) {
+    const K o = CsXor<K, J>::get(k[x]);
+    const bool asc = ((base + 64u * x + lane) & k2) == 0;
+    const bool keep_min = ((lane & (u32)J) == 0) == asc;
+    if ((o < k[x]) == keep_min) k[x] = o;      // (an equal partner may be taken: nothing changes)
+  }
+  if constexpr (J > 1) cs_chunk_step<K, J / 2>(k, base, lane, k2);
+}
 template <typename K>
 __device__ __forceinline__ void cs_chunk_steps(K (&k)[2], u32 base, u32 lane, u32 k2, u32 jtop)      // steps j = jtop .. 1 of stage k2 (jtop <= 64)
 {
@@ -55,23 +76,22 @@ __device__ __forceinline__ void cs_chunk_steps(K (&k)[2], u32 base, u32 lane, u3
     if ((k[1] < k[0]) == asc) { const K t = k[0]; k[0] = k[1]; k[1] = t; }
     jtop = 32;
   }
-  for (u32 j = jtop; j > 0; j >>= 1) {
-#pragma unroll
-    for (int x = 0; x < 2; x++) {
-      const K o = cs_shfl_xor<K>(k[x], (int)j);
-      const bool asc = ((base + 64u * x + lane) & k2) == 0;
-      const bool keep_min = ((lane & j) == 0) == asc;
-      if ((o < k[x]) == keep_min && o != k[x]) k[x] = o;
-    }
+  switch (jtop) {      // (uniform over the wave)
+    case 32: cs_chunk_step<K, 32>(k, base, lane, k2); break;
+    case 16: cs_chunk_step<K, 16>(k, base, lane, k2); break;
+    case 8: cs_chunk_step<K, 8>(k, base, lane, k2); break;
+    case 4: cs_chunk_step<K, 4>(k, base, lane, k2); break;
+    case 2: cs_chunk_step<K, 2>(k, base, lane, k2); break;
+    default: cs_chunk_step<K, 1>(k, base, lane, k2); break;
   }
 }
-template <typename K>
+template <typename K, int TPB = CS_TPB>
 __device__ __forceinline__ void cs_sort_lds(K* s, u32 P, u32 tid)
 {
   if (P < 128u) {
     for (u32 k2 = 2; k2 <= P; k2 <<= 1)
       for (u32 j = k2 >> 1; j > 0; j >>= 1) {
-        for (u32 t = tid; t < P / 2; t += CS_TPB) {
+        for (u32 t = tid; t < P / 2; t += TPB) {
           const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), c = a | j;
           const K x = s[a], y = s[c];
           if ((x > y) == ((a & k2) == 0)) { s[a] = y; s[c] = x; }
@@ -81,7 +101,7 @@ __device__ __forceinline__ void cs_sort_lds(K* s, u32 P, u32 tid)
     return;
   }
   const u32 lane = tid & 63u, wave = tid >> 6;
-  for (u32 base = wave * 128u; base < P; base += (CS_TPB / 64) * 128u) {
+  for (u32 base = wave * 128u; base < P; base += (TPB / 64) * 128u) {
     K k[2] = {s[base + lane], s[base + 64u + lane]};
     for (u32 k2 = 2; k2 <= 128u; k2 <<= 1) cs_chunk_steps<K>(k, base, lane, k2, k2 >> 1);
     s[base + lane] = k[0]; s[base + 64u + lane] = k[1];
@@ -89,14 +109,14 @@ __device__ __forceinline__ void cs_sort_lds(K* s, u32 P, u32 tid)
   __syncthreads();
   for (u32 k2 = 256; k2 <= P; k2 <<= 1) {
     for (u32 j = k2 >> 1; j >= 128u; j >>= 1) {
-      for (u32 t = tid; t < P / 2; t += CS_TPB) {
+      for (u32 t = tid; t < P / 2; t += TPB) {
         const u32 a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), c = a | j;
         const K x = s[a], y = s[c];
         if ((x > y) == ((a & k2) == 0)) { s[a] = y; s[c] = x; }
       }
       __syncthreads();
     }
-    for (u32 base = wave * 128u; base < P; base += (CS_TPB / 64) * 128u) {
+    for (u32 base = wave * 128u; base < P; base += (TPB / 64) * 128u) {
       K k[2] = {s[base + lane], s[base + 64u + lane]};
       cs_chunk_steps<K>(k, base, lane, k2, 64u);
       s[base + lane] = k[0]; s[base + 64u + lane] = k[1];
@@ -105,8 +125,9 @@ __device__ __forceinline__ void cs_sort_lds(K* s, u32 P, u32 tid)
   }
 }
 
+constexpr int CS_SPL_TPB = 1024;          // (a workgroup per partition: few of them for few large partitions -- the sort of the samples is the kernel's time)
 template <typename K>
-__global__ __launch_bounds__(CS_TPB)
+__global__ __launch_bounds__(CS_SPL_TPB)
 void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, K* __restrict__ splitters)
 {
   constexpr u32 SMAX = (u32)CsCap<K>::sample;
@@ -114,12 +135,12 @@ void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts
   const CsPart P = parts[blockIdx.x];
   if (P.nb <= 1) return;
   const u32 tid = threadIdx.x;
-  u32 S = 16 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 16 per bucket (8 for the largest partitions)
-  for (u32 i = tid; i < S; i += CS_TPB) sm[i] = keys[P.key0 + (u32)(((u64)i * P.nkeys) / S)];
+  u32 S = 4 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 4-8 per bucket (the sort of the samples is this kernel; a bucket twice its aim still fits the wave kernel)
+  for (u32 i = tid; i < S; i += CS_SPL_TPB) sm[i] = keys[P.key0 + (u32)(((u64)i * P.nkeys) / S)];
   __syncthreads();
-  cs_sort_lds<K>(sm, S, tid);
+  cs_sort_lds<K, CS_SPL_TPB>(sm, S, tid);
   // bucket b holds the keys k with splitter[b - 1] <= k < splitter[b]
-  for (u32 b = tid; b + 1 < P.nb; b += CS_TPB) splitters[(u64)P.bucket0 + b] = sm[(u32)(((u64)(b + 1) * S) / P.nb)];
+  for (u32 b = tid; b + 1 < P.nb; b += CS_SPL_TPB) splitters[(u64)P.bucket0 + b] = sm[(u32)(((u64)(b + 1) * S) / P.nb)];
 }
 
 template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32 nb, K k)
@@ -133,7 +154,7 @@ template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32
 // (Round 3 tried ordering the chunk by bucket in LDS first, so that the ~5 keys a chunk holds for a bucket leave as adjacent lanes
 //  of one store: 0.32 -> 0.36 ms for the 24 M k-mer sample -- the pieces are as small either way; not kept.)
 template <typename K, bool SCATTER>
-__global__ __launch_bounds__(CS_TPB)
+__global__ __launch_bounds__(CS_WALK_TPB)
 void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, const CsChunk* __restrict__ chunks, const K* __restrict__ splitters,
                u32* __restrict__ counts_or_cursor, K* __restrict__ out)
 {
@@ -143,21 +164,21 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   const CsChunk C = chunks[blockIdx.x];
   const CsPart P = parts[C.part];
   const u32 tid = threadIdx.x;
-  for (u32 b = tid; b < P.nb; b += CS_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
+  for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
   __syncthreads();
-  K k[CS_CHUNK / CS_TPB]; u32 bk[CS_CHUNK / CS_TPB], rk[CS_CHUNK / CS_TPB];
+  K k[CS_CHUNK / CS_WALK_TPB]; u32 bk[CS_CHUNK / CS_WALK_TPB], rk[CS_CHUNK / CS_WALK_TPB];
 #pragma unroll
-  for (int x = 0; x < CS_CHUNK / CS_TPB; x++) {
-    const u32 i = tid + x * CS_TPB;
+  for (int x = 0; x < CS_CHUNK / CS_WALK_TPB; x++) {
+    const u32 i = tid + x * CS_WALK_TPB;
     bk[x] = 0xFFFFFFFFu;
     if (i < C.nkeys) { k[x] = keys[C.key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<K>(spl, P.nb, k[x]) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
   }
   __syncthreads();
-  if (!SCATTER) { for (u32 b = tid; b < P.nb; b += CS_TPB) if (hist[b]) atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]); return; }
-  for (u32 b = tid; b < P.nb; b += CS_TPB) base[b] = hist[b] ? atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]) : 0u;
+  if (!SCATTER) { for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) if (hist[b]) atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]); return; }
+  for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) base[b] = hist[b] ? atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]) : 0u;
   __syncthreads();
 #pragma unroll
-  for (int x = 0; x < CS_CHUNK / CS_TPB; x++) if (bk[x] != 0xFFFFFFFFu) out[base[bk[x]] + rk[x]] = k[x];
+  for (int x = 0; x < CS_CHUNK / CS_WALK_TPB; x++) if (bk[x] != 0xFFFFFFFFu) out[base[bk[x]] + rk[x]] = k[x];
 }
 
 // exclusive scan of n u32 values (n <= a few 100 k): one workgroup, 1024 threads; out[n] = total.  What the caller would otherwise
@@ -166,16 +187,30 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
 __global__ __launch_bounds__(1024)
 void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __restrict__ out2, const u32* __restrict__ flag)
 {
-  __shared__ u32 part[1024];
-  const u32 tid = threadIdx.x, per = (n + 1023) / 1024;
-  u32 s = 0;
-  for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) s += in[i];
-  part[tid] = s;
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry_s;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
   __syncthreads();
-  if (tid == 0) { u32 a = 0; for (u32 t = 0; t < 1024; t++) { const u32 v = part[t]; part[t] = a; a += v; } out[n] = a; if (flag) out[n + 1] = *flag; }
-  __syncthreads();
-  u32 a = part[tid];
-  for (u32 i = tid * per; i < min(n, (tid + 1) * per); i++) { const u32 v = in[i]; out[i] = a; if (out2) out2[i] = a; a += v; }
+  for (u32 t0 = 0; t0 < n; t0 += 4096u) {      // tiles of 4 consecutive values per thread: coalesced both ways
+    const u32 i = t0 + tid * 4u;
+    u32 v[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) v[x] = i + x < n ? in[i + x] : 0u;
+    const u32 s = v[0] + v[1] + v[2] + v[3];
+    const u32 incl = wave_incl_scan(s, (int)lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 a = carry_s + incl - s, tot = 0;
+#pragma unroll
+    for (u32 w = 0; w < 16; w++) { const u32 x = wsum[w]; if (w < wave) a += x; tot += x; }
+#pragma unroll
+    for (int x = 0; x < 4; x++) { if (i + x < n) { out[i + x] = a; if (out2) out2[i + x] = a; } a += v[x]; }
+    __syncthreads();
+    if (tid == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (tid == 0) { out[n] = carry_s; if (flag) out[n + 1] = *flag; }
 }
 
 // ---- a bucket by sorting: keys into LDS, bitonic sort, run starts by neighbour compare, run lengths = counts (n <= CsCap<K>::cap).
@@ -242,7 +277,7 @@ __device__ __forceinline__ void cs_bucket_by_sort(K* sk, u32* starts, u32* wsum,
 template <typename K>
 __global__ __launch_bounds__(CS_TPB)
 void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
-               unsigned long long* __restrict__ hist, u32* __restrict__ overflow)
+               unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */)
 {
   constexpr int CAP = CsCap<K>::cap;
   __shared__ K sk[CAP];
@@ -251,6 +286,7 @@ void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 ha
   __shared__ u32 hh[258];          // abundance histogram of the bucket's runs (hist != nullptr): see kmx_ctx::d_hist
   const u32 b = blockIdx.x;
   const u32 o = boff[b], n = boff[b + 1] - o;
+  if (lo && n <= lo) return;
   if (n == 0) { if (threadIdx.x == 0) nkept[b] = 0; return; }
   if (n > (u32)CAP) { if (threadIdx.x == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } return; }
   cs_bucket_by_sort<K>(sk, starts, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
@@ -269,7 +305,7 @@ static_assert(CS_HT == (1 << 11), "cs_hash takes the top 11 bits of the product"
 
 __global__ __launch_bounds__(CS_TPB)
 void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, u64* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
-                     unsigned long long* __restrict__ hist, u32* __restrict__ overflow)
+                     unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */)
 {
   constexpr int CAP = CsCap<u64>::cap;
   __shared__ u64 la[CAP];          // hash set keys [0, CS_HT) + the distinct keys' dense copy [CS_HT, 2 * CS_HT)  |  the sort path's keys
@@ -281,6 +317,7 @@ void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff
   static_assert(2 * CS_HT <= CAP, "the dense copy lies behind the hash set");
   const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 o = boff[b], n = boff[b + 1] - o;
+  if (lo && n <= lo) return;
   if (n == 0) { if (tid == 0) nkept[b] = 0; return; }
   const u64 EMPTY = ~0ULL;           // (no canonical k-mer and no window hash is all ones)
   for (u32 i = tid; i < (u32)CS_HT; i += CS_TPB) { la[i] = EMPTY; lb[i] = 0; }
@@ -363,6 +400,124 @@ void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff
   if (tid == 0) nkept[b] = tot;
   if (hist) {
     for (u32 i = tid; i < 258; i += CS_TPB) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
+  }
+}
+
+// ---- a bucket by ONE WAVE, the keys in registers (round 3, second half).  The kernels above give a bucket to a workgroup and
+//      sort or hash it in LDS: ~1000 keys per bucket are 4 per thread, and a dozen workgroup barriers with three workgroups per CU
+//      (48 KB of LDS each) is what their time is made of (0.39 ms for a 24 M k-mer sample: 0.5 TB/s).  Here a wave holds NPL keys
+//      per lane (64 * NPL >= the bucket; loaded coalesced -- a sorting network takes any initial order), runs a bitonic network over
+//      them in the blocked layout (element e = lane * NPL + x: steps closer than NPL are compare-exchanges between a lane's own
+//      registers, the others one lane shuffle per register), and reads the runs off the sorted registers: run starts by neighbour
+//      compare (one shuffle for the lane's first key), the length of a lane's last run from a ballot of the lanes that hold a start.
+//      No LDS, no barrier (the abundance histogram, when asked for, is the exception), occupancy bound by registers only.
+//      Two launches cover the sizes (the register file is sized by a kernel's largest NPL): LO < n <= 64 * NPL_B, a wave picking
+//      NPL_A (n <= 64 * NPL_A) or NPL_B.  Larger buckets raise *overflow as before. ----
+template <typename K> __device__ __forceinline__ K cs_shfl_up1(K k);
+template <> __device__ __forceinline__ u64 cs_shfl_up1<u64>(u64 k) { return (u64)__shfl_up((unsigned long long)k, 1); }
+template <> __device__ __forceinline__ __uint128_t cs_shfl_up1<__uint128_t>(__uint128_t k)
+{
+  const u64 lo = (u64)__shfl_up((unsigned long long)(u64)k, 1), hi = (u64)__shfl_up((unsigned long long)(u64)(k >> 64), 1);
+  return ((__uint128_t)hi << 64) | lo;
+}
+
+// the network, a step per instantiation (stage K2, distance J): every register index is a constant
+template <typename K, int NPL, u32 K2, u32 J>
+__device__ __forceinline__ void cs_wave_net(K (&k)[NPL], u32 lane)
+{
+  constexpr u32 N = 64u * NPL;
+  if constexpr (J >= (u32)NPL) {          // partner: the same register of lane ^ (J / NPL)
+    constexpr u32 m = J / (u32)NPL;
+    const bool asc = K2 >= N ? true : ((lane & (K2 / (u32)NPL)) == 0);      // (K2 > J >= NPL: the direction is a lane bit)
+    const bool keep_min = ((lane & m) == 0) == asc;
+#pragma unroll
+    for (int x = 0; x < NPL; x++) {
+      const K p = CsXor<K, (int)m>::get(k[x]);
+      if ((p < k[x]) == keep_min) k[x] = p;      // (an equal partner may be taken: nothing changes)
+    }
+  } else {                                // both keys are mine
+#pragma unroll
+    for (int x = 0; x < NPL; x++) {
+      if ((x & (int)J) == 0) {
+        const bool asc = K2 >= (u32)NPL ? (K2 >= N ? true : ((lane & (K2 / (u32)NPL)) == 0)) : (((u32)x & K2) == 0);
+        const K a = k[x], c = k[x | (int)J];
+        if ((c < a) == asc) { k[x] = c; k[x | (int)J] = a; }
+      }
+    }
+  }
+  if constexpr (J > 1) cs_wave_net<K, NPL, K2, J / 2>(k, lane);
+  else if constexpr (K2 < N) cs_wave_net<K, NPL, K2 * 2, K2>(k, lane);
+}
+
+template <typename K, int NPL>
+__device__ __forceinline__ void cs_wave_bucket(const K* __restrict__ bkeys, u32 o, u32 n, u32 b, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc,
+                                               u32* __restrict__ nkept, u32* hh /* LDS histogram or null */)
+{
+  const u32 lane = threadIdx.x & 63u;
+  K k[NPL];
+#pragma unroll
+  for (int x = 0; x < NPL; x++) { const u32 i = (u32)x * 64u + lane; k[x] = i < n ? bkeys[o + i] : cs_max<K>(); }
+  cs_wave_net<K, NPL, 2, 1>(k, lane);      // bitonic network, blocked layout
+  // run starts among the n real keys (positions decide: pads sort last, a real key may equal the pad value)
+  const u32 e0 = lane * (u32)NPL;
+  const K prev0 = cs_shfl_up1<K>(k[NPL - 1]);
+  u64 sm = 0;                                   // bit x: a run starts at my key x
+#pragma unroll
+  for (int x = 0; x < NPL; x++) {
+    const bool st = (e0 + (u32)x < n) && (x == 0 ? (lane == 0 || k[0] != prev0) : (k[x] != k[x - 1]));
+    sm |= (u64)(st ? 1u : 0u) << x;
+  }
+  // the run that is open at the end of my keys goes on to the next start: in the first lane behind me that holds one, or to n
+  const u64 has = __ballot(sm != 0);
+  const u64 above = lane == 63 ? 0ULL : (has >> (lane + 1)) << (lane + 1);
+  const u32 nl = above ? (u32)__builtin_ctzll(above) : 64u;
+  const u32 fs = sm ? (u32)__builtin_ctzll(sm) : 0u;
+  const u32 nfs = (u32)__shfl((int)fs, (int)(nl & 63u));
+  const u32 next_start = above ? nl * (u32)NPL + nfs : n;      // element index where the run open at my end stops
+  u32 kept = 0;
+#pragma unroll
+  for (int x = 0; x < NPL; x++) {
+    if ((sm >> x) & 1ULL) {
+      const u64 later = x == 63 ? 0ULL : (sm >> (x + 1));
+      const u32 len = later ? (u32)__builtin_ctzll(later) + 1u : next_start - (e0 + (u32)x);
+      if (len >= hard_min) kept++;
+      if (hh) { if (len <= 255u) atomicAdd(&hh[len], 1u); else { atomicAdd(&hh[256], 1u); atomicAdd(&hh[257], len); } }
+    }
+  }
+  const u32 incl = wave_incl_scan(kept, (int)lane);
+  u32 w0 = o + incl - kept;
+#pragma unroll
+  for (int x = 0; x < NPL; x++) {
+    if ((sm >> x) & 1ULL) {
+      const u64 later = x == 63 ? 0ULL : (sm >> (x + 1));
+      const u32 len = later ? (u32)__builtin_ctzll(later) + 1u : next_start - (e0 + (u32)x);
+      if (len >= hard_min) { tk[w0] = k[x]; tc[w0] = len; w0++; }
+    }
+  }
+  if (lane == 63) nkept[b] = incl;
+}
+
+constexpr int CS_WAVES = 4;      // buckets (waves) per workgroup
+template <typename K, int NPL_A, int NPL_B>
+__global__ __launch_bounds__(64 * CS_WAVES)
+void k_cs_wave_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 n_buckets, u32 lo /* this launch takes lo < n <= 64 * NPL_B */, u32 cap,
+                    u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept, unsigned long long* __restrict__ hist, u32* __restrict__ overflow)
+{
+  __shared__ u32 hh[258];
+  const u32 tid = threadIdx.x, b = blockIdx.x * CS_WAVES + (tid >> 6);
+  if (hist) { for (u32 i = tid; i < 258; i += 64 * CS_WAVES) hh[i] = 0; __syncthreads(); }
+  if (b < n_buckets) {
+    const u32 o = boff[b], n = boff[b + 1] - o;
+    if (n == 0) { if (lo == 0 && (tid & 63u) == 0) nkept[b] = 0; }
+    else if (n > cap) { if (lo == 0 && (tid & 63u) == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } }
+    else if (n > lo && n <= 64u * NPL_B) {
+      if (n <= 64u * NPL_A) cs_wave_bucket<K, NPL_A>(bkeys, o, n, b, hard_min, tk, tc, nkept, hist ? hh : nullptr);
+      else cs_wave_bucket<K, NPL_B>(bkeys, o, n, b, hard_min, tk, tc, nkept, hist ? hh : nullptr);
+    }
+  }
+  if (hist) {
+    __syncthreads();
+    for (u32 i = tid; i < 258; i += 64 * CS_WAVES) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
   }
 }
 

@@ -112,6 +112,20 @@ template <int KW> __device__ __forceinline__ Key<KW> wave_min_key(Key<KW> k) {
   }
   return k;
 }
+// the value of lane (l ^ M), M a constant power of two: DPP moves inside a row of 16 lanes, the gfx950 permlane swaps across rows --
+// VALU instructions, where __shfl_xor goes through the LDS crossbar (ds_bpermute_b32: an address register and a slot of the CU's
+// one LDS pipe per dword).  scripts/dev/xor_lanes.hip checks them on the device.
+template <int M> __device__ __forceinline__ u32 xor_lane_u32(u32 v) {
+  static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "a power of two below 64");
+  if constexpr (M == 1) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);            // quad_perm:[1,0,3,2]
+  else if constexpr (M == 2) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);       // quad_perm:[2,3,0,1]
+  else if constexpr (M == 4)                                                                            // row_half_mirror (^ 7), then quad_perm:[3,2,1,0] (^ 3)
+    return (u32)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+  else if constexpr (M == 8) return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);       // row_ror:8
+  else if constexpr (M == 16) { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (threadIdx.x & 16u) ? r[0] : r[1]; }
+  else { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (threadIdx.x & 32u) ? r[0] : r[1]; }
+}
+template <int M> __device__ __forceinline__ u64 xor_lane_u64(u64 v) { return (u64)xor_lane_u32<M>((u32)v) | ((u64)xor_lane_u32<M>((u32)(v >> 32)) << 32); }
 __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { u32 t = __shfl_up(v, off); if (lane >= off) v += t; }

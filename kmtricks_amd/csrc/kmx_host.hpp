@@ -65,7 +65,9 @@ hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hip
 struct kmx_count_req { kmx::u32 k; int hash_mode; kmx::u64 window; kmx::u32 hard_min; uint64_t** keys; uint32_t** counts; uint64_t* n_out;
                        kmx_store* const* stores = nullptr; kmx::u32 n_stores = 0; kmx_list* lists = nullptr; };
 int kmx_count_from_device(kmx_ctx* ctx, const kmx::u8* d_recs, const kmx::u64* d_prefix, const kmx::u16* d_part, kmx::u32 n_recs,
-                          kmx::u64 total_kmers, kmx::u32 n_parts, const kmx::u64* part_kmer_off /* n_parts + 1, host */, const kmx_count_req& rq);
+                          kmx::u64 total_kmers, kmx::u32 n_parts, const kmx::u64* part_kmer_off /* n_parts + 1, host */, const kmx_count_req& rq,
+                          const kmx::u32* d_sbase = nullptr /* set: no record stream -- d_recs are the batch's bases packed by kmx_launch_pack_bases, record i starts at base d_sbase[i] */);
+void kmx_launch_pack_bases(const char* d_bases, kmx::u64 n, kmx::u64* out /* (n + 31) / 32 + 2 words */, hipStream_t st);
 
 // ---- context -------------------------------------------------------------------------------------
 struct kmx_pool_block { void* p; size_t bytes; bool used; };

@@ -228,10 +228,10 @@ __global__ void k_superk_gather_sizes(const u32* __restrict__ ids, const u32* __
 }
 // partition-sorted order: (k-mers << 32 | bytes) per record, so one scan yields both prefixes (both totals < 2^32)
 __global__ void k_superk_gather_sizes2(const u32* __restrict__ ids, const u32* __restrict__ sizes_unsorted, const SkDesc* __restrict__ desc,
-                                       u32 n, u64* __restrict__ sizes_sorted)
+                                       u32 n, u64* __restrict__ sizes_sorted, u32* __restrict__ base_sorted /* or null */)
 {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const u32 j = ids[i]; sizes_sorted[i] = ((u64)desc[j].n << 32) | sizes_unsorted[j]; }
+  if (i < n) { const u32 j = ids[i]; const SkDesc d = desc[j]; sizes_sorted[i] = ((u64)d.n << 32) | sizes_unsorted[j]; if (base_sorted) base_sorted[i] = d.base; }
   else if (i == n) sizes_sorted[n] = 0;      // (the scan runs over n + 1 entries: launch with more than n threads)
 }
 // prefix (k-mers << 32 | bytes) at the first record of every partition (nb_parts + 1 entries) + that record's index
@@ -557,7 +557,17 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   void* d_tmp2 = ctx->dalloc(std::max(tb2, tb3) + 256); blocks.push_back(d_tmp2);
   if (!d_tmp2) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   if ((e = rocprim::radix_sort_pairs(d_tmp2, tb2, d_keys, d_keys2, d_ids, d_ids2, (size_t)nd, 0, 16, st)) != hipSuccess) return fail(e, "sort");
-  hipLaunchKernelGGL(k_superk_gather_sizes2, dim3((nd + 256) / 256), b2, 0, st, d_ids2, d_sz, d_desc, nd, d_szs);
+  // counting without the super-k-mer files: the record stream is never written -- the k-mers are cut from the bases themselves
+  // (2 bits each, k_pack_bases), a record being where its first base lies
+  const bool direct = creq && !streams_to_host;
+  u32* d_sbase = nullptr; u64* d_words = nullptr;
+  if (direct) {
+    d_sbase = (u32*)ctx->dalloc((size_t)nd * 4); d_words = (u64*)ctx->dalloc(((size_t)total_bases / 32 + 4) * 8);
+    blocks.push_back(d_sbase); blocks.push_back(d_words);
+    if (!d_sbase || !d_words) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+    kmx_launch_pack_bases(d_bases, total_bases, d_words, st);
+  }
+  hipLaunchKernelGGL(k_superk_gather_sizes2, dim3((nd + 256) / 256), b2, 0, st, d_ids2, d_sz, d_desc, nd, d_szs, d_sbase);
   if ((e = rocprim::exclusive_scan(d_tmp2, tb3, d_szs, d_boff, (u64)0, (size_t)nd + 1, rocprim::plus<u64>(), st)) != hipSuccess) return fail(e, "scan");
   u64* d_pp = (u64*)d_sum, *d_info = d_pp + P1, *d_nsp = d_info + 2 * (size_t)nb_parts; u32* d_pf = (u32*)(d_nsp + 1);
   hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf, d_nsp);
@@ -577,16 +587,17 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   { const int rc = sd.collect(ctx, st); if (rc != KMX_OK) { release(); return rc; } }
   if (pf[nb_parts] != nd) { release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
   const u64 total_bytes = tot & 0xFFFFFFFFULL;
-  u8* d_out = (u8*)ctx->dalloc(total_bytes + 16); blocks.push_back(d_out);
+  u8* d_out = direct ? nullptr : (u8*)ctx->dalloc(total_bytes + 16);
+  if (!direct) blocks.push_back(d_out);
   u8* h_out = streams_to_host ? (u8*)ctx->halloc(total_bytes + 16) : nullptr;
-  if (!d_out || (streams_to_host && !h_out)) { ctx->hfree(h_out); release(); return ctx->fail(KMX_E_NOMEM, "superk: allocation failed"); }
-  hipLaunchKernelGGL(k_superk_pack, g2, b2, 0, st, d_bases, d_desc, d_ids2, d_boff, nd, (int)k, d_out);
+  if ((!direct && !d_out) || (streams_to_host && !h_out)) { ctx->hfree(h_out); release(); return ctx->fail(KMX_E_NOMEM, "superk: allocation failed"); }
+  if (!direct) hipLaunchKernelGGL(k_superk_pack, g2, b2, 0, st, d_bases, d_desc, d_ids2, d_boff, nd, (int)k, d_out);
   if ((e = hipGetLastError()) != hipSuccess) { ctx->hfree(h_out); return fail(e, "k_superk_pack"); }
   clk.mark("pack");
   for (u32 p = 0; p < nb_parts; p++) out_kmers[p] = (pp[p + 1] >> 32) - (pp[p] >> 32);
   if (creq) {   // count straight from the device-resident stream (kmx_count_reads)
     std::vector<u64> pko((size_t)nb_parts + 1); for (u32 p = 0; p <= nb_parts; p++) pko[p] = pp[p] >> 32;
-    const int rc = kmx_count_from_device(ctx, d_out, d_boff, d_keys2, nd, tot >> 32, nb_parts, pko.data(), *creq);
+    const int rc = kmx_count_from_device(ctx, direct ? (const u8*)d_words : d_out, d_boff, d_keys2, nd, tot >> 32, nb_parts, pko.data(), *creq, d_sbase);
     if (rc != KMX_OK) { ctx->hfree(h_out); release(); return rc; }
     clk.mark("count");
   }
