@@ -744,12 +744,17 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 #ifndef KMX_CK_Z
 #define KMX_CK_Z 16
 #endif
+#ifndef KMX_CK_OCC1
+#define KMX_CK_OCC1 4
+#endif
 constexpr int CK_TPB = KMX_CK_TPB;
 constexpr int CK_Z = KMX_CK_Z;           // workgroups sharing the slice groups of a range
 constexpr int CK_SPEC = KW == 1 ? 5 : 4;               // entries per thread requested together with the slice's count
-constexpr int CK_CAND = KW == 1 ? 2048 : 1024;      // candidates per pass (24 KB of LDS with their payloads)
+constexpr int CK_CAND = 2048;            // candidates per pass (32 or 48 KB of LDS with their payloads)
 constexpr int CK_B2 = 1 << 15;           // bits of the candidate map
 constexpr int CK_NPASS = 8;              // directory entries per group
+constexpr int CK_UNI = CK_BITS / 8 + CK_B2 / 8;      // bytes of the LDS block that is the key maps while candidates are chosen and the rows' staging once they are sorted
+constexpr int CK_STAGE = CK_UNI / (CK_TPB / 64);     // ... a wave's part of it (2560 bytes: 32 PA rows of 500 lists and a 128-bit key)
 
 struct SpDir { u32 base, n, dense_first, dense_n; };      // rows [base, base + n) of the arena: a pass's rows; dense_* filled in entry 0 of a group
 
@@ -814,17 +819,19 @@ __device__ __forceinline__ void ck_sort_block(CKey* ck, u64* cp, u32 P, u32 tid)
 }
 
 template <int MODE, bool RESC>
-__global__ __launch_bounds__(CK_TPB, MODE == 1 ? 4 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores)
+__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores)
 void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
 {
-  __shared__ u32 bits[CK_BITS / 32];
-  __shared__ u32 bits2[CK_B2 / 32];
+  __shared__ __attribute__((aligned(16))) u32 uni[CK_UNI / 4];      // the key maps | the row keys and interval counters (recurrence-min 1) | the rows' staging
+  u32* const bits = uni;
+  u32* const bits2 = uni + CK_BITS / 32;
   __shared__ CKey ck[CK_CAND];           // candidate keys
   __shared__ u64 cp[CK_CAND];            // ... and their (list << 32 | count)
   __shared__ u32 runs[CK_CAND];          // kept runs: first entry | length << 16 ... as two words: see below
   __shared__ u32 wsum[CK_TPB / 64];
   __shared__ u32 flag, total, ncand, rowbase, sover;
-  __shared__ u32 parow[MODE == 1 ? (CK_TPB / 16) * 136 : 1];      // PA: a row per lane group is assembled here (<= 4096 lists + key)
+  u32* const parow = uni;                // PA, rows too long for the staging below: a row per lane group is assembled here (<= 4096 lists + key)
+  static_assert((CK_TPB / 16) * 136 * 4 <= CK_UNI, "the lane groups' rows fit the block");
   auto ent_key = [](const u64* kp, u32 e) -> CKey {
 #if KMX_CL_KW == 1
     return kp[EW * e];
@@ -905,7 +912,8 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
 #define KMX_CK_PER1 1400
 #endif
     const u32 per = (thr <= 1 ? (u32)KMX_CK_PER1 : 3000u) * (u32)CK_CAND / 2048u;
-    u32 npass = 1; while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;
+    u32 npass = 1;
+    if (!(thr <= 1 && tot <= (u32)CK_CAND)) while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;      // (every entry a candidate and all of them fit: one pass, no margin needed)
     if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
     // each of my entries through f(key, payload): four threads per slice
     auto each = [&](u32 pass, auto&& f) {
@@ -938,6 +946,16 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         }
       }
     };
+    // a candidate's place: one LDS atomic per wave and call site, not one per entry (they all hit the same word)
+    auto push = [&](CKey k, u64 pl) {
+      const u64 act = __ballot(1);
+      const u32 ldr = (u32)__builtin_ctzll(act);
+      u32 b0 = 0;
+      if (lane == ldr) b0 = atomicAdd(&ncand, (u32)__popcll(act));
+      b0 = (u32)__shfl((int)b0, (int)ldr);
+      const u32 ps = b0 + (u32)__popcll(act & ((1ULL << lane) - 1ULL));
+      if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; }
+    };
     for (u32 pass = 0; pass < npass; pass++) {
       constexpr bool BY_INTERVAL = MODE == 1;      // (count rows -- 4 N bytes each -- are bound by their stores: +-0 there, 20 more registers)
       if (thr > 1) {
@@ -952,24 +970,32 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       bool sorted = false;
       u32 nc1 = 0;
       if (thr <= 1 && !BY_INTERVAL) {
-        each(pass, [&](CKey k, u64 pl) { const u32 ps = atomicAdd(&ncand, 1u); if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; } });
+        each(pass, push);
         __syncthreads();
       }
       if (thr <= 1 && BY_INTERVAL) {
-        // recurrence-min 1: every entry is a row, the sort is all there is to do -- and the group's ROW KEYS (<= 56, ascending) cut its
-        // key range into intervals of ~20 entries.  An entry finds its interval by binary search, the intervals are laid out one after
-        // the other (count, scan, place) and an entry's place inside its interval is the number of the interval's entries below it.
-        CKey* const rk = reinterpret_cast<CKey*>(bits);            // [64] the group's row keys
-        u32* const ioff = bits + 256;                               // [66] entries per interval, then where each interval starts
-        const u32 nrk = min(dn, 64u);
-        for (u32 t = tid; t < nrk; t += CK_TPB) rk[t] = reinterpret_cast<const CKey*>(C.skel)[d0 + t];
+        // recurrence-min 1: every entry is a row, the sort is all there is to do -- a SAMPLE SORT inside the workgroup.  Every
+        // (n / 256)-th entry, as gathered (slice order: no order in the keys), is a sample; the <= 256 samples are sorted (the
+        // network below, a few barriers at that size), an entry finds its interval by binary search among them, the intervals are
+        // laid out one after the other (count, scan, place) and an entry's place inside its interval is the number of the interval's
+        // entries below it (full compare: ~8 of them).  Balanced whatever the keys look like -- the k-mers of a minimizer partition
+        // crowd a few prefixes: intervals cut by the group's row keys (round 2) or by equal steps of the key's top word came out so
+        // uneven that counting "entries below me" was half of the kernel (phase profile of configs[4]: 48 % of its cycles).
+        constexpr u32 NS = 256, NIV = 320;                                   // samples; interval counters (5 per lane of wave 0)
+        u32* const ioff = bits;                                               // [NIV + 1] entries per interval, then where each interval starts
+        CKey* const sk = reinterpret_cast<CKey*>(bits + 1024);                // [NS] the samples
+        u64* const sp = reinterpret_cast<u64*>(bits + 1024 + NS * (sizeof(CKey) / 4));      // [NS] (their payloads: the network sorts pairs)
+        // (the entries are gathered first, as they come: then every thread of the workgroup has its four to work on at once)
+        each(pass, push);
         __syncthreads();
-        // (the entries are gathered first, as they come: then every thread of the workgroup has its two or four to work on at once)
-        each(pass, [&](CKey k, u64 pl) { const u32 ps = atomicAdd(&ncand, 1u); if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; } });
-        __syncthreads();
+        SPPH(7);
         nc1 = ncand;
         if (nc1 <= (u32)CK_CAND) {
           constexpr int PER = CK_CAND / CK_TPB;      // entries per thread
+          const u32 stride = (nc1 + NS - 1) / NS, ns = (nc1 + stride - 1) / stride, SP = ns <= 128u ? 128u : 256u;
+          for (u32 t = tid; t < SP; t += CK_TPB) { sk[t] = t < ns ? ck[t * stride] : ck_inf(); sp[t] = t < ns ? cp[t * stride] : ~0ULL; }      // (key AND payload: a key that hundreds of lists hold is cut into intervals like any other stretch)
+          __syncthreads();
+          ck_sort_block(sk, sp, SP, tid);
           CKey mk[PER]; u64 mp[PER]; u32 mb[PER], mo[PER];
 #pragma unroll
           for (int x = 0; x < PER; x++) {
@@ -977,17 +1003,17 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
             mk[x] = ck_inf(); mp[x] = 0; mb[x] = 0xFFFFFFFFu; mo[x] = 0;
             if (i < nc1) { mk[x] = ck[i]; mp[x] = cp[i]; }
           }
-          {   // the binary searches of my entries side by side (7 fixed steps cover 64 row keys: their LDS reads overlap)
+          {   // the binary searches of my entries side by side (9 fixed steps cover 256 samples: their LDS reads overlap)
             u32 lo[PER], hi[PER];
 #pragma unroll
-            for (int x = 0; x < PER; x++) { lo[x] = 0; hi[x] = nrk; }
+            for (int x = 0; x < PER; x++) { lo[x] = 0; hi[x] = ns; }
 #pragma unroll
-            for (int it = 0; it < 7; it++) {
+            for (int it = 0; it < 9; it++) {
 #pragma unroll
               for (int x = 0; x < PER; x++) {
                 const u32 m = (lo[x] + hi[x]) >> 1;
                 const bool open = lo[x] < hi[x];
-                const bool below = open && ck_lt(rk[min(m, 63u)], mk[x]);
+                const bool below = open && ck_less(sk[min(m, NS - 1u)], sp[min(m, NS - 1u)], mk[x], mp[x]);
                 lo[x] = below ? m + 1 : lo[x];
                 hi[x] = (open && !below) ? m : hi[x];
               }
@@ -996,18 +1022,21 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
             for (int x = 0; x < PER; x++) if (tid + (u32)x * CK_TPB < nc1) { mb[x] = lo[x]; mo[x] = atomicAdd(&ioff[lo[x]], 1u); }      // my number in my interval
           }
           __syncthreads();
-          if (tid < 64) {      // wave 0: sizes -> offsets (65 intervals: lane 0 takes the last one as well)
-            const u32 v = ioff[tid];
-            const u32 incl = wave_incl_scan(v, (int)tid);
-            const u32 t64 = (u32)__shfl((int)incl, 63);
-            const u32 last = ioff[64];
-            ioff[tid] = incl - v;
-            if (tid == 0) { ioff[64] = t64; ioff[65] = t64 + last; }
+          if (tid < 64) {      // wave 0: sizes -> offsets, five intervals per lane
+            u32 v[5]; u32 sum = 0;
+#pragma unroll
+            for (int x = 0; x < 5; x++) { v[x] = ioff[tid * 5 + x]; sum += v[x]; }
+            const u32 incl = wave_incl_scan(sum, (int)tid);
+            u32 a = incl - sum;
+#pragma unroll
+            for (int x = 0; x < 5; x++) { ioff[tid * 5 + x] = a; a += v[x]; }
+            if (tid == 63) ioff[NIV] = incl;
           }
           __syncthreads();
 #pragma unroll
           for (int x = 0; x < PER; x++) if (mb[x] != 0xFFFFFFFFu) { const u32 ps = ioff[mb[x]] + mo[x]; ck[ps] = mk[x]; cp[ps] = mp[x]; }      // interval after interval
           __syncthreads();
+          SPPH(2);
           u32 mr[PER];
 #pragma unroll
           for (int x = 0; x < PER; x++) {
@@ -1039,8 +1068,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       if (thr > 1) {
         each(pass, [&](CKey k, u64 pl) {
           const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
-          const u32 ps = atomicAdd(&ncand, 1u);
-          if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; }
+          push(k, pl);
         });
         __syncthreads();
       }
@@ -1097,7 +1125,58 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       __syncthreads();
       const u32 rb = rowbase;
       SPPH(5);
-      if (nk && rb != 0xFFFFFFFFu) {
+      if (MODE == 1 && nk && rb != 0xFFFFFFFFu && row_bytes * 8u + 16u <= (u32)CK_STAGE) {
+        // PA rows (N / 8 bytes behind the key, not a multiple of anything): the pass's rows are one contiguous run of the arena, so a
+        // wave assembles RW of them at a time in its own LDS block -- laid out as they will lie in memory, shifted by the run's
+        // offset inside its first 16-byte word -- with a lane per row (the key's dwords and the lists' bits are OR-ed into the
+        // zeroed block: <= 9 LDS atomics for a private k-mer's row), and streams the block out as aligned 16-byte words; only the
+        // first and the last word of a block share their 16 bytes with rows of other waves and go out byte by byte.  (Before:
+        // 8 lanes per row storing single dwords at odd offsets -- partial sectors, 1.47x the bytes.)  No workgroup barrier.
+        u32* const st = uni + wave * (CK_STAGE / 4);
+        const u32 RW = min(64u, ((u32)CK_STAGE - 16u) / row_bytes);
+        for (u32 j0 = wave * RW; j0 < nk; j0 += (CK_TPB / 64) * RW) {
+          const u32 nr = min(RW, nk - j0);
+          u8* const g0 = T.out + (u64)(rb + j0) * row_bytes;
+          const u32 phase = (u32)((uintptr_t)g0 & 15u), nby = nr * row_bytes, nw16 = (phase + nby + 15u) / 16u;
+          for (u32 w = lane; w < nw16; w += 64) reinterpret_cast<uint4*>(st)[w] = make_uint4(0, 0, 0, 0);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the zeros are in before the ORs
+          if (lane < nr) {
+            const u32 rv = runs[j0 + lane], i0 = rv & 0xFFFFu, len = rv >> 16;
+            const u32 b = phase + lane * row_bytes;
+            u32 kw4[4] = {0, 0, 0, 0};
+            ck_store(kw4, ck[i0]);
+            const u32 sh = (b & 3u) * 8u;
+#pragma unroll
+            for (u32 d = 0; d < 2u * KW; d++) {
+              const u32 w = kw4[d], ix = (b >> 2) + d;
+              if (w << sh) atomicOr(&st[ix], w << sh);
+              if (sh && (w >> (32u - sh))) atomicOr(&st[ix + 1], w >> (32u - sh));
+            }
+            for (u32 e = 0; e < len; e++) {
+              const u64 pl = cp[i0 + e];
+              if (RESC && !(u32)pl) continue;      // (a non-solid record that is not rescued, or recurrence-min 0's lone non-solid record: no bit)
+              const u32 li = pl_list(pl), bo = b + 8u * KW + (li >> 3);
+              atomicOr(&st[bo >> 2], 1u << ((bo & 3u) * 8u + (li & 7u)));
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          u8* const a0 = g0 - phase;                                // 16-byte aligned
+          const u32 endb = phase + nby;                             // valid bytes of the block: [phase, endb)
+          for (u32 w = lane; w < nw16; w += 64) {
+            const uint4 v = reinterpret_cast<const uint4*>(st)[w];
+            const u32 lo = w * 16u, hi = lo + 16u;
+            if (lo >= phase && hi <= endb) reinterpret_cast<uint4*>(a0)[w] = v;
+            else {
+              const u32 vv[4] = {v.x, v.y, v.z, v.w};
+              for (u32 t = max(lo, phase); t < min(hi, endb); t++) a0[t] = (u8)(vv[(t - lo) >> 2] >> ((t & 3u) * 8u));
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (my reads of the block are done before the next round's zeros)
+        }
+      } else if (nk && rb != 0xFFFFFFFFu) {
         // lanes per row: a wave for a count row (4 N bytes); 16 for a PA row (N / 8 bytes), 8 when that is at most 128 bytes
         const u32 SG = MODE == 0 ? 64u : row_bytes <= 128u ? 8u : 16u;
         const u32 sg = tid / SG, sl = tid % SG;      // my lane group, my lane in it
@@ -1292,8 +1371,8 @@ void cols_phase_prof_dump()
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_prof), h, sizeof(h));
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_sparse_prof), sizeof(h)) != hipSuccess) return;
   tot = 0; for (int i = 0; i < 8; i++) tot += h[i];
-  static const char* sn[8] = {"group entries", "zero maps", "mark twice", "candidates", "sort", "runs + claim", "rows", "-"};
-  for (int i = 0; i < 7; i++) fprintf(stderr, "[sparse] %-14s %6.2f%%  %llu\n", sn[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
+  static const char* sn[8] = {"group entries", "zero maps", "mark twice | sample + place", "candidates | rank", "sort", "runs + claim", "rows", "gather (rec-min 1)"};
+  for (int i = 0; i < 8; i++) fprintf(stderr, "[sparse] %-14s %6.2f%%  %llu\n", sn[i], tot ? 100.0 * h[i] / tot : 0.0, h[i]);
   memset(h, 0, sizeof(h));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_sparse_prof), h, sizeof(h));
 }
