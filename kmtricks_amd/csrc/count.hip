@@ -452,8 +452,8 @@ template <typename KeyT> static void cs_launch_bucket_count(u32 TB, hipStream_t 
                                                             unsigned long long* hist, u32* overflow);
 static int cs_bucket_kernel()      // 0: a wave per bucket, keys in registers (k_cs_wave_sort), the LDS kernels for the buckets beyond it; 1: hash first in LDS (64-bit keys); 2: bitonic sort in LDS
 {
-  static const int v = []() { const char* e = getenv("KMX_COUNT_BUCKETS"); return !e ? 0 : !strcmp(e, "hash") ? 1 : !strcmp(e, "sort") ? 2 : 0; }();
-  return v;
+  const char* e = getenv("KMX_COUNT_BUCKETS");      // (read per call: the tests switch it)
+  return !e ? 0 : !strcmp(e, "hash") ? 1 : !strcmp(e, "sort") ? 2 : 0;
 }
 template <> void cs_launch_bucket_count<u64>(u32 TB, hipStream_t st, const u64* bkeys, const u32* boff, u32 hard_min, u64* tk, u32* tc, u32* nkept,
                                              unsigned long long* hist, u32* overflow)

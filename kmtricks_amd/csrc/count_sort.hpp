@@ -508,8 +508,8 @@ void k_cs_wave_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u
   if (hist) { for (u32 i = tid; i < 258; i += 64 * CS_WAVES) hh[i] = 0; __syncthreads(); }
   if (b < n_buckets) {
     const u32 o = boff[b], n = boff[b + 1] - o;
+    // (buckets beyond 64 * NPL_B keys are the LDS kernels': the caller launches them with lo = that; they report the ones beyond them)
     if (n == 0) { if (lo == 0 && (tid & 63u) == 0) nkept[b] = 0; }
-    else if (n > cap) { if (lo == 0 && (tid & 63u) == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } }
     else if (n > lo && n <= 64u * NPL_B) {
       if (n <= 64u * NPL_A) cs_wave_bucket<K, NPL_A>(bkeys, o, n, b, hard_min, tk, tc, nkept, hist ? hh : nullptr);
       else cs_wave_bucket<K, NPL_B>(bkeys, o, n, b, hard_min, tk, tc, nkept, hist ? hh : nullptr);
