@@ -72,7 +72,8 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
     const u32 rec_min = T.rec_min, share_min = T.share_min;
     const bool two_pass = rec_min > 1 || share_min > 0;
     const u64 W = T.upper - T.lower + 1, W8 = (W + 7) & ~7ULL;
-    const u64 tiles = (W + BT_RT - 1) / BT_RT;
+    const u32 rt = T.rt;                       // hash rows per tile (BT_RT; the host may pass fewer -- a multiple of 64)
+    const u64 tiles = (W + rt - 1) / rt;
     const u64 tiles_per = (tiles + T.c - 1) / T.c;
     const u64 tile0 = (u64)range * tiles_per, tile1 = min(tiles, tile0 + tiles_per);
     u32* const cur = curs;
@@ -91,8 +92,8 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
     u32* const myrow = img + ((u32)tid / BT_G) * BT_RW;
     bt_barrier();
     for (u64 tile = tile0; tile < tile1; tile++) {
-      const u64 tlo = T.lower + tile * BT_RT;
-      const u64 rows = min((u64)BT_RT, T.upper + 1 - tlo), thi = tlo + rows;
+      const u64 tlo = T.lower + tile * rt;
+      const u64 rows = min((u64)rt, T.upper + 1 - tlo), thi = tlo + rows;
       // a sample's first BT_UNR records per lane from its cursor on: the loads of one round, issued together
       auto issue = [&](const u8* base, u32 idx0, u32 e, BtRound& d) {
 #pragma unroll
@@ -198,7 +199,7 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // out: sample s = col0 + j gets bytes [(tlo - lower) / 8, ...) of its row -- the wave writes its samples' rows, 8 bytes per lane
-        const u32 nby = (u32)((min(tlo + (u64)BT_RT, T.lower + W8) - tlo) >> 3);      // (the last tile carries the pad bits of ceil8(W))
+        const u32 nby = (u32)((min(tlo + (u64)rt, T.lower + W8) - tlo) >> 3);      // (the last tile carries the pad bits of ceil8(W))
         constexpr u32 SPW = 64 / BT_G;                                                  // samples per wave
         for (u32 j = wave * SPW; j < min(nrows_out, (wave + 1) * SPW); j++) {
           u8* dst = T.out + (u64)(col0 + j) * (W8 >> 3) + ((tlo - T.lower) >> 3);

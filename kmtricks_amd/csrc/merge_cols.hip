@@ -913,7 +913,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
 #endif
     const u32 per = (thr <= 1 ? (u32)KMX_CK_PER1 : 3000u) * (u32)CK_CAND / 2048u;
     u32 npass = 1;
-    if (!(thr <= 1 && tot <= (u32)CK_CAND)) while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;      // (every entry a candidate and all of them fit: one pass, no margin needed)
+    if (!(MODE == 1 && thr <= 1 && tot <= (u32)CK_CAND)) while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;      // (PA rows at recurrence-min 1 -- every entry a candidate, placed by the sample sort -- when all of them fit: one pass, no margin needed)
     if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
     // each of my entries through f(key, payload): four threads per slice
     auto each = [&](u32 pass, auto&& f) {
@@ -1126,51 +1126,57 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       const u32 rb = rowbase;
       SPPH(5);
       if (MODE == 1 && nk && rb != 0xFFFFFFFFu && row_bytes * 8u + 16u <= (u32)CK_STAGE) {
-        // PA rows (N / 8 bytes behind the key, not a multiple of anything): the pass's rows are one contiguous run of the arena, so a
-        // wave assembles RW of them at a time in its own LDS block -- laid out as they will lie in memory, shifted by the run's
-        // offset inside its first 16-byte word -- with a lane per row (the key's dwords and the lists' bits are OR-ed into the
-        // zeroed block: <= 9 LDS atomics for a private k-mer's row), and streams the block out as aligned 16-byte words; only the
-        // first and the last word of a block share their 16 bytes with rows of other waves and go out byte by byte.  (Before:
-        // 8 lanes per row storing single dwords at odd offsets -- partial sectors, 1.47x the bytes.)  No workgroup barrier.
+        // PA rows (N / 8 bytes behind the key, not a multiple of anything): the pass's rows are one contiguous run of the arena.  The
+        // run's bytes are cut into 16-byte-aligned pieces of CB bytes; a wave assembles a piece in its own LDS block exactly as it
+        // will lie in memory -- a lane per row that touches the piece (a row across a cut is assembled, in part, by both sides):
+        // the key's dwords and the lists' bits are OR-ed into the zeroed block, <= 9 LDS atomics for a private k-mer's row -- and
+        // streams it out as aligned 16-byte words.  Only the run's first and last word share their 16 bytes with other groups'
+        // rows and go out byte by byte.  (Before: 8 lanes per row storing single dwords at odd offsets.)  No workgroup barrier.
         u32* const st = uni + wave * (CK_STAGE / 4);
-        const u32 RW = min(64u, ((u32)CK_STAGE - 16u) / row_bytes);
-        for (u32 j0 = wave * RW; j0 < nk; j0 += (CK_TPB / 64) * RW) {
-          const u32 nr = min(RW, nk - j0);
-          u8* const g0 = T.out + (u64)(rb + j0) * row_bytes;
-          const u32 phase = (u32)((uintptr_t)g0 & 15u), nby = nr * row_bytes, nw16 = (phase + nby + 15u) / 16u;
+        constexpr u32 CB = (u32)CK_STAGE & ~15u;
+        const uintptr_t A0 = (uintptr_t)(T.out + (u64)rb * row_bytes), Ae = A0 + (uintptr_t)nk * row_bytes, As = A0 & ~(uintptr_t)15;
+        const u32 npieces = (u32)((Ae - As + CB - 1) / CB);
+        for (u32 pc = wave; pc < npieces; pc += CK_TPB / 64) {
+          const uintptr_t lo_a = As + (uintptr_t)pc * CB, hi_a = lo_a + CB < Ae ? lo_a + CB : Ae;      // the piece: [lo_a, hi_a), lo_a aligned
+          const u32 nby = (u32)(hi_a - lo_a), nw16 = (nby + 15u) / 16u;
           for (u32 w = lane; w < nw16; w += 64) reinterpret_cast<uint4*>(st)[w] = make_uint4(0, 0, 0, 0);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the zeros are in before the ORs
-          if (lane < nr) {
-            const u32 rv = runs[j0 + lane], i0 = rv & 0xFFFFu, len = rv >> 16;
-            const u32 b = phase + lane * row_bytes;
+          // rows that touch the piece: [r0, r1]
+          const u32 r0 = lo_a > A0 ? (u32)((lo_a - A0) / row_bytes) : 0u, r1 = (u32)((hi_a - 1 - A0) / row_bytes);
+          for (u32 r = r0 + lane; r <= r1; r += 64) {
+            const u32 rv = runs[r], i0 = rv & 0xFFFFu, len = rv >> 16;
+            const int b = (int)(long long)((long long)(A0 + (uintptr_t)r * row_bytes) - (long long)lo_a);      // the row's first byte in the piece (negative: it began in the piece before)
+            auto or_dword = [&](int o, u32 w) {      // the 4 bytes of w at byte o of the piece, clipped to it
+              const int ix = o >> 2; const u32 sh = ((u32)o & 3u) * 8u;
+              const u32 w0 = w << sh, w1 = sh ? w >> (32u - sh) : 0u;
+              if (w0 && ix >= 0 && (u32)ix < nw16 * 4u) atomicOr(&st[ix], w0);
+              if (w1 && ix + 1 >= 0 && (u32)(ix + 1) < nw16 * 4u) atomicOr(&st[ix + 1], w1);
+            };
             u32 kw4[4] = {0, 0, 0, 0};
             ck_store(kw4, ck[i0]);
-            const u32 sh = (b & 3u) * 8u;
 #pragma unroll
-            for (u32 d = 0; d < 2u * KW; d++) {
-              const u32 w = kw4[d], ix = (b >> 2) + d;
-              if (w << sh) atomicOr(&st[ix], w << sh);
-              if (sh && (w >> (32u - sh))) atomicOr(&st[ix + 1], w >> (32u - sh));
-            }
+            for (u32 d = 0; d < 2u * KW; d++) or_dword(b + 4 * (int)d, kw4[d]);
             for (u32 e = 0; e < len; e++) {
               const u64 pl = cp[i0 + e];
               if (RESC && !(u32)pl) continue;      // (a non-solid record that is not rescued, or recurrence-min 0's lone non-solid record: no bit)
-              const u32 li = pl_list(pl), bo = b + 8u * KW + (li >> 3);
-              atomicOr(&st[bo >> 2], 1u << ((bo & 3u) * 8u + (li & 7u)));
+              const u32 li = pl_list(pl);
+              const int bo = b + 8 * (int)KW + (int)(li >> 3);
+              if (bo >= 0 && (u32)bo < nw16 * 16u) atomicOr(&st[bo >> 2], 1u << (((u32)bo & 3u) * 8u + (li & 7u)));
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          u8* const a0 = g0 - phase;                                // 16-byte aligned
-          const u32 endb = phase + nby;                             // valid bytes of the block: [phase, endb)
+          // (bytes of the block beyond [A0, Ae) belong to other rows: whatever was OR-ed there is not written)
+          u8* const a0 = reinterpret_cast<u8*>(lo_a);
+          const u32 vlo = A0 > lo_a ? (u32)(A0 - lo_a) : 0u;       // valid bytes of the piece: [vlo, nby)
           for (u32 w = lane; w < nw16; w += 64) {
             const uint4 v = reinterpret_cast<const uint4*>(st)[w];
             const u32 lo = w * 16u, hi = lo + 16u;
-            if (lo >= phase && hi <= endb) reinterpret_cast<uint4*>(a0)[w] = v;
+            if (lo >= vlo && hi <= nby) reinterpret_cast<uint4*>(a0)[w] = v;
             else {
               const u32 vv[4] = {v.x, v.y, v.z, v.w};
-              for (u32 t = max(lo, phase); t < min(hi, endb); t++) a0[t] = (u8)(vv[(t - lo) >> 2] >> ((t & 3u) * 8u));
+              for (u32 t = max(lo, vlo); t < min(hi, nby); t++) a0[t] = (u8)(vv[(t - lo) >> 2] >> ((t & 3u) * 8u));
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

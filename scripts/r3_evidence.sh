@@ -13,7 +13,10 @@ python scripts/bench_count_stage.py > $O/bench_count_stage_5Mbp_32.json 2>$O/err
 python scripts/bench_count_stage.py --genome 1e6 --partitions 256 > $O/bench_count_stage_1Mbp_256.json 2>>$O/err_cs.log
 python scripts/bench_count_stage.py --hash > $O/bench_count_stage_hash.json 2>>$O/err_cs.log
 python scripts/bench_count_stage.py --kmer-size 63 > $O/bench_count_stage_k63.json 2>>$O/err_cs.log
-python scripts/bench_pipeline.py --samples 1000 --genome 1e6 --partitions 256 --sync --variants ";--skip-partiinfo;--no-resident;--gpu-workers 1;--gpu-workers 3" > $O/pipeline_1000x1Mbp.jsonl 2>$O/err_pipe.log
+for B in hash sort; do KMX_COUNT_BUCKETS=$B python scripts/bench_count_stage.py > $O/bench_count_stage_5Mbp_32_buckets_$B.json 2>>$O/err_cs.log; done
+KMX_COUNT_BUCKETS=sort python scripts/bench_count_stage.py --kmer-size 63 > $O/bench_count_stage_k63_buckets_sort.json 2>>$O/err_cs.log
+python scripts/bench_pipeline.py --samples 1000 --genome 1e6 --partitions 256 --sync --variants ";;--skip-partiinfo;--no-resident;--gpu-workers 1;--gpu-workers 3" > $O/pipeline_1000x1Mbp.jsonl 2>$O/err_pipe.log
+KMX_RING_PREFILL=1 python scripts/bench_pipeline.py --samples 1000 --genome 1e6 --partitions 256 --sync > $O/pipeline_1000x1Mbp_ring_prefill.jsonl 2>>$O/err_pipe.log
 KMX_OUT_ORDER=1 python scripts/bench_pipeline.py --samples 1000 --genome 1e6 --partitions 256 --sync > $O/pipeline_1000x1Mbp_out_order.jsonl 2>>$O/err_pipe.log
 python scripts/bench_pipeline.py --samples 100 --genome 5e6 --partitions 32 --mode hash:bf:bin --bloom 1e8 --sync > $O/pipeline_100x5Mbp_bf.jsonl 2>>$O/err_pipe.log
 python scripts/bench_pipeline.py --samples 200 --genome 5e6 --partitions 256 --sync > $O/pipeline_200x5Mbp_count.jsonl 2>>$O/err_pipe.log
@@ -32,6 +35,7 @@ prof bft python $R/bench.py --workload bft --no-cpu-baseline
 prof pa63 python $R/bench.py --workload pa63 --no-cpu-baseline
 prof count_stage python $R/scripts/bench_count_stage.py
 prof count_stage_1Mbp_256 python $R/scripts/bench_count_stage.py --genome 1e6 --partitions 256
+prof count_stage_k63 python $R/scripts/bench_count_stage.py --kmer-size 63
 prof pipeline_200x1Mbp python $R/scripts/bench_pipeline.py --samples 200 --genome 1e6 --partitions 256
 pmc() { L=$1; C=$2; shift; shift; rm -rf $O/pmc_${L}_$C; mkdir -p $O/pmc_${L}_$C
   timeout 900 rocprofv3 --pmc $C -d $O/pmc_${L}_$C --output-format csv -- "$@" > $O/pmc_${L}_$C.log 2>&1; }
@@ -70,4 +74,11 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']; print(r['kernel'], round(r['kernel_ms'],3), 'ms kernel', round(d['ms_per_step'],3), 'ms/step', round(d['value']/1e9,1), 'Gk/s frac', round(r['frac'],3), ' hand-backs', back)"
 done; done ) > $O/kernel_grid.txt 2>&1
+( for PP in 32 128 256; do echo -n "N=128 partitions per launch $PP: "; timeout 300 python bench.py --workload count --lists random --samples 128 --partitions-per-gpu $PP --steps 4 --warmup 2 --no-cpu-baseline 2>&1 | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']; print(r['kernel'], round(r['kernel_ms'],3), 'ms kernel', round(d['ms_per_step'],3), 'ms/step', round(d['value']/1e9,1), 'Gk/s frac', round(r['frac'],3))"
+done ) > $O/small_cohort_batches.txt 2>&1
+bash $R/scripts/r3_pipeline_api_profile.sh > $O/pipeline_api_profile.txt 2>&1; cp $R/gpurun_out/r3_api/hip_api_stats.csv $O/pipeline_hip_api_stats.csv; cp $R/gpurun_out/r3_api/kernel_stats.csv $O/pipeline_300x1Mbp_kernel_stats.csv
 ls $O

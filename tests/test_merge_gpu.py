@@ -141,7 +141,8 @@ def test_synthetic_bf(ctx, n, dens, smin, rmin, share, mode):
 @pytest.mark.parametrize("n,dens,smin,rmin,share,W", [(2, 0.3, 1, 1, 0, 6400), (11, 0.3, 10, 3, 2, 19200), (100, 0.05, 1, 1, 0, 19264), (257, 0.02, 3, 1, 5, 1000),
                                                        (1001, 0.01, 1, 2, 0, 12345),
                                                        (2500, 0.004, 2, 1, 1, 19200),    # BASELINE configs[3]: 2500 samples, --soft-min 2 --share-min 1
-                                                       (3000, 0.003, 2, 2, 1, 40000)])   # beyond 2729 samples only the cursors sit in LDS; three tiles of 16384 rows
+                                                       (3000, 0.003, 2, 2, 1, 40000),    # beyond 2729 samples only the cursors sit in LDS; three tiles of 16384 rows
+                                                       (40, 0.002, 1, 2, 1, 300 * 16384 + 777)])   # 301 tiles of 16384 rows: more tiles than workgroups
 def test_synthetic_bft(ctx, merge_kernel, n, dens, smin, rmin, share, W):
     """hash:bft:bin -- HashMerger::write_as_bft (merge.hpp:631-644): the BF rows bit-transposed on the device
     (k_merge_bf -> k_bit_transpose without leaving HBM); windows that are no multiple of 8 / 64 / the tile"""
