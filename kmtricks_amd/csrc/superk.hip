@@ -89,16 +89,34 @@ struct SkStats {          // device tables, zeroed by the caller; any of them ma
   u32* mx;                // [4^m] kx-mers per minimizer
 };
 
-template <bool EMIT, bool STATS>
+// LB (one pass instead of count + scan + emit): a wave keeps its read's descriptors in LDS, the workgroup's four reads get their
+// place among all descriptors -- in read order, as the two-pass path gives it -- by a decoupled look-back over the workgroups:
+// a workgroup takes a ticket (its number: the reads 4 t .. 4 t + 3), publishes how many descriptors it has (flag 1), adds up its
+// predecessors' numbers until one of them has published its inclusive prefix (flag 2), publishes its own.  A workgroup only waits
+// for workgroups with smaller tickets, which are running.  The last state word holds the total.
+struct SkLook { unsigned long long* state; u32* ticket; u32* over; u32 cap; };      // state[workgroup]: flag << 62 | count or prefix; cap: descriptors that fit
+constexpr u32 SK_WCAP = 512;      // descriptors of one read the LDS takes (the host sends longer reads the two-pass way)
+template <bool EMIT, bool STATS, bool LB = false>
 __global__ __launch_bounds__(256)
 void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
                    int k, int m, int maxs, const u16* __restrict__ repart,
-                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so)
+                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so, SkLook lk)
 {
-  const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  __shared__ SkDesc wbuf[LB ? 4 : 1][LB ? SK_WCAP : 1];
+  __shared__ u32 wcnt[4];
+  __shared__ u32 bid_s, base_s;
+  static_assert(!LB || EMIT, "the look-back places descriptors");
   const int lane = threadIdx.x & 63;
-  if (r >= n_seqs) return;
-  const u64 b0 = offsets[r], len = offsets[r + 1] - b0;
+  const u32 wave = threadIdx.x >> 6;
+  u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (LB) {
+    if (threadIdx.x == 0) bid_s = atomicAdd(lk.ticket, 1u);
+    __syncthreads();
+    r = (u64)bid_s * 4u + wave;
+  }
+  if (!LB && r >= n_seqs) return;
+  const bool act = r < n_seqs;
+  const u64 b0 = act ? offsets[r] : 0, len = act ? offsets[r + 1] - b0 : 0;
   u32 nsk = 0;
   if (len >= (u64)k) {
     const char* seq = bases + b0;
@@ -108,7 +126,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
     const u64 nk = len - (u64)k + 1;
     const u64 kmask = (1ULL << k) - 1;               // k <= 63
     const u32 mmask = (1u << m) - 1;
-    u32 out = EMIT ? desc_off[r] : 0;
+    u32 out = (EMIT && !LB) ? desc_off[r] : 0;
     bool pv = false; u32 pmin = 0; u64 run_start = 0, open_start = 0;   // state of the last owned k-mer of the previous chunk
     int pw = 0; u64 t_start = 0, x_start = 0; u32 rf_open = 0;          // (STATS) its strand, strand-run start, kx-mer start + that k-mer's radix
     for (u64 p0 = 0; p0 < nk; p0 += own) {
@@ -156,8 +174,11 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
       if (EMIT && endf) {
         SkDesc d; d.base = (u32)(b0 + ps); d.part = repart[mini]; d.n = (u8)(pk - ps + 1); d.pad = 0;
         const u32 di = out + __popcll(Em & ((1ULL << lane) - 1));
-        desc[di] = d;
-        if (so.keys) { so.keys[di] = d.part; so.ids[di] = di; so.sizes[di] = 1u + ((u32)k + d.n - 1u + 3u) / 4u; }
+        if (LB) { if (di < SK_WCAP) wbuf[wave][di] = d; }
+        else {
+          desc[di] = d;
+          if (so.keys) { so.keys[di] = d.part; so.ids[di] = di; so.sizes[di] = 1u + ((u32)k + d.n - 1u + 3u) / 4u; }
+        }
       }
       int w = 0; u64 ts = 0, xs = 0; u32 rf_s = 0;
       if (STATS) {
@@ -219,6 +240,48 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
     }
   }
   if (!EMIT && lane == 0) counts[r] = nsk;
+  if (LB) {
+    if (lane == 0) wcnt[wave] = min(nsk, SK_WCAP);
+    __syncthreads();
+    if (wave == 0) {      // the look-back, 64 predecessors at a time (the workgroups in flight have only their counts out: ~2000 of them)
+      const u32 bid = bid_s, B = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      const unsigned long long MASK = (1ULL << 62) - 1;
+      if (lane == 0 && bid > 0) __hip_atomic_store(&lk.state[bid], (1ULL << 62) | B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long excl = 0;
+      for (long long top = (long long)bid - 1; top >= 0; top -= 64) {
+        const long long idx = top - lane;
+        unsigned long long st = idx >= 0 ? __hip_atomic_load(&lk.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ULL << 62);      // (before the first workgroup: prefix 0)
+        u32 first_p;
+        for (;;) {
+          const u64 pm = __ballot((st >> 62) == 2), em = __ballot((st >> 62) == 0);
+          first_p = pm ? (u32)__builtin_ctzll(pm) : 64u;
+          const u64 need = first_p >= 63u ? ~0ULL : ((2ULL << first_p) - 1ULL);      // the lanes up to the nearest published prefix
+          if (!(em & need)) break;
+          if ((st >> 62) == 0) st = __hip_atomic_load(&lk.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long v = (u32)lane <= first_p ? (st & MASK) : 0ULL;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += shfl_xor_u64(v, off);
+        excl += v;
+        if (first_p < 64u) break;
+      }
+      if (lane == 0) {
+        __hip_atomic_store(&lk.state[bid], (2ULL << 62) | (excl + B), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (excl + B > (unsigned long long)lk.cap) { atomicOr(lk.over, 1u); base_s = 0xFFFFFFFFu; } else base_s = (u32)excl;
+      }
+    }
+    __syncthreads();
+    u32 at = base_s;
+    if (at != 0xFFFFFFFFu) {
+      for (u32 w = 0; w < wave; w++) at += wcnt[w];
+      const u32 n = wcnt[wave];
+      for (u32 i = (u32)lane; i < n; i += 64) {
+        const SkDesc d = wbuf[wave][i];
+        const u32 di = at + i;
+        desc[di] = d; so.keys[di] = d.part; so.ids[di] = di; so.sizes[di] = 1u + ((u32)k + d.n - 1u + 3u) / 4u;
+      }
+    }
+  }
 }
 
 __global__ void k_superk_gather_sizes(const u32* __restrict__ ids, const u32* __restrict__ sizes_unsorted, u32 n, u64* __restrict__ sizes_sorted)
@@ -338,6 +401,8 @@ struct StatsDev {
   SkStats S{nullptr, nullptr, nullptr, nullptr};
   kmx_superk_stats* dst = nullptr; kmx_superk_raw* raw = nullptr; u32 nb_parts = 0; u64 nm = 0;
   u32* d_sp = nullptr; u32 sp_cap = 0;      // kmx_superk_raw::minim_sparse: the triples on the device, and how many fit
+  u32* blk_ = nullptr; size_t words_ = 0;   // the tables' block (cleared again when a pass over the reads is repeated)
+  hipError_t clear(hipStream_t s) const { return blk_ ? hipMemsetAsync(blk_, 0, words_ * 4, s) : hipSuccess; }
   int alloc(kmx_ctx* ctx, kmx_superk_stats* st, kmx_superk_raw* rw, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s) {
     dst = st; raw = rw; nb_parts = P; nm = nminim;
     if (!st && !rw) return KMX_OK;
@@ -348,6 +413,7 @@ struct StatsDev {
     if (!words) return KMX_OK;
     u32* blk = (u32*)ctx->dalloc(words * 4); blocks.push_back(blk);
     if (!blk) return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
+    blk_ = blk; words_ = words;
     if (hipMemsetAsync(blk, 0, words * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
     u32* at = blk;
     if (w_pc) { S.pc = at; at += n_pc; }
@@ -475,7 +541,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if (repart) { if (rep_upload && (e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) { ctx->rep_host = nullptr; return fail(e, "upload repartition"); } }
   else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
-  if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
+  if (!want_streams && (e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");      // (with streams: below, if the counting pass runs at all)
   StatsDev sd;
   { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st); if (rc != KMX_OK) { release(); return rc; } }
   if (raw) { raw->nb_superk = 0; raw->minim_sparse_n = 0; }
@@ -486,7 +552,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       // the shortest prefix of the reads that holds more than `budget` super-k-mers (the reference's iterator is cancelled by the
       // super-k-mer that brings the count past the sample size, and stops before the next read; RepartitionAlgorithm.cpp:205-211)
       hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                         (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
+                         (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{});
       std::vector<u32> cnt(n_seqs);
       if ((e = hipMemcpyAsync(cnt.data(), d_cnt, n_seqs * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sample counts");
       u64 acc = 0; use = 0;
@@ -496,28 +562,75 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     if (n_used) *n_used = use;
     const dim3 gs((unsigned)((use + 3) / 4));
     hipLaunchKernelGGL((k_superk_wave<false, true>), gs, b1, 0, st, d_bases, d_offs, (u64)use, (int)k, (int)m, maxs, d_rep, d_cnt,
-                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
+                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{});
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_superk_wave");
     const int rc = sd.collect(ctx, st);
     release();
     return rc;
   }
-  hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                     (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
-  size_t tb = 0;
-  if ((e = rocprim::exclusive_scan(nullptr, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan size");
-  void* d_tmp = ctx->dalloc(tb ? tb : 256); blocks.push_back(d_tmp);
-  if (!d_tmp) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-  if ((e = rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan");
   // what the host reads back between the steps lands in one page-locked block (a copy into pageable memory is staged by the
-  // runtime and waited for): [super-k-mers u64] [pp (P + 1) u64] [info 2P u64] [minimizers that occur u64] [pf (P + 1) u32]
+  // runtime and waited for): [super-k-mers u64 + a spare] [pp (P + 1) u64] [info 2P u64] [minimizers that occur u64] [pf (P + 1) u32]
   const size_t P1 = (size_t)nb_parts + 1, sum_bytes = (P1 + 2 * (size_t)nb_parts + 1) * 8 + P1 * 4;
-  u8* h_sum = (u8*)ctx->halloc(8 + sum_bytes);
+  u8* h_sum = (u8*)ctx->halloc(16 + sum_bytes);
   struct HRel { kmx_ctx* c; void* p; ~HRel() { c->hfree(p); } } h_sum_rel{ctx, h_sum};
   if (!h_sum) { release(); return ctx->fail(KMX_E_NOMEM, "superk: host staging allocation failed"); }
-  if ((e = hipMemcpyAsync(h_sum, d_doff + n_seqs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
-  const u32 nd = *reinterpret_cast<const u32*>(h_sum);
+  u32 nd = 0;
+  SkDesc* d_desc = nullptr; u16* d_keys = nullptr, *d_keys2 = nullptr; u32* d_ids = nullptr, *d_ids2 = nullptr, *d_sz = nullptr;
+  u64* d_szs = nullptr, *d_boff = nullptr; u8* d_sum = nullptr;
+  auto alloc_desc = [&](size_t n) -> bool {
+    d_desc = (SkDesc*)ctx->dalloc(n * sizeof(SkDesc));
+    d_keys = (u16*)ctx->dalloc(n * 2); d_keys2 = (u16*)ctx->dalloc(n * 2);
+    d_ids = (u32*)ctx->dalloc(n * 4); d_ids2 = (u32*)ctx->dalloc(n * 4);
+    d_sz = (u32*)ctx->dalloc(n * 4);
+    d_szs = (u64*)ctx->dalloc((n + 1) * 8); d_boff = (u64*)ctx->dalloc((n + 1) * 8);
+    d_sum = (u8*)ctx->dalloc(sum_bytes);
+    bool ok = true;
+    for (void* b : {(void*)d_desc, (void*)d_keys, (void*)d_keys2, (void*)d_ids, (void*)d_ids2, (void*)d_sz, (void*)d_szs, (void*)d_boff, (void*)d_sum}) { blocks.push_back(b); ok = ok && b; }
+    return ok;
+  };
+  // ---- KMX_SUPERK_ONE_PASS: one pass over the reads (k_superk_wave<.., LB>): descriptors placed by a look-back over the workgroups.  Needs every read's
+  //      descriptors in LDS (reads of at most SK_WCAP k-mers) and room for the descriptors before their number is known: half as
+  //      many as there are k-mers (a super-k-mer holds ~9); more than that, or a longer read: the count + scan + emit passes below ----
+  bool emitted = false;
+  {
+    u64 maxlen = 0, nk_total = 0;
+    for (u64 r = 0; r < n_seqs; r++) { const u64 l = offsets[r + 1] - offsets[r]; maxlen = std::max(maxlen, l); if (l >= k) nk_total += l - k + 1; }
+    // (measured: 2.74 against 2.53 ms per call on the 24 M k-mer sample, 0.83 against 0.76 on the 1 Mbp one -- the look-back's
+    //  barriers, LDS staging and spinning cost more than the second walk over bases that are still in L2: off unless asked for)
+    const bool two_pass = getenv("KMX_SUPERK_ONE_PASS") == nullptr;      // (read per call: the tests switch it)
+    const u64 cap = std::min<u64>(nk_total, nk_total / 2 + n_seqs + 1024);
+    if (!two_pass && nk_total > 0 && maxlen >= k && maxlen - k + 1 <= (u64)SK_WCAP && cap < 0xFFFFFF00ULL) {
+      const size_t nwg = (size_t)((n_seqs + 3) / 4);
+      unsigned long long* d_state = (unsigned long long*)ctx->dalloc((nwg + 1) * 8); blocks.push_back(d_state);
+      if (!d_state || !alloc_desc((size_t)cap)) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+      if ((e = hipMemsetAsync(d_state, 0, (nwg + 1) * 8, st)) != hipSuccess) return fail(e, "memset");
+      u32* const d_tick = reinterpret_cast<u32*>(d_state + nwg);      // the ticket counter and the overflow word share the last entry
+      const SkLook lk{d_state, d_tick, d_tick + 1, (u32)cap};
+      if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, (u32*)nullptr,
+                                        (const u32*)nullptr, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, lk);
+      else hipLaunchKernelGGL((k_superk_wave<true, false, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, (u32*)nullptr,
+                              (const u32*)nullptr, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, lk);
+      if ((e = hipMemcpyAsync(h_sum, d_state + nwg - 1, 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+      const unsigned long long last = reinterpret_cast<const unsigned long long*>(h_sum)[0];
+      const u32 over = reinterpret_cast<const u32*>(h_sum)[3];
+      if (!over) { nd = (u32)(last & ((1ULL << 62) - 1)); emitted = true; }
+      else if ((e = sd.clear(st)) != hipSuccess) return fail(e, "memset");      // (the statistics of the abandoned pass)
+    }
+  }
+  if (!emitted) {
+    if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
+    hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{});
+    size_t tb = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan size");
+    void* d_tmp = ctx->dalloc(tb ? tb : 256); blocks.push_back(d_tmp);
+    if (!d_tmp) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+    if ((e = rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan");
+    if ((e = hipMemcpyAsync(h_sum, d_doff + n_seqs, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+    nd = *reinterpret_cast<const u32*>(h_sum);
+  }
   clk.mark("upload+scan");
   if (nd == 0) {
     if (raw) {      // nothing counted: the caller's tables are all zeros
@@ -537,19 +650,13 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     }
     return KMX_OK;
   }
-
-  SkDesc* d_desc = (SkDesc*)ctx->dalloc((size_t)nd * sizeof(SkDesc));
-  u16* d_keys = (u16*)ctx->dalloc((size_t)nd * 2), *d_keys2 = (u16*)ctx->dalloc((size_t)nd * 2);
-  u32* d_ids = (u32*)ctx->dalloc((size_t)nd * 4), *d_ids2 = (u32*)ctx->dalloc((size_t)nd * 4);
-  u32* d_sz = (u32*)ctx->dalloc((size_t)nd * 4);
-  u64* d_szs = (u64*)ctx->dalloc(((size_t)nd + 1) * 8), *d_boff = (u64*)ctx->dalloc(((size_t)nd + 1) * 8);
-  u8* d_sum = (u8*)ctx->dalloc(sum_bytes);
-  for (void* b : {(void*)d_desc, (void*)d_keys, (void*)d_keys2, (void*)d_ids, (void*)d_ids2, (void*)d_sz, (void*)d_szs, (void*)d_boff, (void*)d_sum}) blocks.push_back(b);
-  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-  if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                                    (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz});
-  else hipLaunchKernelGGL((k_superk_wave<true, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                          (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz});
+  if (!emitted) {
+    if (!alloc_desc((size_t)nd)) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+    if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                                      (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{});
+    else hipLaunchKernelGGL((k_superk_wave<true, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                            (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{});
+  }
   const dim3 g2((nd + 255) / 256), b2(256);
   size_t tb2 = 0, tb3 = 0;
   if ((e = rocprim::radix_sort_pairs(nullptr, tb2, d_keys, d_keys2, d_ids, d_ids2, (size_t)nd, 0, 16, st)) != hipSuccess) return fail(e, "sort size");
@@ -573,9 +680,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf, d_nsp);
   if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((nb_parts + 63) / 64), dim3(64), 0, st, d_pf, d_boff, nb_parts, d_info);
   sd.launch_sparse((u32*)d_nsp, st);
-  if ((e = hipMemcpyAsync(h_sum + 8, d_sum, sum_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
-  const u64* pp = reinterpret_cast<const u64*>(h_sum + 8);
-  const u32* pf = reinterpret_cast<const u32*>(h_sum + 8 + (P1 + 2 * (size_t)nb_parts + 1) * 8);
+  if ((e = hipMemcpyAsync(h_sum + 16, d_sum, sum_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  const u64* pp = reinterpret_cast<const u64*>(h_sum + 16);
+  const u32* pf = reinterpret_cast<const u32*>(h_sum + 16 + (P1 + 2 * (size_t)nb_parts + 1) * 8);
   const u64 tot = pp[nb_parts];                 // (the prefix at the end of the last partition: all k-mers << 32 | all bytes)
   clk.mark("emit+sort");
   if (superk_info) memcpy(superk_info, pp + P1, (size_t)nb_parts * 16);

@@ -255,12 +255,19 @@ def test_count_reads_fused_vs_oracle(ctx, k, m, P, hard_min, hashed):
     assert none is None and nk2 == nk and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got, got2))
 
 
+@pytest.mark.parametrize("passes", ["one", "two", "long-read"])
 @pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4)])
-def test_superk_partition_random_reads_vs_oracle(ctx, k, m, P):
+def test_superk_partition_random_reads_vs_oracle(ctx, monkeypatch, k, m, P, passes):
     lut = orc.minimizer_lut(m)
     rep = orc.repart_static(m, P)
     reads = random_reads(7 + k, 900, 150, n_rate=0.004) + ["ACGT" * 70, "A" * 300, "ACGTN" * 40, "ACG", "", "T" * k,
                                                         "acgtacgtnnacgt" * 12]
+    # the descriptors are placed by count + scan + emit passes over the reads, or (KMX_SUPERK_ONE_PASS) in one pass with a look-back
+    # over the workgroups when every read's descriptors fit the LDS (a read of more than 512 k-mers: the passes): the same streams
+    if passes != "two":
+        monkeypatch.setenv("KMX_SUPERK_ONE_PASS", "1")
+    if passes == "long-read":
+        reads = reads[:300] + [("ACGTTGCATGGA" * 200)[:2000 + k]] + reads[300:]
     exp = orc.superk_partition(reads, k, m, lut, rep, P)
     got = ctx.superk_partition(reads, k, m, rep, P)
     assert sum(g[1] for g in got) > 10000
