@@ -30,7 +30,7 @@ constexpr int CS_WALK_TPB = 1024;
 constexpr int CS_CHUNK = 16 * CS_WALK_TPB;  // keys per workgroup in the count / scatter walks (a chunk holds ~11 keys per bucket of a partition cut into 1500: the pieces the scatter writes)
 constexpr int CS_MAXB = 2048;             // buckets per partition (partitions of up to ~1 M keys; beyond: the library sort)
 template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 16384; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (64 KB)
-template <> struct CsCap<__uint128_t> { static constexpr int cap = 2048, sample = 8192; };
+template <> struct CsCap<__uint128_t> { static constexpr int cap = 4096, sample = 8192; };      // (cap: 64 + 16 KB of LDS in k_cs_sort, which only sees the buckets the wave kernel leaves)
 constexpr u32 CS_WAVE_MAX = 1024;         // keys of a bucket that one wave sorts in registers (16 per lane)
 template <typename K> __host__ __device__ inline u32 cs_target() { return CS_WAVE_MAX / 2; }      // aimed bucket size (a bucket may come out twice that and stay with the wave kernel, 4-8x and stay in LDS)
 
@@ -136,7 +136,12 @@ void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts
   if (P.nb <= 1) return;
   const u32 tid = threadIdx.x;
   u32 S = 4 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 4-8 per bucket (the sort of the samples is this kernel; a bucket twice its aim still fits the wave kernel)
-  for (u32 i = tid; i < S; i += CS_SPL_TPB) sm[i] = keys[P.key0 + (u32)(((u64)i * P.nkeys) / S)];
+  // (a sample per stratum of nkeys / S keys, at a hashed place inside it: evenly spaced samples of a batch that holds the same reads
+  //  twice -- a genome given twice, paired files -- are the same keys twice, half as many samples as it looks)
+  for (u32 i = tid; i < S; i += CS_SPL_TPB) {
+    const u32 lo = (u32)(((u64)i * P.nkeys) / S), hi = (u32)(((u64)(i + 1) * P.nkeys) / S);
+    sm[i] = keys[P.key0 + lo + (hi > lo ? (i * 2654435761u >> 7) % (hi - lo) : 0u)];
+  }
   __syncthreads();
   cs_sort_lds<K, CS_SPL_TPB>(sm, S, tid);
   // bucket b holds the keys k with splitter[b - 1] <= k < splitter[b]
