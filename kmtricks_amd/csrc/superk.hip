@@ -121,7 +121,11 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
   if (len >= (u64)k) {
     const char* seq = bases + b0;
     const int nbm = k - m + 1;                       // m-mers per k-mer (<= 60)
-    const u32 C = 64u - (u32)nbm + 1u;               // k-mer positions of a chunk with their whole m-mer window in the chunk
+    // WIDE (k - m >= 32: at k = 63, m = 10 a chunk would own 10 k-mers): the m-mer values of the NEXT 64 positions are computed as well
+    // and a window that runs past lane 63 is the minimum of a suffix of this chunk's values and a prefix of the next chunk's (van
+    // Herk): every lane has its minimizer, a chunk owns 63 k-mers for ~1.5x the instructions
+    const bool wide = nbm > 32;
+    const u32 C = wide ? 64u : 64u - (u32)nbm + 1u;  // k-mer positions of a chunk with their whole m-mer window at hand
     const u32 own = C - 1;                           // the last one only serves as look-ahead
     const u64 nk = len - (u64)k + 1;
     const u64 kmask = (1ULL << k) - 1;               // k <= 63
@@ -152,6 +156,24 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
       if (nbm & 4) { mini = min(mini, (u32)__shfl_down(s2, off)); off += 4; }
       if (nbm & 2) { mini = min(mini, (u32)__shfl_down(s1, off)); off += 2; }
       if (nbm & 1) { mini = min(mini, (u32)__shfl_down(v, off)); }
+      if (wide) {      // (uniform) lanes whose window [lane, lane + nbm) runs past lane 63
+        const u8 c2 = q + 128 < len ? (u8)seq[q + 128] : (u8)'N';
+        const u64 A2 = __ballot((c2 >> 1) & 1), B2 = __ballot((c2 >> 2) & 1);
+        const u64 fa2 = lane ? (A1 >> lane) | (A2 << (64 - lane)) : A1;
+        const u64 fb2 = lane ? (B1 >> lane) | (B2 << (64 - lane)) : B1;
+        const u32 z0 = __brev((u32)fa2 & mmask) >> (32 - m), z1 = __brev((u32)fb2 & mmask) >> (32 - m);
+        u32 pfx = mmer_value(spread16(z0) | (spread16(z1) << 1), m);      // the m-mer at position p0 + 64 + lane ... min over lanes [0, lane]
+        u32 sfx = v;                                                       // ... and this chunk's values: min over lanes [lane, 63]
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+          const u32 t = (u32)__shfl_down(sfx, o2), u = (u32)__shfl_up(pfx, o2);
+          if (lane + o2 < 64) sfx = min(sfx, t);
+          if (lane >= o2) pfx = min(pfx, u);
+        }
+        const int idx2 = lane + nbm - 65;                                  // the last value of my window, as a lane of the next chunk
+        const u32 pm = (u32)__shfl((int)pfx, idx2 >= 0 ? idx2 : 0);
+        if (idx2 >= 0) mini = min(sfx, pm);
+      }
       const u64 pk = p0 + lane;                                           // my k-mer
       const bool valid = (u32)lane < C && pk < nk && (fi & kmask) == 0;
       u32 pmin_l = (u32)__shfl_up(mini, 1); int pv_l = __shfl_up((int)valid, 1);
