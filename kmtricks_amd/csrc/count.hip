@@ -472,7 +472,8 @@ template <> void cs_launch_bucket_count<__uint128_t>(u32 TB, hipStream_t st, con
   const u32 lo = which == 0 ? CS_WAVE_MAX : 0u;
   if (which == 0) hipLaunchKernelGGL((k_cs_wave_sort<__uint128_t, 8, 16>), dim3((TB + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, bkeys, boff, TB, 0u,
                                      (u32)CsCap<__uint128_t>::cap, hard_min, tk, tc, nkept, hist, overflow);
-  hipLaunchKernelGGL((k_cs_sort<__uint128_t>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, lo);
+  hipLaunchKernelGGL((k_cs_sort<__uint128_t, 2048>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, lo, 0u);
+  hipLaunchKernelGGL((k_cs_sort<__uint128_t, 4096>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, 2048u, 1u);
 }
 __global__ void k_hist_add(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst)
 {

@@ -220,11 +220,10 @@ void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __
 
 // ---- a bucket by sorting: keys into LDS, bitonic sort, run starts by neighbour compare, run lengths = counts (n <= CsCap<K>::cap).
 //      LDS arrays are the caller's: sk[cap], starts[cap], wsum[CS_TPB / 64], hh[258] ----
-template <typename K>
+template <typename K, int CAP = CsCap<K>::cap>
 __device__ __forceinline__ void cs_bucket_by_sort(K* sk, u32* starts, u32* wsum, u32* hh, const K* __restrict__ bkeys, u32 o, u32 n, u32 b, u32 hard_min,
                                                   K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept, unsigned long long* __restrict__ hist)
 {
-  constexpr int CAP = CsCap<K>::cap;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (hist) for (u32 i = tid; i < 258; i += CS_TPB) hh[i] = 0;
   u32 Pn = 2; while (Pn < n) Pn <<= 1;
@@ -279,12 +278,13 @@ __device__ __forceinline__ void cs_bucket_by_sort(K* sk, u32* starts, u32* wsum,
 
 // a workgroup per bucket: sort in LDS, run-length count, hard-min.  kept pairs -> tk / tc at the bucket's offset, their number -> nkept.
 // A bucket over the LDS capacity raises *overflow (the caller then takes the library sort for the batch).
-template <typename K>
+// (CAP: the LDS is sized by it -- 128-bit keys: a launch for up to 2048 keys at 40 KB, one for up to 4096 at 80 KB behind it, so that the
+//  rare bucket does not take the usual one's occupancy; last: this launch reports the buckets beyond its CAP)
+template <typename K, int CAP = CsCap<K>::cap>
 __global__ __launch_bounds__(CS_TPB)
 void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
-               unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */)
+               unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */, u32 last = 1)
 {
-  constexpr int CAP = CsCap<K>::cap;
   __shared__ K sk[CAP];
   __shared__ u32 starts[CAP];      // positions of the run starts, in order
   __shared__ u32 wsum[CS_TPB / 64];
@@ -293,8 +293,8 @@ void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 ha
   const u32 o = boff[b], n = boff[b + 1] - o;
   if (lo && n <= lo) return;
   if (n == 0) { if (threadIdx.x == 0) nkept[b] = 0; return; }
-  if (n > (u32)CAP) { if (threadIdx.x == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } return; }
-  cs_bucket_by_sort<K>(sk, starts, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
+  if (n > (u32)CAP) { if (last && threadIdx.x == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } return; }
+  cs_bucket_by_sort<K, CAP>(sk, starts, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
 }
 
 // ---- 64-bit keys: a bucket by HASHING first.  The keys of a bucket are mostly repeats (a k-mer is seen once per read that covers it:
