@@ -299,7 +299,10 @@ typedef struct {
 /* kmx_count_reads with the results left on the device: partition p's (key, count) records -- ascending, packed as a
  * .kmer body with 4-byte counts -- go to stores[p % n_stores] (the merge stage shards partitions round-robin over the
  * GPUs: the list already lies where it will be merged), lists[p] = {device pointer, records}.  stats (added to, u64)
- * or raw (copied, u32) or neither.  KMX_E_NOMEM when a store is full (nothing is left allocated for this call). */
+ * or raw (copied, u32) or neither.  KMX_E_NOMEM when a store is full (nothing is left allocated for this call).
+ * With superk_bytes == NULL (here and in kmx_count_reads) no super-k-mer record stream is built at all: the k-mers are cut
+ * straight from the batch's bases, the counts are the same (SuperKmerBinInfoFile's numbers still come back in superk_info:
+ * they are computed from the records' sizes).  raw's buffers are filled when the call returns. */
 int kmx_count_reads_dev(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
                         uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart, uint32_t nb_parts,
                         int hash_mode, uint64_t window, uint32_t hard_min,
