@@ -110,6 +110,7 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
   if (ctx->d_hist) (void)hipFree(ctx->d_hist);
   if (ctx->d_rep) (void)hipFree(ctx->d_rep);
+  if (ctx->d_stat) (void)hipFree(ctx->d_stat);
   for (auto& b : ctx->hpool) if (b.p) (void)hipHostFree(b.p);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->aux);

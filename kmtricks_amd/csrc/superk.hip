@@ -400,21 +400,34 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
 using namespace kmx;
 
 // the minimizers that occur: {minimizer, super-k-mers, k-mers} triples, in no particular order (kmx_superk_raw::minim_sparse)
-__global__ void k_minim_sparse(const u32* __restrict__ ms, const u32* __restrict__ mk, u64 nm, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out)
+// (16 table entries per thread: a wave takes 1024 of them and claims its output with ONE atomic -- with an entry per thread the 16 000
+//  waves of a 4^10 table queued up on that one word: 40 us for 4 MB)
+__global__ void k_minim_sparse(u32* __restrict__ ms, u32* __restrict__ mk, u64 nm, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out, int clean)
 {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u32 a = i < nm ? ms[i] : 0u;
-  const bool have = a != 0;
-  const u64 bal = __ballot(have);
-  if (!bal) return;
-  u32 base = 0;
+  const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16u;      // (4^m is a multiple of 16: m >= 4)
   const u32 lane = threadIdx.x & 63u;
-  if (lane == 0) base = atomicAdd(n_out, (u32)__popcll(bal));
-  base = (u32)__shfl((int)base, 0);
-  if (have) {
-    const u32 pos = base + (u32)__popcll(bal & ((1ULL << lane) - 1));
-    if (pos < cap) { out[3 * (u64)pos] = (u32)i; out[3 * (u64)pos + 1] = a; out[3 * (u64)pos + 2] = mk[i]; }
+  u32 v[16]; u32 c = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint4 x = i0 + 4 * q < nm ? reinterpret_cast<const uint4*>(ms + i0)[q] : make_uint4(0, 0, 0, 0);
+    v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
   }
+#pragma unroll
+  for (int q = 0; q < 16; q++) c += v[q] != 0 ? 1u : 0u;
+  const u32 incl = wave_incl_scan(c, (int)lane);
+  const u32 total = (u32)__shfl((int)incl, 63);
+  if (!total) return;
+  u32 base = 0;
+  if (lane == 0) base = atomicAdd(n_out, total);
+  base = (u32)__shfl((int)base, 0);
+  u32 pos = base + incl - c;
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (v[q]) {
+      if (pos < cap) { out[3 * (u64)pos] = (u32)(i0 + q); out[3 * (u64)pos + 1] = v[q]; out[3 * (u64)pos + 2] = mk[i0 + q]; }
+      pos++;
+      if (clean) { ms[i0 + q] = 0; mk[i0 + q] = 0; }      // (the tables are the context's: left as the next call wants them)
+    }
 }
 
 // stats tables of one call (u32 on the device): added to the caller's u64 arrays (kmx_superk_stats), or copied as they are into
@@ -424,6 +437,7 @@ struct StatsDev {
   kmx_superk_stats* dst = nullptr; kmx_superk_raw* raw = nullptr; u32 nb_parts = 0; u64 nm = 0;
   u32* d_sp = nullptr; u32 sp_cap = 0;      // kmx_superk_raw::minim_sparse: the triples on the device, and how many fit
   u32* blk_ = nullptr; size_t words_ = 0;   // the tables' block (cleared again when a pass over the reads is repeated)
+  bool persistent = false; kmx_ctx* pctx = nullptr;
   hipError_t clear(hipStream_t s) const { return blk_ ? hipMemsetAsync(blk_, 0, words_ * 4, s) : hipSuccess; }
   int alloc(kmx_ctx* ctx, kmx_superk_stats* st, kmx_superk_raw* rw, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s) {
     dst = st; raw = rw; nb_parts = P; nm = nminim;
@@ -433,10 +447,25 @@ struct StatsDev {
     // the tables lie in one block, cleared with one call
     const size_t n_pc = w_pc ? (size_t)P * 1280 : 0, n_m = nminim, words = n_pc + ((size_t)w_ms + w_mk + w_mx) * n_m;
     if (!words) return KMX_OK;
-    u32* blk = (u32*)ctx->dalloc(words * 4); blocks.push_back(blk);
-    if (!blk) return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
+    // kmx_superk_raw in sparse form and nothing else: the context's own tables, of which only the partitions' counters need a clear
+    persistent = rw && rw->minim_sparse && !st && w_pc;
+    u32* blk;
+    if (persistent) {
+      if (ctx->d_stat && (ctx->stat_parts != P || ctx->stat_nm != nminim)) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->d_stat); ctx->d_stat = nullptr; }
+      if (!ctx->d_stat) {
+        if (hipMalloc((void**)&ctx->d_stat, words * 4) != hipSuccess) { ctx->d_stat = nullptr; return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed"); }
+        ctx->stat_parts = P; ctx->stat_nm = nminim; ctx->stat_dirty = true;
+      }
+      blk = ctx->d_stat;
+      if (hipMemsetAsync(blk, 0, (ctx->stat_dirty ? words : n_pc) * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
+      ctx->stat_dirty = true;      // (until k_minim_sparse has been queued behind the kernel that fills the tables)
+      pctx = ctx;
+    } else {
+      blk = (u32*)ctx->dalloc(words * 4); blocks.push_back(blk);
+      if (!blk) return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
+      if (hipMemsetAsync(blk, 0, words * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
+    }
     blk_ = blk; words_ = words;
-    if (hipMemsetAsync(blk, 0, words * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
     u32* at = blk;
     if (w_pc) { S.pc = at; at += n_pc; }
     if (w_ms) { S.ms = at; at += n_m; }
@@ -453,8 +482,10 @@ struct StatsDev {
   // kmx_superk_raw, behind the kernel that fills the tables: the minimizers that occur are compacted on the device (their number
   // lands in *d_n, which the caller has zeroed on the stream and downloads with its own results) ...
   void launch_sparse(u32* d_n, hipStream_t s) const {
-    if (d_sp) hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, S.ms, S.mk, nm, d_sp, sp_cap, d_n);
+    if (!d_sp) return;
+    hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm / 16 + 255) / 256)), dim3(256), 0, s, S.ms, S.mk, nm, d_sp, sp_cap, d_n, persistent ? 1 : 0);
   }
+  void compacted() const { if (persistent && pctx && d_sp) pctx->stat_dirty = false; }      // (the caller has waited for k_minim_sparse: the per-minimizer tables are zero again)
   // ... and once that number is on the host, the copies into the caller's (page-locked) buffers are queued: no synchronisation
   // here, the caller's next one covers them
   int finish_raw(kmx_ctx* ctx, u32 n_sparse, hipStream_t s) {
@@ -705,6 +736,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = hipMemcpyAsync(h_sum + 16, d_sum, sum_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   const u64* pp = reinterpret_cast<const u64*>(h_sum + 16);
   const u32* pf = reinterpret_cast<const u32*>(h_sum + 16 + (P1 + 2 * (size_t)nb_parts + 1) * 8);
+  sd.compacted();
   const u64 tot = pp[nb_parts];                 // (the prefix at the end of the last partition: all k-mers << 32 | all bytes)
   clk.mark("emit+sort");
   if (superk_info) memcpy(superk_info, pp + P1, (size_t)nb_parts * 16);
