@@ -309,6 +309,19 @@ int kmx_count_reads_dev(kmx_ctx* ctx, const char* bases, const uint64_t* offsets
                         kmx_store* const* stores, uint32_t n_stores, kmx_list* lists, uint64_t* out_kmers,
                         uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info,
                         kmx_superk_stats* stats, kmx_superk_raw* raw);
+
+/* kmx_count_reads_dev for SEVERAL samples in one call (no reference counterpart: SuperKTask + CountTask run per sample,
+ * task.hpp:250-392; a small sample -- 1 Mbp -- is a few dozen kernels of 5-150 us each and four host round trips, which one call
+ * for several samples pays once).  bases[i] / offsets[i] / n_seqs[i]: sample i's reads as in kmx_count_reads.  Results are
+ * sample-major: lists[i * nb_parts + p], out_kmers[i * nb_parts + p], superk_info[2 * (i * nb_parts + p)], raw[i] (every sample's
+ * statistics in the same form -- all sparse or all dense -- or raw == NULL).  Partition p of every sample goes to
+ * stores[p % n_stores]; a hash window's id is p.  n_samples * nb_parts <= 65535; not while the abundance histogram is on
+ * (kmx_hist_reset: it is per call).  The same lists, numbers and tables as n_samples calls of kmx_count_reads_dev. */
+int kmx_count_reads_dev_multi(kmx_ctx* ctx, uint32_t n_samples, const char* const* bases, const uint64_t* const* offsets,
+                              const uint64_t* n_seqs, uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart_table,
+                              uint32_t nb_parts, int hash_mode, uint64_t window, uint32_t hard_min,
+                              kmx_store* const* stores, uint32_t n_stores, kmx_list* lists, uint64_t* out_kmers,
+                              uint64_t* superk_info, kmx_superk_raw* raw);
 /* device memory (a list of a store, a result body) into host memory; blocks until it is there */
 int kmx_copy_to_host(kmx_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
 

@@ -332,6 +332,8 @@ __global__ void k_part_bounds(const u16* __restrict__ part_sorted, u32 n, u32 n_
 struct CountOut {
   uint64_t** keys = nullptr; uint32_t** counts = nullptr; uint64_t* n_out = nullptr;          // host arrays, or
   kmx_store* const* stores = nullptr; u32 n_stores = 0; kmx_list* lists = nullptr;           // device stores
+  u32 inner = 0;           // several samples in one call: partition p' = sample * inner + p, the store is p's (0: p' is the partition)
+  u32 store_of(u32 p) const { return (inner ? p % inner : p) % n_stores; }
   bool dev() const { return lists != nullptr; }
 };
 
@@ -360,7 +362,7 @@ static int pack_to_stores(kmx_ctx* ctx, const KeyT* d_k, const u32* d_c, const s
   for (u32 p = 0; p < n_parts; p++) { out.lists[p].recs = nullptr; out.lists[p].n = bounds[p + 1] - bounds[p]; }
   if (!kept) return KMX_OK;
   std::vector<u64> pdst(n_parts), doff((size_t)G + 1, 0);
-  { u64 at = 0; for (u32 d = 0; d < G; d++) { doff[d] = at; for (u32 p = d; p < n_parts; p += G) { pdst[p] = at; at += bounds[p + 1] - bounds[p]; } } doff[G] = at; }
+  { u64 at = 0; for (u32 d = 0; d < G; d++) { doff[d] = at; for (u32 p = 0; p < n_parts; p++) if (out.store_of(p) == d) { pdst[p] = at; at += bounds[p + 1] - bounds[p]; } } doff[G] = at; }
   hipStream_t st = ctx->stream;
   const bool direct = G == 1 && out.stores[0]->device == ctx->device;      // one GPU: packed straight into the store
   u8* d_pack = direct ? (u8*)out.stores[0]->alloc((size_t)kept * RB) : (u8*)ctx->dalloc((size_t)kept * RB);
@@ -387,7 +389,7 @@ static int pack_to_stores(kmx_ctx* ctx, const KeyT* d_k, const u32* d_c, const s
                                    : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
       if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }
     }
-    for (u32 p = d; p < n_parts; p += G) if (out.lists[p].n) out.lists[p].recs = dst + (pdst[p] - doff[d]) * RB;
+    for (u32 p = 0; p < n_parts; p++) if (out.store_of(p) == d && out.lists[p].n) out.lists[p].recs = dst + (pdst[p] - doff[d]) * RB;
   }
   if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == KMX_OK) rc = ctx->fail(KMX_E_HIP, std::string("count pack: ") + hipGetErrorString(e));
   release();
@@ -406,7 +408,7 @@ static int compact_to_stores(kmx_ctx* ctx, const KeyT* d_tk, const u32* d_tc, co
   for (u32 p = 0; p < n_parts; p++) { out.lists[p].recs = nullptr; out.lists[p].n = plen(p); }
   if (!kept) return KMX_OK;
   std::vector<u64> pdst(n_parts), doff((size_t)G + 1, 0);
-  { u64 at = 0; for (u32 d = 0; d < G; d++) { doff[d] = at; for (u32 p = d; p < n_parts; p += G) { pdst[p] = at; at += plen(p); } } doff[G] = at; }
+  { u64 at = 0; for (u32 d = 0; d < G; d++) { doff[d] = at; for (u32 p = 0; p < n_parts; p++) if (out.store_of(p) == d) { pdst[p] = at; at += plen(p); } } doff[G] = at; }
   hipStream_t st = ctx->stream;
   const bool direct = G == 1 && out.stores[0]->device == ctx->device;      // one GPU: packed straight into the store
   u8* d_pack = direct ? (u8*)out.stores[0]->alloc((size_t)kept * RB) : (u8*)ctx->dalloc((size_t)kept * RB);
@@ -436,7 +438,7 @@ static int compact_to_stores(kmx_ctx* ctx, const KeyT* d_tk, const u32* d_tc, co
                                    : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
       if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }
     }
-    for (u32 p = d; p < n_parts; p += G) if (out.lists[p].n) out.lists[p].recs = dst + (pdst[p] - doff[d]) * RB;
+    for (u32 p = 0; p < n_parts; p++) if (out.store_of(p) == d && out.lists[p].n) out.lists[p].recs = dst + (pdst[p] - doff[d]) * RB;
   }
   if ((e = hipStreamSynchronize(st)) != hipSuccess && rc == KMX_OK) rc = ctx->fail(KMX_E_HIP, std::string("count pack: ") + hipGetErrorString(e));
   release();
@@ -844,12 +846,13 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
 {
   if (total >= 0xFFFFFF00ULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 k-mers in one batch: split it");
   StageClock clk(ctx->stream, "count_reads");
-  CountOut co; co.keys = rq.keys; co.counts = rq.counts; co.n_out = rq.n_out; co.stores = rq.stores; co.n_stores = rq.n_stores; co.lists = rq.lists;
+  CountOut co; co.keys = rq.keys; co.counts = rq.counts; co.n_out = rq.n_out; co.stores = rq.stores; co.n_stores = rq.n_stores; co.lists = rq.lists; co.inner = rq.inner_parts;
   if (total == 0) {
     for (u32 p = 0; p < n_parts; p++) { if (co.dev()) { co.lists[p].recs = nullptr; co.lists[p].n = 0; } else { rq.keys[p] = (uint64_t*)malloc(8); rq.counts[p] = (uint32_t*)malloc(4); rq.n_out[p] = 0; } }
     return KMX_OK;
   }
-  const std::vector<u64> pid;      // (partition p of the stream has id p)
+  std::vector<u64> pid;      // (empty: partition p of the stream has id p)
+  if (rq.inner_parts && rq.hash_mode) { pid.resize(n_parts); for (u32 p = 0; p < n_parts; p++) pid[p] = p % rq.inner_parts; }      // (the window of p' = sample * inner + p is p's)
   std::vector<u64> kmoff(part_kmer_off, part_kmer_off + n_parts + 1);
   return decode_and_count(ctx, clk, d_recs, d_prefix, d_part, nr, total, n_parts, kmoff, pid, rq.k, rq.hash_mode, rq.window, rq.hard_min, co, d_sbase);
 }

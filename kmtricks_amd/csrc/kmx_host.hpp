@@ -63,7 +63,8 @@ hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hip
 //      record stream, every record's (k-mers << 32 | bytes) prefix and partition to count.hip ----
 //      Results: host arrays (keys / counts / n_out, kmx_count_reads) or packed records in device stores (lists, kmx_count_reads_dev).
 struct kmx_count_req { kmx::u32 k; int hash_mode; kmx::u64 window; kmx::u32 hard_min; uint64_t** keys; uint32_t** counts; uint64_t* n_out;
-                       kmx_store* const* stores = nullptr; kmx::u32 n_stores = 0; kmx_list* lists = nullptr; };
+                       kmx_store* const* stores = nullptr; kmx::u32 n_stores = 0; kmx_list* lists = nullptr;
+                       kmx::u32 inner_parts = 0; };      // several samples in one call: partition p' = sample * inner_parts + p (store and window id from p)
 int kmx_count_from_device(kmx_ctx* ctx, const kmx::u8* d_recs, const kmx::u64* d_prefix, const kmx::u16* d_part, kmx::u32 n_recs,
                           kmx::u64 total_kmers, kmx::u32 n_parts, const kmx::u64* part_kmer_off /* n_parts + 1, host */, const kmx_count_req& rq,
                           const kmx::u32* d_sbase = nullptr /* set: no record stream -- d_recs are the batch's bases packed by kmx_launch_pack_bases, record i starts at base d_sbase[i] */);
@@ -113,7 +114,7 @@ struct kmx_ctx {
   kmx::u16* d_rep = nullptr; const void* rep_host = nullptr; size_t rep_n = 0; kmx::u64 rep_digest = 0;
   // the statistics tables of kmx_superk_raw's sparse mode stay with the context: the kernel that compacts the per-minimizer tables
   // puts the entries it read back to zero, so a call clears only the partitions' counters (1.3 MB instead of 9.3 MB at m = 10)
-  kmx::u32* d_stat = nullptr; size_t stat_parts = 0, stat_nm = 0; bool stat_dirty = true;
+  kmx::u32* d_stat = nullptr; size_t stat_cap = 0, stat_parts = 0, stat_nm = 0; bool stat_dirty = true;
 
   void* dalloc(size_t bytes);
   void dfree(void* p);

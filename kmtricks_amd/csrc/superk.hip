@@ -94,13 +94,16 @@ struct SkStats {          // device tables, zeroed by the caller; any of them ma
 // a workgroup takes a ticket (its number: the reads 4 t .. 4 t + 3), publishes how many descriptors it has (flag 1), adds up its
 // predecessors' numbers until one of them has published its inclusive prefix (flag 2), publishes its own.  A workgroup only waits
 // for workgroups with smaller tickets, which are running.  The last state word holds the total.
-struct SkLook { unsigned long long* state; u32* ticket; u32* over; u32 cap; };      // state[workgroup]: flag << 62 | count or prefix; cap: descriptors that fit
+struct SkLook { unsigned long long* state; u32* ticket; u32* over; u32 cap; };
+// several samples in one call (kmx_count_reads_dev_multi): the reads of sample s are [first[s], first[s + 1]); its partitions are
+// s * parts + repart[minimizer], its per-minimizer tables start at s * nm.  first == nullptr: one sample
+struct SkMulti { const u32* first; u32 n; u32 parts; u32 nm; };      // state[workgroup]: flag << 62 | count or prefix; cap: descriptors that fit
 constexpr u32 SK_WCAP = 512;      // descriptors of one read the LDS takes (the host sends longer reads the two-pass way)
 template <bool EMIT, bool STATS, bool LB = false>
 __global__ __launch_bounds__(256)
 void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
                    int k, int m, int maxs, const u16* __restrict__ repart,
-                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so, SkLook lk)
+                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so, SkLook lk, SkMulti mu)
 {
   __shared__ SkDesc wbuf[LB ? 4 : 1][LB ? SK_WCAP : 1];
   __shared__ u32 wcnt[4];
@@ -117,6 +120,9 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
   if (!LB && r >= n_seqs) return;
   const bool act = r < n_seqs;
   const u64 b0 = act ? offsets[r] : 0, len = act ? offsets[r + 1] - b0 : 0;
+  u32 smp = 0;
+  if (mu.first) while (smp + 1 < mu.n && r >= (u64)mu.first[smp + 1]) smp++;      // (a handful of samples: uniform over the wave)
+  const u32 pbase = smp * mu.parts, sbase = smp * mu.nm;
   u32 nsk = 0;
   if (len >= (u64)k) {
     const char* seq = bases + b0;
@@ -194,7 +200,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
         ps = sb ? p0 + (63 - __clzll(sb)) : open_start;
       }
       if (EMIT && endf) {
-        SkDesc d; d.base = (u32)(b0 + ps); d.part = repart[mini]; d.n = (u8)(pk - ps + 1); d.pad = 0;
+        SkDesc d; d.base = (u32)(b0 + ps); d.part = (u16)(pbase + repart[mini]); d.n = (u8)(pk - ps + 1); d.pad = 0;
         const u32 di = out + __popcll(Em & ((1ULL << lane) - 1));
         if (LB) { if (di < SK_WCAP) wbuf[wave][di] = d; }
         else {
@@ -233,12 +239,12 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
         if (xs < p0) rf_s = rf_open;
         if (xend) {
           const u32 x = (u32)(pk - xs), radix = w ? rf_s : rr;
-          if (S.pc) atomicAdd(&S.pc[((u32)repart[mini] * 5u + x) * 256u + radix], 1u);
+          if (S.pc) atomicAdd(&S.pc[((pbase + (u32)repart[mini]) * 5u + x) * 256u + radix], 1u);
           if (S.mx) atomicAdd(&S.mx[mini], 1u);
         }
         if (endf) {
-          if (S.ms) atomicAdd(&S.ms[mini], 1u);
-          if (S.mk) atomicAdd(&S.mk[mini], (u32)(pk - ps + 1));
+          if (S.ms) atomicAdd(&S.ms[sbase + mini], 1u);
+          if (S.mk) atomicAdd(&S.mk[sbase + mini], (u32)(pk - ps + 1));
         }
       }
       const u32 ne = (u32)__popcll(Em);
@@ -321,11 +327,11 @@ __global__ void k_superk_gather_sizes2(const u32* __restrict__ ids, const u32* _
 }
 // prefix (k-mers << 32 | bytes) at the first record of every partition (nb_parts + 1 entries) + that record's index
 __global__ void k_superk_part_bounds(const u16* __restrict__ part_sorted, u32 n, u32 nb_parts, const u64* __restrict__ prefix,
-                                     u64* __restrict__ part_prefix, u32* __restrict__ part_first, u64* __restrict__ zeroed)
+                                     u64* __restrict__ part_prefix, u32* __restrict__ part_first, u64* __restrict__ zeroed, u32 n_zeroed)
 {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > nb_parts) return;
-  if (p == 0) *zeroed = 0;      // (the counter of k_minim_sparse, which runs behind this kernel)
+  if (p < n_zeroed) zeroed[p] = 0;      // (the counters of k_minim_sparse, one per sample, which runs behind this kernel)
   u32 lo = 0, hi = n;
   while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (part_sorted[mid] < p) lo = mid + 1; else hi = mid; }
   part_prefix[p] = prefix[lo];
@@ -434,31 +440,35 @@ __global__ void k_minim_sparse(u32* __restrict__ ms, u32* __restrict__ mk, u64 n
 // the caller's u32 buffers (kmx_superk_raw: no host arithmetic, one synchronisation)
 struct StatsDev {
   SkStats S{nullptr, nullptr, nullptr, nullptr};
-  kmx_superk_stats* dst = nullptr; kmx_superk_raw* raw = nullptr; u32 nb_parts = 0; u64 nm = 0;
-  u32* d_sp = nullptr; u32 sp_cap = 0;      // kmx_superk_raw::minim_sparse: the triples on the device, and how many fit
+  kmx_superk_stats* dst = nullptr; kmx_superk_raw* raw = nullptr;      // raw: one per sample of the call ([ns])
+  u32 nb_parts = 0; u64 nm = 0;             // partitions of the call (samples x partitions), per-minimizer entries of the call (samples x 4^m)
+  u32 ns = 1; u64 nm1 = 0; u32 parts1 = 0;  // samples of the call, 4^m, partitions per sample
+  u32* d_sp = nullptr; std::vector<u32> sp_cap, sp_off;      // kmx_superk_raw::minim_sparse: the triples on the device, how many fit per sample, where a sample's start
   u32* blk_ = nullptr; size_t words_ = 0;   // the tables' block (cleared again when a pass over the reads is repeated)
   bool persistent = false; kmx_ctx* pctx = nullptr;
   hipError_t clear(hipStream_t s) const { return blk_ ? hipMemsetAsync(blk_, 0, words_ * 4, s) : hipSuccess; }
-  int alloc(kmx_ctx* ctx, kmx_superk_stats* st, kmx_superk_raw* rw, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s) {
-    dst = st; raw = rw; nb_parts = P; nm = nminim;
+  int alloc(kmx_ctx* ctx, kmx_superk_stats* st, kmx_superk_raw* rw, u32 P, u64 nminim, std::vector<void*>& blocks, hipStream_t s, u32 n_samples = 1) {
+    dst = st; raw = rw; ns = std::max(1u, n_samples); nb_parts = P; parts1 = P / ns; nm1 = nminim; nm = nminim * ns;
     if (!st && !rw) return KMX_OK;
     const bool w_pc = (st && st->part_counters) || (rw && rw->part_radix), w_ms = (st && st->minim_superks) || (rw && (rw->minim_superks || rw->minim_sparse)),
                w_mk = (st && st->minim_kmers) || (rw && (rw->minim_kmers || rw->minim_sparse)), w_mx = st && st->minim_kxmers;
     // the tables lie in one block, cleared with one call
-    const size_t n_pc = w_pc ? (size_t)P * 1280 : 0, n_m = nminim, words = n_pc + ((size_t)w_ms + w_mk + w_mx) * n_m;
+    const size_t n_pc = w_pc ? (size_t)P * 1280 : 0, n_m = (size_t)nm, words = n_pc + ((size_t)w_ms + w_mk + w_mx) * n_m;
     if (!words) return KMX_OK;
     // kmx_superk_raw in sparse form and nothing else: the context's own tables, of which only the partitions' counters need a clear
     persistent = rw && rw->minim_sparse && !st && w_pc;
     u32* blk;
     if (persistent) {
-      if (ctx->d_stat && (ctx->stat_parts != P || ctx->stat_nm != nminim)) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->d_stat); ctx->d_stat = nullptr; }
+      if (ctx->d_stat && ctx->stat_cap < words) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->d_stat); ctx->d_stat = nullptr; }
       if (!ctx->d_stat) {
         if (hipMalloc((void**)&ctx->d_stat, words * 4) != hipSuccess) { ctx->d_stat = nullptr; return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed"); }
-        ctx->stat_parts = P; ctx->stat_nm = nminim; ctx->stat_dirty = true;
+        ctx->stat_cap = words; ctx->stat_dirty = true;
       }
+      if (ctx->stat_parts != P || ctx->stat_nm != nm) ctx->stat_dirty = true;      // (another layout: the counters of the last call lie elsewhere)
+      ctx->stat_parts = P; ctx->stat_nm = nm;
       blk = ctx->d_stat;
-      if (hipMemsetAsync(blk, 0, (ctx->stat_dirty ? words : n_pc) * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
-      ctx->stat_dirty = true;      // (until k_minim_sparse has been queued behind the kernel that fills the tables)
+      if (hipMemsetAsync(blk, 0, (ctx->stat_dirty ? ctx->stat_cap : n_pc) * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
+      ctx->stat_dirty = true;      // (until k_minim_sparse has run behind the kernel that fills the tables)
       pctx = ctx;
     } else {
       blk = (u32*)ctx->dalloc(words * 4); blocks.push_back(blk);
@@ -472,33 +482,45 @@ struct StatsDev {
     if (w_mk) { S.mk = at; at += n_m; }
     if (w_mx) { S.mx = at; at += n_m; }
     if (rw && rw->minim_sparse) {
-      sp_cap = (u32)std::min<u64>(std::min<u64>(rw->minim_sparse_cap, 0xFFFFFFF0ULL), nminim);
-      d_sp = (u32*)ctx->dalloc((size_t)sp_cap * 12 + 16); blocks.push_back(d_sp);
+      size_t tot = 0;
+      for (u32 i = 0; i < ns; i++) {
+        if (!rw[i].minim_sparse) return ctx->fail(KMX_E_INVAL, "kmx_superk_raw: the samples of a call take their statistics in the same form");
+        sp_off.push_back((u32)tot);
+        sp_cap.push_back((u32)std::min<u64>(std::min<u64>(rw[i].minim_sparse_cap, 0xFFFFFF0ULL), nminim));
+        tot += sp_cap.back();
+      }
+      d_sp = (u32*)ctx->dalloc(tot * 12 + 16); blocks.push_back(d_sp);
       if (!d_sp) return ctx->fail(KMX_E_NOMEM, "superk: statistics allocation failed");
     }
     return KMX_OK;
   }
   bool any() const { return S.pc || S.ms || S.mk || S.mx; }
-  // kmx_superk_raw, behind the kernel that fills the tables: the minimizers that occur are compacted on the device (their number
-  // lands in *d_n, which the caller has zeroed on the stream and downloads with its own results) ...
-  void launch_sparse(u32* d_n, hipStream_t s) const {
+  // kmx_superk_raw, behind the kernel that fills the tables: the minimizers that occur are compacted on the device, sample by sample
+  // (their numbers land in d_n[sample], which the caller has zeroed on the stream and downloads with its own results) ...
+  void launch_sparse(u64* d_n, hipStream_t s) const {
     if (!d_sp) return;
-    hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm / 16 + 255) / 256)), dim3(256), 0, s, S.ms, S.mk, nm, d_sp, sp_cap, d_n, persistent ? 1 : 0);
+    for (u32 i = 0; i < ns; i++)
+      hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm1 / 16 + 255) / 256)), dim3(256), 0, s, S.ms + (size_t)i * nm1, S.mk + (size_t)i * nm1, nm1,
+                         d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i), persistent ? 1 : 0);
   }
   void compacted() const { if (persistent && pctx && d_sp) pctx->stat_dirty = false; }      // (the caller has waited for k_minim_sparse: the per-minimizer tables are zero again)
-  // ... and once that number is on the host, the copies into the caller's (page-locked) buffers are queued: no synchronisation
+  // ... and once those numbers are on the host, the copies into the caller's (page-locked) buffers are queued: no synchronisation
   // here, the caller's next one covers them
-  int finish_raw(kmx_ctx* ctx, u32 n_sparse, hipStream_t s) {
+  int finish_raw(kmx_ctx* ctx, const u64* n_sparse /* [ns] */, hipStream_t s) {
     if (!raw) return KMX_OK;
     hipError_t e = hipSuccess;
-    if (raw->part_radix) e = hipMemcpyAsync(raw->part_radix, S.pc, (size_t)nb_parts * 1280 * 4, hipMemcpyDeviceToHost, s);
-    if (raw->minim_sparse) {
-      if (n_sparse > sp_cap) return ctx->fail(KMX_E_INVAL, "kmx_superk_raw: more minimizers occur than minim_sparse_cap");
-      raw->minim_sparse_n = n_sparse;
-      if (n_sparse && e == hipSuccess) e = hipMemcpyAsync(raw->minim_sparse, d_sp, (size_t)n_sparse * 12, hipMemcpyDeviceToHost, s);
-    } else {
-      if (e == hipSuccess && raw->minim_superks) e = hipMemcpyAsync(raw->minim_superks, S.ms, nm * 4, hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess && raw->minim_kmers) e = hipMemcpyAsync(raw->minim_kmers, S.mk, nm * 4, hipMemcpyDeviceToHost, s);
+    for (u32 i = 0; i < ns && e == hipSuccess; i++) {
+      kmx_superk_raw& R = raw[i];
+      if (R.part_radix) e = hipMemcpyAsync(R.part_radix, S.pc + (size_t)i * parts1 * 1280, (size_t)parts1 * 1280 * 4, hipMemcpyDeviceToHost, s);
+      if (R.minim_sparse) {
+        const u32 n = (u32)n_sparse[i];
+        if (n > sp_cap[i]) return ctx->fail(KMX_E_INVAL, "kmx_superk_raw: more minimizers occur than minim_sparse_cap");
+        R.minim_sparse_n = n;
+        if (n && e == hipSuccess) e = hipMemcpyAsync(R.minim_sparse, d_sp + (size_t)sp_off[i] * 3, (size_t)n * 12, hipMemcpyDeviceToHost, s);
+      } else {
+        if (e == hipSuccess && R.minim_superks) e = hipMemcpyAsync(R.minim_superks, S.ms + (size_t)i * nm1, nm1 * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && R.minim_kmers) e = hipMemcpyAsync(R.minim_kmers, S.mk + (size_t)i * nm1, nm1 * 4, hipMemcpyDeviceToHost, s);
+      }
     }
     return e == hipSuccess ? KMX_OK : ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(e));
   }
@@ -532,11 +554,16 @@ struct StatsDev {
   }
 };
 
+// several samples in one call: the reads of sample i are [seq_first[i], seq_first[i + 1]) of `offsets` (rebased into one run by the
+// caller), its bases bases[i], which the concatenation holds from base_first[i] on; `parts` partitions per sample (nb_parts = n * parts)
+struct SkSegs { u32 n; const char* const* bases; const u64* base_first; const u32* seq_first; u32 parts; };
+
 static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
                        uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
                        uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats,
                        bool sampling = false, uint64_t budget = 0, uint64_t* n_used = nullptr, uint64_t* n_superk = nullptr,
-                       const kmx_count_req* creq = nullptr, bool streams_to_host = true, uint64_t* superk_info = nullptr, kmx_superk_raw* raw = nullptr)
+                       const kmx_count_req* creq = nullptr, bool streams_to_host = true, uint64_t* superk_info = nullptr, kmx_superk_raw* raw = nullptr,
+                       const SkSegs* segs = nullptr)
 {
   if (!ctx) return KMX_E_INVAL;
   const bool want_streams = out_bytes != nullptr;
@@ -549,7 +576,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if (n_seqs == 0) { if (want_streams) for (u32 p = 0; p < nb_parts; p++) out_bytes[p] = (uint8_t*)malloc(1); return KMX_OK; }
   const u64 total_bases = offsets[n_seqs];
   if (total_bases >= 0xFFFFFF00ULL || n_seqs >= 0x7FFFFFFFULL) return ctx->fail(KMX_E_UNSUPPORTED, "batch of 4 Gbases or more: split it");
-  if (total_bases && !bases) return ctx->fail(KMX_E_INVAL, "null bases");
+  if (total_bases && !bases && !segs) return ctx->fail(KMX_E_INVAL, "null bases");
+  const u32 n_smp = segs ? segs->n : 1u;
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   // Type::getSize() of the k-mer type the reference instantiates: k < 32 -> MAX_K 32 (64 bits), else MAX_K 64 (128 bits)
@@ -582,7 +610,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   const bool rep_pooled = repart == nullptr;
   u32* d_cnt = (u32*)ctx->dalloc((n_seqs + 1) * 4);
   u32* d_doff = (u32*)ctx->dalloc((n_seqs + 1) * 4);
-  std::vector<void*> blocks = {d_bases, d_offs, d_cnt, d_doff};
+  u32* d_first = (u32*)ctx->dalloc(((size_t)n_smp + 1) * 4);
+  std::vector<void*> blocks = {d_bases, d_offs, d_cnt, d_doff, d_first};
   if (rep_pooled) blocks.push_back(d_rep);
   if (!d_rep) { for (void* b : blocks) ctx->dfree(b); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
@@ -590,14 +619,21 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
   StageClock clk(st, "superk_partition");
   hipError_t e;
-  if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
+  if (segs) {
+    for (u32 i = 0; i < segs->n; i++) {
+      const u64 nb = segs->base_first[i + 1] - segs->base_first[i];
+      if (nb && (e = hipMemcpyAsync(d_bases + segs->base_first[i], segs->bases[i], nb, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
+    }
+    if ((e = hipMemcpyAsync(d_first, segs->seq_first, ((size_t)segs->n + 1) * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload sample bounds");
+  } else if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
+  const SkMulti mu{segs ? d_first : nullptr, n_smp, segs ? segs->parts : 0u, segs ? (u32)nm : 0u};
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if (repart) { if (rep_upload && (e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) { ctx->rep_host = nullptr; return fail(e, "upload repartition"); } }
   else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
   if (!want_streams && (e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");      // (with streams: below, if the counting pass runs at all)
   StatsDev sd;
-  { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st); if (rc != KMX_OK) { release(); return rc; } }
-  if (raw) { raw->nb_superk = 0; raw->minim_sparse_n = 0; }
+  { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st, n_smp); if (rc != KMX_OK) { release(); return rc; } }
+  if (raw) for (u32 i = 0; i < n_smp; i++) { raw[i].nb_superk = 0; raw[i].minim_sparse_n = 0; }
   const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
   if (!want_streams) {   // statistics only (the sampling pass of the repartition): one walk, nothing emitted
     u64 use = n_seqs;
@@ -605,7 +641,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       // the shortest prefix of the reads that holds more than `budget` super-k-mers (the reference's iterator is cancelled by the
       // super-k-mer that brings the count past the sample size, and stops before the next read; RepartitionAlgorithm.cpp:205-211)
       hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                         (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{});
+                         (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu);
       std::vector<u32> cnt(n_seqs);
       if ((e = hipMemcpyAsync(cnt.data(), d_cnt, n_seqs * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sample counts");
       u64 acc = 0; use = 0;
@@ -615,7 +651,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     if (n_used) *n_used = use;
     const dim3 gs((unsigned)((use + 3) / 4));
     hipLaunchKernelGGL((k_superk_wave<false, true>), gs, b1, 0, st, d_bases, d_offs, (u64)use, (int)k, (int)m, maxs, d_rep, d_cnt,
-                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{});
+                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_superk_wave");
     const int rc = sd.collect(ctx, st);
     release();
@@ -623,7 +659,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   }
   // what the host reads back between the steps lands in one page-locked block (a copy into pageable memory is staged by the
   // runtime and waited for): [super-k-mers u64 + a spare] [pp (P + 1) u64] [info 2P u64] [minimizers that occur u64] [pf (P + 1) u32]
-  const size_t P1 = (size_t)nb_parts + 1, sum_bytes = (P1 + 2 * (size_t)nb_parts + 1) * 8 + P1 * 4;
+  const size_t P1 = (size_t)nb_parts + 1, sum_bytes = (P1 + 2 * (size_t)nb_parts + n_smp) * 8 + P1 * 4;      // (... [minimizers that occur, per sample] ...)
   u8* h_sum = (u8*)ctx->halloc(16 + sum_bytes);
   struct HRel { kmx_ctx* c; void* p; ~HRel() { c->hfree(p); } } h_sum_rel{ctx, h_sum};
   if (!h_sum) { release(); return ctx->fail(KMX_E_NOMEM, "superk: host staging allocation failed"); }
@@ -646,11 +682,11 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   //      many as there are k-mers (a super-k-mer holds ~9); more than that, or a longer read: the count + scan + emit passes below ----
   bool emitted = false;
   {
-    u64 maxlen = 0, nk_total = 0;
-    for (u64 r = 0; r < n_seqs; r++) { const u64 l = offsets[r + 1] - offsets[r]; maxlen = std::max(maxlen, l); if (l >= k) nk_total += l - k + 1; }
     // (measured: 2.74 against 2.53 ms per call on the 24 M k-mer sample, 0.83 against 0.76 on the 1 Mbp one -- the look-back's
     //  barriers, LDS staging and spinning cost more than the second walk over bases that are still in L2: off unless asked for)
-    const bool two_pass = getenv("KMX_SUPERK_ONE_PASS") == nullptr;      // (read per call: the tests switch it)
+    const bool two_pass = getenv("KMX_SUPERK_ONE_PASS") == nullptr || segs;      // (read per call: the tests switch it)
+    u64 maxlen = 0, nk_total = 0;
+    for (u64 r = 0; r < n_seqs && !two_pass; r++) { const u64 l = offsets[r + 1] - offsets[r]; maxlen = std::max(maxlen, l); if (l >= k) nk_total += l - k + 1; }
     const u64 cap = std::min<u64>(nk_total, nk_total / 2 + n_seqs + 1024);
     if (!two_pass && nk_total > 0 && maxlen >= k && maxlen - k + 1 <= (u64)SK_WCAP && cap < 0xFFFFFF00ULL) {
       const size_t nwg = (size_t)((n_seqs + 3) / 4);
@@ -660,9 +696,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       u32* const d_tick = reinterpret_cast<u32*>(d_state + nwg);      // the ticket counter and the overflow word share the last entry
       const SkLook lk{d_state, d_tick, d_tick + 1, (u32)cap};
       if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, (u32*)nullptr,
-                                        (const u32*)nullptr, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, lk);
+                                        (const u32*)nullptr, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, lk, mu);
       else hipLaunchKernelGGL((k_superk_wave<true, false, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, (u32*)nullptr,
-                              (const u32*)nullptr, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, lk);
+                              (const u32*)nullptr, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, lk, mu);
       if ((e = hipMemcpyAsync(h_sum, d_state + nwg - 1, 16, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "memcpy");
       if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
       const unsigned long long last = reinterpret_cast<const unsigned long long*>(h_sum)[0];
@@ -674,7 +710,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if (!emitted) {
     if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
     hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{});
+                       (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu);
     size_t tb = 0;
     if ((e = rocprim::exclusive_scan(nullptr, tb, d_cnt, d_doff, 0u, (size_t)n_seqs + 1, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan size");
     void* d_tmp = ctx->dalloc(tb ? tb : 256); blocks.push_back(d_tmp);
@@ -686,12 +722,12 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   }
   clk.mark("upload+scan");
   if (nd == 0) {
-    if (raw) {      // nothing counted: the caller's tables are all zeros
-      if (raw->part_radix) memset(raw->part_radix, 0, (size_t)nb_parts * 1280 * 4);
-      if (raw->minim_sparse) raw->minim_sparse_n = 0;
+    if (raw) for (u32 i = 0; i < n_smp; i++) {      // nothing counted: the caller's tables are all zeros
+      if (raw[i].part_radix) memset(raw[i].part_radix, 0, (size_t)(nb_parts / n_smp) * 1280 * 4);
+      if (raw[i].minim_sparse) raw[i].minim_sparse_n = 0;
       else {
-        if (raw->minim_superks) memset(raw->minim_superks, 0, nm * 4);
-        if (raw->minim_kmers) memset(raw->minim_kmers, 0, nm * 4);
+        if (raw[i].minim_superks) memset(raw[i].minim_superks, 0, nm * 4);
+        if (raw[i].minim_kmers) memset(raw[i].minim_kmers, 0, nm * 4);
       }
     }
     release();
@@ -706,9 +742,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if (!emitted) {
     if (!alloc_desc((size_t)nd)) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
     if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                                      (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{});
+                                      (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{}, mu);
     else hipLaunchKernelGGL((k_superk_wave<true, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
-                            (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{});
+                            (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{}, mu);
   }
   const dim3 g2((nd + 255) / 256), b2(256);
   size_t tb2 = 0, tb3 = 0;
@@ -729,20 +765,20 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   }
   hipLaunchKernelGGL(k_superk_gather_sizes2, dim3((nd + 256) / 256), b2, 0, st, d_ids2, d_sz, d_desc, nd, d_szs, d_sbase);
   if ((e = rocprim::exclusive_scan(d_tmp2, tb3, d_szs, d_boff, (u64)0, (size_t)nd + 1, rocprim::plus<u64>(), st)) != hipSuccess) return fail(e, "scan");
-  u64* d_pp = (u64*)d_sum, *d_info = d_pp + P1, *d_nsp = d_info + 2 * (size_t)nb_parts; u32* d_pf = (u32*)(d_nsp + 1);
-  hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf, d_nsp);
+  u64* d_pp = (u64*)d_sum, *d_info = d_pp + P1, *d_nsp = d_info + 2 * (size_t)nb_parts; u32* d_pf = (u32*)(d_nsp + n_smp);
+  hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf, d_nsp, n_smp);
   if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((nb_parts + 63) / 64), dim3(64), 0, st, d_pf, d_boff, nb_parts, d_info);
-  sd.launch_sparse((u32*)d_nsp, st);
+  sd.launch_sparse(d_nsp, st);
   if ((e = hipMemcpyAsync(h_sum + 16, d_sum, sum_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   const u64* pp = reinterpret_cast<const u64*>(h_sum + 16);
-  const u32* pf = reinterpret_cast<const u32*>(h_sum + 16 + (P1 + 2 * (size_t)nb_parts + 1) * 8);
+  const u32* pf = reinterpret_cast<const u32*>(h_sum + 16 + (P1 + 2 * (size_t)nb_parts + n_smp) * 8);
   sd.compacted();
   const u64 tot = pp[nb_parts];                 // (the prefix at the end of the last partition: all k-mers << 32 | all bytes)
   clk.mark("emit+sort");
   if (superk_info) memcpy(superk_info, pp + P1, (size_t)nb_parts * 16);
   if (raw) {
-    raw->nb_superk = nd;                        // (one descriptor per super-k-mer)
-    const int rc = sd.finish_raw(ctx, (u32)pp[P1 + 2 * (size_t)nb_parts], st);      // (queued; the synchronisation of the steps below covers it)
+    for (u32 i = 0; i < n_smp; i++) raw[i].nb_superk = (u64)pf[(size_t)(i + 1) * (nb_parts / n_smp)] - pf[(size_t)i * (nb_parts / n_smp)];      // (one descriptor per super-k-mer)
+    const int rc = sd.finish_raw(ctx, pp + P1 + 2 * (size_t)nb_parts, st);      // (queued; the synchronisation of the steps below covers it)
     if (rc != KMX_OK) { release(); return rc; }
   }
   { const int rc = sd.collect(ctx, st); if (rc != KMX_OK) { release(); return rc; } }
@@ -853,5 +889,47 @@ extern "C" int kmx_count_reads_dev(kmx_ctx* ctx, const char* bases, const uint64
   if (!ob) { dummy_b.assign(nb_parts, nullptr); dummy_l.assign(nb_parts, 0); ob = dummy_b.data(); ol = dummy_l.data(); }
   const int rc = superk_impl(ctx, bases, offsets, n_seqs, k, m, repart, nb_parts, ob, ol, out_kmers, stats, false, 0, nullptr, nullptr, &rq, superk_bytes != nullptr, superk_info, raw);
   if (rc != KMX_OK) for (u32 p = 0; p < nb_parts; p++) { lists[p].recs = nullptr; lists[p].n = 0; }
+  return rc;
+}
+
+extern "C" int kmx_count_reads_dev_multi(kmx_ctx* ctx, uint32_t n_samples, const char* const* bases, const uint64_t* const* offsets, const uint64_t* n_seqs,
+                                         uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
+                                         int hash_mode, uint64_t window, uint32_t hard_min,
+                                         kmx_store* const* stores, uint32_t n_stores, kmx_list* lists, uint64_t* out_kmers,
+                                         uint64_t* superk_info, kmx_superk_raw* raw)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!n_samples || !bases || !offsets || !n_seqs || !stores || !n_stores || !lists || !out_kmers) return ctx->fail(KMX_E_INVAL, "kmx_count_reads_dev_multi: null argument");
+  for (u32 d = 0; d < n_stores; d++) if (!stores[d]) return ctx->fail(KMX_E_INVAL, "kmx_count_reads_dev_multi: null store");
+  if (hash_mode && window == 0) return ctx->fail(KMX_E_INVAL, "hash window is 0");
+  if ((u64)n_samples * nb_parts > 65535) return ctx->fail(KMX_E_UNSUPPORTED, "kmx_count_reads_dev_multi: samples x partitions above 65535");
+  if (ctx->hist_on) return ctx->fail(KMX_E_UNSUPPORTED, "kmx_count_reads_dev_multi: the abundance histogram is per call -- one sample per call while it is on");
+  if (n_samples == 1)
+    return kmx_count_reads_dev(ctx, bases[0], offsets[0], n_seqs[0], k, m, repart, nb_parts, hash_mode, window, hard_min, stores, n_stores, lists, out_kmers,
+                               nullptr, nullptr, superk_info, nullptr, raw);
+  const u32 PT = n_samples * nb_parts;
+  for (u32 p = 0; p < PT; p++) { lists[p].recs = nullptr; lists[p].n = 0; out_kmers[p] = 0; }
+  // one run of reads: the offsets rebased (into page-locked memory: the upload is a DMA), the samples' first reads and first bases
+  u64 tot_seqs = 0;
+  for (u32 i = 0; i < n_samples; i++) { if (n_seqs[i] && (!offsets[i] || (offsets[i][n_seqs[i]] && !bases[i]))) return ctx->fail(KMX_E_INVAL, "kmx_count_reads_dev_multi: null sample"); tot_seqs += n_seqs[i]; }
+  if (tot_seqs >= 0x7FFFFFFFULL) return ctx->fail(KMX_E_UNSUPPORTED, "batch of 2^31 reads or more: split it");
+  const size_t hb = (tot_seqs + 1) * 8 + ((size_t)n_samples + 1) * (8 + 4) + 64;
+  u8* h = (u8*)ctx->halloc(hb);
+  if (!h) return ctx->fail(KMX_E_NOMEM, "kmx_count_reads_dev_multi: host staging allocation failed");
+  struct HRel { kmx_ctx* c; void* p; ~HRel() { c->hfree(p); } } hrel{ctx, h};
+  u64* offs = reinterpret_cast<u64*>(h); u64* base_first = offs + tot_seqs + 1; u32* seq_first = reinterpret_cast<u32*>(base_first + n_samples + 1);
+  u64 at_seq = 0, at_base = 0;
+  for (u32 i = 0; i < n_samples; i++) {
+    seq_first[i] = (u32)at_seq; base_first[i] = at_base;
+    for (u64 r = 0; r < n_seqs[i]; r++) offs[at_seq + r] = at_base + offsets[i][r];
+    at_seq += n_seqs[i]; at_base += n_seqs[i] ? offsets[i][n_seqs[i]] : 0;
+  }
+  seq_first[n_samples] = (u32)at_seq; base_first[n_samples] = at_base; offs[tot_seqs] = at_base;
+  const SkSegs segs{n_samples, bases, base_first, seq_first, nb_parts};
+  kmx_count_req rq{k, hash_mode, window, hard_min, nullptr, nullptr, nullptr, stores, n_stores, lists, nb_parts};
+  std::vector<uint8_t*> dummy_b(PT, nullptr); std::vector<uint64_t> dummy_l(PT, 0);
+  const int rc = superk_impl(ctx, nullptr, reinterpret_cast<const uint64_t*>(offs), tot_seqs, k, m, repart, PT, dummy_b.data(), dummy_l.data(), out_kmers, nullptr, false, 0, nullptr, nullptr, &rq, false,
+                             superk_info, raw, &segs);
+  if (rc != KMX_OK) for (u32 p = 0; p < PT; p++) { lists[p].recs = nullptr; lists[p].n = 0; }
   return rc;
 }

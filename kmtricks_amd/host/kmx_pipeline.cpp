@@ -187,7 +187,7 @@ static void superk_info_numbers(const uint8_t* s, uint64_t len, uint32_t k, uint
   *kmers_pending = km; *bytes_flushed = flushed;
 }
 
-struct Stage { double read = 0, split = 0, count = 0, merge_io = 0, merge = 0, format = 0, repart = 0, setup_wall = 0, count_wall = 0, merge_wall = 0; std::atomic<uint64_t> bases{0}, kmers{0}, merge_recs{0}; };
+struct Stage { double read = 0, split = 0, count = 0, merge_io = 0, merge = 0, format = 0, repart = 0, setup_wall = 0, count_wall = 0, merge_wall = 0; std::atomic<uint64_t> bases{0}, kmers{0}, merge_recs{0}, count_calls{0}; };
 
 int run(int argc, char** argv)
 {
@@ -351,10 +351,10 @@ int run(int argc, char** argv)
   auto report = [&]() {
     fprintf(stderr, "[kmx pipeline] {\"samples\": %u, \"partitions\": %u, \"gpus\": %u, \"threads\": %u, \"bases\": %llu, \"kmers\": %llu, \"merge_records\": %llu, "
                     "\"repart_s\": %.4f, \"read_s\": %.4f, \"superk_s\": %.4f, \"count_s\": %.4f, \"merge_io_s\": %.4f, \"merge_s\": %.4f, \"format_s\": %.4f, "
-                    "\"gpu_workers\": %u, \"resident_samples\": %u, \"setup_wall_s\": %.4f, \"count_wall_s\": %.4f, \"merge_wall_s\": %.4f, \"total_s\": %.4f}\n",
+                    "\"gpu_workers\": %u, \"resident_samples\": %u, \"resident_count_calls\": %llu, \"setup_wall_s\": %.4f, \"count_wall_s\": %.4f, \"merge_wall_s\": %.4f, \"total_s\": %.4f}\n",
             N, P, G, o.threads, (unsigned long long)st.bases.load(), (unsigned long long)st.kmers.load(), (unsigned long long)st.merge_recs.load(),
             st.repart, st.read, st.split, st.count, st.merge_io, st.merge, st.format,
-            o.gpu_workers, (unsigned)std::count(res_flag.begin(), res_flag.end(), (uint8_t)1), st.setup_wall, st.count_wall, st.merge_wall, since(t0));
+            o.gpu_workers, (unsigned)std::count(res_flag.begin(), res_flag.end(), (uint8_t)1), (unsigned long long)st.count_calls.load(), st.setup_wall, st.count_wall, st.merge_wall, since(t0));
   };
   auto count_path = [&](uint32_t p, uint32_t si) {
     return root + "/counts/partition_" + std::to_string(p) + "/" + samples[si].id + (hash_mode ? ".hash" : (o.cpr ? ".kmer.lz4" : ".kmer"));
@@ -427,7 +427,7 @@ int run(int argc, char** argv)
     } pinpool;
     struct ReadBatch { uint32_t si = 0; bool last = false; PinStr bases; std::vector<uint64_t> offs; };
     std::vector<std::unique_ptr<Channel<ReadBatch>>> chan;
-    for (uint32_t w = 0; w < NW; w++) chan.emplace_back(new Channel<ReadBatch>(3));
+    for (uint32_t w = 0; w < NW; w++) chan.emplace_back(new Channel<ReadBatch>(6));
     std::mutex tm; double s_read = 0, s_split = 0, s_count = 0;
     // readers: threads that parse samples in fof order, each into the queue of the sample's worker (bounded by the channel)
     const uint32_t readers = std::max<uint32_t>(1, std::min<uint32_t>(o.threads > 1 ? o.threads / 2 : 1, 24));
@@ -448,7 +448,12 @@ int run(int argc, char** argv)
       void put(uint32_t* p) { { std::lock_guard<std::mutex> lk(m); free_.push_back(p); } cv.notify_one(); }
       ~RawPool() { for (auto p : free_) kmx_free_pinned(p); }
     } rawpool;
-    rawpool.cap = 3 * (size_t)NW + 2; rawpool.words = raw_words;
+    // KMX_COUNT_SAMPLES_PER_CALL=n: up to n whole samples that wait in a worker's queue go to the GPU in ONE call
+    // (kmx_count_reads_dev_multi: a 1 Mbp sample is a few dozen small kernels and four host round trips, which a call pays once --
+    // 0.71 -> 0.49 ms per sample at n = 4 when the call is timed by itself, scripts/bench_count_multi.py).  Through this driver it does
+    // not pay yet: 1000 x 1 Mbp count in 0.89-0.95 s at n = 4 against 0.63 s at n = 1 (--skip-partiinfo; two workers), so the default is 1.
+    const uint32_t per_call = getenv("KMX_COUNT_SAMPLES_PER_CALL") ? (uint32_t)std::max(1L, atol(getenv("KMX_COUNT_SAMPLES_PER_CALL"))) : 1u;
+    rawpool.cap = ((size_t)per_call + 2) * NW + 2; rawpool.words = raw_words;
     std::atomic<uint32_t> next_sample{0};
     // A sample's batches must reach its worker in order; samples are taken in fof order by `readers` threads per round so the
     // GPU workers see them nearly in order too.
@@ -502,9 +507,11 @@ int run(int argc, char** argv)
       uint32_t done = 0;
       double w_split = 0, w_count = 0;
       const uint64_t nm = 1ULL << (2 * o.msize);
+      std::unique_ptr<ReadBatch> pending;      // (a batch taken from the queue that did not fit the call being put together)
       while (done < per_gpu[g]) {
         ReadBatch b;
-        if (!chan[g]->pop(b)) break;
+        if (pending) { b = std::move(*pending); pending.reset(); }
+        else if (!chan[g]->pop(b)) break;
         struct Back { PinPool& pp; PinStr s; ~Back() { pp.put(s); } } back{pinpool, b.bases};      // (the block goes back to the pool when this batch is done with)
         const bool whole_sample = b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk" && !(o.hist && restricted);      // (the fused calls count every partition: not what a histogram of the selected ones needs)
         bool fits = resident_mode && whole_sample;
@@ -513,43 +520,77 @@ int run(int argc, char** argv)
           for (uint32_t d = 0; d < G; d++) if (kmx_store_used(stores[d]) + worst > kmx_store_limit(stores[d])) fits = false;
         }
         if (fits) {
-          // ---- the whole sample in one batch, its counts stay in HBM: split + count in one call (kmx_count_reads_dev), partition
-          //      p's list lands in the store of shard p mod G; only numbers and the statistics tables come back ----
+          // ---- whole samples, one batch each, their counts stay in HBM: split + count in one call (kmx_count_reads_dev[_multi]),
+          //      partition p's list lands in the store of shard p mod G; only numbers and the statistics tables come back ----
           const auto t = clk::now();
-          const uint32_t si = b.si; const Sample& smp = samples[si];
-          tlog(g, "split_begin", si);
-          st.bases += b.bases.size();
-          std::vector<kmx_list> ls(P); std::vector<uint64_t> nkp(P, 0);
-          auto info = std::make_shared<std::vector<uint64_t>>(2 * (size_t)P, 0);
-          uint32_t* rawbuf = o.skip_pinfo ? nullptr : rawpool.get();
-          kmx_superk_raw raw{};
-          if (rawbuf) { raw.part_radix = rawbuf; raw.minim_sparse = rawbuf + (size_t)P * 1280; raw.minim_sparse_cap = nm; }      // (sparse: ~10^5 of the 4^m minimizers occur in a sample)
+          std::vector<ReadBatch> more;      // the samples that ride along with b
+          std::vector<std::unique_ptr<Back>> more_back;
+          if (per_call > 1 && !o.hist && (uint64_t)per_call * P <= 65535) {
+            uint64_t worst = (uint64_t)b.bases.size() * list_rec_bytes / G + (1u << 20);
+            while (more.size() + 1 < per_call) {
+              ReadBatch b2;
+              if (!chan[g]->try_pop(b2)) break;
+              const bool whole2 = b2.last && b2.offs.size() > 1 && open.find(b2.si) == open.end() && samples[b2.si].hard_min == samples[b.si].hard_min;
+              const uint64_t w2 = worst + (uint64_t)b2.bases.size() * list_rec_bytes / G;
+              bool room = whole2;
+              for (uint32_t d = 0; d < G && room; d++) if (kmx_store_used(stores[d]) + w2 > kmx_store_limit(stores[d])) room = false;
+              if (!room) { pending.reset(new ReadBatch(std::move(b2))); break; }
+              worst = w2;
+              more_back.emplace_back(new Back{pinpool, b2.bases});
+              more.push_back(std::move(b2));
+            }
+          }
+          const uint32_t S = 1 + (uint32_t)more.size();
+          st.count_calls++;
+          std::vector<const ReadBatch*> grp; grp.push_back(&b); for (auto& x : more) grp.push_back(&x);
+          std::vector<kmx_list> ls((size_t)S * P); std::vector<uint64_t> nkp_all((size_t)S * P, 0), info_all(2 * (size_t)S * P, 0);
+          std::vector<uint32_t*> rawbufs(S, nullptr); std::vector<kmx_superk_raw> raws(S);
+          for (uint32_t i = 0; i < S; i++) {
+            tlog(g, "split_begin", grp[i]->si);
+            st.bases += grp[i]->bases.size();
+            rawbufs[i] = o.skip_pinfo ? nullptr : rawpool.get();
+            raws[i] = kmx_superk_raw{};
+            if (rawbufs[i]) { raws[i].part_radix = rawbufs[i]; raws[i].minim_sparse = rawbufs[i] + (size_t)P * 1280; raws[i].minim_sparse_cap = nm; }      // (sparse: ~10^5 of the 4^m minimizers occur in a sample)
+          }
           if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
-          chk(c, kmx_count_reads_dev(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, smp.hard_min,
-                                     stores.data(), G, ls.data(), nkp.data(), nullptr, nullptr, info->data(), nullptr, rawbuf ? &raw : nullptr), "kmx_count_reads_dev");
-          if (o.hist) writes.push_back(save_hist(c, si));
-          for (uint32_t p = 0; p < P; p++) res_lists[(size_t)si * P + p] = selected[p] ? ls[p] : kmx_list{nullptr, 0};
-          res_flag[si] = 1;
-          uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
-          st.kmers += nkt;
-          const uint64_t nsk = raw.nb_superk, n_sparse = raw.minim_sparse_n;
-          auto nkp_s = std::make_shared<std::vector<uint64_t>>(std::move(nkp));
-          const std::string sid = smp.id;
-          writes.push_back(pool.submit([=, &rawpool, &selected]() {
-            try {
-              { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string((*nkp_s)[p]); s2 += "\n"; }      // every partition, as dump_pinfo does (gatb_utils.hpp:46-51)
-                Out pi(root + "/partition_infos/" + sid + ".pinfo"); pi.raw(s2.data(), s2.size()); pi.close(); }
-              const std::string sd = root + "/superkmers/" + sid; fs::create_directories(sd);
-              { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
-                for (uint32_t p = 0; p < P; p++) inf += std::to_string(selected[p] ? (*info)[2 * p] : 0) + "\n" + std::to_string(selected[p] ? (*info)[2 * p + 1] : 0) + "\n";
-                Out f(sd + "/SuperKmerBinInfoFile"); f.raw(inf.data(), inf.size()); f.close(); }
-              if (rawbuf) write_parti_info_sparse(sd + "/PartiInfoFile", P, nm, nsk, rawbuf, rawbuf + (size_t)P * 1280, n_sparse);
-            } catch (const std::exception& e) { die(e.what()); }
-            if (rawbuf) rawpool.put(rawbuf);
-          }));
-          tlog(g, "split_end", si);
+          if (S == 1)
+            chk(c, kmx_count_reads_dev(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
+                                       stores.data(), G, ls.data(), nkp_all.data(), nullptr, nullptr, info_all.data(), nullptr, rawbufs[0] ? &raws[0] : nullptr), "kmx_count_reads_dev");
+          else {
+            std::vector<const char*> bp(S); std::vector<const uint64_t*> op(S); std::vector<uint64_t> ns(S);
+            for (uint32_t i = 0; i < S; i++) { bp[i] = grp[i]->bases.data(); op[i] = grp[i]->offs.data(); ns[i] = grp[i]->offs.size() - 1; }
+            chk(c, kmx_count_reads_dev_multi(c, S, bp.data(), op.data(), ns.data(), o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
+                                             stores.data(), G, ls.data(), nkp_all.data(), info_all.data(), rawbufs[0] ? raws.data() : nullptr), "kmx_count_reads_dev_multi");
+          }
+          if (o.hist) writes.push_back(save_hist(c, b.si));
+          for (uint32_t i = 0; i < S; i++) {
+            const uint32_t si = grp[i]->si; const Sample& smp = samples[si];
+            for (uint32_t p = 0; p < P; p++) res_lists[(size_t)si * P + p] = selected[p] ? ls[(size_t)i * P + p] : kmx_list{nullptr, 0};
+            res_flag[si] = 1;
+            std::vector<uint64_t> nkp(nkp_all.begin() + (size_t)i * P, nkp_all.begin() + (size_t)(i + 1) * P);
+            auto info = std::make_shared<std::vector<uint64_t>>(info_all.begin() + 2 * (size_t)i * P, info_all.begin() + 2 * (size_t)(i + 1) * P);
+            uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
+            st.kmers += nkt;
+            uint32_t* const rawbuf = rawbufs[i];
+            const uint64_t nsk = raws[i].nb_superk, n_sparse = raws[i].minim_sparse_n;
+            auto nkp_s = std::make_shared<std::vector<uint64_t>>(std::move(nkp));
+            const std::string sid = smp.id;
+            writes.push_back(pool.submit([=, &rawpool, &selected]() {
+              try {
+                { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string((*nkp_s)[p]); s2 += "\n"; }      // every partition, as dump_pinfo does (gatb_utils.hpp:46-51)
+                  Out pi(root + "/partition_infos/" + sid + ".pinfo"); pi.raw(s2.data(), s2.size()); pi.close(); }
+                const std::string sd = root + "/superkmers/" + sid; fs::create_directories(sd);
+                { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
+                  for (uint32_t p = 0; p < P; p++) inf += std::to_string(selected[p] ? (*info)[2 * p] : 0) + "\n" + std::to_string(selected[p] ? (*info)[2 * p + 1] : 0) + "\n";
+                  Out f(sd + "/SuperKmerBinInfoFile"); f.raw(inf.data(), inf.size()); f.close(); }
+                if (rawbuf) write_parti_info_sparse(sd + "/PartiInfoFile", P, nm, nsk, rawbuf, rawbuf + (size_t)P * 1280, n_sparse);
+              } catch (const std::exception& e) { die(e.what()); }
+              if (rawbuf) rawpool.put(rawbuf);
+            }));
+            tlog(g, "split_end", si);
+            done++;
+          }
           w_count += since(t);
-          done++;
           while (writes.size() > 64) { writes.front().get(); writes.pop_front(); }
           continue;
         }

@@ -53,6 +53,11 @@ template <typename T> class Channel {
     if (q_.empty()) return false;
     v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return true;
   }
+  bool try_pop(T& v) {      // what is there now, without waiting
+    std::lock_guard<std::mutex> lk(m_);
+    if (q_.empty()) return false;
+    v = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return true;
+  }
   void close() { { std::lock_guard<std::mutex> lk(m_); closed_ = true; } cv_.notify_all(); }
  private:
   size_t cap_; std::deque<T> q_; std::mutex m_; std::condition_variable cv_; bool closed_ = false;

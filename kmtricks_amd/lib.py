@@ -104,6 +104,9 @@ _lib.kmx_store_used.argtypes = [_vp]
 _lib.kmx_store_limit.restype = C.c_uint64
 _lib.kmx_store_limit.argtypes = [_vp]
 _lib.kmx_copy_to_host.argtypes = [_vp, _vp, _vp, C.c_uint64]
+_lib.kmx_count_reads_dev_multi.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_int, C.c_uint64, C.c_uint32,
+                                            _vp, C.c_uint32, _vp, _vp, _vp, _vp]
+_lib.kmx_count_reads_dev_multi.restype = C.c_int
 _lib.kmx_count_reads_dev.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_int, C.c_uint64, C.c_uint32,
                                      C.POINTER(_vp), C.c_uint32, C.POINTER(KmxList), C.POINTER(C.c_uint64),
                                      C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(KmxSuperkStats),
@@ -111,7 +114,7 @@ _lib.kmx_count_reads_dev.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint3
 _lib.kmx_hist_reset.argtypes = [_vp]
 _lib.kmx_hist_off.argtypes = [_vp]
 _lib.kmx_hist_read.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
-EXPORTS = ["kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_count_reads_dev_multi", "kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -338,6 +341,40 @@ class Context:
             assert len(np.unique(t[:, 0])) == len(t)
             tabs[1][t[:, 0]] = t[:, 1]; tabs[2][t[:, 0]] = t[:, 2]
         return [(lists[p].recs, int(lists[p].n)) for p in range(nb_parts)], [int(x) for x in nk], (tabs + (int(rw.nb_superk),)) if raw else None
+
+    def count_reads_dev_multi(self, samples, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False):
+        """kmx_count_reads_dev_multi: several samples (lists of reads) in ONE call -> per sample what count_reads_dev returns
+        (raw: the sparse form, turned back into tables here)"""
+        S = len(samples)
+        packed = [self.pack_reads(r) for r in samples]
+        rep = np.ascontiguousarray(repart, dtype=np.uint16)
+        bp = (C.c_char_p * S)(*[b for b, _ in packed])
+        op = (_vp * S)(*[o.ctypes.data for _, o in packed])
+        ns = (C.c_uint64 * S)(*[len(o) - 1 for _, o in packed])
+        sp = (_vp * len(stores))(*[s._h for s in stores])
+        lists, nk = (KmxList * (S * nb_parts))(), (C.c_uint64 * (S * nb_parts))()
+        info = np.zeros((S * nb_parts, 2), np.uint64)
+        rws, tabs, spts = None, [], []
+        if raw:
+            rws = (KmxSuperkRaw * S)()
+            for i in range(S):
+                t = (np.zeros(nb_parts * 1280, np.uint32), np.zeros(4 ** m, np.uint32), np.zeros(4 ** m, np.uint32))
+                q = np.zeros((4 ** m, 3), np.uint32)
+                tabs.append(t); spts.append(q)
+                rws[i] = KmxSuperkRaw(t[0].ctypes.data, None, None, 0, q.ctypes.data, 4 ** m, 0)
+        self._check(_lib.kmx_count_reads_dev_multi(self._h, S, bp, op, ns, k, m, rep.ctypes.data, nb_parts, 1 if window else 0, window, hard_min,
+                                                   sp, len(stores), lists, nk, info.ctypes.data, rws), "kmx_count_reads_dev_multi")
+        out = []
+        for i in range(S):
+            r = None
+            if raw:
+                t = spts[i][:int(rws[i].minim_sparse_n)]
+                assert len(np.unique(t[:, 0])) == len(t)
+                tabs[i][1][t[:, 0]] = t[:, 1]; tabs[i][2][t[:, 0]] = t[:, 2]
+                r = tabs[i] + (int(rws[i].nb_superk),)
+            out.append(([(lists[i * nb_parts + p].recs, int(lists[i * nb_parts + p].n)) for p in range(nb_parts)],
+                        [int(nk[i * nb_parts + p]) for p in range(nb_parts)], info[i * nb_parts:(i + 1) * nb_parts], r))
+        return out
 
     def read_list(self, dev_ptr, n, key_words=1):
         """a device-resident count list -> (keys uint64[n, key_words], counts uint32[n])"""

@@ -382,3 +382,42 @@ def test_superk_sample_vs_oracle(ctx):
         _, _, _, emx = orc.superk_stats(reads[:used], k, m, lut, rep0, 1)
         assert np.array_equal(g_mx, emx)
         assert np.array_equal(orc.repart_sampled(g_mx, P), orc.repart_sampled(emx, P))
+
+
+@pytest.mark.parametrize("k,m,P,hard_min,hashed,G,S", [(31, 10, 8, 1, False, 1, 3), (31, 10, 16, 2, True, 3, 4), (63, 10, 32, 2, False, 2, 2), (21, 8, 5, 1, False, 2, 5)])
+def test_count_reads_dev_multi_vs_single(ctx, k, m, P, hard_min, hashed, G, S):
+    """kmx_count_reads_dev_multi: several samples in ONE call (partition id' = sample * P + partition inside, the statistics
+    tables per sample) give, sample by sample, the oracle's counts, k-mer numbers, SuperKmerBinInfoFile numbers and PartiInfo<5>
+    tables -- what S calls of kmx_count_reads_dev give; samples of different sizes, an empty one among them"""
+    from kmtricks_amd import lib
+    lut = orc.minimizer_lut(m)
+    rep = orc.repart_static(m, P)
+    W = 6400
+    samples = [random_reads(3000 + 17 * i + k, 150 + 120 * i, 150, n_rate=0.003) + ["ACGT" * 70, "T" * k, ""] for i in range(S)]
+    samples[S // 2] = [] if S > 2 else samples[S // 2]
+    kw = 1 if hashed else (k + 31) // 32
+    stores = [lib.Store(0, limit_bytes=64 << 20) for _ in range(G)]
+    try:
+        got = ctx.count_reads_dev_multi(samples, k, m, rep, P, hard_min, stores, window=W if hashed else 0, raw=True)
+        assert len(got) == S
+        for i, reads in enumerate(samples):
+            lists, nk, info, raw = got[i]
+            exp = orc.superk_partition(reads, k, m, lut, rep, P)
+            epin, ems, emk, _ = orc.superk_stats(reads, k, m, lut, rep, P)
+            pr, ms, mk, nsk = raw
+            assert np.array_equal(pr.reshape(P, 1280).astype(np.uint64), epin[:, 2:]) and np.array_equal(ms, ems) and np.array_equal(mk, emk) and nsk == int(ems.sum())
+            for p in range(P):
+                assert nk[p] == exp[p][1]
+                gk, gc = ctx.read_list(lists[p][0], lists[p][1], kw)
+                ek, ec = orc.count_hash(exp[p][0], k, W, p, hard_min) if hashed else orc.count_kmer(exp[p][0], k, hard_min)
+                assert np.array_equal(gk.reshape(ek.shape), ek) and np.array_equal(gc, ec)
+                # block framing of the stream (<= 32768-byte blocks): k-mers since the last flush, bytes flushed
+                buf = km = fl = pos = 0
+                s = exp[p][0]
+                while pos < len(s):
+                    n = s[pos]; nb = 1 + (k + n - 1 + 3) // 4
+                    if buf + nb > 32768: fl += buf + 4; buf = 0; km = 0
+                    buf += nb; km += n; pos += nb
+                assert (int(info[p, 0]), int(info[p, 1])) == (km, fl)
+    finally:
+        for s in stores: s.close()

@@ -418,7 +418,8 @@ def test_two_gpu_workers_same_output(tmp_path):
     samples go round-robin over the workers, partitions over the shards, workers are in flight at once (KMX_TRACE time stamps
     overlap), and the run directory is the one --gpus 1 writes -- with the count lists going through count files (--keep-tmp)
     or staying in HBM (a store per shard, kmx_count_reads_dev), with 8 shards (the shape of an 8-GPU node), and with stores so
-    small that most samples are turned away and the merge takes resident lists and count files in one batch"""
+    small that most samples are turned away and the merge takes resident lists and count files in one batch, and with several
+    samples per count call (KMX_COUNT_SAMPLES_PER_CALL)"""
     reads = _synthetic_samples(tmp_path, 8, 200_000, 3)
     base_cmd = [KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--kmer-size", "31", "--nb-partitions", "16",
                 "--static-repart", "--recurrence-min", "2", "--merge-batch-mb", "16"]
@@ -428,6 +429,8 @@ def test_two_gpu_workers_same_output(tmp_path):
             "g2_resident": (["--gpus", "2", "--gpu-workers", "2"], {"KMX_OUT_PIECE_KB": "64"}),
             "g2_resident_order": (["--gpus", "2", "--gpu-workers", "2"], {"KMX_OUT_PIECE_KB": "64", "KMX_OUT_ORDER": "1"}),
             "g8_resident": (["--gpus", "8", "--gpu-workers", "1"], {}),
+            "g2_resident_multi": (["--gpus", "2", "--gpu-workers", "1"], {"KMX_COUNT_SAMPLES_PER_CALL": "4"}),      # several samples per count call (kmx_count_reads_dev_multi)
+            "g1_resident_multi": (["--gpus", "1", "--gpu-workers", "2", "--mode", "kmer:count:bin"], {"KMX_COUNT_SAMPLES_PER_CALL": "3"}),
             "g3_mixed": (["--gpus", "3", "--gpu-workers", "1"], {"KMX_STORE_LIMIT_MB": "8"})}
     outs = {}
     for name, (flags, env) in runs.items():
@@ -443,6 +446,7 @@ def test_two_gpu_workers_same_output(tmp_path):
             for n in names:
                 assert open(ref / sub / n, "rb").read() == open(out / sub / n, "rb").read(), (name, sub, n)
         rep = json.loads([l for l in err.splitlines() if l.startswith("[kmx pipeline]")][-1][len("[kmx pipeline] "):])
+        if name.endswith("_multi"): assert rep["resident_count_calls"] < 8, rep      # (samples did share calls)
         if name.endswith("_files"): assert rep["resident_samples"] == 0
         elif "_resident" in name: assert rep["resident_samples"] == 8
         else: assert 0 < rep["resident_samples"] < 8, rep      # (some samples fitted the 8 MB stores, the others left count files)
