@@ -614,7 +614,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   std::vector<void*> blocks = {d_bases, d_offs, d_cnt, d_doff, d_first};
   if (rep_pooled) blocks.push_back(d_rep);
   if (!d_rep) { for (void* b : blocks) ctx->dfree(b); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
+  bool aux_busy = false;      // (kmx_superk_raw's copies are on the second stream: nothing they read is given back before they are through)
+  auto release = [&]() { if (aux_busy && ctx->aux) (void)hipStreamSynchronize(ctx->aux); for (void* b : blocks) ctx->dfree(b); };
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
   StageClock clk(st, "superk_partition");
@@ -778,7 +779,10 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if (superk_info) memcpy(superk_info, pp + P1, (size_t)nb_parts * 16);
   if (raw) {
     for (u32 i = 0; i < n_smp; i++) raw[i].nb_superk = (u64)pf[(size_t)(i + 1) * (nb_parts / n_smp)] - pf[(size_t)i * (nb_parts / n_smp)];      // (one descriptor per super-k-mer)
-    const int rc = sd.finish_raw(ctx, pp + P1 + 2 * (size_t)nb_parts, st);      // (queued; the synchronisation of the steps below covers it)
+    // (queued on the context's SECOND stream -- the tables are complete, this stream has just been waited for -- so that the 2.5 MB
+    //  per sample cross PCIe beside the count kernels instead of in front of them; waited for before the call returns)
+    aux_busy = true;
+    const int rc = sd.finish_raw(ctx, pp + P1 + 2 * (size_t)nb_parts, ctx->aux ? ctx->aux : st);
     if (rc != KMX_OK) { release(); return rc; }
   }
   { const int rc = sd.collect(ctx, st); if (rc != KMX_OK) { release(); return rc; } }
@@ -799,13 +803,13 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     clk.mark("count");
   }
   if (!streams_to_host) {
-    // (kmx_superk_raw's copies are queued on the stream: normally the count above has waited for it already)
     if ((raw || !creq) && (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+    if (raw && ctx->aux && (e = hipStreamSynchronize(ctx->aux)) != hipSuccess) return fail(e, "sync");      // (kmx_superk_raw's copies)
     release(); return KMX_OK;
   }
   // the partition-ordered stream comes back in one copy; a few host threads cut it into the per-partition buffers
   if ((e = hipMemcpyAsync(h_out, d_out, total_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) { ctx->hfree(h_out); return fail(e, "download"); }
+      (e = hipStreamSynchronize(st)) != hipSuccess || (raw && ctx->aux && (e = hipStreamSynchronize(ctx->aux)) != hipSuccess)) { ctx->hfree(h_out); return fail(e, "download"); }
   release();
   std::atomic<u32> next{0}; std::atomic<int> oom{0};
   auto fill = [&]() {
