@@ -427,7 +427,9 @@ int run(int argc, char** argv)
     } pinpool;
     struct ReadBatch { uint32_t si = 0; bool last = false; PinStr bases; std::vector<uint64_t> offs; };
     std::vector<std::unique_ptr<Channel<ReadBatch>>> chan;
-    for (uint32_t w = 0; w < NW; w++) chan.emplace_back(new Channel<ReadBatch>(6));
+    // (a queue of 3 batches per worker; more when a worker takes several samples per call, KMX_COUNT_SAMPLES_PER_CALL below)
+    { const char* e = getenv("KMX_COUNT_SAMPLES_PER_CALL"); const size_t qcap = e && atol(e) > 1 ? (size_t)atol(e) + 2 : 3;
+      for (uint32_t w = 0; w < NW; w++) chan.emplace_back(new Channel<ReadBatch>(qcap)); }
     std::mutex tm; double s_read = 0, s_split = 0, s_count = 0;
     // readers: threads that parse samples in fof order, each into the queue of the sample's worker (bounded by the channel)
     const uint32_t readers = std::max<uint32_t>(1, std::min<uint32_t>(o.threads > 1 ? o.threads / 2 : 1, 24));
