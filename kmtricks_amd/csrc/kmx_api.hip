@@ -3,6 +3,9 @@
 #include "kmx_host.hpp"
 
 #include <algorithm>
+#include <sys/mman.h>
+#include <unordered_map>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -44,7 +47,8 @@ void* kmx_ctx::halloc(size_t bytes)
         (best < 0 || hpool[i].bytes < hpool[best].bytes)) best = (int)i;
   if (best >= 0) { hpool[best].used = true; return hpool[best].p; }
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  p = kmx_pinned_alloc(bytes);
+  if (!p) return nullptr;
   hpool.push_back({p, bytes, true});
   return p;
 }
@@ -111,7 +115,7 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   if (ctx->d_hist) (void)hipFree(ctx->d_hist);
   if (ctx->d_rep) (void)hipFree(ctx->d_rep);
   if (ctx->d_stat) (void)hipFree(ctx->d_stat);
-  for (auto& b : ctx->hpool) if (b.p) (void)hipHostFree(b.p);
+  for (auto& b : ctx->hpool) if (b.p) kmx_pinned_free(b.p);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->aux);
   (void)hipStreamDestroy(ctx->copy);
@@ -122,13 +126,48 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
 extern "C" const char* kmx_last_error(const kmx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" void* kmx_stream(kmx_ctx* ctx) { if (ctx) ctx->stream_shared = true; return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" void kmx_free(void* p) { free(p); }
-extern "C" void* kmx_alloc_pinned(size_t bytes)
+// Page-locked host memory.  hipHostMalloc pins 4 KB pages one by one -- 5.6 ms for 32 MB, all of it under the runtime's lock, so
+// that a thread pinning the pipeline's buffers stalls every other thread's launches and copies (the output ring, the read
+// buffers).  An anonymous mapping backed by transparent huge pages, touched and then registered, is page-locked in 1.5 ms of which
+// 0.1 ms are the runtime's (hipHostRegister over 16 pages of 2 MB instead of 8192 of 4 KB); device copies run at the same 55 GB/s
+// (scripts/dev/pin_speed.hip).  Blocks of at least 2 MB take that road; smaller ones, and any failure on it, hipHostMalloc.
+namespace {
+std::mutex g_pin_mutex;
+std::unordered_map<void*, size_t> g_pin_mapped;      // blocks that came from mmap + hipHostRegister: their mapped size
+}
+void* kmx_pinned_alloc(size_t bytes)
 {
+  if (bytes == 0) bytes = 256;
+  static const bool thp_off = getenv("KMX_PINNED_HIPHOSTMALLOC") != nullptr;
+  if (bytes >= (2u << 20) && !thp_off) {
+    const size_t n = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    void* q = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (q != MAP_FAILED) {
+      (void)madvise(q, n, MADV_HUGEPAGE);
+      for (size_t o = 0; o < n; o += 4096) static_cast<volatile char*>(q)[o] = 0;      // fault the pages in here, not under the runtime's lock
+      if (hipHostRegister(q, n, hipHostRegisterDefault) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pin_mutex);
+        g_pin_mapped[q] = n;
+        return q;
+      }
+      (void)hipGetLastError();
+      munmap(q, n);
+    }
+  }
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 256, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
   return p;
 }
-extern "C" void kmx_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+void kmx_pinned_free(void* p)
+{
+  if (!p) return;
+  size_t n = 0;
+  { std::lock_guard<std::mutex> lk(g_pin_mutex); auto it = g_pin_mapped.find(p); if (it != g_pin_mapped.end()) { n = it->second; g_pin_mapped.erase(it); } }
+  if (n) { (void)hipHostUnregister(p); munmap(p, n); }
+  else (void)hipHostFree(p);
+}
+extern "C" void* kmx_alloc_pinned(size_t bytes) { return kmx_pinned_alloc(bytes); }
+extern "C" void kmx_free_pinned(void* p) { kmx_pinned_free(p); }
 // ---- kmx_store: count lists resident in HBM between the count and the merge stage ---------------------------------
 void* kmx_store::alloc(size_t bytes)
 {

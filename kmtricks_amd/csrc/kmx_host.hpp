@@ -70,6 +70,10 @@ int kmx_count_from_device(kmx_ctx* ctx, const kmx::u8* d_recs, const kmx::u64* d
                           const kmx::u32* d_sbase = nullptr /* set: no record stream -- d_recs are the batch's bases packed by kmx_launch_pack_bases, record i starts at base d_sbase[i] */);
 void kmx_launch_pack_bases(const char* d_bases, kmx::u64 n, kmx::u64* out /* (n + 31) / 32 + 2 words */, hipStream_t st);
 
+// page-locked host memory (kmx_api.hip: transparent huge pages + hipHostRegister for blocks of 2 MB and more, hipHostMalloc else)
+void* kmx_pinned_alloc(size_t bytes);
+void kmx_pinned_free(void* p);
+
 // ---- context -------------------------------------------------------------------------------------
 struct kmx_pool_block { void* p; size_t bytes; bool used; };
 
