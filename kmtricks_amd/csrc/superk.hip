@@ -267,7 +267,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
       }
     }
   }
-  if (!EMIT && lane == 0) counts[r] = nsk;
+  if (!EMIT && lane == 0) { counts[r] = nsk; if (r == 0) counts[n_seqs] = 0; }      // (every read's entry is written, and the scan's terminating zero: no clear beforehand)
   if (LB) {
     if (lane == 0) wcnt[wave] = min(nsk, SK_WCAP);
     __syncthreads();
@@ -631,7 +631,6 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if (repart) { if (rep_upload && (e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) { ctx->rep_host = nullptr; return fail(e, "upload repartition"); } }
   else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
-  if (!want_streams && (e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");      // (with streams: below, if the counting pass runs at all)
   StatsDev sd;
   { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st, n_smp); if (rc != KMX_OK) { release(); return rc; } }
   if (raw) for (u32 i = 0; i < n_smp; i++) { raw[i].nb_superk = 0; raw[i].minim_sparse_n = 0; }
@@ -709,7 +708,6 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     }
   }
   if (!emitted) {
-    if ((e = hipMemsetAsync(d_cnt, 0, (n_seqs + 1) * 4, st)) != hipSuccess) return fail(e, "memset");
     hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                        (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu);
     size_t tb = 0;
