@@ -145,7 +145,7 @@ void* kmx_pinned_alloc(size_t bytes)
     if (q != MAP_FAILED) {
       (void)madvise(q, n, MADV_HUGEPAGE);
       for (size_t o = 0; o < n; o += 4096) static_cast<volatile char*>(q)[o] = 0;      // fault the pages in here, not under the runtime's lock
-      if (hipHostRegister(q, n, hipHostRegisterDefault) == hipSuccess) {
+      if (hipHostRegister(q, n, hipHostRegisterPortable) == hipSuccess) {      // (portable: a process that drives several GPUs copies to and from it on all of them, as with hipHostMalloc)
         std::lock_guard<std::mutex> lk(g_pin_mutex);
         g_pin_mapped[q] = n;
         return q;
