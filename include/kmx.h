@@ -39,7 +39,9 @@
 extern "C" {
 #endif
 
-#define KMX_VERSION 1
+/* 2: kmx_merge_task carries list_on_device (the struct grew: a caller built against version 1 hands tasks of the wrong stride);
+ *    kmx_set_file_order.  Callers check kmx_version() == KMX_VERSION before anything else. */
+#define KMX_VERSION 2
 
 enum {
   KMX_OK = 0,
@@ -80,6 +82,13 @@ const char* kmx_last_error(const kmx_ctx* ctx);
  *                                              resemble each other): results never depend on the choice
  *   BF / BFC     k_merge_bf;   BFT  k_merge_bft */
 int  kmx_set_profiling(kmx_ctx* ctx, int on);
+/* COUNT / PA rows in FILE ORDER out of the merge itself (default on; KMX_FILE_ORDER=0 in the environment or on = 0 here turns it
+ * off).  The reference's output IS the ascending row stream (merge.hpp:262-272 write_as_bin -> io/matrix_file.hpp:120-127).  On:
+ * the column-blocked pair writes every row at its final place -- k_cols_sparse learns each slice group's offset by a decoupled
+ * look-back and puts the group's rows, the row keys' rows among them, in key order there: the arena IS the matrix body
+ * (kmx_result_body_dev returns it, no second copy, no gather pass).  Off: the row keys' rows first, the other rows behind them in
+ * runs with a directory (kmx_result_arena + kmx_result_copy_order; kmx_result_body_dev then assembles a copy on the device). */
+int  kmx_set_file_order(kmx_ctx* ctx, int on);
 /* HIP stream the ctx launches on (a hipStream_t), so callers can order their own work after it */
 void* kmx_stream(kmx_ctx* ctx);
 

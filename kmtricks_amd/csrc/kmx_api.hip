@@ -95,6 +95,7 @@ extern "C" int kmx_create(int device, kmx_ctx** out)
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
   c->n_cu = prop.multiProcessorCount;
+  { const char* fo = getenv("KMX_FILE_ORDER"); c->file_order = !(fo && fo[0] == '0'); }
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
   if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return KMX_E_NODEVICE; }
   if ((e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->aux); delete c; return KMX_E_NODEVICE; }
@@ -231,6 +232,7 @@ extern "C" int kmx_copy_to_host(kmx_ctx* ctx, void* dst, const void* src, uint64
 }
 
 extern "C" int kmx_set_profiling(kmx_ctx* ctx, int on) { if (!ctx) return KMX_E_INVAL; ctx->profiling = on != 0; return KMX_OK; }
+extern "C" int kmx_set_file_order(kmx_ctx* ctx, int on) { if (!ctx) return KMX_E_INVAL; ctx->file_order = on != 0; return KMX_OK; }
 
 // ---- merge ---------------------------------------------------------------------------------------------
 struct TaskHost {
@@ -262,6 +264,11 @@ struct TaskHost {
   bool body_ready = false;
   hipEvent_t ev_body = nullptr; // ... queued on the assembly stream by kmx_result_prepare_body: body_dev waits for it
   void* d_body_tmp = nullptr;   // ... its scratch (group offsets / segment copies), freed with the result
+  // rows at their final place out of the column-blocked pair (kmx_set_file_order): the row keys' rows wait in d_dense for
+  // k_cols_sparse, which writes every slice group's rows in key order at the group's place -- d_out IS the body
+  u8* d_dense = nullptr; u32 dpitch = 0, dense_cap = 0; size_t o_gbase = 0;
+  u64 row_keys = 0;             // row keys of the task as k_cols_prep counted them (ctrl[7])
+  bool ordered = false;         // the task's rows lie in file order in d_out
   std::vector<u32> src;         // (row-key merge of a task: which of the task's lists it merges)
   int kernel = 0;               // the kernel that completed (or is to complete) the task: 0 rows, 1 pivot, 2 cols
 };
@@ -277,6 +284,7 @@ struct kmx_merge_result {
   bool is_bf = false, is_bft = false, waited = false;
   bool cols_ext = false, slices_full = false;   // k_merge_cols with slice extensions; a task came back because a slice was full
   bool cols_resc = false;                        // the RESC builds of the column-blocked pair (share-min, recurrence-min 0)
+  bool cols_ord = false;                         // ... and their ORD builds: rows written at their final place
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
@@ -376,7 +384,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     KMX_HIP(ctx, CO.merge(mode, (R->cols_ext ? 1 : 0) | (R->cols_resc ? 2 : 0), d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
-    KMX_HIP(ctx, CO.sparse(mode | (R->cols_resc ? 2 : 0), d_tasks, d_cols, d_items, R->n_items, ctx->stream));
+    KMX_HIP(ctx, CO.sparse(mode | (R->cols_resc ? 2 : 0) | (R->cols_ord ? 4 : 0), d_tasks, d_cols, d_items, R->n_items, nt, d_ticket, (u32)ctx->n_cu, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));      // (the launch priced: the rows come out of both kernels)
     return mirror_and_mark(R);
   } else {
@@ -538,6 +546,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     bool long_list = false;
     for (auto& H : R->tasks) { u32 longest = 0; for (u32 l : H.len) longest = std::max(longest, l); long_list |= (u64)longest * H.N * 2 > H.total_recs * 5; }
     R->cols_ext = R->use_cols && (ctx->cols_ext || long_list);
+    R->cols_ord = R->use_cols && ctx->file_order;
   }
   // ranges per task: ~3 work items per resident workgroup over the batch, >= 16K records each
   const u32 slots = (u32)ctx->n_cu * 2;
@@ -676,6 +685,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.o_skel = off; off = align_up(off + 8ull * kw * H.out_cap_rows, 256);
       H.o_nskel = off; off += 256;
       H.o_rbounds = off; off = align_up(off + 4ull * (H.c + 1), 256);
+      H.o_gbase = off; off = align_up(off + 4ull * (H.c + 1), 256);
     }
   }
   R->meta_bytes = off;
@@ -683,7 +693,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->h_meta = (u8*)ctx->halloc(upload_bytes);
   if (!R->d_meta || !R->h_meta) { ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); return ctx->fail(KMX_E_NOMEM, "meta allocation failed"); }
   auto drop_blocks = [&]() {
-    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); ctx->dfree(G.d_rowrec); }
+    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); ctx->dfree(G.d_rowrec); ctx->dfree(G.d_dense); }
     for (auto& G : R->subs) ctx->dfree(G.d_out);
     ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
   };
@@ -696,8 +706,19 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.o_spdir = align_up(H.o_ovx + (size_t)H.xcap * (CO.key_words + 1) * 8, 256);
       H.d_ov = (u8*)ctx->dalloc(H.o_spdir + 256 + (size_t)CO.dir_bytes(H.slots_cap));
       if (H.d_ov && hipMemsetAsync(H.d_ov + H.o_spdir, 0, 256 + (size_t)CO.dir_bytes(H.slots_cap), ctx->aux) != hipSuccess) { ctx->dfree(H.d_ov); H.d_ov = nullptr; }
+      if (R->cols_ord) {
+        // the side store of the row keys' rows (payload only, 8-byte pitch).  Row keys = the keys a merge of S of the lists keeps:
+        // about one list's worth in a cohort (recurrence-min 1: the union of the S lists), or what the context's batches had
+        const TaskHost& Q = R->subs[&H - R->tasks.data()];
+        u64 longest = 0, sum = 0; for (u32 l : Q.len) { longest = std::max<u64>(longest, l); sum += l; }
+        u64 cap = (H.rec_min <= 1 ? std::min<u64>(sum, longest * 5 / 2) : longest * 3 / 2) + 4096;
+        if (ctx->keys_per_longest > 0.0) cap = std::max<u64>(cap, (u64)(ctx->keys_per_longest * 1.25 * (double)longest) + 4096);
+        H.dense_cap = (u32)std::min<u64>(std::min<u64>(cap, H.out_cap_rows), 0xFFFFFF00ULL);
+        H.dpitch = (u32)align_up(H.row_bytes - 8 * kw, 8);
+        H.d_dense = (u8*)ctx->dalloc((size_t)H.dense_cap * H.dpitch);
+      }
     }
-    if (!H.d_out || (cols && !H.d_ov)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
+    if (!H.d_out || (cols && !H.d_ov) || (R->cols_ord && !H.d_dense)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
 
   }
   for (auto& Q : R->subs) {
@@ -772,6 +793,15 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       C.xcap = H.xcap;
       C.spdir = H.d_ov + H.o_spdir + 256;
       C.slots_cap = H.slots_cap; C.nblk = H.nblk; C.nb = H.nb; C.rt = H.rt_cols;
+      if (R->cols_ord) {      // (the sparse rows' directory is not written then: its room holds the look-back chain and the group map)
+        const size_t ng = CO.groups(H.slots_cap);
+        C.dense = H.d_dense; C.dpitch = H.dpitch; C.dense_cap = H.dense_cap;
+        C.gbase = reinterpret_cast<u32*>(R->d_meta + H.o_gbase);
+        C.chain = reinterpret_cast<u64*>(H.d_ov + H.o_spdir + 256);
+        C.gmap = reinterpret_cast<uint4*>(H.d_ov + H.o_spdir + 256 + ng * 8);
+        C.gmax = reinterpret_cast<u32*>(R->d_meta + R->o_ticket) + 2;
+        C.ngcap = (u32)ng;
+      }
       for (u32 j = 0; j < H.c * H.nblk; j++) citems[ci++] = make_uint2(t, j);   // y = range * nblk + block
     }
   }
@@ -808,7 +838,7 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
   for (size_t t = 0; t < nt; t++) {
     TaskHost& H = R->tasks[t];
     const u64* ctrl = hc + t * 8;
-    H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3]; H.sparse_rows = ctrl[6];
+    H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3]; H.sparse_rows = ctrl[6]; H.row_keys = ctrl[7];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
     H.handed_back = false;
     if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; if (ctrl[2] & ERR_DIVERGENT) R->divergent = true; if (ctrl[2] & ERR_SLICES) R->slices_full = true; }
@@ -832,6 +862,11 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   bool overflow = false, fallback = false;
   int rc = fetch_ctrl(R, &overflow, &fallback);
   if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }
+  if (R->use_cols) {   // what the next batches' side stores of row keys' rows are sized from (k_cols_prep reports the count even when it gives up)
+    double ratio = 0.0;
+    for (size_t t = 0; t < R->tasks.size(); t++) { u32 longest = 0; for (u32 l : R->subs[t].len) longest = std::max(longest, l); if (longest) ratio = std::max(ratio, (double)R->tasks[t].row_keys / (double)longest); }
+    ctx->keys_per_longest = ctx->keys_per_longest > 0.0 ? std::max(ratio, 0.75 * ctx->keys_per_longest + 0.25 * ratio) : ratio;
+  }
   while (fallback) {
     // The column-blocked / pivot kernel handed some tasks back (lists that do not resemble each other): those tasks
     // -- only those -- run again with the next kernel down (cols -> pivot -> rows).  Bounds stay valid; their
@@ -950,6 +985,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     for (auto& H : R->tasks) { u32 longest = 0; for (u32 l : H.len) longest = std::max(longest, l); if (longest) ratio = std::max(ratio, (double)H.rows / (double)longest); }
     ctx->rows_per_longest = ctx->rows_per_longest > 0.0 ? std::max(ratio, 0.75 * ctx->rows_per_longest + 0.25 * ratio) : ratio;
   }
+  for (auto& H : R->tasks) H.ordered = R->cols_ord && H.kernel == 2;
   R->waited = true; R->status = KMX_OK;
   if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] batch of %zu tasks (%u-bit keys): %s\n", R->tasks.size(), 64u * R->tasks[0].kw, kmx_result_kernel(R));
   return KMX_OK;
@@ -1035,6 +1071,7 @@ static int assemble_body(kmx_merge_result* R, uint32_t t, bool async = false)
   if (body == 0) { H.body_ready = true; return KMX_OK; }
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   const ColsOps& CO = cols_ops((int)H.kw);
+  if (H.ordered) { H.body_ready = true; return KMX_OK; }      // (the kernels wrote the rows at their final place: d_out is the body)
   if (H.kernel == 2 && H.sparse_rows) {
     const u32 ng = CO.groups(H.slots_cap);
     u8* d_body = (u8*)ctx->dalloc(body);
@@ -1105,6 +1142,7 @@ extern "C" int kmx_result_copy_order(kmx_merge_result* R, uint32_t t, uint32_t* 
   if (H.rows > 0xFFFFFFFFULL || H.arena_rows > 0xFFFFFFFFULL) return ctx->fail(KMX_E_UNSUPPORTED, "more than 2^32 rows in one task");
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   const ColsOps& CO = cols_ops((int)H.kw);
+  if (H.ordered) { for (u64 r = 0; r < H.rows; r++) host_order[r] = (u32)r; return KMX_OK; }
   if (H.kernel == 2 && H.sparse_rows) {
     const u32 ng = CO.groups(H.slots_cap);
     u32* d_order = (u32*)ctx->dalloc((size_t)H.rows * 4);
@@ -1237,7 +1275,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
 #endif
   for (auto& H : R->tasks) {
     if (H.ev_body) { (void)hipEventSynchronize(H.ev_body); (void)hipEventDestroy(H.ev_body); }
-    ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); ctx->dfree(H.d_body); ctx->dfree(H.d_body_tmp);
+    ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); ctx->dfree(H.d_body); ctx->dfree(H.d_body_tmp); ctx->dfree(H.d_dense);
   }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);

@@ -61,6 +61,17 @@ struct ColsDev {
   u32 nblk;                // column blocks
   u32 nb;                  // lists per column block (the last one may hold fewer)
   u32 rt;                  // row keys per tile
+  // rows at their final place (file order) out of the two kernels: k_merge_cols leaves the row keys' rows -- payload only, the key
+  // is in skel -- in `dense` (row r at r * dpitch), k_cols_sparse writes every slice group's rows, those included, at the
+  // group's place in the arena (group offsets by a decoupled look-back over `chain`)
+  u8* dense;               // null: rows where the kernels leave them (row keys' rows first, the others behind, + directory)
+  u32 dpitch;              // bytes between two rows of `dense` (payload rounded up to 8)
+  u32 dense_cap;           // rows `dense` holds
+  u32* gbase;              // [c + 1] slice groups of the task in front of range j (k_cols_prep)
+  u64* chain;              // [groups] status << 62 | rows: 1 = the group's own rows, 2 = all rows up to and including it
+  uint4* gmap;             // [groups] (range, group in the range, the range's first and last row key) of the task's g-th slice group
+  u32* gmax;               // -> max over the batch's tasks of their slice groups (k_cols_sparse's tickets end there)
+  u32 ngcap;               // entries of chain / gmap
 };
 
 // rows are claimed from a task's arena in chunks of this many bytes (one global atomic + one directory entry per chunk)

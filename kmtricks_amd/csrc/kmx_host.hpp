@@ -34,7 +34,7 @@ struct ColsOps {
   hipError_t (*skel)(const TaskDev* subs, const uint2* items, u32 n_items, hipStream_t st);
   hipError_t (*prep)(const TaskDev* tasks, const TaskDev* subs, const ColsDev* cols, u32 n_tasks, hipStream_t st);
   hipError_t (*merge)(int mode, int ext, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st);
-  hipError_t (*sparse)(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st);
+  hipError_t (*sparse)(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, u32 n_tasks, u32* ticket, u32 n_cu, hipStream_t st);
   u64 (*dir_bytes)(u32 slots);
   u32 (*groups)(u32 slots);
   hipError_t (*offsets)(const ColsDev* cols, u32 task, u64* goff, hipStream_t st);
@@ -109,6 +109,10 @@ struct kmx_ctx {
   // sized for 2 x the longest list would make every batch run twice)
   double rows_per_longest = 0.0;
   bool cols_ext = false;                // a batch was handed back for full set-aside slices: k_merge_cols with slice extensions from here on
+  // COUNT / PA rows of the column-blocked pair come out in file order (the matrix body as the reference streams it,
+  // merge.hpp:262-272): kmx_set_file_order, KMX_FILE_ORDER=0 for the rows where the kernels leave them + a directory
+  bool file_order = true;
+  double keys_per_longest = 0.0;        // row keys per record of the longest list they were merged from, as completed batches had it
   // abundance histogram (kmx_hist_reset / kmx_hist_read): distinct keys per count 0..255, [256] = keys counted more than 255
   // times, [257] = the sum of those counts.  Every count call adds to it while it is on.
   unsigned long long* d_hist = nullptr;

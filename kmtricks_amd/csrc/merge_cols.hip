@@ -321,21 +321,22 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
   __shared__ u32 s_n[CP_MAXSEG];
   const u32 tid = threadIdx.x;
   const u64 serr = S.ctrl[2], nseg64 = S.ctrl[1], rows = S.ctrl[3];
+  if (tid == 0) T.ctrl[7] = rows;      // (the host sizes the next batches' stores of row keys' rows from it, whatever becomes of this task)
   const u64 slots = rows / C.rt + T.c + 2;
   const bool bad = serr != 0 || nseg64 > (u64)CP_MAXSEG || nseg64 > S.seg_cap || rows > T.out_cap_rows || rows > 0xFFFFFF00ULL ||
-                   slots > C.slots_cap;
+                   slots > C.slots_cap || (C.dense != nullptr && rows > (u64)C.dense_cap);
   // the share of the merged lists' solid records that the row keys do not cover estimates what every list would set aside:
   // above 1/8 the slices would overflow (and k_merge_pivot gives up at the same point): straight to k_merge_rows
   const u64 nsolid = S.ctrl[4], ncov = S.ctrl[5];
   const bool divergent = (nsolid - ncov) * 8 > nsolid;
   if (divergent && !bad) {
     if (tid == 0) { atomicOr(&T.ctrl[2], (u64)(ERR_FALLBACK | ERR_DIVERGENT)); *C.nskel = 0; atomicAdd(&kmx_cols_dbg[4], 1u); }
-    for (u32 j = tid; j <= T.c; j += CP_TPB) C.rbounds[j] = 0;
+    for (u32 j = tid; j <= T.c; j += CP_TPB) { C.rbounds[j] = 0; if (C.gbase) C.gbase[j] = 0; }
     return;
   }
   if (bad) {   // the row keys could not be built (arena too small, ...): the general kernels take the task
     if (tid == 0) { atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK); *C.nskel = 0; }
-    for (u32 j = tid; j <= T.c; j += CP_TPB) C.rbounds[j] = 0;
+    for (u32 j = tid; j <= T.c; j += CP_TPB) { C.rbounds[j] = 0; if (C.gbase) C.gbase[j] = 0; }      // (no slice groups: k_cols_sparse has nothing to wait for)
     return;
   }
   const u32 nseg = (u32)nseg64;
@@ -374,6 +375,25 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
     T.ctrl[0] = rows; T.ctrl[1] = 1; T.ctrl[3] = rows;
     Seg sg; sg.range = 0; sg.seq = 0; sg.row_off = 0; sg.nrows = (u32)rows; sg.pad = 0;
     T.segs[0] = sg;
+  }
+  if (C.gbase) {
+    // file order out of the kernels: the task's slice groups numbered in key order -- k_cols_sparse hands them out by ticket in that
+    // order (a group's place in the arena is the sum of the rows of the groups in front of it: decoupled look-back)
+    __shared__ u32 s_ng;
+    __syncthreads();
+    if (tid == 0) {
+      u32 g = 0;
+      for (u32 j = 0; j < T.c; j++) { C.gbase[j] = g; const u32 n = C.rbounds[j + 1] - C.rbounds[j]; g += max(1u, (n + C.rt - 1) / C.rt) * (u32)CL_HALVES; }
+      C.gbase[T.c] = g; s_ng = g;
+      atomicMax(C.gmax, g);
+    }
+    __syncthreads();
+    const u32 ng = s_ng;
+    for (u32 g = tid; g < ng; g += CP_TPB) {
+      u32 lo = 0, hi = T.c;      // the last range with gbase <= g
+      while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (C.gbase[mid] <= g) lo = mid; else hi = mid; }
+      C.gmap[g] = make_uint4(lo + 1, g - C.gbase[lo], C.rbounds[lo], C.rbounds[lo + 1]);      // (range + 1: 0 = no such group; all k_cols_sparse needs to start on the group, in one load)
+    }
   }
 }
 
@@ -438,6 +458,11 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
     const u32 slot0 = s_lo / rt + range;
     const CKey* const skel = reinterpret_cast<const CKey*>(C.skel);
+    // where the row keys' rows go: the arena, row r at row r (key + payload) -- or, when the rows are to come out in file order,
+    // the side store k_cols_sparse copies them from (payload only: the key is in skel)
+    const bool ord = cl_uni(C.dense != nullptr ? 1u : 0u) != 0;
+    u8* const obase = ord ? C.dense : T.out + KW * 8;
+    const u32 opitch = ord ? cl_uni(C.dpitch) : row_bytes;
 
     // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + CL_G * u
     // (mod CL_W) inside [cur, cur + CL_W)
@@ -473,7 +498,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         have[x] = j < rt && s_lo + j < s_hi;
         if (have[x]) {
           skn[x] = skel[s_lo + j];
-          if (blk == 0) ck_store(reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes), skn[x]);
+          if (blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes), skn[x]);
         }
       }
       const u32 mult = cl_build(ptab, skn, have, (u32)tid, myslot);
@@ -648,18 +673,18 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           for (int x = 0; x < CL_KPL; x++) {
             const u32 j = (u32)lane + 64u * x;
             have[x] = j < rt && sn + j < s_hi;
-            if (have[x] && blk == 0) ck_store(reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes), skn[x]);
+            if (have[x] && blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes), skn[x]);
           }
           const u32 m2 = cl_build(ptab + ((q + 1) % CL_NT) * CL_PT, skn, have, (u32)lane, myslot);
           if (lane == 0) { sh[4 + ((q + 1) % CL_NT)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
         if (MODE == 0) {
-          u8* const out0 = T.out + (u64)s0 * row_bytes + KW * 8 + 4ull * col0;
-          const bool wide = ((row_bytes | (4u * col0) | (4u * nbs)) & 7u) == 0;
+          u8* const out0 = obase + (u64)s0 * opitch + 4ull * col0;
+          const bool wide = ((opitch | (4u * col0) | (4u * nbs)) & 7u) == 0;
           for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
             u32* const src = img + j * nbs;
-            u8* const dst = out0 + (u64)j * row_bytes;
+            u8* const dst = out0 + (u64)j * opitch;
             if (wide) {
               const u32 n2 = nbl >> 1;
               for (u32 t0 = 0; t0 < n2; t0 += 256) {
@@ -676,11 +701,11 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           }
         } else {
           // a row's slice is (lists of the block) / 8 bytes (the block starts at a multiple of 8 lists): a byte per lane
-          u8* const out0 = T.out + (u64)s0 * row_bytes + KW * 8 + (col0 >> 3);
+          u8* const out0 = obase + (u64)s0 * opitch + (col0 >> 3);
           const u32 nby = (nbl + 7) >> 3;
           for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
             u32* const src = img + j * iw;
-            u8* const dst = out0 + (u64)j * row_bytes;
+            u8* const dst = out0 + (u64)j * opitch;
             for (u32 t = lane; t < nby; t += 64) dst[t] = (u8)(src[t >> 2] >> ((t & 3u) * 8));
             for (u32 t = lane; t < iw; t += 64) src[t] = 0;      // (same wave, behind the reads)
           }
@@ -818,18 +843,65 @@ __device__ __forceinline__ void ck_sort_block(CKey* ck, u64* cp, u32 P, u32 tid)
   }
 }
 
-template <int MODE, bool RESC>
-__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores)
-void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items)
+// a kept run in runs[]: its first entry (11 bits: < CK_CAND) | its entries << 11 (13 bits: one per list, <= 4096) | (ORD) how many of the
+// pass's row keys lie below its key << 24 (<= 56)
+static_assert(CK_CAND <= 2048, "11 bits for a run's first entry");
+#define CK_RUN_I0(v) ((v) & 0x7FFu)
+#define CK_RUN_LEN(v) (((v) >> 11) & 0x1FFFu)
+#define CK_RUN_ND(v) ((v) >> 24)
+constexpr u32 CK_OVF = 0xFFFFFFFFu;      // a pass found more candidates than the LDS holds
+
+// ---- ORD: the rows in front of a slice group.  A task's groups are numbered in key order (k_cols_prep) and handed out by ticket in
+//      that order; chain[g] = status << 62 | rows.  Wave 0 of the workgroup that holds group g publishes the group's own rows
+//      (status 1) as soon as it knows them -- before it waits for anything --, adds up its predecessors' entries backwards until it
+//      meets one that carries a whole prefix (status 2), and publishes its own prefix.  The holder of the lowest unfinished ticket
+//      never waits: no deadlock whatever the number of resident workgroups. ----
+__device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mine, const u32 lane)
+{
+  constexpr u64 VAL = (1ULL << 62) - 1ULL;
+  if (g == 0) { if (lane == 0) __hip_atomic_store(&chain[0], (2ULL << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+  if (lane == 0) __hip_atomic_store(&chain[g], (1ULL << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u64 excl = 0;
+  u32 i = g;      // the entries below i are still to be added
+  for (;;) {
+    const u64 v = lane < i ? __hip_atomic_load(&chain[i - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ULL << 62);      // (in front of group 0: a prefix of 0)
+    const u32 st = (u32)(v >> 62);
+    const u64 inv = __ballot(st == 0), pfx = __ballot(st == 2);
+    const u32 lim = inv ? (u32)__builtin_ctzll(inv) : 64u;      // the lanes below lim hold published entries
+    const u64 pm = lim == 64u ? pfx : (pfx & ((1ULL << lim) - 1ULL));
+    const u32 take = pm ? (u32)__builtin_ctzll(pm) + 1u : lim;
+    u64 s = lane < take ? (v & VAL) : 0ULL;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += shfl_xor_u64(s, off);
+    excl += s;
+    if (pm) break;
+    i -= take;
+    if (take == 0) __builtin_amdgcn_s_sleep(8);
+  }
+  if (lane == 0) __hip_atomic_store(&chain[g], (2ULL << 62) | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
+// ORD (rows at their final place): the kernel is persistent, a slice group per ticket; a group's passes are cut by KEY RANGE (at the
+// group's row keys), so that a pass's rows -- the row keys' rows of its stretch, copied from C.dense, and the rows of the keys set
+// aside there, interleaved by key -- are one contiguous run of the body; the group's place comes from the look-back above.  A
+// group of several passes counts its rows first (every pass sorted once without writing), publishes, and sorts again to write.
+template <int MODE, bool RESC, bool ORD>
+__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : ORD ? 2 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores: one workgroup per CU either way, and the ORD build keeps four row keys' rows per wave in flight)
+void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items, u32 n_tasks, u32* tkt)
 {
   __shared__ __attribute__((aligned(16))) u32 uni[CK_UNI / 4];      // the key maps | the row keys and interval counters (recurrence-min 1) | the rows' staging
   u32* const bits = uni;
   u32* const bits2 = uni + CK_BITS / 32;
   __shared__ CKey ck[CK_CAND];           // candidate keys
   __shared__ u64 cp[CK_CAND];            // ... and their (list << 32 | count)
-  __shared__ u32 runs[CK_CAND];          // kept runs: first entry | length << 16 ... as two words: see below
+  __shared__ u32 runs[CK_CAND];          // kept runs (CK_RUN_*)
   __shared__ u32 wsum[CK_TPB / 64];
-  __shared__ u32 flag, total, ncand, rowbase, sover;
+  __shared__ u32 total, ncand, rowbase, sover;
+  __shared__ CKey dkeys[ORD ? 64 : 1];   // ORD: the group's row keys
+  __shared__ u32 dpos[ORD ? 64 : 1];     // ... and where their rows go among the pass's rows
+  __shared__ u32 s_tk;
+  __shared__ u64 s_base;
   u32* const parow = uni;                // PA, rows too long for the staging below: a row per lane group is assembled here (<= 4096 lists + key)
   static_assert((CK_TPB / 16) * 136 * 4 <= CK_UNI, "the lane groups' rows fit the block");
   auto ent_key = [](const u64* kp, u32 e) -> CKey {
@@ -839,40 +911,36 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     CKey k; k.lo = kp[EW * e]; k.hi = kp[EW * e + 1]; return k;
 #endif
   };
-  const u32 item = blockIdx.x;
-  if (item >= n_items) return;
 #ifdef KMX_PHASE_PROF
   long long spt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long spc = clock64();
 #define SPPH(i) do { const long long n_ = clock64(); spt[i] += n_ - spc; spc = n_; } while (0)
 #else
 #define SPPH(i) do {} while (0)
 #endif
-  const TaskDev& T = tasks[items[item].x];
-  const ColsDev& C = cols[items[item].x];
-  if (T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) return;
-  // thr: solid records that make a key a row (RESC: 0 is taken literally -- a key only non-solid records hold is a row of zeros);
-  // share: solid records from which a key's non-solid records are rescued (0: never)
-  const u32 range = items[item].y, thr = RESC ? T.rec_min : max(1u, T.rec_min), share = RESC ? T.share_min : 0u, rt = C.rt, nsl = C.nblk * CL_NW, row_bytes = T.row_bytes;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto pl_list = [](u64 pl) -> u32 { return (u32)(pl >> 32) & 0x7FFFFFFFu; };
   auto pl_solid = [](u64 pl) -> bool { return !RESC || !(pl & CL_NONSOLID); };
-  const u32 s_lo = C.rbounds[range], s_hi = C.rbounds[range + 1];
-  const u32 ntiles = max(1u, (s_hi - s_lo + rt - 1) / rt);
-  const u32 slot0 = (s_lo / rt + range) * CL_HALVES;
-  const u32 ngroups = ntiles * CL_HALVES;
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  SpDir* const dir = reinterpret_cast<SpDir*>(C.spdir);
-  if (tid == 0) { flag = 0; total = 0; sover = 0; }
+  if (tid == 0) { total = 0; sover = 0; }
   __syncthreads();
-  const bool single = nsl <= (u32)CK_TPB / 4;
-  for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) {
+
+  // ---- one slice group (the records the column blocks set aside for half a tile); false: the task is handed back ----
+  auto group = [&](const TaskDev& T, const ColsDev& C, const u32 range, const u32 q, const u32 s_lo, const u32 s_hi, const u32 gord) -> bool {
+    // thr: solid records that make a key a row (RESC: 0 is taken literally -- a key only non-solid records hold is a row of zeros);
+    // share: solid records from which a key's non-solid records are rescued (0: never)
+    const u32 thr = RESC ? T.rec_min : max(1u, T.rec_min), share = RESC ? T.share_min : 0u, rt = C.rt, nsl = C.nblk * CL_NW, row_bytes = T.row_bytes;
+    const u32 slot0 = (s_lo / rt + range) * CL_HALVES;
+    SpDir* const dir = reinterpret_cast<SpDir*>(C.spdir);
+    const bool single = nsl <= (u32)CK_TPB / 4;
     const u64 sbase = (u64)(slot0 + q) * nsl;
     const u32 gid = slot0 + q;
+    auto hand_back = [&](int why) { if (tid == 0) { atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK); atomicAdd(&kmx_cols_dbg[why], 1u); } };
     // the group's row keys: rows [d0, d0 + dn) (a tile's first half: 56 rows, second: the rest)
     const u32 tq = q / CL_HALVES, hq = q % CL_HALVES;
     const u32 t0 = s_lo + tq * rt, te = min(s_hi, t0 + rt);
     u32 d0 = t0, dn = te - t0;
     if (CL_HALVES > 1) { const u32 mid = min(te, t0 + 56u); d0 = hq ? mid : t0; dn = hq ? te - mid : mid - t0; }
     if (s_hi == s_lo) { d0 = s_lo; dn = 0; }
+    if (ORD && tid < dn) dkeys[tid] = reinterpret_cast<const CKey*>(C.skel)[d0 + tid];
     // four threads per (block, wave) slice; when every slice has its four threads at once (<= 1024 lists) a slice's count and its
     // first 20 entries (5 per thread; the usual slice holds ~14; the slice's memory is there whatever the count) are requested
     // together and kept in registers for both walks over the entries: one memory round trip per group
@@ -904,9 +972,10 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     const bool over = sover != 0;
     __syncthreads();
     SPPH(0);
-    if (tid == 0) { total = 0; dir[(u64)gid * CK_NPASS].dense_first = d0; dir[(u64)gid * CK_NPASS].dense_n = dn; }
-    if (over) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[1], 1u); } break; }
-    if (tot == 0) continue;
+    if (tid == 0) { total = 0; sover = 0; if (!ORD) { dir[(u64)gid * CK_NPASS].dense_first = d0; dir[(u64)gid * CK_NPASS].dense_n = dn; } }
+    bool failed = false;
+    if (over) { hand_back(1); if (!ORD) return false; failed = true; }
+    if (!ORD && tot == 0) return true;
     // passes: ~1400 entries each when every entry is a candidate, ~3000 when only the keys seen twice are
 #ifndef KMX_CK_PER1
 #define KMX_CK_PER1 1400
@@ -914,18 +983,22 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     const u32 per = (thr <= 1 ? (u32)KMX_CK_PER1 : 3000u) * (u32)CK_CAND / 2048u;
     u32 npass = 1;
     if (!(MODE == 1 && thr <= 1 && tot <= (u32)CK_CAND)) while (npass < (u32)CK_NPASS && tot > per * npass) npass <<= 1;      // (PA rows at recurrence-min 1 -- every entry a candidate, placed by the sample sort -- when all of them fit: one pass, no margin needed)
-    if (tot > per * npass * 2) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
-    // each of my entries through f(key, payload): four threads per slice
-    auto each = [&](u32 pass, auto&& f) {
+    if (!ORD && tot > per * npass * 2) { hand_back(3); return false; }
+    if (ORD) {
+      if (thr <= 1 && tot <= (u32)CK_CAND) npass = 1;      // (every entry a candidate, and they fit: a pass too full would only be cut finer and sorted again)
+      while (npass > 1 && npass > dn) npass >>= 1;         // (cut at the group's row keys: a pass holds at least one)
+    }
+    // each of my entries of the pass in hand through f(key, payload): four threads per slice
+    auto each = [&](auto&& in_pass, auto&& f) {
       if (single) {
         const u32 sub = tid & 3u;
 #pragma unroll
         for (int x = 0; x < CK_SPEC; x++)
-          if (sub + 4 * x < n0 && !(npass > 1 && ((cl_mix(kk0[x]) >> 24) & (npass - 1)) != pass)) f(kk0[x], pp0[x]);
+          if (sub + 4 * x < n0 && in_pass(kk0[x])) f(kk0[x], pp0[x]);
         for (u32 e = sub + 4 * CK_SPEC; e < n0; e += 4) {
           const u64* const kp = e < (u32)CL_OVW ? kp0 : kpx0; const u32 ee = e < (u32)CL_OVW ? e : e - (u32)CL_OVW;      // (the slice, then its extension)
           const CKey k = ent_key(kp, ee);
-          if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
+          if (!in_pass(k)) continue;
           f(k, kp[EW * ee + KW]);
         }
         return;
@@ -941,7 +1014,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         for (u32 e = sub; e < n; e += 4) {
           const u64* const kp = e < (u32)CL_OVW ? kpb : kpx; const u32 ee = e < (u32)CL_OVW ? e : e - (u32)CL_OVW;
           const CKey k = ent_key(kp, ee);
-          if (npass > 1 && ((cl_mix(k) >> 24) & (npass - 1)) != pass) continue;
+          if (!in_pass(k)) continue;
           f(k, kp[EW * ee + KW]);
         }
       }
@@ -956,8 +1029,19 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       const u32 ps = b0 + (u32)__popcll(act & ((1ULL << lane) - 1ULL));
       if (ps < (u32)CK_CAND) { ck[ps] = k; cp[ps] = pl; }
     };
-    for (u32 pass = 0; pass < npass; pass++) {
+
+    // ---- a pass, first half: its candidates gathered and sorted, the kept runs in runs[] -> how many (CK_OVF: more candidates than
+    //      fit).  final: the rescue's statistics are added and the entries marked for the rows (a counting sweep must do neither).
+    //      ORD: the pass holds the keys between row keys dlo and dlo + dnp of the group. ----
+    auto sort_pass = [&](const u32 pass, const bool final, const u32 dlo, const u32 dnp) -> u32 {
       constexpr bool BY_INTERVAL = MODE == 1;      // (count rows -- 4 N bytes each -- are bound by their stores: +-0 there, 20 more registers)
+      CKey plo = ck_inf(), phi = ck_inf(); bool has_lo = false, has_hi = false;
+      if (ORD && npass > 1) { has_lo = pass > 0; has_hi = pass + 1 < npass; if (has_lo) plo = dkeys[dlo]; if (has_hi) phi = dkeys[dlo + dnp]; }
+      auto in_pass = [&](CKey k) -> bool {
+        if (npass <= 1) return true;
+        if (ORD) return !(has_lo && ck_lt(k, plo)) && !(has_hi && !ck_lt(k, phi));
+        return ((cl_mix(k) >> 24) & (npass - 1)) == pass;      // (by hash bits: equal keys meet in the same pass)
+      };
       if (thr > 1) {
         for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
         for (u32 t = tid; t < (u32)CK_B2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
@@ -970,7 +1054,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       bool sorted = false;
       u32 nc1 = 0;
       if (thr <= 1 && !BY_INTERVAL) {
-        each(pass, push);
+        each(in_pass, push);
         __syncthreads();
       }
       if (thr <= 1 && BY_INTERVAL) {
@@ -986,13 +1070,13 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         CKey* const sk = reinterpret_cast<CKey*>(bits + 1024);                // [NS] the samples
         u64* const sp = reinterpret_cast<u64*>(bits + 1024 + NS * (sizeof(CKey) / 4));      // [NS] (their payloads: the network sorts pairs)
         // (the entries are gathered first, as they come: then every thread of the workgroup has its four to work on at once)
-        each(pass, push);
+        each(in_pass, push);
         __syncthreads();
         SPPH(7);
         nc1 = ncand;
         if (nc1 <= (u32)CK_CAND) {
           constexpr int PER = CK_CAND / CK_TPB;      // entries per thread
-          const u32 stride = (nc1 + NS - 1) / NS, ns = (nc1 + stride - 1) / stride, SP = ns <= 128u ? 128u : 256u;
+          const u32 stride = (nc1 + NS - 1) / NS, ns = stride ? (nc1 + stride - 1) / stride : 0u, SP = ns <= 128u ? 128u : 256u;
           for (u32 t = tid; t < SP; t += CK_TPB) { sk[t] = t < ns ? ck[t * stride] : ck_inf(); sp[t] = t < ns ? cp[t * stride] : ~0ULL; }      // (key AND payload: a key that hundreds of lists hold is cut into intervals like any other stretch)
           __syncthreads();
           ck_sort_block(sk, sp, SP, tid);
@@ -1056,7 +1140,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         __syncthreads();
       }
       if (thr > 1) {
-        each(pass, [&](CKey k, u64) {
+        each(in_pass, [&](CKey k, u64) {
           const u32 hx = cl_mix(k);
           const u32 bit = hx & (CK_BITS - 1);
           const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
@@ -1066,7 +1150,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         SPPH(2);
       }
       if (thr > 1) {
-        each(pass, [&](CKey k, u64 pl) {
+        each(in_pass, [&](CKey k, u64 pl) {
           const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
           push(k, pl);
         });
@@ -1074,9 +1158,8 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       }
       SPPH(3);
       const u32 nc = ncand;
-      if (nc > (u32)CK_CAND) { if (tid == 0) { flag = 1; atomicAdd(&kmx_cols_dbg[3], 1u); } break; }
-      if (tid == 0) { dir[(u64)gid * CK_NPASS + pass].base = 0; dir[(u64)gid * CK_NPASS + pass].n = 0; }
-      if (nc == 0) { __syncthreads(); continue; }
+      if (nc > (u32)CK_CAND) return CK_OVF;
+      if (nc == 0) return 0u;
       if (!sorted) {
         u32 P = 128; while (P < nc) P <<= 1;
         for (u32 t = nc + tid; t < P; t += CK_TPB) { ck[t] = ck_inf(); cp[t] = ~0ULL; }      // (pads: larger than any entry, the key of all ones included)
@@ -1097,15 +1180,23 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           const CKey k = ck[i];
           const bool first = i == 0 || !ck_eq(ck[i - 1], k);
           bool kept = first && (thr == 0 || (i + thr - 1 < nc && ck_eq(ck[i + thr - 1], k) && pl_solid(cp[i + thr - 1])));
+          u32 len = 1;
           if (RESC && first) {
-            u32 len = 1; while (i + len < nc && ck_eq(ck[i + len], k)) len++;
+            while (i + len < nc && ck_eq(ck[i + len], k)) len++;
             u32 ns = 0; while (ns < len && pl_solid(cp[i + ns])) ns++;
-            if (share && ns >= share) for (u32 e = ns; e < len; e++) { const u64 pl = cp[i + e]; atomicAdd(&T.stats[1 * (u64)T.N + pl_list(pl)], 1ULL); atomicAdd(&T.stats[5 * (u64)T.N + pl_list(pl)], (u64)(u32)pl); }
-            if (kept) rl[x] = i | (len << 16);
+            if (final && share && ns >= share) for (u32 e = ns; e < len; e++) { const u64 pl = cp[i + e]; atomicAdd(&T.stats[1 * (u64)T.N + pl_list(pl)], 1ULL); atomicAdd(&T.stats[5 * (u64)T.N + pl_list(pl)], (u64)(u32)pl); }
             // the row's entries: the solid ones, and all of them when the rescue applies -- marked by clearing / keeping the flags:
             // a non-solid entry that is NOT rescued gets count 0 (it must not reach the row)
-            if (kept && !(share && ns >= share)) for (u32 e = ns; e < len; e++) cp[i + e] &= ~0xFFFFFFFFULL;
-          } else if (kept) { u32 len = 1; while (i + len < nc && ck_eq(ck[i + len], k)) len++; rl[x] = i | (len << 16); }      // (len <= lists <= 4096, i < 2048)
+            if (final && kept && !(share && ns >= share)) for (u32 e = ns; e < len; e++) cp[i + e] &= ~0xFFFFFFFFULL;
+          } else if (kept) { while (i + len < nc && ck_eq(ck[i + len], k)) len++; }      // (len <= lists <= 4096, i < 2048)
+          if (kept) {
+            rl[x] = i | (len << 11);
+            if (ORD) {      // the pass's row keys below this key (<= 56: six steps)
+              u32 lo = 0, hi = dnp;
+              while (lo < hi) { const u32 m = (lo + hi) >> 1; if (ck_lt(dkeys[dlo + m], k)) lo = m + 1; else hi = m; }
+              rl[x] |= lo << 24;
+            }
+          }
           km |= (kept ? 1u : 0u) << x; mine += kept ? 1u : 0u;
         }
       }
@@ -1116,16 +1207,98 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       for (u32 w = 0; w < CK_TPB / 64; w++) { if (w < wave) rank += wsum[w]; nk += wsum[w]; }
 #pragma unroll
       for (u32 x = 0; x < 4; x++) if ((km >> x) & 1u) runs[rank++] = rl[x];
-      if (tid == 0 && nk) {
-        const u64 at = atomicAdd(&T.ctrl[0], (u64)nk);      // rows of the arena: behind the row keys' rows
-        atomicAdd(&T.ctrl[3], (u64)nk); atomicAdd(&T.ctrl[6], (u64)nk);
-        if (at + nk > T.out_cap_rows) { atomicOr(&T.ctrl[2], (u64)ERR_ROWS_OVERFLOW); rowbase = 0xFFFFFFFFu; }
-        else { rowbase = (u32)at; dir[(u64)gid * CK_NPASS + pass].base = (u32)at; dir[(u64)gid * CK_NPASS + pass].n = nk; }
+      return nk;      // (runs[] is complete behind the caller's next barrier)
+    };
+
+    // ---- a pass, second half: its nk kept runs become rows [rb, rb + nk) of the arena -- ORD: rows [rb, rb + nk + dnp), the rows of
+    //      the pass's row keys (payload in C.dense) among them, by key ----
+    auto dense_places = [&](const u32 t, const u32 nk, const u32 dlo, const u32 dnp) {      // thread t < dnp: where row key dlo + t's row goes among the pass's rows -- behind the kept runs with a smaller key
+      const CKey k = dkeys[dlo + t];
+      u32 lo = 0, hi = nk;
+      while (lo < hi) { const u32 m = (lo + hi) >> 1; if (ck_lt(ck[CK_RUN_I0(runs[m])], k)) lo = m + 1; else hi = m; }
+      dpos[t] = t + lo;
+    };
+    auto write_pass = [&](const u64 rb, const u32 nk, const u32 dlo, const u32 dnp, const bool have_dpos) {
+      const u32 nrows = ORD ? nk + dnp : nk;
+      const u32 dwords = (row_bytes - (u32)KW * 8u + 3u) / 4u, dtail = (row_bytes - (u32)KW * 8u) & 3u;      // ORD: payload dwords of a row of C.dense, bytes of the last one (0: all four)
+      auto dense_src = [&](u32 i) -> const u32* { return reinterpret_cast<const u32*>(C.dense + (u64)(d0 + dlo + i) * C.dpitch); };
+      auto dense_word = [&](const u32* src, u32 w) -> u32 {      // dword w of the payload, the bytes behind it masked off
+        if (w >= dwords) return 0u;
+        const u32 v = src[w];
+        return (w + 1 == dwords && dtail) ? v & ((1u << (8u * dtail)) - 1u) : v;
+      };
+      if (ORD && !have_dpos) {
+        if (tid < dnp) dense_places(tid, nk, dlo, dnp);
+        __syncthreads();
       }
-      __syncthreads();
-      const u32 rb = rowbase;
-      SPPH(5);
-      if (MODE == 1 && nk && rb != 0xFFFFFFFFu && row_bytes * 8u + 16u <= (u32)CK_STAGE) {
+      // lanes per row: a wave for a count row (4 N bytes); 16 for a PA row (N / 8 bytes), 8 when that is at most 128 bytes
+      const u32 SG = MODE == 0 ? 64u : row_bytes <= 128u ? 8u : 16u;
+      const u32 sg = tid / SG, sl = tid % SG;      // my lane group, my lane in it
+      // a PA row starts at any byte (rows are row_bytes apart): the aligned dwords inside the row are stored whole, each taken
+      // from two words of the row as word(w) gives them, the <= 3 bytes before and after them one by one
+      auto put_bytes = [&](u8* const row, auto&& word) {
+        const u32 head = (4u - (u32)((uintptr_t)row & 3u)) & 3u;
+        const u32 nd = (row_bytes - head) / 4, tail0 = head + 4 * nd;
+        if (sl < head) row[sl] = (u8)(word(0) >> (sl * 8));
+        for (u32 t = sl; t < nd; t += SG) {
+          const u32 off = head + 4 * t, w = off >> 2;
+          const u64 two = (u64)word(w) | ((u64)word(w + 1) << 32);
+          reinterpret_cast<u32*>(row + off)[0] = (u32)(two >> ((off & 3u) * 8));
+        }
+        if (sl < row_bytes - tail0) { const u32 t = tail0 + sl; row[t] = (u8)(word(t >> 2) >> ((t & 3u) * 8)); }
+      };
+      // ORD: the row keys' rows -- key from the group's row keys, payload from C.dense -- a lane group per row.  Count rows: four
+      // rows of a wave in flight at once (a row is read at the latency of HBM: one at a time a wave would spend its time waiting)
+      auto dense_rows = [&]() {
+        if (MODE == 0) {
+          constexpr int RF = 4;
+          const bool wide = (row_bytes & 7u) == 0;      // (C.dense's rows are 8-byte aligned)
+          const u32 n8 = row_bytes / 8, n4 = row_bytes / 4;
+          for (u32 i0 = wave * RF; i0 < dnp; i0 += (CK_TPB / 64) * RF) {
+            for (u32 t0 = 0; t0 < (wide ? n8 : n4); t0 += 8 * 64) {
+              u64 w[RF][8];
+#pragma unroll
+              for (int r = 0; r < RF; r++) {
+                const u32 i = i0 + r;
+                const u32* const src = dense_src(i < dnp ? i : 0);
+                u32 kw4[4] = {0, 0, 0, 0};
+                ck_store(kw4, dkeys[dlo + (i < dnp ? i : 0)]);
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                  const u32 t = t0 + 64 * x + lane;
+                  w[r][x] = 0;
+                  if (i < dnp) {
+                    if (wide) { if (t < n8) w[r][x] = t < (u32)KW ? ((u64)kw4[2 * (t & 1u)] | ((u64)kw4[2 * (t & 1u) + 1] << 32)) : reinterpret_cast<const u64*>(src)[t - KW]; }
+                    else if (t < n4) w[r][x] = t < 2u * KW ? kw4[t & 3u] : src[t - 2u * KW];
+                  }
+                }
+              }
+#pragma unroll
+              for (int r = 0; r < RF; r++) {
+                const u32 i = i0 + r;
+                if (i < dnp) {
+                  u8* const row = T.out + (rb + dpos[i]) * row_bytes;
+#pragma unroll
+                  for (int x = 0; x < 8; x++) {
+                    const u32 t = t0 + 64 * x + lane;
+                    if (wide) { if (t < n8) reinterpret_cast<u64*>(row)[t] = w[r][x]; }
+                    else if (t < n4) reinterpret_cast<u32*>(row)[t] = (u32)w[r][x];
+                  }
+                }
+              }
+            }
+          }
+        } else {
+          for (u32 i = sg; i < dnp; i += CK_TPB / SG) {
+            u8* const row = T.out + (rb + dpos[i]) * row_bytes;
+            const u32* const src = dense_src(i);
+            u32 kw4[4] = {0, 0, 0, 0};
+            ck_store(kw4, dkeys[dlo + i]);
+            put_bytes(row, [&](u32 w) -> u32 { return w < 2u * KW ? kw4[w & 3u] : dense_word(src, w - 2u * KW); });
+          }
+        }
+      };
+      if (MODE == 1 && nrows && row_bytes * 8u + 16u <= (u32)CK_STAGE) {
         // PA rows (N / 8 bytes behind the key, not a multiple of anything): the pass's rows are one contiguous run of the arena.  The
         // run's bytes are cut into 16-byte-aligned pieces of CB bytes; a wave assembles a piece in its own LDS block exactly as it
         // will lie in memory -- a lane per row that touches the piece (a row across a cut is assembled, in part, by both sides):
@@ -1134,7 +1307,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         // rows and go out byte by byte.  (Before: 8 lanes per row storing single dwords at odd offsets.)  No workgroup barrier.
         u32* const st = uni + wave * (CK_STAGE / 4);
         constexpr u32 CB = (u32)CK_STAGE & ~15u;
-        const uintptr_t A0 = (uintptr_t)(T.out + (u64)rb * row_bytes), Ae = A0 + (uintptr_t)nk * row_bytes, As = A0 & ~(uintptr_t)15;
+        const uintptr_t A0 = (uintptr_t)(T.out + rb * row_bytes), Ae = A0 + (uintptr_t)nrows * row_bytes, As = A0 & ~(uintptr_t)15;
         const u32 npieces = (u32)((Ae - As + CB - 1) / CB);
         for (u32 pc = wave; pc < npieces; pc += CK_TPB / 64) {
           const uintptr_t lo_a = As + (uintptr_t)pc * CB, hi_a = lo_a + CB < Ae ? lo_a + CB : Ae;      // the piece: [lo_a, hi_a), lo_a aligned
@@ -1144,15 +1317,15 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the zeros are in before the ORs
           // rows that touch the piece: [r0, r1]
           const u32 r0 = lo_a > A0 ? (u32)((lo_a - A0) / row_bytes) : 0u, r1 = (u32)((hi_a - 1 - A0) / row_bytes);
-          for (u32 r = r0 + lane; r <= r1; r += 64) {
-            const u32 rv = runs[r], i0 = rv & 0xFFFFu, len = rv >> 16;
+          auto or_dword = [&](int o, u32 w) {      // the 4 bytes of w at byte o of the piece, clipped to it
+            const int ix = o >> 2; const u32 sh = ((u32)o & 3u) * 8u;
+            const u32 w0 = w << sh, w1 = sh ? w >> (32u - sh) : 0u;
+            if (w0 && ix >= 0 && (u32)ix < nw16 * 4u) atomicOr(&st[ix], w0);
+            if (w1 && ix + 1 >= 0 && (u32)(ix + 1) < nw16 * 4u) atomicOr(&st[ix + 1], w1);
+          };
+          auto sparse_row = [&](const u32 r, const u32 rv) {      // row r of the pass's rows: the kept run rv
+            const u32 i0 = CK_RUN_I0(rv), len = CK_RUN_LEN(rv);
             const int b = (int)(long long)((long long)(A0 + (uintptr_t)r * row_bytes) - (long long)lo_a);      // the row's first byte in the piece (negative: it began in the piece before)
-            auto or_dword = [&](int o, u32 w) {      // the 4 bytes of w at byte o of the piece, clipped to it
-              const int ix = o >> 2; const u32 sh = ((u32)o & 3u) * 8u;
-              const u32 w0 = w << sh, w1 = sh ? w >> (32u - sh) : 0u;
-              if (w0 && ix >= 0 && (u32)ix < nw16 * 4u) atomicOr(&st[ix], w0);
-              if (w1 && ix + 1 >= 0 && (u32)(ix + 1) < nw16 * 4u) atomicOr(&st[ix + 1], w1);
-            };
             u32 kw4[4] = {0, 0, 0, 0};
             ck_store(kw4, ck[i0]);
 #pragma unroll
@@ -1164,6 +1337,14 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
               const int bo = b + 8 * (int)KW + (int)(li >> 3);
               if (bo >= 0 && (u32)bo < nw16 * 16u) atomicOr(&st[bo >> 2], 1u << (((u32)bo & 3u) * 8u + (li & 7u)));
             }
+          };
+          if (!ORD) {
+            for (u32 r = r0 + lane; r <= r1; r += 64) sparse_row(r, runs[r]);
+          } else if (nk) {
+            // the kept runs whose rows touch the piece: run j's row is j + (row keys below it, <= dnp), so they are among runs
+            // r0 - dnp .. r1 -- looked at without a search.  (The row keys' rows are left as zeros here and written afterwards.)
+            const u32 jmin = r0 > dnp ? r0 - dnp : 0u, jmax = min(nk - 1u, r1);
+            for (u32 j = jmin + lane; j <= jmax; j += 64) { const u32 rv = runs[j], r = j + CK_RUN_ND(rv); if (r >= r0 && r <= r1) sparse_row(r, rv); }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1182,30 +1363,19 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (my reads of the block are done before the next round's zeros)
         }
-      } else if (nk && rb != 0xFFFFFFFFu) {
-        // lanes per row: a wave for a count row (4 N bytes); 16 for a PA row (N / 8 bytes), 8 when that is at most 128 bytes
-        const u32 SG = MODE == 0 ? 64u : row_bytes <= 128u ? 8u : 16u;
-        const u32 sg = tid / SG, sl = tid % SG;      // my lane group, my lane in it
+        if (ORD && dnp) {
+          __syncthreads();      // (the pieces' zeros at the row keys' rows are out before the rows themselves)
+          dense_rows();
+        }
+      } else if (nrows) {
+        if (ORD && MODE == 0) dense_rows();      // (first: their reads are what a wave waits for)
         for (u32 j = sg; j < nk; j += CK_TPB / SG) {      // a lane group per row
-          const u32 i0 = runs[j] & 0xFFFFu, len = runs[j] >> 16;
+          const u32 rv = runs[j], i0 = CK_RUN_I0(rv), len = CK_RUN_LEN(rv);
           const CKey key = ck[i0];
-          u8* const row = T.out + (u64)(rb + j) * row_bytes;
+          u8* const row = T.out + (rb + (ORD ? j + CK_RUN_ND(rv) : j)) * row_bytes;
           u32 kw4[4] = {0, 0, 0, 0};
           ck_store(kw4, key);                      // the key's dwords (2 or 4 of them)
           auto kword = [&](u32 w) -> u32 { return w == 0 ? kw4[0] : w == 1 ? kw4[1] : w == 2 ? kw4[2] : kw4[3]; };
-          // a PA row starts at any byte (rows are row_bytes apart): the aligned dwords inside the row are stored whole, each taken
-          // from two words of the row as word(w) gives them, the <= 3 bytes before and after them one by one
-          auto put_bytes = [&](auto&& word) {
-            const u32 head = (4u - (u32)((uintptr_t)row & 3u)) & 3u;
-            const u32 nd = (row_bytes - head) / 4, tail0 = head + 4 * nd;
-            if (sl < head) row[sl] = (u8)(word(0) >> (sl * 8));
-            for (u32 t = sl; t < nd; t += SG) {
-              const u32 off = head + 4 * t, w = off >> 2;
-              const u64 two = (u64)word(w) | ((u64)word(w + 1) << 32);
-              reinterpret_cast<u32*>(row + off)[0] = (u32)(two >> ((off & 3u) * 8));
-            }
-            if (sl < row_bytes - tail0) { const u32 t = tail0 + sl; row[t] = (u8)(word(t >> 2) >> ((t & 3u) * 8)); }
-          };
           if (len == 1) {
             // the usual row here: a key one list holds (a private k-mer) -- every lane knows the whole row, no staging
             const u64 pl = cp[i0];
@@ -1221,7 +1391,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
                 for (u32 t = sl; t < row_bytes / 4; t += SG) r4[t] = t < 2u * KW ? kword(t) : (t - 2u * KW == li ? cnt : 0u);
               }
             } else {
-              put_bytes([&](u32 w) -> u32 { return w < 2u * KW ? kword(w) : (w - 2u * KW == (li >> 5) ? bitv << (li & 31u) : 0u); });
+              put_bytes(row, [&](u32 w) -> u32 { return w < 2u * KW ? kword(w) : (w - 2u * KW == (li >> 5) ? bitv << (li & 31u) : 0u); });
             }
             continue;
           }
@@ -1243,20 +1413,121 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             for (u32 e = sl; e < len; e += SG) { const u64 pl = cp[i0 + e]; const u32 li = pl_list(pl); if (!RESC || (u32)pl) atomicOr(&pr[2 * KW + (li >> 5)], 1u << (li & 31u)); }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            put_bytes([&](u32 w) -> u32 { return pr[w]; });
+            put_bytes(row, [&](u32 w) -> u32 { return pr[w]; });
           }
         }
+        if (ORD && MODE == 1) dense_rows();
       }
       __syncthreads();
       SPPH(6);
+    };
+
+    if (!ORD) {
+      for (u32 pass = 0; pass < npass; pass++) {
+        const u32 nk = sort_pass(pass, true, 0, 0);
+        if (nk == CK_OVF) { hand_back(3); return false; }
+        if (tid == 0) { dir[(u64)gid * CK_NPASS + pass].base = 0; dir[(u64)gid * CK_NPASS + pass].n = 0; }
+        if (nk == 0) { __syncthreads(); continue; }
+        if (tid == 0) {
+          const u64 at = atomicAdd(&T.ctrl[0], (u64)nk);      // rows of the arena: behind the row keys' rows
+          atomicAdd(&T.ctrl[3], (u64)nk); atomicAdd(&T.ctrl[6], (u64)nk);
+          if (at + nk > T.out_cap_rows) { atomicOr(&T.ctrl[2], (u64)ERR_ROWS_OVERFLOW); rowbase = 0xFFFFFFFFu; }
+          else { rowbase = (u32)at; dir[(u64)gid * CK_NPASS + pass].base = (u32)at; dir[(u64)gid * CK_NPASS + pass].n = nk; }
+        }
+        __syncthreads();
+        const u32 rb = rowbase;
+        SPPH(5);
+        if (rb != 0xFFFFFFFFu) write_pass((u64)rb, nk, 0, 0, false);
+        else __syncthreads();
+      }
+      return true;
     }
-    if (flag) break;
+    // ---- ORD: count the group's rows, publish, learn its place, write ----
+    __syncthreads();      // (dkeys)
+    u32 nks = 0;
+    while (!failed && tot) {
+      bool ovf = false;
+      nks = 0;
+      if (npass == 1) { const u32 r = sort_pass(0, true, 0, dn); if (r == CK_OVF) ovf = true; else nks = r; __syncthreads(); }
+      else for (u32 p = 0; p < npass; p++) {
+        const u32 dlo = (u32)(((u64)dn * p) / npass), dhi = (u32)(((u64)dn * (p + 1)) / npass);
+        const u32 r = sort_pass(p, false, dlo, dhi - dlo);
+        __syncthreads();
+        if (r == CK_OVF) { ovf = true; break; }
+        nks += r;
+      }
+      if (!ovf) break;
+      if (npass * 2 > (u32)CK_NPASS || npass * 2 > dn) { hand_back(3); failed = true; break; }
+      npass *= 2;      // (an uneven stretch of keys: finer passes)
+    }
+    const u64 grows = failed ? 0ULL : (u64)dn + nks;
+    if (wave == 0) { const u64 b = ck_lookback(C.chain, gord, grows, lane); if (lane == 0) s_base = b; }
+    else if (npass == 1 && !failed && tid - 64u < dn) dense_places(tid - 64u, nks, 0, dn);      // (beside the look-back: where the row keys' rows go)
+    __syncthreads();
+    SPPH(5);
+    if (failed) return false;
+    // (the task's row counters: behind the rows, where no barrier waits for the atomics -- the next one is the next ticket's)
+    auto count_rows = [&]() { if (tid == 0 && nks) { atomicAdd(&T.ctrl[0], (u64)nks); atomicAdd(&T.ctrl[3], (u64)nks); atomicAdd(&T.ctrl[6], (u64)nks); } };
+    const u64 base = s_base;
+    if (base + grows > T.out_cap_rows) { if (tid == 0) atomicOr(&T.ctrl[2], (u64)ERR_ROWS_OVERFLOW); count_rows(); return true; }      // (the batch is re-run with arenas of the size ctrl[0] asks for)
+    if (npass == 1) write_pass(base, nks, 0, dn, true);
+    else {
+      u64 b = base;
+      for (u32 p = 0; p < npass; p++) {
+        const u32 dlo = (u32)(((u64)dn * p) / npass), dhi = (u32)(((u64)dn * (p + 1)) / npass);
+        const u32 nk = sort_pass(p, true, dlo, dhi - dlo);
+        __syncthreads();
+        write_pass(b, nk, dlo, dhi - dlo, false);
+        b += nk + (dhi - dlo);
+      }
+    }
+    count_rows();
+    return true;
+  };
+
+  if (!ORD) {
+    // one workgroup per (task, range) x CK_Z, sharing the range's slice groups
+    const u32 item = blockIdx.x;
+    if (item < n_items) {
+      const TaskDev& T = tasks[items[item].x];
+      const ColsDev& C = cols[items[item].x];
+      if (!(T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW))) {
+        const u32 range = items[item].y, rt = C.rt;
+        const u32 s_lo = C.rbounds[range], s_hi = C.rbounds[range + 1];
+        const u32 ngroups = max(1u, (s_hi - s_lo + rt - 1) / rt) * CL_HALVES;
+        for (u32 q = blockIdx.y; q < ngroups; q += CK_Z) if (!group(T, C, range, q, s_lo, s_hi, 0u)) break;
+      }
+    }
+  } else {
+    // persistent: ticket t -> group t / n_tasks of task t % n_tasks (the tasks' chains advance side by side).  A ticket is taken
+    // only when the workgroup is ready to start on it: requesting the next one ahead (to hide the atomic's round trip) was tried and
+    // made the kernel 30 % slower -- a ticket held back for the length of a group holds back every later group of its task's chain.
+    for (;;) {
+      __syncthreads();
+      if (tid == 0) s_tk = atomicAdd(&tkt[1], 1u);
+      __syncthreads();
+      const u32 t = s_tk;
+      const u32 ti = t % n_tasks, g = t / n_tasks;
+      if (g >= tkt[2]) break;      // (k_cols_prep: the largest number of groups a task of the batch has)
+      const TaskDev& T = tasks[ti];
+      const ColsDev& C = cols[ti];
+      if (g >= C.ngcap) continue;
+      // (the group's descriptor and the task's error word in one round trip: no branch between the two loads)
+      const uint4 rq = C.gmap[g];
+      const u64 terr = __hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (rq.x == 0) continue;      // (beyond the task's groups: the map is zeroed before every batch)
+      if (terr & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) {
+        // a task that is handed back anyway: nobody may wait for this group
+        if (tid == 0) __hip_atomic_store(&C.chain[g], 2ULL << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
+      (void)group(T, C, rq.x - 1u, rq.y, rq.z, rq.w, g);
+    }
   }
-  __syncthreads();
 #ifdef KMX_PHASE_PROF
+  __syncthreads();
   if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&kmx_sparse_prof[i], (u64)spt[i]);
 #endif
-  if (tid == 0 && flag) atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK);
 }
 
 // ---- the body of a task the column-blocked merge completed: row keys' rows and the sparse rows, interleaved by key.
@@ -1424,15 +1695,36 @@ hipError_t launch_merge_cols(int mode, int ext, const TaskDev* tasks, const Cols
   return mode == 0 ? KMX_CL_LAUNCH(0) : KMX_CL_LAUNCH(1);
 #undef KMX_CL_LAUNCH
 }
-// mode: bit 0 = PA rows, bit 1 = the RESC build
-hipError_t launch_cols_sparse(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, hipStream_t st)
+template <int MODE, bool RESC>
+static hipError_t launch_cols_sparse_ord(const TaskDev* tasks, const ColsDev* cols, u32 n_tasks, u32* ticket, u32 n_cu, hipStream_t st)
 {
+  // persistent: as many workgroups as the device holds at once (a slice group per ticket)
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_cols_sparse<MODE, RESC, true>), CK_TPB, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    per_cu = n;
+  }
+  hipLaunchKernelGGL((k_cols_sparse<MODE, RESC, true>), dim3(n_cu * (u32)per_cu), dim3(CK_TPB), 0, st, tasks, cols, (const uint2*)nullptr, 0u, n_tasks, ticket);
+  return hipGetLastError();
+}
+// mode: bit 0 = PA rows, bit 1 = the RESC build, bit 2 = rows at their final place (ORD: persistent, tickets from ticket[1])
+hipError_t launch_cols_sparse(int mode, const TaskDev* tasks, const ColsDev* cols, const uint2* range_items, u32 n_items, u32 n_tasks, u32* ticket, u32 n_cu, hipStream_t st)
+{
+  if (mode & 4) {
+    switch (mode & 3) {
+      case 0: return launch_cols_sparse_ord<0, false>(tasks, cols, n_tasks, ticket, n_cu, st);
+      case 1: return launch_cols_sparse_ord<1, false>(tasks, cols, n_tasks, ticket, n_cu, st);
+      case 2: return launch_cols_sparse_ord<0, true>(tasks, cols, n_tasks, ticket, n_cu, st);
+      default: return launch_cols_sparse_ord<1, true>(tasks, cols, n_tasks, ticket, n_cu, st);
+    }
+  }
   const dim3 grid(n_items, CK_Z), block(CK_TPB);
   switch (mode & 3) {
-    case 0: hipLaunchKernelGGL((k_cols_sparse<0, false>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
-    case 1: hipLaunchKernelGGL((k_cols_sparse<1, false>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
-    case 2: hipLaunchKernelGGL((k_cols_sparse<0, true>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
-    default: hipLaunchKernelGGL((k_cols_sparse<1, true>), grid, block, 0, st, tasks, cols, range_items, n_items); break;
+    case 0: hipLaunchKernelGGL((k_cols_sparse<0, false, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
+    case 1: hipLaunchKernelGGL((k_cols_sparse<1, false, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
+    case 2: hipLaunchKernelGGL((k_cols_sparse<0, true, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
+    default: hipLaunchKernelGGL((k_cols_sparse<1, true, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
   }
   return hipGetLastError();
 }

@@ -510,6 +510,55 @@ int run(int argc, char** argv)
       double w_split = 0, w_count = 0;
       const uint64_t nm = 1ULL << (2 * o.msize);
       std::unique_ptr<ReadBatch> pending;      // (a batch taken from the queue that did not fit the call being put together)
+      // a whole sample through count FILES (no room in the stores, --keep-tmp, --no-resident): split + count in one call, the
+      // super-k-mer streams stay in HBM (kmx_count_reads), the counts come back and are written as counts/partition_<p>/<id>.kmer
+      auto whole_to_files = [&](const ReadBatch& b) {
+        // ---- the whole sample in one batch: split + count in one call, the super-k-mer streams stay in HBM (kmx_count_reads) ----
+        const auto t = clk::now();
+        const uint32_t si = b.si; const Sample& smp = samples[si];
+        tlog(g, "split_begin", si);
+        st.bases += b.bases.size();
+        std::vector<uint64_t*> keys(P, nullptr); std::vector<uint32_t*> cnts(P, nullptr); std::vector<uint64_t> cnt(P, 0), nkp(P, 0), info(2 * (size_t)P, 0);
+        std::vector<uint8_t*> ob(P, nullptr); std::vector<uint64_t> ol(P, 0);
+        auto pc = std::make_shared<std::vector<uint64_t>>(), ms = std::make_shared<std::vector<uint64_t>>(), mk = std::make_shared<std::vector<uint64_t>>();
+        kmx_superk_stats ks{};
+        if (!o.skip_pinfo) { pc->assign((size_t)P * KMX_PINFO_STRIDE, 0); ms->assign(nm, 0); mk->assign(nm, 0); ks.part_counters = pc->data(); ks.minim_superks = ms->data(); ks.minim_kmers = mk->data(); }
+        if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
+        chk(c, kmx_count_reads(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, smp.hard_min,
+                               keys.data(), cnts.data(), cnt.data(), nkp.data(), o.keep_tmp ? ob.data() : nullptr, o.keep_tmp ? ol.data() : nullptr, info.data(),
+                               o.skip_pinfo ? nullptr : &ks), "kmx_count_reads");
+        if (o.hist) writes.push_back(save_hist(c, si));
+        uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
+        st.kmers += nkt;
+        { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string(nkp[p]); s2 += "\n"; }      // every partition, as dump_pinfo does (gatb_utils.hpp:46-51; the split counts them all, fill_partitions.hpp:59-105)
+          Out pi(root + "/partition_infos/" + smp.id + ".pinfo"); pi.raw(s2.data(), s2.size()); pi.close(); }
+        const std::string sd = root + "/superkmers/" + smp.id; fs::create_directories(sd);
+        { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
+          for (uint32_t p = 0; p < P; p++) {
+            inf += std::to_string(selected[p] ? info[2 * p] : 0) + "\n" + std::to_string(selected[p] ? info[2 * p + 1] : 0) + "\n";
+            if (o.keep_tmp && selected[p]) { SuperkBlockWriter w(sd + "/skp." + std::to_string(p), p, o.cpr); w.add_stream(ob[p], ol[p], o.k); w.flush(); w.out.close(); }
+            if (o.keep_tmp) kmx_free(ob[p]);
+          }
+          Out f(sd + "/SuperKmerBinInfoFile"); f.raw(inf.data(), inf.size()); f.close(); }
+        if (!o.skip_pinfo) {
+          uint64_t nk_all = 0; for (uint32_t p = 0; p < P; p++) nk_all += nkp[p];
+          const uint64_t nsk = ks.nb_superk;
+          writes.push_back(pool.submit([=]() { try { write_parti_info(sd + "/PartiInfoFile", P, nm, nsk, nk_all, pc->data(), ms->data(), mk->data()); } catch (const std::exception& e) { die(e.what()); } }));
+        }
+        for (uint32_t p = 0; p < P; p++) {
+          uint64_t* kk = keys[p]; uint32_t* cc = cnts[p]; const uint64_t nn = cnt[p];
+          if (!selected[p]) { kmx_free(kk); kmx_free(cc); continue; }
+          writes.push_back(pool.submit([=, &o]() {
+            try { if (hash_mode) write_hash_file(count_path(p, si), si, p, kk, cc, nn); else write_kmer_file(count_path(p, si), o.k, si, p, kk, cc, nn, o.cpr); }
+            catch (const std::exception& e) { die(e.what()); }
+            kmx_free(kk); kmx_free(cc);
+          }));
+        }
+        tlog(g, "split_end", si);
+        w_count += since(t);
+        done++;
+        while (writes.size() > 4u * P) { writes.front().get(); writes.pop_front(); }
+      };
       while (done < per_gpu[g]) {
         ReadBatch b;
         if (pending) { b = std::move(*pending); pending.reset(); }
@@ -555,15 +604,25 @@ int run(int argc, char** argv)
             if (rawbufs[i]) { raws[i].part_radix = rawbufs[i]; raws[i].minim_sparse = rawbufs[i] + (size_t)P * 1280; raws[i].minim_sparse_cap = nm; }      // (sparse: ~10^5 of the 4^m minimizers occur in a sample)
           }
           if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
+          int crc = KMX_OK;
           if (S == 1)
-            chk(c, kmx_count_reads_dev(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
-                                       stores.data(), G, ls.data(), nkp_all.data(), nullptr, nullptr, info_all.data(), nullptr, rawbufs[0] ? &raws[0] : nullptr), "kmx_count_reads_dev");
+            crc = kmx_count_reads_dev(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
+                                      stores.data(), G, ls.data(), nkp_all.data(), nullptr, nullptr, info_all.data(), nullptr, rawbufs[0] ? &raws[0] : nullptr);
           else {
             std::vector<const char*> bp(S); std::vector<const uint64_t*> op(S); std::vector<uint64_t> ns(S);
             for (uint32_t i = 0; i < S; i++) { bp[i] = grp[i]->bases.data(); op[i] = grp[i]->offs.data(); ns[i] = grp[i]->offs.size() - 1; }
-            chk(c, kmx_count_reads_dev_multi(c, S, bp.data(), op.data(), ns.data(), o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
-                                             stores.data(), G, ls.data(), nkp_all.data(), info_all.data(), rawbufs[0] ? raws.data() : nullptr), "kmx_count_reads_dev_multi");
+            crc = kmx_count_reads_dev_multi(c, S, bp.data(), op.data(), ns.data(), o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
+                                            stores.data(), G, ls.data(), nkp_all.data(), info_all.data(), rawbufs[0] ? raws.data() : nullptr);
           }
+          if (crc == KMX_E_NOMEM) {
+            // a store filled up under us (the room check above is not atomic with the other workers' calls, and worst-case sizes
+            // are estimates): these samples go through count files, as a sample that finds the stores full up front does
+            for (uint32_t i = 0; i < S; i++) { if (rawbufs[i]) rawpool.put(rawbufs[i]); st.bases -= grp[i]->bases.size(); }
+            if (o.hist) chk(c, kmx_hist_off(c), "kmx_hist_off");
+            for (uint32_t i = 0; i < S; i++) whole_to_files(*grp[i]);
+            continue;
+          }
+          chk(c, crc, S == 1 ? "kmx_count_reads_dev" : "kmx_count_reads_dev_multi");
           if (o.hist) writes.push_back(save_hist(c, b.si));
           for (uint32_t i = 0; i < S; i++) {
             const uint32_t si = grp[i]->si; const Sample& smp = samples[si];
@@ -596,54 +655,7 @@ int run(int argc, char** argv)
           while (writes.size() > 64) { writes.front().get(); writes.pop_front(); }
           continue;
         }
-        if (whole_sample) {
-          // ---- the whole sample in one batch: split + count in one call, the super-k-mer streams stay in HBM (kmx_count_reads) ----
-          const auto t = clk::now();
-          const uint32_t si = b.si; const Sample& smp = samples[si];
-          tlog(g, "split_begin", si);
-          st.bases += b.bases.size();
-          std::vector<uint64_t*> keys(P, nullptr); std::vector<uint32_t*> cnts(P, nullptr); std::vector<uint64_t> cnt(P, 0), nkp(P, 0), info(2 * (size_t)P, 0);
-          std::vector<uint8_t*> ob(P, nullptr); std::vector<uint64_t> ol(P, 0);
-          auto pc = std::make_shared<std::vector<uint64_t>>(), ms = std::make_shared<std::vector<uint64_t>>(), mk = std::make_shared<std::vector<uint64_t>>();
-          kmx_superk_stats ks{};
-          if (!o.skip_pinfo) { pc->assign((size_t)P * KMX_PINFO_STRIDE, 0); ms->assign(nm, 0); mk->assign(nm, 0); ks.part_counters = pc->data(); ks.minim_superks = ms->data(); ks.minim_kmers = mk->data(); }
-          if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
-          chk(c, kmx_count_reads(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, smp.hard_min,
-                                 keys.data(), cnts.data(), cnt.data(), nkp.data(), o.keep_tmp ? ob.data() : nullptr, o.keep_tmp ? ol.data() : nullptr, info.data(),
-                                 o.skip_pinfo ? nullptr : &ks), "kmx_count_reads");
-          if (o.hist) writes.push_back(save_hist(c, si));
-          uint64_t nkt = 0; for (uint32_t p = 0; p < P; p++) if (selected[p]) nkt += nkp[p];
-          st.kmers += nkt;
-          { std::string s2; for (uint32_t p = 0; p < P; p++) { s2 += std::to_string(nkp[p]); s2 += "\n"; }      // every partition, as dump_pinfo does (gatb_utils.hpp:46-51; the split counts them all, fill_partitions.hpp:59-105)
-            Out pi(root + "/partition_infos/" + smp.id + ".pinfo"); pi.raw(s2.data(), s2.size()); pi.close(); }
-          const std::string sd = root + "/superkmers/" + smp.id; fs::create_directories(sd);
-          { std::string inf = "skp\n" + sd + "\n" + std::to_string(P) + "\n";
-            for (uint32_t p = 0; p < P; p++) {
-              inf += std::to_string(selected[p] ? info[2 * p] : 0) + "\n" + std::to_string(selected[p] ? info[2 * p + 1] : 0) + "\n";
-              if (o.keep_tmp && selected[p]) { SuperkBlockWriter w(sd + "/skp." + std::to_string(p), p, o.cpr); w.add_stream(ob[p], ol[p], o.k); w.flush(); w.out.close(); }
-              if (o.keep_tmp) kmx_free(ob[p]);
-            }
-            Out f(sd + "/SuperKmerBinInfoFile"); f.raw(inf.data(), inf.size()); f.close(); }
-          if (!o.skip_pinfo) {
-            uint64_t nk_all = 0; for (uint32_t p = 0; p < P; p++) nk_all += nkp[p];
-            const uint64_t nsk = ks.nb_superk;
-            writes.push_back(pool.submit([=]() { try { write_parti_info(sd + "/PartiInfoFile", P, nm, nsk, nk_all, pc->data(), ms->data(), mk->data()); } catch (const std::exception& e) { die(e.what()); } }));
-          }
-          for (uint32_t p = 0; p < P; p++) {
-            uint64_t* kk = keys[p]; uint32_t* cc = cnts[p]; const uint64_t nn = cnt[p];
-            if (!selected[p]) { kmx_free(kk); kmx_free(cc); continue; }
-            writes.push_back(pool.submit([=, &o]() {
-              try { if (hash_mode) write_hash_file(count_path(p, si), si, p, kk, cc, nn); else write_kmer_file(count_path(p, si), o.k, si, p, kk, cc, nn, o.cpr); }
-              catch (const std::exception& e) { die(e.what()); }
-              kmx_free(kk); kmx_free(cc);
-            }));
-          }
-          tlog(g, "split_end", si);
-          w_count += since(t);
-          done++;
-          while (writes.size() > 4u * P) { writes.front().get(); writes.pop_front(); }
-          continue;
-        }
+        if (whole_sample) { whole_to_files(b); continue; }
         SampleState& S = open[b.si];
         if (S.streams.empty()) { S.streams.resize(P); S.nk.assign(P, 0); S.nk_all.assign(P, 0); if (!o.skip_pinfo) { S.pc.assign((size_t)P * KMX_PINFO_STRIDE, 0); S.ms.assign(nm, 0); S.mk.assign(nm, 0); } }
         if (b.offs.size() > 1) {

@@ -4,7 +4,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmx.so")
+LIB_PATH = os.environ.get("KMX_LIB") or os.path.join(_HERE, "libkmx.so")      # (KMX_LIB: a tuning build, scripts/dev/build_variant.sh)
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(libkmx has no CPU fallback)")
@@ -34,6 +34,10 @@ _lib.kmx_last_error.argtypes = [_vp]
 _lib.kmx_stream.restype = _vp
 _lib.kmx_stream.argtypes = [_vp]
 _lib.kmx_set_profiling.argtypes = [_vp, C.c_int]
+_lib.kmx_set_file_order.argtypes = [_vp, C.c_int]
+KMX_VERSION = 2
+if _lib.kmx_version() != KMX_VERSION:
+    raise ImportError(f"{LIB_PATH} is version {_lib.kmx_version()}, this binding is for version {KMX_VERSION} (kmx_merge_task layout)")
 _lib.kmx_result_kernel.restype = C.c_char_p
 _lib.kmx_result_kernel.argtypes = [_vp]
 _lib.kmx_result_kernel_ms.restype = C.c_double
@@ -114,7 +118,7 @@ _lib.kmx_count_reads_dev.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.c_uint3
 _lib.kmx_hist_reset.argtypes = [_vp]
 _lib.kmx_hist_off.argtypes = [_vp]
 _lib.kmx_hist_read.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
-EXPORTS = ["kmx_count_reads_dev_multi", "kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_set_file_order", "kmx_count_reads_dev_multi", "kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -164,6 +168,10 @@ class Context:
 
     def set_profiling(self, on=True):
         self._check(_lib.kmx_set_profiling(self._h, 1 if on else 0), "kmx_set_profiling")
+
+    def set_file_order(self, on=True):
+        """COUNT / PA rows at their final place out of the column-blocked kernels (default), or where the kernels leave them"""
+        self._check(_lib.kmx_set_file_order(self._h, 1 if on else 0), "kmx_set_file_order")
 
     @property
     def stream(self):

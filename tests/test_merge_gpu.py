@@ -12,20 +12,25 @@ pytestmark = pytest.mark.gpu
 GD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(autouse=True, params=["rows", "pivot", "cols"])
-def merge_kernel(request, monkeypatch):
-    """Every merge test runs once per COUNT/PA kernel: k_merge_rows, k_merge_pivot and k_merge_cols (which hand tasks
-    they do not suit -- dissimilar lists, 128-bit keys, share-min, PA rows -- down to the next kernel inside libkmx)."""
-    monkeypatch.setenv("KMX_MERGE_KERNEL", request.param)
-    return request.param
-
-
 @pytest.fixture(scope="module")
 def ctx():
     from kmtricks_amd import lib
     c = lib.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True, params=["rows", "pivot", "cols", "cols-arena"])
+def merge_kernel(request, monkeypatch, ctx):
+    """Every merge test runs once per COUNT/PA kernel: k_merge_rows, k_merge_pivot and k_merge_cols (which hand tasks
+    they do not suit -- dissimilar lists, 128-bit keys, share-min, PA rows -- down to the next kernel inside libkmx).
+    The column-blocked pair twice: with its rows written at their final place (file order out of the kernels: the
+    default) and with the rows where the kernels leave them + a directory ("cols-arena": kmx_set_file_order off)."""
+    kern, _, how = request.param.partition("-")
+    monkeypatch.setenv("KMX_MERGE_KERNEL", kern)
+    monkeypatch.setenv("KMX_FILE_ORDER", "0" if how == "arena" else "1")      # (contexts the tests create themselves)
+    ctx.set_file_order(how != "arena")
+    return kern
 
 
 def check(ctx, lists, kw, soft_min, rec_min, share_min, mode, lower=0, upper=0, bitw=2, rows_hint=0):
