@@ -96,7 +96,7 @@ def xxh64_u32(v):
     return h
 
 
-def gen_counted(ctx, lib, N, k, genome, d, total_parts, my_parts, seed, log):
+def gen_counted(ctx, lib, N, k, genome, d, total_parts, my_parts, seed, log, all_lists=None):
     """Lists produced by the product's count stage: sample i = ancestor genome with i.i.d. substitutions at rate d (PCG64 seeds of
     SURVEY 8d), given twice so that every k-mer passes --hard-min 2; split with the static repartition of `total_parts`
     partitions and counted in one call with the results left in HBM (kmx_count_reads_dev into a kmx_store: what `kmx pipeline`
@@ -123,6 +123,9 @@ def gen_counted(ctx, lib, N, k, genome, d, total_parts, my_parts, seed, log):
         ls, _, _ = ctx.count_reads_dev((seq + seq, offs), k, m, table, total_parts, 2, [store])
         for j, p in enumerate(my_parts):
             lists[j].append(ls[p])
+        if all_lists is not None:      # (every partition of the job: the whole-job figure of a one-GPU run)
+            for p in range(total_parts):
+                all_lists[p].append(ls[p])
         if log and (i + 1) % 100 == 0:
             print(f"[bench] counted lists: {i + 1}/{N} samples, {time.perf_counter() - t0:.1f} s, {store.used() / 1e9:.1f} GB resident", file=sys.stderr, flush=True)
     return store, lists
@@ -137,6 +140,11 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     import numpy as np
     ctx = lib.Context(local)
     ctx.set_profiling(True)
+    # COUNT / PA: the line's own step leaves the rows where the kernels put them (kmx_set_file_order off: the pair's raw speed, the
+    # figure of the earlier rounds); the library's default -- rows at their final place, the arena IS the matrix body -- is timed
+    # right behind it with the same steps and reported in roofline.file_order / frac_with_file_order
+    if hasattr(ctx, "set_file_order"):
+        ctx.set_file_order(False)
     defaults = {"count": (1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
     N = a.samples or defaults[0]
     P = a.partitions_per_gpu or defaults[1]
@@ -150,13 +158,15 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     p_present = (1.0 - a.subst_rate) ** k
     n_private = int(round(shared * (1.0 - p_present)))
     keep, tasks_d, label, mode = [], [], "", lib.MODE_COUNT      # keep: whatever owns the lists' device memory
+    job_lists = None                                              # (one GPU, headline workload: the lists of EVERY partition of the job)
     host_lists = None                                             # j -> [(keys, counts)] of partition my_parts[j] on the host (cpu_baseline)
     W = 0
     rb = 8 * kw + 4
     if wl in ("count", "pa63"):
         mode = lib.MODE_COUNT if wl == "count" else lib.MODE_PA
         if lists_kind == "counted":
-            store, lists = gen_counted(ctx, lib, N, k, genome, a.subst_rate, total_parts, my_parts, 20240601, rank == 0)
+            job_lists = [[] for _ in range(total_parts)] if (wl == "count" and world == 1 and a.whole_job) else None
+            store, lists = gen_counted(ctx, lib, N, k, genome, a.subst_rate, total_parts, my_parts, 20240601, rank == 0, job_lists)
             keep.append(store)
             def host_lists(j):
                 return [ctx.read_list(ptr, n, kw) for ptr, n in lists[j]]
@@ -214,10 +224,11 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
         n8 = (N + 7) // 8 * 8
         xbuf = [torch.empty((n8, W // 8), dtype=torch.uint8, device=dev) for _ in range(P)]
 
-    def run(n, record):
+    def run(n, record, batches=None):
         """n steps = n kmx_merge_dev batches; batch i+1 is submitted before batch i is waited for (the host
         prepares the next batch while the GPU merges the current one, as the pipeline driver does with
-        consecutive partition batches); every batch is waited for before the clock stops."""
+        consecutive partition batches); every batch is waited for before the clock stops.
+        batches: a list of prepared task batches run once each instead (the whole job of a one-GPU run)."""
         nonlocal algo_bytes, rows_out
 
         def finish(res):
@@ -237,8 +248,8 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
             res.free()
 
         prev = None                      # two batches in flight (double buffering: no new device blocks)
-        for _ in range(n):
-            cur = ctx.merge_dev(tasks)
+        for it in range(n if batches is None else len(batches)):
+            cur = ctx.merge_dev(tasks if batches is None else batches[it])
             if prev is not None:
                 finish(prev)
             prev = cur
@@ -256,6 +267,40 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     barrier()
     dt = time.perf_counter() - t0
     dt, job_recs = shard.reduce_job(dist if world > 1 else None, dev, dt, float(total_recs))
+    # ---- the same steps with the rows written at their final place (the library's default): the arena is the matrix body ----
+    fo = None
+    if wl in ("count", "pa63") and hasattr(ctx, "set_file_order"):
+        ctx.set_file_order(True)
+        head_ms, head_name = list(kernel_ms), kernel_name
+        kernel_ms.clear()
+        for _ in range(3):
+            run(1, False)
+        run(a.warmup, False)
+        barrier()
+        t1 = time.perf_counter()
+        run(a.steps, True)
+        barrier()
+        dt_fo = time.perf_counter() - t1
+        dt_fo, _ = shard.reduce_job(dist if world > 1 else None, dev, dt_fo, float(total_recs))
+        fo_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        fo = {"kernel_ms": fo_ms, "ms_per_step": dt_fo / a.steps * 1e3, "value": job_recs * a.steps / dt_fo, "kernel": kernel_name}
+        # ---- ... and, on one GPU, the WHOLE job that way: all partitions of configs[2] (8 batches of 32 on one MI355X) ----
+        if job_lists is not None and rank == 0:
+            per = P
+            jb = [ctx.prepare([dict(lists=job_lists[p], key_words=kw, soft_min=[1] * N, rec_min=rec_min, share_min=a.share_min, mode=mode)
+                               for p in range(b0, min(total_parts, b0 + per))]) for b0 in range(0, total_parts, per)]
+            run(0, False, jb)      # (once untimed: the context's pool then holds the blocks two batches in flight need)
+            sync()
+            t2 = time.perf_counter()
+            run(0, False, jb)
+            sync()
+            dt_job = time.perf_counter() - t2
+            recs_job = sum(n for ls in job_lists for _, n in ls)
+            fo["whole_job"] = {"partitions": total_parts, "batches": len(jb), "records": recs_job, "wall_ms": dt_job * 1e3, "value": recs_job / dt_job,
+                               "what": f"every partition of the job merged on this one GPU, {len(jb)} batches of {per}, two in flight, rows in file order, results left in HBM"}
+            del jb
+        kernel_ms[:] = head_ms; kernel_name = head_name
+        ctx.set_file_order(False)
     # the timed step leaves COUNT / PA rows in HBM as the kernels produce them (k_merge_cols: the row keys' rows and the rows out of
     # k_cols_sparse, each list ascending); a consumer that wants the body in file order ON THE DEVICE (kmx_result_body_dev: the
     # pipeline's writer, an RCCL send) pays a device-to-device pass once per result: timed here, outside the step, and reported
@@ -304,6 +349,9 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name),
                          "kernel": kname, "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
+                         "rows": "where the kernels leave them (kmx_set_file_order off); file_order: the same steps with the rows at their final place (the library's default)",
+                         "file_order": fo,
+                         "frac_with_file_order": (algo_bytes / (fo["kernel_ms"] * 1e-3) / 1e9 / 8000.0) if (fo and fo["kernel_ms"] > 0) else None,
                          "file_order_gather_ms": gather_ms, "row_order_ms": order_ms,
                          "frac_with_row_order": (algo_bytes / ((kms + order_ms) * 1e-3) / 1e9 / 8000.0) if (order_ms is not None and kms > 0) else None,
                          "frac_with_file_order_gather": (algo_bytes / ((kms + gather_ms) * 1e-3) / 1e9 / 8000.0) if (gather_ms is not None and kms > 0) else None,
@@ -346,33 +394,16 @@ def _pipeline_make_sample(args):
     return path
 
 
-def _pipeline_cpu_sample(args):
-    """the oracle's split + count of one sample's FASTA file (every partition) -> [(keys, counts)] per partition"""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import orc
-    path, k, m, P, hard_min = args
-    raw = np.fromfile(path, np.uint8)
-    reads = [bytes(r) for r in raw.reshape(-1, 154)[:, 3:153]]      # (the generator's fixed-width records)
-    lut = orc.minimizer_lut(m)
-    rep = orc.repart_static(m, P)
-    sk = orc.superk_partition(reads, k, m, lut, rep, P)
-    out = []
-    for p in range(P):
-        keys, cnts = orc.count_kmer(sk[p][0], k, hard_min)
-        out.append((np.ascontiguousarray(keys).reshape(-1), cnts))
-    return out
-
-
-def pipeline_workload(a, n_gpus=1):
+def pipeline_workload(a, n_gpus=1, genome=None, tmp_root=None, cpu=True):
     """`kmx pipeline` end to end on SURVEY 8d's cohort: FASTA files on local disk in, the run directory (matrices) out; wall clock
     around the process.  Then the oracle (split + count + merge, a port of the reference's CPU path) over a bounded sample of the
-    same files on the host cores."""
+    same files on the host cores.  genome / tmp_root: another genome size, files in another place (the full-size run keeps its
+    30 GB of FASTA and ~100 GB of matrices in a RAM file system: the box's disk holds 79 GB)."""
     import shutil, subprocess, tempfile
     import multiprocessing
     Pool = multiprocessing.get_context("spawn").Pool      # (not fork: this process may hold a HIP runtime and tens of GB of mappings)
-    S, G, P, k = a.pipeline_samples, int(a.pipeline_genome), a.total_partitions, 31
-    tmp = tempfile.mkdtemp(prefix="kmx_bench_", dir=a.tmp)
+    S, G, P, k = a.pipeline_samples, int(genome or a.pipeline_genome), a.total_partitions, 31
+    tmp = tempfile.mkdtemp(prefix="kmx_bench_", dir=tmp_root or a.tmp)
     try:
         nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         t0 = time.perf_counter()
@@ -400,68 +431,64 @@ def pipeline_workload(a, n_gpus=1):
         out = {"metric": "end-to-end wall-clock of kmx pipeline (FASTA in, matrices out)", "value": wall, "unit": "s", "higher_is_better": False,
                "kmers_merged_per_s_end_to_end": d["merge_records"] / wall, "Mbases_per_s_end_to_end": d["bases"] / wall / 1e6,
                "n_gpus": n_gpus, "data": "synthetic",
-               "config": {"workload": f"BASELINE configs[2] end to end: {S} samples x {G} bp (d={a.subst_rate}, 150-bp reads at 6x, plain FASTA on local disk), k=31, "
+               "config": {"workload": f"BASELINE configs[2] end to end: {S} samples x {G} bp (d={a.subst_rate}, 150-bp reads at 6x, plain FASTA {'in ' + tmp_root + ' (RAM)' if tmp_root else 'on local disk'}), k=31, "
                                       f"kmer:count:bin --hard-min 2 --recurrence-min 2, {P} partitions, static repartition, {threads} host threads",
                           "command": " ".join(cmd[1:]), "bases": d["bases"], "kmers": d["kmers"], "merge_records": d["merge_records"], "matrix_bytes": out_bytes},
                "stages": {kk: d[kk] for kk in ("setup_wall_s", "count_wall_s", "merge_wall_s", "total_s", "read_s", "count_s", "merge_io_s", "merge_s", "gpu_workers", "resident_samples") if kk in d},
                "fasta_generation_s": gen_s}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and cpu:
             # the host's share: the oracle over a bounded sample of the same files, in a process of its own (a plain Python process
             # forks its workers cheaply; this one may hold a HIP runtime and tens of GB of mappings)
-            Sc = min(S, a.pipeline_cpu_samples or nproc, nproc)
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--pipeline-cpu-child", json.dumps({"paths": paths[:Sc], "k": k, "m": 10, "P": P, "hard_min": 2, "S": S})],
-                               capture_output=True, text=True)
             try:
-                out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
-            except Exception:
-                out["cpu_baseline"] = {"error": (r.stderr or r.stdout)[-800:]}
+                out["cpu_baseline"] = pipeline_cpu_baseline(paths[:a.pipeline_cpu_samples] if a.pipeline_cpu_samples else paths, k, 10, P, 2, 2, S)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pipeline_cpu_child(spec):
-    """cpu_baseline of the end-to-end workload (runs in a process of its own, see pipeline_workload): whole samples through the
-    oracle's split + count, one per worker process (warmed up first: forking and importing are not the reference's work), then
-    one oracle merge task per partition on a thread pool -- as the reference's task pool would run them, in memory."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def physical_cores():
+    """one hardware thread per physical core of this process's affinity set (SMT siblings counted once)"""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, n = set(), 0
+    for c in cpus:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib); n += 1
+    return max(1, n), len(cpus)
+
+
+def pipeline_cpu_baseline(paths, k, m, P, hard_min, rec_min, S_total):
+    """cpu_baseline of the end-to-end workload: oracle/kmx_oracle_pipeline -- plain C and pthreads around the oracle, no Python in
+    the loop: whole samples through the oracle's split + count, one task per sample on a pool of T threads (T = physical cores, at
+    most one sample each), then one oracle merge task per partition on the same pool, in memory.  The per-core rate of the split +
+    count leg (CPU seconds of the workers) must agree with one thread working alone on a sample within 2x -- else the figure is
+    a harness artefact, not the CPU path (round 3's was: 0.42 Mbases/s per core under 256 Python processes)."""
     import subprocess
-    from multiprocessing import Pool
-    from concurrent.futures import ThreadPoolExecutor
-    so = os.path.join(ROOT, "oracle", "libkmx_oracle.so")
-    if not os.path.exists(so):
+    exe = os.path.join(ROOT, "oracle", "kmx_oracle_pipeline")
+    if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
-    import orc
-    paths, k, m, P, hard_min, S = spec["paths"], spec["k"], spec["m"], spec["P"], spec["hard_min"], spec["S"]
-    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    Sc = len(paths)
-    with Pool(min(Sc, nproc)) as pool:
-        pool.map(_pipeline_cpu_warm, range(min(Sc, nproc)), chunksize=1)
-        t0 = time.perf_counter()
-        counted = pool.map(_pipeline_cpu_sample, [(pth, k, m, P, hard_min) for pth in paths], chunksize=1)
-        t_count = time.perf_counter() - t0
-    def merge_p(p):
-        _, rows, _ = orc.merge_matrix([counted[s][p] for s in range(Sc)], 1, [1] * Sc, 2, 0, orc.MODE_COUNT)
-        return rows
-    t1 = time.perf_counter()
-    with ThreadPoolExecutor(min(nproc, P)) as ex:
-        rows = list(ex.map(merge_p, range(P)))
-    t_merge = time.perf_counter() - t1
-    recs = sum(len(counted[s][p][1]) for s in range(Sc) for p in range(P))
-    cw = t_count + t_merge
-    print(json.dumps({"value": recs / cw, "unit": "k-mers merged/s end to end", "cores": min(Sc, nproc), "kind": "port", "host_cores": nproc,
-                      "wall_s_per_sample_set": cw, "split_count_s": t_count, "merge_s": t_merge,
-                      "sample": f"{Sc} of the {S} samples' FASTA files: oracle split + count of a whole sample per process ({min(Sc, nproc)} processes, started and warmed "
-                                f"before the clock), then one oracle merge task per partition ({P}) on a thread pool; {recs} records merged, {sum(rows)} rows; in memory, no "
-                                f"intermediate files (the reference writes and re-reads super-k-mer and count files)"}))
-
-
-def _pipeline_cpu_warm(i):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy, orc      # noqa: F401
-    orc.minimizer_lut(10)
-    time.sleep(0.05)
-    return i
+    phys, logical = physical_cores()
+    T = min(phys, len(paths))
+    r = subprocess.run([exe, str(k), str(m), str(P), str(hard_min), str(rec_min), str(T)] + list(paths[:T]), capture_output=True, text=True)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cw = d["split_count_wall_s"] + d["merge_wall_s"]
+    ratio = d["single_core_Mbases_per_s"] / max(1e-9, d["split_count_Mbases_per_s_per_core"])
+    out = {"value": d["merge_records"] / cw, "unit": "k-mers merged/s end to end", "cores": T, "kind": "port", "host_cores": logical, "physical_cores": phys,
+           "wall_s_per_sample_set": cw, "split_count_s": d["split_count_wall_s"], "merge_s": d["merge_wall_s"],
+           "split_count": {"Mbases_per_s_per_core": d["split_count_Mbases_per_s_per_core"], "single_core_Mbases_per_s": d["single_core_Mbases_per_s"],
+                           "single_over_pooled": ratio, "Mbases_per_s": d["bases"] / d["split_count_wall_s"] / 1e6},
+           "merge": {"Mrecords_per_s_per_core": d["merge_Mrecords_per_s_per_core"], "threads": d["merge_threads"]},
+           "sample": f"{T} of the {S_total} samples' FASTA files: oracle/kmx_oracle_pipeline (C, pthreads): split + count of a whole sample per thread ({T} threads = one "
+                     f"per physical core, host has {logical} hardware threads), then one oracle merge task per partition ({P}) on the same pool; {d['merge_records']} records "
+                     f"merged, {d['rows']} rows; in memory, no intermediate files (the reference writes and re-reads super-k-mer and count files)"}
+    if not (0.5 <= ratio <= 2.0):
+        out["warning"] = f"pooled per-core rate and single-core rate differ by {ratio:.2f}x: the pooled figure is not the CPU path's"
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- main
@@ -481,17 +508,18 @@ def parse_args(argv=None):
     ap.add_argument("--share-min", type=int, default=0)
     ap.add_argument("--bloom", type=float, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-whole-job", dest="whole_job", action="store_false", help="skip the one-GPU whole-job figure of the headline workload")
     ap.add_argument("--pipeline-samples", type=int, default=1000)
     ap.add_argument("--pipeline-genome", type=float, default=1e6)
     ap.add_argument("--pipeline-cpu-samples", type=int, default=0, help="samples of the end-to-end cpu_baseline (0: one per host core)")
     ap.add_argument("--tmp", default=None, help="directory for the end-to-end workload's files (default: the system's temporary directory)")
+    ap.add_argument("--tmp-ram", default="/dev/shm", help="RAM file system for the end-to-end workload at full size (5 Mbp genomes: 130 GB of files)")
+    ap.add_argument("--no-full-size", dest="full_size", action="store_false", help="skip the end-to-end run at G = 5 Mbp")
+    ap.add_argument("--no-multi-gpu-pipeline", dest="multi_gpu_pipeline", action="store_false", help="several ranks: skip the `kmx pipeline --gpus N` point behind the merge steps")
     return ap.parse_args(argv)
 
 
 def main():
-    if len(sys.argv) >= 3 and sys.argv[1] == "--pipeline-cpu-child":
-        pipeline_cpu_child(json.loads(sys.argv[2]))
-        return
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -544,8 +572,34 @@ def run_workloads(a, wl, env):
             except Exception as e:
                 pipe = {"error": repr(e)}
             print(f"[bench] workload pipeline done, {time.perf_counter() - t_all:.0f} s", file=sys.stderr, flush=True)
+            # ... and at SURVEY 8d's stated size (G = 5 Mbp: 30 GB of FASTA in, ~100 GB of count matrices out -- more than the box's
+            # disk): in a RAM file system when the box has one with room for it
+            if a.full_size and isinstance(pipe, dict) and "error" not in pipe:
+                try:
+                    import shutil as _sh
+                    big = a.tmp_ram if os.path.isdir(a.tmp_ram) else None
+                    free = _sh.disk_usage(big).free if big else 0
+                    need = int(a.pipeline_samples * 5e6 * (6 * 1.03 + 22))      # FASTA + matrices (~21 bytes per base pair of genome here)
+                    if big and free > need * 1.2:
+                        pipe["full_size"] = pipeline_workload(a, genome=5e6, tmp_root=big, cpu=False)
+                    else:
+                        pipe["full_size"] = {"skipped": f"no RAM file system with {need / 1e9:.0f} GB free at {a.tmp_ram} ({free / 1e9:.0f} GB)"}
+                except Exception as e:
+                    pipe["full_size"] = {"error": repr(e)}
+                print(f"[bench] workload pipeline at 5 Mbp done, {time.perf_counter() - t_all:.0f} s", file=sys.stderr, flush=True)
         wl = "count"
     out = merge_workload(env, a, wl, a.lists, want_cpu)
+    if world > 1 and a.multi_gpu_pipeline and wl == "count" and env.get("run_pipeline", True):
+        # several ranks (the scaling runs): the PRODUCT's own multi-GPU path gets a point too -- `kmx pipeline --gpus <world>`, one
+        # process driving every GPU of the node (partitions p -> GPU p mod G, count lists to the merging GPU's store over xGMI),
+        # started by rank 0 once every rank has let go of its device memory; the other ranks wait at the barrier
+        env["dist"].barrier()
+        if rank == 0:
+            try:
+                pipe = pipeline_workload(a, n_gpus=world, cpu=False)
+            except Exception as e:
+                pipe = {"error": repr(e)}
+        env["dist"].barrier()
     if rank == 0:
         if extras:
             out["workloads"] = extras

@@ -65,7 +65,8 @@ class Kmer {
   static constexpr size_t NWORDS = (MAX_K + 31) / 32;
   typedef const uint64_t* data_ptr64;
   typedef const uint8_t* data_ptr8;
-  static std::string name() { return "Kmer<" + std::to_string(MAX_K) + "> - uint64_t[" + std::to_string(NWORDS) + "]"; }
+  // (the reference's 32 and 64 specialisations name their storage types, kmer.hpp:645, 919; the generic one its array, :185)
+  static std::string name() { return "Kmer<" + std::to_string(MAX_K) + "> - " + (MAX_K == 32 ? std::string("uint64_t") : MAX_K == 64 ? std::string("__uint128_t") : "uint64_t[" + std::to_string(NWORDS) + "]"); }
   static const size_t get_size_bits() { return 64 * NWORDS; }
 
   Kmer() { zero(); }

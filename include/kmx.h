@@ -285,6 +285,11 @@ typedef struct kmx_store kmx_store;
 int      kmx_store_create(int device, uint64_t limit_bytes, kmx_store** out);
 void     kmx_store_destroy(kmx_store* s);
 uint64_t kmx_store_used(const kmx_store* s);
+/* How a context on GPU from_device fills a store on GPU to_device: 1 = peer access between the two is enabled (asked for on first
+ * use: hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess) and the copy is one DMA over their xGMI link; 0 = the runtime stages it
+ * through host memory; negative = KMX_E_INVAL.  `kmx pipeline --gpus G` asks for every pair when it creates its stores and prints
+ * the outcome in its summary line. */
+int      kmx_peer_access(int from_device, int to_device);
 uint64_t kmx_store_limit(const kmx_store* s);
 
 /* kmx_superk_stats without the host arithmetic: the device's own u32 tables of ONE call, copied (not added) into the

@@ -384,7 +384,9 @@ static int pack_to_stores(kmx_ctx* ctx, const KeyT* d_k, const u32* d_c, const s
       kmx_store* S = out.stores[d];
       dst = (u8*)S->alloc(nb);
       if (!dst) { rc = ctx->fail(KMX_E_NOMEM, "count store is full"); break; }
-      // the store of another GPU is filled over xGMI (hipMemcpyPeerAsync stages through the host when the two have no peer access)
+      // the store of another GPU is filled over xGMI: peer access is enabled for the pair the first time it is used
+      // (kmx_peer_path; hipMemcpyPeerAsync stages through the host when the two GPUs have none)
+      if (S->device != ctx->device) (void)kmx_peer_path(ctx->device, S->device);
       e = S->device == ctx->device ? hipMemcpyAsync(dst, d_pack + doff[d] * RB, nb, hipMemcpyDeviceToDevice, st)
                                    : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
       if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }
@@ -433,7 +435,9 @@ static int compact_to_stores(kmx_ctx* ctx, const KeyT* d_tk, const u32* d_tc, co
       kmx_store* S = out.stores[d];
       dst = (u8*)S->alloc(nb);
       if (!dst) { rc = ctx->fail(KMX_E_NOMEM, "count store is full"); break; }
-      // the store of another GPU is filled over xGMI (hipMemcpyPeerAsync stages through the host when the two have no peer access)
+      // the store of another GPU is filled over xGMI: peer access is enabled for the pair the first time it is used
+      // (kmx_peer_path; hipMemcpyPeerAsync stages through the host when the two GPUs have none)
+      if (S->device != ctx->device) (void)kmx_peer_path(ctx->device, S->device);
       e = S->device == ctx->device ? hipMemcpyAsync(dst, d_pack + doff[d] * RB, nb, hipMemcpyDeviceToDevice, st)
                                    : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
       if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }

@@ -218,6 +218,39 @@ extern "C" void kmx_store_destroy(kmx_store* s)
   if (cur >= 0 && cur != s->device) (void)hipSetDevice(cur);
   delete s;
 }
+// ---- peer access between the GPUs of a node: a counting context on GPU a fills the store of GPU b with hipMemcpyPeerAsync.  With
+//      peer access enabled that copy is one DMA over the xGMI link between the two; without it the runtime stages it through host
+//      memory.  Asked for once per ordered pair, the outcome kept (and printed with KMX_TRACE=1): 1 direct, 0 staged. ----
+namespace {
+std::mutex g_peer_mutex;
+signed char g_peer[64][64];      // 0 unknown, 1 enabled, -1 not available
+}
+int kmx_peer_path(int from, int to)
+{
+  if (from == to) return 1;
+  if (from < 0 || to < 0 || from >= 64 || to >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_peer_mutex);
+  if (g_peer[from][to] == 0) {
+    int can = 0, cur = -1;
+    (void)hipGetDevice(&cur);
+    signed char st = -1;
+    if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can && hipSetDevice(from) == hipSuccess) {
+      const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+      if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) st = 1;
+      (void)hipGetLastError();
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+    g_peer[from][to] = st;
+    if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx] GPU %d -> GPU %d: %s\n", from, to, st == 1 ? "peer access enabled (copies go over xGMI)" : "no peer access (copies are staged through host memory)");
+  }
+  return g_peer[from][to] == 1 ? 1 : 0;
+}
+extern "C" int kmx_peer_access(int from_device, int to_device)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || from_device < 0 || to_device < 0 || from_device >= n || to_device >= n) return KMX_E_INVAL;
+  return kmx_peer_path(from_device, to_device);
+}
 extern "C" uint64_t kmx_store_used(const kmx_store* s) { return s ? s->used : 0; }
 extern "C" uint64_t kmx_store_limit(const kmx_store* s) { return s ? s->limit : 0; }
 extern "C" int kmx_copy_to_host(kmx_ctx* ctx, void* dst, const void* src, uint64_t bytes)

@@ -71,6 +71,7 @@ int kmx_count_from_device(kmx_ctx* ctx, const kmx::u8* d_recs, const kmx::u64* d
 void kmx_launch_pack_bases(const char* d_bases, kmx::u64 n, kmx::u64* out /* (n + 31) / 32 + 2 words */, hipStream_t st);
 
 // page-locked host memory (kmx_api.hip: transparent huge pages + hipHostRegister for blocks of 2 MB and more, hipHostMalloc else)
+int kmx_peer_path(int from, int to);      // 1: GPU `from` reaches GPU `to`'s memory directly (peer access enabled on first use), 0: staged
 void* kmx_pinned_alloc(size_t bytes);
 void kmx_pinned_free(void* p);
 

@@ -47,6 +47,7 @@ struct Sample { std::string id; std::vector<std::string> files; uint32_t hard_mi
 
 struct Opt {
   std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file, bf_format = "howdesbt", soft_min_path;
+  double soft_f = 0.0; bool soft_float = false;      // --soft-min <fraction> (src/cli.cpp:234-240)
   uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1, gpu_workers = 2;
   uint64_t bloom = 10000000, merge_batch_mb = 4096;
   double restrict_to = 1.0, focus = 0.5;
@@ -102,9 +103,17 @@ static Opt parse_cli(int argc, char** argv)
     else if (a == "--soft-min") {      // INT / STR / FLOAT (src/cli.cpp:228-248): an integer, a file with one threshold per sample, or a fraction
       const std::string v = need(i);
       if (fs::is_regular_file(v)) o.soft_min_path = v;
-      else if (v.find('.') != std::string::npos)
-        die("--soft-min " + v + ": thresholds derived from the abundance histograms (a fraction) are not supported by this build -- the reference's own "
-            "computation is broken (histogram.hpp:221-234 pushes onto a pre-sized vector); give an integer, or a file with one threshold per sample");
+      else if (v.find('.') != std::string::npos) {
+        // a fraction: thresholds "derived from the abundance histograms" (histogram.hpp:218-243).  The reference's computation pushes
+        // its thresholds onto a vector it has already sized to one entry per sample, so the entries the merge reads -- the first N
+        // -- are all 0: it behaves as --soft-min 0, implies --hist, and leaves merge_amin.txt with N zeros followed by the values it
+        // computed.  Reproduced as it is (drop-in), with a note on stderr.
+        double f = -1; try { size_t n = 0; f = std::stod(v, &n); if (n != v.size()) f = -1; } catch (...) { f = -1; }
+        if (!(f >= 0.0 && f <= 1.0)) die("--abundance-min<float>: Not in range [0.0, 1.0] : " + v);      // (bcli's range check, src/cli.cpp:237)
+        o.soft_f = f; o.soft_float = true; o.hist = true;
+        fprintf(stderr, "[kmx] --soft-min %s: as in kmtricks 1.6.0 the thresholds computed from the histograms do not reach the merge (histogram.hpp:221-234 appends them "
+                        "behind one zero per sample): every sample is merged with soft-min 0; merge_amin.txt holds the zeros and the computed values\n", v.c_str());
+      }
       else { try { size_t n = 0; o.soft_min = (uint32_t)std::stoul(v, &n); if (n != v.size()) throw 1; } catch (...) { die("bad number for --soft-min: " + v); } }
     }
     else if (a == "--recurrence-min") o.rec_min = num(i);
@@ -217,7 +226,7 @@ int run(int argc, char** argv)
   { std::ofstream b(root + "/build_infos.txt"); b << "kmx (MI355X-native kmtricks pipeline), libkmx ABI " << kmx_version() << "\n"; }
   { std::ofstream f(root + "/options.txt");   // cmd/all.hpp:85-125: `kmtricks combine` re-parses mode= from this line
     f << "Options: dir=" << root << ", verbosity=info, nb_threads=" << o.threads << ", fof=" << o.fof << ", kmer_size=" << o.k << ", c_ab_min=" << o.hard_min
-      << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", m_ab_min_path=" << o.soft_min_path << ", m_ab_min_f=0, m_ab_float=0, save_if=" << o.share_min << ", minim_size=" << o.msize
+      << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", m_ab_min_path=" << o.soft_min_path << ", m_ab_min_f=" << o.soft_f << ", m_ab_float=" << o.soft_float << ", save_if=" << o.share_min << ", minim_size=" << o.msize
       << ", minim_type=0, repart_type=0, nb_parts=" << P << ", bloom_size=" << o.bloom << ", keep_tmp=" << o.keep_tmp << ", lz4=" << o.cpr << ", kff=0, hist=" << o.hist << ", static_repart=" << o.static_repart
       << ", focus=" << o.focus << ", restrict_to=" << o.restrict_to << ", bwidth=" << o.bitw << ", bam_exclude_refs=, bam_include_flags=0, bam_exclude_flags=0, mode=" << what      // (mode_to_str: count | pa | bf | bfc; cmd/all.hpp:119)
       << ", format=bin, bf_format=" << o.bf_format << ", count_format=" << (hash_mode ? "hash" : "kmer") << ", until=" << o.until << "\n"; }
@@ -249,6 +258,13 @@ int run(int argc, char** argv)
       if (kmx_store_create(dev, std::max<uint64_t>(lim, 1), &st_) != KMX_OK) die(kmx_last_error(nullptr));
       stores.push_back(st_);
     }
+  }
+  // how a count worker on one GPU fills the store of another: peer access is asked for here, once per ordered pair of devices in
+  // use ("p2p": copies over xGMI; "staged": through host memory); the summary line says which
+  uint32_t peer_pairs = 0, peer_direct = 0;
+  if (resident_mode) {
+    const uint32_t nd = std::min<uint32_t>(G, (uint32_t)ndev);
+    for (uint32_t a = 0; a < nd; a++) for (uint32_t b = 0; b < nd; b++) if (a != b) { peer_pairs++; if (kmx_peer_access((int)a, (int)b) == 1) peer_direct++; }
   }
   struct CtxGuard { std::vector<kmx_ctx*>& v; std::vector<kmx_store*>& s; ~CtxGuard() { for (auto x : s) kmx_store_destroy(x); for (auto x : v) kmx_destroy(x); } } ctx_guard{gpu, stores};
   // where sample i's count list of partition p is: resident (res_flag[i]) -> res_lists[i * P + p], else its count file
@@ -340,9 +356,11 @@ int run(int argc, char** argv)
   const bool restricted = plist.size() != P;
   // --hist: the sample's abundance histogram comes off the device after its count calls (kmx_hist_reset / kmx_hist_read) and goes
   // to histograms/<id>.hist as KHist(i, k, 1, 255) leaves it (task_scheduler.hpp:54-57, 103)
+  std::vector<std::vector<uint64_t>> hist_u(o.soft_float ? N : 0);      // --soft-min <fraction>: every sample's unique bins 1..255, [255] = its distinct k-mers
   auto save_hist = [&](kmx_ctx* c, uint32_t si) {
     auto ub = std::make_shared<std::vector<uint64_t>>(255), tb = std::make_shared<std::vector<uint64_t>>(255), ex = std::make_shared<std::vector<uint64_t>>(6);
     chk(c, kmx_hist_read(c, 1, 255, ub->data(), tb->data(), ex->data(), ex->data() + 4), "kmx_hist_read");
+    if (o.soft_float) { hist_u[si] = *ub; hist_u[si].push_back((*ex)[4]); }
     chk(c, kmx_hist_off(c), "kmx_hist_off");
     const std::string path = root + "/histograms/" + samples[si].id + ".hist"; const uint32_t k = o.k;
     return pool.submit([=]() { try { write_hist_file(path, k, si, 1, 255, ub->data(), tb->data(), ex->data(), ex->data() + 4); } catch (const std::exception& e) { die(e.what()); } });
@@ -351,10 +369,10 @@ int run(int argc, char** argv)
   auto report = [&]() {
     fprintf(stderr, "[kmx pipeline] {\"samples\": %u, \"partitions\": %u, \"gpus\": %u, \"threads\": %u, \"bases\": %llu, \"kmers\": %llu, \"merge_records\": %llu, "
                     "\"repart_s\": %.4f, \"read_s\": %.4f, \"superk_s\": %.4f, \"count_s\": %.4f, \"merge_io_s\": %.4f, \"merge_s\": %.4f, \"format_s\": %.4f, "
-                    "\"gpu_workers\": %u, \"resident_samples\": %u, \"resident_count_calls\": %llu, \"setup_wall_s\": %.4f, \"count_wall_s\": %.4f, \"merge_wall_s\": %.4f, \"total_s\": %.4f}\n",
+                    "\"gpu_workers\": %u, \"resident_samples\": %u, \"resident_count_calls\": %llu, \"devices\": %d, \"peer_pairs\": %u, \"peer_pairs_direct\": %u, \"setup_wall_s\": %.4f, \"count_wall_s\": %.4f, \"merge_wall_s\": %.4f, \"total_s\": %.4f}\n",
             N, P, G, o.threads, (unsigned long long)st.bases.load(), (unsigned long long)st.kmers.load(), (unsigned long long)st.merge_recs.load(),
             st.repart, st.read, st.split, st.count, st.merge_io, st.merge, st.format,
-            o.gpu_workers, (unsigned)std::count(res_flag.begin(), res_flag.end(), (uint8_t)1), (unsigned long long)st.count_calls.load(), st.setup_wall, st.count_wall, st.merge_wall, since(t0));
+            o.gpu_workers, (unsigned)std::count(res_flag.begin(), res_flag.end(), (uint8_t)1), (unsigned long long)st.count_calls.load(), ndev, peer_pairs, peer_direct, st.setup_wall, st.count_wall, st.merge_wall, since(t0));
   };
   auto count_path = [&](uint32_t p, uint32_t si) {
     return root + "/counts/partition_" + std::to_string(p) + "/" + samples[si].id + (hash_mode ? ".hash" : (o.cpr ? ".kmer.lz4" : ".kmer"));
@@ -772,6 +790,19 @@ int run(int argc, char** argv)
     std::ifstream in(o.soft_min_path); if (!in) die("Unable to read at " + o.soft_min_path);
     for (std::string line; std::getline(in, line);) { if (line.empty()) continue; try { soft.push_back((uint32_t)std::stol(line)); } catch (...) { die("bad threshold in " + o.soft_min_path + ": " + line); } }
     if (soft.size() != N) die("The number of thresholds in " + o.soft_min_path + " is different from the number of samples.");
+  }
+  if (o.soft_float) {
+    // compute_merge_thresholds (histogram.hpp:218-243) to the letter: `thresholds` starts as N zeros; per sample, the first index i
+    // of the unique bins at which the running sum (32-bit) exceeds unique() * p is APPENDED; the file gets every entry, the merge
+    // the first N (all zero)
+    std::vector<uint32_t> th(N, 0);
+    for (uint32_t h = 0; h < N; h++) {
+      if (hist_u[h].size() != 256) die("--soft-min <fraction>: no histogram for sample " + samples[h].id);
+      uint32_t sum = 0; const uint32_t n = (uint32_t)((double)hist_u[h][255] * o.soft_f);
+      for (size_t i = 0; i < 255; i++) { if (sum > n) { th.push_back((uint32_t)i); break; } sum += (uint32_t)hist_u[h][i]; }
+    }
+    { Out f(root + "/merge_amin.txt"); std::string t; for (uint32_t v : th) t += std::to_string(v) + "\n"; f.raw(t.data(), t.size()); f.close(); }      // kmdir.hpp:183
+    soft.assign(th.begin(), th.begin() + N);
   }
   const bool is_bloom = what == "bf" || what == "bfc" || what == "bft";
   const uint32_t mkw = hash_mode ? 1 : kw;

@@ -5,7 +5,8 @@ container only, where /root/reference exists; the outputs are committed).
 What is copied is DATA: the fixture files the reference's own tests read
 (tests/data/**) and the expected values its tests assert (parsed out of the
 EXPECT_/ASSERT_ lines of tests/task_main.cpp, tests/merge_test.cpp,
-tests/repartition_test.cpp, tests/packc_test.cpp, tests/histogram_test.cpp).  No reference source text
+tests/repartition_test.cpp, tests/packc_test.cpp, tests/histogram_test.cpp, tests/kmer_test.cpp,
+tests/processor_test.cpp).  No reference source text
 is stored.
 """
 import json, os, re, shutil, struct, sys
@@ -97,12 +98,49 @@ def histogram_goldens():
     return {"counts": vec("v"), "unique": vec("r"), "total": vec("rn"), "lower": int(lo), "upper": int(hi), "kmer_size": 20}
 
 
+def kmer_goldens():
+    """tests/kmer_test.cpp:9-152: the asserted names, the canonical / comparison / m-mer / minimizer strings (the random-sequence
+    cases assert identities -- to_string(Kmer(s)) == s, rev_comp == str_rev_comp -- which the tests re-run on their own strings)"""
+    src = open(f"{REF}/tests/kmer_test.cpp").read()
+    names = re.findall(r'km::Kmer<(\d+)> \w+\(\w\);\s*EXPECT_EQ\(\w+\.name\(\), "([^"]+)"\)', src)
+    can = src.split("TEST(kmer, canonical)")[1].split("TEST(")[0]
+    strs = dict(re.findall(r'std::string (\w) = "([ACGT]+)"', can))
+    canon = [[strs["a"], strs["a"]], [strs["b"], strs["c"]]]      # canonical(a) == a; canonical(b) == c != b
+    op = src.split("TEST(kmer, operator)")[1].split("TEST(")[0]
+    ostr = dict(re.findall(r'std::string (\w) = "([ACGT]+)"', op))
+    less = [[int(mk), ostr[x], ostr[y]] for mk, x, y in re.findall(r'km::Kmer<(\d+)> kmer(\w)\(\w\); km::Kmer<\d+> kmer(\w)\(\w\);', op)]
+    mi = src.split("TEST(kmer, minimizer)")[1]
+    seq = re.search(r'std::string a = "([ACGT]+)"', mi).group(1)
+    msize = int(re.search(r'kmer\.mmers\((\d+)\)', mi).group(1))
+    blk = mi.split("Mmer m = kmer.minimizer")[0]
+    mmers = [m for _, m in sorted(set((int(i), m) for m, i in re.findall(r'EXPECT_EQ\("([ACGT]+)", v\[(\d+)\]\.to_string\(\)\)', blk)))]
+    mini = re.search(r'EXPECT_EQ\(m\.to_string\(\), "([ACGT]+)"\)', mi).group(1)
+    return {"names": [[int(a), b] for a, b in names], "canonical": canon, "less": less,
+            "minimizer": {"kmer": seq, "m": msize, "mmers": mmers, "minimizer": mini}}
+
+
+def processor_goldens():
+    """tests/processor_test.cpp:10-75: records fed to the count processors with abundance-min 3 and what the files hold afterwards"""
+    src = open(f"{REF}/tests/processor_test.cpp").read()
+    hc = src.split("TEST(processor, hash_count_processor)")[1].split("TEST(")[0]
+    ksz, amin = re.search(r'HashCountProcessor<32, 255> p\((\d+), (\d+),', hc).groups()
+    fed = [[int(h), int(c)] for h, c in re.findall(r'p\.process\(0, (\d+), (\d+)\)', hc)]
+    kept = [[int(re.search(r'EXPECT_EQ\(hash, (\d+)\)', hc).group(1)), int(re.search(r'EXPECT_EQ\(c, (\d+)\)', hc).group(1))]]
+    kc = src.split("TEST(processor, kmer_count_processor)")[1]
+    k2, a2 = re.search(r'KmerCountProcessor<32, 255> p\((\d+), (\d+),', kc).groups()
+    kfed = [int(c) for c in re.findall(r'p\.process\(0, gk\d, (\d+)\)', kc)]
+    kkept = [int(re.search(r'EXPECT_EQ\(c, (\d+)\)', kc).group(1))]
+    return {"hash": {"kmer_size": int(ksz), "abundance_min": int(amin), "fed": fed, "kept": kept},
+            "kmer": {"kmer_size": int(k2), "abundance_min": int(a2), "fed_counts": kfed, "kept_counts": kkept}}
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not mounted; goldens are already committed")
     copy_data()
     g = {"repartition_table": repart_sparse(), "task_main": task_main_goldens(),
          "merge_test": merge_goldens(), "repartition_test": repartition_goldens(),
-         "packc_test": packc_goldens(), "histogram_test": histogram_goldens()}
+         "packc_test": packc_goldens(), "histogram_test": histogram_goldens(),
+         "kmer_test": kmer_goldens(), "processor_test": processor_goldens()}
     json.dump(g, open(f"{OUT}/reference_goldens.json", "w"), indent=1, sort_keys=True)
     print("wrote", f"{OUT}/reference_goldens.json")

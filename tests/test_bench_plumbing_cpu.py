@@ -49,7 +49,7 @@ def _worker(rank, world, port, q, argv, wl):
     import bench
     from kmtricks_amd import shard
     a = bench.parse_args(argv)
-    env = dict(torch=torch, dist=dist, lib=_StubLib, shard=shard, rank=rank, world=world, local=0, dev=torch.device("cpu"),
+    env = dict(torch=torch, dist=dist, lib=_StubLib, shard=shard, rank=rank, world=world, local=0, dev=torch.device("cpu"), run_pipeline=False,
                sync=lambda: None, empty_cache=lambda: None)
     out = bench.run_workloads(a, wl, env)
     q.put((rank, out, _StubLib.last_log))

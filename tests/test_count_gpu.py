@@ -50,6 +50,31 @@ def test_count_reference_goldens(ctx):
                 assert len(hc) == exph["n"]
 
 
+def test_processor_test_hard_min(ctx):
+    """tests/processor_test.cpp:10-75 through the HIP count path: a 20-mer counted twice and one counted six times under
+    abundance-min 3 -- only the second comes out, with its count (count_processor.hpp:61-70, 135-146), k-mer and hash mode"""
+    Gp = G["processor_test"]
+    for kind in ("kmer", "hash"):
+        g = Gp[kind]
+        k, amin = g["kmer_size"], g["abundance_min"]
+        fed = g["fed_counts"] if kind == "kmer" else [c for _, c in g["fed"]]
+        kept = g["kept_counts"] if kind == "kmer" else [c for _, c in g["kept"]]
+        rng = np.random.default_rng(3)
+        kmers = ["".join(rng.choice(list("ACGT"), size=k)) for _ in fed]
+        reads = [km for km, c in zip(kmers, fed) for _ in range(c)]
+        lut = orc.minimizer_lut(8); rep = orc.repart_static(8, 1)
+        sk = orc.superk_partition(reads, k, 8, lut, rep, 1)
+        if kind == "kmer":
+            keys, counts = ctx.count_kmer(sk[0][0], k, amin)
+            ek, ec = orc.count_kmer(sk[0][0], k, amin)
+        else:
+            keys, counts = ctx.count_hash(sk[0][0], k, 1 << 20, 0, amin)
+            ek, ec = orc.count_hash(sk[0][0], k, 1 << 20, 0, amin)
+        assert [int(c) for c in counts] == kept and np.array_equal(np.asarray(keys).reshape(-1), np.asarray(ek).reshape(-1))
+        out, _, _, _ = ctx.count_reads(reads, k, 8, rep, 1, amin, window=(1 << 20) if kind == "hash" else 0)      # the fused split + count too
+        assert [int(c) for c in out[0][1]] == kept
+
+
 @pytest.mark.parametrize("k,m", [(31, 10), (21, 8), (32, 10), (47, 11), (63, 10), (20, 7)])
 def test_count_random_reads_vs_oracle(ctx, k, m):
     lut = orc.minimizer_lut(m)

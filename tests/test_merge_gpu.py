@@ -159,6 +159,30 @@ def test_synthetic_bft(ctx, merge_kernel, n, dens, smin, rmin, share, W):
     assert rows == (n + 7) // 8 * 8
 
 
+@pytest.mark.parametrize("which", ["configs1_bf", "configs3_bft"])
+def test_full_window_bloom_configs(ctx, merge_kernel, which):
+    """BASELINE configs[1] and configs[3] at their real window against the oracle, bit for bit: 100 samples x 156 k hashes,
+    hash:bf:bin, W = 3 125 056 (bloom 1e8 / 32 partitions, hash.hpp:31-40) -- and 2500 samples x 19.5 k hashes, hash:bft:bin
+    --soft-min 2 --share-min 1, W = 3 906 304 (bloom 1e9 / 256): 239 tiles of 16384 rows, every sample block, the rescue"""
+    if merge_kernel != "rows":
+        pytest.skip("Bloom modes have one kernel")
+    if which == "configs1_bf":
+        n, W, per, mode, smin, share = 100, 3125056, 156250, orc.MODE_BF, 1, 0
+    else:
+        n, W, per, mode, smin, share = 2500, 3906304, 19531, orc.MODE_BFT, 2, 1
+    lower = 3 * W
+    rng = np.random.default_rng(99 + n)
+    pool = np.unique(rng.integers(lower, lower + W, per, dtype=np.uint64))
+    lists = []
+    for i in range(n):      # the bench's cohort: 96.9 % of a shared pool + private hashes, counts 1..11 (a third below soft-min 2)
+        keep = pool[rng.random(len(pool)) < 0.969]
+        priv = rng.integers(lower, lower + W, int(per * 0.031), dtype=np.uint64)
+        hs = np.unique(np.concatenate([keep, priv]))
+        lists.append((hs.reshape(-1, 1), rng.integers(1, 12, len(hs), dtype=np.uint32)))
+    rows = check(ctx, lists, 1, [smin] * n, 1, share, mode, lower, lower + W - 1)
+    assert rows == (W if mode == orc.MODE_BF else (n + 7) // 8 * 8)
+
+
 def test_limits_fail_loudly(ctx, merge_kernel):
     """what this build does not take is refused with a message, not computed wrongly: more samples per hash:bft task than cursors
     fit the LDS, more than 4096 lists per COUNT / PA task"""

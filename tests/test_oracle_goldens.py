@@ -194,3 +194,48 @@ def test_histogram_reference_vector():
     assert h["oob"].tolist() == [0, 0, 0, 0] and h["sums"].tolist() == [len(g["counts"]), sum(g["counts"])]
     h2 = orc.khist([0, 11, 300], 1, 10, acc=h)      # out of bounds on both sides
     assert h2["oob"].tolist() == [1, 2, 0, 311]
+
+
+def test_kmer_test_vectors():
+    """tests/kmer_test.cpp:71-152 on the oracle's primitives: canonical forms, the most-significant-word-first order, the m-mers and
+    the minimizer of a k-mer (kmer.hpp:848-886: smallest valid m-mer value over the k-mer's m-mers and their reverse complements)"""
+    Gk = G["kmer_test"]
+    for a, c in Gk["canonical"]:
+        k = len(a)
+        w = orc.kmer_from_string(a); rc = orc.revcomp(w, k)
+        less = tuple(int(x) for x in w[::-1]) < tuple(int(x) for x in rc[::-1])
+        assert (a if less else orc.kmer_to_string(rc, k)) == c
+    for mk, x, y in Gk["less"]:
+        if len(x) > 64:
+            continue      # (three words: beyond the oracle's one- and two-word keys; the shipped kmer.hpp is checked in test_tools_cpu)
+        wx, wy = orc.kmer_from_string(x), orc.kmer_from_string(y)
+        assert tuple(int(v) for v in wx[::-1]) < tuple(int(v) for v in wy[::-1])
+    mi = Gk["minimizer"]
+    s, m = mi["kmer"], mi["m"]
+    assert [s[i:i + m] for i in range(len(s) - m + 1)] == mi["mmers"]
+    lut = orc.minimizer_lut(m)
+    code = {"A": 0, "C": 1, "T": 2, "G": 3}
+    val = lambda t: sum(code[c] << (2 * (m - 1 - i)) for i, c in enumerate(t))
+    best = min(int(lut[val(t)]) for t in mi["mmers"])
+    assert best == val(mi["minimizer"])
+    assert orc.minimizer_of(orc.kmer_from_string(s), len(s), m, lut) == best
+
+
+def test_processor_test_hard_min():
+    """tests/processor_test.cpp:10-75: records counted 2 and 6 times under abundance-min 3 -> only the second reaches the file"""
+    Gp = G["processor_test"]
+    for kind in ("kmer", "hash"):
+        g = Gp[kind]
+        k, amin = g["kmer_size"], g["abundance_min"]
+        fed = g["fed_counts"] if kind == "kmer" else [c for _, c in g["fed"]]
+        kept = g["kept_counts"] if kind == "kmer" else [c for _, c in g["kept"]]
+        rng = np.random.default_rng(3)
+        kmers = ["".join(rng.choice(list("ACGT"), size=k)) for _ in fed]
+        reads = [km for km, c in zip(kmers, fed) for _ in range(c)]
+        lut = orc.minimizer_lut(8); rep = orc.repart_static(8, 1)
+        sk = orc.superk_partition(reads, k, 8, lut, rep, 1)
+        if kind == "kmer":
+            keys, counts = orc.count_kmer(sk[0][0], k, amin)
+        else:
+            keys, counts = orc.count_hash(sk[0][0], k, 1 << 20, 0, amin)
+        assert sorted(int(c) for c in counts) == sorted(kept)

@@ -109,6 +109,36 @@ def test_soft_min_file(inputs, tmp_path):
     assert r.returncode == 1 and "different from the number of samples" in r.stderr
 
 
+@pytest.mark.parametrize("frac", ["0.2", "0.95", "1.0"])
+def test_soft_min_fraction_is_the_reference_s(inputs, tmp_path, frac):
+    """--soft-min <fraction> (src/cli.cpp:228-248): kmtricks 1.6.0 derives thresholds from the abundance histograms but appends
+    them to a vector that already holds one zero per sample (histogram.hpp:218-243), so the merge reads zeros: the run is the
+    `--soft-min 0 --hist` run, and merge_amin.txt holds N zeros followed by the values it computed -- per sample the first index of
+    the unique bins at which the running sum exceeds unique() * p, none when it never does"""
+    out = run(inputs, tmp_path / "f", "--mode", "kmer:count:bin", "--soft-min", frac, "--recurrence-min", "1")
+    ref = run(inputs, tmp_path / "z", "--mode", "kmer:count:bin", "--soft-min", "0", "--recurrence-min", "1", "--hist")
+    for sub in ("matrices", "merge_infos", "histograms"):
+        names = sorted(os.listdir(ref / sub))
+        assert names and names == sorted(os.listdir(out / sub))
+        for f in names:
+            assert open(out / sub / f, "rb").read() == open(ref / sub / f, "rb").read(), (sub, f)
+    opts = open(out / "options.txt").read()
+    assert "m_ab_float=1" in opts and "hist=1" in opts
+    lists = oracle_lists(False)
+    exp = [0, 0]
+    for si in range(2):
+        h = None
+        for p in range(P): h = orc.khist(lists[p][si][1], 1, 255, acc=h)
+        n = int(np.uint32(int(float(int(h["sums"][0])) * float(frac))))
+        acc = 0
+        for i, v in enumerate(h["unique"]):
+            if acc > n:
+                exp.append(i); break
+            acc = (acc + int(v)) & 0xFFFFFFFF
+    assert open(out / "merge_amin.txt").read() == "".join(f"{v}\n" for v in exp)
+    assert not os.path.exists(ref / "merge_amin.txt")
+
+
 def test_pa_and_recurrence_pipeline(inputs, tmp_path):
     out = run(inputs, tmp_path / "run", "--mode", "kmer:pa:bin", "--recurrence-min", "1")
     lists = oracle_lists(False)
@@ -205,8 +235,8 @@ def test_cli_errors(inputs, tmp_path):
     r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "y"), "--mode", "hash:bft:bin",
                         "--restrict-to-list", "0"], capture_output=True, text=True)
     assert r.returncode == 1 and "requires all partitions" in r.stderr  # cmd/all.hpp:137-143
-    r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "w"), "--soft-min", "0.5"], capture_output=True, text=True)
-    assert r.returncode == 1 and "not supported by this build" in r.stderr and "histogram.hpp:221-234" in r.stderr
+    r = subprocess.run([KMX, "pipeline", "--file", str(inputs / "in.fof"), "--run-dir", str(tmp_path / "w"), "--soft-min", "1.5"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Not in range [0.0, 1.0]" in r.stderr      # src/cli.cpp:237
     (tmp_path / "bad.fof").write_text(f"D1 : {tmp_path}/missing.fasta\n")
     r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "bad.fof"), "--run-dir", str(tmp_path / "z"), "--static-repart"],
                        capture_output=True, text=True)

@@ -93,6 +93,63 @@ int main(int argc, char** argv) {
         assert f[6] == "1" and f[7] == "1" and f[8] == "1"
 
 
+def test_shipped_kmer_header_against_the_reference_vectors(tmp_path):
+    """the values tests/kmer_test.cpp:9-152 asserts (tests/golden/reference_goldens.json "kmer_test"), on the shipped
+    include/kmtricks/kmer.hpp: type names, to_string / at / rev_comp identities on random strings of 20, 40 and 90 nucleotides
+    (Kmer<32>, <64>, <92>), canonical forms, comparisons for one, two and three words, the m-mers and the minimizer"""
+    import json
+    Gk = json.load(open(os.path.join(GD, "reference_goldens.json")))["kmer_test"]
+    src = tmp_path / "v.cpp"
+    src.write_text(r'''
+#include <kmtricks/kmer.hpp>
+#include <iostream>
+template <size_t MK> void ident(const std::string& s) {
+  km::Kmer<MK> a(s); std::string at; for (size_t i = 0; i < s.size(); i++) at.push_back(a.at(i));
+  std::cout << "ident " << km::Kmer<MK>::name() << "|" << a.to_string() << "|" << at << "|" << a.rev_comp().to_string() << "|" << km::str_rev_comp(s) << "\n";
+}
+template <size_t MK> void less(const std::string& x, const std::string& y) {
+  km::Kmer<MK> a(x), b(y);
+  std::cout << "less " << (a < b) << (a > b) << (a == b) << (a != b) << (a == a) << "\n";
+}
+int main(int argc, char** argv) {
+  for (int i = 1; i < argc; i++) {
+    const std::string c = argv[i];
+    if (c == "ident") { const size_t mk = std::stoul(argv[i + 1]); const std::string s = argv[i + 2]; i += 2; if (mk == 32) ident<32>(s); else if (mk == 64) ident<64>(s); else ident<92>(s); }
+    else if (c == "canon") { km::Kmer<32> a(argv[++i]); std::cout << "canon " << a.canonical().to_string() << "\n"; }
+    else if (c == "less") { const size_t mk = std::stoul(argv[i + 1]); const std::string x = argv[i + 2], y = argv[i + 3]; i += 3; if (mk == 32) less<32>(x, y); else if (mk == 64) less<64>(x, y); else less<96>(x, y); }
+    else if (c == "mmers") { km::Kmer<32> a(argv[i + 1]); const unsigned m = std::stoul(argv[i + 2]); i += 2; std::cout << "mmers"; for (auto& v : a.mmers(m)) std::cout << " " << v.to_string(); std::cout << " | " << a.minimizer(m).to_string() << "\n"; }
+  }
+}
+''')
+    exe = tmp_path / "v"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", f"-I{ROOT}/include", str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(11)
+    rnd = {mk: "".join(rng.choice(list("ACGT"), size=n)) for mk, n in ((32, 20), (64, 40), (92, 90))}      # (kmer_test.cpp:11-14: random_dna_seq(20 / 40 / 90))
+    args = []
+    for mk, _ in Gk["names"]:
+        args += ["ident", str(mk), rnd[mk]]
+    for a, _ in Gk["canonical"]:
+        args += ["canon", a]
+    for mk, x, y in Gk["less"]:
+        args += ["less", str(mk), x, y]
+    mi = Gk["minimizer"]
+    args += ["mmers", mi["kmer"], str(mi["m"])]
+    out = subprocess.run([str(exe)] + args, capture_output=True, text=True).stdout.splitlines()
+    it = iter(out)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for mk, name in Gk["names"]:
+        f = next(it)[len("ident "):].split("|")
+        s = rnd[mk]
+        assert f[0] == name and f[1] == s and f[2] == s
+        assert f[3] == "".join(comp[c] for c in reversed(s)) == f[4]
+    for _, c in Gk["canonical"]:
+        assert next(it) == "canon " + c
+    for _ in Gk["less"]:
+        assert next(it) == "less 10011"      # a < b, !(a > b), !(a == b), a != b, a == a (kmer_test.cpp:97-115)
+    assert next(it) == "mmers " + " ".join(mi["mmers"]) + " | " + mi["minimizer"]
+
+
 def _mmers(s, m):
     code = {"A": 0, "C": 1, "T": 2, "G": 3}
     for i in range(len(s) - m + 1):
