@@ -3,6 +3,7 @@
 #include "kmx_host.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <sys/mman.h>
 #include <unordered_map>
 #include <mutex>
@@ -278,6 +279,7 @@ struct TaskHost {
   size_t o_recs = 0, o_len = 0, o_smin = 0, o_bounds = 0, o_stats = 0, o_ctrl = 0, o_segs = 0;
   u8* d_out = nullptr; size_t out_bytes = 0;
   u16* d_rowrec = nullptr;                      // BFT: recurrence per hash row (k_bf_rowrec)
+  u32 bft_c = 1;                                // BFT: work items (runs of consecutive tiles) of the task
   u8* d_img = nullptr; size_t img_bytes = 0;   // (unused since k_merge_bft writes the transposed matrix directly)
   u64 t_rows = 0, t_cols = 0;                   // BFT: rows / columns of that image rounded up to 8 (merge.hpp:634)
   Seg* d_segs = nullptr;        // directory in use (inside the meta blob, or d_segs_own after a retry)
@@ -332,6 +334,8 @@ struct kmx_merge_result {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
   hipEvent_t ev2 = nullptr;                  // BFT: behind the transposes (ev1 .. ev2 = their duration)
   u8* d_in = nullptr;                        // kmx_merge_host: the uploaded lists (freed with the result)
+  u64* d_rem = nullptr; u32 rem_cap = 0;     // BFT, one-bit recurrences: the single walk's scratch (records put aside until a tile's map is complete)
+  bool bft_two_walks = false;                // ... a tile ran out of it: the batch ran again with two walks
   hipEvent_t ev_in = nullptr;                // ... and the end of their upload
   u64* d_hctrl = nullptr;                    // device address of the control words' place in h_meta
   hipEvent_t ev_pre = nullptr;               // cols: preparation (second stream) done
@@ -378,10 +382,27 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   if (!R->use_cols) KMX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 16, ctx->stream));      // (cols runs once per result: the upload zeroed it)
   if (ctx->profiling && !R->ev0) { KMX_HIP(ctx, hipEventCreate(&R->ev0)); KMX_HIP(ctx, hipEventCreate(&R->ev1)); }
   if (R->is_bf) {
-    if (with_bounds) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));
+    if (with_bounds && !R->is_bft) KMX_HIP(ctx, launch_range_bounds_bf(d_tasks, nt, R->max_n, R->max_c, ctx->stream));      // (k_merge_bft finds where the lists enter its work items itself)
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     if (R->is_bft) {   // sample-major matrix straight from the merge (merge_bft.hip)
-      KMX_HIP(ctx, launch_merge_bft(d_tasks, d_items, R->n_items, d_ticket, std::min(R->n_items, (u32)ctx->n_cu * 2u), R->max_n, ctx->stream));
+      u32 rt_max = 0; bool rec_bits = true, any_share = false;
+      for (auto& H : R->tasks) { rt_max = std::max(rt_max, H.rt); rec_bits = rec_bits && std::max(H.rec_min, H.share_min) <= 1u; any_share = any_share || H.share_min > 0; }
+      const u32 bgrid = std::min(R->n_items, (u32)ctx->n_cu * 2u);
+      static const bool two_walks_env = getenv("KMX_BFT_TWO_WALKS") != nullptr;
+      if (rec_bits && any_share && !R->bft_two_walks && !two_walks_env && !R->d_rem) {
+        // the single walk's scratch: a quarter of a tile's records per workgroup (cohort data puts ~1 % aside), at most 1 GB in all
+        u64 per_tile = 0;
+        for (auto& H : R->tasks) { const u64 tiles = std::max<u64>(1, ((H.upper - H.lower + 1) + H.rt - 1) / H.rt); per_tile = std::max(per_tile, H.total_recs / tiles); }
+        u64 cap = std::max<u64>(4096, per_tile / 4);
+        cap = std::min<u64>(cap, ((1ull << 30) / 8) / std::max(1u, bgrid));
+        R->rem_cap = (u32)cap;
+        R->d_rem = (u64*)ctx->dalloc((size_t)bgrid * cap * 8);      // (no room for it: two walks)
+      }
+      const bool one_walk = R->d_rem && !R->bft_two_walks;
+      // (rounds of 8 x 16 records per sample unless a tile is expected to hold more of the average list than that, with margin)
+      bool wide = false;
+      for (auto& H : R->tasks) { const double m = (double)H.total_recs / H.N * (double)H.rt / (double)(H.upper - H.lower + 1); wide = wide || m + 2.6 * std::sqrt(m) + 8 > (double)bft_round_records(false); }
+      KMX_HIP(ctx, launch_merge_bft(d_tasks, d_items, R->n_items, d_ticket, bgrid, R->max_n, rt_max, rec_bits, wide, one_walk ? R->d_rem : nullptr, R->rem_cap, ctx->stream));
     } else
     KMX_HIP(ctx, launch_merge_bf(mode == KMX_MODE_BFC, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->bf_lds, ctx->stream));
   } else if (R->use_cols) {
@@ -500,7 +521,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       H.row_bytes = mode != KMX_MODE_BFC ? (H.N + 7) / 8 : (u32)(((u64)H.N * K.bitw + 7) / 8);
       u32 rt = (40960u / H.row_bytes) & ~63u; if (rt < 64) rt = 64;
       if (!is_bft && (u64)rt * H.row_bytes > 96 * 1024) return ctx->fail(KMX_E_UNSUPPORTED, "BF row too wide for one LDS tile");
-      H.rt = is_bft ? bft_tile_rows() : rt;
+      H.rt = is_bft ? bft_tile_rows(K.rec_min, K.share_min) : rt;
       H.out_bytes = (size_t)((K.upper - K.lower + 1) * H.row_bytes);
       if (is_bft && H.N > bft_max_lists()) return ctx->fail(KMX_E_UNSUPPORTED, "more than " + std::to_string(bft_max_lists()) + " samples per hash:bft task not supported");
       if (is_bft) {   // write_as_bft (merge.hpp:631-644): BitMatrix(ROUND_UP(W, 8), ROUND_UP(N, 8) / 8), transposed, dumped whole
@@ -518,6 +539,28 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       if (ctx->rows_per_longest > 0.0) guess = std::max<u64>(guess, (u64)(ctx->rows_per_longest * 1.125 * (double)longest) + 4096);
       if (guess > H.total_recs) guess = H.total_recs;
       H.rows_guess = std::max<u64>(guess, 1);   // arena = guess + chunk slack, sized once c is known
+    }
+  }
+  if (is_bft) {
+    // tiles and work items of a hash:bft batch.  (1) The larger tile needs every task on the one-bit recurrence (the LDS regions are
+    // sized per launch).  (2) One tile size for the batch, cut so that the tiles come to a whole number of rounds of one workgroup per
+    // CU: configs[3]'s 4 x 3.9 M rows are 764 tiles of 20480 rows = 3 rounds of 256; with the largest tile (24576 rows: 636 tiles)
+    // a third of the CUs idle through the last round.  (3) A work item is a RUN of up to `rounds` consecutive tiles of a task, about
+    // one item per workgroup: where the lists enter an item is searched once, the cursors carry from tile to tile.
+    bool all1 = true; u64 wsum = 0;
+    for (auto& H : R->tasks) { all1 = all1 && std::max(H.rec_min, H.share_min) <= 1u; wsum += H.upper - H.lower + 1; }
+    const u32 cap = all1 ? bft_tile_rows(1, 1) : bft_tile_rows(2, 2);
+    u32 rounds = 1, rt = cap;
+    for (;; rounds++) {
+      const u64 want = (wsum + (u64)rounds * ctx->n_cu - 1) / ((u64)rounds * ctx->n_cu);
+      rt = (u32)std::max<u64>(1024, (want + 255) / 256 * 256);
+      if (rt <= cap) break;
+    }
+    for (auto& H : R->tasks) {
+      H.rt = rt;
+      const u64 tiles = ((H.upper - H.lower + 1) + rt - 1) / rt;
+      H.bft_c = (u32)std::max<u64>(1, (tiles + rounds - 1) / rounds);
+      if (getenv("KMX_BFT_TILE_ITEMS")) H.bft_c = (u32)tiles;      // (tuning: an item per tile, handed out by ticket)
     }
   }
   // ---- which COUNT/PA kernel ----
@@ -609,6 +652,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       c = std::min<u64>(c, tiles);
     } else c = std::min<u64>(c, std::max<u32>(1, H.len[H.pivot]));
     H.c = (u32)std::max<u64>(1, c);
+    if (is_bft) H.c = H.bft_c;
     H.seg_cap = is_bf ? 1 : (u32)std::min<u64>(0x7FFFFFFF, H.total_recs / 512 + 8ULL * H.c + 4096);
     if (!is_bf) {   // rows are claimed in chunks: every range may leave one chunk partly unused
       H.out_cap_rows = H.rows_guess + (u64)(H.c + 1) * rows_chunk_rows(H.row_bytes);
@@ -728,7 +772,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   auto drop_blocks = [&]() {
     for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); ctx->dfree(G.d_rowrec); ctx->dfree(G.d_dense); }
     for (auto& G : R->subs) ctx->dfree(G.d_out);
-    ctx->dfree(R->d_meta); ctx->hfree(R->h_meta);
+    ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); ctx->dfree(R->d_rem); R->d_rem = nullptr;
   };
   for (auto& H : R->tasks) {
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
@@ -887,6 +931,24 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   KMX_HIP(ctx, hipEventSynchronize(R->ev_done));
   if (R->is_bf) {
+    if (R->is_bft && R->d_rem && !R->bft_two_walks) {
+      // the single walk put more records aside in some tile than its scratch holds (lists with hardly a solid record): the batch
+      // runs again with two walks -- every tile rewrites all of its bytes, the statistics restart
+      const u64* hc = reinterpret_cast<const u64*>(R->h_meta + R->o_ctrl0);
+      bool again = false;
+      for (size_t t = 0; t < R->tasks.size(); t++) again = again || (hc[t * 8 + 2] & ERR_FALLBACK);
+      if (again) {
+        if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] k_merge_bft: a tile overflowed the single walk's scratch: the batch runs again with two walks\n");
+        R->bft_two_walks = true;
+        for (auto& H : R->tasks) {
+          KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_stats, 0, 8ull * 6 * H.N, ctx->stream));
+          KMX_HIP(ctx, hipMemsetAsync(R->d_meta + H.o_ctrl, 0, 64, ctx->stream));
+        }
+        int rc2 = launch_batch(R, false);
+        if (rc2 != KMX_OK) { R->waited = true; R->status = rc2; return rc2; }
+        KMX_HIP(ctx, hipEventSynchronize(R->ev_done));
+      }
+    }
     for (auto& H : R->tasks) H.rows = R->is_bft ? H.t_cols : H.upper - H.lower + 1;
     R->waited = true; R->status = KMX_OK;
     return KMX_OK;
@@ -1293,7 +1355,7 @@ extern "C" int kmx_result_copy_stats(kmx_merge_result* R, uint32_t t, uint64_t* 
 }
 
 #ifdef KMX_PHASE_PROF
-namespace kmx { void rows_phase_prof_dump(); void pivot_phase_prof_dump(); }
+namespace kmx { void rows_phase_prof_dump(); void pivot_phase_prof_dump(); void bft_phase_prof_dump(); }
 #endif
 extern "C" void kmx_result_free(kmx_merge_result* R)
 {
@@ -1304,6 +1366,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   else (void)hipStreamSynchronize(ctx->stream);
 #ifdef KMX_PHASE_PROF
   const ColsOps& CO = cols_ops((int)R->tasks[0].kw);
+  if (R->is_bft) kmx::bft_phase_prof_dump();
   if (!R->is_bf) { if (R->use_cols) { if (CO.phase_prof_dump) CO.phase_prof_dump(); } else if (R->use_pivot) kmx::pivot_phase_prof_dump(); else kmx::rows_phase_prof_dump(); }
 #endif
   for (auto& H : R->tasks) {
@@ -1314,6 +1377,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   ctx->dfree(R->d_meta);
   ctx->hfree(R->h_meta);
   ctx->dfree(R->d_in);
+  ctx->dfree(R->d_rem);
   if (R->ev_in) (void)hipEventDestroy(R->ev_in);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
   if (R->ev2) (void)hipEventDestroy(R->ev2);

@@ -51,10 +51,11 @@ int bf_lds_bytes(u32 rt, u32 nb, u32 n_lists);
 hipError_t launch_range_bounds_bf(const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);
 hipError_t launch_merge_bf(int bfc, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
                            u32 grid_x, int lds, hipStream_t st);
-u32 bft_tile_rows();
+u32 bft_tile_rows(u32 rec_min, u32 share_min);
 u32 bft_block_lists();
 u32 bft_max_lists();
-hipError_t launch_merge_bft(const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, u32 max_n, hipStream_t st);
+u32 bft_round_records(bool wide);
+hipError_t launch_merge_bft(const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, u32 max_n, u32 rt_max, bool rec_bits, bool wide, u64* rem, u32 rem_cap, hipStream_t st);
 hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hipStream_t st);
 
 }  // namespace kmx

@@ -183,6 +183,43 @@ def test_full_window_bloom_configs(ctx, merge_kernel, which):
     assert rows == (W if mode == orc.MODE_BF else (n + 7) // 8 * 8)
 
 
+@pytest.mark.parametrize("kind", ["cohort", "nothing_solid", "half_solid"])
+def test_bft_single_walk_and_its_fallback(ctx, merge_kernel, kind, monkeypatch, capfd):
+    """hash:bft:bin with --share-min 1 (one-bit recurrences): k_merge_bft walks a tile's records ONCE, puts aside the non-solid
+    records whose row has no solid record yet and settles them when the tile's map is complete.  cohort: few are put aside.
+    nothing_solid: every record is below its soft-min -- everything is put aside, the scratch overflows, the batch runs again with
+    two walks.  half_solid: private hashes, half of them solid -- a lot is put aside and dropped.  Same bytes and statistics as the
+    oracle every time, and as the two-walk kernel (KMX_BFT_TWO_WALKS)"""
+    if merge_kernel != "rows":
+        pytest.skip("Bloom modes have one kernel")
+    n, W = 300, 70000
+    lower = 2 * W
+    rng = np.random.default_rng(17)
+    lists = []
+    if kind == "cohort":
+        pool = np.unique(rng.integers(lower, lower + W, 9000, dtype=np.uint64))
+        for i in range(n):
+            hs = np.unique(np.concatenate([pool[rng.random(len(pool)) < 0.95], rng.integers(lower, lower + W, 300, dtype=np.uint64)]))
+            lists.append((hs.reshape(-1, 1), rng.integers(1, 12, len(hs), dtype=np.uint32)))
+        soft = [2] * n
+    else:
+        for i in range(n):
+            hs = np.unique(rng.integers(lower, lower + W, 6000, dtype=np.uint64))
+            lists.append((hs.reshape(-1, 1), rng.integers(1, 5, len(hs), dtype=np.uint32)))
+        soft = [100] * n if kind == "nothing_solid" else [3] * n
+    monkeypatch.setenv("KMX_TRACE", "1")
+    capfd.readouterr()
+    for rmin in (1, 0):
+        check(ctx, lists, 1, soft, rmin, 1, orc.MODE_BFT, lower, lower + W - 1)
+    err = capfd.readouterr().err
+    assert ("runs again with two walks" in err) == (kind == "nothing_solid")
+    monkeypatch.setenv("KMX_BFT_TWO_WALKS", "1")
+    from kmtricks_amd import lib
+    c2 = lib.Context(0)
+    check(c2, lists, 1, soft, 1, 1, orc.MODE_BFT, lower, lower + W - 1)
+    c2.close()
+
+
 def test_limits_fail_loudly(ctx, merge_kernel):
     """what this build does not take is refused with a message, not computed wrongly: more samples per hash:bft task than cursors
     fit the LDS, more than 4096 lists per COUNT / PA task"""
