@@ -48,7 +48,7 @@ struct Sample { std::string id; std::vector<std::string> files; uint32_t hard_mi
 struct Opt {
   std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file, bf_format = "howdesbt", soft_min_path;
   double soft_f = 0.0; bool soft_float = false;      // --soft-min <fraction> (src/cli.cpp:234-240)
-  uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1, gpu_workers = 2;
+  uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1, gpu_workers = 2, per_call = 0;
   uint64_t bloom = 10000000, merge_batch_mb = 4096;
   double restrict_to = 1.0, focus = 0.5;
   std::vector<uint32_t> restrict_list;
@@ -139,6 +139,7 @@ static Opt parse_cli(int argc, char** argv)
     else if (a == "--plugin-config") o.plugin_config = need(i);
     else if (a == "-t" || a == "--threads") o.threads = num(i);
     else if (a == "--gpus") o.gpus = num(i);                    // kmx extension: samples / partitions shard round-robin over this many GPUs
+    else if (a == "--samples-per-call") o.per_call = num(i);      // kmx extension: whole samples a count worker hands the GPU in one call (0: the default)
     else if (a == "--gpu-workers") o.gpu_workers = num(i);      // kmx extension: count workers (host thread + context) per shard
     else if (a == "--no-resident") o.no_resident = true;        // kmx extension: count lists go through count files (as with --keep-tmp) instead of staying in HBM
     else if (a == "--merge-batch-mb") o.merge_batch_mb = num(i); // kmx extension: count-list bytes per merge batch and GPU
@@ -472,7 +473,7 @@ int run(int argc, char** argv)
     // (kmx_count_reads_dev_multi: a 1 Mbp sample is a few dozen small kernels and four host round trips, which a call pays once --
     // 0.71 -> 0.49 ms per sample at n = 4 when the call is timed by itself, scripts/bench_count_multi.py).  Through this driver it does
     // not pay yet: 1000 x 1 Mbp count in 0.89-0.95 s at n = 4 against 0.63 s at n = 1 (--skip-partiinfo; two workers), so the default is 1.
-    const uint32_t per_call = getenv("KMX_COUNT_SAMPLES_PER_CALL") ? (uint32_t)std::max(1L, atol(getenv("KMX_COUNT_SAMPLES_PER_CALL"))) : 1u;
+    const uint32_t per_call = o.per_call ? o.per_call : getenv("KMX_COUNT_SAMPLES_PER_CALL") ? (uint32_t)std::max(1L, atol(getenv("KMX_COUNT_SAMPLES_PER_CALL"))) : 1u;
     rawpool.cap = ((size_t)per_call + 2) * NW + 2; rawpool.words = raw_words;
     std::atomic<uint32_t> next_sample{0};
     // A sample's batches must reach its worker in order; samples are taken in fof order by `readers` threads per round so the

@@ -1,12 +1,11 @@
-# count and pa63 bench lines with the rows in file order (1) and not (0): one summary line each
+# count and pa63 bench lines: the pair with the rows where the kernels leave them, and with the rows in file order (bench.py times both)
 mkdir -p gpurun_out/$1
-for fo in ${FOS:-1 0}; do for wl in ${WLS:-count pa63}; do KMX_FILE_ORDER=$fo python bench.py --workload $wl --no-cpu-baseline --steps 10 $EXTRA > gpurun_out/$1/${wl}_fo$fo.json 2> gpurun_out/$1/${wl}_fo$fo.err; done; done
+for wl in ${WLS:-count pa63}; do python bench.py --workload $wl --no-cpu-baseline --no-whole-job --steps 10 $EXTRA > gpurun_out/$1/${wl}.json 2> gpurun_out/$1/${wl}.err; done
 python - $1 <<PY
 import json, sys, os
 for w in os.environ.get("WLS", "count pa63").split():
-  for fo in os.environ.get("FOS", "1 0").split():
     try:
-      d=json.load(open(f"gpurun_out/{sys.argv[1]}/{w}_fo{fo}.json")); r=d["roofline"]
-      print(w,fo,"ms_step",round(d["ms_per_step"],3),"kernel_ms",round(r["kernel_ms"],3),"frac",round(r["frac"],3),"gather",round(r["file_order_gather_ms"],2),"order",round(r["row_order_ms"],2), "rows", d["config"]["rows_out_per_step_per_gpu"], r["kernel"])
-    except Exception as e: print(w, fo, "failed", e, open(f"gpurun_out/{sys.argv[1]}/{w}_fo{fo}.err").read()[-600:])
+      d=json.load(open(f"gpurun_out/{sys.argv[1]}/{w}.json")); r=d["roofline"]; fo=r.get("file_order") or {}
+      print(w, "arena: step %.3f kernel %.3f frac %.3f | file order: step %.3f kernel %.3f frac %.3f | gather %.2f" % (d["ms_per_step"], r["kernel_ms"], r["frac"], fo.get("ms_per_step", 0), fo.get("kernel_ms", 0), r.get("frac_with_file_order") or 0, r["file_order_gather_ms"]))
+    except Exception as e: print(w, "failed", e, open(f"gpurun_out/{sys.argv[1]}/{w}.err").read()[-600:])
 PY
