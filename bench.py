@@ -283,7 +283,8 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
         dt_fo = time.perf_counter() - t1
         dt_fo, _ = shard.reduce_job(dist if world > 1 else None, dev, dt_fo, float(total_recs))
         fo_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        fo = {"kernel_ms": fo_ms, "ms_per_step": dt_fo / a.steps * 1e3, "value": job_recs * a.steps / dt_fo, "kernel": kernel_name}
+        fo = {"kernel_ms": fo_ms, "ms_per_step": dt_fo / a.steps * 1e3, "value": job_recs * a.steps / dt_fo, "kernel": kernel_name,
+              "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name + ":file_order")}
         # ---- ... and, on one GPU, the WHOLE job that way: all partitions of configs[2] (8 batches of 32 on one MI355X) ----
         if job_lists is not None and rank == 0:
             per = P

@@ -313,7 +313,9 @@ typedef struct {
 /* kmx_count_reads with the results left on the device: partition p's (key, count) records -- ascending, packed as a
  * .kmer body with 4-byte counts -- go to stores[p % n_stores] (the merge stage shards partitions round-robin over the
  * GPUs: the list already lies where it will be merged), lists[p] = {device pointer, records}.  stats (added to, u64)
- * or raw (copied, u32) or neither.  KMX_E_NOMEM when a store is full (nothing is left allocated for this call).
+ * or raw (copied, u32) or neither.  KMX_E_NOMEM when a store is full: the call's results are dropped, but a store is a bump arena
+ * without rollback -- what the call had already placed in other stores stays consumed until kmx_store_destroy (the caller sends the
+ * sample through count files: kmx_count_reads; `kmx pipeline` does).
  * With superk_bytes == NULL (here and in kmx_count_reads) no super-k-mer record stream is built at all: the k-mers are cut
  * straight from the batch's bases, the counts are the same (SuperKmerBinInfoFile's numbers still come back in superk_info:
  * they are computed from the records' sizes).  raw's buffers are filled when the call returns. */

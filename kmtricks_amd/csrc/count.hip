@@ -794,7 +794,9 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
     while (pos < len[p]) {
       const u32 n = s[pos];
       const u64 nb = ((u64)k + n - 1 + 3) / 4;
-      if (n == 0 || pos + 1 + nb > len[p]) { bad = 1; return; }
+      // (a super-k-mer holds at most 28 k-mers for k < 32, 60 above -- Sequence2SuperKmer.hpp:90-132; the lane-per-k-mer decode cuts a
+      //  record's k-mers from one 64- / 128-bit window and relies on it: a longer record is a malformed stream, not silently wrong keys)
+      if (n == 0 || n > (k < 32 ? 28u : 60u) || pos + 1 + nb > len[p]) { bad = 1; return; }
       nr++; nk += n; pos += 1 + nb;
     }
     n_rec[p] = nr; n_km[p] = nk;

@@ -29,7 +29,10 @@ constexpr int CS_TPB = 256;
 constexpr int CS_WALK_TPB = 1024;
 constexpr int CS_CHUNK = 16 * CS_WALK_TPB;  // keys per workgroup in the count / scatter walks (a chunk holds ~11 keys per bucket of a partition cut into 1500: the pieces the scatter writes)
 constexpr int CS_MAXB = 2048;             // buckets per partition (partitions of up to ~1 M keys; beyond: the library sort)
-template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 16384; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (64 KB)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "count_sort.hpp is written for gfx950 (MI355X): 160 KB of LDS per workgroup (k_cs_splitters: 128 KB), v_permlane16_swap / v_permlane32_swap"
+#endif
+template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 16384; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (16384 x 8 B or 8192 x 16 B = 128 KB of LDS in k_cs_splitters)
 template <> struct CsCap<__uint128_t> { static constexpr int cap = 4096, sample = 8192; };      // (cap: 64 + 16 KB of LDS in k_cs_sort, which only sees the buckets the wave kernel leaves)
 constexpr u32 CS_WAVE_MAX = 1024;         // keys of a bucket that one wave sorts in registers (16 per lane)
 template <typename K> __host__ __device__ inline u32 cs_target() { return CS_WAVE_MAX / 2; }      // aimed bucket size (a bucket may come out twice that and stay with the wave kernel, 4-8x and stay in LDS)

@@ -549,7 +549,8 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     // one item per workgroup: where the lists enter an item is searched once, the cursors carry from tile to tile.
     bool all1 = true; u64 wsum = 0;
     for (auto& H : R->tasks) { all1 = all1 && std::max(H.rec_min, H.share_min) <= 1u; wsum += H.upper - H.lower + 1; }
-    const u32 cap = all1 ? bft_tile_rows(1, 1) : bft_tile_rows(2, 2);
+    u32 mxn = 0; for (auto& H : R->tasks) mxn = std::max(mxn, H.N);
+    const u32 cap = std::min(all1 ? bft_tile_rows(1, 1) : bft_tile_rows(2, 2), bft_fit_rows(mxn, all1));      // (thousands of samples: their cursors take the image's room)
     u32 rounds = 1, rt = cap;
     for (;; rounds++) {
       const u64 want = (wsum + (u64)rounds * ctx->n_cu - 1) / ((u64)rounds * ctx->n_cu);

@@ -55,6 +55,7 @@ u32 bft_tile_rows(u32 rec_min, u32 share_min);
 u32 bft_block_lists();
 u32 bft_max_lists();
 u32 bft_round_records(bool wide);
+u32 bft_fit_rows(u32 max_n, bool bits);
 hipError_t launch_merge_bft(const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, u32 max_n, u32 rt_max, bool rec_bits, bool wide, u64* rem, u32 rem_cap, hipStream_t st);
 hipError_t launch_bit_transpose(const u8* in, u8* out, u64 nrows, u64 ncols, hipStream_t st);
 

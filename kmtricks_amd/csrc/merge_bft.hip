@@ -390,6 +390,13 @@ void k_merge_bft(const TaskDev* __restrict__ tasks, const uint2* __restrict__ it
 
 // the most rows a tile of a task may have: the larger tile when its rows' recurrences are one bit each or not needed (thresholds <= 1)
 u32 bft_tile_rows(u32 rec_min, u32 share_min) { return std::max(rec_min, share_min) <= 1u ? (u32)BT_RT1 : (u32)BT_RT; }
+// the most rows a tile may have when the launch's largest task has max_n samples: image + recurrences + at least the cursors fit the LDS
+u32 bft_fit_rows(u32 max_n, bool bits)
+{
+  for (u32 rt = bits ? (u32)BT_RT1 : (u32)BT_RT; rt >= 1024u; rt -= 256u)
+    if ((size_t)bt_img_bytes(rt) + bt_rec_bytes(rt, bits) + (size_t)max_n * 4 + 16 <= (size_t)BT_LDS) return rt;
+  return 1024u;
+}
 u32 bft_round_records(bool wide) { return (u32)(wide ? KMX_BT_UNR1 : KMX_BT_UNR) * BT_G; }
 u32 bft_block_lists() { return BT_NB; }
 #ifdef KMX_PHASE_PROF

@@ -23,7 +23,8 @@ for case in range(n_cases):
     if big: N = rng.choice([300, 600, 1000]); pool = rng.choice([20000, 40000])      # work items of many tiles
     p = rng.choice([0.999, 0.97, 0.9, 0.6, 0.2]) if not big else rng.choice([0.999, 0.97, 0.93, 0.85])
     priv = int(pool * (rng.choice([0.0, 0.01, 0.03, 0.1, 0.4]) if not big else rng.choice([0.0, 0.01, 0.03, 0.08])))
-    rec_min = rng.choice([1, 2, 2, 2, 3, 5, 9])
+    rec_min = rng.choice([0, 1, 1, 2, 2, 2, 3, 5, 9])
+    share = rng.choice([0, 0, 0, 1, max(1, rec_min)])      # (share-min <= max(1, recurrence-min): the RESC builds of the pair; beyond, k_merge_rows)
     mode = rng.choice([lib.MODE_COUNT, lib.MODE_COUNT, lib.MODE_PA])
     os.environ["KMX_ITEMS_PER_SLOT"] = rng.choice(["1", "3"])
     lists = synth_lists(rng.randrange(1 << 30), N, pool, p, priv, kw=KW, key_bits=62 if KW == 1 else rng.choice([66, 72, 126]),
@@ -36,11 +37,11 @@ for case in range(n_cases):
             k2 = np.concatenate([k, run]); c2 = np.concatenate([c, np.full(len(run), 3, np.uint32)])
             o = np.argsort(k2[:, 0]); lists[i] = (np.ascontiguousarray(k2[o]), np.ascontiguousarray(c2[o]))
     soft = [rng.choice([1, 1, 2, 3]) for _ in range(N)]
-    print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} mode={mode} ...", flush=True)
-    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], KW, soft, rec_min, 0, mode)
-    body, rows, stats = ctx.merge(lists, KW, soft, rec_min, 0, mode)
+    print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} share={share} mode={mode} ...", flush=True)
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], KW, soft, rec_min, share, mode)
+    body, rows, stats = ctx.merge(lists, KW, soft, rec_min, share, mode)
     ok = rows == er and body == eb and np.array_equal(stats, es)
-    print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} mode={mode} rows={rows} {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {case}: N={N} pool={pool} p={p} priv={priv} rec_min={rec_min} share={share} mode={mode} rows={rows} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         sys.exit(1)
 print("all", n_cases, "cases equal the oracle")

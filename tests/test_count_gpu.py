@@ -115,6 +115,19 @@ def test_count_batch_vs_oracle(ctx, k, m):
     assert all(len(c) == 0 for _, c in ctx.count_batch([b"", b""], k, 1))
 
 
+def test_count_rejects_records_longer_than_a_super_kmer(ctx):
+    """a record that claims more k-mers than a super-k-mer can hold (28 for k < 32, 60 above: Sequence2SuperKmer.hpp:90-132) is a
+    malformed stream -- refused, not decoded into wrong keys (the lane-per-k-mer decode reads a record's k-mers from one window)"""
+    from kmtricks_amd import lib
+    for k, n in ((31, 29), (31, 255), (40, 61)):
+        rec = bytes([n]) + bytes((k + n - 1 + 3) // 4)
+        with pytest.raises(lib.KmxError, match="malformed super-k-mer stream"):
+            ctx.count_kmer(rec, k, 1)
+    ok = bytes([28]) + bytes((31 + 28 - 1 + 3) // 4)      # (28 k-mers of poly-A: one key counted 28 times)
+    keys, counts = ctx.count_kmer(ok, 31, 1)
+    assert list(counts) == [28]
+
+
 def test_count_empty_stream(ctx):
     k_, c_ = ctx.count_kmer(b"", 31, 2)
     assert len(c_) == 0

@@ -227,7 +227,9 @@ def test_limits_fail_loudly(ctx, merge_kernel):
         pytest.skip("one run is enough")
     empty = (np.zeros((0, 1), np.uint64), np.zeros(0, np.uint32))
     with pytest.raises(Exception, match="hash:bft"):
-        ctx.merge([empty] * 9000, 1, [1] * 9000, 1, 0, orc.MODE_BFT, 0, 6399)
+        ctx.merge([empty] * 17000, 1, [1] * 17000, 1, 0, orc.MODE_BFT, 0, 6399)
+    one = (np.array([[7]], np.uint64), np.array([3], np.uint32))
+    check(ctx, [one] + [empty] * 8999, 1, [1] * 9000, 1, 1, orc.MODE_BFT, 0, 6399)      # (9000 samples: the tables no longer fit the LDS, only the cursors; smaller tiles)
     with pytest.raises(Exception, match="4096 lists"):
         ctx.merge([empty] * 5000, 1, [1] * 5000, 1, 0, orc.MODE_COUNT)
     check(ctx, [empty] * 3, 1, [1] * 3, 1, 0, orc.MODE_COUNT)      # (the context is still usable)
