@@ -593,6 +593,51 @@ def test_k63_pa_cohort_pipeline(tmp_path):
     assert total_rows > 100_000
 
 
+def test_cohort_pipeline_where_the_limits_interact(tmp_path):
+    """a cohort large enough for the column-blocked pair (256 samples x 300 kbp, k = 31, count rows, 32 partitions, rows in file
+    order out of the kernels), run three ways whose run directories must be identical: (a) plain; (b) stores of 48 MB shared by two
+    shards, a 4 MB output ring in 256 KB pieces, 40 000 k-mers per count call, three samples per call -- some samples resident, the
+    others through count files, every batch a mix, bodies leaving in many pieces; (c) no resident lists at all (count files, as
+    the reference).  Partition 0 of (a) equals the oracle's matrix."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    NS, GL, PP = 256, 300_000, 32
+    paths = [bench._pipeline_make_sample((s_, GL, 0.002, 6, str(tmp_path))) for s_ in range(NS)]
+    (tmp_path / "c.fof").write_text("".join(f"S{i:04d} : {p}\n" for i, p in enumerate(paths)))
+    base = [KMX, "pipeline", "--file", str(tmp_path / "c.fof"), "--kmer-size", "31", "--hard-min", "2", "--nb-partitions", str(PP), "--static-repart",
+            "--recurrence-min", "2", "--mode", "kmer:count:bin", "-t", "16"]
+    runs = {"plain": ([], {}),
+            "tight": (["--gpus", "2", "--samples-per-call", "3", "--merge-batch-mb", "64"], {"KMX_STORE_LIMIT_MB": "48", "KMX_OUT_RING_MB": "4", "KMX_OUT_PIECE_KB": "256", "KMX_COUNT_GROUP_LIMIT": "40000"}),
+            "files": (["--no-resident"], {})}
+    outs = {}
+    for name, (flags, env) in runs.items():
+        r = subprocess.run(base + ["--run-dir", str(tmp_path / name)] + flags, capture_output=True, text=True, env=dict(os.environ, KMX_TRACE="1", **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = json.loads([l for l in r.stderr.splitlines() if l.startswith("[kmx pipeline]")][-1][len("[kmx pipeline] "):])
+        if name == "plain":
+            ran = [l for l in r.stderr.splitlines() if l.startswith("[kmx merge] batch of")]
+            assert ran and any(l.endswith("k_merge_cols") for l in ran), ran      # (the first, one-partition batch may be too small for it)
+    assert outs["plain"]["resident_samples"] == NS and outs["files"]["resident_samples"] == 0
+    assert 0 < outs["tight"]["resident_samples"] < NS, outs["tight"]
+    for sub in ("matrices", "merge_infos", "partition_infos"):
+        names = sorted(os.listdir(tmp_path / "plain" / sub))
+        assert names
+        for other in ("tight", "files"):
+            assert names == sorted(os.listdir(tmp_path / other / sub)), (other, sub)
+            for n in names:
+                assert open(tmp_path / "plain" / sub / n, "rb").read() == open(tmp_path / other / sub / n, "rb").read(), (other, sub, n)
+    reads = [[bytes(r) for r in np.fromfile(p, np.uint8).reshape(-1, 154)[:, 3:153]] for p in paths]
+    lut = orc.minimizer_lut(10); rep = orc.repart_static(10, PP)
+    lists = []
+    for rs in reads:
+        sk = orc.superk_partition(rs, 31, 10, lut, rep, PP)
+        k_, c_ = orc.count_kmer(sk[0][0], 31, 2)
+        lists.append((k_.reshape(-1), c_))
+    body, rows, _ = orc.merge_matrix(lists, 1, [1] * NS, 2, 0, orc.MODE_COUNT)
+    assert rows > 5000 and open(tmp_path / "plain" / "matrices" / "matrix_0.count", "rb").read()[45:] == body
+
+
 def test_combine_two_runs_equals_one_run(inputs, tmp_path):
     """`kmx combine` over two `kmx pipeline` runs that share a repartition (one sample each) == the matrix of one run over both
     samples (recurrence-min 1) -- with --reference-compat up to MatrixMerger's dropped last key (matrix.hpp:534-583); also with
