@@ -405,8 +405,19 @@ int run(int argc, char** argv)
     }
     ~Ring() { for (auto p : free_) kmx_free_pinned(p); }
   } ring;
-  if (const char* e = getenv("KMX_OUT_RING_MB")) ring.cap = std::max<size_t>(2, (size_t)atol(e) / 32);
-  if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(32768, (size_t)atol(e) << 10); ring.cap = std::max<size_t>(ring.cap, 4); }      // (small pieces: for the tests)
+  // (round 4) pieces of 32 MB, 2 GB in all -- or, for 16 GB of input files and more, of 128 MB, 4 GB in all:
+  // 1000 x 5 Mbp (92 GB of matrices) leaves in 2.1-2.8 s through 128 MB pieces against 3.7-4.1 s through 32 MB ones (a device-to-host
+  // copy by itself costs the same per byte at either size: what a piece costs beside its bytes is its hand-over to the writers and
+  // their pwrite), 1000 x 1 Mbp the same either way.
+  size_t ring_total_mb = 0; bool ring_piece_set = false;
+  if (const char* e = getenv("KMX_OUT_RING_MB")) ring_total_mb = (size_t)std::max(64L, atol(e));
+  if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(32768, (size_t)atol(e) << 10); ring_piece_set = true; }      // (small pieces: for the tests)
+  auto size_ring = [&](uint64_t list_bytes) {
+    if (!ring_piece_set && list_bytes >= (2ull << 30)) ring.bytes = (size_t)128 << 20;
+    const size_t total = ring_total_mb ? ring_total_mb << 20 : (ring.bytes > ((size_t)32 << 20) ? (size_t)4096 << 20 : (size_t)2048 << 20);
+    ring.cap = std::max<size_t>(4, total / ring.bytes);
+  };
+  size_ring(0);
   std::atomic<bool> ring_stop{false};
   std::thread ring_filler;
   {
@@ -415,6 +426,7 @@ int run(int argc, char** argv)
     // (as many pieces as the matrices can fill: input bytes bound them loosely; small runs do not pin 2 GB for nothing)
     // KMX_RING_PREFILL: a thread pins the pieces while the samples are counted.  Measured on 1000 x 1 Mbp: the merge stage gains
     // 0.1 s, the count stage loses 0.3 s (page pinning and the workers' HIP calls share the runtime's locks) -- off by default.
+    size_ring(in_bytes >= (16ull << 30) ? (2ull << 30) : 0);      // (16 GB of input and more: the large pieces)
     if (streams) { ring.cap = std::max<size_t>(4, std::min<size_t>(ring.cap, (size_t)(in_bytes * 4 / ring.bytes) + 4)); if (getenv("KMX_RING_PREFILL")) ring_filler = std::thread([&]() { ring.prefill(ring_stop); }); }
   }
   struct RingJoin { std::atomic<bool>& stop; std::thread& t; ~RingJoin() { stop = true; if (t.joinable()) t.join(); } } ring_join{ring_stop, ring_filler};
