@@ -302,6 +302,7 @@ struct TaskHost {
   // rows at their final place out of the column-blocked pair (kmx_set_file_order): the row keys' rows wait in d_dense for
   // k_cols_sparse, which writes every slice group's rows in key order at the group's place -- d_out IS the body
   u8* d_dense = nullptr; u32 dpitch = 0, dense_cap = 0; size_t o_gbase = 0;
+  u8* d_narrow = nullptr; u32 npitch = 0;
   u64 row_keys = 0;             // row keys of the task as k_cols_prep counted them (ctrl[7])
   bool ordered = false;         // the task's rows lie in file order in d_out
   std::vector<u32> src;         // (row-key merge of a task: which of the task's lists it merges)
@@ -771,7 +772,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->h_meta = (u8*)ctx->halloc(upload_bytes);
   if (!R->d_meta || !R->h_meta) { ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); return ctx->fail(KMX_E_NOMEM, "meta allocation failed"); }
   auto drop_blocks = [&]() {
-    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); ctx->dfree(G.d_rowrec); ctx->dfree(G.d_dense); }
+    for (auto& G : R->tasks) { ctx->dfree(G.d_out); ctx->dfree(G.d_ov); ctx->dfree(G.d_img); ctx->dfree(G.d_rowrec); ctx->dfree(G.d_dense); ctx->dfree(G.d_narrow); }
     for (auto& G : R->subs) ctx->dfree(G.d_out);
     ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); ctx->dfree(R->d_rem); R->d_rem = nullptr;
   };
@@ -794,6 +795,14 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         H.dense_cap = (u32)std::min<u64>(std::min<u64>(cap, H.out_cap_rows), 0xFFFFFF00ULL);
         H.dpitch = (u32)align_up(H.row_bytes - 8 * kw, 8);
         H.d_dense = (u8*)ctx->dalloc((size_t)H.dense_cap * H.dpitch);
+        // count rows of up to 1022 lists in at most 8 column blocks: a byte per count where a block's counts of a row all fit one
+        // (+ 8 flag bytes): what k_merge_cols writes and k_cols_sparse reads back is then a quarter of the row (KMX_DENSE_NARROW=0:
+        // the 4-byte rows only)
+        static const bool narrow_off = getenv("KMX_DENSE_NARROW") && getenv("KMX_DENSE_NARROW")[0] == '0';
+        if (mode == KMX_MODE_COUNT && !narrow_off && (H.row_bytes & 7u) == 0 && H.row_bytes / 8 <= 512 && H.nblk <= 8) {
+          H.npitch = (u32)align_up((size_t)H.N, 8) + 8;
+          H.d_narrow = (u8*)ctx->dalloc((size_t)H.dense_cap * H.npitch);      // (none: the wide rows alone)
+        }
       }
     }
     if (!H.d_out || (cols && !H.d_ov) || (R->cols_ord && !H.d_dense)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
@@ -874,6 +883,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       if (R->cols_ord) {      // (the sparse rows' directory is not written then: its room holds the look-back chain and the group map)
         const size_t ng = CO.groups(H.slots_cap);
         C.dense = H.d_dense; C.dpitch = H.dpitch; C.dense_cap = H.dense_cap;
+        C.dnarrow = H.d_narrow; C.npitch = H.npitch;
         C.gbase = reinterpret_cast<u32*>(R->d_meta + H.o_gbase);
         C.chain = reinterpret_cast<u64*>(H.d_ov + H.o_spdir + 256);
         C.gmap = reinterpret_cast<uint4*>(H.d_ov + H.o_spdir + 256 + ng * 8);
@@ -1372,7 +1382,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
 #endif
   for (auto& H : R->tasks) {
     if (H.ev_body) { (void)hipEventSynchronize(H.ev_body); (void)hipEventDestroy(H.ev_body); }
-    ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); ctx->dfree(H.d_body); ctx->dfree(H.d_body_tmp); ctx->dfree(H.d_dense);
+    ctx->dfree(H.d_out); ctx->dfree(H.d_segs_own); ctx->dfree(H.d_ov); ctx->dfree(H.d_img); ctx->dfree(H.d_rowrec); ctx->dfree(H.d_body); ctx->dfree(H.d_body_tmp); ctx->dfree(H.d_dense); ctx->dfree(H.d_narrow);
   }
   for (auto& Q : R->subs) ctx->dfree(Q.d_out);
   ctx->dfree(R->d_meta);

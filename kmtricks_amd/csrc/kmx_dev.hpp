@@ -67,6 +67,8 @@ struct ColsDev {
   u8* dense;               // null: rows where the kernels leave them (row keys' rows first, the others behind, + directory)
   u32 dpitch;              // bytes between two rows of `dense` (payload rounded up to 8)
   u32 dense_cap;           // rows `dense` holds
+  u8* dnarrow;             // count rows (null: not used): the same rows with a BYTE per count, padded to 8, + a flag byte per column block (1: this block's counts of the row are in `dense`)
+  u32 npitch;              // ... bytes between two of them
   u32* gbase;              // [c + 1] slice groups of the task in front of range j (k_cols_prep)
   u64* chain;              // [groups] status << 62 | rows: 1 = the group's own rows, 2 = all rows up to and including it
   uint4* gmap;             // [groups] (range, group in the range, the range's first and last row key) of the task's g-th slice group

@@ -463,6 +463,11 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const bool ord = cl_uni(C.dense != nullptr ? 1u : 0u) != 0;
     u8* const obase = ord ? C.dense : T.out + KW * 8;
     const u32 opitch = ord ? cl_uni(C.dpitch) : row_bytes;
+    // ... count rows there as ONE BYTE per count where a block's slice of the row holds none above 254 (the usual case by far): the
+    // side store is written here and read again by k_cols_sparse -- a quarter of the bytes both ways.  C.dnarrow row r = [N count
+    // bytes, padded to 8][a flag byte per column block: 1 = this block's counts of the row are in the 4-byte row]
+    u8* const nar = (MODE == 0 && ord) ? C.dnarrow : nullptr;
+    const u32 npitch = nar ? cl_uni(C.npitch) : 0u;
 
     // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + CL_G * u
     // (mod CL_W) inside [cur, cur + CL_W)
@@ -685,7 +690,26 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
             u32* const src = img + j * nbs;
             u8* const dst = out0 + (u64)j * opitch;
-            if (wide) {
+            if (wide && nar) {
+              const u32 n2 = nbl >> 1;      // (<= 256 pairs: CL_NB <= 256 lists per block, four per lane)
+              u64 w[4]; u32 tail = 0;
+              bool big = false;
+#pragma unroll
+              for (int x = 0; x < 4; x++) { const u32 t = 64 * x + lane; w[x] = 0; if (t < n2) { w[x] = reinterpret_cast<u64*>(src)[t]; reinterpret_cast<u64*>(src)[t] = 0; } big |= (u32)w[x] > 254u || (u32)(w[x] >> 32) > 254u; }
+              if ((nbl & 1u) && lane == 0) { tail = src[nbl - 1]; src[nbl - 1] = 0; big |= tail > 254u; }
+              const bool anyb = __ballot(big) != 0;
+              u8* const nrow = nar + (u64)(s0 + j) * npitch;
+              if (!anyb) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) { const u32 t = 64 * x + lane; if (t < n2) *reinterpret_cast<u16*>(nrow + col0 + 2 * t) = (u16)((u32)w[x] | ((u32)(w[x] >> 32) << 8)); }
+                if ((nbl & 1u) && lane == 0) nrow[col0 + nbl - 1] = (u8)tail;
+              } else {
+#pragma unroll
+                for (int x = 0; x < 4; x++) { const u32 t = 64 * x + lane; if (t < n2) reinterpret_cast<u64*>(dst)[t] = w[x]; }
+                if ((nbl & 1u) && lane == 0) reinterpret_cast<u32*>(dst)[nbl - 1] = tail;
+              }
+              if (lane == 0) nrow[((N + 7u) & ~7u) + blk] = anyb ? 1 : 0;
+            } else if (wide) {
               const u32 n2 = nbl >> 1;
               for (u32 t0 = 0; t0 < n2; t0 += 256) {
                 u64 w[4];
@@ -1426,6 +1450,58 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           constexpr int RF = 4;
           const u32 n8 = row_bytes / 8;
           const u32 rounds = max(1u, (dnp + (CK_TPB / 64) * RF - 1) / ((CK_TPB / 64) * RF));
+          if (C.dnarrow) {
+            // the NARROW side store: a byte per count (+ a flag byte per column block: 1 = that block's counts of the row hold one above
+            // 254 and lie in the 4-byte row).  A lane takes two groups of eight lists: an 8-byte load each, four 8-byte stores each; the
+            // row's eight flag bytes in one (uniform) load.
+            const u8* const nar = C.dnarrow; const u32 npitch = C.npitch, nbs = C.nb, NL = T.N, FO = (NL + 7u) & ~7u;
+            const u32 ng = (NL + 7u) / 8u;      // (<= 128: row_bytes / 8 <= 512)
+            u32 fsh0[2], fsh1[2];                // 8 x the column block of my groups' first and last list
+#pragma unroll
+            for (int y = 0; y < 2; y++) { const u32 l = min(8u * (64u * y + lane), NL - 1u); fsh0[y] = 8u * (l / nbs); fsh1[y] = 8u * (min(l + 7u, NL - 1u) / nbs); }
+            for (u32 c = 0; c < rounds; c++) {
+              const u32 i0 = c * (CK_TPB / 64) * RF + wave * RF;
+              u64 nv[RF][2], fl[RF];
+#pragma unroll
+              for (int r = 0; r < RF; r++) {
+                const u32 i = i0 + r;
+                const u8* const nrow = nar + (u64)(d0 + dlo + (i < dnp ? i : 0)) * npitch;
+                fl[r] = i < dnp ? *reinterpret_cast<const u64*>(nrow + FO) : 0ULL;
+#pragma unroll
+                for (int y = 0; y < 2; y++) { const u32 g = 64u * y + lane; nv[r][y] = (i < dnp && g < ng) ? *reinterpret_cast<const u64*>(nrow + 8u * g) : 0ULL; }
+              }
+              sparse_rows((u32)(((u64)nk * c) / rounds), (u32)(((u64)nk * (c + 1)) / rounds));
+#pragma unroll
+              for (int r = 0; r < RF; r++) {
+                const u32 i = i0 + r;
+                if (i >= dnp) continue;
+                u8* const row = T.out + (rb + dpos[i]) * row_bytes;
+                if (lane == 0) {
+                  u32 kw4[4] = {0, 0, 0, 0};
+                  ck_store(kw4, dkeys[dlo + i]);
+#pragma unroll
+                  for (u32 d = 0; d < 2u * KW; d++) reinterpret_cast<u32*>(row)[d] = kw4[d];
+                }
+                u64* const out64 = reinterpret_cast<u64*>(row + 8u * KW);
+#pragma unroll
+                for (int y = 0; y < 2; y++) {
+                  const u32 g = 64u * y + lane;
+                  if (g >= ng) continue;
+                  const u64 v = nv[r][y];
+                  const u32 f = (u32)((fl[r] >> fsh0[y]) | (fl[r] >> fsh1[y])) & 0xFFu;
+                  if (!f && 8u * g + 8u <= NL) {
+                    out64[4 * g + 0] = (v & 0xFFULL) | (((v >> 8) & 0xFFULL) << 32);
+                    out64[4 * g + 1] = ((v >> 16) & 0xFFULL) | (((v >> 24) & 0xFFULL) << 32);
+                    out64[4 * g + 2] = ((v >> 32) & 0xFFULL) | (((v >> 40) & 0xFFULL) << 32);
+                    out64[4 * g + 3] = ((v >> 48) & 0xFFULL) | ((v >> 56) << 32);
+                  } else {      // the row's last lists, or a block whose counts of this row are in the 4-byte row
+                    const u32* const wsrc = dense_src(i); u32* const cnt = reinterpret_cast<u32*>(out64);
+                    for (u32 l = 8u * g; l < min(NL, 8u * g + 8u); l++) cnt[l] = ((fl[r] >> (8u * (l / nbs))) & 0xFFULL) ? wsrc[l] : (u32)((v >> (8u * (l - 8u * g))) & 0xFFULL);
+                  }
+                }
+              }
+            }
+          } else
           for (u32 c = 0; c < rounds; c++) {
             const u32 i0 = c * (CK_TPB / 64) * RF + wave * RF;
             u64 w[RF][8];

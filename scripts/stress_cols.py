@@ -28,7 +28,7 @@ for case in range(n_cases):
     mode = rng.choice([lib.MODE_COUNT, lib.MODE_COUNT, lib.MODE_PA])
     os.environ["KMX_ITEMS_PER_SLOT"] = rng.choice(["1", "3"])
     lists = synth_lists(rng.randrange(1 << 30), N, pool, p, priv, kw=KW, key_bits=62 if KW == 1 else rng.choice([66, 72, 126]),
-                        count_max=rng.choice([2, 5, 50]), ragged=rng.random() < 0.2)
+                        count_max=rng.choice([2, 5, 50, 300, 70000]), ragged=rng.random() < 0.2)
     if KW == 1 and rng.random() < 0.3:      # a list with a long run of keys nobody else has
         i = rng.randrange(N); k, c = lists[i]
         if len(k):

@@ -814,3 +814,36 @@ def test_arena_and_row_order(n, kw, mode):
         res.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n,kw", [(200, 1), (300, 1), (1022, 1), (262, 2), (301, 1)])
+@pytest.mark.parametrize("heavy", [0.002, 0.3])
+def test_file_order_count_rows_across_the_one_byte_boundary(n, kw, heavy, monkeypatch):
+    """Count rows in file order leave k_merge_cols through a side store that holds a byte per count where a column block's slice of
+    a row has none above 254, and the 4-byte counts otherwise (a flag byte per block says which): counts of 254, 255, 256 and
+    2^32-1 sprinkled over the lists (a few per row: most blocks narrow; and a third of all: most blocks wide), list counts
+    whose last group of eight lists is ragged, one (301) whose rows are not a multiple of 8 bytes (the 4-byte rows alone)."""
+    from kmtricks_amd import lib
+    torch = pytest.importorskip("torch")
+    if os.environ.get("KMX_MERGE_KERNEL") != "cols":
+        pytest.skip("the side store is k_merge_cols' own")
+    lists = synth_lists(9100 + n, n, 3000, 0.9, 40, kw=kw, key_bits=62 if kw == 1 else 100, count_max=254)
+    rng = np.random.default_rng(n)
+    edge = np.array([254, 255, 256, 65535, 65536, 0xFFFFFFFF], dtype=np.uint32)
+    for _, c in lists:
+        m = rng.random(len(c)) < heavy
+        c[m] = edge[rng.integers(0, len(edge), int(m.sum()))]
+    soft = [1 + (i % 2) for i in range(n)]
+    eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], kw, soft, 2, 0, orc.MODE_COUNT)
+    ctx = lib.Context(0)
+    try:
+        recs = [torch.from_numpy(lib.pack_records(k, c, kw).view(np.int32)).cuda() for k, c in lists]
+        for order in (True, False):
+            ctx.set_file_order(order)
+            res = ctx.merge_dev([dict(lists=[(r.data_ptr(), r.shape[0]) for r in recs], key_words=kw, soft_min=soft, rec_min=2, share_min=0, mode=orc.MODE_COUNT)])
+            res.wait()
+            assert res.kernel() == "k_merge_cols"
+            assert res.rows() == er and res.body() == eb and np.array_equal(res.stats(0), es)
+            res.free()
+    finally:
+        ctx.close()
