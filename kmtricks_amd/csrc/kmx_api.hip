@@ -3,6 +3,7 @@
 #include "kmx_host.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <sys/mman.h>
 #include <unordered_map>
@@ -25,6 +26,8 @@ void* kmx_ctx::dalloc(size_t bytes)
         (best < 0 || pool[i].bytes < pool[best].bytes)) best = (int)i;
   if (best >= 0) { pool[best].used = true; return pool[best].p; }
   void* p = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  struct Tr { size_t b; std::chrono::steady_clock::time_point t; ~Tr() { static const bool on = getenv("KMX_TRACE") != nullptr; if (on) fprintf(stderr, "[kmx alloc] device pool +%zu MB: %.2f ms\n", b >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); } } tr{bytes, t0};
   if (hipMalloc(&p, bytes) != hipSuccess) {
     // drop cached blocks and retry once
     for (auto& b : pool) if (!b.used && b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
@@ -146,8 +149,14 @@ void* kmx_pinned_alloc(size_t bytes)
     void* q = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (q != MAP_FAILED) {
       (void)madvise(q, n, MADV_HUGEPAGE);
+      static const bool trace = getenv("KMX_TRACE") != nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
       for (size_t o = 0; o < n; o += 4096) static_cast<volatile char*>(q)[o] = 0;      // fault the pages in here, not under the runtime's lock
-      if (hipHostRegister(q, n, hipHostRegisterPortable) == hipSuccess) {      // (portable: a process that drives several GPUs copies to and from it on all of them, as with hipHostMalloc)
+      const auto t1 = std::chrono::steady_clock::now();
+      const hipError_t re = hipHostRegister(q, n, hipHostRegisterPortable);
+      if (trace) fprintf(stderr, "[kmx alloc] pinned %zu MB: touch %.2f ms, register %.2f ms\n", n >> 20, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+      if (re == hipSuccess) {      // (portable: a process that drives several GPUs copies to and from it on all of them, as with hipHostMalloc)
         std::lock_guard<std::mutex> lk(g_pin_mutex);
         g_pin_mapped[q] = n;
         return q;
@@ -182,8 +191,10 @@ void* kmx_store::alloc(size_t bytes)
   if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
   size_t cap = std::max(bytes, chunk_bytes);
   void* p = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&p, cap);
   if (e != hipSuccess && cap > bytes) { cap = bytes; e = hipMalloc(&p, cap); }      // (the device is nearly full: an exact block)
+  { static const bool trace = getenv("KMX_TRACE") != nullptr; if (trace) fprintf(stderr, "[kmx alloc] store chunk %zu MB: %.2f ms\n", cap >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
   if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
   if (e != hipSuccess) return nullptr;
   chunks.push_back({(u8*)p, cap, bytes});

@@ -87,6 +87,12 @@ struct SkStats {          // device tables, zeroed by the caller; any of them ma
   u32* ms;                // [4^m] super-k-mers per minimizer
   u32* mk;                // [4^m] k-mers per minimizer
   u32* mx;                // [4^m] kx-mers per minimizer
+  // DEFER (k_superk_wave<.., DEFER>): no counter is touched while the reads are walked -- a descriptor takes its minimizer and the
+  // strands of its k-mers along, and k_part_stats counts partition by partition once the descriptors are sorted
+  // [n] per descriptor, ONE 16-byte record (k_part_stats gathers them through the sorted ids: one sector each):
+  //   .x = strands (bit t: k-mer t of the super-k-mer is its own canonical form, t < 60) | (k-mers & 15) << 60
+  //   .y = first base | minimizer << 32 (m <= 15: 30 bits) | (k-mers >> 4) << 62
+  ulonglong2* sk_rec;
 };
 
 // LB (one pass instead of count + scan + emit): a wave keeps its read's descriptors in LDS, the workgroup's four reads get their
@@ -99,7 +105,7 @@ struct SkLook { unsigned long long* state; u32* ticket; u32* over; u32 cap; };
 // s * parts + repart[minimizer], its per-minimizer tables start at s * nm.  first == nullptr: one sample
 struct SkMulti { const u32* first; u32 n; u32 parts; u32 nm; };      // state[workgroup]: flag << 62 | count or prefix; cap: descriptors that fit
 constexpr u32 SK_WCAP = 512;      // descriptors of one read the LDS takes (the host sends longer reads the two-pass way)
-template <bool EMIT, bool STATS, bool LB = false>
+template <bool EMIT, bool STATS, bool LB = false, bool DEFER = false>
 __global__ __launch_bounds__(256)
 void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
                    int k, int m, int maxs, const u16* __restrict__ repart,
@@ -109,6 +115,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
   __shared__ u32 wcnt[4];
   __shared__ u32 bid_s, base_s;
   static_assert(!LB || EMIT, "the look-back places descriptors");
+  static_assert(!DEFER || (EMIT && STATS && !LB), "deferred statistics travel with the descriptors of the two-pass path");
   const int lane = threadIdx.x & 63;
   const u32 wave = threadIdx.x >> 6;
   u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -139,6 +146,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
     u32 out = (EMIT && !LB) ? desc_off[r] : 0;
     bool pv = false; u32 pmin = 0; u64 run_start = 0, open_start = 0;   // state of the last owned k-mer of the previous chunk
     int pw = 0; u64 t_start = 0, x_start = 0; u32 rf_open = 0;          // (STATS) its strand, strand-run start, kx-mer start + that k-mer's radix
+    u64 hist = 0;                                                       // (DEFER) the strands of the 64 positions before p0: bit 63 is p0 - 1
     for (u64 p0 = 0; p0 < nk; p0 += own) {
       const u64 q = p0 + lane;
       const u8 c0 = q < len ? (u8)seq[q] : (u8)'N';
@@ -199,9 +207,9 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
         const u64 sb = Sall & lowmask;
         ps = sb ? p0 + (63 - __clzll(sb)) : open_start;
       }
+      const u32 di = out + __popcll(Em & ((1ULL << lane) - 1));
       if (EMIT && endf) {
         SkDesc d; d.base = (u32)(b0 + ps); d.part = (u16)(pbase + repart[mini]); d.n = (u8)(pk - ps + 1); d.pad = 0;
-        const u32 di = out + __popcll(Em & ((1ULL << lane) - 1));
         if (LB) { if (di < SK_WCAP) wbuf[wave][di] = d; }
         else {
           desc[di] = d;
@@ -219,6 +227,17 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
           const u32 xb = (u32)(fb_k >> i0) & 1u, yb = (u32)(nrb >> i0) & 1u, xa = (u32)(fa_k >> i0) & 1u, ya = (u32)(ra >> i0) & 1u;
           w = xb != yb ? xb < yb : xa < ya;          // forward is the smaller one (KmerCanonical::which, Model.hpp:294; a palindrome counts as reverse)
         }
+        if (DEFER) {
+          const u64 Wb = __ballot(w != 0);
+          if (endf) {      // the strands of my super-k-mer's k-mers, the first one in bit 0 (at most 60 of them: they reach into the previous chunk(s) at most)
+            const u32 n = (u32)(pk - ps + 1);
+            u64 bits;
+            if (ps >= p0) bits = Wb >> (u32)(ps - p0);
+            else { const u32 dd = (u32)(p0 - ps); bits = (hist >> (64u - dd)) | (Wb << dd); }
+            S.sk_rec[di] = make_ulonglong2((bits & ((1ULL << n) - 1ULL)) | ((u64)(n & 15u) << 60), (u64)(u32)(b0 + ps) | ((u64)mini << 32) | ((u64)(n >> 4) << 62));
+          }
+          hist = (hist >> own) | (Wb << (64u - own));      // (own = 33 .. 63)
+        } else {
         int w_l = __shfl_up(w, 1); if (lane == 0) w_l = pw;
         const bool T = valid && (start || w != w_l);                       // first k-mer of a run of one strand
         const u64 Tm = __ballot(T) & lowmask;
@@ -246,6 +265,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
           if (S.ms) atomicAdd(&S.ms[sbase + mini], 1u);
           if (S.mk) atomicAdd(&S.mk[sbase + mini], (u32)(pk - ps + 1));
         }
+        }
       }
       const u32 ne = (u32)__popcll(Em);
       nsk += ne; out += ne;
@@ -259,7 +279,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
         const u64 sb = Sall & ((2ULL << lo) - 1);
         if (sb) open_start = p0 + (63 - __clzll(sb));
       }
-      if (STATS) {
+      if (STATS && !DEFER) {
         pw = __builtin_amdgcn_readlane(w, lo);
         t_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)ts, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ts >> 32), lo) << 32);
         x_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)xs, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(xs >> 32), lo) << 32);
@@ -401,6 +421,81 @@ __global__ void k_superk_pack(const char* __restrict__ bases, const SkDesc* __re
   }
 }
 
+// ---- the PartiInfo<5> statistics of a sample from its SORTED descriptors (DEFER): a workgroup per partition ------------------------
+// fill_partitions.hpp:67-102 counts, per super-k-mer, its minimizer's super-k-mers and k-mers and, per kx-mer (a run of at most 5
+// k-mers of one strand), the (partition, run length, radix) counter.  Walking the reads (k_superk_wave<.., STATS>) that is three
+// device-scope atomics per super-k-mer into 9 MB of tables that must be cleared and compacted again: a third of the count stage.
+// Here a partition's descriptors are one run (the sort by partition that the stage makes anyway); its 5 x 256 counters and the
+// minimizers that map to it (a few thousand of 4^m: an open-addressing table) live in LDS, the counters leave as plain stores (no
+// clear beforehand), the minimizers as the {minimizer, super-k-mers, k-mers} triples kmx_superk_raw::minim_sparse wants.  A
+// minimizer that finds no slot within PS_PROBE steps goes the old way (dense tables + k_minim_sparse, which n_out[1] switches on).
+constexpr int PS_TPB = 1024;
+constexpr u32 PS_H = 4096, PS_PROBE = 48, PS_EMPTY = 0xFFFFFFFFu;
+__global__ __launch_bounds__(PS_TPB)
+void k_part_stats(const u32* __restrict__ ids, const u32* __restrict__ part_first, u32 part0, const ulonglong2* __restrict__ sk_rec, const char* __restrict__ bases, int k,
+                  u32* __restrict__ pc, u32* __restrict__ ms_dense, u32* __restrict__ mk_dense, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out)
+{
+  __shared__ u32 tab[5 * 256];
+  __shared__ u32 hkey[PS_H], hms[PS_H], hmk[PS_H];
+  __shared__ u32 wtot[PS_TPB / 64], out_base;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 p = part0 + blockIdx.x;
+  for (u32 j = tid; j < 5 * 256; j += PS_TPB) tab[j] = 0;
+  for (u32 j = tid; j < PS_H; j += PS_TPB) { hkey[j] = PS_EMPTY; hms[j] = 0; hmk[j] = 0; }
+  __syncthreads();
+  const u32 i1 = part_first[p + 1];
+  for (u32 i = part_first[p] + tid; i < i1; i += PS_TPB) {
+    const ulonglong2 rec = sk_rec[ids[i]];
+    const u32 mini = (u32)(rec.y >> 32) & 0x3FFFFFFFu, n = (u32)(rec.x >> 60) | ((u32)(rec.y >> 62) << 4);
+    const u64 bits = rec.x & ((1ULL << 60) - 1ULL);
+    {
+      u32 h = (mini * 2654435761u) >> 20;      // (PS_H = 2^12)
+      bool done = false;
+      for (u32 t = 0; t < PS_PROBE; t++) {
+        const u32 prev = atomicCAS(&hkey[h], PS_EMPTY, mini);
+        if (prev == PS_EMPTY || prev == mini) { atomicAdd(&hms[h], 1u); atomicAdd(&hmk[h], n); done = true; break; }
+        h = (h + 1u) & (PS_H - 1u);
+      }
+      if (!done) { atomicAdd(&ms_dense[mini], 1u); atomicAdd(&mk_dense[mini], n); n_out[1] = 1u; }
+    }
+    const char* const seq = bases + (u32)rec.y;
+    for (u32 t = 0; t < n;) {
+      const u32 w = (u32)(bits >> t) & 1u;
+      const u64 same = (w ? bits : ~bits) >> t;                       // ones: the k-mers from t on that share its strand
+      const u32 run = min((u32)(~same ? __builtin_ctzll(~same) : 64), n - t);
+      for (u32 s0 = 0; s0 < run; s0 += 5) {
+        const u32 len = min(5u, run - s0), first = t + s0, last = first + len - 1u;
+        u32 radix;
+        if (w) { const u32 c = (load4(seq + first) >> 1) & 0x03030303u; radix = ((c & 3u) << 6) | (((c >> 8) & 3u) << 4) | (((c >> 16) & 3u) << 2) | (c >> 24); }
+        else { const u32 c = ((load4(seq + last + (u32)k - 4u) >> 1) & 0x03030303u) ^ 0x02020202u; radix = ((c >> 24) << 6) | (((c >> 16) & 3u) << 4) | (((c >> 8) & 3u) << 2) | (c & 3u); }
+        atomicAdd(&tab[(len - 1u) * 256u + radix], 1u);
+      }
+      t += run;
+    }
+  }
+  __syncthreads();
+  for (u32 j = tid; j < 5 * 256; j += PS_TPB) pc[(u64)p * 1280u + j] = tab[j];
+  // the minimizers that occur: slots tid * 8 .. tid * 8 + 7, their places by a scan over the workgroup, ONE global atomic
+  u32 c = 0;
+#pragma unroll
+  for (u32 q = 0; q < PS_H / PS_TPB; q++) c += hkey[tid * (PS_H / PS_TPB) + q] != PS_EMPTY ? 1u : 0u;
+  const u32 incl = wave_incl_scan(c, (int)lane);
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  if (tid == 0) { u32 t = 0; for (u32 q = 0; q < PS_TPB / 64; q++) t += wtot[q]; out_base = t ? atomicAdd(n_out, t) : 0u; }
+  __syncthreads();
+  u32 pos = out_base + incl - c;
+  for (u32 q = 0; q < wave; q++) pos += wtot[q];
+#pragma unroll
+  for (u32 q = 0; q < PS_H / PS_TPB; q++) {
+    const u32 j = tid * (PS_H / PS_TPB) + q;
+    if (hkey[j] != PS_EMPTY) {
+      if (pos < cap) { out[3 * (u64)pos] = hkey[j]; out[3 * (u64)pos + 1] = hms[j]; out[3 * (u64)pos + 2] = hmk[j]; }
+      pos++;
+    }
+  }
+}
+
 }  // namespace kmx
 
 using namespace kmx;
@@ -408,8 +503,9 @@ using namespace kmx;
 // the minimizers that occur: {minimizer, super-k-mers, k-mers} triples, in no particular order (kmx_superk_raw::minim_sparse)
 // (16 table entries per thread: a wave takes 1024 of them and claims its output with ONE atomic -- with an entry per thread the 16 000
 //  waves of a 4^10 table queued up on that one word: 40 us for 4 MB)
-__global__ void k_minim_sparse(u32* __restrict__ ms, u32* __restrict__ mk, u64 nm, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out, int clean)
+__global__ void k_minim_sparse(u32* __restrict__ ms, u32* __restrict__ mk, u64 nm, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out, int clean, int only_if_flag)
 {
+  if (only_if_flag && n_out[1] == 0) return;      // (behind k_part_stats: the tables were touched only when a partition's minimizers did not fit its LDS)
   const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16u;      // (4^m is a multiple of 16: m >= 4)
   const u32 lane = threadIdx.x & 63u;
   u32 v[16]; u32 c = 0;
@@ -439,7 +535,8 @@ __global__ void k_minim_sparse(u32* __restrict__ ms, u32* __restrict__ mk, u64 n
 // stats tables of one call (u32 on the device): added to the caller's u64 arrays (kmx_superk_stats), or copied as they are into
 // the caller's u32 buffers (kmx_superk_raw: no host arithmetic, one synchronisation)
 struct StatsDev {
-  SkStats S{nullptr, nullptr, nullptr, nullptr};
+  SkStats S{nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool want_defer = false, deferred = false;      // DEFER: asked for by the caller (the two-pass path) / granted (kmx_superk_raw in sparse form: the context's tables)
   kmx_superk_stats* dst = nullptr; kmx_superk_raw* raw = nullptr;      // raw: one per sample of the call ([ns])
   u32 nb_parts = 0; u64 nm = 0;             // partitions of the call (samples x partitions), per-minimizer entries of the call (samples x 4^m)
   u32 ns = 1; u64 nm1 = 0; u32 parts1 = 0;  // samples of the call, 4^m, partitions per sample
@@ -467,7 +564,10 @@ struct StatsDev {
       if (ctx->stat_parts != P || ctx->stat_nm != nm) ctx->stat_dirty = true;      // (another layout: the counters of the last call lie elsewhere)
       ctx->stat_parts = P; ctx->stat_nm = nm;
       blk = ctx->d_stat;
-      if (hipMemsetAsync(blk, 0, (ctx->stat_dirty ? ctx->stat_cap : n_pc) * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
+      deferred = want_defer && !w_mx;
+      // (deferred: k_part_stats writes every counter of every partition and leaves the per-minimizer tables as they are -- zero -- or cleans them)
+      const size_t n_clear = ctx->stat_dirty ? ctx->stat_cap : deferred ? 0 : n_pc;
+      if (n_clear && hipMemsetAsync(blk, 0, n_clear * 4, s) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk: statistics memset failed");
       ctx->stat_dirty = true;      // (until k_minim_sparse has run behind the kernel that fills the tables)
       pctx = ctx;
     } else {
@@ -501,7 +601,14 @@ struct StatsDev {
     if (!d_sp) return;
     for (u32 i = 0; i < ns; i++)
       hipLaunchKernelGGL(k_minim_sparse, dim3((unsigned)((nm1 / 16 + 255) / 256)), dim3(256), 0, s, S.ms + (size_t)i * nm1, S.mk + (size_t)i * nm1, nm1,
-                         d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i), persistent ? 1 : 0);
+                         d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i), persistent ? 1 : 0, deferred ? 1 : 0);
+  }
+  // DEFER: the statistics from the sorted descriptors, a launch per sample (d_n[sample]: low word the triples, high word "the dense tables were used")
+  void launch_part_stats(const u32* ids_sorted, const u32* part_first, const char* bases, u32 k, u64* d_n, hipStream_t s) const {
+    if (!deferred) return;
+    for (u32 i = 0; i < ns; i++)
+      hipLaunchKernelGGL(k_part_stats, dim3(parts1), dim3(PS_TPB), 0, s, ids_sorted, part_first, i * parts1, (const ulonglong2*)S.sk_rec, bases, (int)k,
+                         S.pc, S.ms + (size_t)i * nm1, S.mk + (size_t)i * nm1, d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i));
   }
   void compacted() const { if (persistent && pctx && d_sp) pctx->stat_dirty = false; }      // (the caller has waited for k_minim_sparse: the per-minimizer tables are zero again)
   // ... and once those numbers are on the host, the copies into the caller's (page-locked) buffers are queued: no synchronisation
@@ -631,7 +738,10 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if (repart) { if (rep_upload && (e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) { ctx->rep_host = nullptr; return fail(e, "upload repartition"); } }
   else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
+  // (KMX_SUPERK_ONE_PASS: see below; KMX_STATS_ATOMICS=1: the statistics by atomics while the reads are walked, as rounds 1-3 had them)
+  const bool two_pass = getenv("KMX_SUPERK_ONE_PASS") == nullptr || segs;      // (read per call: the tests switch it)
   StatsDev sd;
+  sd.want_defer = two_pass && want_streams && getenv("KMX_STATS_ATOMICS") == nullptr;
   { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st, n_smp); if (rc != KMX_OK) { release(); return rc; } }
   if (raw) for (u32 i = 0; i < n_smp; i++) { raw[i].nb_superk = 0; raw[i].minim_sparse_n = 0; }
   const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
@@ -684,7 +794,6 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   {
     // (measured: 2.74 against 2.53 ms per call on the 24 M k-mer sample, 0.83 against 0.76 on the 1 Mbp one -- the look-back's
     //  barriers, LDS staging and spinning cost more than the second walk over bases that are still in L2: off unless asked for)
-    const bool two_pass = getenv("KMX_SUPERK_ONE_PASS") == nullptr || segs;      // (read per call: the tests switch it)
     u64 maxlen = 0, nk_total = 0;
     for (u64 r = 0; r < n_seqs && !two_pass; r++) { const u64 l = offsets[r + 1] - offsets[r]; maxlen = std::max(maxlen, l); if (l >= k) nk_total += l - k + 1; }
     const u64 cap = std::min<u64>(nk_total, nk_total / 2 + n_seqs + 1024);
@@ -740,6 +849,13 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   }
   if (!emitted) {
     if (!alloc_desc((size_t)nd)) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+    if (sd.deferred) {
+      sd.S.sk_rec = (ulonglong2*)ctx->dalloc((size_t)nd * 16);
+      blocks.push_back(sd.S.sk_rec);
+      if (!sd.S.sk_rec) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+      hipLaunchKernelGGL((k_superk_wave<true, true, false, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                         (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{}, mu);
+    } else
     if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                                       (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{}, mu);
     else hipLaunchKernelGGL((k_superk_wave<true, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
@@ -767,6 +883,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   u64* d_pp = (u64*)d_sum, *d_info = d_pp + P1, *d_nsp = d_info + 2 * (size_t)nb_parts; u32* d_pf = (u32*)(d_nsp + n_smp);
   hipLaunchKernelGGL(k_superk_part_bounds, dim3((nb_parts + 256) / 256), dim3(256), 0, st, d_keys2, nd, nb_parts, d_boff, d_pp, d_pf, d_nsp, n_smp);
   if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((nb_parts + 63) / 64), dim3(64), 0, st, d_pf, d_boff, nb_parts, d_info);
+  sd.launch_part_stats(d_ids2, d_pf, d_bases, k, d_nsp, st);
   sd.launch_sparse(d_nsp, st);
   if ((e = hipMemcpyAsync(h_sum + 16, d_sum, sum_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
   const u64* pp = reinterpret_cast<const u64*>(h_sum + 16);

@@ -25,6 +25,10 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <filesystem>
 #include <iomanip>
 #include <iostream>
@@ -384,13 +388,43 @@ int run(int argc, char** argv)
   // what is pending is bounded in bytes, whatever the cohort.  Page-locking memory is slow (~10 ms per piece, 0.6 s for the ring:
   // the whole merge stage of the 1000 x 1 Mbp cohort, as the first runs of round 3 showed): a thread of its own fills the ring
   // while the samples are counted.
+  // Page-locked memory is asked for by readers, writers and workers alike -- and a thread's FIRST call into the HIP runtime costs it
+  // ~28 ms under the runtime's lock (its per-thread state), during which every other thread's launches and copies wait: 24 readers
+  // pinning their first read buffer were 24 x 28 ms of stalled count calls (0.45 s of the 2.6 s count stage of 1000 x 5 Mbp; the
+  // stage clocks of KMX_TRACE=1 showed them).  All page-locking therefore goes through ONE thread that has paid that once.
+  struct PinServer {
+    struct Req { size_t bytes; void* p = nullptr; bool done = false; };
+    std::mutex m; std::condition_variable cv_req, cv_done; std::deque<Req*> q; bool stop = false; std::thread th;
+    PinServer() { th = std::thread([this]() { run(); }); }
+    void run() {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv_req.wait(lk, [&]() { return stop || !q.empty(); });
+        if (q.empty()) return;
+        Req* r = q.front(); q.pop_front();
+        lk.unlock();
+        void* p = kmx_alloc_pinned(r->bytes);
+        lk.lock();
+        r->p = p; r->done = true; cv_done.notify_all();
+      }
+    }
+    void* alloc(size_t bytes) {
+      Req r{bytes};
+      std::unique_lock<std::mutex> lk(m);
+      q.push_back(&r); cv_req.notify_one();
+      cv_done.wait(lk, [&]() { return r.done; });
+      return r.p;
+    }
+    ~PinServer() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv_req.notify_one(); if (th.joinable()) th.join(); }
+  };
+  static PinServer pins;      // (static: alive until the process leaves, whatever the order the pools below are destroyed in)
   struct Ring {
     std::mutex m; std::condition_variable cv; std::vector<uint8_t*> free_; size_t made = 0, cap = 64, bytes = (size_t)32 << 20;
     uint8_t* get() {
       std::unique_lock<std::mutex> lk(m);
       for (;;) {
         if (!free_.empty()) { uint8_t* p = free_.back(); free_.pop_back(); return p; }
-        if (made < cap) { made++; lk.unlock(); uint8_t* p = (uint8_t*)kmx_alloc_pinned(bytes); if (!p) die("pinned host allocation failed"); return p; }
+        if (made < cap) { made++; lk.unlock(); uint8_t* p = (uint8_t*)pins.alloc(bytes); if (!p) die("pinned host allocation failed"); return p; }
         cv.wait(lk);
       }
     }
@@ -398,7 +432,7 @@ int run(int argc, char** argv)
     void prefill(const std::atomic<bool>& stop) {      // (pieces the writers will want, made ahead of them)
       for (;;) {
         { std::lock_guard<std::mutex> lk(m); if (made >= cap || stop.load()) return; made++; }
-        uint8_t* p = (uint8_t*)kmx_alloc_pinned(bytes);
+        uint8_t* p = (uint8_t*)pins.alloc(bytes);
         if (!p) { std::lock_guard<std::mutex> lk(m); made--; return; }
         put(p);
       }
@@ -449,7 +483,7 @@ int run(int argc, char** argv)
           for (size_t i = 0; i < free_.size(); i++) if (free_[i].cap >= want && (best < 0 || free_[i].cap < free_[best].cap)) best = (int)i;
           if (best >= 0) { PinStr r = free_[best]; free_.erase(free_.begin() + best); r.len = 0; return r; }
         }
-        PinStr r; r.cap = want + want / 8 + (1u << 16); r.p = (char*)kmx_alloc_pinned(r.cap);
+        PinStr r; r.cap = want + want / 8 + (1u << 16); r.p = (char*)pins.alloc(r.cap);
         if (!r.p) die("pinned host allocation failed");
         return r;
       }
@@ -474,7 +508,7 @@ int run(int argc, char** argv)
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
           if (!free_.empty()) { uint32_t* p = free_.back(); free_.pop_back(); return p; }
-          if (made < cap) { made++; lk.unlock(); uint32_t* p = (uint32_t*)kmx_alloc_pinned(words * 4); if (!p) die("pinned host allocation failed"); return p; }
+          if (made < cap) { made++; lk.unlock(); uint32_t* p = (uint32_t*)pins.alloc(words * 4); if (!p) die("pinned host allocation failed"); return p; }
           cv.wait(lk);
         }
       }
@@ -840,7 +874,7 @@ int run(int argc, char** argv)
     std::mutex tm; double s_io = 0, s_merge = 0, s_format = 0;
     struct PartIn { uint32_t p = 0; std::vector<kmx_list> lists; std::vector<uint8_t> on_dev; };
     struct Batch { std::vector<PartIn> parts; uint8_t* buf = nullptr; uint64_t bytes = 0; double io_s = 0; };
-    struct Pinned { uint8_t* p = nullptr; uint64_t cap = 0; void need(uint64_t n) { if (n <= cap) return; kmx_free_pinned(p); cap = n + n / 8 + (1u << 20); p = (uint8_t*)kmx_alloc_pinned(cap); if (!p) die("pinned host allocation failed"); } ~Pinned() { kmx_free_pinned(p); } };
+    struct Pinned { uint8_t* p = nullptr; uint64_t cap = 0; void need(uint64_t n) { if (n <= cap) return; kmx_free_pinned(p); cap = n + n / 8 + (1u << 20); p = (uint8_t*)pins.alloc(cap); if (!p) die("pinned host allocation failed"); } ~Pinned() { kmx_free_pinned(p); } };
 
     auto worker_fn = [&](uint32_t g) {
       kmx_ctx* c = gpu[g];

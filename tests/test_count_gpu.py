@@ -314,12 +314,20 @@ def test_superk_partition_random_reads_vs_oracle(ctx, monkeypatch, k, m, P, pass
         assert got[p][0] == exp[p][0]
 
 
-@pytest.mark.parametrize("k,m,P,hard_min,hashed,G", [(31, 10, 8, 1, False, 1), (31, 10, 8, 2, True, 2), (63, 10, 32, 2, False, 3), (21, 8, 5, 3, False, 2), (32, 10, 16, 1, True, 1)])
-def test_count_reads_dev_vs_oracle(ctx, k, m, P, hard_min, hashed, G):
+@pytest.mark.parametrize("stats_by", ["partition", "atomics"])
+@pytest.mark.parametrize("k,m,P,hard_min,hashed,G", [(31, 10, 8, 1, False, 1), (31, 10, 8, 2, True, 2), (63, 10, 32, 2, False, 3), (21, 8, 5, 3, False, 2), (32, 10, 16, 1, True, 1),
+                                                      (31, 10, 2, 1, False, 2), (40, 12, 3, 1, False, 2)])
+def test_count_reads_dev_vs_oracle(ctx, k, m, P, hard_min, hashed, G, stats_by, monkeypatch):
     """kmx_count_reads_dev: the counts stay in HBM as packed .kmer-body records, partition p in store p % G (what the merge stage
     of GPU p % G reads); read back they are the oracle's counts, merged where they lie (kmx_merge_dev) they give the oracle's
     matrix; the raw PartiInfo<5> tables are the oracle's counters"""
     from kmtricks_amd import lib
+    # (the sparse form of the tables, G >= 2: counted per partition from the sorted descriptors -- k_part_stats; with few partitions a
+    #  partition's minimizers do not fit its LDS table and the rest goes through the dense tables --, or, KMX_STATS_ATOMICS, by atomics while
+    #  the reads are walked, as the dense form always is)
+    if stats_by == "atomics":
+        if G < 2: pytest.skip("the dense form is counted by atomics anyway")
+        monkeypatch.setenv("KMX_STATS_ATOMICS", "1")
     lut = orc.minimizer_lut(m)
     rep = orc.repart_static(m, P)
     reads = random_reads(900 + k, 400, 150, n_rate=0.003) * 2 + ["ACGT" * 70, "A" * 300, "", "T" * k, "acgtacgtnnacgt" * 12]
@@ -329,7 +337,7 @@ def test_count_reads_dev_vs_oracle(ctx, k, m, P, hard_min, hashed, G):
     kw = 1 if hashed else (k + 31) // 32
     stores = [lib.Store(0) for _ in range(G)]
     try:
-        lists, nk, raw = ctx.count_reads_dev(reads, k, m, rep, P, hard_min, stores, window=W if hashed else 0, raw=True, sparse=(G == 2))
+        lists, nk, raw = ctx.count_reads_dev(reads, k, m, rep, P, hard_min, stores, window=W if hashed else 0, raw=True, sparse=(G >= 2))
         # a second sample (the reads reversed) in the same stores: lists of both must stay valid
         reads2 = reads[::-1][:300]
         lists2, nk2, _ = ctx.count_reads_dev(reads2, k, m, rep, P, hard_min, stores, window=W if hashed else 0)
