@@ -326,6 +326,17 @@ int kmx_count_reads_dev(kmx_ctx* ctx, const char* bases, const uint64_t* offsets
                         uint8_t** superk_bytes, uint64_t* superk_len, uint64_t* superk_info,
                         kmx_superk_stats* stats, kmx_superk_raw* raw);
 
+/* The bases of a batch on their way to the device AHEAD of the call that counts them (no reference counterpart: the reference reads
+ * its super-k-mer files while it counts, task.hpp:367-392).  The copy is queued on a stream of its own and runs beside the kernels
+ * of the call before it -- two count workers that each upload and then compute fall into step and leave the GPU idle for the length
+ * of every upload (a third of the count stage of 1000 x 5 Mbp).  bases: page-locked (kmx_alloc_pinned), unchanged until
+ * the counting call that takes them has returned.  *dev_bases is what kmx_count_reads_dev / kmx_count_reads of the SAME context then
+ * get as `bases` (with the same offsets as for the host copy); kmx_reads_release gives the device block back after that call (or
+ * instead of it).  At most KMX_READS_AHEAD uploads per context are alive at a time (KMX_E_INVAL beyond). */
+#define KMX_READS_AHEAD 4
+int  kmx_reads_upload(kmx_ctx* ctx, const char* bases, uint64_t n_bytes, const char** dev_bases);
+void kmx_reads_release(kmx_ctx* ctx, const char* dev_bases);
+
 /* kmx_count_reads_dev for SEVERAL samples in one call (no reference counterpart: SuperKTask + CountTask run per sample,
  * task.hpp:250-392; a small sample -- 1 Mbp -- is a few dozen kernels of 5-150 us each and four host round trips, which one call
  * for several samples pays once).  bases[i] / offsets[i] / n_seqs[i]: sample i's reads as in kmx_count_reads.  Results are

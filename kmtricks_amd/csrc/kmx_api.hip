@@ -116,6 +116,7 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   (void)hipStreamSynchronize(ctx->aux);
   (void)hipStreamSynchronize(ctx->copy);
   (void)hipStreamSynchronize(ctx->up);
+  for (auto& a : ctx->ahead) if (a.ev) (void)hipEventDestroy(a.ev);
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
   if (ctx->d_hist) (void)hipFree(ctx->d_hist);
   if (ctx->d_rep) (void)hipFree(ctx->d_rep);

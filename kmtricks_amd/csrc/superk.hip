@@ -693,7 +693,11 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   int maxs = (span_bits - 8) / 2; if (maxs > 255) maxs = 255;   // Sequence2SuperKmer.hpp:146
   const u64 nm = 1ULL << (2 * m);
 
-  char* d_bases = (char*)ctx->dalloc(total_bases + 16);
+  // (bases that kmx_reads_upload has sent ahead: they lie on the device already, or are on their way there)
+  kmx_ctx::ReadsAhead* ahead = nullptr;
+  if (!segs && bases) for (auto& a : ctx->ahead) if (a.live && a.d == bases) ahead = &a;
+  if (ahead && ahead->bytes < total_bases) return ctx->fail(KMX_E_INVAL, "kmx_reads_upload: fewer bytes were uploaded than the offsets name");
+  char* d_bases = ahead ? ahead->d : (char*)ctx->dalloc(total_bases + 16);
   u64* d_offs = (u64*)ctx->dalloc((n_seqs + 1) * 8);
   // the repartition table: resident in the context, uploaded when it is another one than the previous call's (address, size, and a
   // digest over all of it: 8 words at a time, ~0.05 ms for 2 MB -- against a 2 MB upload from pageable memory per sample)
@@ -718,7 +722,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   u32* d_cnt = (u32*)ctx->dalloc((n_seqs + 1) * 4);
   u32* d_doff = (u32*)ctx->dalloc((n_seqs + 1) * 4);
   u32* d_first = (u32*)ctx->dalloc(((size_t)n_smp + 1) * 4);
-  std::vector<void*> blocks = {d_bases, d_offs, d_cnt, d_doff, d_first};
+  std::vector<void*> blocks = {d_offs, d_cnt, d_doff, d_first};
+  if (!ahead) blocks.push_back(d_bases);
   if (rep_pooled) blocks.push_back(d_rep);
   if (!d_rep) { for (void* b : blocks) ctx->dfree(b); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   bool aux_busy = false;      // (kmx_superk_raw's copies are on the second stream: nothing they read is given back before they are through)
@@ -733,7 +738,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       if (nb && (e = hipMemcpyAsync(d_bases + segs->base_first[i], segs->bases[i], nb, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
     }
     if ((e = hipMemcpyAsync(d_first, segs->seq_first, ((size_t)segs->n + 1) * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload sample bounds");
-  } else if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
+  } else if (ahead) { if ((e = hipStreamWaitEvent(st, ahead->ev, 0)) != hipSuccess) return fail(e, "wait for the uploaded bases"); }
+  else if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
   const SkMulti mu{segs ? d_first : nullptr, n_smp, segs ? segs->parts : 0u, segs ? (u32)nm : 0u};
   if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if (repart) { if (rep_upload && (e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) { ctx->rep_host = nullptr; return fail(e, "upload repartition"); } }
@@ -947,6 +953,34 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   clk.mark("download");
   if (oom) return ctx->fail(KMX_E_NOMEM, "superk: host allocation failed");
   return KMX_OK;
+}
+
+extern "C" int kmx_reads_upload(kmx_ctx* ctx, const char* bases, uint64_t n_bytes, const char** dev_bases)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!dev_bases || (!bases && n_bytes)) return ctx->fail(KMX_E_INVAL, "kmx_reads_upload: null argument");
+  *dev_bases = nullptr;
+  kmx_ctx::ReadsAhead* slot = nullptr;
+  for (auto& a : ctx->ahead) if (!a.live) { slot = &a; break; }
+  if (!slot) return ctx->fail(KMX_E_INVAL, "kmx_reads_upload: KMX_READS_AHEAD uploads are alive already");
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  if (!slot->ev) KMX_HIP(ctx, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming));
+  slot->d = (char*)ctx->dalloc(n_bytes + 64);
+  if (!slot->d) return ctx->fail(KMX_E_NOMEM, "kmx_reads_upload: device allocation failed");
+  hipError_t e = n_bytes ? hipMemcpyAsync(slot->d, bases, n_bytes, hipMemcpyHostToDevice, ctx->up) : hipSuccess;
+  if (e == hipSuccess) e = hipEventRecord(slot->ev, ctx->up);
+  if (e != hipSuccess) { ctx->dfree(slot->d); slot->d = nullptr; return ctx->fail(KMX_E_HIP, std::string("kmx_reads_upload: ") + hipGetErrorString(e)); }
+  slot->bytes = n_bytes; slot->live = true;
+  *dev_bases = slot->d;
+  return KMX_OK;
+}
+extern "C" void kmx_reads_release(kmx_ctx* ctx, const char* dev_bases)
+{
+  if (!ctx || !dev_bases) return;
+  for (auto& a : ctx->ahead) if (a.live && a.d == dev_bases) {
+    (void)hipEventSynchronize(a.ev);      // (released instead of counted: the copy must be through before the block is used again)
+    ctx->dfree(a.d); a.d = nullptr; a.live = false; a.bytes = 0;
+  }
 }
 
 extern "C" int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,

@@ -574,7 +574,12 @@ int run(int argc, char** argv)
       uint32_t done = 0;
       double w_split = 0, w_count = 0;
       const uint64_t nm = 1ULL << (2 * o.msize);
-      std::unique_ptr<ReadBatch> pending;      // (a batch taken from the queue that did not fit the call being put together)
+      std::unique_ptr<ReadBatch> pending;      // (a batch taken from the queue that did not fit the call being put together, or taken ahead: below)
+      // the NEXT sample's bases travel to the device while this one is counted (kmx_reads_upload): two workers that each upload
+      // and then compute fall into step -- both upload, the GPU idles; both compute, the link idles: 1.0 of every 4.3 ms at
+      // 5 Mbp per sample (the GPU's timeline, scripts/dev/gantt.sh).  KMX_READS_AHEAD=0: off
+      static const bool reads_ahead = !(getenv("KMX_READS_AHEAD") && getenv("KMX_READS_AHEAD")[0] == '0');
+      const char* pending_dev = nullptr;
       // a whole sample through count FILES (no room in the stores, --keep-tmp, --no-resident): split + count in one call, the
       // super-k-mer streams stay in HBM (kmx_count_reads), the counts come back and are written as counts/partition_<p>/<id>.kmer
       auto whole_to_files = [&](const ReadBatch& b) {
@@ -628,6 +633,8 @@ int run(int argc, char** argv)
         ReadBatch b;
         if (pending) { b = std::move(*pending); pending.reset(); }
         else if (!chan[g]->pop(b)) break;
+        struct Ahead { kmx_ctx* c; const char* d; ~Ahead() { if (d) kmx_reads_release(c, d); } } ahead{c, pending_dev};      // (b's bases on the device, when they were sent ahead)
+        pending_dev = nullptr;
         struct Back { PinPool& pp; PinStr s; ~Back() { pp.put(s); } } back{pinpool, b.bases};      // (the block goes back to the pool when this batch is done with)
         const bool whole_sample = b.last && b.offs.size() > 1 && open.find(b.si) == open.end() && o.until != "superk" && !(o.hist && restricted);      // (the fused calls count every partition: not what a histogram of the selected ones needs)
         bool fits = resident_mode && whole_sample;
@@ -657,6 +664,14 @@ int run(int argc, char** argv)
             }
           }
           const uint32_t S = 1 + (uint32_t)more.size();
+          if (reads_ahead && per_call == 1 && !pending) {      // the next batch, if one waits: its bases start their way now
+            ReadBatch b2;
+            if (chan[g]->try_pop(b2)) {
+              pending.reset(new ReadBatch(std::move(b2)));
+              if (pending->last && pending->offs.size() > 1 && open.find(pending->si) == open.end())
+                chk(c, kmx_reads_upload(c, pending->bases.data(), pending->bases.size(), &pending_dev), "kmx_reads_upload");
+            }
+          }
           st.count_calls++;
           std::vector<const ReadBatch*> grp; grp.push_back(&b); for (auto& x : more) grp.push_back(&x);
           std::vector<kmx_list> ls((size_t)S * P); std::vector<uint64_t> nkp_all((size_t)S * P, 0), info_all(2 * (size_t)S * P, 0);
@@ -671,7 +686,7 @@ int run(int argc, char** argv)
           if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
           int crc = KMX_OK;
           if (S == 1)
-            crc = kmx_count_reads_dev(c, b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
+            crc = kmx_count_reads_dev(c, ahead.d ? ahead.d : b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
                                       stores.data(), G, ls.data(), nkp_all.data(), nullptr, nullptr, info_all.data(), nullptr, rawbufs[0] ? &raws[0] : nullptr);
           else {
             std::vector<const char*> bp(S); std::vector<const uint64_t*> op(S); std::vector<uint64_t> ns(S);

@@ -84,6 +84,9 @@ _lib.kmx_superk_partition_stats.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64, C.
 
 _lib.kmx_merge_host.argtypes = [_vp, C.POINTER(KmxMergeTask), C.c_uint32, C.POINTER(_vp)]
 _lib.kmx_alloc_pinned.restype = _vp
+_lib.kmx_reads_upload.argtypes = [_vp, _vp, C.c_uint64, C.POINTER(_vp)]
+_lib.kmx_reads_release.argtypes = [_vp, _vp]
+_lib.kmx_reads_release.restype = None
 _lib.kmx_alloc_pinned.argtypes = [C.c_size_t]
 _lib.kmx_free_pinned.argtypes = [_vp]
 
@@ -119,7 +122,7 @@ _lib.kmx_hist_reset.argtypes = [_vp]
 _lib.kmx_hist_off.argtypes = [_vp]
 _lib.kmx_hist_read.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
 _lib.kmx_peer_access.argtypes = [C.c_int, C.c_int]
-EXPORTS = ["kmx_peer_access", "kmx_set_file_order", "kmx_count_reads_dev_multi", "kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_reads_upload", "kmx_reads_release", "kmx_peer_access", "kmx_set_file_order", "kmx_count_reads_dev_multi", "kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
@@ -327,7 +330,7 @@ class Context:
                 _lib.kmx_free(ob[p])
         return out, [int(x) for x in nk], st, np.array(list(info), dtype=np.uint64).reshape(nb_parts, 2)
 
-    def count_reads_dev(self, reads, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False, sparse=False):
+    def count_reads_dev(self, reads, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False, sparse=False, ahead=False):
         """kmx_count_reads_dev: as count_reads, the results left on the device as packed records in `stores` (partition p ->
         stores[p % len(stores)]) -> ([(device pointer, records)] per partition, k-mers per partition, raw tables or None)"""
         blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
@@ -342,9 +345,24 @@ class Context:
             if sparse:      # the per-minimizer records as {minimizer, super-k-mers, k-mers} triples: turned back into the tables here
                 spt = np.zeros((4 ** m, 3), np.uint32)
                 rw = KmxSuperkRaw(tabs[0].ctypes.data, None, None, 0, spt.ctypes.data, 4 ** m, 0)
-        self._check(_lib.kmx_count_reads_dev(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
-                                             1 if window else 0, window, hard_min, sp, len(stores), lists, nk, None, None, None, None,
-                                             C.byref(rw) if raw else None), "kmx_count_reads_dev")
+        dev = None
+        if ahead:      # kmx_reads_upload: the bases sent to the device ahead of the call (from page-locked memory), the call given the device pointer
+            n = len(blob)
+            pin = _lib.kmx_alloc_pinned(max(n, 1))
+            C.memmove(pin, blob, n)
+            dev = _vp()
+            self._check(_lib.kmx_reads_upload(self._h, pin, n, C.byref(dev)), "kmx_reads_upload")
+            blob_arg = C.cast(dev, C.c_char_p)
+        else:
+            blob_arg = blob
+        try:
+            self._check(_lib.kmx_count_reads_dev(self._h, blob_arg, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
+                                                 1 if window else 0, window, hard_min, sp, len(stores), lists, nk, None, None, None, None,
+                                                 C.byref(rw) if raw else None), "kmx_count_reads_dev")
+        finally:
+            if ahead:
+                _lib.kmx_reads_release(self._h, dev)
+                _lib.kmx_free_pinned(pin)
         if spt is not None:
             t = spt[:int(rw.minim_sparse_n)]
             assert len(np.unique(t[:, 0])) == len(t)

@@ -337,7 +337,8 @@ def test_count_reads_dev_vs_oracle(ctx, k, m, P, hard_min, hashed, G, stats_by, 
     kw = 1 if hashed else (k + 31) // 32
     stores = [lib.Store(0) for _ in range(G)]
     try:
-        lists, nk, raw = ctx.count_reads_dev(reads, k, m, rep, P, hard_min, stores, window=W if hashed else 0, raw=True, sparse=(G >= 2))
+        # (G == 3 / the 12-mer minimizers: the bases sent ahead of the call -- kmx_reads_upload --, the call given the device pointer)
+        lists, nk, raw = ctx.count_reads_dev(reads, k, m, rep, P, hard_min, stores, window=W if hashed else 0, raw=True, sparse=(G >= 2), ahead=(G == 3 or m == 12))
         # a second sample (the reads reversed) in the same stores: lists of both must stay valid
         reads2 = reads[::-1][:300]
         lists2, nk2, _ = ctx.count_reads_dev(reads2, k, m, rep, P, hard_min, stores, window=W if hashed else 0)
