@@ -490,7 +490,16 @@ int run(int argc, char** argv)
       void put(PinStr b) { if (!b.p) return; std::lock_guard<std::mutex> lk(m); free_.push_back(b); }
       ~PinPool() { for (auto& b : free_) kmx_free_pinned(b.p); }
     } pinpool;
-    struct ReadBatch { uint32_t si = 0; bool last = false; PinStr bases; std::vector<uint64_t> offs; };
+    // (offs_pin: the offsets once more, behind the bases in the page-locked block when there is room -- 8 bytes per read in the block's
+    //  spare eighth --: the call uploads them by DMA instead of through the runtime's staging copy on the worker's thread)
+    struct ReadBatch {
+      uint32_t si = 0; bool last = false; PinStr bases; std::vector<uint64_t> offs; const uint64_t* offs_pin = nullptr;
+      void seal() {
+        const size_t at = (bases.len + 63) & ~(size_t)63, nb = offs.size() * 8;
+        if (bases.p && at + nb <= bases.cap) { memcpy(bases.p + at, offs.data(), nb); offs_pin = reinterpret_cast<const uint64_t*>(bases.p + at); }
+      }
+      const uint64_t* offsets() const { return offs_pin ? offs_pin : offs.data(); }
+    };
     std::vector<std::unique_ptr<Channel<ReadBatch>>> chan;
     // (a queue of 3 batches per worker; more when a worker takes several samples per call, KMX_COUNT_SAMPLES_PER_CALL below)
     { const char* e = getenv("KMX_COUNT_SAMPLES_PER_CALL"); const size_t qcap = e && atol(e) > 1 ? (size_t)atol(e) + 2 : 3;
@@ -544,7 +553,7 @@ int run(int argc, char** argv)
             while (rd.next(seq)) {
               if (b.bases.len + seq.size() > b.bases.cap || (b.bases.len + seq.size() > batch_bytes && b.offs.size() > 1)) {
                 rs += since(t);
-                ch.push(std::move(b));
+                b.seal(); ch.push(std::move(b));
                 b = ReadBatch(); b.si = si; b.offs.assign(1, 0); b.bases = pinpool.get(std::max(want, seq.size()));
                 t = clk::now();
               }
@@ -553,7 +562,7 @@ int run(int argc, char** argv)
             rs += since(t);
           }
         } catch (const std::exception& e) { die(e.what()); }
-        b.last = true; ch.push(std::move(b));
+        b.last = true; b.seal(); ch.push(std::move(b));
         std::lock_guard<std::mutex> lk(tm); s_read += rs;
       }
     };
@@ -686,7 +695,7 @@ int run(int argc, char** argv)
           if (o.hist) chk(c, kmx_hist_reset(c), "kmx_hist_reset");
           int crc = KMX_OK;
           if (S == 1)
-            crc = kmx_count_reads_dev(c, ahead.d ? ahead.d : b.bases.data(), b.offs.data(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
+            crc = kmx_count_reads_dev(c, ahead.d ? ahead.d : b.bases.data(), b.offsets(), b.offs.size() - 1, o.k, o.msize, table.data(), P, hash_mode ? 1 : 0, hash_mode ? hw.wbits : 0, samples[b.si].hard_min,
                                       stores.data(), G, ls.data(), nkp_all.data(), nullptr, nullptr, info_all.data(), nullptr, rawbufs[0] ? &raws[0] : nullptr);
           else {
             std::vector<const char*> bp(S); std::vector<const uint64_t*> op(S); std::vector<uint64_t> ns(S);

@@ -9,7 +9,10 @@ python bench.py --workload count --share-min 1 --steps 20 --warmup 5 --no-cpu-ba
 python bench.py --workload count --rec-min 1 --partitions-per-gpu 8 --steps 20 --warmup 5 --no-cpu-baseline --no-whole-job 2>/dev/null | line > $O/bench_count_recmin1.json
 python scripts/bench_pipeline.py --samples 1000 --genome 1e6 --partitions 256 --sync --variants ";;--skip-partiinfo;--samples-per-call 4" > $O/pipeline_1000x1Mbp.jsonl 2>$O/err_pipe.log
 KMX_FILE_ORDER=0 python scripts/bench_pipeline.py --samples 1000 --genome 1e6 --partitions 256 --sync > $O/pipeline_1000x1Mbp_gather.jsonl 2>>$O/err_pipe.log
-python scripts/bench_pipeline.py --samples 1000 --genome 5e6 --partitions 256 --tmp /dev/shm > $O/pipeline_1000x5Mbp_count_shm.jsonl 2>>$O/err_pipe.log
+# (the first run of a box pays its page faults in /dev/shm: three runs of the default, then the count stage as it was before this round's
+#  last changes -- statistics by atomics, no uploads ahead)
+python scripts/bench_pipeline.py --samples 1000 --genome 5e6 --partitions 256 --tmp /dev/shm --variants ";;;" --env "A=1;A=1;A=1;KMX_STATS_ATOMICS=1 KMX_READS_AHEAD=0" > $O/pipeline_1000x5Mbp_count_shm.jsonl 2>>$O/err_pipe.log
+KMX_SLOW_EXIT=1 bash scripts/dev/prof_pipeline.sh r4/prof_count_stage --samples 200 --genome 5e6 --partitions 256 --tmp /dev/shm > $O/count_stage_5Mbp_kernels.txt 2>&1; cp $O/prof_count_stage/kernel_stats_0.csv $O/kernel_stats_count_stage_5Mbp.csv; rm -rf $O/prof_count_stage
 python scripts/bench_pipeline.py --samples 500 --genome 5e6 --partitions 256 --kmer-size 63 --mode kmer:pa:bin --extra "--recurrence-min 1" --tmp /dev/shm > $O/pipeline_500x5Mbp_k63_pa.jsonl 2>>$O/err_pipe.log
 df -h /tmp /dev/shm > $O/box.txt; nproc >> $O/box.txt; free -g >> $O/box.txt
 python scripts/verify_bench_parity.py --workload count > $O/verify_count.json 2>$O/err_verify.log
