@@ -810,8 +810,11 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         // count rows of up to 1022 lists in at most 8 column blocks: a byte per count where a block's counts of a row all fit one
         // (+ 8 flag bytes): what k_merge_cols writes and k_cols_sparse reads back is then a quarter of the row (KMX_DENSE_NARROW=0:
         // the 4-byte rows only)
-        static const bool narrow_off = getenv("KMX_DENSE_NARROW") && getenv("KMX_DENSE_NARROW")[0] == '0';
-        if (mode == KMX_MODE_COUNT && !narrow_off && (H.row_bytes & 7u) == 0 && H.row_bytes / 8 <= 512 && H.nblk <= 8) {
+        // (from 512 lists: below, the two ways cost the same within the noise -- grid of N = 200 .. 1000, profiles/r04_dense_narrow_store.txt --;
+        //  KMX_DENSE_NARROW=1: wherever it applies, =0: nowhere.  Read per batch: the tests switch it)
+        const char* const nenv = getenv("KMX_DENSE_NARROW");
+        const bool narrow_on = nenv ? nenv[0] != '0' : H.N >= 512;
+        if (mode == KMX_MODE_COUNT && narrow_on && (H.row_bytes & 7u) == 0 && H.row_bytes / 8 <= 512 && H.nblk <= 8) {
           H.npitch = (u32)align_up((size_t)H.N, 8) + 8;
           H.d_narrow = (u8*)ctx->dalloc((size_t)H.dense_cap * H.npitch);      // (none: the wide rows alone)
         }

@@ -1489,12 +1489,13 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
                   if (g >= ng) continue;
                   const u64 v = nv[r][y];
                   const u32 f = (u32)((fl[r] >> fsh0[y]) | (fl[r] >> fsh1[y])) & 0xFFu;
-                  if (!f && 8u * g + 8u <= NL) {
+                  if (!f) {      // (the row's last group may be ragged: N is even here -- rows of whole 8-byte words -- so it ends with a pair)
+                    const u32 npair = min(4u, (NL - 8u * g) >> 1);
                     out64[4 * g + 0] = (v & 0xFFULL) | (((v >> 8) & 0xFFULL) << 32);
-                    out64[4 * g + 1] = ((v >> 16) & 0xFFULL) | (((v >> 24) & 0xFFULL) << 32);
-                    out64[4 * g + 2] = ((v >> 32) & 0xFFULL) | (((v >> 40) & 0xFFULL) << 32);
-                    out64[4 * g + 3] = ((v >> 48) & 0xFFULL) | ((v >> 56) << 32);
-                  } else {      // the row's last lists, or a block whose counts of this row are in the 4-byte row
+                    if (npair > 1) out64[4 * g + 1] = ((v >> 16) & 0xFFULL) | (((v >> 24) & 0xFFULL) << 32);
+                    if (npair > 2) out64[4 * g + 2] = ((v >> 32) & 0xFFULL) | (((v >> 40) & 0xFFULL) << 32);
+                    if (npair > 3) out64[4 * g + 3] = ((v >> 48) & 0xFFULL) | ((v >> 56) << 32);
+                  } else {      // a block whose counts of this row are in the 4-byte row
                     const u32* const wsrc = dense_src(i); u32* const cnt = reinterpret_cast<u32*>(out64);
                     for (u32 l = 8u * g; l < min(NL, 8u * g + 8u); l++) cnt[l] = ((fl[r] >> (8u * (l / nbs))) & 0xFFULL) ? wsrc[l] : (u32)((v >> (8u * (l - 8u * g))) & 0xFFULL);
                   }

@@ -827,6 +827,7 @@ def test_file_order_count_rows_across_the_one_byte_boundary(n, kw, heavy, monkey
     torch = pytest.importorskip("torch")
     if os.environ.get("KMX_MERGE_KERNEL") != "cols":
         pytest.skip("the side store is k_merge_cols' own")
+    monkeypatch.setenv("KMX_DENSE_NARROW", "1")      # (by default from 512 lists on)
     lists = synth_lists(9100 + n, n, 3000, 0.9, 40, kw=kw, key_bits=62 if kw == 1 else 100, count_max=254)
     rng = np.random.default_rng(n)
     edge = np.array([254, 255, 256, 65535, 65536, 0xFFFFFFFF], dtype=np.uint32)
