@@ -458,10 +458,13 @@ int run(int argc, char** argv)
     const bool will_merge = o.until == "all" || o.until == "merge";
     const bool streams = will_merge && o.plugin.empty() && !(o.cpr && !(o.mode == "hash:bf:bin" || o.mode == "hash:bfc:bin")) && o.mode != "hash:bft:bin";
     // (as many pieces as the matrices can fill: input bytes bound them loosely; small runs do not pin 2 GB for nothing)
-    // KMX_RING_PREFILL: a thread pins the pieces while the samples are counted.  Measured on 1000 x 1 Mbp: the merge stage gains
-    // 0.1 s, the count stage loses 0.3 s (page pinning and the workers' HIP calls share the runtime's locks) -- off by default.
+    // A thread asks for the pieces while the samples are counted (KMX_RING_PREFILL=0: the writers ask when they need them).  Round 3
+    // measured that as a loss (the merge stage gained 0.1 s, the count stage lost 0.3 s: hipHostMalloc under the runtime's lock, and the
+    // filler's own first HIP call); with the pieces page-locked from huge pages by the one pin server thread it costs the count stage
+    // nothing, and the merge stage of 1000 x 5 Mbp no longer starts with 0.4 s of pinning 32 pieces of 128 MB (the link's timeline:
+    // scripts/dev/merge_d2h.sh).
     size_ring(in_bytes >= (16ull << 30) ? (2ull << 30) : 0);      // (16 GB of input and more: the large pieces)
-    if (streams) { ring.cap = std::max<size_t>(4, std::min<size_t>(ring.cap, (size_t)(in_bytes * 4 / ring.bytes) + 4)); if (getenv("KMX_RING_PREFILL")) ring_filler = std::thread([&]() { ring.prefill(ring_stop); }); }
+    if (streams) { ring.cap = std::max<size_t>(4, std::min<size_t>(ring.cap, (size_t)(in_bytes * 4 / ring.bytes) + 4)); if (!(getenv("KMX_RING_PREFILL") && getenv("KMX_RING_PREFILL")[0] == '0')) ring_filler = std::thread([&]() { ring.prefill(ring_stop); }); }
   }
   struct RingJoin { std::atomic<bool>& stop; std::thread& t; ~RingJoin() { stop = true; if (t.joinable()) t.join(); } } ring_join{ring_stop, ring_filler};
   st.setup_wall = since(t0);
