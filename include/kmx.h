@@ -351,6 +351,14 @@ int kmx_count_reads_dev_multi(kmx_ctx* ctx, uint32_t n_samples, const char* cons
                               uint64_t* superk_info, kmx_superk_raw* raw);
 /* device memory (a list of a store, a result body) into host memory; blocks until it is there */
 int kmx_copy_to_host(kmx_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
+/* ... without the wait: the copy is queued behind the context's earlier ones and runs back to back with them -- a writer that
+ * brings a matrix body over in pieces keeps two in flight, so the link does not idle while it hands a piece on (0.6 ms per piece
+ * otherwise: 0.4 s of the 2.0 s that 92 GB of matrices take).  host_dst: page-locked (kmx_alloc_pinned).
+ * kmx_copy_wait(ctx, ticket) blocks until that copy (and every one queued before it) is in host memory and gives the ticket back;
+ * at most KMX_COPIES_AHEAD tickets are out at a time (KMX_E_INVAL beyond). */
+#define KMX_COPIES_AHEAD 8
+int kmx_copy_to_host_async(kmx_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes, uint32_t* ticket);
+int kmx_copy_wait(kmx_ctx* ctx, uint32_t ticket);
 
 /* The abundance histogram of a sample (`--hist`): the reference's KHist (histogram.hpp:35-68) is fed EVERY distinct k-mer /
  * hash of the sample with its count, before the hard-min filter (count_processor.hpp:61, 135), one clone per partition,

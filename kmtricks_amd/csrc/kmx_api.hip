@@ -117,6 +117,7 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   (void)hipStreamSynchronize(ctx->copy);
   (void)hipStreamSynchronize(ctx->up);
   for (auto& a : ctx->ahead) if (a.ev) (void)hipEventDestroy(a.ev);
+  for (auto& e : ctx->copy_ev) if (e) (void)hipEventDestroy(e);
   for (auto& b : ctx->pool) if (b.p) (void)hipFree(b.p);
   if (ctx->d_hist) (void)hipFree(ctx->d_hist);
   if (ctx->d_rep) (void)hipFree(ctx->d_rep);
@@ -274,6 +275,30 @@ extern "C" int kmx_copy_to_host(kmx_ctx* ctx, void* dst, const void* src, uint64
   KMX_HIP(ctx, hipSetDevice(ctx->device));
   KMX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->copy));
   KMX_HIP(ctx, hipStreamSynchronize(ctx->copy));
+  return KMX_OK;
+}
+
+extern "C" int kmx_copy_to_host_async(kmx_ctx* ctx, void* dst, const void* src, uint64_t bytes, uint32_t* ticket)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (!ticket || (bytes && (!dst || !src))) return ctx->fail(KMX_E_INVAL, "kmx_copy_to_host_async: null pointer");
+  int slot = -1;
+  for (int i = 0; i < 8; i++) if (!ctx->copy_out[i]) { slot = i; break; }
+  if (slot < 0) return ctx->fail(KMX_E_INVAL, "kmx_copy_to_host_async: KMX_COPIES_AHEAD tickets are out already");
+  KMX_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->copy_ev[slot]) KMX_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev[slot], hipEventDisableTiming));
+  if (bytes) KMX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->copy));
+  KMX_HIP(ctx, hipEventRecord(ctx->copy_ev[slot], ctx->copy));
+  ctx->copy_out[slot] = true;
+  *ticket = (uint32_t)slot;
+  return KMX_OK;
+}
+extern "C" int kmx_copy_wait(kmx_ctx* ctx, uint32_t ticket)
+{
+  if (!ctx) return KMX_E_INVAL;
+  if (ticket >= 8 || !ctx->copy_out[ticket]) return ctx->fail(KMX_E_INVAL, "kmx_copy_wait: no such ticket");
+  ctx->copy_out[ticket] = false;
+  KMX_HIP(ctx, hipEventSynchronize(ctx->copy_ev[ticket]));
   return KMX_OK;
 }
 

@@ -97,6 +97,7 @@ struct kmx_ctx {
   bool stream_shared = false;           // the caller asked for the stream (kmx_stream): its own work may be queued on it
   hipStream_t copy = nullptr;           // third stream: results are read back without queueing behind later batches
   hipStream_t up = nullptr;             // uploads of kmx_merge_host: the next batch's lists travel while this batch merges
+  hipEvent_t copy_ev[8] = {}; bool copy_out[8] = {};      // kmx_copy_to_host_async: tickets
   struct ReadsAhead { char* d = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool live = false; };      // kmx_reads_upload
   ReadsAhead ahead[4];
   hipStream_t aux = nullptr;            // second stream: meta uploads, scratch clears (and, with KMX_COLS_PREP_OVERLAP, the small kernels that prepare a batch)

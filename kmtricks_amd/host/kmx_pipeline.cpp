@@ -394,24 +394,25 @@ int run(int argc, char** argv)
   // stage clocks of KMX_TRACE=1 showed them).  All page-locking therefore goes through ONE thread that has paid that once.
   struct PinServer {
     struct Req { size_t bytes; void* p = nullptr; bool done = false; };
-    std::mutex m; std::condition_variable cv_req, cv_done; std::deque<Req*> q; bool stop = false; std::thread th;
+    std::mutex m; std::condition_variable cv_req, cv_done; std::deque<Req*> q, q_low; bool stop = false; std::thread th;      // (q_low: the output ring's pieces asked for ahead -- behind whatever somebody waits for)
     PinServer() { th = std::thread([this]() { run(); }); }
     void run() {
       std::unique_lock<std::mutex> lk(m);
       for (;;) {
-        cv_req.wait(lk, [&]() { return stop || !q.empty(); });
-        if (q.empty()) return;
-        Req* r = q.front(); q.pop_front();
+        cv_req.wait(lk, [&]() { return stop || !q.empty() || !q_low.empty(); });
+        if (q.empty() && q_low.empty()) return;
+        Req* r;
+        if (!q.empty()) { r = q.front(); q.pop_front(); } else { r = q_low.front(); q_low.pop_front(); }
         lk.unlock();
         void* p = kmx_alloc_pinned(r->bytes);
         lk.lock();
         r->p = p; r->done = true; cv_done.notify_all();
       }
     }
-    void* alloc(size_t bytes) {
+    void* alloc(size_t bytes, bool ahead = false) {
       Req r{bytes};
       std::unique_lock<std::mutex> lk(m);
-      q.push_back(&r); cv_req.notify_one();
+      (ahead ? q_low : q).push_back(&r); cv_req.notify_one();
       cv_done.wait(lk, [&]() { return r.done; });
       return r.p;
     }
@@ -432,23 +433,25 @@ int run(int argc, char** argv)
     void prefill(const std::atomic<bool>& stop) {      // (pieces the writers will want, made ahead of them)
       for (;;) {
         { std::lock_guard<std::mutex> lk(m); if (made >= cap || stop.load()) return; made++; }
-        uint8_t* p = (uint8_t*)pins.alloc(bytes);
+        uint8_t* p = (uint8_t*)pins.alloc(bytes, true);
         if (!p) { std::lock_guard<std::mutex> lk(m); made--; return; }
         put(p);
       }
     }
     ~Ring() { for (auto p : free_) kmx_free_pinned(p); }
   } ring;
-  // (round 4) pieces of 32 MB, 2 GB in all -- or, for 16 GB of input files and more, of 128 MB, 4 GB in all:
-  // 1000 x 5 Mbp (92 GB of matrices) leaves in 2.1-2.8 s through 128 MB pieces against 3.7-4.1 s through 32 MB ones (a device-to-host
-  // copy by itself costs the same per byte at either size: what a piece costs beside its bytes is its hand-over to the writers and
-  // their pwrite), 1000 x 1 Mbp the same either way.
+  // (round 4) A piece as large as a partition's matrix is expected to be (input bytes x 3 / partitions: count rows of a cohort;
+  // 32 MB .. 512 MB), 32 of them (2 .. 16 GB): a file then leaves in ONE copy and ONE pwrite.  The pieces of one file are written one
+  // after the other whatever the number of threads (a write holds the file's inode lock), and every further piece of a file costs
+  // ~0.6 ms of wall clock: 1000 x 5 Mbp (92 GB of matrices of 360 MB; the copies by themselves take 1.63 s at the link's 56.5 GB/s,
+  // scripts/dev/d2h_bench.cpp) leaves in 3.6-3.8 s through 32 MB pieces, 2.6 s through 64 MB, 2.0-2.1 s through 128 MB (the size of
+  // this round's first half), 1.9 s through 256 MB and 1.72 s through 384 or 512 MB -- a piece per file.
   size_t ring_total_mb = 0; bool ring_piece_set = false;
   if (const char* e = getenv("KMX_OUT_RING_MB")) ring_total_mb = (size_t)std::max(64L, atol(e));
   if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(32768, (size_t)atol(e) << 10); ring_piece_set = true; }      // (small pieces: for the tests)
-  auto size_ring = [&](uint64_t list_bytes) {
-    if (!ring_piece_set && list_bytes >= (2ull << 30)) ring.bytes = (size_t)128 << 20;
-    const size_t total = ring_total_mb ? ring_total_mb << 20 : (ring.bytes > ((size_t)32 << 20) ? (size_t)4096 << 20 : (size_t)2048 << 20);
+  auto size_ring = [&](uint64_t body_bytes) {      // body_bytes: what a partition's matrix is expected to hold (0: not known)
+    if (!ring_piece_set && body_bytes) ring.bytes = (size_t)std::min<uint64_t>((uint64_t)512 << 20, std::max<uint64_t>((uint64_t)32 << 20, (body_bytes + ((32u << 20) - 1)) & ~(uint64_t)((32u << 20) - 1)));
+    const size_t total = ring_total_mb ? ring_total_mb << 20 : std::min<size_t>((size_t)16384 << 20, std::max<size_t>((size_t)2048 << 20, 32 * ring.bytes));
     ring.cap = std::max<size_t>(4, total / ring.bytes);
   };
   size_ring(0);
@@ -463,7 +466,7 @@ int run(int argc, char** argv)
     // filler's own first HIP call); with the pieces page-locked from huge pages by the one pin server thread it costs the count stage
     // nothing, and the merge stage of 1000 x 5 Mbp no longer starts with 0.4 s of pinning 32 pieces of 128 MB (the link's timeline:
     // scripts/dev/merge_d2h.sh).
-    size_ring(in_bytes >= (16ull << 30) ? (2ull << 30) : 0);      // (16 GB of input and more: the large pieces)
+    size_ring(in_bytes * 3 / std::max<uint32_t>(1, o.nb_parts));
     if (streams) { ring.cap = std::max<size_t>(4, std::min<size_t>(ring.cap, (size_t)(in_bytes * 4 / ring.bytes) + 4)); if (!(getenv("KMX_RING_PREFILL") && getenv("KMX_RING_PREFILL")[0] == '0')) ring_filler = std::thread([&]() { ring.prefill(ring_stop); }); }
   }
   struct RingJoin { std::atomic<bool>& stop; std::thread& t; ~RingJoin() { stop = true; if (t.joinable()) t.join(); } } ring_join{ring_stop, ring_filler};
@@ -985,6 +988,24 @@ int run(int argc, char** argv)
       std::atomic<uint64_t> pending_bytes{0};
       std::deque<std::future<void>> writes;
       double w_io = 0, w_merge = 0, w_format = 0;
+      // a matrix body leaves in pieces, two copies in flight (kmx_copy_to_host_async): the link runs the next piece while this one is
+      // handed to its writer -- a synchronous copy per piece cost ~0.6 ms of idle link each, whatever its size (32 MB pieces: 3.6 s
+      // for the 92 GB of 1000 x 5 Mbp, 128 MB: 2.05 s, 256 MB: 1.9 s; the copies themselves take 1.63 s)
+      struct Landing { uint8_t* piece; uint32_t ticket; uint64_t n, off, hl; int fd; std::shared_ptr<std::atomic<uint64_t>> left; std::string path; };
+      std::deque<Landing> fly;
+      auto land = [&](size_t keep) {
+        while (fly.size() > keep) {
+          Landing f = std::move(fly.front()); fly.pop_front();
+          chk(c, kmx_copy_wait(c, f.ticket), "kmx_copy_wait");
+          writes.push_back(pool.submit([f, &ring]() {
+            uint64_t done = 0;
+            while (done < f.n) { const ssize_t r = pwrite(f.fd, f.piece + done, f.n - done, (off_t)(f.hl + f.off + done)); if (r <= 0) break; done += (uint64_t)r; }
+            ring.put(f.piece);
+            if (done != f.n) die("write failed: " + f.path);
+            if (--*f.left == 0) close(f.fd);
+          }));
+        }
+      };
       // output of a finished batch: bodies + statistics back, files written on the pool
       auto finish = [&](Flight& F) {
         auto t = clk::now();
@@ -1026,14 +1047,10 @@ int run(int argc, char** argv)
               for (uint64_t off = 0; off < nbytes; off += ring.bytes) {
                 const uint64_t n = std::min<uint64_t>(ring.bytes, nbytes - off);
                 uint8_t* piece = ring.get();
-                chk(c, kmx_copy_to_host(c, piece, dbody + off, n), "kmx_copy_to_host");
-                writes.push_back(pool.submit([=, &ring]() {
-                  uint64_t done = 0;
-                  while (done < n) { const ssize_t r = pwrite(fd, piece + done, n - done, (off_t)(hl + off + done)); if (r <= 0) break; done += (uint64_t)r; }
-                  ring.put(piece);
-                  if (done != n) die("write failed: " + path);
-                  if (--*left == 0) close(fd);
-                }));
+                uint32_t ticket = 0;
+                chk(c, kmx_copy_to_host_async(c, piece, dbody + off, n, &ticket), "kmx_copy_to_host_async");
+                fly.push_back(Landing{piece, ticket, n, off, hl, fd, left, path});
+                land(1);      // (this piece travels while the one before it is handed on)
               }
             } else if (nbytes) {
               // count / pa rows: the arena as the kernels left it (k_merge_cols: the row keys' rows, then the rows out of k_cols_sparse;
@@ -1182,6 +1199,7 @@ int run(int argc, char** argv)
             } catch (const std::exception& e) { die(e.what()); }
           }));
         }
+        land(0);      // (the last pieces of the batch: the device bodies go with the result)
         kmx_result_free(F.R); F.R = nullptr;
         w_io += since(t);
         // (bodies handed to the pool whole -- plugin, lz4, per-sample filters -- are bounded in BYTES: at most ~8 GB wait to be written)

@@ -122,7 +122,7 @@ _lib.kmx_hist_reset.argtypes = [_vp]
 _lib.kmx_hist_off.argtypes = [_vp]
 _lib.kmx_hist_read.argtypes = [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
 _lib.kmx_peer_access.argtypes = [C.c_int, C.c_int]
-EXPORTS = ["kmx_reads_upload", "kmx_reads_release", "kmx_peer_access", "kmx_set_file_order", "kmx_count_reads_dev_multi", "kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
+EXPORTS = ["kmx_copy_to_host_async", "kmx_copy_wait", "kmx_reads_upload", "kmx_reads_release", "kmx_peer_access", "kmx_set_file_order", "kmx_count_reads_dev_multi", "kmx_version", "kmx_result_prepare_body", "kmx_result_arena", "kmx_result_copy_order", "kmx_result_sparse_rows", "kmx_device_memory", "kmx_superk_sample", "kmx_store_create", "kmx_store_destroy", "kmx_store_used", "kmx_store_limit", "kmx_copy_to_host", "kmx_count_reads_dev", "kmx_hist_reset", "kmx_hist_read", "kmx_hist_off", "kmx_device_count", "kmx_count_reads", "kmx_result_copy_body_dev", "kmx_merge_host", "kmx_alloc_pinned", "kmx_free_pinned", "kmx_superk_partition_stats", "kmx_result_transpose_ms", "kmx_result_body_dev", "kmx_set_profiling", "kmx_result_kernel_ms", "kmx_result_kernel", "kmx_create", "kmx_destroy", "kmx_last_error", "kmx_stream", "kmx_merge_dev",
            "kmx_result_wait", "kmx_result_rows", "kmx_result_row_bytes", "kmx_result_body_bytes",
            "kmx_result_algo_bytes", "kmx_result_copy_body", "kmx_result_copy_stats", "kmx_result_free",
            "kmx_merge", "kmx_count_kmer", "kmx_count_hash", "kmx_count_batch", "kmx_transpose_bits", "kmx_superk_partition",
