@@ -512,7 +512,7 @@ int run(int argc, char** argv)
       for (uint32_t w = 0; w < NW; w++) chan.emplace_back(new Channel<ReadBatch>(qcap)); }
     std::mutex tm; double s_read = 0, s_split = 0, s_count = 0;
     // readers: threads that parse samples in fof order, each into the queue of the sample's worker (bounded by the channel)
-    const uint32_t readers = std::max<uint32_t>(1, std::min<uint32_t>(o.threads > 1 ? o.threads / 2 : 1, 24));
+    const uint32_t readers = getenv("KMX_READERS") ? (uint32_t)std::max(1L, atol(getenv("KMX_READERS"))) : std::max<uint32_t>(1, std::min<uint32_t>(o.threads > 1 ? o.threads / 2 : 1, 24));
     // pinned blocks for the statistics tables of a sample (kmx_superk_raw: P * 1280 + 2 * 4^m u32), handed back by the task that
     // has written the sample's PartiInfoFile
     const uint64_t nm_ = 1ULL << (2 * o.msize);
