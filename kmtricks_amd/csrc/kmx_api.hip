@@ -357,6 +357,7 @@ struct kmx_merge_result {
   bool is_bf = false, is_bft = false, waited = false;
   bool cols_ext = false, slices_full = false;   // k_merge_cols with slice extensions; a task came back because a slice was full
   bool cols_resc = false;                        // the RESC builds of the column-blocked pair (share-min, recurrence-min 0)
+  bool share_fix = false;                        // ... with a task whose share-min is above its recurrence-min: k_share_fix behind them
   bool cols_ord = false;                         // ... and their ORD builds: rows written at their final place
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
@@ -407,6 +408,7 @@ __global__ void k_ctrl_mirror(const u64* __restrict__ src, u64* __restrict__ dst
   __threadfence_system();
 }
 static int mirror_and_mark(kmx_merge_result* R);
+__global__ void k_share_fix(const TaskDev* __restrict__ tasks, u32 kw);
 
 static int launch_batch(kmx_merge_result* R, bool with_bounds)
 {
@@ -477,6 +479,11 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, CO.merge(mode, (R->cols_ext ? 1 : 0) | (R->cols_resc ? 2 : 0), d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
     // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
     KMX_HIP(ctx, CO.sparse(mode | (R->cols_resc ? 2 : 0) | (R->cols_ord ? 4 : 0), d_tasks, d_cols, d_items, R->n_items, nt, d_ticket, (u32)ctx->n_cu, ctx->stream));
+    if (R->share_fix) {
+      if ((size_t)R->max_n * 4 > 48 * 1024) KMX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_fix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>((size_t)R->max_n * 4, 160 * 1024)));
+      hipLaunchKernelGGL(k_share_fix, dim3((unsigned)ctx->n_cu * 2u, nt), dim3(256), (size_t)R->max_n * 4, ctx->stream, (const TaskDev*)d_tasks, kw);
+      KMX_HIP(ctx, hipGetLastError());
+    }
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));      // (the launch priced: the rows come out of both kernels)
     return mirror_and_mark(R);
   } else {
@@ -487,6 +494,48 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
   }
   if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
   return mirror_and_mark(R);
+}
+
+// Share-min ABOVE the recurrence-min on the column-blocked pair (count rows).  k_cols_sparse sees all records of a key and rescues
+// from share-min solid ones, whatever share-min is; k_merge_cols writes a row key's row block by block and rescues every non-solid
+// record on the assumption that the row's recurrence-min solid records are share-min of them.  When they need not be
+// (share-min > max(1, recurrence-min)) this pass over the finished rows takes those rescues back: a row with fewer than share-min
+// solid counts (count >= soft-min of its list) loses its non-solid counts, and the statistics lose them (rows 1 and 5: rescued
+// records and their sum; merge.hpp:234-247).  One read of the matrix (+0.5 ms on configs[2]) instead of k_merge_rows for the whole batch.
+__global__ __launch_bounds__(256)
+void k_share_fix(const TaskDev* __restrict__ tasks, u32 kw)
+{
+  extern __shared__ u32 sm_s[];      // the task's soft-mins
+  const TaskDev& T = tasks[blockIdx.y];
+  if (T.mode != KMX_MODE_COUNT || T.share_min <= max(1u, T.rec_min)) return;
+  if (T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) return;      // (handed back: k_merge_rows does the task over, with its own rescue)
+  const u64 rows = T.ctrl[0];
+  const u32 lane = threadIdx.x & 63u, N = T.N;
+  for (u32 l = threadIdx.x; l < N; l += 256) sm_s[l] = T.soft_min[l];
+  __syncthreads();
+  const u64 nw = (u64)gridDim.x * 4u;
+  for (u64 r = (u64)blockIdx.x * 4u + (threadIdx.x >> 6); r < rows; r += nw) {
+    u32* const cnt = reinterpret_cast<u32*>(T.out + r * T.row_bytes + 8u * kw);
+    u32 solid = 0, weak = 0;      // (weak: the row holds non-solid counts at all)
+    for (u32 l0 = 0; l0 < N; l0 += 64u * 16u) {      // 16 loads of a lane in flight
+      u32 c[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const u32 l = l0 + 64u * j + lane; c[j] = l < N ? cnt[l] : 0u; }
+#pragma unroll
+      for (int j = 0; j < 16; j++) { const u32 l = l0 + 64u * j + lane; if (c[j]) { if (c[j] >= sm_s[l]) solid++; else weak++; } }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { solid += (u32)__shfl_xor((int)solid, o); weak += (u32)__shfl_xor((int)weak, o); }
+    if (solid >= T.share_min || !weak) continue;
+    for (u32 l = lane; l < N; l += 64) {
+      const u32 c = cnt[l];
+      if (c && c < sm_s[l]) {
+        cnt[l] = 0;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&T.stats[(u64)N + l]), ~0ULL);                       // - 1
+        atomicAdd(reinterpret_cast<unsigned long long*>(&T.stats[5ull * N + l]), 0ULL - (unsigned long long)c);
+      }
+    }
+  }
 }
 
 static int mirror_and_mark(kmx_merge_result* R)
@@ -621,7 +670,13 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     // (both key widths: merge_cols.hip, merge_cols_k2.hip; share-min up to max(1, recurrence-min): the RESC builds, which also take
     //  recurrence-min 0 -- there a key only non-solid records hold is a row)
     bool resc_ok = true, need_resc = false;
-    for (auto& H : R->tasks) { resc_ok = resc_ok && H.share_min <= std::max(1u, H.rec_min); need_resc = need_resc || H.share_min > 0 || H.rec_min == 0; }
+    // (share-min above that on count rows: the RESC builds + k_share_fix behind them)
+    R->share_fix = false;
+    for (auto& H : R->tasks) {
+      const bool above = H.share_min > std::max(1u, H.rec_min);
+      resc_ok = resc_ok && (!above || mode == KMX_MODE_COUNT); need_resc = need_resc || H.share_min > 0 || H.rec_min == 0;
+      R->share_fix = R->share_fix || (above && mode == KMX_MODE_COUNT);
+    }
     bool can_cols = !is_bf && resc_ok && mx_n <= (u32)rows_cap();
     R->cols_resc = need_resc;
     if (can_cols) {

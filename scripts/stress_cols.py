@@ -24,7 +24,7 @@ for case in range(n_cases):
     p = rng.choice([0.999, 0.97, 0.9, 0.6, 0.2]) if not big else rng.choice([0.999, 0.97, 0.93, 0.85])
     priv = int(pool * (rng.choice([0.0, 0.01, 0.03, 0.1, 0.4]) if not big else rng.choice([0.0, 0.01, 0.03, 0.08])))
     rec_min = rng.choice([0, 1, 1, 2, 2, 2, 3, 5, 9])
-    share = rng.choice([0, 0, 0, 1, max(1, rec_min)])      # (share-min <= max(1, recurrence-min): the RESC builds of the pair; beyond, k_merge_rows)
+    share = rng.choice([0, 0, 0, 1, max(1, rec_min), rec_min + 2, int(N * p * 0.5)])      # (above max(1, recurrence-min): count rows through the pair + k_share_fix, PA rows through k_merge_rows)
     mode = rng.choice([lib.MODE_COUNT, lib.MODE_COUNT, lib.MODE_PA])
     os.environ["KMX_ITEMS_PER_SLOT"] = rng.choice(["1", "3"])
     lists = synth_lists(rng.randrange(1 << 30), N, pool, p, priv, kw=KW, key_bits=62 if KW == 1 else rng.choice([66, 72, 126]),

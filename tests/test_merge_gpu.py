@@ -761,14 +761,16 @@ def test_bench_workload_full_size_parity(workload):
     assert rep["all_kernels_equal_sha256"] and rep["rows_from_k_cols_sparse"] > 0 and rep["rows_total"] > 1_000_000
 
 
-@pytest.mark.parametrize("n,kw,smin,rmin,share", [(300, 1, 10, 2, 1), (300, 1, 10, 2, 2), (600, 1, 25, 1, 1), (257, 2, 10, 3, 2), (300, 1, 10, 0, 0), (300, 1, 10, 0, 1), (200, 2, 12, 0, 0)])
+@pytest.mark.parametrize("n,kw,smin,rmin,share", [(300, 1, 10, 2, 1), (300, 1, 10, 2, 2), (600, 1, 25, 1, 1), (257, 2, 10, 3, 2), (300, 1, 10, 0, 0), (300, 1, 10, 0, 1), (200, 2, 12, 0, 0),
+                                                  (300, 1, 10, 2, 215), (300, 1, 10, 1, 3), (257, 2, 10, 3, 185), (300, 1, 10, 0, 220)])
 @pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
 def test_cols_share_min_and_recurrence_min_0(n, kw, smin, rmin, share, mode):
     """share-min (rescue, merge.hpp:210-247) and recurrence-min 0 in the column-blocked pair (the RESC builds): cohorts with many
     non-solid records (counts 1..49 against soft-mins of 10..30) -- a row key's non-solid records are rescued in k_merge_cols, the
     keys outside the row keys have their solid records counted in k_cols_sparse (rows from recurrence-min, rescue from share-min,
     statistics for every key); with recurrence-min 0 a key only non-solid records hold is a row of zeros.  The result must be the
-    oracle's, and must have come from k_merge_cols."""
+    oracle's, and must have come from k_merge_cols.  Share-min ABOVE the recurrence-min (215 of ~213 solid records per key: about
+    half of the row keys' rows lose their rescued records again): count rows through the pair + k_share_fix, PA rows through k_merge_rows."""
     if os.environ.get("KMX_MERGE_KERNEL") != "cols":
         pytest.skip("column-blocked kernel only")
     from kmtricks_amd import lib
@@ -782,7 +784,8 @@ def test_cols_share_min_and_recurrence_min_0(n, kw, smin, rmin, share, mode):
         recs = [torch.from_numpy(lib.pack_records(k, c, kw).view(np.int32)).cuda() for k, c in lists]
         task = dict(lists=[(r.data_ptr(), r.shape[0]) for r in recs], key_words=kw, soft_min=soft, rec_min=rmin, share_min=share, mode=mode)
         res = ctx.merge_dev([task]); res.wait()
-        assert res.kernel() == "k_merge_cols", res.kernel()
+        above = share > max(1, rmin)
+        assert res.kernel() == ("k_merge_rows" if above and mode == orc.MODE_PA else "k_merge_cols"), res.kernel()
         assert res.rows() == er
         body = res.body()
         assert body == eb, "body differs"
