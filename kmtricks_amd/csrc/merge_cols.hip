@@ -28,7 +28,8 @@
 // the solid ones: the run is a row from recurrence-min of them, its non-solid records are rescued from share-min of them (statistics
 // for every key, kept or not, as the reference accumulates them).  Recurrence-min 0 takes the same builds: a key only non-solid
 // records hold is a row of zeros there.
-// Applicable to COUNT and PA rows, 64- and 128-bit keys, share-min <= max(1, recurrence-min); chosen from 192 lists and recurrence-min <= 21
+// Applicable to COUNT and PA rows, 64- and 128-bit keys, share-min <= max(1, recurrence-min) (count rows: any share-min, with k_share_fix
+// of kmx_api.hip behind the pair); chosen from 192 lists and recurrence-min <= 21
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
 #include "kmx_host.hpp"
 #include <algorithm>
