@@ -20,6 +20,7 @@
 #include <kmtricks/plugin.hpp>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <sys/resource.h>
 #include <algorithm>
 #include <atomic>
@@ -451,7 +452,10 @@ int run(int argc, char** argv)
   if (const char* e = getenv("KMX_OUT_PIECE_KB")) { ring.bytes = std::max<size_t>(32768, (size_t)atol(e) << 10); ring_piece_set = true; }      // (small pieces: for the tests)
   auto size_ring = [&](uint64_t body_bytes) {      // body_bytes: what a partition's matrix is expected to hold (0: not known)
     if (!ring_piece_set && body_bytes) ring.bytes = (size_t)std::min<uint64_t>((uint64_t)512 << 20, std::max<uint64_t>((uint64_t)32 << 20, (body_bytes + ((32u << 20) - 1)) & ~(uint64_t)((32u << 20) - 1)));
-    const size_t total = ring_total_mb ? ring_total_mb << 20 : std::min<size_t>((size_t)16384 << 20, std::max<size_t>((size_t)2048 << 20, 32 * ring.bytes));
+    // (never more than an eighth of the host's memory: the pieces are page-locked)
+    const size_t ram8 = (size_t)sysconf(_SC_PHYS_PAGES) / 8 * (size_t)sysconf(_SC_PAGE_SIZE);
+    const size_t total = ring_total_mb ? ring_total_mb << 20 : std::min<size_t>(std::max<size_t>(ram8, (size_t)512 << 20), std::min<size_t>((size_t)16384 << 20, std::max<size_t>((size_t)2048 << 20, 32 * ring.bytes)));
+    if (!ring_piece_set && ring.bytes > total / 4) ring.bytes = std::max<size_t>((size_t)32 << 20, (total / 4) & ~(size_t)((32u << 20) - 1));
     ring.cap = std::max<size_t>(4, total / ring.bytes);
   };
   size_ring(0);
