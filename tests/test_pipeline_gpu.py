@@ -461,7 +461,9 @@ def test_two_gpu_workers_same_output(tmp_path):
             "g8_resident": (["--gpus", "8", "--gpu-workers", "1"], {}),
             "g2_resident_multi": (["--gpus", "2", "--gpu-workers", "1"], {"KMX_COUNT_SAMPLES_PER_CALL": "4"}),      # several samples per count call (kmx_count_reads_dev_multi)
             "g1_resident_multi": (["--gpus", "1", "--gpu-workers", "2", "--mode", "kmer:count:bin"], {"KMX_COUNT_SAMPLES_PER_CALL": "3"}),
-            "g3_mixed": (["--gpus", "3", "--gpu-workers", "1"], {"KMX_STORE_LIMIT_MB": "8"})}
+            "g3_mixed": (["--gpus", "3", "--gpu-workers", "1"], {"KMX_STORE_LIMIT_MB": "8"}),
+            # round 4's defaults off: statistics by atomics, a sample's bases uploaded inside its call, ring pieces pinned when first needed
+            "g1_resident_r3": (["--gpus", "1", "--gpu-workers", "2"], {"KMX_STATS_ATOMICS": "1", "KMX_READS_AHEAD": "0", "KMX_RING_PREFILL": "0"})}
     outs = {}
     for name, (flags, env) in runs.items():
         out = tmp_path / name
@@ -482,6 +484,9 @@ def test_two_gpu_workers_same_output(tmp_path):
         else: assert 0 < rep["resident_samples"] < 8, rep      # (some samples fitted the 8 MB stores, the others left count files)
         if not name.endswith("_files"):   # no count file survives a run without --keep-tmp
             assert all(not os.listdir(out / "counts" / f"partition_{p}") for p in range(16)), name
+    for s_ in range(8):      # the PartiInfo<5> statistics: per partition from the sorted descriptors (default) == by atomics
+        n = f"S{s_:04d}/PartiInfoFile"
+        assert open(outs["g1_resident"][0] / "superkmers" / n, "rb").read() == open(outs["g1_resident_r3"][0] / "superkmers" / n, "rb").read(), n
     for p in range(16):
         for s_ in range(8):
             n = f"partition_{p}/S{s_:04d}.kmer"
