@@ -207,6 +207,7 @@ struct Stage { double read = 0, split = 0, count = 0, merge_io = 0, merge = 0, f
 int run(int argc, char** argv)
 {
   const auto t0 = clk::now();
+  if (getenv("KMX_TRACE")) { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[kmx epoch] pipeline starts %.6f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
   Opt o = parse_cli(argc, argv);
   std::vector<Sample> samples = parse_fof(o.fof, o.hard_min);
   const uint32_t N = (uint32_t)samples.size(), kw = (o.k + 31) / 32;
@@ -442,7 +443,9 @@ int run(int argc, char** argv)
     ~Ring() { for (auto p : free_) kmx_free_pinned(p); }
   } ring;
   // (round 4) A piece as large as a partition's matrix is expected to be (input bytes x 3 / partitions: count rows of a cohort;
-  // 32 MB .. 512 MB), 32 of them (2 .. 16 GB): a file then leaves in ONE copy and ONE pwrite.  The pieces of one file are written one
+  // 32 MB .. 512 MB), 18 of them (2 .. 9 GB; a file's copy takes 6 ms, its pwrite ~90: 14 in flight keep the link busy, and what is
+  // page-locked is paid for once more when the process leaves -- 0.023 s per GB: 32 pieces = 16 GB merged no faster and left 0.3 s
+  // later): a file then leaves in ONE copy and ONE pwrite.  The pieces of one file are written one
   // after the other whatever the number of threads (a write holds the file's inode lock), and every further piece of a file costs
   // ~0.6 ms of wall clock: 1000 x 5 Mbp (92 GB of matrices of 360 MB; the copies by themselves take 1.63 s at the link's 56.5 GB/s,
   // scripts/dev/d2h_bench.cpp) leaves in 3.6-3.8 s through 32 MB pieces, 2.6 s through 64 MB, 2.0-2.1 s through 128 MB (the size of
@@ -454,7 +457,7 @@ int run(int argc, char** argv)
     if (!ring_piece_set && body_bytes) ring.bytes = (size_t)std::min<uint64_t>((uint64_t)512 << 20, std::max<uint64_t>((uint64_t)32 << 20, (body_bytes + ((32u << 20) - 1)) & ~(uint64_t)((32u << 20) - 1)));
     // (never more than an eighth of the host's memory: the pieces are page-locked)
     const size_t ram8 = (size_t)sysconf(_SC_PHYS_PAGES) / 8 * (size_t)sysconf(_SC_PAGE_SIZE);
-    const size_t total = ring_total_mb ? ring_total_mb << 20 : std::min<size_t>(std::max<size_t>(ram8, (size_t)512 << 20), std::min<size_t>((size_t)16384 << 20, std::max<size_t>((size_t)2048 << 20, 32 * ring.bytes)));
+    const size_t total = ring_total_mb ? ring_total_mb << 20 : std::min<size_t>(std::max<size_t>(ram8, (size_t)512 << 20), std::min<size_t>((size_t)9216 << 20, std::max<size_t>((size_t)2048 << 20, 18 * ring.bytes)));
     if (!ring_piece_set && ring.bytes > total / 4) ring.bytes = std::max<size_t>((size_t)32 << 20, (total / 4) & ~(size_t)((32u << 20) - 1));
     ring.cap = std::max<size_t>(4, total / ring.bytes);
   };
@@ -1255,6 +1258,7 @@ int run(int argc, char** argv)
        << "Memory: " << ru.ru_maxrss / 1024 << "MB\n"; }
   // every file is written and closed, every worker joined: leave without giving tens of GB of device and pinned memory back
   // block by block (the driver and the OS take them back with the process; KMX_SLOW_EXIT=1 runs the destructors, for leak checks)
+  if (getenv("KMX_TRACE")) { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[kmx epoch] leaving %.6f\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec); }
   if (!getenv("KMX_SLOW_EXIT")) { fflush(stdout); fflush(stderr); _exit(0); }
   return 0;
 }
