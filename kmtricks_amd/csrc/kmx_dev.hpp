@@ -89,12 +89,14 @@ enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2, ERR_FALLBACK = 4,
 template <int KW> struct Key { u64 w[KW]; };
 
 template <int KW> __device__ __forceinline__ bool key_less(const Key<KW>& a, const Key<KW>& b) {
-  if (KW == 2) { if (a.w[KW - 1] != b.w[KW - 1]) return a.w[KW - 1] < b.w[KW - 1]; }
+#pragma unroll
+  for (int i = KW - 1; i > 0; i--) { if (a.w[i] != b.w[i]) return a.w[i] < b.w[i]; }
   return a.w[0] < b.w[0];
 }
 template <int KW> __device__ __forceinline__ bool key_eq(const Key<KW>& a, const Key<KW>& b) {
   bool e = a.w[0] == b.w[0];
-  if (KW == 2) e = e && (a.w[KW - 1] == b.w[KW - 1]);
+#pragma unroll
+  for (int i = 1; i < KW; i++) e = e && (a.w[i] == b.w[i]);
   return e;
 }
 template <int KW> __device__ __forceinline__ bool key_le(const Key<KW>& a, const Key<KW>& b) { return !key_less<KW>(b, a); }

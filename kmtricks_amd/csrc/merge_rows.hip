@@ -36,15 +36,17 @@ namespace kmx {
 #endif
 constexpr int TPB = KMX_ROWS_TPB;  // 8 or 16 waves
 constexpr int CAP = KMX_ROWS_CAP;  // record slots per tile
-constexpr int M = CAP / TPB;       // record slots per thread
-constexpr int TS = 2 * CAP;        // hash set entries (load factor <= 0.5)
-constexpr int KLBYTES = CAP * 2 + 4096;   // kept keys: u16 table slots [CAP] + fast-path key copies (4 KiB)
-constexpr int WGS_PER_CU = (TPB <= 512 && (CAP * 8 + TS * 4 + KLBYTES + 384) * 2 <= 160 * 1024) ? 2 : 1;   // KW = 1: LDS and 128-VGPR budget
+// per tile and key width (cap_of below): M = CAP / TPB record slots per thread, TS = 2 CAP hash set entries (load factor <= 0.5),
+// KLBYTES = CAP * 2 + 4096 for the kept keys: u16 table slots [CAP] + fast-path key copies (4 KiB)
+constexpr int WGS_PER_CU = (TPB <= 512 && (CAP * 8 + 2 * CAP * 4 + CAP * 2 + 4096 + 384) * 2 <= 160 * 1024) ? 2 : 1;   // KW = 1: LDS and 128-VGPR budget
 constexpr int NWAVE = TPB / 64;
+// keys of three and four words (k = 64 ... 127, Kmer<96> / Kmer<128>; include/kmtricks/kmer.hpp:164-630 of the reference): half the record
+// slots per tile -- the staged keys of 4096 slots alone would be 128 KB of the 160 KB, and a thread's keys leave the registers
+__host__ __device__ constexpr int cap_of(int kw) { return kw <= 2 ? CAP : CAP / 2; }
 
 // LDS image of the row batch being assembled: aliases the staged keys
-__host__ __device__ inline int rows_emit_bytes(int kw) { return CAP * kw * 8; }
-__host__ __device__ inline int rows_fixed_bytes(int kw) { return CAP * kw * 8 + TS * 4 + KLBYTES; }
+__host__ __device__ inline int rows_emit_bytes(int kw) { return cap_of(kw) * kw * 8; }
+__host__ __device__ inline int rows_fixed_bytes(int kw) { return cap_of(kw) * kw * 8 + 2 * cap_of(kw) * 4 + cap_of(kw) * 2 + 4096; }
 
 // ---- range bounds ------------------------------------------------------------------------------
 // bounds[j*N + i] = first record of list i whose key >= Q_j, Q_j = pivot[j * len_pivot / c].
@@ -100,9 +102,11 @@ __device__ u64 kmx_phase_prof[16];
 template <int KW> __device__ __forceinline__ u32 key_hash(const Key<KW>& k)
 { // cheap 32-bit mix (a handful of VALU ops); quality only matters for the probe length
   u32 x = (u32)k.w[0] ^ ((u32)(k.w[0] >> 32) * 0x9E3779B1u);
-  if (KW == 2) x ^= ((u32)k.w[KW - 1] * 0x85EBCA77u) ^ ((u32)(k.w[KW - 1] >> 32) * 0xC2B2AE3Du);
+  if (KW >= 2) x ^= ((u32)k.w[KW - 1] * 0x85EBCA77u) ^ ((u32)(k.w[KW - 1] >> 32) * 0xC2B2AE3Du);
+  if (KW >= 3) x ^= ((u32)k.w[1] * 0x27D4EB2Fu) ^ ((u32)(k.w[1] >> 32) * 0x165667B1u);
+  if (KW >= 4) x ^= ((u32)k.w[2] * 0x9E3779B1u) ^ ((u32)(k.w[2] >> 32) * 0x85EBCA77u);
   x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
-  return x & (TS - 1);
+  return x & (2 * cap_of(KW) - 1);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt on gfx950
@@ -115,7 +119,7 @@ template <int KW>
 __device__ __noinline__ u64 probe_slow(u32* tab, const Key<KW>* keysL, Key<KW> k, u32 h, u32 s)
 {
   for (;;) {
-    h = (h + 1) & (TS - 1);
+    h = (h + 1) & (2 * cap_of(KW) - 1);
     u32 o = tab[h];
     if (o == 0) {
       o = atomicCAS(&tab[h], 0u, s + 1);
@@ -133,6 +137,8 @@ __global__ __launch_bounds__(TPB, (KW == 1 ? WGS_PER_CU : 1) * TPB / 256)
 void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ items, u32 n_items, u32* ticket)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CAP = cap_of(KW), M = CAP / TPB, TS = 2 * CAP, KLBYTES = CAP * 2 + 4096;      // (the file's constants, for this key width)
+  constexpr int WMIN = KW <= 2 ? 256 : NWAVE * KW * 8;                                          // bytes of the waves' candidate keys
   constexpr int RB4 = (KW * 8 + 4) / 4;
   constexpr int KEYS_BYTES = CAP * KW * 8;
   constexpr int DKMAX = 4096 / (KW * 8);
@@ -144,9 +150,9 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
   Key<KW>* dkeys = reinterpret_cast<Key<KW>*>(smem + KEYS_BYTES + TS * 4 + CAP * 2);   // their keys, fast path (4 KiB)
   unsigned char* misc = smem + KEYS_BYTES + TS * 4 + KLBYTES;
   Key<KW>* wmin = reinterpret_cast<Key<KW>*>(misc);                 // NWAVE keys (<= 256 B)
-  u32* wany = reinterpret_cast<u32*>(misc + 256);                   // NWAVE flags (64 B)
-  u64* bc64 = reinterpret_cast<u64*>(misc + 320);                   // broadcast: row offset
-  u32* bc32 = reinterpret_cast<u32*>(misc + 336);                   // [0] item  [1] can-write  [2] kept counter
+  u32* wany = reinterpret_cast<u32*>(misc + WMIN);                  // NWAVE flags (64 B)
+  u64* bc64 = reinterpret_cast<u64*>(misc + WMIN + 64);             // broadcast: row offset
+  u32* bc32 = reinterpret_cast<u32*>(misc + WMIN + 80);             // [0] item  [1] can-write  [2] kept counter
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef KMX_PHASE_PROF
@@ -494,18 +500,24 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
 // explicit instantiations used by the host side
 template __global__ void k_range_bounds<1>(const TaskDev*, u32);
 template __global__ void k_range_bounds<2>(const TaskDev*, u32);
+template __global__ void k_range_bounds<3>(const TaskDev*, u32);
+template __global__ void k_range_bounds<4>(const TaskDev*, u32);
 template __global__ void k_merge_rows<1, 0>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<1, 1>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<2, 0>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<2, 1>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<3, 0>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<3, 1>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<4, 0>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<4, 1>(const TaskDev*, const uint2*, u32, u32*);
 
 }  // namespace kmx
 
 // ---- host-side launchers (plain functions so other translation units need no device code) -----
 namespace kmx {
 
-int rows_lds_bytes(int kw, u32) { return rows_fixed_bytes(kw) + 384; }
-int rows_cap() { return CAP; }
+int rows_lds_bytes(int kw, u32) { return rows_fixed_bytes(kw) + (kw <= 2 ? 384 : NWAVE * kw * 8 + 128); }
+int rows_cap(int kw) { return cap_of(kw); }
 int rows_wgs_per_cu(int kw) { return kw == 1 ? WGS_PER_CU : 1; }
 u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, (u32)KMX_CHUNK_BYTES / row_bytes); }
 u32 rows_image_bytes(int kw) { return (u32)rows_emit_bytes(kw); }
@@ -526,7 +538,9 @@ hipError_t launch_range_bounds(int kw, const TaskDev* tasks, u32 n_tasks, u32 ma
 {
   dim3 grid((max_n + 255) / 256, max_c + 1, n_tasks), block(256);
   if (kw == 1) hipLaunchKernelGGL(k_range_bounds<1>, grid, block, 0, st, tasks, max_c);
-  else hipLaunchKernelGGL(k_range_bounds<2>, grid, block, 0, st, tasks, max_c);
+  else if (kw == 2) hipLaunchKernelGGL(k_range_bounds<2>, grid, block, 0, st, tasks, max_c);
+  else if (kw == 3) hipLaunchKernelGGL(k_range_bounds<3>, grid, block, 0, st, tasks, max_c);
+  else hipLaunchKernelGGL(k_range_bounds<4>, grid, block, 0, st, tasks, max_c);
   return hipGetLastError();
 }
 
@@ -546,6 +560,10 @@ hipError_t launch_merge_rows(int kw, int mode, const TaskDev* tasks, const uint2
   else if (kw == 1 && mode == 1) KMX_LAUNCH(1, 1);
   else if (kw == 2 && mode == 0) KMX_LAUNCH(2, 0);
   else if (kw == 2 && mode == 1) KMX_LAUNCH(2, 1);
+  else if (kw == 3 && mode == 0) KMX_LAUNCH(3, 0);
+  else if (kw == 3 && mode == 1) KMX_LAUNCH(3, 1);
+  else if (kw == 4 && mode == 0) KMX_LAUNCH(4, 0);
+  else if (kw == 4 && mode == 1) KMX_LAUNCH(4, 1);
   else return hipErrorInvalidValue;
 #undef KMX_LAUNCH
   return hipGetLastError();

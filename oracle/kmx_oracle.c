@@ -499,7 +499,7 @@ int orc_merge(const orc_list* lists, uint32_t N, int kw,
   uint64_t* ns = stats, *rd = stats ? stats + N : 0, *uwo = stats ? stats + 2 * (size_t)N : 0,
           *uw = stats ? stats + 3 * (size_t)N : 0, *two = stats ? stats + 4 * (size_t)N : 0,
           *tw = stats ? stats + 5 * (size_t)N : 0;
-  uint64_t current[2] = {0, 0}, next[2] = {0, 0};
+  uint64_t current[4] = {0, 0, 0, 0}, next[4] = {0, 0, 0, 0};      /* (Kmer<128>: four words) */
   int next_set = 0;
   /* init_state: smallest head, merge.hpp:150-168 */
   for (uint32_t i = 0; i < N; i++) {

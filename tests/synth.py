@@ -12,8 +12,17 @@ def synth_lists(seed, n_lists, pool, p_present, n_private, kw=1, key_bits=62, co
         lo = rng.integers(0, 1 << min(key_bits, 62), n, dtype=np.uint64)
         if kw == 1:
             return lo.reshape(n, 1)
-        hi = rng.integers(0, 1 << max(1, min(key_bits - 64, 62)), n, dtype=np.uint64)
-        return np.stack([lo, hi], axis=1)
+        if kw == 2:
+            hi = rng.integers(0, 1 << max(1, min(key_bits - 64, 62)), n, dtype=np.uint64)
+            return np.stack([lo, hi], axis=1)
+        # three and four words (k = 64 ... 127): the upper words take one of eight values spread over all 64 bits (the top bit
+        # included), so that many keys agree in some of their words and every word decides some comparisons
+        ws = [lo if rng.random() < 0.9 else (lo & np.uint64(7))]
+        for _ in range(kw - 1):
+            ws.append(rng.integers(0, 8, n, dtype=np.uint64) * np.uint64(0x2492492492492492))
+        top_bits = max(1, min(key_bits - 64 * (kw - 1), 62))
+        ws[-1] = ws[-1] >> np.uint64(64 - top_bits) if top_bits < 62 else ws[-1]
+        return np.stack(ws, axis=1)
 
     allk = np.unique(draw(int(total * 1.1) + 8), axis=0)
     rng.shuffle(allk, axis=0)
