@@ -52,8 +52,18 @@ __device__ __forceinline__ u128 revcomp128(u128 x, int k)
 #define XP4 0x85EBCA77C2B2AE63ULL
 #define XP5 0x27D4EB2F165667C5ULL
 __device__ __forceinline__ u64 rotl64d(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ u64 xxh64_round(u64 acc, u64 in) { return rotl64d(acc + in * XP2, 31) * XP1; }
+__device__ __forceinline__ u64 xxh64_merge(u64 h, u64 v) { return (h ^ xxh64_round(0, v)) * XP1 + XP4; }
 __device__ __forceinline__ u64 xxh64_words(const u64* w, int nw)
 {
+  if (nw == 4) {      // 32 bytes (Kmer<128>): one stripe through the four accumulators, nothing left over
+    const u64 v1 = xxh64_round(XP1 + XP2, w[0]), v2 = xxh64_round(XP2, w[1]), v3 = xxh64_round(0, w[2]), v4 = xxh64_round(0ULL - XP1, w[3]);
+    u64 h = rotl64d(v1, 1) + rotl64d(v2, 7) + rotl64d(v3, 12) + rotl64d(v4, 18);
+    h = xxh64_merge(h, v1); h = xxh64_merge(h, v2); h = xxh64_merge(h, v3); h = xxh64_merge(h, v4);
+    h += 32;
+    h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+    return h;
+  }
   u64 h = XP5 + (u64)nw * 8;
   for (int i = 0; i < nw; i++) {
     h ^= rotl64d(w[i] * XP2, 31) * XP1;
@@ -166,6 +176,128 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
     }
   }
   (void)nrec_s;
+}
+
+// ---- keys of three and four words: k = 64 ... 95 (Kmer<96>) and 96 ... 127 (Kmer<128>), the reference's default KMER_LIST "32 64 96 128"
+//      (CMakeLists.txt:25-27, kmer.hpp:164-630).  Correct first: a lane per k-mer as above, the record's integer S in nine registers'
+//      worth of words, multi-word shifts; a super-k-mer holds up to 92 / 124 k-mers there (Sequence2SuperKmer.hpp:146: (bits - 8) / 2).
+template <int NW> __device__ __forceinline__ void w_shr(const u64* a, u32 bits, u64* out)      // out = a >> bits (bits < 64 NW)
+{
+  const u32 ws = bits >> 6, bs = bits & 63u;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    u64 lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < NW; q++) { if ((u32)q == (u32)i + ws) lo = a[q]; if ((u32)q == (u32)i + ws + 1u) hi = a[q]; }
+    out[i] = bs ? (lo >> bs) | (hi << (64u - bs)) : lo;
+  }
+}
+template <int NW> __device__ __forceinline__ void w_shl(const u64* a, u32 bits, u64* out)      // out = a << bits (bits < 64 NW), NW words kept
+{
+  const u32 ws = bits >> 6, bs = bits & 63u;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    u64 hi = 0, lo = 0;
+#pragma unroll
+    for (int q = 0; q < NW; q++) { if ((u32)q + ws == (u32)i) hi = a[q]; if ((u32)q + ws + 1u == (u32)i) lo = a[q]; }
+    out[i] = bs ? (hi << bs) | (lo >> (64u - bs)) : hi;
+  }
+}
+template <int KW, int HASH>
+__global__ __launch_bounds__(256)
+void k_superk_decode_wide(const u8* __restrict__ recs, const u64* __restrict__ prefix, const u32* __restrict__ blk_first, const u16* __restrict__ rec_part,
+                          const u64* __restrict__ part_ids, u32 n_recs, u32 total, int k, u64 win, u64* __restrict__ out)
+{
+  __shared__ u64 pk[DK + 1];
+  const u32 tid = threadIdx.x;
+  const u32 g0 = blockIdx.x * DK;
+  const u32 r0 = blk_first[blockIdx.x];
+  const u32 avail = min((u32)DK + 1u, n_recs + 1u - r0);
+  for (u32 t = tid; t < avail; t += 256) pk[t] = prefix[r0 + t];
+  __syncthreads();
+  for (int x = 0; x < DK / 256; x++) {
+    const u32 g = g0 + tid + x * 256;
+    if (g >= total) break;
+    u32 lo = 0, hi = avail - 1;
+    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if ((u32)(pk[mid] >> 32) <= g) lo = mid; else hi = mid - 1; }
+    const u64 pe = pk[lo];
+    const u32 j = g - (u32)(pe >> 32);                 // my k-mer of the record
+    const u8* p = recs + (u32)pe + 1;                  // behind the record's length byte
+    u64 S[8];                                          // 2 (k + j) <= 500 bits of the record (the stream is readable 64 bytes past a record's start)
+#pragma unroll
+    for (int i = 0; i < 8; i++) S[i] = load8u(p + 8 * i);
+    // digits j .. k-1: the seed's digits shifted up by j; digits 0 .. j-1: the j nucleotides that follow the seed (S's digits k, k + 1, ...) in reverse order
+    u64 A[8], E[8], f[KW];
+    w_shl<8>(S, 2u * j, A);
+    w_shr<8>(S, 2u * (u32)k, E);
+    u64 R[4] = {rev_digits64(E[3]), rev_digits64(E[2]), rev_digits64(E[1]), rev_digits64(E[0])}, B[4] = {0, 0, 0, 0};
+    if (j) w_shr<4>(R, 256u - 2u * j, B);
+    const u32 topbits = 2u * (u32)k - 64u * (KW - 1);   // 1 .. 64 bits of the top word
+    const u64 topmask = topbits >= 64u ? ~0ULL : ((1ULL << topbits) - 1ULL);
+#pragma unroll
+    for (int i = 0; i < KW; i++) f[i] = A[i] | B[i];
+    f[KW - 1] &= topmask;
+    // reverse complement: the digits reversed over all KW words, digit ^ 2, shifted down to k digits
+    u64 RC[KW], r[KW];
+#pragma unroll
+    for (int i = 0; i < KW; i++) RC[i] = rev_digits64(f[KW - 1 - i]) ^ 0xAAAAAAAAAAAAAAAAULL;
+    w_shr<KW>(RC, 64u * KW - 2u * (u32)k, r);
+    bool less = false, decided = false;
+#pragma unroll
+    for (int i = KW - 1; i >= 0; i--) if (!decided && f[i] != r[i]) { less = f[i] < r[i]; decided = true; }
+    u64 c[KW];
+#pragma unroll
+    for (int i = 0; i < KW; i++) c[i] = less ? f[i] : r[i];
+    if (HASH) {
+      const u32 rr = r0 + lo;
+      const u64 part = part_ids ? part_ids[rec_part[rr]] : (u64)rec_part[rr];
+      out[g] = xxh64_words(c, KW) % win + win * part;
+    } else {
+#pragma unroll
+      for (int i = 0; i < KW; i++) out[(u64)g * KW + i] = c[i];
+    }
+  }
+}
+
+// the sort of such keys: least significant word first, a stable 64-bit radix sort of (word, index) pairs per word, the partition last
+__global__ void k_wide_iota(u32* __restrict__ perm, u32 n) { const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) perm[i] = i; }
+__global__ void k_wide_gather_word(const u64* __restrict__ keys, const u32* __restrict__ perm, u32 n, int kw, int w, u64* __restrict__ out)
+{ const u32 i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = keys[(u64)perm[i] * kw + w]; }
+__global__ void k_wide_heads(const u64* __restrict__ keys, const u32* __restrict__ perm, const u16* __restrict__ spart, u32 n, int kw, u32* __restrict__ flag)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 f = 1;
+  if (i && spart[i] == spart[i - 1]) {
+    const u64* a = keys + (u64)perm[i] * kw, *b = keys + (u64)perm[i - 1] * kw;
+    f = 0;
+    for (int w = 0; w < kw; w++) f |= a[w] != b[w] ? 1u : 0u;
+  }
+  flag[i] = f;
+}
+__global__ void k_wide_run_starts(const u32* __restrict__ flag, const u32* __restrict__ incl, u32 n, u32* __restrict__ start)
+{
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) start[incl[i] - 1] = i;
+  if (i == n - 1) start[incl[i]] = n;
+}
+__global__ void k_wide_run_keep(const u32* __restrict__ start, u32 runs, u32 hard_min, u32* __restrict__ cnt, u32* __restrict__ keep)
+{
+  const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= runs) return;
+  const u32 c = start[r + 1] - start[r];
+  cnt[r] = c; keep[r] = c >= hard_min ? 1u : 0u;
+}
+__global__ void k_wide_emit(const u64* __restrict__ keys, const u32* __restrict__ perm, const u16* __restrict__ spart, const u32* __restrict__ start,
+                            const u32* __restrict__ cnt, const u32* __restrict__ keep, const u32* __restrict__ pos, u32 runs, int kw,
+                            u64* __restrict__ okeys, u32* __restrict__ ocnt, u16* __restrict__ opart)
+{
+  const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= runs || !keep[r]) return;
+  const u32 o = pos[r], at = start[r];
+  const u64* a = keys + (u64)perm[at] * kw;
+  for (int w = 0; w < kw; w++) okeys[(u64)o * kw + w] = a[w];
+  ocnt[o] = cnt[r]; opart[o] = spart[at];
 }
 
 // ASCII bases -> 2 bits each ((c >> 1) & 3: A 0, C 1, T 2, G 3), 32 to a word, the first one in the top bits; a thread per word.
@@ -706,6 +838,91 @@ static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kp
   return KMX_OK;
 }
 
+// ---- keys of three and four words (k = 64 ... 127): sorted word by word (the library's stable radix sort on 64-bit keys, least
+//      significant word first, the partition last), runs counted by head flags + scans.  d_keys: total keys of kw words, partition p =
+//      k-mers [kmoff[p], kmoff[p + 1]).  Host output only (kmx_count_batch): keys[p] = n_out[p] * kw words, low word first ----
+static int wide_sort_count(kmx_ctx* ctx, StageClock& clk, const u64* d_keys, int kw, const std::vector<u64>& kmoff, u32 n_parts, u32 total, u32 hard_min, const CountOut& co)
+{
+  if (co.dev()) return ctx->fail(KMX_E_UNSUPPORTED, "k >= 64: counts are handed back to the host (kmx_count_batch)");
+  hipStream_t st = ctx->stream; hipError_t e;
+  std::vector<void*> blocks;
+  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
+  auto get = [&](size_t bytes) { void* b = ctx->dalloc(bytes ? bytes : 256); blocks.push_back(b); return b; };
+  u64* d_w = (u64*)get((size_t)total * 8), *d_w2 = (u64*)get((size_t)total * 8);
+  u32* d_perm = (u32*)get((size_t)total * 4), *d_perm2 = (u32*)get((size_t)total * 4);
+  u16* d_kpart = (u16*)get((size_t)total * 2), *d_gp = (u16*)get((size_t)total * 2), *d_sp = (u16*)get((size_t)total * 2);
+  u32* d_kmo = (u32*)get(((size_t)n_parts + 1) * 4);
+  u32* d_flag = (u32*)get((size_t)total * 4), *d_incl = (u32*)get((size_t)total * 4), *d_start = (u32*)get(((size_t)total + 1) * 4);
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  unsigned pbits = 1; while ((1u << pbits) < n_parts) pbits++;
+  e = rocprim::radix_sort_pairs(nullptr, t1, d_w, d_w2, d_perm, d_perm2, (size_t)total, 0, 64, st);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t2, d_gp, d_sp, d_perm, d_perm2, (size_t)total, 0, pbits, st);
+  if (e == hipSuccess) e = rocprim::inclusive_scan(nullptr, t3, d_flag, d_incl, (size_t)total, rocprim::plus<u32>(), st);
+  const size_t tmax = std::max(t1, std::max(t2, t3)) + 256;
+  void* d_tmp = get(tmax);
+  for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "count (k >= 64): device allocation failed"); }
+  auto fail = [&](hipError_t er, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(er)); };
+  if (e != hipSuccess) return fail(e, "rocPRIM temp sizing");
+  std::vector<u32> kmo32(kmoff.begin(), kmoff.end());
+  if ((e = hipMemcpyAsync(d_kmo, kmo32.data(), ((size_t)n_parts + 1) * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "count upload");
+  const dim3 gt((total + 255) / 256), b256(256);
+  hipLaunchKernelGGL(k_fill_kpart, gt, b256, 0, st, d_kmo, n_parts, total, d_kpart);
+  hipLaunchKernelGGL(k_wide_iota, gt, b256, 0, st, d_perm, total);
+  for (int w = 0; w < kw; w++) {
+    hipLaunchKernelGGL(k_wide_gather_word, gt, b256, 0, st, d_keys, d_perm, total, kw, w, d_w);
+    size_t t = tmax;
+    if ((e = rocprim::radix_sort_pairs(d_tmp, t, d_w, d_w2, d_perm, d_perm2, (size_t)total, 0, 64, st)) != hipSuccess) return fail(e, "radix_sort_pairs");
+    std::swap(d_perm, d_perm2);
+  }
+  hipLaunchKernelGGL(k_gather_u16, gt, b256, 0, st, d_perm, total, d_kpart, d_gp);
+  { size_t t = tmax; if ((e = rocprim::radix_sort_pairs(d_tmp, t, d_gp, d_sp, d_perm, d_perm2, (size_t)total, 0, pbits, st)) != hipSuccess) return fail(e, "radix_sort_pairs"); }
+  std::swap(d_perm, d_perm2);
+  clk.mark("sort");
+  hipLaunchKernelGGL(k_wide_heads, gt, b256, 0, st, d_keys, d_perm, d_sp, total, kw, d_flag);
+  { size_t t = tmax; if ((e = rocprim::inclusive_scan(d_tmp, t, d_flag, d_incl, (size_t)total, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan"); }
+  hipLaunchKernelGGL(k_wide_run_starts, gt, b256, 0, st, d_flag, d_incl, total, d_start);
+  u32 runs = 0;
+  if ((e = hipMemcpyAsync(&runs, d_incl + (total - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");      // (kmo32 is this frame's, too)
+  u32* d_cnt = (u32*)get((size_t)runs * 4), *d_keep = (u32*)get((size_t)runs * 4), *d_pos = (u32*)get(((size_t)runs + 1) * 4);
+  u32* d_bounds = (u32*)get(((size_t)n_parts + 1) * 4);
+  if (!d_cnt || !d_keep || !d_pos || !d_bounds) { release(); return ctx->fail(KMX_E_NOMEM, "count (k >= 64): device allocation failed"); }
+  const dim3 gr((runs + 255) / 256);
+  hipLaunchKernelGGL(k_wide_run_keep, gr, b256, 0, st, d_start, runs, hard_min, d_cnt, d_keep);
+  hist_runs(ctx, d_cnt, runs);
+  { size_t t = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, t, d_keep, d_pos, 0u, (size_t)runs, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan size");
+    void* tmp = t <= tmax ? d_tmp : get(t);
+    if (!tmp) { release(); return ctx->fail(KMX_E_NOMEM, "count (k >= 64): device allocation failed"); }
+    if ((e = rocprim::exclusive_scan(tmp, t, d_keep, d_pos, 0u, (size_t)runs, rocprim::plus<u32>(), st)) != hipSuccess) return fail(e, "scan"); }
+  u32 last[2] = {0, 0};
+  if ((e = hipMemcpyAsync(&last[0], d_pos + (runs - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(&last[1], d_keep + (runs - 1), 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+  const u32 kept = last[0] + last[1];
+  clk.mark("rle");
+  std::vector<u32> bounds(n_parts + 1, 0);
+  std::vector<u64> h_k((size_t)kept * kw); std::vector<u32> h_c(kept);
+  if (kept) {
+    u64* d_ok = (u64*)get((size_t)kept * kw * 8); u32* d_oc = (u32*)get((size_t)kept * 4); u16* d_op = (u16*)get((size_t)kept * 2);
+    if (!d_ok || !d_oc || !d_op) { release(); return ctx->fail(KMX_E_NOMEM, "count (k >= 64): device allocation failed"); }
+    hipLaunchKernelGGL(k_wide_emit, gr, b256, 0, st, d_keys, d_perm, d_sp, d_start, d_cnt, d_keep, d_pos, runs, kw, d_ok, d_oc, d_op);
+    hipLaunchKernelGGL(k_part_bounds, dim3((n_parts + 256) / 256), b256, 0, st, d_op, kept, n_parts, d_bounds);
+    if ((e = hipMemcpyAsync(bounds.data(), d_bounds, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(h_k.data(), d_ok, (size_t)kept * kw * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(h_c.data(), d_oc, (size_t)kept * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "download");
+  }
+  release();
+  for (u32 p = 0; p < n_parts; p++) {
+    const size_t n = bounds[p + 1] - bounds[p];
+    co.keys[p] = (uint64_t*)malloc(n ? n * kw * 8 : 8);
+    co.counts[p] = (uint32_t*)malloc(n ? n * 4 : 4);
+    if (!co.keys[p] || !co.counts[p]) return ctx->fail(KMX_E_NOMEM, "count (k >= 64): host allocation failed");
+    co.n_out[p] = n;
+    if (n) { memcpy(co.keys[p], h_k.data() + (size_t)bounds[p] * kw, n * kw * 8); memcpy(co.counts[p], h_c.data() + bounds[p], n * 4); }
+  }
+  clk.mark("download");
+  return KMX_OK;
+}
+
 // ---- a batch from its record stream to its counts: decode (one lane per k-mer), partition-local count, the library sort if a
 //      bucket is beyond the count kernel.  d_prefix: u64[nr + 1], record i starts at byte lo(d_prefix[i]), its first k-mer is number
 //      hi(d_prefix[i]); d_rpart[i]: the record's partition (index into pid / kmoff); kmoff: first k-mer of every partition ----
@@ -713,7 +930,8 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
                             const std::vector<u64>& kmoff, const std::vector<u64>& pid, u32 k, int hash_mode, u64 window, u32 hard_min, const CountOut& co,
                             const u32* d_sbase = nullptr /* set: d_recs are packed bases (k_pack_bases), record i starts at base d_sbase[i] */)
 {
-  const int kw = (k + 31) / 32;
+  const int kw = k < 64 ? (k + 31) / 32 : k / 32 + 1;      // (from 64 on: Kmer<96> / Kmer<128>, loop_executor.hpp:47-63)
+  if (kw > 2 && d_sbase) return ctx->fail(KMX_E_UNSUPPORTED, "k >= 64: counted from super-k-mer records (kmx_count_batch)");
   const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
   const u32 NB = (u32)((total + DK - 1) / DK);
   u64* d_pid = (u64*)ctx->dalloc(pid.empty() ? 8 : (size_t)n_parts * 8);      // (pid empty: partition p has id p, nothing to upload)
@@ -731,7 +949,11 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
   hipLaunchKernelGGL(k_decode_block_starts, dim3((nr + 255) / 256), dim3(256), 0, st, d_prefix, nr, d_blk);
   const dim3 grid(NB), block(256);
 #define KMX_DECODE(KW_, H_, D_) hipLaunchKernelGGL((k_superk_decode_kmers<KW_, H_, D_>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys, d_sbase)
-  if (d_sbase) {
+  if (kw > 2) {
+#define KMX_DECODE_W(KW_, H_) hipLaunchKernelGGL((k_superk_decode_wide<KW_, H_>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, (u64*)d_keys)
+    if (kw == 3 && !hash_mode) KMX_DECODE_W(3, 0); else if (kw == 3) KMX_DECODE_W(3, 1); else if (!hash_mode) KMX_DECODE_W(4, 0); else KMX_DECODE_W(4, 1);
+#undef KMX_DECODE_W
+  } else if (d_sbase) {
     if (kw == 1 && !hash_mode) KMX_DECODE(1, 0, true); else if (kw == 1) KMX_DECODE(1, 1, true); else if (!hash_mode) KMX_DECODE(2, 0, true); else KMX_DECODE(2, 1, true);
   } else {
     if (kw == 1 && !hash_mode) KMX_DECODE(1, 0, false); else if (kw == 1) KMX_DECODE(1, 1, false); else if (!hash_mode) KMX_DECODE(2, 0, false); else KMX_DECODE(2, 1, false);
@@ -741,6 +963,7 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
   clk.mark("decode");
   int rc;
   // partition-local sample sort / hash count first (count_sort.hpp); the library sort when a bucket is beyond it
+  if (!hash_mode && kw > 2) { rc = wide_sort_count(ctx, clk, (const u64*)d_keys, kw, kmoff, n_parts, (u32)total, hard_min, co); release(); return rc; }
   if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, kmoff, n_parts, hard_min, co);
   else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, kmoff, n_parts, hard_min, co);
   if (rc == 1) {
@@ -769,7 +992,7 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
 {
   if (!ctx) return KMX_E_INVAL;
   if (!n_parts || !superk || !len || !keys || !counts || !n_out) return ctx->fail(KMX_E_INVAL, "kmx_count_batch: null argument");
-  if (k < 8 || k > 63) return ctx->fail(KMX_E_UNSUPPORTED, "k-mer size outside 8..63");
+  if (k < 8 || k > 127) return ctx->fail(KMX_E_UNSUPPORTED, "k-mer size outside 8..127");
   if (hash_mode && (window == 0 || !partition_ids)) return ctx->fail(KMX_E_INVAL, "hash mode needs window and partition ids");
   if (n_parts > 65535) return ctx->fail(KMX_E_UNSUPPORTED, "more than 65535 partitions in one batch");
   KMX_HIP(ctx, hipSetDevice(ctx->device));
@@ -796,7 +1019,7 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
       const u64 nb = ((u64)k + n - 1 + 3) / 4;
       // (a super-k-mer holds at most 28 k-mers for k < 32, 60 above -- Sequence2SuperKmer.hpp:90-132; the lane-per-k-mer decode cuts a
       //  record's k-mers from one 64- / 128-bit window and relies on it: a longer record is a malformed stream, not silently wrong keys)
-      if (n == 0 || n > (k < 32 ? 28u : 60u) || pos + 1 + nb > len[p]) { bad = 1; return; }
+      if (n == 0 || n > (k < 32 ? 28u : k < 64 ? 60u : k < 96 ? 92u : 124u) || pos + 1 + nb > len[p]) { bad = 1; return; }      // ((type bits - 8) / 2: Kmer<96> 92, Kmer<128> 124)
       nr++; nk += n; pos += 1 + nb;
     }
     n_rec[p] = nr; n_km[p] = nk;
@@ -823,7 +1046,7 @@ extern "C" int kmx_count_batch(kmx_ctx* ctx, uint32_t n_parts, const uint8_t* co
   clk.mark("parse");
   auto empty_out = [&]() { for (u32 p = 0; p < n_parts; p++) { if (!keys[p]) { keys[p] = (uint64_t*)malloc(8); counts[p] = (uint32_t*)malloc(4); n_out[p] = 0; } } };
   if (total == 0) { hrelease(); empty_out(); return KMX_OK; }
-  u8* d_recs = (u8*)ctx->dalloc(bytes + 32);
+  u8* d_recs = (u8*)ctx->dalloc(bytes + 128);      // (the decode reads whole words past a record: 64 bytes from its start for k >= 64)
   u64* d_prefix = (u64*)ctx->dalloc(((size_t)nr + 1) * 8);
   u16* d_rp = (u16*)ctx->dalloc((size_t)nr * 2);
   std::vector<void*> blocks = {d_recs, d_prefix, d_rp};

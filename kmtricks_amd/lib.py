@@ -129,6 +129,11 @@ EXPORTS = ["kmx_copy_to_host_async", "kmx_copy_wait", "kmx_reads_upload", "kmx_r
            "kmx_free"]
 
 
+def key_words_of(k):
+    """64-bit words of a k-mer key: ceil(k / 32) below 64; 3 for 64 ... 95 and 4 for 96 ... 127 (the reference's Kmer<96> / Kmer<128>)"""
+    return (k + 31) // 32 if k < 64 else k // 32 + 1
+
+
 class KmxError(RuntimeError):
     pass
 
@@ -226,7 +231,7 @@ class Context:
         kp, cp, n = _vp(), _vp(), C.c_uint64()
         self._check(_lib.kmx_count_kmer(self._h, superk, len(superk), k, hard_min, C.byref(kp), C.byref(cp),
                                         C.byref(n)), "kmx_count_kmer")
-        return self._take(kp, cp, n.value, (k + 31) // 32)
+        return self._take(kp, cp, n.value, key_words_of(k))
 
     def count_hash(self, superk: bytes, k, window, partition, hard_min):
         kp, cp, n = _vp(), _vp(), C.c_uint64()
@@ -245,7 +250,7 @@ class Context:
         kp, cp, no = (_vp * n)(), (_vp * n)(), (C.c_uint64 * n)()
         self._check(_lib.kmx_count_batch(self._h, n, sp, ln, k, 1 if window else 0, window, pid, hard_min, kp, cp, no),
                     "kmx_count_batch")
-        width = 1 if window else (k + 31) // 32
+        width = 1 if window else key_words_of(k)
         out = []
         for p in range(n):
             keys, cnts = self._take(_vp(kp[p]), _vp(cp[p]), no[p], width)
@@ -317,7 +322,7 @@ class Context:
         self._check(_lib.kmx_count_reads(self._h, blob, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,
                                          1 if window else 0, window, hard_min, kp, cp, no, nk, ob if streams else None,
                                          ol if streams else None, info, None), "kmx_count_reads")
-        width = 1 if window else (k + 31) // 32
+        width = 1 if window else key_words_of(k)
         out = []
         for p in range(nb_parts):
             keys, cnts = self._take(_vp(kp[p]), _vp(cp[p]), no[p], width)

@@ -372,32 +372,39 @@ int orc_superk_partition_stats(const char* seq, size_t len, int k, int m,
 /* ===================================================================== */
 /* count */
 
+/* words of the k-mer type the reference instantiates for k: the first KMER_LIST entry (32 64 96 128, CMakeLists.txt:25-27) above k
+ * (loop_executor.hpp:47-63); below 64 this restatement keeps its ceil(k / 32) words (k = 32: one word, as its callers size it) */
+static int kw_of_k(int k) { return k < 64 ? (k + 31) / 32 : k / 32 + 1; }
+
 uint64_t orc_superk_decode(const uint8_t* recs, size_t len, int k, int kw, uint64_t* out)
-{ /* sorting_count.hpp:141-312 (decode), canonical = min(fwd, revcomp) */
-  uint64_t kmask[2];
-  if (kw == 1) { kmask[0] = (k == 32) ? ~0ULL : (((uint64_t)1 << (2 * k)) - 1); kmask[1] = 0; }
-  else { kmask[0] = ~0ULL; kmask[1] = (k == 64) ? ~0ULL : (((uint64_t)1 << (2 * (k - 32))) - 1); }
+{ /* sorting_count.hpp:141-312 (decode), canonical = min(fwd, revcomp); keys of up to four words (Kmer<128>) */
+  uint64_t kmask[4] = {0, 0, 0, 0};
+  for (int w = 0; w < kw; w++) {
+    const int bits = 2 * k - 64 * w;
+    kmask[w] = bits >= 64 ? ~0ULL : bits > 0 ? (((uint64_t)1 << bits) - 1) : 0;
+  }
   const uint8_t* p = recs; const uint8_t* end = recs + len;
   uint64_t n = 0;
   while (p < end) {
     unsigned nbk = *p++;
-    uint64_t seed[2] = {0, 0};
+    uint64_t seed[4] = {0, 0, 0, 0};
     int rem = k, nbr = 0;
     uint8_t nb = 0;
     while (rem >= 4) {
       nb = *p++;
-      if (nbr < 8) seed[0] |= (uint64_t)nb << (8 * nbr); else seed[1] |= (uint64_t)nb << (8 * (nbr - 8));
+      seed[nbr >> 3] |= (uint64_t)nb << (8 * (nbr & 7));
       rem -= 4; nbr++;
     }
     int uid = 4;
     if (rem > 0) {
       nb = *p++;
-      if (nbr < 8) seed[0] |= (uint64_t)nb << (8 * nbr); else seed[1] |= (uint64_t)nb << (8 * (nbr - 8));
+      seed[nbr >> 3] |= (uint64_t)nb << (8 * (nbr & 7));
       uid = rem;
     }
-    seed[0] &= kmask[0]; seed[1] &= kmask[1];
-    uint64_t fwd[2] = {seed[0], seed[1]}, rev[2];
+    uint64_t fwd[4], rev[4];
+    for (int w = 0; w < 4; w++) fwd[w] = w < kw ? seed[w] & kmask[w] : 0;
     orc_revcomp(fwd, rev, k, kw);
+    for (int w = kw; w < 4; w++) rev[w] = 0;
     for (unsigned ii = 0; ii < nbk; ii++) {
       if (out) {
         const uint64_t* c = kw_less(fwd, rev, kw) ? fwd : rev;
@@ -407,13 +414,14 @@ uint64_t orc_superk_decode(const uint8_t* recs, size_t len, int k, int kw, uint6
       if (ii + 1 >= nbk) break;
       if (uid >= 4) { nb = *p++; uid = 0; }
       unsigned nt = (nb >> (2 * uid)) & 3u; uid++;
-      fwd[1] = ((fwd[1] << 2) | (fwd[0] >> 62)) & kmask[1];
+      for (int w = kw - 1; w > 0; w--) fwd[w] = ((fwd[w] << 2) | (fwd[w - 1] >> 62)) & kmask[w];
       fwd[0] = ((fwd[0] << 2) | nt) & kmask[0];
       uint64_t cc = (uint64_t)(nt ^ 2u);
-      rev[0] = (rev[0] >> 2) | (rev[1] << 62); rev[1] >>= 2;
+      for (int w = 0; w + 1 < kw; w++) rev[w] = (rev[w] >> 2) | (rev[w + 1] << 62);
+      rev[kw - 1] >>= 2;
       int sh = 2 * (k - 1);
-      if (sh < 64) rev[0] |= cc << sh; else rev[1] |= cc << (sh - 64);
-      rev[0] &= kmask[0]; rev[1] &= kmask[1];
+      rev[sh >> 6] |= cc << (sh & 63);
+      for (int w = 0; w < kw; w++) rev[w] &= kmask[w];
     }
   }
   return n;
@@ -425,6 +433,19 @@ static int cmp_u128(const void* a, const void* b)
 {
   const uint64_t* x = (const uint64_t*)a; const uint64_t* y = (const uint64_t*)b;
   if (x[1] != y[1]) return x[1] < y[1] ? -1 : 1;
+  return x[0] < y[0] ? -1 : x[0] > y[0];
+}
+
+static int cmp_u192(const void* a, const void* b)
+{
+  const uint64_t* x = (const uint64_t*)a; const uint64_t* y = (const uint64_t*)b;
+  for (int w = 2; w > 0; w--) if (x[w] != y[w]) return x[w] < y[w] ? -1 : 1;
+  return x[0] < y[0] ? -1 : x[0] > y[0];
+}
+static int cmp_u256(const void* a, const void* b)
+{
+  const uint64_t* x = (const uint64_t*)a; const uint64_t* y = (const uint64_t*)b;
+  for (int w = 3; w > 0; w--) if (x[w] != y[w]) return x[w] < y[w] ? -1 : 1;
   return x[0] < y[0] ? -1 : x[0] > y[0];
 }
 
@@ -453,12 +474,12 @@ static int rle_filter(uint64_t* arr, uint64_t n, int kw, uint32_t hard_min,
 int orc_count_kmer(const uint8_t* recs, size_t len, int k, uint32_t hard_min,
                    uint64_t** keys, uint32_t** counts, uint64_t* n_out)
 {
-  int kw = (k + 31) / 32;
+  int kw = kw_of_k(k);
   uint64_t n = orc_superk_decode(recs, len, k, kw, NULL);
   uint64_t* arr = (uint64_t*)malloc((n ? n : 1) * (size_t)kw * 8);
   if (!arr) return -1;
   orc_superk_decode(recs, len, k, kw, arr);
-  qsort(arr, n, (size_t)kw * 8, kw == 1 ? cmp_u64 : cmp_u128);
+  qsort(arr, n, (size_t)kw * 8, kw == 1 ? cmp_u64 : kw == 2 ? cmp_u128 : kw == 3 ? cmp_u192 : cmp_u256);
   int rc = rle_filter(arr, n, kw, hard_min, keys, counts, n_out);
   free(arr);
   return rc;
@@ -467,7 +488,7 @@ int orc_count_kmer(const uint8_t* recs, size_t len, int k, uint32_t hard_min,
 int orc_count_hash(const uint8_t* recs, size_t len, int k, uint64_t win, uint64_t part,
                    uint32_t hard_min, uint64_t** hashes, uint32_t** counts, uint64_t* n_out)
 {
-  int kw = (k + 31) / 32;
+  int kw = kw_of_k(k);
   uint64_t n = orc_superk_decode(recs, len, k, kw, NULL);
   uint64_t* arr = (uint64_t*)malloc((n ? n : 1) * (size_t)kw * 8);
   uint64_t* h = (uint64_t*)malloc((n ? n : 1) * 8);

@@ -138,8 +138,13 @@ def repart_sampled(minim_kxmers, nb_parts):
     return out
 
 
+def kw_of_k(k):
+    """words of a k-mer: ceil(k / 32) below 64; from 64 on the reference's Kmer<96> / Kmer<128> (loop_executor.hpp:47-63)"""
+    return (k + 31) // 32 if k < 64 else k // 32 + 1
+
+
 def superk_decode(recs: bytes, k):
-    kw = (k + 31) // 32
+    kw = kw_of_k(k)
     n = _lib.orc_superk_decode(recs, len(recs), k, kw, None)
     out = np.zeros((n, kw), dtype=np.uint64)
     _lib.orc_superk_decode(recs, len(recs), k, kw, out.ctypes.data)
@@ -157,7 +162,7 @@ def _take(ptr, n, dtype, width=1):
 
 
 def count_kmer(recs: bytes, k, hard_min):
-    kw = (k + 31) // 32
+    kw = kw_of_k(k)
     kp, cp, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
     rc = _lib.orc_count_kmer(recs, len(recs), k, hard_min, C.byref(kp), C.byref(cp), C.byref(n))
     assert rc == 0

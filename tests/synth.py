@@ -53,3 +53,48 @@ def synth_hash_lists(seed, n_lists, lower, window, density, count_max=20):
         cs = rng.integers(1, count_max, len(hs), dtype=np.uint32)
         out.append((hs.reshape(-1, 1), cs))
     return out
+
+
+_NT = {"A": 0, "C": 1, "T": 2, "G": 3}
+
+
+def kmer_value(s):
+    """a k-mer's value as the reference encodes it: A0 C1 T2 G3, the first nucleotide in the top digit (kmer.hpp:938)"""
+    v = 0
+    for c in s:
+        v = v * 4 + _NT[c]
+    return v
+
+
+def canonical_value(s):
+    rc = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    return min(kmer_value(s), kmer_value(rc))
+
+
+def superk_record(seq, k):
+    """the super-k-mer record of the len(seq) - k + 1 consecutive k-mers of `seq` (gatb Model.hpp:1388-1433 as sorting_count.hpp:153-275
+    reads it): [u8 n][ceil((k + n - 1) / 4) bytes of S, little endian], S = the first k-mer's value + the following nucleotides at
+    digits k, k + 1, ..."""
+    n = len(seq) - k + 1
+    assert 1 <= n <= 255
+    S = kmer_value(seq[:k])
+    for j, c in enumerate(seq[k:]):
+        S |= _NT[c] << (2 * (k + j))
+    return bytes([n]) + S.to_bytes((k + n - 1 + 3) // 4, "little")
+
+
+def synth_superk_stream(seed, k, n_records, max_kmers, genome=4000):
+    """records cut at random places of a random genome (so that k-mers repeat), 1 .. max_kmers k-mers each -> (bytes, {canonical value: count})"""
+    rng = np.random.default_rng(seed)
+    g = "".join("ACGT"[i] for i in rng.integers(0, 4, genome + k + max_kmers))
+    out, counts = [], {}
+    for _ in range(n_records):
+        n = int(rng.integers(1, max_kmers + 1)); at = int(rng.integers(0, genome))
+        seq = g[at:at + k + n - 1]
+        if rng.random() < 0.5:
+            seq = seq[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        out.append(superk_record(seq, k))
+        for j in range(n):
+            v = canonical_value(seq[j:j + k])
+            counts[v] = counts.get(v, 0) + 1
+    return b"".join(out), counts

@@ -115,11 +115,44 @@ def test_count_batch_vs_oracle(ctx, k, m):
     assert all(len(c) == 0 for _, c in ctx.count_batch([b"", b""], k, 1))
 
 
+@pytest.mark.parametrize("k", [64, 65, 80, 95, 96, 97, 112, 127])
+def test_count_wide_kmers_vs_oracle(ctx, k):
+    """k = 64 ... 127 (Kmer<96> / Kmer<128>; the reference's default KMER_LIST "32 64 96 128", CMakeLists.txt:25-27): kmx_count_batch on
+    super-k-mer record streams of up to 92 / 124 k-mers a record == the oracle per partition (k-mers low word first, window hashes over
+    the 24 / 32 key bytes), == the counts of the strings the records were cut from; then those lists merged (k_merge_rows, 3 / 4 words)"""
+    from synth import synth_superk_stream
+    P, mx, kw = 5, (92 if k < 96 else 124), orc.kw_of_k(k)
+    streams, truth = [], []
+    for p in range(P):
+        recs, cnt = synth_superk_stream(1000 * k + p, k, 400 if p != 2 else 0, mx if p != 1 else 1, genome=3000)
+        streams.append(recs); truth.append(cnt)
+    for hard_min in (1, 2):
+        got = ctx.count_batch(streams, k, hard_min)
+        goth = ctx.count_batch(streams, k, hard_min, window=1000003, partitions=[7, 0, 3, 1, 12])
+        for p in range(P):
+            ek, ec = orc.count_kmer(streams[p], k, hard_min)
+            assert got[p][0].shape == (len(ec), kw)
+            assert np.array_equal(ek, got[p][0]) and np.array_equal(ec, got[p][1]), (k, p, hard_min)
+            vals = [sum(int(ek[i, w]) << (64 * w) for w in range(kw)) for i in range(len(ec))]
+            exp = sorted((v, n) for v, n in truth[p].items() if n >= hard_min)
+            assert vals == [v for v, _ in exp] and list(map(int, ec)) == [n for _, n in exp]
+            eh, ehc = orc.count_hash(streams[p], k, 1000003, [7, 0, 3, 1, 12][p], hard_min)
+            assert np.array_equal(eh, goth[p][0]) and np.array_equal(ehc, goth[p][1]), (k, p, hard_min)
+    keys, counts = ctx.count_kmer(streams[0], k, 1)
+    ek, ec = orc.count_kmer(streams[0], k, 1)
+    assert np.array_equal(keys, ek) and np.array_equal(counts, ec)      # (kmx_count_kmer: one stream)
+    # the samples' lists of "one partition", merged: the matrix the oracle builds from the oracle's lists
+    lists = [ctx.count_batch([s], k, 1)[0] for s in streams]
+    exp_body, exp_rows, exp_stats = orc.merge_matrix([(a.reshape(-1), c) for a, c in lists], kw, [1, 2, 1, 1, 2], 1, 0, orc.MODE_COUNT)
+    body, rows, stats = ctx.merge(lists, kw, [1, 2, 1, 1, 2], 1, 0, orc.MODE_COUNT)
+    assert rows == exp_rows and body == exp_body and np.array_equal(stats, exp_stats)
+
+
 def test_count_rejects_records_longer_than_a_super_kmer(ctx):
     """a record that claims more k-mers than a super-k-mer can hold (28 for k < 32, 60 above: Sequence2SuperKmer.hpp:90-132) is a
     malformed stream -- refused, not decoded into wrong keys (the lane-per-k-mer decode reads a record's k-mers from one window)"""
     from kmtricks_amd import lib
-    for k, n in ((31, 29), (31, 255), (40, 61)):
+    for k, n in ((31, 29), (31, 255), (40, 61), (64, 93), (95, 93), (96, 125), (127, 255)):
         rec = bytes([n]) + bytes((k + n - 1 + 3) // 4)
         with pytest.raises(lib.KmxError, match="malformed super-k-mer stream"):
             ctx.count_kmer(rec, k, 1)

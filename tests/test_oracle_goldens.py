@@ -239,3 +239,19 @@ def test_processor_test_hard_min():
         else:
             keys, counts = orc.count_hash(sk[0][0], k, 1 << 20, 0, amin)
         assert sorted(int(c) for c in counts) == sorted(kept)
+
+
+@pytest.mark.parametrize("k", [21, 31, 32, 47, 63, 64, 80, 95, 96, 127])
+def test_count_oracle_against_an_independent_restatement(k):
+    """the oracle's record decode + count (pinned to the reference's vectors for k = 31 above) against counts taken from the strings
+    the records were cut from (tests/synth.py: big-integer k-mer values, reverse complement by string) -- the same code path of the
+    oracle for every k, so the k <= 63 cases tie the k = 64 ... 127 ones (Kmer<96> / Kmer<128>, no reference vector exists) to it"""
+    from synth import synth_superk_stream
+    mx = 28 if k < 32 else 60 if k < 64 else 92 if k < 96 else 124
+    recs, cnt = synth_superk_stream(k, k, 300, mx)
+    kw = orc.kw_of_k(k)
+    for hm in (1, 2):
+        keys, c = orc.count_kmer(recs, k, hm)
+        vals = [sum(int(keys[i, w]) << (64 * w) for w in range(kw)) for i in range(len(c))]
+        exp = sorted((v, n) for v, n in cnt.items() if n >= hm)
+        assert vals == [v for v, _ in exp] and list(map(int, c)) == [n for _, n in exp]
