@@ -67,6 +67,10 @@ static inline unsigned nt_code(unsigned char c) { return (c >> 1) & 3u; } /* A0 
 static inline unsigned kw_digit(const uint64_t* w, int i) { return (unsigned)(w[i >> 5] >> ((i & 31) * 2)) & 3u; }
 static inline void kw_set_digit(uint64_t* w, int i, unsigned d) { w[i >> 5] |= (uint64_t)d << ((i & 31) * 2); }
 
+/* words of the k-mer type the reference instantiates for k: the first KMER_LIST entry (32 64 96 128, CMakeLists.txt:25-27) above k
+ * (loop_executor.hpp:47-63); below 64 this restatement keeps its ceil(k / 32) words (k = 32: one word, as its callers size it) */
+static int kw_of_k(int k) { return k < 64 ? (k + 31) / 32 : k / 32 + 1; }
+
 static inline int kw_less(const uint64_t* a, const uint64_t* b, int kw)
 { /* most significant word first, kmer.hpp:262-268 */
   for (int i = kw - 1; i >= 0; i--) { if (a[i] != b[i]) return a[i] < b[i]; }
@@ -178,9 +182,9 @@ void orc_buf_free(orc_buf* b) { free(b->data); b->data = NULL; b->len = b->cap =
 
 #define SK_MAX 255
 typedef struct {
-  uint64_t fwd[SK_MAX + 1][2]; /* forward value of each k-mer */
+  uint64_t fwd[SK_MAX + 1][4]; /* forward value of each k-mer (up to Kmer<128>: four words) */
   uint8_t  which[SK_MAX + 1];  /* forward < revcomp */
-  uint64_t canon[SK_MAX + 1][2];
+  uint64_t canon[SK_MAX + 1][4];
   int n;
   uint64_t minimizer;
   int valid;                   /* minimizer != DEFAULT_MINIMIZER */
@@ -218,11 +222,13 @@ static int superk_flush(superk_t* sk, int k, int kw, const uint16_t* repart, uin
   uint8_t* d = b->data + b->len;
   size_t idx = 0;
   d[idx++] = (uint8_t)n;
-  uint64_t base[2] = {sk->fwd[0][0], kw > 1 ? sk->fwd[0][1] : 0};
+  uint64_t base[4] = {0, 0, 0, 0};
+  for (int w = 0; w < kw; w++) base[w] = sk->fwd[0][w];
   int rem = k;
   while (rem >= 4) {
     d[idx++] = (uint8_t)(base[0] & 255u);
-    base[0] = (base[0] >> 8) | (base[1] << 56); base[1] >>= 8;
+    for (int w = 0; w < 3; w++) base[w] = (base[w] >> 8) | (base[w + 1] << 56);
+    base[3] >>= 8;
     rem -= 4;
   }
   uint8_t nb = (uint8_t)(base[0] & 255u);
@@ -264,34 +270,37 @@ int orc_superk_partition(const char* seq, size_t len, int k, int m,
                          const uint32_t* lut, const uint16_t* repart,
                          uint32_t nb_parts, orc_buf* out, uint64_t* pinfo)
 {
-  if (k < m || k > 64 || m > 15) return -3;
+  if (k < m || k > 127 || m > 15) return -3;
   if ((int64_t)len - k + 1 <= 0) return 0;                 /* Sequence2SuperKmer.hpp:143-144 */
-  const int kw = (k + 31) / 32;
+  const int kw = kw_of_k(k);
   /* Type::getSize(): the reference dispatches k to the first KMER_LIST entry with k < entry
    * (include/kmtricks/loop_executor.hpp:47-52), so k = 32 runs as Kmer<64> (128 bits) */
-  const int span_bits = k < 32 ? 64 : 128;
+  const int span_bits = k < 32 ? 64 : k < 64 ? 128 : k < 96 ? 192 : 256;   /* (Kmer<96>: 92 k-mers a super-k-mer, Kmer<128>: 124) */
   int maxs = (span_bits - 8) / 2; if (maxs > 255) maxs = 255; /* Sequence2SuperKmer.hpp:146 */
   const int nbm = k - m + 1;                                /* _nbMinimizers */
   const uint32_t maskm = (uint32_t)(((uint64_t)1 << (2 * m)) - 1);
   const uint64_t DEFAULT_MIN = 1000000000ULL;               /* Model.hpp:1349 */
 
-  uint64_t kmask[2];
-  if (kw == 1) { kmask[0] = (k == 32) ? ~0ULL : (((uint64_t)1 << (2 * k)) - 1); kmask[1] = 0; }
-  else { kmask[0] = ~0ULL; kmask[1] = (k == 64) ? ~0ULL : (((uint64_t)1 << (2 * (k - 32))) - 1); }
+  uint64_t kmask[4] = {0, 0, 0, 0};
+  for (int w = 0; w < kw; w++) {
+    const int bits = 2 * k - 64 * w;
+    kmask[w] = bits >= 64 ? ~0ULL : bits > 0 ? (((uint64_t)1 << bits) - 1) : 0;
+  }
 
   superk_t* sk = (superk_t*)calloc(1, sizeof(superk_t));
   if (!sk) return -1;
   sk->minimizer = DEFAULT_MIN; sk->valid = 0;
 
-  uint64_t fwd[2] = {0, 0}, rev[2] = {0, 0};
+  uint64_t fwd[4] = {0, 0, 0, 0}, rev[4] = {0, 0, 0, 0};
   int bad = -1;
   /* first k-mer: polynom, Model.hpp:636-657, 857-866 */
   for (int i = 0; i < k; i++) {
     unsigned c = nt_code((unsigned char)seq[i]);
-    fwd[1] = (fwd[1] << 2) | (fwd[0] >> 62); fwd[0] = (fwd[0] << 2) + c;
+    for (int w = 3; w > 0; w--) fwd[w] = (fwd[w] << 2) | (fwd[w - 1] >> 62);
+    fwd[0] = (fwd[0] << 2) + c;
     if (!orc_nt_valid((unsigned char)seq[i])) bad = i;
   }
-  fwd[0] &= kmask[0]; fwd[1] &= kmask[1];
+  for (int w = 0; w < 4; w++) fwd[w] &= kmask[w];
   orc_revcomp(fwd, rev, k, kw);
   /* minimizer state, Model.hpp:1254-1287 */
   uint32_t minim = orc_minimizer_of(fwd, k, kw, m, lut);
@@ -320,9 +329,8 @@ int orc_superk_partition(const char* seq, size_t len, int k, int m,
       }
       sk->minimizer = h; sk->valid = 1;
       int w = kw_less(fwd, rev, kw);
-      sk->fwd[sk->n][0] = fwd[0]; sk->fwd[sk->n][1] = fwd[1];
       sk->which[sk->n] = (uint8_t)w;
-      sk->canon[sk->n][0] = w ? fwd[0] : rev[0]; sk->canon[sk->n][1] = w ? fwd[1] : rev[1];
+      for (int q = 0; q < 4; q++) { sk->fwd[sk->n][q] = fwd[q]; sk->canon[sk->n][q] = w ? fwd[q] : rev[q]; }
       sk->n++;
     }
     if (idx >= len) break;
@@ -331,14 +339,15 @@ int orc_superk_partition(const char* seq, size_t len, int k, int m,
     unsigned c = nt_code(ch);
     if (!orc_nt_valid(ch)) bad = k - 1; else bad--;
     is_valid = bad < 0;
-    fwd[1] = ((fwd[1] << 2) | (fwd[0] >> 62)) & kmask[1];
+    for (int w = 3; w > 0; w--) fwd[w] = ((fwd[w] << 2) | (fwd[w - 1] >> 62)) & kmask[w];
     fwd[0] = ((fwd[0] << 2) + c) & kmask[0];
     { /* rev = (rev >> 2) + comp(c) << 2(k-1) */
       uint64_t cc = (uint64_t)(c ^ 2u);
-      rev[0] = (rev[0] >> 2) | (rev[1] << 62); rev[1] >>= 2;
+      for (int w = 0; w < 3; w++) rev[w] = (rev[w] >> 2) | (rev[w + 1] << 62);
+      rev[3] >>= 2;
       int sh = 2 * (k - 1);
-      if (sh < 64) rev[0] |= cc << sh; else rev[1] |= cc << (sh - 64);
-      rev[0] &= kmask[0]; rev[1] &= kmask[1];
+      rev[sh >> 6] |= cc << (sh & 63);
+      for (int w = 0; w < 4; w++) rev[w] &= kmask[w];
     }
     uint32_t mmer = lut[(uint32_t)fwd[0] & maskm];
     pos--;
@@ -371,10 +380,6 @@ int orc_superk_partition_stats(const char* seq, size_t len, int k, int m,
 
 /* ===================================================================== */
 /* count */
-
-/* words of the k-mer type the reference instantiates for k: the first KMER_LIST entry (32 64 96 128, CMakeLists.txt:25-27) above k
- * (loop_executor.hpp:47-63); below 64 this restatement keeps its ceil(k / 32) words (k = 32: one word, as its callers size it) */
-static int kw_of_k(int k) { return k < 64 ? (k + 31) / 32 : k / 32 + 1; }
 
 uint64_t orc_superk_decode(const uint8_t* recs, size_t len, int k, int kw, uint64_t* out)
 { /* sorting_count.hpp:141-312 (decode), canonical = min(fwd, revcomp); keys of up to four words (Kmer<128>) */
