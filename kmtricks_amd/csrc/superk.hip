@@ -332,6 +332,163 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
   }
 }
 
+// ---- k = 64 ... 127 (Kmer<96> / Kmer<128>: the reference's default KMER_LIST "32 64 96 128", CMakeLists.txt:25-27).  The same wave per
+//      read and lane per k-mer position, written for correctness first: a lane's k-mer is up to 127 bits of each plane (two words, from
+//      three ballots), its window holds 50 ... 124 m-mers that start in this chunk's 64 positions or the 128 behind them -- the
+//      minimum over a window comes from a sparse table over the 192 values (spans of 32 and 64, shuffles across the three
+//      registers); a chunk owns 63 k-mers.  Two passes (count, emit), statistics by atomics: the per-partition pass over the sorted
+//      descriptors (k_part_stats) carries the strands of at most 60 k-mers a descriptor.
+__device__ __forceinline__ u32 sk_at(u32 a, u32 b, int d, int lane)      // the value at position lane + d of the 128 positions (a: 0 .. 63, b: 64 .. 127), 0 <= d < 64
+{
+  const int src = (lane + d) & 63;
+  const u32 x = (u32)__shfl((int)a, src), y = (u32)__shfl((int)b, src);
+  return lane + d < 64 ? x : y;
+}
+__device__ __forceinline__ u32 sk_bit(u64 lo, u64 hi, int i) { return (u32)((i < 64 ? lo >> i : hi >> (i - 64)) & 1ULL); }
+// the k bits (lo, hi) in reverse order (bit i <- bit k - 1 - i), 64 <= k <= 127
+__device__ __forceinline__ void sk_rev(u64 lo, u64 hi, int k, u64& rlo, u64& rhi)
+{
+  const u64 RL = __brevll(hi), RH = __brevll(lo);      // the 128 bits reversed: RH:RL
+  const int sft = 128 - k;                             // 1 .. 64
+  if (sft == 64) { rlo = RH; rhi = 0; }
+  else { rlo = (RL >> sft) | (RH << (64 - sft)); rhi = RH >> sft; }
+}
+template <bool EMIT, bool STATS>
+__global__ __launch_bounds__(256)
+void k_superk_wide(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
+                   int k, int m, int maxs, const u16* __restrict__ repart,
+                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so)
+{
+  const int lane = threadIdx.x & 63;
+  const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= n_seqs) return;
+  const u64 b0 = offsets[r], len = offsets[r + 1] - b0;
+  u32 nsk = 0;
+  if (len >= (u64)k) {
+    const char* seq = bases + b0;
+    const int nbm = k - m + 1;                       // m-mers per k-mer: 50 .. 124
+    const u32 own = 63;                              // the 64th k-mer of a chunk only serves as look-ahead
+    const u64 nk = len - (u64)k + 1;
+    const u64 himask = k > 64 ? (1ULL << (k - 64)) - 1ULL : 0ULL;      // the k-mer's bits beyond the first 64
+    const u32 mmask = (1u << m) - 1;
+    u32 out = EMIT ? desc_off[r] : 0;
+    bool pv = false; u32 pmin = 0; u64 run_start = 0, open_start = 0;
+    int pw = 0; u64 t_start = 0, x_start = 0; u32 rf_open = 0;
+    for (u64 p0 = 0; p0 < nk; p0 += own) {
+      const u64 q = p0 + lane;
+      u8 c[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) c[i] = q + 64u * i < len ? (u8)seq[q + 64u * i] : (u8)'N';
+      u64 I[3], A[4], B[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { if (i < 3) I[i] = __ballot(!nt_valid(c[i])); A[i] = __ballot((c[i] >> 1) & 1); B[i] = __ballot((c[i] >> 2) & 1); }
+      auto fun = [&](u64 x, u64 y) { return lane ? (x >> lane) | (y << (64 - lane)) : x; };
+      const u64 fi_lo = fun(I[0], I[1]), fi_hi = fun(I[1], I[2]);
+      const u64 fa_lo = fun(A[0], A[1]), fa_hi = fun(A[1], A[2]), fa_2 = fun(A[2], A[3]);
+      const u64 fb_lo = fun(B[0], B[1]), fb_hi = fun(B[1], B[2]), fb_2 = fun(B[2], B[3]);
+      auto mval = [&](u64 a, u64 b) {      // the m-mer that starts at bit 0 of (a, b): base j is digit m-1-j
+        const u32 y0 = __brev((u32)a & mmask) >> (32 - m), y1 = __brev((u32)b & mmask) >> (32 - m);
+        return mmer_value(spread16(y0) | (spread16(y1) << 1), m);
+      };
+      u32 t0 = mval(fa_lo, fb_lo), t1 = mval(fa_hi, fb_hi), t2 = mval(fa_2, fb_2);      // positions lane, 64 + lane, 128 + lane
+#pragma unroll
+      for (int d = 1; d <= 16; d <<= 1) {      // spans 2, 4, ..., 32
+        const u32 n0 = min(t0, sk_at(t0, t1, d, lane)), n1 = min(t1, sk_at(t1, t2, d, lane)), n2 = min(t2, sk_at(t2, 0xFFFFFFFFu, d, lane));
+        t0 = n0; t1 = n1; t2 = n2;
+      }
+      u32 mini;
+      if (nbm >= 64) {                         // (uniform) two spans of 64
+        const u32 u0 = min(t0, sk_at(t0, t1, 32, lane)), u1 = min(t1, sk_at(t1, t2, 32, lane));
+        const int o = nbm - 64;                // 0 .. 60
+        mini = o ? min(u0, sk_at(u0, u1, o, lane)) : u0;
+      } else mini = min(t0, sk_at(t0, t1, nbm - 32, lane));      // two spans of 32
+      const u64 pk = p0 + lane;
+      const bool valid = pk < nk && fi_lo == 0 && (fi_hi & himask) == 0;
+      u32 pmin_l = (u32)__shfl_up(mini, 1); int pv_l = __shfl_up((int)valid, 1);
+      if (lane == 0) { pmin_l = pmin; pv_l = pv; }
+      const bool brk = valid && (!pv_l || mini != pmin_l);
+      const u64 lowmask = (2ULL << lane) - 1;
+      const u64 Bm = __ballot(brk) & lowmask;
+      const u64 rs = Bm ? p0 + (63 - __clzll(Bm)) : run_start;
+      const bool start = valid && (brk || (u32)((pk - rs) % (u64)maxs) == 0);
+      const u64 Sall = __ballot(start);
+      const int nvalid = __shfl_down((int)valid, 1), nstart = __shfl_down((int)start, 1);
+      const bool owned = (u32)lane < own && pk < nk;
+      const bool endf = valid && owned && (pk + 1 == nk || !nvalid || nstart);
+      const u64 Em = __ballot(endf);
+      u64 ps = 0;
+      if ((EMIT || STATS) && endf) {
+        const u64 sb = Sall & lowmask;
+        ps = sb ? p0 + (63 - __clzll(sb)) : open_start;
+      }
+      const u32 di = out + __popcll(Em & ((1ULL << lane) - 1));
+      if (EMIT && endf) {
+        SkDesc d; d.base = (u32)(b0 + ps); d.part = (u16)repart[mini]; d.n = (u8)(pk - ps + 1); d.pad = 0;
+        desc[di] = d;
+        if (so.keys) { so.keys[di] = d.part; so.ids[di] = di; so.sizes[di] = 1u + ((u32)k + d.n - 1u + 3u) / 4u; }
+      }
+      int w = 0; u64 ts = 0, xs = 0; u32 rf_s = 0;
+      if (STATS) {
+        const u64 fa_h = fa_hi & himask, fb_h = fb_hi & himask;
+        u64 ra_lo, ra_hi, rb_lo, rb_hi;
+        sk_rev(fa_lo, fa_h, k, ra_lo, ra_hi); sk_rev(fb_lo, fb_h, k, rb_lo, rb_hi);
+        const u64 nrb_lo = ~rb_lo, nrb_hi = ~rb_hi & himask;
+        const u64 D_lo = (fa_lo ^ ra_lo) | (fb_lo ^ nrb_lo), D_hi = (fa_h ^ ra_hi) | (fb_h ^ nrb_hi);
+        if (D_lo | D_hi) {
+          const int i0 = D_lo ? __builtin_ctzll(D_lo) : 64 + __builtin_ctzll(D_hi);
+          const u32 xb = sk_bit(fb_lo, fb_h, i0), yb = sk_bit(nrb_lo, nrb_hi, i0), xa = sk_bit(fa_lo, fa_h, i0), ya = sk_bit(ra_lo, ra_hi, i0);
+          w = xb != yb ? xb < yb : xa < ya;
+        }
+        int w_l = __shfl_up(w, 1); if (lane == 0) w_l = pw;
+        const bool T = valid && (start || w != w_l);
+        const u64 Tm = __ballot(T) & lowmask;
+        ts = Tm ? p0 + (63 - __clzll(Tm)) : t_start;
+        const bool X = valid && (T || (u32)((pk - ts) % 5u) == 0);
+        const u64 Xall = __ballot(X);
+        const int nX = __shfl_down((int)X, 1);
+        const bool xend = valid && owned && (endf || nX);
+        const u64 xm = Xall & lowmask;
+        xs = xm ? p0 + (63 - __clzll(xm)) : x_start;
+        u32 rf = 0, rr = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          rf |= ((((u32)(fb_lo >> j) & 1u) << 1) | ((u32)(fa_lo >> j) & 1u)) << (6 - 2 * j);
+          rr |= (((sk_bit(fb_lo, fb_h, k - 1 - j) ^ 1u) << 1) | sk_bit(fa_lo, fa_h, k - 1 - j)) << (6 - 2 * j);
+        }
+        rf_s = (u32)__shfl((int)rf, xs >= p0 ? (int)(xs - p0) : 0);
+        if (xs < p0) rf_s = rf_open;
+        if (xend) {
+          const u32 x = (u32)(pk - xs), radix = w ? rf_s : rr;
+          if (S.pc) atomicAdd(&S.pc[((u32)repart[mini] * 5u + x) * 256u + radix], 1u);
+          if (S.mx) atomicAdd(&S.mx[mini], 1u);
+        }
+        if (endf) {
+          if (S.ms) atomicAdd(&S.ms[mini], 1u);
+          if (S.mk) atomicAdd(&S.mk[mini], (u32)(pk - ps + 1));
+        }
+      }
+      const u32 ne = (u32)__popcll(Em);
+      nsk += ne; out += ne;
+      const u64 rem = nk - p0;
+      const int lo = (int)(rem < (u64)own ? rem : (u64)own) - 1;
+      pv = __builtin_amdgcn_readlane((int)valid, lo) != 0;
+      pmin = (u32)__builtin_amdgcn_readlane((int)mini, lo);
+      if (pv) {
+        run_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)rs, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(rs >> 32), lo) << 32);
+        const u64 sb = Sall & ((2ULL << lo) - 1);
+        if (sb) open_start = p0 + (63 - __clzll(sb));
+      }
+      if (STATS) {
+        pw = __builtin_amdgcn_readlane(w, lo);
+        t_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)ts, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ts >> 32), lo) << 32);
+        x_start = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)xs, lo) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(xs >> 32), lo) << 32);
+        rf_open = (u32)__builtin_amdgcn_readlane((int)rf_s, lo);
+      }
+    }
+  }
+  if (!EMIT && lane == 0) { counts[r] = nsk; if (r == 0) counts[n_seqs] = 0; }
+}
+
 __global__ void k_superk_gather_sizes(const u32* __restrict__ ids, const u32* __restrict__ sizes_unsorted, u32 n, u64* __restrict__ sizes_sorted)
 {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -676,7 +833,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   const bool want_streams = out_bytes != nullptr;
   if (!offsets || (!repart && want_streams) || (want_streams && (!out_len || !out_kmers)) || (!want_streams && !stats) || nb_parts == 0 || nb_parts > 65535)
     return ctx->fail(KMX_E_INVAL, "kmx_superk_partition: bad argument");
-  if (k < 8 || k > 63 || m < 4 || m > 15 || m > k) return ctx->fail(KMX_E_UNSUPPORTED, "k outside 8..63 or minimizer size outside 4..15");
+  if (k < 8 || k > 127 || m < 4 || m > 15 || m > k) return ctx->fail(KMX_E_UNSUPPORTED, "k outside 8..127 or minimizer size outside 4..15");
+  const bool wide_k = k >= 64;      // Kmer<96> / Kmer<128>: k_superk_wide, two passes, statistics by atomics, counts from the record stream
+  if (wide_k && segs) return ctx->fail(KMX_E_UNSUPPORTED, "k >= 64: one sample per call");
   if (want_streams) for (u32 p = 0; p < nb_parts; p++) { out_bytes[p] = nullptr; out_len[p] = 0; out_kmers[p] = 0; }
   if (n_used) *n_used = 0;
   if (n_superk) *n_superk = 0;
@@ -689,7 +848,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   hipStream_t st = ctx->stream;
   // Type::getSize() of the k-mer type the reference instantiates: k < 32 -> MAX_K 32 (64 bits), else MAX_K 64 (128 bits)
   // (loop_executor.hpp:47-52: first KMER_LIST entry with k < entry) -- so k = 32 already gets 60, not 28
-  const int span_bits = k < 32 ? 64 : 128;
+  const int span_bits = k < 32 ? 64 : k < 64 ? 128 : k < 96 ? 192 : 256;
   int maxs = (span_bits - 8) / 2; if (maxs > 255) maxs = 255;   // Sequence2SuperKmer.hpp:146
   const u64 nm = 1ULL << (2 * m);
 
@@ -745,9 +904,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if (repart) { if (rep_upload && (e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) { ctx->rep_host = nullptr; return fail(e, "upload repartition"); } }
   else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
   // (KMX_SUPERK_ONE_PASS: see below; KMX_STATS_ATOMICS=1: the statistics by atomics while the reads are walked, as rounds 1-3 had them)
-  const bool two_pass = getenv("KMX_SUPERK_ONE_PASS") == nullptr || segs;      // (read per call: the tests switch it)
+  const bool two_pass = getenv("KMX_SUPERK_ONE_PASS") == nullptr || segs || wide_k;      // (read per call: the tests switch it)
   StatsDev sd;
-  sd.want_defer = two_pass && want_streams && getenv("KMX_STATS_ATOMICS") == nullptr;
+  sd.want_defer = two_pass && want_streams && getenv("KMX_STATS_ATOMICS") == nullptr && !wide_k;
   { const int rc = sd.alloc(ctx, stats, raw, nb_parts, nm, blocks, st, n_smp); if (rc != KMX_OK) { release(); return rc; } }
   if (raw) for (u32 i = 0; i < n_smp; i++) { raw[i].nb_superk = 0; raw[i].minim_sparse_n = 0; }
   const dim3 g1((unsigned)((n_seqs + 3) / 4)), b1(256);   // one wave per read
@@ -756,6 +915,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     if (sampling) {
       // the shortest prefix of the reads that holds more than `budget` super-k-mers (the reference's iterator is cancelled by the
       // super-k-mer that brings the count past the sample size, and stops before the next read; RepartitionAlgorithm.cpp:205-211)
+      if (wide_k) hipLaunchKernelGGL((k_superk_wide<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                                     (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
+      else
       hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                          (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu);
       std::vector<u32> cnt(n_seqs);
@@ -766,6 +928,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     }
     if (n_used) *n_used = use;
     const dim3 gs((unsigned)((use + 3) / 4));
+    if (wide_k) hipLaunchKernelGGL((k_superk_wide<false, true>), gs, b1, 0, st, d_bases, d_offs, (u64)use, (int)k, (int)m, maxs, d_rep, d_cnt,
+                                   (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
+    else
     hipLaunchKernelGGL((k_superk_wave<false, true>), gs, b1, 0, st, d_bases, d_offs, (u64)use, (int)k, (int)m, maxs, d_rep, d_cnt,
                        (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_superk_wave");
@@ -823,6 +988,9 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     }
   }
   if (!emitted) {
+    if (wide_k) hipLaunchKernelGGL((k_superk_wide<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                                   (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr});
+    else
     hipLaunchKernelGGL((k_superk_wave<false, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                        (const u32*)nullptr, (SkDesc*)nullptr, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu);
     size_t tb = 0;
@@ -861,6 +1029,11 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       if (!sd.S.sk_rec) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
       hipLaunchKernelGGL((k_superk_wave<true, true, false, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                          (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{}, mu);
+    } else if (wide_k) {
+      if (sd.any()) hipLaunchKernelGGL((k_superk_wide<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                                       (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz});
+      else hipLaunchKernelGGL((k_superk_wide<true, false>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
+                              (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz});
     } else
     if (sd.any()) hipLaunchKernelGGL((k_superk_wave<true, true>), g1, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_cnt,
                                       (const u32*)d_doff, d_desc, sd.S, SkSort{d_keys, d_ids, d_sz}, SkLook{}, mu);
@@ -876,7 +1049,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   if ((e = rocprim::radix_sort_pairs(d_tmp2, tb2, d_keys, d_keys2, d_ids, d_ids2, (size_t)nd, 0, 16, st)) != hipSuccess) return fail(e, "sort");
   // counting without the super-k-mer files: the record stream is never written -- the k-mers are cut from the bases themselves
   // (2 bits each, k_pack_bases), a record being where its first base lies
-  const bool direct = creq && !streams_to_host;
+  const bool direct = creq && !streams_to_host && !wide_k;
   u32* d_sbase = nullptr; u64* d_words = nullptr;
   if (direct) {
     d_sbase = (u32*)ctx->dalloc((size_t)nd * 4); d_words = (u64*)ctx->dalloc(((size_t)total_bases / 32 + 4) * 8);

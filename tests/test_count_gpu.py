@@ -192,7 +192,8 @@ def test_superk_partition_reference_goldens(ctx):
             assert got[p][0] == exp[p][0] and got[p][1] == exp[p][1]
 
 
-@pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4), (12, 4, 2)])
+@pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4), (12, 4, 2),
+                                   (64, 10, 8), (64, 15, 4), (77, 11, 5), (95, 10, 16), (96, 4, 3), (111, 12, 8), (127, 10, 32), (127, 4, 2)])
 def test_superk_statistics_vs_oracle(ctx, k, m, P):
     """PartiInfo<5> from the HIP split (fill_partitions.hpp:67-102): kx-mer / radix counters per partition, super-k-mers,
     k-mers and kx-mers per minimizer; long reads (strand runs and kx-mers that straddle the 64-position chunks),
@@ -296,7 +297,8 @@ def test_abundance_histogram_vs_oracle(ctx, monkeypatch, path):
         ctx.hist_read(1, 256)
 
 
-@pytest.mark.parametrize("k,m,P,hard_min,hashed", [(31, 10, 8, 1, False), (31, 10, 8, 2, True), (63, 10, 32, 2, False), (21, 8, 5, 3, False), (32, 10, 16, 1, True)])
+@pytest.mark.parametrize("k,m,P,hard_min,hashed", [(31, 10, 8, 1, False), (31, 10, 8, 2, True), (63, 10, 32, 2, False), (21, 8, 5, 3, False), (32, 10, 16, 1, True),
+                                                   (64, 10, 8, 1, False), (95, 11, 5, 2, True), (96, 10, 16, 2, False), (127, 12, 8, 1, True), (127, 10, 4, 1, False)])
 def test_count_reads_fused_vs_oracle(ctx, k, m, P, hard_min, hashed):
     """kmx_count_reads (split + count with the streams resident in HBM) == oracle split, then oracle count of every partition;
     the streams it can hand back are the split's, the info numbers those of the skp block framing"""
@@ -327,7 +329,8 @@ def test_count_reads_fused_vs_oracle(ctx, k, m, P, hard_min, hashed):
 
 
 @pytest.mark.parametrize("passes", ["one", "two", "long-read"])
-@pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4)])
+@pytest.mark.parametrize("k,m,P", [(31, 10, 8), (21, 8, 5), (32, 10, 16), (47, 11, 3), (63, 10, 32), (20, 7, 4),
+                                   (64, 10, 8), (65, 15, 3), (90, 9, 16), (96, 10, 8), (113, 13, 5), (127, 10, 32)])
 def test_superk_partition_random_reads_vs_oracle(ctx, monkeypatch, k, m, P, passes):
     lut = orc.minimizer_lut(m)
     rep = orc.repart_static(m, P)
