@@ -178,8 +178,8 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
   (void)nrec_s;
 }
 
-// ---- keys of three and four words: k = 64 ... 95 (Kmer<96>) and 96 ... 127 (Kmer<128>), the reference's default KMER_LIST "32 64 96 128"
-//      (CMakeLists.txt:25-27, kmer.hpp:164-630).  Correct first: a lane per k-mer as above, the record's integer S in nine registers'
+// ---- k = 64 ... 95 (Kmer<96>) and 96 ... 127 (Kmer<128>), the reference's default KMER_LIST "32 64 96 128" (CMakeLists.txt:25-27,
+//      kmer.hpp:164-630): keys of ceil(k / 32) words (kmer.hpp:215) -- two at k = 64, three up to 96, four beyond.  Correct first: a lane per k-mer as above, the record's integer S in nine registers'
 //      worth of words, multi-word shifts; a super-k-mer holds up to 92 / 124 k-mers there (Sequence2SuperKmer.hpp:146: (bits - 8) / 2).
 template <int NW> __device__ __forceinline__ void w_shr(const u64* a, u32 bits, u64* out)      // out = a >> bits (bits < 64 NW)
 {
@@ -930,8 +930,9 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
                             const std::vector<u64>& kmoff, const std::vector<u64>& pid, u32 k, int hash_mode, u64 window, u32 hard_min, const CountOut& co,
                             const u32* d_sbase = nullptr /* set: d_recs are packed bases (k_pack_bases), record i starts at base d_sbase[i] */)
 {
-  const int kw = k < 64 ? (k + 31) / 32 : k / 32 + 1;      // (from 64 on: Kmer<96> / Kmer<128>, loop_executor.hpp:47-63)
-  if (kw > 2 && d_sbase) return ctx->fail(KMX_E_UNSUPPORTED, "k >= 64: counted from super-k-mer records (kmx_count_batch)");
+  const int kw = (k + 31) / 32;      // (kmer.hpp:215: the words files, hashes and comparisons see -- two at k = 64, three up to 96, four beyond)
+  const bool wide_k = k >= 64;       // Kmer<96> / Kmer<128> (loop_executor.hpp:47-63): records of up to 92 / 124 k-mers, k_superk_decode_wide
+  if (wide_k && d_sbase) return ctx->fail(KMX_E_UNSUPPORTED, "k >= 64: counted from super-k-mer records (kmx_count_batch)");
   const size_t key_bytes = hash_mode ? 8 : (size_t)kw * 8;
   const u32 NB = (u32)((total + DK - 1) / DK);
   u64* d_pid = (u64*)ctx->dalloc(pid.empty() ? 8 : (size_t)n_parts * 8);      // (pid empty: partition p has id p, nothing to upload)
@@ -949,9 +950,10 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
   hipLaunchKernelGGL(k_decode_block_starts, dim3((nr + 255) / 256), dim3(256), 0, st, d_prefix, nr, d_blk);
   const dim3 grid(NB), block(256);
 #define KMX_DECODE(KW_, H_, D_) hipLaunchKernelGGL((k_superk_decode_kmers<KW_, H_, D_>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, d_keys, d_sbase)
-  if (kw > 2) {
+  if (wide_k) {
 #define KMX_DECODE_W(KW_, H_) hipLaunchKernelGGL((k_superk_decode_wide<KW_, H_>), grid, block, 0, st, d_recs, d_prefix, d_blk, d_rpart, d_pid_arg, nr, (u32)total, (int)k, window, (u64*)d_keys)
-    if (kw == 3 && !hash_mode) KMX_DECODE_W(3, 0); else if (kw == 3) KMX_DECODE_W(3, 1); else if (!hash_mode) KMX_DECODE_W(4, 0); else KMX_DECODE_W(4, 1);
+    if (kw == 2 && !hash_mode) KMX_DECODE_W(2, 0); else if (kw == 2) KMX_DECODE_W(2, 1);      // (k = 64: two words, the records of a Kmer<96>)
+    else if (kw == 3 && !hash_mode) KMX_DECODE_W(3, 0); else if (kw == 3) KMX_DECODE_W(3, 1); else if (!hash_mode) KMX_DECODE_W(4, 0); else KMX_DECODE_W(4, 1);
 #undef KMX_DECODE_W
   } else if (d_sbase) {
     if (kw == 1 && !hash_mode) KMX_DECODE(1, 0, true); else if (kw == 1) KMX_DECODE(1, 1, true); else if (!hash_mode) KMX_DECODE(2, 0, true); else KMX_DECODE(2, 1, true);

@@ -40,7 +40,7 @@ constexpr int CAP = KMX_ROWS_CAP;  // record slots per tile
 // KLBYTES = CAP * 2 + 4096 for the kept keys: u16 table slots [CAP] + fast-path key copies (4 KiB)
 constexpr int WGS_PER_CU = (TPB <= 512 && (CAP * 8 + 2 * CAP * 4 + CAP * 2 + 4096 + 384) * 2 <= 160 * 1024) ? 2 : 1;   // KW = 1: LDS and 128-VGPR budget
 constexpr int NWAVE = TPB / 64;
-// keys of three and four words (k = 64 ... 127, Kmer<96> / Kmer<128>; include/kmtricks/kmer.hpp:164-630 of the reference): half the record
+// keys of three and four words (k = 65 ... 96 and 97 ... 127: ceil(k / 32) words of a Kmer<96> / Kmer<128>; include/kmtricks/kmer.hpp:164-630, :215 of the reference): half the record
 // slots per tile -- the staged keys of 4096 slots alone would be 128 KB of the 160 KB, and a thread's keys leave the registers
 __host__ __device__ constexpr int cap_of(int kw) { return kw <= 2 ? CAP : CAP / 2; }
 

@@ -130,8 +130,8 @@ EXPORTS = ["kmx_copy_to_host_async", "kmx_copy_wait", "kmx_reads_upload", "kmx_r
 
 
 def key_words_of(k):
-    """64-bit words of a k-mer key: ceil(k / 32) below 64; 3 for 64 ... 95 and 4 for 96 ... 127 (the reference's Kmer<96> / Kmer<128>)"""
-    return (k + 31) // 32 if k < 64 else k // 32 + 1
+    """64-bit words of a k-mer key: ceil(k / 32) (kmer.hpp:215 m_n_data; io/kmer_file.hpp:84 kmer_slots) -- 3 for 65 ... 96, 4 for 97 ... 127"""
+    return (k + 31) // 32
 
 
 class KmxError(RuntimeError):

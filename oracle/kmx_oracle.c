@@ -67,9 +67,10 @@ static inline unsigned nt_code(unsigned char c) { return (c >> 1) & 3u; } /* A0 
 static inline unsigned kw_digit(const uint64_t* w, int i) { return (unsigned)(w[i >> 5] >> ((i & 31) * 2)) & 3u; }
 static inline void kw_set_digit(uint64_t* w, int i, unsigned d) { w[i >> 5] |= (uint64_t)d << ((i & 31) * 2); }
 
-/* words of the k-mer type the reference instantiates for k: the first KMER_LIST entry (32 64 96 128, CMakeLists.txt:25-27) above k
- * (loop_executor.hpp:47-63); below 64 this restatement keeps its ceil(k / 32) words (k = 32: one word, as its callers size it) */
-static int kw_of_k(int k) { return k < 64 ? (k + 31) / 32 : k / 32 + 1; }
+/* words of a k-mer as files, hashes and comparisons see it: ceil(k / 32) (kmer.hpp:215 m_n_data, io/kmer_file.hpp:84 kmer_slots,
+ * gatb/sorting_count.hpp:351 the hashed bytes) -- whatever Kmer<MAX_K> the reference instantiates for k (the first KMER_LIST entry
+ * 32 64 96 128 above k, loop_executor.hpp:47-63), which only sets how many k-mers a super-k-mer holds: (MAX_K * 2 - 8) / 2 */
+static int kw_of_k(int k) { return (k + 31) / 32; }
 
 static inline int kw_less(const uint64_t* a, const uint64_t* b, int kw)
 { /* most significant word first, kmer.hpp:262-268 */

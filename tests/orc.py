@@ -139,8 +139,8 @@ def repart_sampled(minim_kxmers, nb_parts):
 
 
 def kw_of_k(k):
-    """words of a k-mer: ceil(k / 32) below 64; from 64 on the reference's Kmer<96> / Kmer<128> (loop_executor.hpp:47-63)"""
-    return (k + 31) // 32 if k < 64 else k // 32 + 1
+    """words of a k-mer in files, hashes and comparisons: ceil(k / 32) (kmer.hpp:215), whatever Kmer<MAX_K> holds it"""
+    return (k + 31) // 32
 
 
 def superk_decode(recs: bytes, k):

@@ -118,8 +118,8 @@ def test_count_batch_vs_oracle(ctx, k, m):
 @pytest.mark.parametrize("k", [64, 65, 80, 95, 96, 97, 112, 127])
 def test_count_wide_kmers_vs_oracle(ctx, k):
     """k = 64 ... 127 (Kmer<96> / Kmer<128>; the reference's default KMER_LIST "32 64 96 128", CMakeLists.txt:25-27): kmx_count_batch on
-    super-k-mer record streams of up to 92 / 124 k-mers a record == the oracle per partition (k-mers low word first, window hashes over
-    the 24 / 32 key bytes), == the counts of the strings the records were cut from; then those lists merged (k_merge_rows, 3 / 4 words)"""
+    super-k-mer record streams of up to 92 / 124 k-mers a record == the oracle per partition (k-mers of ceil(k / 32) words, low word
+    first; window hashes over those 16 / 24 / 32 key bytes), == the counts of the strings the records were cut from; then those lists merged (k_merge_rows, 3 / 4 words)"""
     from synth import synth_superk_stream
     P, mx, kw = 5, (92 if k < 96 else 124), orc.kw_of_k(k)
     streams, truth = [], []

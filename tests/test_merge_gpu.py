@@ -113,11 +113,11 @@ def test_synthetic_k63_rows(ctx, case, mode):
 @pytest.mark.parametrize("case", [(1, 400, 1.0, 0, 1, 1, 0), (2, 2500, 0.6, 700, 1, 1, 0), (50, 800, 0.9, 30, 4, 2, 3), (333, 300, 0.97, 7, 10, 50, 20),
                                   (700, 150, 0.95, 5, 1, 2, 0), (2048, 40, 0.9, 2, 3, 1, 100), (4, 20000, 0.3, 6000, 1, 1, 0)])
 @pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
-@pytest.mark.parametrize("kw,k", [(3, 64), (3, 95), (4, 96), (4, 127)])
+@pytest.mark.parametrize("kw,k", [(3, 65), (3, 96), (4, 97), (4, 127)])
 def test_synthetic_wide_key_rows(ctx, merge_kernel, case, mode, kw, k):
-    """keys of three and four words (k = 64 ... 95: Kmer<96>, 96 ... 127: Kmer<128>; the reference's default KMER_LIST "32 64 96 128",
-    CMakeLists.txt:25-27): k_merge_rows whatever kernel is asked for; rows = the key's words low word first + counts / bits"""
-    if merge_kernel != "rows" and k not in (64, 127):
+    """keys of three and four words (k = 65 ... 96 and 97 ... 127, ceil(k / 32) words: kmer.hpp:215; the reference's default KMER_LIST
+    "32 64 96 128", CMakeLists.txt:25-27): k_merge_rows whatever kernel is asked for; rows = the key's words low word first + counts / bits"""
+    if merge_kernel != "rows" and k not in (65, 127):
         pytest.skip("wide keys run on k_merge_rows: one forced kernel suffices for the inner sizes")
     n, pool, pp, npriv, smin, rmin, share = case
     lists = synth_lists(31 * kw + n, n, pool, pp, npriv, kw=kw, key_bits=2 * k)
