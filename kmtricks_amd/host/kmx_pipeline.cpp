@@ -154,8 +154,7 @@ static Opt parse_cli(int argc, char** argv)
   }
   if (o.fof.empty() || o.dir.empty()) die("--file and --run-dir are required");
   if (fs::exists(o.dir)) die("--run-dir already exists: " + o.dir);                  // src/cli.cpp:101-104
-  if (o.k < 8 || o.k > 63) die("--kmer-size must be in [8, 63]: this build is the reference built with KMER_LIST=\"32 64\" (keys of one or two 64-bit words; "
-                                "the reference's default list also has 96 and 128, loop_executor.hpp:47-63)");
+  if (o.k < 8 || o.k > 127) die("--kmer-size must be in [8, 127]: the reference's default KMER_LIST \"32 64 96 128\" (keys of one to four 64-bit words, loop_executor.hpp:47-63)");
   if (o.msize < 4 || o.msize > 15 || o.msize >= o.k) die("--minimizer-size must be in [4, 15] and < k");
   static const char* modes[] = {"kmer:count:bin", "kmer:pa:bin", "hash:count:bin", "hash:pa:bin", "hash:bf:bin", "hash:bfc:bin", "hash:bft:bin"};
   if (std::find_if(std::begin(modes), std::end(modes), [&](const char* m) { return o.mode == m; }) == std::end(modes))
@@ -252,7 +251,8 @@ int run(int argc, char** argv)
   for (uint32_t w = 0; w < NW; w++) { kmx_ctx* x = nullptr; if (kmx_create((int)((w % G) % (uint32_t)ndev), &x) != KMX_OK) die(kmx_last_error(nullptr)); gpu.push_back(x); }
   // count lists resident in HBM between count and merge: one store per shard.  Not with --keep-tmp / --until count (the count
   // files are the product then) nor with --no-resident.
-  const bool resident_mode = !o.keep_tmp && !o.no_resident && (o.until == "all" || o.until == "merge");
+  // (k >= 64 -- Kmer<96> / Kmer<128> -- goes through the count files as well: the wide count path hands its lists back to the host)
+  const bool resident_mode = !o.keep_tmp && !o.no_resident && (o.until == "all" || o.until == "merge") && o.k < 64;
   std::vector<kmx_store*> stores;
   if (resident_mode) {
     for (uint32_t g = 0; g < G; g++) {

@@ -571,6 +571,52 @@ def test_synthetic_multi_sample_pipeline(tmp_path, mode):
     assert total_rows > 50_000
 
 
+@pytest.mark.parametrize("KK,mode", [(64, "kmer:count:bin"), (80, "kmer:pa:bin"), (96, "hash:count:bin"), (97, "kmer:count:bin"), (127, "kmer:pa:bin"), (127, "hash:bf:bin")])
+def test_wide_kmer_pipeline(tmp_path, KK, mode):
+    """k = 64 ... 127 (the reference's default KMER_LIST "32 64 96 128", CMakeLists.txt:25-27: Kmer<96> / Kmer<128>, keys of ceil(k / 32)
+    words) end to end: FASTQ(.gz) -> `kmx pipeline` (split by k_superk_wide, counts through the count files, merged by k_merge_rows) ->
+    every matrix body, header and merge_info against the oracle run stage by stage on the same reads"""
+    NS, GL, PP = 9, 30_000, 4
+    reads = _synthetic_samples(tmp_path, NS, GL, 100 + KK)
+    out = tmp_path / "run"
+    args = [KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out), "--kmer-size", str(KK), "--hard-min", "2",
+            "--nb-partitions", str(PP), "--static-repart", "--mode", mode, "--recurrence-min", "2", "--bloom-size", "400000"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    kw = orc.kw_of_k(KK)
+    lut = orc.minimizer_lut(10); rep = orc.repart_static(10, PP)
+    sk = [orc.superk_partition(rs, KK, 10, lut, rep, PP) for rs in reads]
+    W = struct.unpack("<QQQQI", open(out / "hash.info", "rb").read())[2] if mode.startswith("hash") else 0
+    total_rows = 0
+    for p in range(PP):
+        if mode.startswith("kmer"):
+            lists = [tuple(x if i else x.reshape(-1) for i, x in enumerate(orc.count_kmer(s[p][0], KK, 2))) for s in sk]
+            omode, ext = (orc.MODE_COUNT, "count") if mode == "kmer:count:bin" else (orc.MODE_PA, "pa")
+            body, rows, stats = orc.merge_matrix(lists, kw, [1] * NS, 2, 0, omode)
+            raw = open(out / "matrices" / f"matrix_{p}.{ext}", "rb").read()
+            assert struct.unpack_from("<II", raw, 21) == (KK, kw) and raw[45:] == body
+        elif mode == "hash:count:bin":
+            lists = [orc.count_hash(s[p][0], KK, W, p, 2) for s in sk]
+            body, rows, stats = orc.merge_matrix(lists, 1, [1] * NS, 2, 0, orc.MODE_COUNT)
+            raw = open(out / "matrices" / f"matrix_{p}.count_hash", "rb").read()
+            assert raw[37:] == body
+        else:
+            lists = [orc.count_hash(s[p][0], KK, W, p, 2) for s in sk]
+            body, rows, stats = orc.merge_matrix(lists, 1, [1] * NS, 2, 0, orc.MODE_BF, W * p, W * (p + 1) - 1)
+            raw = open(out / "matrices" / f"matrix_{p}.cmbf", "rb").read()
+            assert raw[49:] == body
+        total_rows += rows
+        mi = [l.split("\t") for l in open(out / "merge_infos" / f"partition{p}.merge_info").read().splitlines()]
+        for rix in range(6):
+            assert [int(x) for x in mi[rix][1:1 + NS]] == [int(x) for x in stats[rix]]
+    assert total_rows > 10_000
+    if mode == "kmer:count:bin":      # the text dump of a matrix: the k-mers as strings (kmer.hpp:797-810), ascending
+        d = subprocess.run([KMX, "dump", "--input", str(out / "matrices" / "matrix_0.count")], capture_output=True, text=True)
+        if d.returncode == 0:
+            first = d.stdout.splitlines()[0].split()
+            assert len(first[0]) == KK and set(first[0]) <= set("ACGT") and len(first) == 1 + NS
+
+
 def test_k63_pa_cohort_pipeline(tmp_path):
     """BASELINE configs[4] in small (200 samples x 40 kbp, k = 63, `kmer:pa:bin`, recurrence-min 1, 4 partitions): the 128-bit-key
     build of the column-blocked merge runs the batches (KMX_TRACE names the kernel), every PA matrix and merge_info equals the oracle's"""
