@@ -106,7 +106,8 @@ typedef struct {
 /* One merge task = one partition (merge.hpp:115-125, 376-385). */
 typedef struct {
   uint32_t        n_lists;     /* N samples, fof order = column order (kmdir.hpp:65-72) */
-  uint32_t        key_words;   /* 1: k <= 31 or hash keys; 2: 32 <= k <= 63 */
+  uint32_t        key_words;   /* ceil(k / 32) (kmer.hpp:215 m_n_data, io/kmer_file.hpp:84 kmer_slots): 1 for k <= 32 and hash keys, 2 up to 64,
+                                  3 up to 96, 4 up to 128.  3 and 4 (the reference's Kmer<96> / Kmer<128>): COUNT / PA rows, at most 2048 lists a task */
   const kmx_list* lists;       /* [n_lists] */
   const uint32_t* soft_min;    /* [n_lists] per-sample abundance min (m_a_min_vec) */
   uint32_t        rec_min;     /* recurrence-min (m_r_min) */
@@ -196,7 +197,10 @@ int kmx_merge(kmx_ctx* ctx, const kmx_merge_task* task, void** body, uint64_t* b
  * (sample, partition) with the u32 block-size framing of skp.<p> removed
  * (io/superk_storage.hpp:215-225).  HOST pointers.  Output: ascending
  * canonical k-mers (key_words = ceil(k/32) words each) with
- * count >= hard_min, saturated to u32; buffers released with kmx_free. */
+ * count >= hard_min, saturated to u32; buffers released with kmx_free.
+ * 8 <= kmer_size <= 127: the reference's default KMER_LIST "32 64 96 128" (CMakeLists.txt:25-27; loop_executor.hpp:47-63 picks
+ * the first entry above k, and that type's width bounds a record: 28 k-mers for k < 32, 60 below 64, 92 below 96, 124 beyond --
+ * Sequence2SuperKmer.hpp:146).  A record that claims more is refused (KMX_E_INVAL), not decoded. */
 int kmx_count_kmer(kmx_ctx* ctx, const uint8_t* superk, uint64_t len, uint32_t kmer_size,
                    uint32_t hard_min, uint64_t** keys, uint32_t** counts, uint64_t* n_out);
 /* window hashes XXH64(words, 8*ceil(k/32), 0) % window + window * partition */
@@ -224,7 +228,10 @@ int kmx_transpose_bits(kmx_ctx* ctx, const uint8_t* in, uint64_t nrows, uint64_t
  * into super-k-mers and returns, per partition, the concatenated 2-bit records
  * (same bytes the reference buffers before block framing).  repart: u16[4^m]
  * minimizer -> partition table.  out_bytes[p] / out_len[p] / out_kmers[p] are
- * arrays of nb_parts entries; each out_bytes[p] is released with kmx_free. */
+ * arrays of nb_parts entries; each out_bytes[p] is released with kmx_free.
+ * 8 <= kmer_size <= 127, 4 <= minim_size <= 15.  From k = 64 on (Kmer<96> / Kmer<128>) the split, its statistics, the sampling pass
+ * and kmx_count_reads work as below that; the device-resident variants (kmx_count_reads_dev with three- and four-word keys,
+ * kmx_count_reads_dev_multi) answer KMX_E_UNSUPPORTED -- `kmx pipeline` takes k >= 64 through the count files. */
 int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
                          uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart,
                          uint32_t nb_parts, uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers);
