@@ -469,6 +469,11 @@ struct CountOut {
   bool dev() const { return lists != nullptr; }
 };
 
+template <int KW> struct WideKey { u64 w[KW]; };      // keys of three and four words (k = 65 ... 127), low word first
+template <typename KeyT> __device__ __forceinline__ u32 key_dword(const KeyT& k, u32 w) { return (u32)(k >> (32 * w)); }
+template <> __device__ __forceinline__ u32 key_dword<WideKey<3>>(const WideKey<3>& k, u32 w) { return (u32)(k.w[w >> 1] >> (32 * (w & 1))); }
+template <> __device__ __forceinline__ u32 key_dword<WideKey<4>>(const WideKey<4>& k, u32 w) { return (u32)(k.w[w >> 1] >> (32 * (w & 1))); }
+
 template <typename KeyT>
 __global__ __launch_bounds__(256)
 void k_pack_recs(const KeyT* __restrict__ keys, const u32* __restrict__ cnt, u32 n, const u32* __restrict__ bounds, u32 n_parts,
@@ -482,7 +487,7 @@ void k_pack_recs(const KeyT* __restrict__ keys, const u32* __restrict__ cnt, u32
   u32* o = reinterpret_cast<u32*>(out + (pdst[lo] + (i - bounds[lo])) * (u64)(sizeof(KeyT) + 4));
   const KeyT k = keys[i];
 #pragma unroll
-  for (u32 w = 0; w < KWD; w++) o[w] = (u32)(k >> (32 * w));
+  for (u32 w = 0; w < KWD; w++) o[w] = key_dword<KeyT>(k, w);
   o[KWD] = cnt[i];
 }
 
@@ -840,10 +845,9 @@ static int batch_sort_rle(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, u16* d_kp
 
 // ---- keys of three and four words (k = 64 ... 127): sorted word by word (the library's stable radix sort on 64-bit keys, least
 //      significant word first, the partition last), runs counted by head flags + scans.  d_keys: total keys of kw words, partition p =
-//      k-mers [kmoff[p], kmoff[p + 1]).  Host output only (kmx_count_batch): keys[p] = n_out[p] * kw words, low word first ----
+//      k-mers [kmoff[p], kmoff[p + 1]).  Host output: keys[p] = n_out[p] * kw words, low word first; or packed records in the stores ----
 static int wide_sort_count(kmx_ctx* ctx, StageClock& clk, const u64* d_keys, int kw, const std::vector<u64>& kmoff, u32 n_parts, u32 total, u32 hard_min, const CountOut& co)
 {
-  if (co.dev()) return ctx->fail(KMX_E_UNSUPPORTED, "k >= 64: counts are handed back to the host (kmx_count_batch)");
   hipStream_t st = ctx->stream; hipError_t e;
   std::vector<void*> blocks;
   auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
@@ -900,17 +904,26 @@ static int wide_sort_count(kmx_ctx* ctx, StageClock& clk, const u64* d_keys, int
   const u32 kept = last[0] + last[1];
   clk.mark("rle");
   std::vector<u32> bounds(n_parts + 1, 0);
-  std::vector<u64> h_k((size_t)kept * kw); std::vector<u32> h_c(kept);
+  std::vector<u64> h_k(co.dev() ? 0 : (size_t)kept * kw); std::vector<u32> h_c(co.dev() ? 0 : kept);
   if (kept) {
     u64* d_ok = (u64*)get((size_t)kept * kw * 8); u32* d_oc = (u32*)get((size_t)kept * 4); u16* d_op = (u16*)get((size_t)kept * 2);
     if (!d_ok || !d_oc || !d_op) { release(); return ctx->fail(KMX_E_NOMEM, "count (k >= 64): device allocation failed"); }
     hipLaunchKernelGGL(k_wide_emit, gr, b256, 0, st, d_keys, d_perm, d_sp, d_start, d_cnt, d_keep, d_pos, runs, kw, d_ok, d_oc, d_op);
     hipLaunchKernelGGL(k_part_bounds, dim3((n_parts + 256) / 256), b256, 0, st, d_op, kept, n_parts, d_bounds);
+    if (co.dev()) {      // (kmx_count_reads_dev: the kept pairs become packed records in the stores of the GPUs that merge them)
+      if ((e = hipMemcpyAsync(bounds.data(), d_bounds, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "sync");
+      const int rc = kw == 3 ? pack_to_stores<WideKey<3>>(ctx, (const WideKey<3>*)d_ok, d_oc, bounds, n_parts, co)
+                             : pack_to_stores<WideKey<4>>(ctx, (const WideKey<4>*)d_ok, d_oc, bounds, n_parts, co);
+      release();
+      clk.mark("pack");
+      return rc;
+    }
     if ((e = hipMemcpyAsync(bounds.data(), d_bounds, ((size_t)n_parts + 1) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (e = hipMemcpyAsync(h_k.data(), d_ok, (size_t)kept * kw * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (e = hipMemcpyAsync(h_c.data(), d_oc, (size_t)kept * 4, hipMemcpyDeviceToHost, st)) != hipSuccess || (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "download");
   }
   release();
+  if (co.dev()) { for (u32 p = 0; p < n_parts; p++) { co.lists[p].recs = nullptr; co.lists[p].n = 0; } return KMX_OK; }      // (nothing kept)
   for (u32 p = 0; p < n_parts; p++) {
     const size_t n = bounds[p + 1] - bounds[p];
     co.keys[p] = (uint64_t*)malloc(n ? n * kw * 8 : 8);

@@ -251,8 +251,7 @@ int run(int argc, char** argv)
   for (uint32_t w = 0; w < NW; w++) { kmx_ctx* x = nullptr; if (kmx_create((int)((w % G) % (uint32_t)ndev), &x) != KMX_OK) die(kmx_last_error(nullptr)); gpu.push_back(x); }
   // count lists resident in HBM between count and merge: one store per shard.  Not with --keep-tmp / --until count (the count
   // files are the product then) nor with --no-resident.
-  // (k >= 64 -- Kmer<96> / Kmer<128> -- goes through the count files as well: the wide count path hands its lists back to the host)
-  const bool resident_mode = !o.keep_tmp && !o.no_resident && (o.until == "all" || o.until == "merge") && o.k < 64;
+  const bool resident_mode = !o.keep_tmp && !o.no_resident && (o.until == "all" || o.until == "merge");
   std::vector<kmx_store*> stores;
   if (resident_mode) {
     for (uint32_t g = 0; g < G; g++) {

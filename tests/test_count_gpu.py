@@ -352,7 +352,8 @@ def test_superk_partition_random_reads_vs_oracle(ctx, monkeypatch, k, m, P, pass
 
 @pytest.mark.parametrize("stats_by", ["partition", "atomics"])
 @pytest.mark.parametrize("k,m,P,hard_min,hashed,G", [(31, 10, 8, 1, False, 1), (31, 10, 8, 2, True, 2), (63, 10, 32, 2, False, 3), (21, 8, 5, 3, False, 2), (32, 10, 16, 1, True, 1),
-                                                      (31, 10, 2, 1, False, 2), (40, 12, 3, 1, False, 2)])
+                                                      (31, 10, 2, 1, False, 2), (40, 12, 3, 1, False, 2),
+                                                      (64, 10, 8, 2, False, 3), (80, 10, 8, 1, False, 2), (96, 10, 4, 1, True, 2), (97, 11, 3, 1, False, 1), (127, 12, 5, 2, False, 1)])
 def test_count_reads_dev_vs_oracle(ctx, k, m, P, hard_min, hashed, G, stats_by, monkeypatch):
     """kmx_count_reads_dev: the counts stay in HBM as packed .kmer-body records, partition p in store p % G (what the merge stage
     of GPU p % G reads); read back they are the oracle's counts, merged where they lie (kmx_merge_dev) they give the oracle's
