@@ -230,8 +230,8 @@ int kmx_transpose_bits(kmx_ctx* ctx, const uint8_t* in, uint64_t nrows, uint64_t
  * minimizer -> partition table.  out_bytes[p] / out_len[p] / out_kmers[p] are
  * arrays of nb_parts entries; each out_bytes[p] is released with kmx_free.
  * 8 <= kmer_size <= 127, 4 <= minim_size <= 15.  From k = 64 on (Kmer<96> / Kmer<128>) the split, its statistics, the sampling pass
- * and kmx_count_reads work as below that; the device-resident variants (kmx_count_reads_dev with three- and four-word keys,
- * kmx_count_reads_dev_multi) answer KMX_E_UNSUPPORTED -- `kmx pipeline` takes k >= 64 through the count files. */
+ * kmx_count_reads and kmx_count_reads_dev work as below that; kmx_count_reads_dev_multi (several samples a call) answers
+ * KMX_E_UNSUPPORTED there. */
 int kmx_superk_partition(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
                          uint32_t kmer_size, uint32_t minim_size, const uint16_t* repart,
                          uint32_t nb_parts, uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers);
