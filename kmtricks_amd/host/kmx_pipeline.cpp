@@ -1168,7 +1168,7 @@ int run(int argc, char** argv)
               else {   // the plugin's return value replaces the recurrence test: every row was produced, filter here
                 const uint32_t kb = T.key_words * 8; const size_t rb = kb + 4ull * N;
                 std::vector<km::IMergePlugin::count_type> cv(N); std::vector<uint8_t> pa((N + 7) / 8);
-                uint64_t last_key[2] = {0, 0};
+                uint64_t last_key[4] = {0, 0, 0, 0};      // (up to Kmer<128>)
                 for (uint64_t r = 0; r <= rows; r++) {   // r == rows: the reference's extra call after the last row (merge.hpp:185-259)
                   const uint8_t* row = body->data() + r * rb;
                   if (r < rows) { memcpy(last_key, row, kb); for (uint32_t i = 0; i < N; i++) { uint32_t v; memcpy(&v, row + kb + 4 * i, 4); cv[i] = (km::IMergePlugin::count_type)v; } }

@@ -617,6 +617,28 @@ def test_wide_kmer_pipeline(tmp_path, KK, mode):
             assert len(first[0]) == KK and set(first[0]) <= set("ACGT") and len(first) == 1 + NS
 
 
+def test_wide_kmer_plugin_pipeline(tmp_path):
+    """--plugin at k = 97 (rows of four-word keys reach process_kmer as the reference's Kmer<128>::get_data64() would hand them):
+    the test plugin doubles sample 0's count of every row it keeps"""
+    NS, GL, PP, KK = 3, 20_000, 4, 97
+    reads = _synthetic_samples(tmp_path, NS, GL, 5)
+    out = tmp_path / "run"
+    plug = os.path.join(ROOT, "kmtricks_amd", "libkmx_test_plugin.so")
+    r = subprocess.run([KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--run-dir", str(out), "--kmer-size", str(KK), "--hard-min", "1",
+                        "--nb-partitions", str(PP), "--static-repart", "--mode", "kmer:count:bin", "--plugin", plug, "--plugin-config", "0"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    kw = orc.kw_of_k(KK)
+    lut = orc.minimizer_lut(10); rep = orc.repart_static(10, PP)
+    sk = [orc.superk_partition(rs, KK, 10, lut, rep, PP) for rs in reads]
+    for p in range(PP):
+        lists = [tuple(x if i else x.reshape(-1) for i, x in enumerate(orc.count_kmer(s[p][0], KK, 1))) for s in sk]
+        body, rows, _ = orc.merge_matrix(lists, kw, [1] * NS, 0, 0, orc.MODE_COUNT)
+        exp = np.frombuffer(body, np.uint8).reshape(rows, kw * 8 + 4 * NS).copy()
+        c0 = exp[:, kw * 8:kw * 8 + 4].copy().view(np.uint32); c0 *= 2; exp[:, kw * 8:kw * 8 + 4] = c0.view(np.uint8)
+        assert rows > 1000 and open(out / "matrices" / f"matrix_{p}.count", "rb").read()[45:] == exp.tobytes()
+
+
 def test_k63_pa_cohort_pipeline(tmp_path):
     """BASELINE configs[4] in small (200 samples x 40 kbp, k = 63, `kmer:pa:bin`, recurrence-min 1, 4 partitions): the 128-bit-key
     build of the column-blocked merge runs the batches (KMX_TRACE names the kernel), every PA matrix and merge_info equals the oracle's"""
