@@ -617,6 +617,37 @@ def test_wide_kmer_pipeline(tmp_path, KK, mode):
             assert len(first[0]) == KK and set(first[0]) <= set("ACGT") and len(first) == 1 + NS
 
 
+@pytest.mark.parametrize("KK", [80, 127])
+def test_wide_kmer_pipeline_through_files(tmp_path, KK):
+    """k >= 64 with --keep-tmp --hist (super-k-mer and count files written and read back; the abundance histograms) and with --cpr:
+    the matrices of the plain run; the count files hold the oracle's lists with ceil(k / 32)-word keys; histograms as KHist gives them"""
+    NS, GL, PP = 4, 30_000, 4
+    reads = _synthetic_samples(tmp_path, NS, GL, 300 + KK)
+    base = [KMX, "pipeline", "--file", str(tmp_path / "syn.fof"), "--kmer-size", str(KK), "--hard-min", "2", "--nb-partitions", str(PP), "--static-repart",
+            "--mode", "kmer:count:bin"]
+    for name, extra in (("plain", []), ("files", ["--keep-tmp", "--hist"]), ("cpr", ["--cpr"])):
+        r = subprocess.run(base + ["--run-dir", str(tmp_path / name)] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr)
+    kw = orc.kw_of_k(KK)
+    lut = orc.minimizer_lut(10); rep = orc.repart_static(10, PP)
+    sk = [orc.superk_partition(rs, KK, 10, lut, rep, PP) for rs in reads]
+    for p in range(PP):
+        plain = open(tmp_path / "plain" / "matrices" / f"matrix_{p}.count", "rb").read()
+        assert plain == open(tmp_path / "files" / "matrices" / f"matrix_{p}.count", "rb").read() and len(plain) > 45 + 1000 * (kw * 8 + 4 * NS)
+        d = subprocess.run([KMX, "dump", "--input", str(tmp_path / "cpr" / "matrices" / f"matrix_{p}.count.lz4")], capture_output=True, text=True)
+        d0 = subprocess.run([KMX, "dump", "--input", str(tmp_path / "plain" / "matrices" / f"matrix_{p}.count")], capture_output=True, text=True)
+        assert d.returncode == 0 and d0.returncode == 0 and d.stdout == d0.stdout, (d.stderr, d0.stderr)
+        first = d0.stdout.splitlines()[0].split()
+        assert len(first[0]) == KK and set(first[0]) <= set("ACGT") and len(first) == 1 + NS
+        for si in range(NS):
+            f = kmfiles.read_kmer_file(tmp_path / "files" / "counts" / f"partition_{p}" / f"S{si:04d}.kmer")
+            ek, ec = orc.count_kmer(sk[si][p][0], KK, 2)
+            assert (f["k"], f["slots"]) == (KK, kw) and np.array_equal(f["keys"], ek) and np.array_equal(f["counts"], ec)
+    for si in range(NS):
+        exp, _ = _hist_bytes(KK, si, [orc.count_kmer(sk[si][p][0], KK, 1)[1] for p in range(PP)])
+        assert open(tmp_path / "files" / "histograms" / f"S{si:04d}.hist", "rb").read() == exp
+
+
 def test_wide_kmer_plugin_pipeline(tmp_path):
     """--plugin at k = 97 (rows of four-word keys reach process_kmer as the reference's Kmer<128>::get_data64() would hand them):
     the test plugin doubles sample 0's count of every row it keeps"""
