@@ -29,3 +29,23 @@ def test_no_cpu_fallback_without_device():
     from kmtricks_amd import lib
     with pytest.raises(lib.KmxError, match="no HIP device"):
         lib.Context(0)
+
+
+def test_product_never_reaches_the_oracle():
+    """The oracle is test infrastructure: nothing under kmtricks_amd/ or include/ may include, link, dlopen or execute anything under
+    oracle/ (bench.py may, in its cpu_baseline legs only -- that is checked by reading where it uses `orc`)."""
+    import subprocess
+    bad = []
+    for top in ("kmtricks_amd", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if not f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c", "Makefile")): continue
+                txt = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"kmx_oracle|liborc|oracle/|tests\.orc|import orc", txt): bad.append(os.path.join(d, f))
+    assert not bad, f"product files that mention the oracle: {bad}"
+    # the built library and the driver link neither of the oracle's objects
+    for name in ("libkmx.so", "kmx"):
+        path = os.path.join(ROOT, "kmtricks_amd", name)
+        if not os.path.exists(path): continue
+        out = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+        assert "oracle" not in out, f"{name} links the oracle:\n{out}"
