@@ -577,17 +577,20 @@ def test_default_kernel_for_presence_absence_rows(monkeypatch, n):
     res.free(); ctx.close()
 
 
-@pytest.mark.parametrize("similar", [True, False])
-def test_default_kernel_from_192_lists(monkeypatch, similar):
-    """KMX_MERGE_KERNEL unset, 200 lists x 25k records: a cohort goes to k_merge_cols;
-    unrelated lists are handed straight down to k_merge_rows (k_merge_pivot is not in the chain below 513 lists)."""
+@pytest.mark.parametrize("similar,order,N", [(True, False, 200), (False, False, 200), (True, True, 200), (True, True, 300), (False, True, 300)])
+def test_default_kernel_from_192_lists(monkeypatch, similar, order, N):
+    """KMX_MERGE_KERNEL unset, N lists x 25k records.  Rows left where the kernels put them: a cohort goes to k_merge_cols from 192
+    lists.  Rows in file order (the library's default): from 257 lists, where k_merge_rows' windows halve -- up to 256 lists
+    k_merge_rows is the faster one (profiles/r04_crossover.txt).  Unrelated lists are handed straight down to k_merge_rows
+    (k_merge_pivot is not in the chain below 513 lists)."""
     torch = pytest.importorskip("torch")
     from kmtricks_amd import lib
     if os.environ.get("KMX_MERGE_KERNEL") != "cols":
         pytest.skip("one run is enough")
     monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    monkeypatch.delenv("KMX_COLS_MIN_LISTS", raising=False); monkeypatch.delenv("KMX_COLS_MIN_LISTS_ORD", raising=False)
     ctx = lib.Context(0)
-    N = 200
+    ctx.set_file_order(order)
     lists = synth_lists(9700, N, 25000, 0.97, 700, kw=1) if similar else synth_lists(9701, N, 60000, 0.3, 7000, kw=1)
     dev = torch.device("cuda", 0)
     recs = [lib.pack_records(k, c, 1) for k, c in lists]
@@ -597,7 +600,7 @@ def test_default_kernel_from_192_lists(monkeypatch, similar):
     task = dict(lists=[(dt.data_ptr() + 12 * int(offs[i]), int(offs[i + 1] - offs[i])) for i in range(N)], key_words=1,
                 soft_min=[1] * N, rec_min=2, share_min=0, mode=lib.MODE_COUNT)
     res = ctx.merge_dev([task]); res.wait()
-    assert res.kernel() == ("k_merge_cols" if similar else "k_merge_rows")
+    assert res.kernel() == ("k_merge_cols" if similar and N >= (257 if order else 192) else "k_merge_rows")
     eb, er, es = orc.merge_matrix([(k.reshape(-1), c) for k, c in lists], 1, [1] * N, 2, 0, orc.MODE_COUNT)
     assert res.rows(0) == er and res.body(0) == eb and np.array_equal(res.stats(0), es)
     res.free(); ctx.close()
@@ -748,6 +751,7 @@ def test_batch_of_tasks_with_different_list_counts(monkeypatch):
     if os.environ.get("KMX_MERGE_KERNEL") != "cols":
         pytest.skip("one run is enough")
     monkeypatch.delenv("KMX_MERGE_KERNEL", raising=False)
+    monkeypatch.setenv("KMX_COLS_MIN_LISTS_ORD", "192")      # (rows in file order: the pair is libkmx's choice from 257 lists; the knob brings the 200-list task in)
     ctx = lib.Context(0)
     dev = torch.device("cuda", 0)
     for mode in (lib.MODE_COUNT, lib.MODE_PA):

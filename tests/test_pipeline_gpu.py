@@ -711,7 +711,7 @@ def test_cohort_pipeline_where_the_limits_interact(tmp_path):
     (tmp_path / "c.fof").write_text("".join(f"S{i:04d} : {p}\n" for i, p in enumerate(paths)))
     base = [KMX, "pipeline", "--file", str(tmp_path / "c.fof"), "--kmer-size", "31", "--hard-min", "2", "--nb-partitions", str(PP), "--static-repart",
             "--recurrence-min", "2", "--mode", "kmer:count:bin", "-t", "16"]
-    runs = {"plain": ([], {}),
+    runs = {"plain": ([], {"KMX_COLS_MIN_LISTS_ORD": "192"}),      # (libkmx's own choice for count rows in file order starts at 257 lists)
             "tight": (["--gpus", "2", "--samples-per-call", "3", "--merge-batch-mb", "64"], {"KMX_STORE_LIMIT_MB": "48", "KMX_OUT_RING_MB": "4", "KMX_OUT_PIECE_KB": "256", "KMX_COUNT_GROUP_LIMIT": "40000"}),
             "files": (["--no-resident"], {})}
     outs = {}
