@@ -76,7 +76,8 @@ const char* kmx_last_error(const kmx_ctx* ctx);
 /* When on, the merge driver brackets its dominant kernel with HIP events on the ctx stream so that bench.py can report
  * the kernel's launch duration.  Which kernel a batch runs (libkmx chooses; KMX_MERGE_KERNEL=rows|pivot|cols forces one):
  *   COUNT / PA   k_merge_cols + k_cols_sparse  every task has >= 192 lists (>= 257 for count rows with 64-bit keys in file
- *                                              order; KMX_COLS_MIN_LISTS[_ORD]), recurrence-min <= 21, share-min <= max(1,
+ *                                              order, >= 160 / 96 for PA rows with 128-bit keys in file order / not;
+ *                                              KMX_COLS_MIN_LISTS[_ORD]), recurrence-min <= 21, share-min <= max(1,
  *                                              recurrence-min), >= 1 M records in the batch; 64- and 128-bit keys
  *                k_merge_pivot                 otherwise, tasks of more than 512 lists, 64-bit keys, no share-min
  *                k_merge_rows                  everything else -- and the tasks the two above hand back (lists that do not

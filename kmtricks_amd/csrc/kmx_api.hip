@@ -100,8 +100,8 @@ extern "C" int kmx_create(int device, kmx_ctx** out)
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
   c->n_cu = prop.multiProcessorCount;
   { const char* fo = getenv("KMX_FILE_ORDER"); c->file_order = !(fo && fo[0] == '0'); }
-  { const char* v = getenv("KMX_COLS_MIN_LISTS"); if (v && atoi(v) > 0) c->cols_min_lists = (unsigned)atoi(v);
-    v = getenv("KMX_COLS_MIN_LISTS_ORD"); if (v && atoi(v) > 0) c->cols_min_lists_ord = (unsigned)atoi(v); }
+  { const char* v = getenv("KMX_COLS_MIN_LISTS"); if (v && atoi(v) > 0) { c->cols_min_lists = (unsigned)atoi(v); c->cols_min_env = true; }
+    v = getenv("KMX_COLS_MIN_LISTS_ORD"); if (v && atoi(v) > 0) { c->cols_min_lists_ord = (unsigned)atoi(v); c->cols_min_env = true; } }
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete c; return KMX_E_NODEVICE; }
   if ((e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return KMX_E_NODEVICE; }
   if ((e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking)) != hipSuccess) { g_create_err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->aux); delete c; return KMX_E_NODEVICE; }
@@ -709,7 +709,12 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       //  the rows at their place at no cost, where the pair pays the look-back and the side store: 1.19 / 1.40 ms against 1.72 / 1.93
       //  at 192 / 256 lists, 2.38 against 2.11 at 320, profiles/r04_crossover.txt; PA rows and 128-bit keys: not measured, as before)
       const bool ord_count = ctx->file_order && kw == 1 && R->tasks[0].mode == KMX_MODE_COUNT;
-      R->use_cols = can_cols && min_n >= (ord_count ? ctx->cols_min_lists_ord : ctx->cols_min_lists) && grand_total >= (1ull << 20) && cols_row_lists(std::max(1u, max_rec)) != 0;
+      // (PA rows with 128-bit keys -- k = 32 ... 63, configs[4]'s shape --: k_merge_rows pays for its 20-byte records; the pair is ahead
+      //  from 96 lists with the rows left where they fall (1.70 against 2.31 ms) and from 160 in file order (3.09 against 3.91 ms; even
+      //  at 128), profiles/r04_crossover_pa63.txt.  The environment's numbers, when given, hold for every kind of row)
+      const bool pa_wide = kw == 2 && mode == KMX_MODE_PA && !ctx->cols_min_env;
+      const u32 min_lists = pa_wide ? (ctx->file_order ? 160u : 96u) : (ord_count ? ctx->cols_min_lists_ord : ctx->cols_min_lists);
+      R->use_cols = can_cols && min_n >= min_lists && grand_total >= (1ull << 20) && cols_row_lists(std::max(1u, max_rec)) != 0;
       if (R->use_cols && ctx->cols_skip) { ctx->cols_skip--; R->use_cols = false; }
       R->cols_auto = R->use_cols;
       R->use_pivot = !R->use_cols && can && min_n > 512;

@@ -110,6 +110,7 @@ struct kmx_ctx {
   // (doubling back-off, reset by the first batch the pivot kernel completes)
   unsigned pivot_backoff = 0, pivot_skip = 0;
   unsigned cols_backoff = 0, cols_skip = 0;   // the same for the column-blocked kernel
+  bool cols_min_env = false;
   unsigned cols_min_lists = 192, cols_min_lists_ord = 257;   // lists per task from which libkmx picks the column-blocked pair (rows left where they fall / in file order: k_merge_rows' windows halve above 256 lists, and up to there it is the faster one, profiles/r04_crossover.txt); KMX_COLS_MIN_LISTS[_ORD]
   // rows kept per record of a task's longest list, as the batches completed so far had it (COUNT/PA arenas are sized from it:
   // a cohort whose samples share their private k-mers pairwise keeps several times more rows than a list is long, and an arena
