@@ -140,11 +140,9 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     import numpy as np
     ctx = lib.Context(local)
     ctx.set_profiling(True)
-    # COUNT / PA: the line's own step leaves the rows where the kernels put them (kmx_set_file_order off: the pair's raw speed, the
-    # figure of the earlier rounds); the library's default -- rows at their final place, the arena IS the matrix body -- is timed
-    # right behind it with the same steps and reported in roofline.file_order / frac_with_file_order
-    if hasattr(ctx, "set_file_order"):
-        ctx.set_file_order(False)
+    # COUNT / PA: the line's own step runs the library's default -- rows written at their final place (kmx_set_file_order on: the arena
+    # IS the matrix body, the ascending row stream the reference writes, merge.hpp:262-272).  The pair's speed with the rows left where
+    # the kernels put them (the headline of rounds 1-4) is timed right behind it and reported in roofline.rows_left_in_arena.
     defaults = {"count": (1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
     N = a.samples or defaults[0]
     P = a.partitions_per_gpu or defaults[1]
@@ -267,11 +265,29 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     barrier()
     dt = time.perf_counter() - t0
     dt, job_recs = shard.reduce_job(dist if world > 1 else None, dev, dt, float(total_recs))
-    # ---- the same steps with the rows written at their final place (the library's default): the arena is the matrix body ----
-    fo = None
+    # ---- on one GPU, the WHOLE job: all partitions of configs[2] (8 batches of 32 on one MI355X), rows in file order ----
+    whole_job = None
+    if job_lists is not None and rank == 0:
+        per = P
+        jb = [ctx.prepare([dict(lists=job_lists[p], key_words=kw, soft_min=[1] * N, rec_min=rec_min, share_min=a.share_min, mode=mode)
+                           for p in range(b0, min(total_parts, b0 + per))]) for b0 in range(0, total_parts, per)]
+        run(0, False, jb)      # (once untimed: the context's pool then holds the blocks two batches in flight need)
+        sync()
+        t2 = time.perf_counter()
+        run(0, False, jb)
+        sync()
+        dt_job = time.perf_counter() - t2
+        recs_job = sum(n for ls in job_lists for _, n in ls)
+        whole_job = {"partitions": total_parts, "batches": len(jb), "records": recs_job, "wall_ms": dt_job * 1e3, "value": recs_job / dt_job,
+                     "what": f"every partition of the job merged on this one GPU, {len(jb)} batches of {per}, two in flight, rows in file order, results left in HBM"}
+        del jb
+    # ---- the same steps with the rows left where the kernels put them (kmx_set_file_order off: the row keys' rows, then the rows out of
+    #      k_cols_sparse, each list ascending -- NOT the matrix body; the headline of rounds 1-4, kept for continuity) ----
+    arena = None
+    gather_ms = order_ms = None
     if wl in ("count", "pa63") and hasattr(ctx, "set_file_order"):
-        ctx.set_file_order(True)
-        head_ms, head_name = list(kernel_ms), kernel_name
+        ctx.set_file_order(False)
+        head_ms, head_name, head_algo, head_rows = list(kernel_ms), kernel_name, algo_bytes, rows_out
         kernel_ms.clear()
         for _ in range(3):
             run(1, False)
@@ -280,54 +296,38 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
         t1 = time.perf_counter()
         run(a.steps, True)
         barrier()
-        dt_fo = time.perf_counter() - t1
-        dt_fo, _ = shard.reduce_job(dist if world > 1 else None, dev, dt_fo, float(total_recs))
-        fo_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        fo = {"kernel_ms": fo_ms, "ms_per_step": dt_fo / a.steps * 1e3, "value": job_recs * a.steps / dt_fo, "kernel": kernel_name,
-              "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name + ":file_order")}
-        # ---- ... and, on one GPU, the WHOLE job that way: all partitions of configs[2] (8 batches of 32 on one MI355X) ----
-        if job_lists is not None and rank == 0:
-            per = P
-            jb = [ctx.prepare([dict(lists=job_lists[p], key_words=kw, soft_min=[1] * N, rec_min=rec_min, share_min=a.share_min, mode=mode)
-                               for p in range(b0, min(total_parts, b0 + per))]) for b0 in range(0, total_parts, per)]
-            run(0, False, jb)      # (once untimed: the context's pool then holds the blocks two batches in flight need)
+        dt_ar = time.perf_counter() - t1
+        dt_ar, _ = shard.reduce_job(dist if world > 1 else None, dev, dt_ar, float(total_recs))
+        ar_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        arena = {"kernel_ms": ar_ms, "ms_per_step": dt_ar / a.steps * 1e3, "value": job_recs * a.steps / dt_ar, "kernel": kernel_name,
+                 "frac": (algo_bytes / (ar_ms * 1e-3) / 1e9 / 8000.0) if ar_ms > 0 else None,
+                 "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name)}
+        # a consumer of THAT result who wants the body in file order on the device (kmx_result_body_dev) pays a device-to-device pass once
+        # per result (k_cols_offsets + k_cols_gather); one who places the rows itself needs only their order (kmx_result_copy_order)
+        if hasattr(lib, "_lib"):
+            import numpy as _np
+            res = ctx.merge_dev(tasks); res.wait()
             sync()
-            t2 = time.perf_counter()
-            run(0, False, jb)
+            tg = time.perf_counter()
+            for t in range(P):      # (queued for every task first, as a writer does: the passes run back to back)
+                ctx._check(lib._lib.kmx_result_prepare_body(res._h, t), "kmx_result_prepare_body")
+            for t in range(P):
+                res.body_dev(t)
             sync()
-            dt_job = time.perf_counter() - t2
-            recs_job = sum(n for ls in job_lists for _, n in ls)
-            fo["whole_job"] = {"partitions": total_parts, "batches": len(jb), "records": recs_job, "wall_ms": dt_job * 1e3, "value": recs_job / dt_job,
-                               "what": f"every partition of the job merged on this one GPU, {len(jb)} batches of {per}, two in flight, rows in file order, results left in HBM"}
-            del jb
-        kernel_ms[:] = head_ms; kernel_name = head_name
-        ctx.set_file_order(False)
-    # the timed step leaves COUNT / PA rows in HBM as the kernels produce them (k_merge_cols: the row keys' rows and the rows out of
-    # k_cols_sparse, each list ascending); a consumer that wants the body in file order ON THE DEVICE (kmx_result_body_dev: the
-    # pipeline's writer, an RCCL send) pays a device-to-device pass once per result: timed here, outside the step, and reported
-    gather_ms = order_ms = None
-    if wl in ("count", "pa63") and hasattr(lib, "_lib"):
-        import numpy as _np
-        res = ctx.merge_dev(tasks); res.wait()
-        sync()
-        tg = time.perf_counter()
-        for t in range(P):      # (queued for every task first, as a writer does: the passes run back to back)
-            ctx._check(lib._lib.kmx_result_prepare_body(res._h, t), "kmx_result_prepare_body")
-        for t in range(P):
-            res.body_dev(t)
-        sync()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        res.free()
-        # ... a consumer that writes the rows to a file does not need that pass: the order of the arena's rows is enough
-        # (kmx_result_copy_order: ranks from the keys only, 4 bytes per row back to the host) -- what `kmx pipeline` uses
-        res = ctx.merge_dev(tasks); res.wait()
-        bufs = [_np.zeros(max(1, res.rows(t)), _np.uint32) for t in range(P)]
-        sync()
-        tg = time.perf_counter()
-        for t in range(P):
-            ctx._check(lib._lib.kmx_result_copy_order(res._h, t, bufs[t].ctypes.data), "kmx_result_copy_order")
-        order_ms = (time.perf_counter() - tg) * 1e3
-        res.free()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            res.free()
+            res = ctx.merge_dev(tasks); res.wait()
+            bufs = [_np.zeros(max(1, res.rows(t)), _np.uint32) for t in range(P)]
+            sync()
+            tg = time.perf_counter()
+            for t in range(P):
+                ctx._check(lib._lib.kmx_result_copy_order(res._h, t, bufs[t].ctypes.data), "kmx_result_copy_order")
+            order_ms = (time.perf_counter() - tg) * 1e3
+            res.free()
+            arena["file_order_gather_ms"] = gather_ms; arena["row_order_ms"] = order_ms
+            arena["frac_with_gather"] = (algo_bytes / ((ar_ms + gather_ms) * 1e-3) / 1e9 / 8000.0) if ar_ms > 0 else None
+        kernel_ms[:] = head_ms; kernel_name = head_name; algo_bytes = head_algo; rows_out = head_rows
+        ctx.set_file_order(True)
 
     out = None
     if rank == 0:
@@ -348,14 +348,11 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
                        "records_per_step_per_gpu": total_recs, "rows_out_per_step_per_gpu": rows_out,
                        "parallelism": f"partitions sharded over {world} GPU(s), " + ("per-sample Bloom rows exchanged by one RCCL all-to-all" if xbuf is not None else "no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name),
+                         "frac": (achieved / 8000.0) if achieved else None,
+                         "traffic": pmc_traffic(wl, lists_kind, N, P, kernel_name + (":file_order" if wl in ("count", "pa63") else "")),
                          "kernel": kname, "kernel_ms": kms, "algo_bytes_per_launch": algo_bytes,
-                         "rows": "where the kernels leave them (kmx_set_file_order off); file_order: the same steps with the rows at their final place (the library's default)",
-                         "file_order": fo,
-                         "frac_with_file_order": (algo_bytes / (fo["kernel_ms"] * 1e-3) / 1e9 / 8000.0) if (fo and fo["kernel_ms"] > 0) else None,
-                         "file_order_gather_ms": gather_ms, "row_order_ms": order_ms,
-                         "frac_with_row_order": (algo_bytes / ((kms + order_ms) * 1e-3) / 1e9 / 8000.0) if (order_ms is not None and kms > 0) else None,
-                         "frac_with_file_order_gather": (algo_bytes / ((kms + gather_ms) * 1e-3) / 1e9 / 8000.0) if (gather_ms is not None and kms > 0) else None,
+                         "rows": "at their final place (kmx_set_file_order on, the library's default: the arena is the matrix body)" if wl in ("count", "pa63") else "the matrix body",
+                         "whole_job": whole_job, "rows_left_in_arena": arena,
                          # streaming read rate of this access pattern measured on an MI355X (profiles/r01_h_fetch_calibration.txt)
                          "measured_stream_peak": 5654.0, "frac_of_measured": (achieved / 5654.0) if achieved else None},
         }

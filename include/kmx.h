@@ -140,6 +140,10 @@ int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t n_tasks, k
 int      kmx_result_wait(kmx_merge_result* r);
 /* duration in ms of the batch's merge kernel launch (needs kmx_set_profiling(ctx, 1)); < 0 if unavailable */
 double   kmx_result_kernel_ms(kmx_merge_result* r);
+/* the same launch in its two kernels when the column-blocked pair produced the result: k_merge_cols (the column blocks' walk over the
+ * lists), then k_cols_sparse (the rows of the keys outside the row keys; with kmx_set_file_order on also the row keys' rows at their
+ * final place).  -1 in both for every other kernel, without profiling, or when tasks were re-run behind the pair. */
+int      kmx_result_kernel_parts_ms(kmx_merge_result* r, double* first_ms, double* second_ms);
 /* name of the device kernel that produced (most of) the result: "k_merge_cols", "k_merge_pivot", "k_merge_rows",
  * "k_merge_bf" or "k_merge_bft" (see kmx_set_profiling for when each is chosen); valid after kmx_result_wait (tasks a cohort
  * kernel handed back count for the kernel that completed them) */

@@ -373,6 +373,7 @@ struct kmx_merge_result {
   u32 n_subitems = 0, n_citems = 0, sub_grid = 0, cols_grid = 0, sub_max_c = 0, sub_max_n = 0, items_grid = 0;
   int status = KMX_OK;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the merge kernel when ctx->profiling
+  hipEvent_t ev_mid = nullptr;               // ... between k_merge_cols and k_cols_sparse (kmx_result_kernel_parts_ms)
   hipEvent_t ev2 = nullptr;                  // BFT: behind the transposes (ev1 .. ev2 = their duration)
   u8* d_in = nullptr;                        // kmx_merge_host: the uploaded lists (freed with the result)
   u64* d_rem = nullptr; u32 rem_cap = 0;     // BFT, one-bit recurrences: the single walk's scratch (records put aside until a tile's map is complete)
@@ -478,9 +479,14 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     KMX_HIP(ctx, hipStreamWaitEvent(ctx->stream, R->ev_pre, 0));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
-    KMX_HIP(ctx, CO.merge(mode, (R->cols_ext ? 1 : 0) | (R->cols_resc ? 2 : 0), d_tasks, d_cols, d_citems, R->n_citems, d_ticket, R->cols_grid, ctx->stream));
+    // (tuning knobs: KMX_COLS_GRID / KMX_SPARSE_GRID = workgroups of the two persistent kernels -- what each loses on a part of the chip)
+    const u32 cols_grid_env = getenv("KMX_COLS_GRID") ? (u32)atoi(getenv("KMX_COLS_GRID")) : 0u;
+    const u32 sparse_cus_env = getenv("KMX_SPARSE_CUS") ? (u32)atoi(getenv("KMX_SPARSE_CUS")) : 0u;
+    KMX_HIP(ctx, CO.merge(mode, (R->cols_ext ? 1 : 0) | (R->cols_resc ? 2 : 0) | (R->cols_ord ? 4 : 0), d_tasks, d_cols, d_citems, R->n_citems, d_ticket,
+                          cols_grid_env ? std::min(cols_grid_env, R->cols_grid) : R->cols_grid, ctx->stream));
+    if (R->ev0) { if (!R->ev_mid) KMX_HIP(ctx, hipEventCreate(&R->ev_mid)); KMX_HIP(ctx, hipEventRecord(R->ev_mid, ctx->stream)); }
     // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
-    KMX_HIP(ctx, CO.sparse(mode | (R->cols_resc ? 2 : 0) | (R->cols_ord ? 4 : 0), d_tasks, d_cols, d_items, R->n_items, nt, d_ticket, (u32)ctx->n_cu, ctx->stream));
+    KMX_HIP(ctx, CO.sparse(mode | (R->cols_resc ? 2 : 0) | (R->cols_ord ? 4 : 0), d_tasks, d_cols, d_items, R->n_items, nt, d_ticket, sparse_cus_env ? std::min(sparse_cus_env, (u32)ctx->n_cu) : (u32)ctx->n_cu, ctx->stream));
     if (R->share_fix) {
       if ((size_t)R->max_n * 4 > 48 * 1024) KMX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_share_fix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>((size_t)R->max_n * 4, 160 * 1024)));
       hipLaunchKernelGGL(k_share_fix, dim3((unsigned)ctx->n_cu * 2u, nt), dim3(256), (size_t)R->max_n * 4, ctx->stream, (const TaskDev*)d_tasks, kw);
@@ -1004,6 +1010,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     (void)hipStreamSynchronize(ctx->aux);
     drop_blocks();
     if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
+    if (R->ev_mid) (void)hipEventDestroy(R->ev_mid);
     if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
     if (R->ev_up) (void)hipEventDestroy(R->ev_up);
     if (R->ev_done) (void)hipEventDestroy(R->ev_done);
@@ -1219,6 +1226,16 @@ extern "C" double kmx_result_kernel_ms(kmx_merge_result* R)
   float ms = -1.f;
   if (hipEventElapsedTime(&ms, R->ev0, R->ev1) != hipSuccess) return -1.0;
   return (double)ms;
+}
+extern "C" int kmx_result_kernel_parts_ms(kmx_merge_result* R, double* first_ms, double* second_ms)
+{
+  if (!R || !first_ms || !second_ms) return KMX_E_INVAL;
+  *first_ms = *second_ms = -1.0;
+  if (!R->ev0 || !R->ev_mid || kmx_result_wait(R) != KMX_OK || R->rerun_rows) return KMX_OK;      // (not the column-blocked pair, or tasks were run again behind it)
+  float a = -1.f, b = -1.f;
+  if (hipEventElapsedTime(&a, R->ev0, R->ev_mid) != hipSuccess || hipEventElapsedTime(&b, R->ev_mid, R->ev1) != hipSuccess) { (void)hipGetLastError(); return KMX_OK; }
+  *first_ms = a; *second_ms = b;
+  return KMX_OK;
 }
 extern "C" uint64_t kmx_result_rows(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size()) ? R->tasks[t].rows : 0; }
 extern "C" uint64_t kmx_result_sparse_rows(const kmx_merge_result* R, uint32_t t) { return (R && t < R->tasks.size() && R->tasks[t].kernel == 2) ? R->tasks[t].sparse_rows : 0; }

@@ -412,7 +412,9 @@ __device__ u64 kmx_sparse_prof[8];
 // EXT: a wave whose set-aside slice is full claims an extension (cohorts with outlier samples; the plain build hands such a task
 // back and the context's next batches use this one: 1-2 % slower on cohorts that never need it)
 constexpr u64 CL_NONSOLID = 1ULL << 63;      // set-aside entry of a RESC build: the record is below its list's soft-min
-template <int MODE, bool EXT, bool RESC>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
+// ORD: the row keys' rows go to the side store k_cols_sparse copies them from (rows at their final place, kmx_set_file_order) -- a
+// build of its own: as a run-time switch the side store's code cost the other build seven more spilled registers (round 4: 2.53 -> 2.70 ms)
+template <int MODE, bool EXT, bool RESC, bool ORD>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
 __global__ __launch_bounds__(CL_TPB, CL_WGS)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
                   u32 n_items, u32* ticket)
@@ -461,7 +463,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     const CKey* const skel = reinterpret_cast<const CKey*>(C.skel);
     // where the row keys' rows go: the arena, row r at row r (key + payload) -- or, when the rows are to come out in file order,
     // the side store k_cols_sparse copies them from (payload only: the key is in skel)
-    const bool ord = cl_uni(C.dense != nullptr ? 1u : 0u) != 0;
+    constexpr bool ord = ORD;
     u8* const obase = ord ? C.dense : T.out + KW * 8;
     const u32 opitch = ord ? cl_uni(C.dpitch) : row_bytes;
     // ... count rows there as ONE BYTE per count where a block's slice of the row holds none above 254 (the usual case by far): the
@@ -1796,22 +1798,24 @@ hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const Col
   hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(CP_TPB), 0, st, tasks, subs, cols);
   return hipGetLastError();
 }
-template <int MODE, bool EXT, bool RESC>
+template <int MODE, bool EXT, bool RESC, bool ORD>
 static hipError_t launch_merge_cols_as(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
   const int lds = cols_lds_bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<MODE, EXT, RESC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<MODE, EXT, RESC, ORD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_merge_cols<MODE, EXT, RESC>), dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
+  hipLaunchKernelGGL((k_merge_cols<MODE, EXT, RESC, ORD>), dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
   return hipGetLastError();
 }
-// ext: bit 0 = slice extensions (outlier samples), bit 1 = the RESC build (share-min, recurrence-min 0)
+// ext: bit 0 = slice extensions (outlier samples), bit 1 = the RESC build (share-min, recurrence-min 0), bit 2 = the ORD build (the row
+// keys' rows into the side store: every task of the batch has one)
 hipError_t launch_merge_cols(int mode, int ext, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
-  const bool x = ext & 1, r = (ext & 2) != 0;
-#define KMX_CL_LAUNCH(M) (r ? (x ? launch_merge_cols_as<M, true, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<M, false, true>(tasks, cols, items, n_items, ticket, grid_x, st)) \
-                            : (x ? launch_merge_cols_as<M, true, false>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<M, false, false>(tasks, cols, items, n_items, ticket, grid_x, st)))
+  const bool x = ext & 1, r = (ext & 2) != 0, o = (ext & 4) != 0;
+#define KMX_CL_L3(M, X, R) (o ? launch_merge_cols_as<M, X, R, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<M, X, R, false>(tasks, cols, items, n_items, ticket, grid_x, st))
+#define KMX_CL_LAUNCH(M) (r ? (x ? KMX_CL_L3(M, true, true) : KMX_CL_L3(M, false, true)) : (x ? KMX_CL_L3(M, true, false) : KMX_CL_L3(M, false, false)))
   return mode == 0 ? KMX_CL_LAUNCH(0) : KMX_CL_LAUNCH(1);
+#undef KMX_CL_L3
 #undef KMX_CL_LAUNCH
 }
 template <int MODE, bool RESC>

@@ -51,6 +51,8 @@ using clk = std::chrono::steady_clock;
 struct Sample { std::string id; std::vector<std::string> files; uint32_t hard_min; };
 
 struct Opt {
+  bool merge_only = false;      // `kmx merge --run-dir <dir>`: the merge module by itself over the count files of an existing run directory (src/cli.cpp:526-646)
+  bool text = false;      // --mode <count-format>:<count|pa>:text (src/cli.cpp:151-157): rows as text lines, merge.hpp:288-316, 531-572
   std::string fof, dir, mode = "kmer:count:bin", until = "all", plugin, plugin_config, repart_from, repart_file, bf_format = "howdesbt", soft_min_path;
   double soft_f = 0.0; bool soft_float = false;      // --soft-min <fraction> (src/cli.cpp:234-240)
   uint32_t k = 31, hard_min = 2, soft_min = 1, rec_min = 1, share_min = 0, nb_parts = 0, msize = 10, bitw = 2, threads = 8, gpus = 1, gpu_workers = 2, per_call = 0;
@@ -93,8 +95,12 @@ static std::vector<Sample> parse_fof(const std::string& path, uint32_t default_h
 
 static Opt parse_cli(int argc, char** argv)
 {
-  if (argc < 2 || std::string(argv[1]) != "pipeline") die("usage: kmx pipeline --file <fof> --run-dir <dir> [options] | kmx dump --input <file> [-o out] | kmx aggregate --run-dir <dir> --matrix kmer|hash ...  (see INTEGRATION.md)");
+  if (argc < 2 || (std::string(argv[1]) != "pipeline" && std::string(argv[1]) != "merge")) die("usage: kmx pipeline --file <fof> --run-dir <dir> [options] | kmx merge --run-dir <dir> [options] | kmx dump --input <file> [-o out] | kmx aggregate --run-dir <dir> --matrix kmer|hash ...  (see INTEGRATION.md)");
   Opt o;
+  // `kmtricks merge` (src/cli.cpp:526-646): --run-dir, --partition-id, --soft-min, --recurrence-min, --share-min, --mode, --clear, --cpr,
+  // -t; what the run was made with (k, partitions, Bloom size, minimizer size) is read back from its options.txt below
+  o.merge_only = std::string(argv[1]) == "merge";
+  if (o.merge_only) { o.until = "merge"; o.keep_tmp = true; o.no_resident = true; o.k = 0; }
   auto need = [&](int& i) -> std::string { if (i + 1 >= argc) die(std::string("missing value for ") + argv[i]); return argv[++i]; };
   auto num = [&](int& i) -> unsigned long { const std::string v = need(i); try { size_t n = 0; const unsigned long x = std::stoul(v, &n); if (n != v.size()) throw 1; return x; } catch (...) { die(std::string("bad number for ") + argv[i - 1] + ": " + v); } };
   auto real = [&](int& i) -> double { const std::string v = need(i); try { return std::stod(v); } catch (...) { die(std::string("bad number for ") + argv[i - 1] + ": " + v); } };
@@ -138,6 +144,8 @@ static Opt parse_cli(int argc, char** argv)
     else if (a == "--restrict-to-list") { std::stringstream ss(need(i)); std::string t; while (std::getline(ss, t, ',')) { try { o.restrict_list.push_back((uint32_t)std::stoul(t)); } catch (...) { die("--restrict-to-list: bad partition " + t); } } }
     else if (a == "--focus") { o.focus = real(i); if (o.focus < 0.0 || o.focus > 1.0) die("--focus must be in [0.0, 1.0]"); }
     else if (a == "--keep-tmp") o.keep_tmp = true;
+    else if (a == "--clear" && o.merge_only) o.keep_tmp = false;      // clear the partition files once merged (src/cli.cpp:640-642)
+    else if (a == "--partition-id" && o.merge_only) { const std::string v = need(i); if (v != "-1") { try { o.restrict_list.assign(1, (uint32_t)std::stoul(v)); } catch (...) { die("bad number for --partition-id: " + v); } } }
     else if (a == "--cpr") o.cpr = true;
     else if (a == "--hist") o.hist = true;                      // histograms/<id>.hist (src/cli.cpp:207-209)
     else if (a == "--plugin") o.plugin = need(i);
@@ -152,13 +160,41 @@ static Opt parse_cli(int argc, char** argv)
     else if (a == "-v" || a == "--verbose") need(i);
     else die("unknown option " + a);
   }
+  if (o.merge_only) {
+    // the run directory must be one (kmtricks.fof marks it, src/cli.cpp:106-115); its options.txt (cmd/all.hpp:85-125, one line of
+    // key=value pairs that both kmtricks and kmx write) says what the counts were made with
+    if (o.dir.empty()) die("--run-dir is required");
+    if (!fs::exists(o.dir + "/kmtricks.fof")) die(o.dir + " is not a kmtricks runtime directory.");
+    o.fof = o.dir + "/kmtricks.fof";
+    std::string opt; { std::ifstream f(o.dir + "/options.txt"); std::getline(f, opt); }
+    auto val = [&](const std::string& key) -> std::string {
+      const size_t at = opt.find(" " + key + "="); if (at == std::string::npos) return "";
+      const size_t b = at + key.size() + 2, e = opt.find(',', b); return opt.substr(b, e == std::string::npos ? std::string::npos : e - b);
+    };
+    auto uval = [&](const std::string& key, uint64_t dflt) -> uint64_t { const std::string v = val(key); if (v.empty()) return dflt; try { return (uint64_t)std::stod(v); } catch (...) { return dflt; } };
+    if (o.k == 0) o.k = (uint32_t)uval("kmer_size", 31);
+    if (o.nb_parts == 0) o.nb_parts = (uint32_t)uval("nb_parts", 0);
+    o.msize = (uint32_t)uval("minim_size", o.msize);
+    o.bloom = uval("bloom_size", o.bloom);
+    o.bitw = (uint32_t)uval("bwidth", o.bitw);
+    if (!o.cpr) o.cpr = uval("lz4", 0) != 0;
+    if (o.nb_parts == 0) {      // (no options.txt: the partitions are the directories that are there)
+      while (fs::exists(o.dir + "/counts/partition_" + std::to_string(o.nb_parts))) o.nb_parts++;
+      if (o.nb_parts == 0) die(o.dir + " holds no counts/partition_<p>.");
+    }
+  } else {
   if (o.fof.empty() || o.dir.empty()) die("--file and --run-dir are required");
   if (fs::exists(o.dir)) die("--run-dir already exists: " + o.dir);                  // src/cli.cpp:101-104
+  }
   if (o.k < 8 || o.k > 127) die("--kmer-size must be in [8, 127]: the reference's default KMER_LIST \"32 64 96 128\" (keys of one to four 64-bit words, loop_executor.hpp:47-63)");
   if (o.msize < 4 || o.msize > 15 || o.msize >= o.k) die("--minimizer-size must be in [4, 15] and < k");
+  {   // the four text modes: the same merge, another writer (the mode string is the :bin one from here on)
+    static const char* tmodes[] = {"kmer:count:text", "kmer:pa:text", "hash:count:text", "hash:pa:text"};
+    for (const char* m : tmodes) if (o.mode == m) { o.text = true; o.mode = o.mode.substr(0, o.mode.size() - 4) + "bin"; break; }
+  }
   static const char* modes[] = {"kmer:count:bin", "kmer:pa:bin", "hash:count:bin", "hash:pa:bin", "hash:bf:bin", "hash:bfc:bin", "hash:bft:bin"};
   if (std::find_if(std::begin(modes), std::end(modes), [&](const char* m) { return o.mode == m; }) == std::end(modes))
-    die("--mode " + o.mode + " is not supported (kmer:{count,pa}:bin, hash:{count,pa,bf,bfc,bft}:bin)");
+    die("--mode " + o.mode + " is not supported (kmer:{count,pa}:{bin,text}, hash:{count,pa}:{bin,text}, hash:{bf,bfc,bft}:bin)");
   static const char* untils[] = {"all", "repart", "superk", "count", "merge"};
   if (std::find_if(std::begin(untils), std::end(untils), [&](const char* m) { return o.until == m; }) == std::end(untils)) die("bad --until");
   if (o.bf_format != "howdesbt") die("--bf-format " + o.bf_format + " is not supported (howdesbt)");
@@ -217,9 +253,9 @@ int run(int argc, char** argv)
   // ---- number of partitions (task.hpp:108-115): 0 = gatb's ConfigurationAlgorithm sizes it from the estimated volume,
   // memory and open-file limits of the host (system dependent); this build uses volume / 2^30 k-mers, at least 4 ----
   std::vector<std::string> all_files; uint64_t in_bytes = 0;
-  for (auto& s : samples) for (auto& f : s.files) { all_files.push_back(f); std::error_code ec; const auto sz = fs::file_size(f, ec); if (ec) die("Unable to read at " + f); in_bytes += sz * (f.size() > 3 && f.substr(f.size() - 3) == ".gz" ? 4 : 1); }
+  if (!o.merge_only) for (auto& s : samples) for (auto& f : s.files) { all_files.push_back(f); std::error_code ec; const auto sz = fs::file_size(f, ec); if (ec) die("Unable to read at " + f); in_bytes += sz * (f.size() > 3 && f.substr(f.size() - 3) == ".gz" ? 4 : 1); }
   if (o.nb_parts == 0) { uint64_t p = in_bytes / (1ull << 30) + 1; o.nb_parts = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(p, 4), 2000); }
-  if (o.nb_parts < 4) o.nb_parts = 4;                                                  // task.hpp:112-113
+  if (o.nb_parts < 4 && !o.merge_only) o.nb_parts = 4;                                 // task.hpp:112-113
   const uint32_t P = o.nb_parts;
   for (uint32_t p : o.restrict_list) if (p >= P) die("Ask to process part " + std::to_string(p) + " but nb_partitions is " + std::to_string(P));   // task_scheduler.hpp:152-158
 
@@ -228,6 +264,7 @@ int run(int argc, char** argv)
   for (const char* d : {"", "/superkmers", "/counts", "/matrices", "/filters", "/histograms", "/merge_infos", "/howde_index",
                         "/partition_infos", "/fpr", "/plugin_output", "/repartition_gatb", "/config_gatb"})
     fs::create_directories(root + d);
+  if (!o.merge_only) {
   fs::copy_file(o.fof, root + "/kmtricks.fof");
   { std::ofstream b(root + "/build_infos.txt"); b << "kmx (MI355X-native kmtricks pipeline), libkmx ABI " << kmx_version() << "\n"; }
   { std::ofstream f(root + "/options.txt");   // cmd/all.hpp:85-125: `kmtricks combine` re-parses mode= from this line
@@ -235,11 +272,17 @@ int run(int argc, char** argv)
       << ", m_ab_min=" << o.soft_min << ", r_min=" << o.rec_min << ", m_ab_min_path=" << o.soft_min_path << ", m_ab_min_f=" << o.soft_f << ", m_ab_float=" << o.soft_float << ", save_if=" << o.share_min << ", minim_size=" << o.msize
       << ", minim_type=0, repart_type=0, nb_parts=" << P << ", bloom_size=" << o.bloom << ", keep_tmp=" << o.keep_tmp << ", lz4=" << o.cpr << ", kff=0, hist=" << o.hist << ", static_repart=" << o.static_repart
       << ", focus=" << o.focus << ", restrict_to=" << o.restrict_to << ", bwidth=" << o.bitw << ", bam_exclude_refs=, bam_include_flags=0, bam_exclude_flags=0, mode=" << what      // (mode_to_str: count | pa | bf | bfc; cmd/all.hpp:119)
-      << ", format=bin, bf_format=" << o.bf_format << ", count_format=" << (hash_mode ? "hash" : "kmer") << ", until=" << o.until << "\n"; }
+      << ", format=" << (o.text ? "text" : "bin") << ", bf_format=" << o.bf_format << ", count_format=" << (hash_mode ? "hash" : "kmer") << ", until=" << o.until << "\n"; }
+  }
   for (uint32_t p = 0; p < P; p++) fs::create_directories(root + "/counts/partition_" + std::to_string(p));
   HashWindow hw(o.bloom, P, o.msize);
-  hw.save(root + "/hash.info");                                                       // task.hpp:98-124
-  { GatbConfig gc; gc.kmer_size = o.k; gc.minim_size = o.msize; gc.nb_cores = o.threads; gc.nb_partitions = P; gc.nb_banks = (uint16_t)std::min<size_t>(all_files.size(), 65535);
+  if (o.merge_only) {      // the windows the hash counts were made with: hash.info's (hash.hpp:52-60: bloom size, partitions, window bits, ...)
+    std::ifstream hi(root + "/hash.info", std::ios::binary); uint64_t h4[4] = {0, 0, 0, 0};
+    if (hi.read(reinterpret_cast<char*>(h4), 32) && h4[1] == P && h4[0]) hw = HashWindow(h4[0], P, o.msize);
+    for (uint32_t p = 0; p < P; p++) for (auto& sm : samples) { std::error_code ec; const auto sz = fs::file_size(root + "/counts/partition_" + std::to_string(p) + "/" + sm.id + (o.mode.rfind("hash:", 0) == 0 ? ".hash" : (o.cpr ? ".kmer.lz4" : ".kmer")), ec); if (!ec) in_bytes += sz; }
+  }
+  if (!o.merge_only) hw.save(root + "/hash.info");                                    // task.hpp:98-124
+  if (!o.merge_only) { GatbConfig gc; gc.kmer_size = o.k; gc.minim_size = o.msize; gc.nb_cores = o.threads; gc.nb_partitions = P; gc.nb_banks = (uint16_t)std::min<size_t>(all_files.size(), 65535);
     gc.est_seq_total = in_bytes; gc.save(root + "/config_gatb/gatb.config"); }
 
   // ---- devices and host threads ----
@@ -285,7 +328,7 @@ int run(int argc, char** argv)
   // ---- repartition (task.hpp:170-225) ----
   std::vector<uint16_t> table;
   const std::string rpath = root + "/repartition_gatb/repartition.minimRepart";
-  {
+  if (!o.merge_only) {
     const auto t_rep = clk::now();
     if (!o.repart_file.empty() || !o.repart_from.empty()) {
       uint16_t np = 0;
@@ -465,7 +508,7 @@ int run(int argc, char** argv)
   std::thread ring_filler;
   {
     const bool will_merge = o.until == "all" || o.until == "merge";
-    const bool streams = will_merge && o.plugin.empty() && !(o.cpr && !(o.mode == "hash:bf:bin" || o.mode == "hash:bfc:bin")) && o.mode != "hash:bft:bin";
+    const bool streams = will_merge && o.plugin.empty() && !o.text && !(o.cpr && !(o.mode == "hash:bf:bin" || o.mode == "hash:bfc:bin")) && o.mode != "hash:bft:bin";
     // (as many pieces as the matrices can fill: input bytes bound them loosely; small runs do not pin 2 GB for nothing)
     // A thread asks for the pieces while the samples are counted (KMX_RING_PREFILL=0: the writers ask when they need them).  Round 3
     // measured that as a loss (the merge stage gained 0.1 s, the count stage lost 0.3 s: hipHostMalloc under the runtime's lock, and the
@@ -482,7 +525,7 @@ int run(int argc, char** argv)
   // Readers (pool threads) parse a sample's files into batches of reads; the worker of GPU (sample mod G) splits every batch
   // (kmx_superk_partition[_stats]) and, at the sample's last batch, counts all its partitions (kmx_count_batch) and hands the
   // count files to the pool for writing.
-  {
+  if (!o.merge_only) {
     // a batch of reads: the bases lie in page-locked memory (the upload is a DMA at the link's rate and does not hold the worker's
     // thread; from a std::string the runtime stages it through its own pinned block, synchronously), blocks from a pool
     struct PinStr { char* p = nullptr; size_t cap = 0, len = 0; const char* data() const { return p; } size_t size() const { return len; } };
@@ -943,7 +986,20 @@ int run(int argc, char** argv)
       auto load = [&](size_t bi, Batch& B) {
         const auto t = clk::now();
         const auto& parts = batches[bi]; const auto& sz = fsize[bi];
-        const bool direct = !hash_mode && !o.cpr;       // our own .kmer files: 41-byte header, then the records exactly as kmx_list wants them
+        // our own .kmer files: 41-byte header, then the records exactly as kmx_list wants them.  `kmx merge` over a directory somebody
+        // else counted: the files of a build with MAX_C <= 65535 hold 1- or 2-byte counts (CMakeLists.txt:25-41, utils.hpp:311-327; the
+        // reference's own fixtures do) -- those go through read_kmer_records, which widens them
+        bool direct = !hash_mode && !o.cpr;
+        if (direct && o.merge_only) {
+          for (size_t j = 0; j < parts.size() * N && direct; j++) {
+            if (res_flag[j % N] || sz[j] < 41) continue;
+            const std::string path = count_path(parts[j / N], (uint32_t)(j % N));
+            const int fd = open(path.c_str(), O_RDONLY); uint8_t h[41];
+            if (fd < 0 || pread(fd, h, 41, 0) != 41 || rd<uint32_t>(h + 29) != 4 || h[12] != 0) direct = false;
+            if (fd >= 0) close(fd);
+            break;      // (a directory's files come from one build: the first one tells)
+          }
+        }
         B.parts.resize(parts.size());
         for (size_t a = 0; a < parts.size(); a++) {      // the resident lists: merged where they lie
           B.parts[a].p = parts[a]; B.parts[a].lists.assign(N, kmx_list{nullptr, 0}); B.parts[a].on_dev.assign(N, 0);
@@ -1019,7 +1075,7 @@ int run(int argc, char** argv)
         w_merge += since(t);
         t = clk::now();
         // the plain case -- no plugin, no lz4 body, not the per-sample filters -- streams the body from the device to its file
-        const bool stream_out = !plug.create && !(o.cpr && !is_bloom) && what != "bft";
+        const bool stream_out = !plug.create && !o.text && !(o.cpr && !is_bloom) && what != "bft";
         for (size_t a = 0; a < F.B.parts.size(); a++) {
           const uint32_t p = F.B.parts[a].p;
           const uint64_t nbytes = kmx_result_body_bytes(F.R, (uint32_t)a), rows = kmx_result_rows(F.R, (uint32_t)a);
@@ -1153,10 +1209,11 @@ int run(int argc, char** argv)
             struct Done { std::atomic<uint64_t>& p; uint64_t n; ~Done() { p -= n; } } done_{pending_bytes, (uint64_t)body->size()};
             try {
               const std::string ext = what == "count" ? (hash_mode ? "count_hash" : "count") : what == "pa" ? (hash_mode ? "pa_hash" : "pa") : "cmbf";
-              const bool lz4_name = o.cpr && !hash_mode && !is_bloom;                       // hash-mode matrices never get the suffix (task.hpp:794-795)
-              const bool cpr_body = o.cpr && !is_bloom;
-              Out out(root + "/matrices/matrix_" + std::to_string(p) + "." + ext + (lz4_name ? ".lz4" : ""));
-              if (what == "count") { if (hash_mode) matrix_count_hash_header(out, N, p, cpr_body); else matrix_count_header(out, o.k, N, p, cpr_body); }
+              const bool lz4_name = o.cpr && !hash_mode && !is_bloom && !o.text;             // hash-mode matrices never get the suffix (task.hpp:794-795), text ones neither (kmdir.hpp:127-130)
+              const bool cpr_body = o.cpr && !is_bloom && !o.text;
+              Out out(root + "/matrices/matrix_" + std::to_string(p) + "." + ext + (o.text ? ".txt" : "") + (lz4_name ? ".lz4" : ""));
+              if (o.text) {}      // (a text matrix has no header: a plain ofstream, merge.hpp:288-316)
+              else if (what == "count") { if (hash_mode) matrix_count_hash_header(out, N, p, cpr_body); else matrix_count_header(out, o.k, N, p, cpr_body); }
               else if (what == "pa") { if (hash_mode) matrix_pa_hash_header(out, N, p, cpr_body); else matrix_pa_header(out, o.k, N, p, cpr_body); }
               else matrix_bf_header(out, what == "bfc" ? N * o.bitw : N, T.lower, T.upper - T.lower + 1, p);
               km::IMergePlugin* pl = nullptr;
@@ -1164,7 +1221,27 @@ int run(int argc, char** argv)
                 pl = plug.create(); pl->configure(o.plugin_config);                              // plugin_manager.hpp:106-111
                 pl->set_out_dir(root + "/plugin_output"); pl->set_kmer_size(hash_mode ? 0 : o.k); pl->set_partition(p);   // task.hpp:701-712
               }
-              if (!pl) out.raw(body->data(), body->size());
+              // a row as a line of text (write_as_text / write_as_pa_text, merge.hpp:288-316, 531-572): the k-mer as letters
+              // (Kmer::to_string, kmer.hpp:541-550: most significant digit first, A C T G = 0 1 2 3) or the hash in decimal, then
+              // " <count>" -- " 1" / " 0" for presence/absence -- per sample.  The batch ran as count rows (key + N x u32).
+              std::string line;
+              auto text_row = [&](const uint64_t* key, auto&& count_of) {
+                line.clear();
+                if (hash_mode) line += std::to_string(key[0]);
+                else for (uint32_t d = o.k; d-- > 0;) line += "ACTG"[(key[d >> 5] >> (2 * (d & 31))) & 3];
+                for (uint32_t i = 0; i < N; i++) { line += ' '; const uint32_t cnt = count_of(i); if (what == "pa") line += cnt ? '1' : '0'; else line += std::to_string(cnt); }
+                line += '\n';
+                out.raw(line.data(), line.size());
+              };
+              if (!pl && o.text) {
+                const uint32_t kb = T.key_words * 8; const size_t rb = kb + 4ull * N;
+                uint64_t key[4] = {0, 0, 0, 0};
+                for (uint64_t r = 0; r < rows; r++) {
+                  const uint8_t* row = body->data() + r * rb;
+                  memcpy(key, row, kb);
+                  text_row(key, [&](uint32_t i) { uint32_t v; memcpy(&v, row + kb + 4 * i, 4); return v; });
+                }
+              } else if (!pl) out.raw(body->data(), body->size());
               else {   // the plugin's return value replaces the recurrence test: every row was produced, filter here
                 const uint32_t kb = T.key_words * 8; const size_t rb = kb + 4ull * N;
                 std::vector<km::IMergePlugin::count_type> cv(N); std::vector<uint8_t> pa((N + 7) / 8);
@@ -1175,6 +1252,7 @@ int run(int argc, char** argv)
                   else std::fill(cv.begin(), cv.end(), 0);
                   const bool keep = hash_mode ? pl->process_hash(last_key[0], cv) : pl->process_kmer(last_key, cv);
                   if (r == rows || !keep) continue;
+                  if (o.text) { text_row(last_key, [&](uint32_t i) { return (uint32_t)cv[i]; }); continue; }
                   out.raw(last_key, kb);
                   if (what == "count") for (uint32_t i = 0; i < N; i++) { const uint32_t v = (uint32_t)cv[i]; out.raw(&v, 4); }
                   else { std::fill(pa.begin(), pa.end(), 0); for (uint32_t i = 0; i < N; i++) if (cv[i]) pa[i >> 3] |= (uint8_t)(1u << (i & 7)); out.raw(pa.data(), pa.size()); }
@@ -1228,6 +1306,7 @@ int run(int argc, char** argv)
           t.mode = what == "count" ? KMX_MODE_COUNT : what == "pa" ? KMX_MODE_PA : what == "bf" ? KMX_MODE_BF : what == "bfc" ? KMX_MODE_BFC : KMX_MODE_BFT;
           if (is_bloom) { t.lower = hw.lower(p); t.upper = hw.upper(p); }
           if (plug.create) { t.rec_min = 0; t.mode = KMX_MODE_COUNT; }
+          if (o.text) t.mode = KMX_MODE_COUNT;      // (the text writers print the counts, or whether they are zero)
           t.list_on_device = F->B.parts[a].on_dev.data();
           for (uint32_t i = 0; i < N; i++) st.merge_recs += t.lists[i].n;
         }

@@ -42,6 +42,7 @@ _lib.kmx_result_kernel.restype = C.c_char_p
 _lib.kmx_result_kernel.argtypes = [_vp]
 _lib.kmx_result_kernel_ms.restype = C.c_double
 _lib.kmx_result_kernel_ms.argtypes = [_vp]
+_lib.kmx_result_kernel_parts_ms.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 _lib.kmx_result_transpose_ms.restype = C.c_double
 _lib.kmx_result_transpose_ms.argtypes = [_vp]
 _lib.kmx_result_body_dev.restype = _vp
@@ -477,6 +478,12 @@ class MergeResult:
 
     def kernel_ms(self):
         return _lib.kmx_result_kernel_ms(self._h)
+
+    def kernel_parts_ms(self):
+        """(k_merge_cols ms, k_cols_sparse ms) of a result of the column-blocked pair; (-1, -1) otherwise"""
+        a, b = C.c_double(-1.0), C.c_double(-1.0)
+        self._ctx._check(_lib.kmx_result_kernel_parts_ms(self._h, C.byref(a), C.byref(b)), "kmx_result_kernel_parts_ms")
+        return a.value, b.value
 
     def kernel(self):
         return _lib.kmx_result_kernel(self._h).decode()

@@ -505,3 +505,16 @@ def test_count_reads_dev_multi_vs_single(ctx, k, m, P, hard_min, hashed, G, S):
                 assert (int(info[p, 0]), int(info[p, 1])) == (km, fl)
     finally:
         for s in stores: s.close()
+
+
+@pytest.mark.parametrize("k,m,P", [(31, 10, 4), (47, 9, 4), (63, 10, 4), (64, 10, 3), (96, 11, 4), (127, 10, 2)])
+def test_parti_info_through_hip_against_the_string_restatement(ctx, k, m, P):
+    """the PartiInfo<5> counters of the HIP split against tests/test_merge_independent.py's `pinfo_from_strings` (super-k-mers and kx-mers
+    cut out of the reads as strings, fill_partitions.hpp:59-105): the reference's tests never read PartiInfoFile, this is the pin"""
+    from test_merge_independent import pinfo_from_strings
+    rep = orc.repart_static(m, P)
+    reads = random_reads(900 + k, 60, 220, n_rate=0.004) + ["A" * 200, "ACGTN" * 40, "GAATTC" * 50, "acgtacgtnnacgt" * 12]
+    exp, minim = pinfo_from_strings(reads, k, m, rep, P)
+    _, pin, ms, mk, _ = ctx.superk_partition_stats(reads, k, m, rep, P)
+    assert pin.tolist() == exp
+    assert {int(v): [int(ms[v]), int(mk[v])] for v in np.nonzero(ms)[0]} == minim

@@ -880,3 +880,41 @@ def test_file_order_count_rows_across_the_one_byte_boundary(n, kw, heavy, monkey
             res.free()
     finally:
         ctx.close()
+
+
+def test_hand_worked_merge_vectors_through_the_hip_path(ctx):
+    """the vectors of tests/test_merge_independent.py -- every cell and statistic written down from merge.hpp:183-260, the deciding
+    line cited there -- through the C ABI: the HIP merge is pinned to the reference's arithmetic without the oracle in between
+    (rescue granted / denied at the share-min boundary, non-solid records with share-min 0, recurrence-min 0 rows of zeros, each of
+    the six statistics; 64- to 256-bit keys)"""
+    from test_merge_independent import HAND_CASES, HAND_SOFT, hand_arrays, body_of
+    for kw, shift in ((1, 0), (1, 40), (2, 70), (3, 130), (4, 200)):
+        lists = hand_arrays(kw, shift)
+        for r, s, rows, stats in HAND_CASES:
+            for mode in (orc.MODE_COUNT, orc.MODE_PA):
+                body, n, st = ctx.merge(lists, kw, HAND_SOFT, r, s, mode)
+                assert n == len(rows) and body == body_of(rows, kw, 3, mode, shift), (kw, r, s, mode)
+                assert st.tolist() == stats, (kw, r, s, mode)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hip_merge_against_the_second_restatement(ctx, seed):
+    """random cohorts (up to 300 lists, so that the column-blocked pair takes them when it is the forced kernel) judged by
+    `dict_merge` -- a per-key dictionary over all samples, no cursors: another shape of merge.hpp:183-260 than the oracle's"""
+    from test_merge_independent import dict_merge, random_cohort, body_of
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([2, 7, 40, 200, 300]))
+    kw = int(rng.choice([1, 2]))
+    lists = random_cohort(rng, n, 3000, kw)
+    soft = [int(x) for x in rng.integers(1, 5, n)]
+    arrays = []
+    for l in lists:
+        ks = sorted(l)
+        arrays.append((np.array([[(key >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(kw)] for key in ks], np.uint64).reshape(len(ks), kw),
+                       np.array([l[key] for key in ks], np.uint32)))
+    for r, s in ((1, 0), (2, 1), (0, 0), (2, 3), (1, 2)):
+        rows, stats = dict_merge(lists, soft, r, s)
+        for mode in (orc.MODE_COUNT, orc.MODE_PA):
+            body, nrows, st = ctx.merge(arrays, kw, soft, r, s, mode)
+            assert nrows == len(rows) and body == body_of(rows, kw, n, mode), (n, kw, r, s, mode)
+            assert st.tolist() == stats, (n, kw, r, s)

@@ -801,3 +801,90 @@ def test_dump_and_aggregate(inputs, tmp_path):
     assert [int(x) for x in got[:, :8].copy().view(np.uint64).reshape(-1)] == [k for k, _, _ in sorted(flat)]
     r = subprocess.run([KMX, "aggregate", "--run-dir", str(out), "--count", "D1:kmer", "--sorted"], capture_output=True, text=True)
     assert r.returncode == 0 and len(r.stdout.splitlines()) == sum(G["task_main"]["superk_info_D1"][1::2])
+
+
+def _text_rows(body, kw, n, hash_mode, k=K):
+    """the oracle's count rows (key + n x u32) as write_as_text / write_as_pa_text print them (merge.hpp:288-316, 531-572): the k-mer as
+    letters (Kmer::to_string, kmer.hpp:541-550) or the hash in decimal, then the counts"""
+    rb = 8 * kw + 4 * n
+    out = []
+    for r in range(len(body) // rb):
+        row = body[r * rb:(r + 1) * rb]
+        key = int.from_bytes(row[:8 * kw], "little")
+        name = str(key) if hash_mode else "".join("ACTG"[(key >> (2 * d)) & 3] for d in range(k - 1, -1, -1))
+        out.append((name, list(struct.unpack(f"<{n}I", row[8 * kw:]))))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["kmer:count:text", "kmer:pa:text", "hash:count:text", "hash:pa:text"])
+def test_text_modes(inputs, tmp_path, mode):
+    """the four :text modes (src/cli.cpp:151-157): matrix_<p>.<ext>.txt, no header, a line per kept row -- key, then " <count>" or
+    " 0" / " 1" per sample (merge.hpp:288-316, 531-572); the rows are the :bin run's rows"""
+    hash_mode, what = mode.startswith("hash"), mode.split(":")[1]
+    out = run(inputs, tmp_path / "run", "--mode", mode, "--recurrence-min", "1", "--soft-min", "1", "--bloom-size", "1000000")
+    opts = open(out / "options.txt").read()
+    assert f"mode={what}," in opts and "format=text," in opts
+    W = ((1000000 + P - 1) // P + 63) // 64 * 64
+    lists = oracle_lists(hash_mode, W)
+    ext = {"count": "count", "pa": "pa"}[what] + ("_hash" if hash_mode else "") + ".txt"
+    assert sorted(os.listdir(out / "matrices")) == sorted(f"matrix_{p}.{ext}" for p in range(P))
+    for p in range(P):
+        body, rows, stats = orc.merge_matrix(lists[p], 1, [1, 1], 1, 0, orc.MODE_COUNT)
+        exp = "".join(name + "".join(" " + (str(c) if what == "count" else ("1" if c else "0")) for c in cnt) + "\n" for name, cnt in _text_rows(body, 1, 2, hash_mode))
+        got = open(out / "matrices" / f"matrix_{p}.{ext}").read()
+        assert got == exp and got.count("\n") == rows
+        if not hash_mode:
+            assert rows == G["merge_test"]["kmer_rows"][p]
+        mi = open(out / "merge_infos" / f"partition{p}.merge_info").read().splitlines()
+        assert [int(x) for x in mi[2].split("\t")[1:3]] == [int(x) for x in stats[2]]
+
+
+def _fixture_run_dir(d, kind):
+    """a run directory as `kmtricks pipeline --until count --keep-tmp` leaves it, made of the REFERENCE's committed count files
+    (tests/data/partitions/{kmers,hashes}: files of a MAX_C = 255 build, 1-byte counts)"""
+    import shutil
+    os.makedirs(d)
+    shutil.copy(os.path.join(GD, "kmtricks.fof"), d / "kmtricks.fof")
+    shutil.copy(os.path.join(GD, "hash.info"), d / "hash.info")
+    for p in range(P):
+        os.makedirs(d / "counts" / f"partition_{p}")
+        for s in ("D1", "D2"):
+            shutil.copy(os.path.join(GD, "partitions", kind + "s" if kind == "kmer" else "hashes", f"partition_{p}", f"{s}.{kind}"), d / "counts" / f"partition_{p}" / f"{s}.{kind}")
+    (d / "options.txt").write_text(f"Options: dir={d}, verbosity=info, nb_threads=8, fof=x, kmer_size=31, c_ab_min=1, m_ab_min=1, r_min=1, save_if=0, minim_size=10, "
+                                   f"nb_parts=4, bloom_size=1000192, keep_tmp=1, lz4=0, mode=count, format=bin, count_format={kind}, until=count\n")
+    return d
+
+
+@pytest.mark.parametrize("kind", ["kmer", "hash"])
+def test_merge_module_over_the_reference_s_count_files(tmp_path, kind):
+    """`kmx merge --run-dir` (the reference's `kmtricks merge`, src/cli.cpp:526-646) over the count files the REFERENCE committed with its
+    tests -- 1-byte counts (count_slots 1: a MAX_C = 255 build, CMakeLists.txt:25-41): the 57 / 67 / 70 / 82 rows of
+    tests/merge_test.cpp:21-39, bodies = the oracle's over the same files, and `kmx dump` reads them back"""
+    d = _fixture_run_dir(tmp_path / "run", kind)
+    hash_mode = kind == "hash"
+    sub = "kmers" if kind == "kmer" else "hashes"
+    one = (kmfiles.read_kmer_file if kind == "kmer" else kmfiles.read_hash_file)(f"{GD}/partitions/{sub}/partition_0/D1.{kind}")
+    assert one["count_slots"] == 1
+    r = subprocess.run([KMX, "merge", "--run-dir", str(d), "--mode", f"{kind}:count:bin", "--recurrence-min", "1", "--soft-min", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows_exp = G["merge_test"]["kmer_rows" if kind == "kmer" else "hash_rows"]
+    for p in range(P):
+        fs = [(kmfiles.read_kmer_file if kind == "kmer" else kmfiles.read_hash_file)(f"{GD}/partitions/{sub}/partition_{p}/{s}.{kind}") for s in ("D1", "D2")]
+        lists = [(np.ascontiguousarray(f["keys"]).reshape(-1), f["counts"].astype(np.uint32)) for f in fs]
+        body, rows, stats = orc.merge_matrix(lists, 1, [1, 1], 1, 0, orc.MODE_COUNT)
+        raw = open(d / "matrices" / f"matrix_{p}.{'count_hash' if hash_mode else 'count'}", "rb").read()
+        assert rows == rows_exp[p] and raw[(37 if hash_mode else 45):] == body
+        assert (d / "counts" / f"partition_{p}" / f"D1.{kind}").exists()      # (no --clear: the partition files stay)
+        mi = open(d / "merge_infos" / f"partition{p}.merge_info").read().splitlines()
+        assert [int(x) for x in mi[2].split("\t")[1:3]] == [int(x) for x in stats[2]]
+    dump = subprocess.run([KMX, "dump", "--input", str(d / "matrices" / f"matrix_0.{'count_hash' if hash_mode else 'count'}")], capture_output=True, text=True)
+    assert dump.returncode == 0 and dump.stdout.count("\n") == rows_exp[0]
+    # --partition-id: one partition; --clear: its count files go; a directory that is no run directory is refused
+    d2 = _fixture_run_dir(tmp_path / "run2", kind)
+    r = subprocess.run([KMX, "merge", "--run-dir", str(d2), "--mode", f"{kind}:pa:text", "--partition-id", "2", "--clear"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.listdir(d2 / "matrices") == [f"matrix_2.{'pa_hash' if hash_mode else 'pa'}.txt"]
+    assert not (d2 / "counts" / "partition_2" / f"D1.{kind}").exists() and (d2 / "counts" / "partition_1" / f"D1.{kind}").exists()
+    assert open(d2 / "matrices" / os.listdir(d2 / "matrices")[0]).read().count("\n") == rows_exp[2]
+    r = subprocess.run([KMX, "merge", "--run-dir", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "not a kmtricks runtime directory" in r.stderr
