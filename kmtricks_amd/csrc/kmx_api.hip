@@ -313,6 +313,7 @@ struct TaskHost {
   u32 rec_min = 0, share_min = 0, row_bytes = 0, seg_cap = 0;
   u64 lower = 0, upper = 0, total_recs = 0, out_cap_rows = 0, rows_guess = 0;
   u64 arena_rows = 0;            // rows claimed in the arena (kept rows + unused chunk tails)
+  bool rows_overflow = false;    // ... and the kernel flagged that they did not fit
   std::vector<u32> len;
   // offsets into the meta blob
   size_t o_recs = 0, o_len = 0, o_smin = 0, o_bounds = 0, o_stats = 0, o_ctrl = 0, o_segs = 0;
@@ -361,6 +362,8 @@ struct kmx_merge_result {
   bool cols_resc = false;                        // the RESC builds of the column-blocked pair (share-min, recurrence-min 0)
   bool share_fix = false;                        // ... with a task whose share-min is above its recurrence-min: k_share_fix behind them
   bool cols_ord = false;                         // ... and their ORD builds: rows written at their final place
+  bool back_other = false;           // tasks were handed back for another reason than ERR_DENSE_CAP
+  bool cols_narrow = false;          // k_merge_cols' NAR build: every task's side store of row keys' rows is the byte-wide one
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
   bool use_pivot = false;            // COUNT/PA: pivot-tiled kernel first, k_merge_rows as the general fallback
@@ -482,7 +485,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     // (tuning knobs: KMX_COLS_GRID / KMX_SPARSE_GRID = workgroups of the two persistent kernels -- what each loses on a part of the chip)
     const u32 cols_grid_env = getenv("KMX_COLS_GRID") ? (u32)atoi(getenv("KMX_COLS_GRID")) : 0u;
     const u32 sparse_cus_env = getenv("KMX_SPARSE_CUS") ? (u32)atoi(getenv("KMX_SPARSE_CUS")) : 0u;
-    KMX_HIP(ctx, CO.merge(mode, (R->cols_ext ? 1 : 0) | (R->cols_resc ? 2 : 0) | (R->cols_ord ? 4 : 0), d_tasks, d_cols, d_citems, R->n_citems, d_ticket,
+    KMX_HIP(ctx, CO.merge(mode, (R->cols_ext ? 1 : 0) | (R->cols_resc ? 2 : 0) | (R->cols_ord ? 4 : 0) | (R->cols_narrow ? 8 : 0), d_tasks, d_cols, d_citems, R->n_citems, d_ticket,
                           cols_grid_env ? std::min(cols_grid_env, R->cols_grid) : R->cols_grid, ctx->stream));
     if (R->ev0) { if (!R->ev_mid) KMX_HIP(ctx, hipEventCreate(&R->ev_mid)); KMX_HIP(ctx, hipEventRecord(R->ev_mid, ctx->stream)); }
     // (the second kernel stays on the merge's stream: on one of its own it takes CUs from the next batch's merge -- step +8 %)
@@ -674,7 +677,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       min_rec = std::min(min_rec, H.rec_min); max_rec = std::max(max_rec, H.rec_min);
     }
     const char* force = getenv("KMX_MERGE_KERNEL");
-    const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists();
+    // (recurrence-min 0 -- a key only non-solid records hold is a row of zeros -- is beyond k_merge_pivot: it drops such records before
+    //  they reach its tables; found by tests/test_merge_gpu.py::test_hip_merge_against_the_second_restatement, round 5)
+    const bool can = !is_bf && !rescue && kw == 1 && mx_n <= pivot_max_lists() && min_rec >= 1;
     // (both key widths: merge_cols.hip, merge_cols_k2.hip; share-min up to max(1, recurrence-min): the RESC builds, which also take
     //  recurrence-min 0 -- there a key only non-solid records hold is a row)
     bool resc_ok = true, need_resc = false;
@@ -746,11 +751,25 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   const u32 cols_cus = (u32)ctx->n_cu * CO.wgs_per_cu();
   const u32 target_items = (R->use_cols ? cols_cus : slots) * per_slot;
   u32 n_items = 0, max_n = 0, max_c = 0;
+  // the byte-wide side store of the row keys' rows (count rows in file order; k_merge_cols' NAR build): count rows of 512 to 1022 lists in
+  // at most 8 column blocks -- every task of the batch, the build is chosen per launch (KMX_DENSE_NARROW=1: from any size, =0: never)
+  R->cols_narrow = false;
+  if (R->use_cols && R->cols_ord && mode == KMX_MODE_COUNT) {
+    const char* const nenv = getenv("KMX_DENSE_NARROW");
+    bool all = true;
+    for (auto& H : R->tasks) {
+      const u32 nblk0 = (H.N + CO.block_lists() - 1) / CO.block_lists();
+      const bool on = nenv ? nenv[0] != '0' : H.N >= 512;
+      all = all && on && (H.row_bytes & 7u) == 0 && H.row_bytes / 8 <= 512 && nblk0 <= 8 && CO.block_lists() % 16 == 0;
+    }
+    R->cols_narrow = all;
+  }
   for (auto& H : R->tasks) {
     if (R->use_cols) {
       H.nblk = (H.N + CO.block_lists() - 1) / CO.block_lists();
       // (lists per block: even for count rows -- 8-byte stores --, a multiple of 8 for PA rows -- whole bytes per block)
       H.nb = std::min<u32>(CO.block_lists(), mode == KMX_MODE_COUNT ? ((((H.N + H.nblk - 1) / H.nblk) + 1) & ~1u) : ((((H.N + H.nblk - 1) / H.nblk) + 7) & ~7u));
+      if (R->cols_narrow) H.nb = std::min<u32>(CO.block_lists(), (((H.N + H.nblk - 1) / H.nblk) + 15) & ~15u);      // (a row's slice of a block leaves as 16-byte pieces)
       H.nblk = (H.N + H.nb - 1) / H.nb;
       H.rt_cols = CO.tile_rows(H.nb);
     }
@@ -909,11 +928,10 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         // the 4-byte rows only)
         // (from 512 lists: below, the two ways cost the same within the noise -- grid of N = 200 .. 1000, profiles/r04_dense_narrow_store.txt --;
         //  KMX_DENSE_NARROW=1: wherever it applies, =0: nowhere.  Read per batch: the tests switch it)
-        const char* const nenv = getenv("KMX_DENSE_NARROW");
-        const bool narrow_on = nenv ? nenv[0] != '0' : H.N >= 512;
-        if (mode == KMX_MODE_COUNT && narrow_on && (H.row_bytes & 7u) == 0 && H.row_bytes / 8 <= 512 && H.nblk <= 8) {
-          H.npitch = (u32)align_up((size_t)H.N, 8) + 8;
-          H.d_narrow = (u8*)ctx->dalloc((size_t)H.dense_cap * H.npitch);      // (none: the wide rows alone)
+        if (R->cols_narrow) {      // [N count bytes, padded to 16][16 bytes: a flag byte per column block]
+          H.npitch = (u32)align_up((size_t)H.N, 16) + 16;
+          H.d_narrow = (u8*)ctx->dalloc((size_t)H.dense_cap * H.npitch);
+          if (!H.d_narrow) { ctx->dfree(H.d_dense); H.d_dense = nullptr; }
         }
       }
     }
@@ -1041,8 +1059,9 @@ static int fetch_ctrl(kmx_merge_result* R, bool* overflow, bool* fallback = null
     const u64* ctrl = hc + t * 8;
     H.arena_rows = ctrl[0]; H.nsegs = ctrl[1]; H.rows = ctrl[3]; H.sparse_rows = ctrl[6]; H.row_keys = ctrl[7];
     if (ctrl[2] & (ERR_ROWS_OVERFLOW | ERR_SEGS_OVERFLOW)) *overflow = true;
+    H.rows_overflow = (ctrl[2] & ERR_ROWS_OVERFLOW) != 0;
     H.handed_back = false;
-    if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; if (ctrl[2] & ERR_DIVERGENT) R->divergent = true; if (ctrl[2] & ERR_SLICES) R->slices_full = true; }
+    if ((ctrl[2] & ERR_FALLBACK) && fallback) { *fallback = true; H.handed_back = true; if (ctrl[2] & ERR_DIVERGENT) R->divergent = true; if (ctrl[2] & ERR_SLICES) R->slices_full = true; if (!(ctrl[2] & ERR_DENSE_CAP)) R->back_other = true; }
   }
   return KMX_OK;
 }
@@ -1105,7 +1124,9 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
       // suit -- the context's next batches run the build whose waves claim slice extensions; no pause
       const bool retry_ext = R->slices_full && !R->cols_ext && !R->divergent;
       if (retry_ext) ctx->cols_ext = true;
-      if (R->cols_auto && n_back * 4 >= R->given && !retry_ext) {   // a cohort it does not suit: back off for the next batches
+      // (tasks that came back ONLY because the side store of the row keys' rows was sized too small -- a host estimate the next batch
+      //  corrects from this one's row keys, keys_per_longest above -- are no sign of a cohort the kernel does not suit: no back-off)
+      if (R->cols_auto && n_back * 4 >= R->given && !retry_ext && R->back_other) {   // a cohort it does not suit: back off for the next batches
         // (doubling; at once to the longest pause when three quarters of the batch came back: a try costs a whole merge)
         ctx->cols_backoff = n_back * 4 >= 3 * R->given ? 64u : std::min(64u, std::max(1u, ctx->cols_backoff * 2));
         ctx->cols_skip = ctx->cols_backoff;
@@ -1162,6 +1183,10 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     TaskDev* td = reinterpret_cast<TaskDev*>(R->h_meta + R->o_tasks);
     for (size_t t = 0; t < R->tasks.size(); t++) {
       TaskHost& H = R->tasks[t];
+      // (the file-order build of k_cols_sparse stops counting a task's rows once a group has overflowed the arena -- the later tickets
+      //  of the task skip their groups --, so ctrl[0] may come back BELOW the arena's size: the retry then gets half as much again
+      //  instead of the same arena a second time)
+      if (H.rows_overflow && H.arena_rows <= H.out_cap_rows) H.arena_rows = H.out_cap_rows + H.out_cap_rows / 2 + 1;
       if (H.arena_rows > H.out_cap_rows) {
         ctx->dfree(H.d_out);
         // (what the kernel claimed, plus a chunk per range: the retry may run with another kernel -- tasks a cohort

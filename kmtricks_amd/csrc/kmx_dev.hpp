@@ -83,7 +83,9 @@ struct ColsDev {
 
 enum { ERR_ROWS_OVERFLOW = 1, ERR_SEGS_OVERFLOW = 2, ERR_FALLBACK = 4,
        ERR_DIVERGENT = 8,    // (with ERR_FALLBACK, from k_cols_prep: the lists share too few keys for the kernels built for cohorts)
-       ERR_SLICES = 16 };    // (with ERR_FALLBACK, from k_merge_cols: a wave's set-aside slice ran over -- the batches that follow use the build with extensions)
+       ERR_SLICES = 16,      // (with ERR_FALLBACK, from k_merge_cols: a wave's set-aside slice ran over -- the batches that follow use the build with extensions)
+       ERR_DENSE_CAP = 32 }; // (with ERR_FALLBACK, from k_cols_prep: more row keys than the side store of their rows was sized for -- a host estimate;
+                             //  the next batches are sized from what this one reported: no back-off)
 
 // ---- keys -------------------------------------------------------------------------------------
 template <int KW> struct Key { u64 w[KW]; };

@@ -33,6 +33,7 @@
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
 #include "kmx_host.hpp"
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstring>
 
@@ -66,8 +67,13 @@ constexpr int EW = KW + 1;               // u64 words per set-aside entry: the k
 constexpr int CL_U = KW == 1 ? 16 : 8;   // window slots per lane (a 128-bit record is 5 registers: 8 slots keep the kernel under 128 VGPRs)
 constexpr int CL_W = CL_G * CL_U;        // records per window
 constexpr int CL_NB = CL_TPB / CL_G;     // lists per column block
-constexpr int CL_IMG = 61440 / CL_WGS;   // LDS image bytes (rt rows x nb u32 counts)
 constexpr int CL_RT = CL_W * 7 / 8;      // row keys per tile (< window: a similar list needs no second round)
+constexpr int CL_IMG = CL_RT * CL_NB * 4;   // LDS image bytes (rt rows x nb u32 counts: 56 KB for 64-bit keys, 28 KB for 128-bit ones)
+#ifndef KMX_CL_STK
+#define KMX_CL_STK 2
+#endif
+constexpr int CL_STK = KMX_CL_STK;       // records that are no row keys staged per lane and round (LDS: key words + count, a column per thread)
+constexpr int CL_STG = (CL_STK + 1) * CL_TPB * (KW * 8 + 4);      // ... bytes of that staging area (+ a row for the writes of a lane whose rows are full)
 constexpr int CL_KPL = (CL_RT + 63) / 64;   // row keys per lane of wave 0 (which builds the row table)
 constexpr int CL_NT = (CL_KPL == 1 && CL_WGS == 1 && KW == 1) ? 2 : 1;  // row tables: two of 2048 entries (the next tile's is built beside this tile's), or one
 constexpr int CL_PT = CL_KPL == 1 ? 2048 : 4096;      // row-key table entries
@@ -108,7 +114,7 @@ __device__ __forceinline__ CKey cl_key(const CRec& r) { return (u64)r.v.x | ((u6
 __device__ __forceinline__ u32 cl_cnt(const CRec& r) { return r.v.z; }
 __device__ __forceinline__ CRec cl_none() { CRec r; r.v.x = ~0u; r.v.y = ~0u; r.v.z = 0; return r; }
 __device__ __forceinline__ CRec cl_load(gu32* p) { CRec r; r.v = *(gu32x3*)p; return r; }
-__device__ __forceinline__ bool ent_hit(const ClEnt& e, CKey k) { return e.klo == (u32)k && e.khi == (u32)(k >> 32) && e.idx != 0; }
+__device__ __forceinline__ bool ent_hit(const ClEnt& e, CKey k) { return (((u64)e.khi << 32) | e.klo) == k && e.idx != 0; }      // (one 64-bit compare)
 __device__ __forceinline__ void ent_set(ClEnt& e, CKey k) { e.klo = (u32)k; e.khi = (u32)(k >> 32); }
 __device__ __forceinline__ ClEnt ent_load(const ClEnt* tab, u32 h) { const uint4 v = reinterpret_cast<const uint4*>(tab)[h]; ClEnt e; e.klo = v.x; e.khi = v.y; e.idx = v.z; e.pad = v.w; return e; }      // one 16-byte LDS read
 #else
@@ -165,6 +171,24 @@ __device__ __forceinline__ u32 cl_thash(CKey key, u32 hf)
 #endif
   return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
 }
+// the same with the family a compile-time constant (the slot loop is built once per family: the branch on the tile's hash word left
+// the loop -- 4 scalar and 2 vector instructions per record)
+template <bool WHOLE>
+__device__ __forceinline__ u32 cl_thash_f(CKey key, u32 hf)
+{
+  const u64 k = ck_fold(key);
+  if (WHOLE) {
+    const u64 m = 0x9E3779B97F4A7C15ULL + 2ULL * (u64)(hf & 0xFFFFu) * 0xBF58476D1CE4E5B9ULL;
+    return (u32)((k * m) >> (CL_PT == 2048 ? 53 : 52));
+  }
+#if KMX_CL_KW == 1
+  const u32 x = ((u32)k ^ (u32)(k >> (hf >> 24))) & 0xFFFFFFu;
+#else
+  const u32 f = (u32)k ^ (u32)(k >> 32);
+  const u32 x = (f ^ (f >> 8)) & 0xFFFFFFu;
+#endif
+  return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);
+}
 __device__ __forceinline__ u32 cl_mult(u32 seed)
 {
   if (KW == 2 && seed >= 16u) return 0x80000000u | (seed - 15u);      // (its cheap hashes differ in the multiplier only: 16 tries tell)
@@ -179,9 +203,9 @@ __device__ __forceinline__ u32 cl_mix(CKey key)
   return x;
 }
 // wave 0: lane j holds row keys j, j + 64, ...  -> the hash, 0 when no try worked; slot[x] = entry of my key x
-__device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL])
+__device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL], u32 first = 0)
 {
-  for (u32 s = 0; s < (u32)CL_SEEDS; s++) {
+  for (u32 s = first; s < (u32)CL_SEEDS; s++) {
     const u32 mult = cl_mult(s);
     u32 h[CL_KPL], old[CL_KPL];
     bool clash = false;
@@ -200,6 +224,35 @@ __device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], c
     for (int x = 0; x < CL_KPL; x++) if (have[x] && old[x] == 0) atomicExch(&tab[h[x]].idx, 0u);      // take my claims back, next hash
   }
   return 0;
+}
+
+// ---- the same search by every wave of the workgroup at once (round 5): wave w tries hash `first + w` of the family on the tile's row keys
+//      in a bit map of its own (a bit per table entry), no table touched; the lowest wave that found no clash names the tile's hash and
+//      wave 0 then puts the keys in.  One parallel try finds a hash for 49 tiles in 50 (a try works with probability ~0.22 for 112 keys
+//      in 4096 entries); round 4's wave 0 went through its ~4.6 tries one after the other while the other fifteen waves, done with the
+//      image, waited for it at the barrier -- the longest pole of every tile.  Lane j holds row keys j, j + 64, ... (ck_inf where none). ----
+__device__ __forceinline__ u32 cl_try(u32* const bm, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], const u32 lane, const u32 mult)
+{
+#pragma unroll
+  for (u32 t = 0; t < (u32)CL_PT / 32u / 64u; t++) bm[lane + 64u * t] = 0;      // (my wave's map: the same wave's LDS operations stay in order)
+  bool clash = false;
+#pragma unroll
+  for (int x = 0; x < CL_KPL; x++) {
+    const u32 h = cl_thash(key[x], mult);
+    const u32 old = have[x] ? atomicOr(&bm[h >> 5], 1u << (h & 31u)) : 0u;
+    clash |= (old >> (h & 31u)) & 1u;
+  }
+  return __ballot(clash) == 0 ? mult : 0u;
+}
+// wave 0: the keys into the (emptied) table under the hash that was found
+__device__ __forceinline__ void cl_fill(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], const u32 lane, const u32 mult, u32 (&slot)[CL_KPL])
+{
+#pragma unroll
+  for (int x = 0; x < CL_KPL; x++) {
+    const u32 h = cl_thash(key[x], mult);
+    if (have[x]) { ent_set(tab[h], key[x]); tab[h].idx = lane + 64u * x + 1; }
+    slot[x] = h;
+  }
 }
 
 }  // namespace
@@ -324,8 +377,9 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
   const u64 serr = S.ctrl[2], nseg64 = S.ctrl[1], rows = S.ctrl[3];
   if (tid == 0) T.ctrl[7] = rows;      // (the host sizes the next batches' stores of row keys' rows from it, whatever becomes of this task)
   const u64 slots = rows / C.rt + T.c + 2;
+  const bool dense_small = C.dense != nullptr && rows > (u64)C.dense_cap;      // (the host's estimate of the row keys fell short: its own flag, see ERR_DENSE_CAP)
   const bool bad = serr != 0 || nseg64 > (u64)CP_MAXSEG || nseg64 > S.seg_cap || rows > T.out_cap_rows || rows > 0xFFFFFF00ULL ||
-                   slots > C.slots_cap || (C.dense != nullptr && rows > (u64)C.dense_cap);
+                   slots > C.slots_cap || dense_small;
   // the share of the merged lists' solid records that the row keys do not cover estimates what every list would set aside:
   // above 1/8 the slices would overflow (and k_merge_pivot gives up at the same point): straight to k_merge_rows
   const u64 nsolid = S.ctrl[4], ncov = S.ctrl[5];
@@ -336,7 +390,8 @@ void k_cols_prep(const TaskDev* __restrict__ tasks, const TaskDev* __restrict__ 
     return;
   }
   if (bad) {   // the row keys could not be built (arena too small, ...): the general kernels take the task
-    if (tid == 0) { atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK); *C.nskel = 0; }
+    const bool only_dense = dense_small && !(serr != 0 || nseg64 > (u64)CP_MAXSEG || nseg64 > S.seg_cap || rows > T.out_cap_rows || rows > 0xFFFFFF00ULL || slots > C.slots_cap);
+    if (tid == 0) { atomicOr(&T.ctrl[2], (u64)(ERR_FALLBACK | (only_dense ? ERR_DENSE_CAP : 0))); *C.nskel = 0; }
     for (u32 j = tid; j <= T.c; j += CP_TPB) { C.rbounds[j] = 0; if (C.gbase) C.gbase[j] = 0; }      // (no slice groups: k_cols_sparse has nothing to wait for)
     return;
   }
@@ -414,7 +469,11 @@ __device__ u64 kmx_sparse_prof[8];
 constexpr u64 CL_NONSOLID = 1ULL << 63;      // set-aside entry of a RESC build: the record is below its list's soft-min
 // ORD: the row keys' rows go to the side store k_cols_sparse copies them from (rows at their final place, kmx_set_file_order) -- a
 // build of its own: as a run-time switch the side store's code cost the other build seven more spilled registers (round 4: 2.53 -> 2.70 ms)
-template <int MODE, bool EXT, bool RESC, bool ORD>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
+// NAR (count rows of an ORD build): the side store holds ONE BYTE per count (C.dnarrow) -- and so does the tile's image in LDS: a
+// deposit is a byte (255 = "the count is in the 4-byte row", written there by the lane that holds it: rare), a row's slice of the
+// block leaves as 16-byte pieces (round 4 kept the u32 image and squeezed it on the way out: a row at a time per wave, 2-byte
+// stores -- 19 % of the kernel)
+template <int MODE, bool EXT, bool RESC, bool ORD, bool NAR>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
 __global__ __launch_bounds__(CL_TPB, CL_WGS)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
                   u32 n_items, u32* ticket)
@@ -423,6 +482,9 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   u32* const img = reinterpret_cast<u32*>(smem);                                   // [rt][nb] counts of the tile
   ClEnt* const ptab = reinterpret_cast<ClEnt*>(smem + CL_IMG);                     // [CL_NT][CL_PT] row key -> row
   u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt)); // [0] item [1..3] "another round" flags, used in turn [4],[5] the tables' multipliers
+  u32* const tryres = sh + 80;                                                     // [CL_NW] what each wave's try of a hash for the next tile's row table gave (0: a clash)
+  u32* const trymap = reinterpret_cast<u32*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt) + 384) + (threadIdx.x >> 6) * (CL_PT / 32);      // my wave's bit map for it (the set-aside stage's room: idle between the scans)
+  static_assert(CL_NW * (CL_PT / 8) <= CL_STG, "the waves' bit maps fit the stage");
   const u32 dummy = (u32)(CL_IMG + CL_NT * CL_PT * sizeof(ClEnt)) / 4 + 16 + (u32)(threadIdx.x & 63);   // image index of a scratch word of my own (deposits that are none)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -469,8 +531,12 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     // ... count rows there as ONE BYTE per count where a block's slice of the row holds none above 254 (the usual case by far): the
     // side store is written here and read again by k_cols_sparse -- a quarter of the bytes both ways.  C.dnarrow row r = [N count
     // bytes, padded to 8][a flag byte per column block: 1 = this block's counts of the row are in the 4-byte row]
-    u8* const nar = (MODE == 0 && ord) ? C.dnarrow : nullptr;
-    const u32 npitch = nar ? cl_uni(C.npitch) : 0u;
+    static_assert(!NAR || (MODE == 0 && ORD), "the byte-wide side store is for count rows in file order");
+    u8* const nar = NAR ? C.dnarrow : nullptr;
+    const u32 npitch = NAR ? cl_uni(C.npitch) : 0u;
+    u8* const img8 = reinterpret_cast<u8*>(img);                  // NAR: [rt][nbs] count bytes
+    u8* const rowbig = reinterpret_cast<u8*>(smem) + CL_IMG - 128;   // NAR: [rt] "this row of the tile holds a count above 254" (the image's last bytes: rt * nbs <= CL_IMG / 4)
+    const u32 dummyb = dummy * 4u;
 
     // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + CL_G * u
     // (mod CL_W) inside [cur, cur + CL_W)
@@ -498,19 +564,32 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     bool failed = false;
 #pragma unroll
     for (int x = 0; x < CL_KPL; x++) { skn[x] = ck_inf(); myslot[x] = 0; }
-    if (tid < 64) {
+    // (every wave holds the tile's row keys and tries one hash of the family on them: cl_try)
+    auto pick = [&]() -> u32 {      // the lowest wave's hash that worked (0: none did); uniform
+      const u32 v = tryres[lane & (CL_NW - 1)];
+      const u64 okm = __ballot(v != 0);
+      return okm ? (u32)__builtin_amdgcn_readlane((int)v, (int)__builtin_ctzll(okm)) : 0u;
+    };
+    {
       bool have[CL_KPL];
 #pragma unroll
       for (int x = 0; x < CL_KPL; x++) {
-        const u32 j = (u32)tid + 64u * x;
+        const u32 j = (u32)lane + 64u * x;
         have[x] = j < rt && s_lo + j < s_hi;
         if (have[x]) {
           skn[x] = skel[s_lo + j];
-          if (blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes), skn[x]);
+          if (wave == 0 && blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes), skn[x]);
         }
       }
-      const u32 mult = cl_build(ptab, skn, have, (u32)tid, myslot);
-      if (tid == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
+      const u32 res = cl_try(trymap, skn, have, (u32)lane, cl_mult(wave));
+      if (lane == 0) tryres[wave] = res;
+      cl_barrier();
+      if (wave == 0) {
+        u32 mult = pick();
+        if (mult) cl_fill(ptab, skn, have, (u32)lane, mult, myslot);
+        else mult = cl_build(ptab, skn, have, (u32)lane, myslot, (u32)CL_NW);
+        if (lane == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
+      }
     }
     CKey khi_n = ntiles > 1 ? skel[s_lo + rt] : ck_inf();     // upper key of tile 0 (uniform address: scalar load)
     CKey kmid_n = (CL_HALVES > 1 && s_lo + 56 < s_hi) ? skel[s_lo + 56] : ck_inf();      // ... and the key its second slice group starts at
@@ -525,10 +604,10 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       const CKey khi = ck_uni(khi_n);
       const CKey kmid = ck_uni(kmid_n);
       if (!last) {
-        // the next tile's row keys are wave 0's business alone: nobody else ever waits for these loads
-        if (tid < 64) {
+        // the next tile's row keys: requested now, looked at when this tile is done
+        {   // (every wave: each tries a hash for the next tile's table on them when this tile is done)
 #pragma unroll
-          for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)tid + 64u * x; skn[x] = ck_inf(); if (j < rt && s0 + rt + j < s_hi) skn[x] = skel[s0 + rt + j]; }
+          for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)lane + 64u * x; skn[x] = ck_inf(); if (j < rt && s0 + rt + j < s_hi) skn[x] = skel[s0 + rt + j]; }
         }
         khi_n = q + 2 < ntiles ? skel[s0 + 2 * rt] : ck_inf();
         kmid_n = (CL_HALVES > 1 && s0 + rt + 56 < s_hi) ? skel[s0 + rt + 56] : ck_inf();
@@ -551,6 +630,142 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       };
       gu64w* const ovx = (gu64w*)(uintptr_t)C.ovx;
 
+      // ---- the records that are no row keys: staged in LDS per lane while the window's slots are walked (key words + count at
+      //      the lane's column of stage row `nov`, written for EVERY slot, kept -- nov moves on -- only for such a record), and
+      //      appended to the wave's slices once per round: one pass per staged row (2-3 of them) instead of a ballot, a branch and
+      //      the positions' arithmetic per window slot (16 of them; with 3 % of the records set aside a slot of SOME lane of the wave
+      //      is one 86 % of the time: round 4's loop spent a third of its instructions there) ----
+      u64* const stk = reinterpret_cast<u64*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt) + 384);                                     // [CL_STK + 1][KW][CL_TPB]
+      u32* const stc = reinterpret_cast<u32*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt) + 384 + (size_t)(CL_STK + 1) * KW * CL_TPB * 8);   // [CL_STK + 1][CL_TPB]
+      u32 nov = 0;                                  // my staged records
+      // one record per lane (where `has`) to the wave's slices: positions from ballots
+      auto append = [&](const bool has, const CKey kk, const u32 cc) {
+        const u64 bal = __ballot(has);
+        const u64 pay = li_hi | cc | ((RESC && cc < smin) ? CL_NONSOLID : 0ULL);
+#if KMX_CL_KW == 1
+#define CL_PUT(o, pos) do { (o)[2 * (pos)] = kk; (o)[2 * (pos) + 1] = pay; } while (0)
+#else
+#define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = pay; } while (0)
+#endif
+        if (CL_HALVES == 1) {
+          if (EXT && __builtin_expect(wov + (u32)__popcll(bal) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
+          if (has) {
+            const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+            if (pos < (u32)CL_OVW) CL_PUT(ovk0, pos);
+            else if (EXT && xb0 - 1u < 0xFFFFFFFEu && pos - (u32)CL_OVW < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb0 - 1u) * EW; const u32 px = pos - (u32)CL_OVW; CL_PUT(o, px); }
+          }
+          wov += (u32)__popcll(bal);
+        } else {
+          const bool up = !ck_lt(kk, kmid);
+          const u64 hi = __ballot(has && up), lo = bal & ~hi;
+          if (EXT && __builtin_expect(wov + (u32)__popcll(lo) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
+          if (EXT && __builtin_expect(wov1 + (u32)__popcll(hi) > (u32)CL_OVW && xb1 == 0, 0)) extend(xb1);
+          if (has) {
+            const u64 m = up ? hi : lo;
+            const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+            if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; CL_PUT(o, pos); }
+            else if (EXT) {
+              const u32 xb = up ? xb1 : xb0, px = pos - (u32)CL_OVW;
+              if (xb - 1u < 0xFFFFFFFEu && px < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb - 1u) * EW; CL_PUT(o, px); }
+            }
+          }
+          wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
+        }
+      };
+      auto flush = [&]() {
+#pragma unroll 1
+        for (u32 kq = 0; kq < (u32)CL_STK; kq++) {
+          const bool has = kq < nov;
+          if (!__ballot(has)) break;
+          const u32 sx = kq * (u32)CL_TPB + (u32)tid;
+#if KMX_CL_KW == 1
+          const CKey kk = stk[sx];
+#else
+          CKey kk; kk.lo = stk[2 * kq * (u32)CL_TPB + (u32)tid]; kk.hi = stk[(2 * kq + 1) * (u32)CL_TPB + (u32)tid];
+#endif
+          append(has, kk, stc[sx]);
+        }
+        nov = 0;
+      };
+      // the walk over the window's slots, built once per hash family of the tile's row table (a uniform choice per tile)
+      auto walk = [&](const u32 consm, u32& cur_) {
+#pragma unroll
+        for (int g = 0; g < CL_U; g += 4) {
+          __builtin_amdgcn_sched_barrier(0);
+          u32 curg = cur_; asm volatile("" : "+v"(curg));      // (re-derived per group: 16 slot indices kept live get spilled)
+          ClEnt pe[4];
+#if defined(KMX_CL_LEVEL) && KMX_CL_LEVEL == 0      // (timing experiments, not builds: 0 = the window's loads and nothing else, 1 = + the table lookups, 2 = + the deposits, 3 = everything)
+#pragma unroll
+          for (int j = 0; j < 4; j++) { tsum += cl_cnt(rec[g + j]); tn += (u32)ck_fold(cl_key(rec[g + j])); }
+          asm volatile("" : "+v"(tsum), "+v"(tn));
+          if (false)
+#else
+#pragma unroll
+          for (int j = 0; j < 4; j++) pe[j] = ent_load(tab, cl_thash(cl_key(rec[g + j]), mult));
+#endif
+#if defined(KMX_CL_LEVEL) && KMX_CL_LEVEL == 1
+#pragma unroll
+          for (int j = 0; j < 4; j++) { tsum += cl_cnt(rec[g + j]); tn += ent_hit(pe[j], cl_key(rec[g + j])) ? pe[j].idx : 0u; }
+          asm volatile("" : "+v"(tsum), "+v"(tn));
+          if (false)
+#endif
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            // straight-line: masks and selects, no branches (a deposit that is none goes to a scratch word)
+            const int u = g + j;
+            const bool cons = (consm >> u) & 1u;
+            const CKey k = cl_key(rec[u]);
+            const u32 c = cl_cnt(rec[u]);
+            const bool solid = cons && c >= smin;
+            const bool hit = ent_hit(pe[j], k);
+            tsum += solid ? c : 0u;
+            tn += (cons && !solid) ? 1u : 0u;
+            // (RESC: a row key's row has recurrence-min >= share-min solid records: its non-solid records are rescued, written like the others)
+            const bool dep = RESC ? (cons && hit && (solid || rescue)) : (solid && hit);
+            if (RESC) { const bool rs = cons && hit && !solid && rescue; rsum += rs ? c : 0u; rn += rs ? 1u : 0u; }
+            if (NAR) {
+              img8[dep ? __umul24(pe[j].idx - 1, nbs) + lg : dummyb] = (u8)min(c, 255u);
+              if (__builtin_expect(__ballot(dep && c > 254u) != 0, 0)) {      // (a count that does not fit the byte: to the 4-byte row, by the lane that holds it)
+                if (dep && c > 254u) { reinterpret_cast<u32*>(C.dense + (u64)(s0 + pe[j].idx - 1) * opitch)[li] = c; rowbig[pe[j].idx - 1] = 1; }
+              }
+            }
+            else if (MODE == 0) img[dep ? __umul24(pe[j].idx - 1, iw) + lg : dummy] = c;
+            else if (dep) atomicOr(&img[__umul24(pe[j].idx - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
+            // a solid record that is no row key (RESC: any such record): staged -- written whatever it is, kept when it is one
+#if defined(KMX_CL_LEVEL) && KMX_CL_LEVEL == 2
+            if (true) continue;
+#endif
+            const bool ov = (RESC ? cons : solid) && !hit;
+            // (a lane whose CL_STK stage rows are full -- a third such record in one round: rare -- writes to a row nobody reads, and its
+            //  record goes to the slices at once)
+            const bool full = nov >= (u32)CL_STK;
+            if (__builtin_expect(__ballot(ov && full) != 0, 0)) append(ov && full, k, c);
+            const u32 sx = nov * (u32)CL_TPB + (u32)tid;
+#if KMX_CL_KW == 1
+            stk[sx] = k;
+#else
+            stk[2 * nov * (u32)CL_TPB + (u32)tid] = k.lo; stk[(2 * nov + 1) * (u32)CL_TPB + (u32)tid] = k.hi;
+#endif
+            stc[sx] = c;
+            nov += (ov && !full) ? 1u : 0u;
+          }
+          asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
+          if (RESC) asm volatile("" : "+v"(rsum), "+v"(rn));
+          // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record is
+          // the one 64 positions further (one past the list's end: the sentinel).  A slot that was not consumed is left
+          // alone: loading it again would fetch the window's last line twice (it is evicted from L2 by the next tile).
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int u = g + j;
+            if ((consm >> u) & 1u) {
+              const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + (u32)CL_W;
+              gu32* const src = ix < end ? base + (u64)ix * RD : sentinel;
+              rec[u] = cl_load(src);
+            }
+          }
+        }
+      };
+
       for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
         // (three flags in turn: the one cleared here was last read two rounds ago, a barrier away)
         if (tid == 0) sh[1 + (rnd == 2 ? 0 : rnd + 1)] = 0;
@@ -566,85 +781,8 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
         }
         asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
         CLPH(1);
-#pragma unroll
-        for (int g = 0; g < CL_U; g += 4) {
-          __builtin_amdgcn_sched_barrier(0);
-          u32 curg = cur; asm volatile("" : "+v"(curg));      // (re-derived per group: 16 slot indices kept live get spilled)
-          ClEnt pe[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) pe[j] = ent_load(tab, cl_thash(cl_key(rec[g + j]), mult));
-          u32 ovm = 0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            // straight-line: masks and selects, no branches (a deposit that is none goes to a scratch word)
-            const int u = g + j;
-            const bool cons = (consm >> u) & 1u;
-            const CKey k = cl_key(rec[u]);
-            const u32 c = cl_cnt(rec[u]);
-            const bool solid = cons && c >= smin;
-            const bool hit = ent_hit(pe[j], k);
-            tsum += solid ? c : 0u;
-            tn += (cons && !solid) ? 1u : 0u;
-            // (RESC: a row key's row has recurrence-min >= share-min solid records: its non-solid records are rescued, written like the others)
-            const bool dep = RESC ? (cons && hit && (solid || rescue)) : (solid && hit);
-            if (RESC) { const bool rs = cons && hit && !solid && rescue; rsum += rs ? c : 0u; rn += rs ? 1u : 0u; }
-            if (MODE == 0) img[dep ? __umul24(pe[j].idx - 1, iw) + lg : dummy] = c;
-            else if (dep) atomicOr(&img[__umul24(pe[j].idx - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
-            ovm |= (((RESC ? cons : solid) && !hit) ? 1u : 0u) << j;
-          }
-          asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
-          if (RESC) asm volatile("" : "+v"(rsum), "+v"(rn));
-          // solid records that are not row keys: appended to the wave's slice of the tile (positions from ballots)
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const u64 bal = __ballot((ovm >> j) & 1u);
-            if (bal) {
-              const CKey kk = cl_key(rec[g + j]);
-              const u64 pay = li_hi | cl_cnt(rec[g + j]) | ((RESC && cl_cnt(rec[g + j]) < smin) ? CL_NONSOLID : 0ULL);
-#if KMX_CL_KW == 1
-#define CL_PUT(o, pos) do { (o)[2 * (pos)] = kk; (o)[2 * (pos) + 1] = pay; } while (0)
-#else
-#define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = pay; } while (0)
-#endif
-              if (CL_HALVES == 1) {
-                if (EXT && __builtin_expect(wov + (u32)__popcll(bal) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
-                if ((ovm >> j) & 1u) {
-                  const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                  if (pos < (u32)CL_OVW) CL_PUT(ovk0, pos);
-                  else if (EXT && xb0 - 1u < 0xFFFFFFFEu && pos - (u32)CL_OVW < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb0 - 1u) * EW; const u32 px = pos - (u32)CL_OVW; CL_PUT(o, px); }
-                }
-                wov += (u32)__popcll(bal);
-              } else {
-                const u64 hi = __ballot(((ovm >> j) & 1u) && !ck_lt(kk, kmid)), lo = bal & ~hi;
-                if (EXT && __builtin_expect(wov + (u32)__popcll(lo) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
-                if (EXT && __builtin_expect(wov1 + (u32)__popcll(hi) > (u32)CL_OVW && xb1 == 0, 0)) extend(xb1);
-                if ((ovm >> j) & 1u) {
-                  const bool up = !ck_lt(kk, kmid);
-                  const u64 m = up ? hi : lo;
-                  const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                  if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; CL_PUT(o, pos); }
-                  else if (EXT) {
-                    const u32 xb = up ? xb1 : xb0, px = pos - (u32)CL_OVW;
-                    if (xb - 1u < 0xFFFFFFFEu && px < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb - 1u) * EW; CL_PUT(o, px); }
-                  }
-                }
-                wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
-              }
-            }
-          }
-          // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record is
-          // the one 64 positions further (one past the list's end: the sentinel).  A slot that was not consumed is left
-          // alone: loading it again would fetch the window's last line twice (it is evicted from L2 by the next tile).
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int u = g + j;
-            if ((consm >> u) & 1u) {
-              const u32 ix = curg + ((r + CL_G * u - curg) & (CL_W - 1)) + (u32)CL_W;
-              gu32* const src = ix < end ? base + (u64)ix * RD : sentinel;
-              rec[u] = cl_load(src);
-            }
-          }
-        }
+        walk(consm, cur);
+        flush();
         u32 c = __popc(consm);
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
@@ -670,49 +808,52 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       }
 
       // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
+      bool have_n[CL_KPL];
+#pragma unroll
+      for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)lane + 64u * x; have_n[x] = !last && j < rt && s0 + rt + j < s_hi; }
+      if (!last) {      // every wave: one hash of the family tried on the next tile's row keys (cl_try), then the workgroup meets
+        const u32 res = cl_try(trymap, skn, have_n, (u32)lane, cl_mult(wave));
+        if (lane == 0) tryres[wave] = res;
+        cl_barrier();
+      }
       if (wave == 0) {
         ClEnt* const old = ptab + (q % CL_NT) * CL_PT;
 #pragma unroll
         for (int x = 0; x < CL_KPL; x++) if ((u32)lane + 64u * x < rte) old[myslot[x]].idx = 0;        // (keys may stay: an entry without a row is never a hit)
         if (!last) {
           const u32 sn = s0 + rt;
-          bool have[CL_KPL];
 #pragma unroll
           for (int x = 0; x < CL_KPL; x++) {
             const u32 j = (u32)lane + 64u * x;
-            have[x] = j < rt && sn + j < s_hi;
-            if (have[x] && blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes), skn[x]);
+            if (have_n[x] && blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes), skn[x]);
           }
-          const u32 m2 = cl_build(ptab + ((q + 1) % CL_NT) * CL_PT, skn, have, (u32)lane, myslot);
+          ClEnt* const ntab = ptab + ((q + 1) % CL_NT) * CL_PT;
+          u32 m2 = pick();
+          if (m2) cl_fill(ntab, skn, have_n, (u32)lane, m2, myslot);
+          else m2 = cl_build(ntab, skn, have_n, (u32)lane, myslot, (u32)CL_NW);      // (one tile in fifty: the rest of the family, one hash after the other)
           if (lane == 0) { sh[4 + ((q + 1) % CL_NT)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
+        if (NAR) {
+          // a row's slice of the block: nbl count bytes, 16 per lane, eight lanes a row, eight rows a wave and step
+          const u32 lr = (u32)lane >> 3, lc = (u32)lane & 7u, nch = (nbl + 15u) >> 4;
+          for (u32 j = (wave - 1) * 8u + lr; j < rte; j += (CL_NW - 1) * 8u) {
+            u8* const nrow = nar + (u64)(s0 + j) * npitch;
+            if (lc < nch) {
+              uint4* const src = reinterpret_cast<uint4*>(img8 + j * nbs + 16u * lc);
+              const uint4 v = *src; *src = make_uint4(0, 0, 0, 0);
+              *reinterpret_cast<uint4*>(nrow + col0 + 16u * lc) = v;
+            }
+            if (lc == 0) { const u8 f = rowbig[j]; rowbig[j] = 0; nrow[npitch - 16u + blk] = f; }      // (the row's flag byte of this block: some count of it is in the 4-byte row)
+          }
+        } else
         if (MODE == 0) {
           u8* const out0 = obase + (u64)s0 * opitch + 4ull * col0;
           const bool wide = ((opitch | (4u * col0) | (4u * nbs)) & 7u) == 0;
           for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
             u32* const src = img + j * nbs;
             u8* const dst = out0 + (u64)j * opitch;
-            if (wide && nar) {
-              const u32 n2 = nbl >> 1;      // (<= 256 pairs: CL_NB <= 256 lists per block, four per lane)
-              u64 w[4]; u32 tail = 0;
-              bool big = false;
-#pragma unroll
-              for (int x = 0; x < 4; x++) { const u32 t = 64 * x + lane; w[x] = 0; if (t < n2) { w[x] = reinterpret_cast<u64*>(src)[t]; reinterpret_cast<u64*>(src)[t] = 0; } big |= (u32)w[x] > 254u || (u32)(w[x] >> 32) > 254u; }
-              if ((nbl & 1u) && lane == 0) { tail = src[nbl - 1]; src[nbl - 1] = 0; big |= tail > 254u; }
-              const bool anyb = __ballot(big) != 0;
-              u8* const nrow = nar + (u64)(s0 + j) * npitch;
-              if (!anyb) {
-#pragma unroll
-                for (int x = 0; x < 4; x++) { const u32 t = 64 * x + lane; if (t < n2) *reinterpret_cast<u16*>(nrow + col0 + 2 * t) = (u16)((u32)w[x] | ((u32)(w[x] >> 32) << 8)); }
-                if ((nbl & 1u) && lane == 0) nrow[col0 + nbl - 1] = (u8)tail;
-              } else {
-#pragma unroll
-                for (int x = 0; x < 4; x++) { const u32 t = 64 * x + lane; if (t < n2) reinterpret_cast<u64*>(dst)[t] = w[x]; }
-                if ((nbl & 1u) && lane == 0) reinterpret_cast<u32*>(dst)[nbl - 1] = tail;
-              }
-              if (lane == 0) nrow[((N + 7u) & ~7u) + blk] = anyb ? 1 : 0;
-            } else if (wide) {
+            if (wide) {
               const u32 n2 = nbl >> 1;
               for (u32 t0 = 0; t0 < n2; t0 += 256) {
                 u64 w[4];
@@ -914,7 +1055,13 @@ __device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mi
 // aside there, interleaved by key -- are one contiguous run of the body; the group's place comes from the look-back above.  A
 // group of several passes counts its rows first (every pass sorted once without writing), publishes, and sorts again to write.
 template <int MODE, bool RESC, bool ORD>
-__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : ORD ? 2 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores: one workgroup per CU either way, and the ORD build keeps four row keys' rows per wave in flight)
+#ifndef KMX_CK_ORD_OCC
+#define KMX_CK_ORD_OCC 2
+#endif
+#ifndef KMX_CK_RF
+#define KMX_CK_RF 4
+#endif
+__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : ORD ? KMX_CK_ORD_OCC : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores: one workgroup per CU either way, and the ORD build keeps four row keys' rows per wave in flight)
 void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items, u32 n_tasks, u32* tkt)
 {
   __shared__ __attribute__((aligned(16))) u32 uni[CK_UNI / 4];      // the key maps | the row keys and interval counters (recurrence-min 1) | the rows' staging
@@ -1069,9 +1216,17 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         if (ORD) return !(has_lo && ck_lt(k, plo)) && !(has_hi && !ck_lt(k, phi));
         return ((cl_mix(k) >> 24) & (npass - 1)) == pass;      // (by hash bits: equal keys meet in the same pass)
       };
+#ifdef KMX_CK_ADAPT_MAPS
+      // the maps as large as the group's entries ask for: 16 bits of the first map per entry (an entry meets another key's bit with
+      // probability 1/16: such chance candidates only make the sort a little larger), a quarter of that for the second
+      u32 mb1 = 8192; while (mb1 < (u32)CK_BITS && mb1 < 16u * tot) mb1 <<= 1;
+      const u32 mb2 = max(2048u, mb1 >> 2);
+#else
+      const u32 mb1 = (u32)CK_BITS, mb2 = (u32)CK_B2;
+#endif
       if (thr > 1) {
-        for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
-        for (u32 t = tid; t < (u32)CK_B2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
+        for (u32 t = tid; t < mb1 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
+        for (u32 t = tid; t < mb2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
       } else {
         for (u32 t = tid; t < 512u; t += CK_TPB) bits[t] = 0;      // (the interval counters below live in the key map's room)
       }
@@ -1169,16 +1324,16 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       if (thr > 1) {
         each(in_pass, [&](CKey k, u64) {
           const u32 hx = cl_mix(k);
-          const u32 bit = hx & (CK_BITS - 1);
+          const u32 bit = hx & (mb1 - 1);
           const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
-          if ((old >> (bit & 31u)) & 1u) { const u32 b2 = (hx >> 7) & (CK_B2 - 1); atomicOr(&bits2[b2 >> 5], 1u << (b2 & 31u)); }
+          if ((old >> (bit & 31u)) & 1u) { const u32 b2 = (hx >> 7) & (mb2 - 1); atomicOr(&bits2[b2 >> 5], 1u << (b2 & 31u)); }
         });
         __syncthreads();
         SPPH(2);
       }
       if (thr > 1) {
         each(in_pass, [&](CKey k, u64 pl) {
-          const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
+          const u32 b2 = (cl_mix(k) >> 7) & (mb2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
           push(k, pl);
         });
         __syncthreads();
@@ -1278,7 +1433,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       // rows of a wave in flight at once (a row is read at the latency of HBM: one at a time a wave would spend its time waiting)
       auto dense_rows = [&]() {
         if (MODE == 0) {
-          constexpr int RF = 4;
+          constexpr int RF = KMX_CK_RF;
           const bool wide = (row_bytes & 7u) == 0;      // (C.dense's rows are 8-byte aligned)
           const u32 n8 = row_bytes / 8, n4 = row_bytes / 4;
           for (u32 i0 = wave * RF; i0 < dnp; i0 += (CK_TPB / 64) * RF) {
@@ -1450,14 +1605,14 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           // other rows are only written.  So the two are interleaved: a wave asks for RF of its row keys' rows, writes its share of
           // a stretch of the kept runs' rows while they travel, stores them, asks for the next RF.  (All of them up front, the wave
           // waiting: rows phase 2.8x the arena build's for a fifth more rows.)
-          constexpr int RF = 4;
+          constexpr int RF = KMX_CK_RF;
           const u32 n8 = row_bytes / 8;
           const u32 rounds = max(1u, (dnp + (CK_TPB / 64) * RF - 1) / ((CK_TPB / 64) * RF));
           if (C.dnarrow) {
-            // the NARROW side store: a byte per count (+ a flag byte per column block: 1 = that block's counts of the row hold one above
-            // 254 and lie in the 4-byte row).  A lane takes two groups of eight lists: an 8-byte load each, four 8-byte stores each; the
-            // row's eight flag bytes in one (uniform) load.
-            const u8* const nar = C.dnarrow; const u32 npitch = C.npitch, nbs = C.nb, NL = T.N, FO = (NL + 7u) & ~7u;
+            // the NARROW side store: a byte per count (+ a flag byte per column block: 1 = some count of that block's slice of the row is
+            // above 254: its byte is 255 and the count lies in the 4-byte row).  A lane takes two groups of eight lists: an 8-byte load
+            // each, four 8-byte stores each; the row's eight flag bytes in one (uniform) load.
+            const u8* const nar = C.dnarrow; const u32 npitch = C.npitch, nbs = C.nb, NL = T.N, FO = npitch - 16u;      // (the row's last 16 bytes: a flag byte per column block)
             const u32 ng = (NL + 7u) / 8u;      // (<= 128: row_bytes / 8 <= 512)
             u32 fsh0[2], fsh1[2];                // 8 x the column block of my groups' first and last list
 #pragma unroll
@@ -1500,7 +1655,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
                     if (npair > 3) out64[4 * g + 3] = ((v >> 48) & 0xFFULL) | ((v >> 56) << 32);
                   } else {      // a block whose counts of this row are in the 4-byte row
                     const u32* const wsrc = dense_src(i); u32* const cnt = reinterpret_cast<u32*>(out64);
-                    for (u32 l = 8u * g; l < min(NL, 8u * g + 8u); l++) cnt[l] = ((fl[r] >> (8u * (l / nbs))) & 0xFFULL) ? wsrc[l] : (u32)((v >> (8u * (l - 8u * g))) & 0xFFULL);
+                    for (u32 l = 8u * g; l < min(NL, 8u * g + 8u); l++) { const u32 b = (u32)((v >> (8u * (l - 8u * g))) & 0xFFULL); cnt[l] = b == 255u ? wsrc[l] : b; }      // (255: the count is in the 4-byte row)
                   }
                 }
               }
@@ -1777,7 +1932,7 @@ void cols_phase_prof_dump()
 #endif
 
 // ---- host side ------------------------------------------------------------------------------------------
-int cols_lds_bytes() { return CL_IMG + CL_NT * CL_PT * (int)sizeof(ClEnt) + 64 + 256; }
+int cols_lds_bytes() { return CL_IMG + CL_NT * CL_PT * (int)sizeof(ClEnt) + 64 + 256 + 64 + CL_STG; }
 u32 cols_halves() { return CL_HALVES; }
 u32 cols_wgs_per_cu() { return CL_WGS; }
 u32 cols_block_lists() { return CL_NB; }
@@ -1798,22 +1953,24 @@ hipError_t launch_cols_prep(const TaskDev* tasks, const TaskDev* subs, const Col
   hipLaunchKernelGGL(k_cols_prep, dim3(n_tasks), dim3(CP_TPB), 0, st, tasks, subs, cols);
   return hipGetLastError();
 }
-template <int MODE, bool EXT, bool RESC, bool ORD>
+template <int MODE, bool EXT, bool RESC, bool ORD, bool NAR>
 static hipError_t launch_merge_cols_as(const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
   const int lds = cols_lds_bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<MODE, EXT, RESC, ORD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_cols<MODE, EXT, RESC, ORD, NAR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_merge_cols<MODE, EXT, RESC, ORD>), dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
+  hipLaunchKernelGGL((k_merge_cols<MODE, EXT, RESC, ORD, NAR>), dim3(grid_x), dim3(CL_TPB), lds, st, tasks, cols, items, n_items, ticket);
   return hipGetLastError();
 }
 // ext: bit 0 = slice extensions (outlier samples), bit 1 = the RESC build (share-min, recurrence-min 0), bit 2 = the ORD build (the row
-// keys' rows into the side store: every task of the batch has one)
+// keys' rows into the side store: every task of the batch has one), bit 3 = NAR (count rows, ORD: every task's side store is the byte-wide one)
 hipError_t launch_merge_cols(int mode, int ext, const TaskDev* tasks, const ColsDev* cols, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, hipStream_t st)
 {
-  const bool x = ext & 1, r = (ext & 2) != 0, o = (ext & 4) != 0;
-#define KMX_CL_L3(M, X, R) (o ? launch_merge_cols_as<M, X, R, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<M, X, R, false>(tasks, cols, items, n_items, ticket, grid_x, st))
+  const bool x = ext & 1, r = (ext & 2) != 0, o = (ext & 4) != 0, n = (ext & 8) != 0 && o && mode == 0;
+#define KMX_CL_L3(M, X, R) (o ? launch_merge_cols_as<M, X, R, true, false>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<M, X, R, false, false>(tasks, cols, items, n_items, ticket, grid_x, st))
 #define KMX_CL_LAUNCH(M) (r ? (x ? KMX_CL_L3(M, true, true) : KMX_CL_L3(M, false, true)) : (x ? KMX_CL_L3(M, true, false) : KMX_CL_L3(M, false, false)))
+  if (n) return r ? (x ? launch_merge_cols_as<0, true, true, true, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<0, false, true, true, true>(tasks, cols, items, n_items, ticket, grid_x, st))
+                  : (x ? launch_merge_cols_as<0, true, false, true, true>(tasks, cols, items, n_items, ticket, grid_x, st) : launch_merge_cols_as<0, false, false, true, true>(tasks, cols, items, n_items, ticket, grid_x, st));
   return mode == 0 ? KMX_CL_LAUNCH(0) : KMX_CL_LAUNCH(1);
 #undef KMX_CL_L3
 #undef KMX_CL_LAUNCH

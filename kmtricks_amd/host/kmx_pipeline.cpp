@@ -583,7 +583,8 @@ int run(int argc, char** argv)
     // (kmx_count_reads_dev_multi: a 1 Mbp sample is a few dozen small kernels and four host round trips, which a call pays once --
     // 0.71 -> 0.49 ms per sample at n = 4 when the call is timed by itself, scripts/bench_count_multi.py).  Through this driver it does
     // not pay yet: 1000 x 1 Mbp count in 0.89-0.95 s at n = 4 against 0.63 s at n = 1 (--skip-partiinfo; two workers), so the default is 1.
-    const uint32_t per_call = o.per_call ? o.per_call : getenv("KMX_COUNT_SAMPLES_PER_CALL") ? (uint32_t)std::max(1L, atol(getenv("KMX_COUNT_SAMPLES_PER_CALL"))) : 1u;
+    uint32_t per_call = o.per_call ? o.per_call : getenv("KMX_COUNT_SAMPLES_PER_CALL") ? (uint32_t)std::max(1L, atol(getenv("KMX_COUNT_SAMPLES_PER_CALL"))) : 1u;
+    if (o.k >= 64) per_call = 1;      // (kmx_count_reads_dev_multi takes keys of one and two words: wider k-mers go a sample a call)
     rawpool.cap = ((size_t)per_call + 2) * NW + 2; rawpool.words = raw_words;
     std::atomic<uint32_t> next_sample{0};
     // A sample's batches must reach its worker in order; samples are taken in fof order by `readers` threads per round so the
@@ -643,7 +644,9 @@ int run(int argc, char** argv)
       // and then compute fall into step -- both upload, the GPU idles; both compute, the link idles: 1.0 of every 4.3 ms at
       // 5 Mbp per sample (the GPU's timeline, scripts/dev/gantt.sh).  KMX_READS_AHEAD=0: off
       static const bool reads_ahead = !(getenv("KMX_READS_AHEAD") && getenv("KMX_READS_AHEAD")[0] == '0');
-      const char* pending_dev = nullptr;
+      // (released with the worker whatever way its loop ends -- the queue closed behind an upload, an early exit: ADVICE r4)
+      struct DevAhead { kmx_ctx* c; const char* d; ~DevAhead() { if (d) kmx_reads_release(c, d); } } pend_dev{c, nullptr};
+      const char*& pending_dev = pend_dev.d;
       // a whole sample through count FILES (no room in the stores, --keep-tmp, --no-resident): split + count in one call, the
       // super-k-mer streams stay in HBM (kmx_count_reads), the counts come back and are written as counts/partition_<p>/<id>.kmer
       auto whole_to_files = [&](const ReadBatch& b) {
