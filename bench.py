@@ -367,6 +367,62 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- count stage
+def count_stage_workload(env, a):
+    """The count stage by itself, as `kmx pipeline` runs it for configs[2]: one synthetic sample (5 Mbp genome, 150-bp error-free reads at
+    6x = 30 Mbases, k = 31, m = 10, 256 static partitions) through kmx_count_reads_dev (split + count in one call, reads uploaded from
+    page-locked host memory, results left in HBM).  Live: device time per call from HIP events on the context's own stream, wall clock
+    per call.  Roofline: B = super-k-mer bytes + 12 per distinct solid k-mer over the kernels' time -- the stage is a chain
+    of ~25 instruction-bound kernels, so next to it, per kernel, what share of the chip's instruction issue it uses (from the committed
+    rocprofv3 passes, profiles/count_stage_kernels.json: scripts/r5_count_stage_profile.sh)."""
+    torch, lib = env["torch"], env["lib"]
+    import numpy as np
+    rng = np.random.default_rng(20240601)
+    G, L, COV, K, M, P = 5_000_000, 150, 6, 31, 10, a.total_partitions
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=G)
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+    n_reads = G * COV // L
+    starts = rng.integers(0, G - L, n_reads)
+    reads = genome[starts[:, None] + np.arange(L)[None, :]]
+    rc = rng.random(n_reads) < 0.5
+    reads[rc] = comp[reads[rc]][:, ::-1]
+    blob = reads.tobytes(); offs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L))
+    table = (xxh64_u32(np.arange(4 ** M, dtype=np.uint32)) % np.uint64(P)).astype(np.uint16)
+    ctx = lib.Context(env["local"]); store = lib.Store(env["local"])
+    st = torch.cuda.ExternalStream(ctx.stream(), device=env["dev"])
+    for _ in range(3):
+        ctx.count_reads_dev((blob, offs), K, M, table, P, 2, [store])
+    reps, dev_ms, wall = 10, [], []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record(st)
+        lists, nk, _ = ctx.count_reads_dev((blob, offs), K, M, table, P, 2, [store])
+        e1.record(st); e1.synchronize(); wall.append(time.perf_counter() - t0); dev_ms.append(e0.elapsed_time(e1))
+    got = ctx.count_reads((blob, offs), K, M, table, P, 2, streams=True)
+    sk_bytes = sum(len(x) for x in got[2]); distinct = sum(n for _, n in lists)
+    B = sk_bytes + 12 * distinct
+    d_ms, w_ms = sorted(dev_ms)[reps // 2], sorted(wall)[reps // 2] * 1e3
+    out = {"metric": "count stage: bases counted/s (one sample per call, results resident in HBM)", "value": n_reads * L / (w_ms * 1e-3), "unit": "bases/s",
+           "ms_per_sample_wall": w_ms, "ms_per_sample_device": d_ms, "kmers_per_s": sum(nk) / (w_ms * 1e-3), "higher_is_better": True, "data": "synthetic", "dtype": "u64 keys / u32 counts (integer)",
+           "config": {"workload": f"configs[2]'s sample: {G} bp genome, {n_reads} reads of {L} bp ({n_reads * L} bases), k={K}, m={M}, {P} static partitions, --hard-min 2; "
+                                  f"{sum(nk)} k-mers, {sk_bytes} super-k-mer bytes, {distinct} distinct solid k-mers"},
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algo_bytes_per_sample": B, "achieved": B / (d_ms * 1e-3) / 1e9, "frac": B / (d_ms * 1e-3) / 1e9 / 8000.0,
+                        "kernel": "the stage's ~25 kernels (split, decode, bucket sort, compaction) between two HIP events on the context's stream, the reads' upload included",
+                        "note": "instruction-bound small kernels: see kernels[].issue_frac"}}
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "count_stage_kernels.json")))
+        out["roofline"]["kernels_us_per_sample_profiled"] = prof["kernels_us_per_sample"]
+        out["roofline"]["launches_per_sample"] = prof["launches_per_sample"]
+        out["roofline"]["library_us_per_sample"] = prof["library_us_per_sample"]
+        out["roofline"]["frac_of_kernel_time_profiled"] = prof["hbm_frac_algorithmic"]
+        out["roofline"]["kernels"] = [{kk: r[kk] for kk in ("kernel", "calls_per_sample", "us_per_sample", "issue_frac", "hbm_frac")} for r in prof["kernels"][:6]]
+        out["roofline"]["source"] = "profiles/count_stage_kernels.json"
+    except Exception:
+        pass
+    store.close(); ctx.close()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- end to end
 def _pipeline_make_sample(args):
     """one sample of SURVEY 8d's cohort as a FASTA file of error-free 150-bp reads at the given coverage, random strands"""
@@ -515,7 +571,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["auto", "all", "count", "bf", "pa63", "bft", "pipeline"], default="auto")
+    ap.add_argument("--workload", choices=["auto", "all", "count", "bf", "pa63", "bft", "pipeline", "count_stage"], default="auto")
     ap.add_argument("--lists", choices=["counted", "random"], default="counted")
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--partitions-per-gpu", type=int, default=0)
@@ -577,9 +633,9 @@ def run_workloads(a, wl, env):
     extras, pipe = {}, None
     if wl == "all":
         t_all = time.perf_counter()
-        for w in ("bf", "bft", "pa63"):
+        for w in ("count_stage", "bf", "bft", "pa63"):
             try:
-                extras[w] = merge_workload(env, a, w, "counted", want_cpu)
+                extras[w] = count_stage_workload(env, a) if w == "count_stage" else merge_workload(env, a, w, "counted", want_cpu)
             except Exception as e:      # (a side line must not cost the headline one)
                 extras[w] = {"error": repr(e)}
             if rank == 0:
@@ -606,6 +662,8 @@ def run_workloads(a, wl, env):
                     pipe["full_size"] = {"error": repr(e)}
                 print(f"[bench] workload pipeline at 5 Mbp done, {time.perf_counter() - t_all:.0f} s", file=sys.stderr, flush=True)
         wl = "count"
+    if wl == "count_stage":
+        return count_stage_workload(env, a) if rank == 0 else None
     out = merge_workload(env, a, wl, a.lists, want_cpu)
     if world > 1 and a.multi_gpu_pipeline and wl == "count" and env.get("run_pipeline", True):
         # several ranks (the scaling runs): the PRODUCT's own multi-GPU path gets a point too -- `kmx pipeline --gpus <world>`, one
@@ -619,6 +677,17 @@ def run_workloads(a, wl, env):
                 pipe = {"error": repr(e)}
         env["dist"].barrier()
     if rank == 0:
+        # what the scaling runs need to be read without a second look: the world the ranks saw, and the one-GPU line of the last round
+        # the driver recorded (BENCH_r*.json at the repository's root), so that N ranks x that value is at hand
+        out["ranks"] = {"world_size": world, "backend": ("nccl (RCCL)" if world > 1 else None),
+                        "devices": env["torch"].cuda.device_count() if hasattr(env["torch"], "cuda") else None}
+        try:
+            import glob
+            last = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")))[-1]
+            d = json.load(open(last)); pv = d.get("parsed", d)
+            out["ranks"]["one_gpu_line"] = {"file": os.path.basename(last), "value": pv.get("value"), "ms_per_step": pv.get("ms_per_step"), "n_gpus": pv.get("n_gpus")}
+        except Exception:
+            pass
         if extras:
             out["workloads"] = extras
         if pipe is not None:

@@ -25,6 +25,8 @@
 #include "count_sort.hpp"
 
 namespace kmx {
+static bool list_copy_trace() { static const bool on = getenv("KMX_TRACE") != nullptr; return on; }
+
 
 typedef __uint128_t u128;
 
@@ -524,6 +526,8 @@ static int pack_to_stores(kmx_ctx* ctx, const KeyT* d_k, const u32* d_c, const s
       // the store of another GPU is filled over xGMI: peer access is enabled for the pair the first time it is used
       // (kmx_peer_path; hipMemcpyPeerAsync stages through the host when the two GPUs have none)
       if (S->device != ctx->device) (void)kmx_peer_path(ctx->device, S->device);
+      // (KMX_TRACE=1: a line per copy -- one per destination store and count call is the contract: partitions bound for one GPU are contiguous)
+      if (list_copy_trace()) fprintf(stderr, "[kmx copy] lists from device %d to store %u on device %d: %zu bytes, %s\n", ctx->device, d, S->device, nb, S->device == ctx->device ? "device copy" : "hipMemcpyPeerAsync");
       e = S->device == ctx->device ? hipMemcpyAsync(dst, d_pack + doff[d] * RB, nb, hipMemcpyDeviceToDevice, st)
                                    : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
       if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }
@@ -575,6 +579,8 @@ static int compact_to_stores(kmx_ctx* ctx, const KeyT* d_tk, const u32* d_tc, co
       // the store of another GPU is filled over xGMI: peer access is enabled for the pair the first time it is used
       // (kmx_peer_path; hipMemcpyPeerAsync stages through the host when the two GPUs have none)
       if (S->device != ctx->device) (void)kmx_peer_path(ctx->device, S->device);
+      // (KMX_TRACE=1: a line per copy -- one per destination store and count call is the contract: partitions bound for one GPU are contiguous)
+      if (list_copy_trace()) fprintf(stderr, "[kmx copy] lists from device %d to store %u on device %d: %zu bytes, %s\n", ctx->device, d, S->device, nb, S->device == ctx->device ? "device copy" : "hipMemcpyPeerAsync");
       e = S->device == ctx->device ? hipMemcpyAsync(dst, d_pack + doff[d] * RB, nb, hipMemcpyDeviceToDevice, st)
                                    : hipMemcpyPeerAsync(dst, S->device, d_pack + doff[d] * RB, ctx->device, nb, st);
       if (e != hipSuccess) { rc = ctx->fail(KMX_E_HIP, std::string("count list copy: ") + hipGetErrorString(e)); break; }

@@ -33,7 +33,6 @@
 // (the row keys come from 8..32 of the lists, more for a larger recurrence-min: cols_row_lists in kmx_api.hip).
 #include "kmx_host.hpp"
 #include <algorithm>
-#include <type_traits>
 #include <cstdio>
 #include <cstring>
 
@@ -67,13 +66,8 @@ constexpr int EW = KW + 1;               // u64 words per set-aside entry: the k
 constexpr int CL_U = KW == 1 ? 16 : 8;   // window slots per lane (a 128-bit record is 5 registers: 8 slots keep the kernel under 128 VGPRs)
 constexpr int CL_W = CL_G * CL_U;        // records per window
 constexpr int CL_NB = CL_TPB / CL_G;     // lists per column block
+constexpr int CL_IMG = 61440 / CL_WGS;   // LDS image bytes (rt rows x nb u32 counts)
 constexpr int CL_RT = CL_W * 7 / 8;      // row keys per tile (< window: a similar list needs no second round)
-constexpr int CL_IMG = CL_RT * CL_NB * 4;   // LDS image bytes (rt rows x nb u32 counts: 56 KB for 64-bit keys, 28 KB for 128-bit ones)
-#ifndef KMX_CL_STK
-#define KMX_CL_STK 2
-#endif
-constexpr int CL_STK = KMX_CL_STK;       // records that are no row keys staged per lane and round (LDS: key words + count, a column per thread)
-constexpr int CL_STG = (CL_STK + 1) * CL_TPB * (KW * 8 + 4);      // ... bytes of that staging area (+ a row for the writes of a lane whose rows are full)
 constexpr int CL_KPL = (CL_RT + 63) / 64;   // row keys per lane of wave 0 (which builds the row table)
 constexpr int CL_NT = (CL_KPL == 1 && CL_WGS == 1 && KW == 1) ? 2 : 1;  // row tables: two of 2048 entries (the next tile's is built beside this tile's), or one
 constexpr int CL_PT = CL_KPL == 1 ? 2048 : 4096;      // row-key table entries
@@ -171,24 +165,6 @@ __device__ __forceinline__ u32 cl_thash(CKey key, u32 hf)
 #endif
   return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);      // (__umul24 takes the low 24 bits of hf, and returns int)
 }
-// the same with the family a compile-time constant (the slot loop is built once per family: the branch on the tile's hash word left
-// the loop -- 4 scalar and 2 vector instructions per record)
-template <bool WHOLE>
-__device__ __forceinline__ u32 cl_thash_f(CKey key, u32 hf)
-{
-  const u64 k = ck_fold(key);
-  if (WHOLE) {
-    const u64 m = 0x9E3779B97F4A7C15ULL + 2ULL * (u64)(hf & 0xFFFFu) * 0xBF58476D1CE4E5B9ULL;
-    return (u32)((k * m) >> (CL_PT == 2048 ? 53 : 52));
-  }
-#if KMX_CL_KW == 1
-  const u32 x = ((u32)k ^ (u32)(k >> (hf >> 24))) & 0xFFFFFFu;
-#else
-  const u32 f = (u32)k ^ (u32)(k >> 32);
-  const u32 x = (f ^ (f >> 8)) & 0xFFFFFFu;
-#endif
-  return ((u32)__umul24(x, hf) >> CL_PTSHIFT) & (u32)(CL_PT - 1);
-}
 __device__ __forceinline__ u32 cl_mult(u32 seed)
 {
   if (KW == 2 && seed >= 16u) return 0x80000000u | (seed - 15u);      // (its cheap hashes differ in the multiplier only: 16 tries tell)
@@ -203,9 +179,9 @@ __device__ __forceinline__ u32 cl_mix(CKey key)
   return x;
 }
 // wave 0: lane j holds row keys j, j + 64, ...  -> the hash, 0 when no try worked; slot[x] = entry of my key x
-__device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL], u32 first = 0)
+__device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL])
 {
-  for (u32 s = first; s < (u32)CL_SEEDS; s++) {
+  for (u32 s = 0; s < (u32)CL_SEEDS; s++) {
     const u32 mult = cl_mult(s);
     u32 h[CL_KPL], old[CL_KPL];
     bool clash = false;
@@ -224,35 +200,6 @@ __device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], c
     for (int x = 0; x < CL_KPL; x++) if (have[x] && old[x] == 0) atomicExch(&tab[h[x]].idx, 0u);      // take my claims back, next hash
   }
   return 0;
-}
-
-// ---- the same search by every wave of the workgroup at once (round 5): wave w tries hash `first + w` of the family on the tile's row keys
-//      in a bit map of its own (a bit per table entry), no table touched; the lowest wave that found no clash names the tile's hash and
-//      wave 0 then puts the keys in.  One parallel try finds a hash for 49 tiles in 50 (a try works with probability ~0.22 for 112 keys
-//      in 4096 entries); round 4's wave 0 went through its ~4.6 tries one after the other while the other fifteen waves, done with the
-//      image, waited for it at the barrier -- the longest pole of every tile.  Lane j holds row keys j, j + 64, ... (ck_inf where none). ----
-__device__ __forceinline__ u32 cl_try(u32* const bm, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], const u32 lane, const u32 mult)
-{
-#pragma unroll
-  for (u32 t = 0; t < (u32)CL_PT / 32u / 64u; t++) bm[lane + 64u * t] = 0;      // (my wave's map: the same wave's LDS operations stay in order)
-  bool clash = false;
-#pragma unroll
-  for (int x = 0; x < CL_KPL; x++) {
-    const u32 h = cl_thash(key[x], mult);
-    const u32 old = have[x] ? atomicOr(&bm[h >> 5], 1u << (h & 31u)) : 0u;
-    clash |= (old >> (h & 31u)) & 1u;
-  }
-  return __ballot(clash) == 0 ? mult : 0u;
-}
-// wave 0: the keys into the (emptied) table under the hash that was found
-__device__ __forceinline__ void cl_fill(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], const u32 lane, const u32 mult, u32 (&slot)[CL_KPL])
-{
-#pragma unroll
-  for (int x = 0; x < CL_KPL; x++) {
-    const u32 h = cl_thash(key[x], mult);
-    if (have[x]) { ent_set(tab[h], key[x]); tab[h].idx = lane + 64u * x + 1; }
-    slot[x] = h;
-  }
 }
 
 }  // namespace
@@ -464,6 +411,11 @@ __device__ u64 kmx_sparse_prof[8];
 #endif
 
 // ---- the merge: work item = (task, key range, column block) ----------------------------------------------
+// (Round 5 measured what each part of the slot walk costs on configs[2], profiles/r05b_cols_levels.jsonl: the window's loads and the tile
+//  skeleton alone 1.84 ms, + the table lookups 1.85, + the deposits 2.03, + the records that are no row keys 2.68 -- the branch per
+//  window slot, not its instructions: staged per lane in LDS and appended once per round they cost half as much as long as nothing
+//  overflows the stage, but every way of handling the overflow that was tried -- a branch per slot, per four slots, a second walk --
+//  gave it back in spilled registers around the loop, and the window's loads issued any later than they are cost more than all of it.)
 // EXT: a wave whose set-aside slice is full claims an extension (cohorts with outlier samples; the plain build hands such a task
 // back and the context's next batches use this one: 1-2 % slower on cohorts that never need it)
 constexpr u64 CL_NONSOLID = 1ULL << 63;      // set-aside entry of a RESC build: the record is below its list's soft-min
@@ -472,7 +424,7 @@ constexpr u64 CL_NONSOLID = 1ULL << 63;      // set-aside entry of a RESC build:
 // NAR (count rows of an ORD build): the side store holds ONE BYTE per count (C.dnarrow) -- and so does the tile's image in LDS: a
 // deposit is a byte (255 = "the count is in the 4-byte row", written there by the lane that holds it: rare), a row's slice of the
 // block leaves as 16-byte pieces (round 4 kept the u32 image and squeezed it on the way out: a row at a time per wave, 2-byte
-// stores -- 19 % of the kernel)
+// stores)
 template <int MODE, bool EXT, bool RESC, bool ORD, bool NAR>      // MODE 0: count rows (u32 per list), 1: presence/absence rows (a bit per list, LSB first)
 __global__ __launch_bounds__(CL_TPB, CL_WGS)
 void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items,
@@ -482,9 +434,6 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
   u32* const img = reinterpret_cast<u32*>(smem);                                   // [rt][nb] counts of the tile
   ClEnt* const ptab = reinterpret_cast<ClEnt*>(smem + CL_IMG);                     // [CL_NT][CL_PT] row key -> row
   u32* const sh = reinterpret_cast<u32*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt)); // [0] item [1..3] "another round" flags, used in turn [4],[5] the tables' multipliers
-  u32* const tryres = sh + 80;                                                     // [CL_NW] what each wave's try of a hash for the next tile's row table gave (0: a clash)
-  u32* const trymap = reinterpret_cast<u32*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt) + 384) + (threadIdx.x >> 6) * (CL_PT / 32);      // my wave's bit map for it (the set-aside stage's room: idle between the scans)
-  static_assert(CL_NW * (CL_PT / 8) <= CL_STG, "the waves' bit maps fit the stage");
   const u32 dummy = (u32)(CL_IMG + CL_NT * CL_PT * sizeof(ClEnt)) / 4 + 16 + (u32)(threadIdx.x & 63);   // image index of a scratch word of my own (deposits that are none)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -535,7 +484,7 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     u8* const nar = NAR ? C.dnarrow : nullptr;
     const u32 npitch = NAR ? cl_uni(C.npitch) : 0u;
     u8* const img8 = reinterpret_cast<u8*>(img);                  // NAR: [rt][nbs] count bytes
-    u8* const rowbig = reinterpret_cast<u8*>(smem) + CL_IMG - 128;   // NAR: [rt] "this row of the tile holds a count above 254" (the image's last bytes: rt * nbs <= CL_IMG / 4)
+    u8* const rowbig = reinterpret_cast<u8*>(smem) + CL_RT * CL_NB;   // NAR: [rt] "this row of the tile holds a count above 254" (behind the image's rt x nb bytes)
     const u32 dummyb = dummy * 4u;
 
     // CL_G adjacent lanes per list; circular window: lane r, slot u holds the record whose index is == r + CL_G * u
@@ -564,32 +513,19 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     bool failed = false;
 #pragma unroll
     for (int x = 0; x < CL_KPL; x++) { skn[x] = ck_inf(); myslot[x] = 0; }
-    // (every wave holds the tile's row keys and tries one hash of the family on them: cl_try)
-    auto pick = [&]() -> u32 {      // the lowest wave's hash that worked (0: none did); uniform
-      const u32 v = tryres[lane & (CL_NW - 1)];
-      const u64 okm = __ballot(v != 0);
-      return okm ? (u32)__builtin_amdgcn_readlane((int)v, (int)__builtin_ctzll(okm)) : 0u;
-    };
-    {
+    if (tid < 64) {
       bool have[CL_KPL];
 #pragma unroll
       for (int x = 0; x < CL_KPL; x++) {
-        const u32 j = (u32)lane + 64u * x;
+        const u32 j = (u32)tid + 64u * x;
         have[x] = j < rt && s_lo + j < s_hi;
         if (have[x]) {
           skn[x] = skel[s_lo + j];
-          if (wave == 0 && blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes), skn[x]);
+          if (blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(s_lo + j) * row_bytes), skn[x]);
         }
       }
-      const u32 res = cl_try(trymap, skn, have, (u32)lane, cl_mult(wave));
-      if (lane == 0) tryres[wave] = res;
-      cl_barrier();
-      if (wave == 0) {
-        u32 mult = pick();
-        if (mult) cl_fill(ptab, skn, have, (u32)lane, mult, myslot);
-        else mult = cl_build(ptab, skn, have, (u32)lane, myslot, (u32)CL_NW);
-        if (lane == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
-      }
+      const u32 mult = cl_build(ptab, skn, have, (u32)tid, myslot);
+      if (tid == 0) { sh[4] = mult; if (mult == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
     }
     CKey khi_n = ntiles > 1 ? skel[s_lo + rt] : ck_inf();     // upper key of tile 0 (uniform address: scalar load)
     CKey kmid_n = (CL_HALVES > 1 && s_lo + 56 < s_hi) ? skel[s_lo + 56] : ck_inf();      // ... and the key its second slice group starts at
@@ -604,10 +540,10 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       const CKey khi = ck_uni(khi_n);
       const CKey kmid = ck_uni(kmid_n);
       if (!last) {
-        // the next tile's row keys: requested now, looked at when this tile is done
-        {   // (every wave: each tries a hash for the next tile's table on them when this tile is done)
+        // the next tile's row keys are wave 0's business alone: nobody else ever waits for these loads
+        if (tid < 64) {
 #pragma unroll
-          for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)lane + 64u * x; skn[x] = ck_inf(); if (j < rt && s0 + rt + j < s_hi) skn[x] = skel[s0 + rt + j]; }
+          for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)tid + 64u * x; skn[x] = ck_inf(); if (j < rt && s0 + rt + j < s_hi) skn[x] = skel[s0 + rt + j]; }
         }
         khi_n = q + 2 < ntiles ? skel[s0 + 2 * rt] : ck_inf();
         kmid_n = (CL_HALVES > 1 && s0 + rt + 56 < s_hi) ? skel[s0 + rt + 56] : ck_inf();
@@ -630,85 +566,29 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       };
       gu64w* const ovx = (gu64w*)(uintptr_t)C.ovx;
 
-      // ---- the records that are no row keys: staged in LDS per lane while the window's slots are walked (key words + count at
-      //      the lane's column of stage row `nov`, written for EVERY slot, kept -- nov moves on -- only for such a record), and
-      //      appended to the wave's slices once per round: one pass per staged row (2-3 of them) instead of a ballot, a branch and
-      //      the positions' arithmetic per window slot (16 of them; with 3 % of the records set aside a slot of SOME lane of the wave
-      //      is one 86 % of the time: round 4's loop spent a third of its instructions there) ----
-      u64* const stk = reinterpret_cast<u64*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt) + 384);                                     // [CL_STK + 1][KW][CL_TPB]
-      u32* const stc = reinterpret_cast<u32*>(smem + CL_IMG + CL_NT * CL_PT * sizeof(ClEnt) + 384 + (size_t)(CL_STK + 1) * KW * CL_TPB * 8);   // [CL_STK + 1][CL_TPB]
-      u32 nov = 0;                                  // my staged records
-      // one record per lane (where `has`) to the wave's slices: positions from ballots
-      auto append = [&](const bool has, const CKey kk, const u32 cc) {
-        const u64 bal = __ballot(has);
-        const u64 pay = li_hi | cc | ((RESC && cc < smin) ? CL_NONSOLID : 0ULL);
-#if KMX_CL_KW == 1
-#define CL_PUT(o, pos) do { (o)[2 * (pos)] = kk; (o)[2 * (pos) + 1] = pay; } while (0)
-#else
-#define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = pay; } while (0)
-#endif
-        if (CL_HALVES == 1) {
-          if (EXT && __builtin_expect(wov + (u32)__popcll(bal) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
-          if (has) {
-            const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-            if (pos < (u32)CL_OVW) CL_PUT(ovk0, pos);
-            else if (EXT && xb0 - 1u < 0xFFFFFFFEu && pos - (u32)CL_OVW < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb0 - 1u) * EW; const u32 px = pos - (u32)CL_OVW; CL_PUT(o, px); }
-          }
-          wov += (u32)__popcll(bal);
+      for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
+        // (three flags in turn: the one cleared here was last read two rounds ago, a barrier away)
+        if (tid == 0) sh[1 + (rnd == 2 ? 0 : rnd + 1)] = 0;
+        // which slots are consumed (this is where the window loads are waited for, all at once: the
+        // refills issued further down then never stall a slot that is looked at after them)
+        u32 consm = 0;
+        if (last) {
+#pragma unroll
+          for (int u = 0; u < CL_U; u++) consm |= ((cur + ((r + CL_G * u - cur) & (CL_W - 1))) < end ? 1u : 0u) << u;
         } else {
-          const bool up = !ck_lt(kk, kmid);
-          const u64 hi = __ballot(has && up), lo = bal & ~hi;
-          if (EXT && __builtin_expect(wov + (u32)__popcll(lo) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
-          if (EXT && __builtin_expect(wov1 + (u32)__popcll(hi) > (u32)CL_OVW && xb1 == 0, 0)) extend(xb1);
-          if (has) {
-            const u64 m = up ? hi : lo;
-            const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-            if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; CL_PUT(o, pos); }
-            else if (EXT) {
-              const u32 xb = up ? xb1 : xb0, px = pos - (u32)CL_OVW;
-              if (xb - 1u < 0xFFFFFFFEu && px < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb - 1u) * EW; CL_PUT(o, px); }
-            }
-          }
-          wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
+#pragma unroll
+          for (int u = 0; u < CL_U; u++) consm |= (ck_lt(cl_key(rec[u]), khi) ? 1u : 0u) << u;      // (an empty slot holds the largest key)
         }
-      };
-      auto flush = [&]() {
-#pragma unroll 1
-        for (u32 kq = 0; kq < (u32)CL_STK; kq++) {
-          const bool has = kq < nov;
-          if (!__ballot(has)) break;
-          const u32 sx = kq * (u32)CL_TPB + (u32)tid;
-#if KMX_CL_KW == 1
-          const CKey kk = stk[sx];
-#else
-          CKey kk; kk.lo = stk[2 * kq * (u32)CL_TPB + (u32)tid]; kk.hi = stk[(2 * kq + 1) * (u32)CL_TPB + (u32)tid];
-#endif
-          append(has, kk, stc[sx]);
-        }
-        nov = 0;
-      };
-      // the walk over the window's slots, built once per hash family of the tile's row table (a uniform choice per tile)
-      auto walk = [&](const u32 consm, u32& cur_) {
+        asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
+        CLPH(1);
 #pragma unroll
         for (int g = 0; g < CL_U; g += 4) {
           __builtin_amdgcn_sched_barrier(0);
-          u32 curg = cur_; asm volatile("" : "+v"(curg));      // (re-derived per group: 16 slot indices kept live get spilled)
+          u32 curg = cur; asm volatile("" : "+v"(curg));      // (re-derived per group: 16 slot indices kept live get spilled)
           ClEnt pe[4];
-#if defined(KMX_CL_LEVEL) && KMX_CL_LEVEL == 0      // (timing experiments, not builds: 0 = the window's loads and nothing else, 1 = + the table lookups, 2 = + the deposits, 3 = everything)
-#pragma unroll
-          for (int j = 0; j < 4; j++) { tsum += cl_cnt(rec[g + j]); tn += (u32)ck_fold(cl_key(rec[g + j])); }
-          asm volatile("" : "+v"(tsum), "+v"(tn));
-          if (false)
-#else
 #pragma unroll
           for (int j = 0; j < 4; j++) pe[j] = ent_load(tab, cl_thash(cl_key(rec[g + j]), mult));
-#endif
-#if defined(KMX_CL_LEVEL) && KMX_CL_LEVEL == 1
-#pragma unroll
-          for (int j = 0; j < 4; j++) { tsum += cl_cnt(rec[g + j]); tn += ent_hit(pe[j], cl_key(rec[g + j])) ? pe[j].idx : 0u; }
-          asm volatile("" : "+v"(tsum), "+v"(tn));
-          if (false)
-#endif
+          u32 ovm = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             // straight-line: masks and selects, no branches (a deposit that is none goes to a scratch word)
@@ -731,26 +611,48 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             }
             else if (MODE == 0) img[dep ? __umul24(pe[j].idx - 1, iw) + lg : dummy] = c;
             else if (dep) atomicOr(&img[__umul24(pe[j].idx - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
-            // a solid record that is no row key (RESC: any such record): staged -- written whatever it is, kept when it is one
-#if defined(KMX_CL_LEVEL) && KMX_CL_LEVEL == 2
-            if (true) continue;
-#endif
-            const bool ov = (RESC ? cons : solid) && !hit;
-            // (a lane whose CL_STK stage rows are full -- a third such record in one round: rare -- writes to a row nobody reads, and its
-            //  record goes to the slices at once)
-            const bool full = nov >= (u32)CL_STK;
-            if (__builtin_expect(__ballot(ov && full) != 0, 0)) append(ov && full, k, c);
-            const u32 sx = nov * (u32)CL_TPB + (u32)tid;
-#if KMX_CL_KW == 1
-            stk[sx] = k;
-#else
-            stk[2 * nov * (u32)CL_TPB + (u32)tid] = k.lo; stk[(2 * nov + 1) * (u32)CL_TPB + (u32)tid] = k.hi;
-#endif
-            stc[sx] = c;
-            nov += (ov && !full) ? 1u : 0u;
+            ovm |= (((RESC ? cons : solid) && !hit) ? 1u : 0u) << j;
           }
           asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
           if (RESC) asm volatile("" : "+v"(rsum), "+v"(rn));
+          // solid records that are not row keys: appended to the wave's slice of the tile (positions from ballots)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const u64 bal = __ballot((ovm >> j) & 1u);
+            if (bal) {
+              const CKey kk = cl_key(rec[g + j]);
+              const u64 pay = li_hi | cl_cnt(rec[g + j]) | ((RESC && cl_cnt(rec[g + j]) < smin) ? CL_NONSOLID : 0ULL);
+#if KMX_CL_KW == 1
+#define CL_PUT(o, pos) do { (o)[2 * (pos)] = kk; (o)[2 * (pos) + 1] = pay; } while (0)
+#else
+#define CL_PUT(o, pos) do { (o)[3 * (pos)] = kk.lo; (o)[3 * (pos) + 1] = kk.hi; (o)[3 * (pos) + 2] = pay; } while (0)
+#endif
+              if (CL_HALVES == 1) {
+                if (EXT && __builtin_expect(wov + (u32)__popcll(bal) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
+                if ((ovm >> j) & 1u) {
+                  const u32 pos = wov + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                  if (pos < (u32)CL_OVW) CL_PUT(ovk0, pos);
+                  else if (EXT && xb0 - 1u < 0xFFFFFFFEu && pos - (u32)CL_OVW < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb0 - 1u) * EW; const u32 px = pos - (u32)CL_OVW; CL_PUT(o, px); }
+                }
+                wov += (u32)__popcll(bal);
+              } else {
+                const u64 hi = __ballot(((ovm >> j) & 1u) && !ck_lt(kk, kmid)), lo = bal & ~hi;
+                if (EXT && __builtin_expect(wov + (u32)__popcll(lo) > (u32)CL_OVW && xb0 == 0, 0)) extend(xb0);
+                if (EXT && __builtin_expect(wov1 + (u32)__popcll(hi) > (u32)CL_OVW && xb1 == 0, 0)) extend(xb1);
+                if ((ovm >> j) & 1u) {
+                  const bool up = !ck_lt(kk, kmid);
+                  const u64 m = up ? hi : lo;
+                  const u32 pos = (up ? wov1 : wov) + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                  if (pos < (u32)CL_OVW) { gu64w* const o = up ? ovk1 : ovk0; CL_PUT(o, pos); }
+                  else if (EXT) {
+                    const u32 xb = up ? xb1 : xb0, px = pos - (u32)CL_OVW;
+                    if (xb - 1u < 0xFFFFFFFEu && px < (u32)CL_XS) { gu64w* const o = ovx + (u64)(xb - 1u) * EW; CL_PUT(o, px); }
+                  }
+                }
+                wov += (u32)__popcll(lo); wov1 += (u32)__popcll(hi);
+              }
+            }
+          }
           // refill in place: the consumed records are a prefix of the window, so a consumed slot's next record is
           // the one 64 positions further (one past the list's end: the sentinel).  A slot that was not consumed is left
           // alone: loading it again would fetch the window's last line twice (it is evicted from L2 by the next tile).
@@ -764,25 +666,6 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             }
           }
         }
-      };
-
-      for (;;) {   // rounds: one, unless a list has more than a window of records below the upper key
-        // (three flags in turn: the one cleared here was last read two rounds ago, a barrier away)
-        if (tid == 0) sh[1 + (rnd == 2 ? 0 : rnd + 1)] = 0;
-        // which slots are consumed (this is where the window loads are waited for, all at once: the
-        // refills issued further down then never stall a slot that is looked at after them)
-        u32 consm = 0;
-        if (last) {
-#pragma unroll
-          for (int u = 0; u < CL_U; u++) consm |= ((cur + ((r + CL_G * u - cur) & (CL_W - 1))) < end ? 1u : 0u) << u;
-        } else {
-#pragma unroll
-          for (int u = 0; u < CL_U; u++) consm |= (ck_lt(cl_key(rec[u]), khi) ? 1u : 0u) << u;      // (an empty slot holds the largest key)
-        }
-        asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
-        CLPH(1);
-        walk(consm, cur);
-        flush();
         u32 c = __popc(consm);
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         c += (u32)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
@@ -808,29 +691,20 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
       }
 
       // ---- tile out: wave 0 turns the row table over, the others stream the image out (and leave it zeroed) ----
-      bool have_n[CL_KPL];
-#pragma unroll
-      for (int x = 0; x < CL_KPL; x++) { const u32 j = (u32)lane + 64u * x; have_n[x] = !last && j < rt && s0 + rt + j < s_hi; }
-      if (!last) {      // every wave: one hash of the family tried on the next tile's row keys (cl_try), then the workgroup meets
-        const u32 res = cl_try(trymap, skn, have_n, (u32)lane, cl_mult(wave));
-        if (lane == 0) tryres[wave] = res;
-        cl_barrier();
-      }
       if (wave == 0) {
         ClEnt* const old = ptab + (q % CL_NT) * CL_PT;
 #pragma unroll
         for (int x = 0; x < CL_KPL; x++) if ((u32)lane + 64u * x < rte) old[myslot[x]].idx = 0;        // (keys may stay: an entry without a row is never a hit)
         if (!last) {
           const u32 sn = s0 + rt;
+          bool have[CL_KPL];
 #pragma unroll
           for (int x = 0; x < CL_KPL; x++) {
             const u32 j = (u32)lane + 64u * x;
-            if (have_n[x] && blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes), skn[x]);
+            have[x] = j < rt && sn + j < s_hi;
+            if (have[x] && blk == 0 && !ord) ck_store(reinterpret_cast<u32*>(T.out + (u64)(sn + j) * row_bytes), skn[x]);
           }
-          ClEnt* const ntab = ptab + ((q + 1) % CL_NT) * CL_PT;
-          u32 m2 = pick();
-          if (m2) cl_fill(ntab, skn, have_n, (u32)lane, m2, myslot);
-          else m2 = cl_build(ntab, skn, have_n, (u32)lane, myslot, (u32)CL_NW);      // (one tile in fifty: the rest of the family, one hash after the other)
+          const u32 m2 = cl_build(ptab + ((q + 1) % CL_NT) * CL_PT, skn, have, (u32)lane, myslot);
           if (lane == 0) { sh[4 + ((q + 1) % CL_NT)] = m2; if (m2 == 0) { failed = true; atomicAdd(&kmx_cols_dbg[0], 1u); } }
         }
       } else {
@@ -1055,13 +929,7 @@ __device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mi
 // aside there, interleaved by key -- are one contiguous run of the body; the group's place comes from the look-back above.  A
 // group of several passes counts its rows first (every pass sorted once without writing), publishes, and sorts again to write.
 template <int MODE, bool RESC, bool ORD>
-#ifndef KMX_CK_ORD_OCC
-#define KMX_CK_ORD_OCC 2
-#endif
-#ifndef KMX_CK_RF
-#define KMX_CK_RF 4
-#endif
-__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : ORD ? KMX_CK_ORD_OCC : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores: one workgroup per CU either way, and the ORD build keeps four row keys' rows per wave in flight)
+__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : ORD ? 2 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores: one workgroup per CU either way, and the ORD build keeps four row keys' rows per wave in flight)
 void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items, u32 n_tasks, u32* tkt)
 {
   __shared__ __attribute__((aligned(16))) u32 uni[CK_UNI / 4];      // the key maps | the row keys and interval counters (recurrence-min 1) | the rows' staging
@@ -1216,17 +1084,9 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         if (ORD) return !(has_lo && ck_lt(k, plo)) && !(has_hi && !ck_lt(k, phi));
         return ((cl_mix(k) >> 24) & (npass - 1)) == pass;      // (by hash bits: equal keys meet in the same pass)
       };
-#ifdef KMX_CK_ADAPT_MAPS
-      // the maps as large as the group's entries ask for: 16 bits of the first map per entry (an entry meets another key's bit with
-      // probability 1/16: such chance candidates only make the sort a little larger), a quarter of that for the second
-      u32 mb1 = 8192; while (mb1 < (u32)CK_BITS && mb1 < 16u * tot) mb1 <<= 1;
-      const u32 mb2 = max(2048u, mb1 >> 2);
-#else
-      const u32 mb1 = (u32)CK_BITS, mb2 = (u32)CK_B2;
-#endif
       if (thr > 1) {
-        for (u32 t = tid; t < mb1 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
-        for (u32 t = tid; t < mb2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
+        for (u32 t = tid; t < (u32)CK_BITS / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits)[t] = make_uint4(0, 0, 0, 0);
+        for (u32 t = tid; t < (u32)CK_B2 / 128; t += CK_TPB) reinterpret_cast<uint4*>(bits2)[t] = make_uint4(0, 0, 0, 0);
       } else {
         for (u32 t = tid; t < 512u; t += CK_TPB) bits[t] = 0;      // (the interval counters below live in the key map's room)
       }
@@ -1324,16 +1184,16 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       if (thr > 1) {
         each(in_pass, [&](CKey k, u64) {
           const u32 hx = cl_mix(k);
-          const u32 bit = hx & (mb1 - 1);
+          const u32 bit = hx & (CK_BITS - 1);
           const u32 old = atomicOr(&bits[bit >> 5], 1u << (bit & 31u));
-          if ((old >> (bit & 31u)) & 1u) { const u32 b2 = (hx >> 7) & (mb2 - 1); atomicOr(&bits2[b2 >> 5], 1u << (b2 & 31u)); }
+          if ((old >> (bit & 31u)) & 1u) { const u32 b2 = (hx >> 7) & (CK_B2 - 1); atomicOr(&bits2[b2 >> 5], 1u << (b2 & 31u)); }
         });
         __syncthreads();
         SPPH(2);
       }
       if (thr > 1) {
         each(in_pass, [&](CKey k, u64 pl) {
-          const u32 b2 = (cl_mix(k) >> 7) & (mb2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
+          const u32 b2 = (cl_mix(k) >> 7) & (CK_B2 - 1); if (!((bits2[b2 >> 5] >> (b2 & 31u)) & 1u)) return;
           push(k, pl);
         });
         __syncthreads();
@@ -1433,7 +1293,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       // rows of a wave in flight at once (a row is read at the latency of HBM: one at a time a wave would spend its time waiting)
       auto dense_rows = [&]() {
         if (MODE == 0) {
-          constexpr int RF = KMX_CK_RF;
+          constexpr int RF = 4;
           const bool wide = (row_bytes & 7u) == 0;      // (C.dense's rows are 8-byte aligned)
           const u32 n8 = row_bytes / 8, n4 = row_bytes / 4;
           for (u32 i0 = wave * RF; i0 < dnp; i0 += (CK_TPB / 64) * RF) {
@@ -1605,7 +1465,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           // other rows are only written.  So the two are interleaved: a wave asks for RF of its row keys' rows, writes its share of
           // a stretch of the kept runs' rows while they travel, stores them, asks for the next RF.  (All of them up front, the wave
           // waiting: rows phase 2.8x the arena build's for a fifth more rows.)
-          constexpr int RF = KMX_CK_RF;
+          constexpr int RF = 4;
           const u32 n8 = row_bytes / 8;
           const u32 rounds = max(1u, (dnp + (CK_TPB / 64) * RF - 1) / ((CK_TPB / 64) * RF));
           if (C.dnarrow) {
@@ -1932,7 +1792,7 @@ void cols_phase_prof_dump()
 #endif
 
 // ---- host side ------------------------------------------------------------------------------------------
-int cols_lds_bytes() { return CL_IMG + CL_NT * CL_PT * (int)sizeof(ClEnt) + 64 + 256 + 64 + CL_STG; }
+int cols_lds_bytes() { return CL_IMG + CL_NT * CL_PT * (int)sizeof(ClEnt) + 64 + 256; }
 u32 cols_halves() { return CL_HALVES; }
 u32 cols_wgs_per_cu() { return CL_WGS; }
 u32 cols_block_lists() { return CL_NB; }

@@ -484,6 +484,16 @@ def test_two_gpu_workers_same_output(tmp_path):
         else: assert 0 < rep["resident_samples"] < 8, rep      # (some samples fitted the 8 MB stores, the others left count files)
         if not name.endswith("_files"):   # no count file survives a run without --keep-tmp
             assert all(not os.listdir(out / "counts" / f"partition_{p}") for p in range(16)), name
+        if name == "g8_resident":
+            # the 8-GPU shape: a sample's lists reach the stores in ONE copy per destination shard (the partitions bound for a GPU lie
+            # back to back; over xGMI that is one hipMemcpyPeerAsync per destination GPU and sample) -- 8 samples x 8 stores, every
+            # store by every sample; on this one-GPU box all of them device copies
+            import re
+            copies = re.findall(r"\[kmx copy\] lists from device (\d+) to store (\d+) on device (\d+): (\d+) bytes, (device copy|hipMemcpyPeerAsync)", err)
+            assert len(copies) == 8 * 8, len(copies)
+            assert sorted(int(c[1]) for c in copies) == sorted(list(range(8)) * 8)
+            assert all(int(c[3]) > 0 for c in copies)
+            assert rep["gpus"] == 8 and rep["peer_pairs"] >= 0
     for s_ in range(8):      # the PartiInfo<5> statistics: per partition from the sorted descriptors (default) == by atomics
         n = f"S{s_:04d}/PartiInfoFile"
         assert open(outs["g1_resident"][0] / "superkmers" / n, "rb").read() == open(outs["g1_resident_r3"][0] / "superkmers" / n, "rb").read(), n
