@@ -389,7 +389,7 @@ def count_stage_workload(env, a):
     blob = reads.tobytes(); offs = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L))
     table = (xxh64_u32(np.arange(4 ** M, dtype=np.uint32)) % np.uint64(P)).astype(np.uint16)
     ctx = lib.Context(env["local"]); store = lib.Store(env["local"])
-    st = torch.cuda.ExternalStream(ctx.stream(), device=env["dev"])
+    st = torch.cuda.ExternalStream(ctx.stream() if callable(ctx.stream) else ctx.stream, device=env["dev"])
     for _ in range(3):
         ctx.count_reads_dev((blob, offs), K, M, table, P, 2, [store])
     reps, dev_ms, wall = 10, [], []

@@ -212,9 +212,17 @@ void k_merge_bf(const TaskDev* __restrict__ tasks, const uint2* __restrict__ ite
       // stream the tile out: tile starts at a multiple of rt rows (rt % 4 == 0) -> 4-byte aligned
       u8* dst = T.out + (tlo - T.lower) * nb;
       {
+        // 16-byte stores where the destination allows them (round 5: dword stores before): the dwords in front of the first 16-byte
+        // boundary one by one, then four image dwords a lane and store, then the tail
         u32* d32 = reinterpret_cast<u32*>(dst);
         const u32 nw = bytes >> 2;
-        for (u32 t = tid; t < nw; t += BF_TPB) d32[t] = img[t];
+        const u32 head = min(nw, (u32)(((16u - (u32)((uintptr_t)dst & 15u)) & 15u) >> 2)), nq = (nw - head) >> 2;
+        if (tid < head) d32[tid] = img[tid];
+        for (u32 t = tid; t < nq; t += BF_TPB) {
+          const u32 w = head + 4 * t;
+          *reinterpret_cast<uint4*>(d32 + w) = make_uint4(img[w], img[w + 1], img[w + 2], img[w + 3]);
+        }
+        for (u32 t = head + 4 * nq + tid; t < nw; t += BF_TPB) d32[t] = img[t];
         for (u32 t = (nw << 2) + tid; t < bytes; t += BF_TPB) dst[t] = lds[t];
       }
       __syncthreads();

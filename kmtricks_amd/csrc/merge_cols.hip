@@ -89,6 +89,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef __attribute__((address_space(1))) const u32x3 gu32x3;
 typedef __attribute__((address_space(1))) const u32x4 gu32x4;
 typedef __attribute__((address_space(1))) u64 gu64w;
+typedef u64 u64x2 __attribute__((ext_vector_type(2), aligned(8)));      // a 16-byte store at an 8-byte aligned place (a count row starts at a multiple of its 8 * k bytes)
 __device__ __forceinline__ u32 cl_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 cl_uni64(u64 v) { return (u64)cl_uni((u32)v) | ((u64)cl_uni((u32)(v >> 32)) << 32); }
 
@@ -603,23 +604,28 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
             // (RESC: a row key's row has recurrence-min >= share-min solid records: its non-solid records are rescued, written like the others)
             const bool dep = RESC ? (cons && hit && (solid || rescue)) : (solid && hit);
             if (RESC) { const bool rs = cons && hit && !solid && rescue; rsum += rs ? c : 0u; rn += rs ? 1u : 0u; }
-            if (NAR) {
-              img8[dep ? __umul24(pe[j].idx - 1, nbs) + lg : dummyb] = (u8)min(c, 255u);
-              if (__builtin_expect(__ballot(dep && c > 254u) != 0, 0)) {      // (a count that does not fit the byte: to the 4-byte row, by the lane that holds it)
-                if (dep && c > 254u) { reinterpret_cast<u32*>(C.dense + (u64)(s0 + pe[j].idx - 1) * opitch)[li] = c; rowbig[pe[j].idx - 1] = 1; }
-              }
-            }
+            bool big = false;      // NAR: a count that does not fit its byte -- to the 4-byte row, by the lane that holds it (below, in the slot's one branch)
+            if (NAR) { img8[dep ? __umul24(pe[j].idx - 1, nbs) + lg : dummyb] = (u8)min(c, 255u); big = dep && c > 254u; }
             else if (MODE == 0) img[dep ? __umul24(pe[j].idx - 1, iw) + lg : dummy] = c;
             else if (dep) atomicOr(&img[__umul24(pe[j].idx - 1, iw) + (lg >> 5)], 1u << (lg & 31u));
             ovm |= (((RESC ? cons : solid) && !hit) ? 1u : 0u) << j;
+            if (NAR) ovm |= (big ? 0x11u : 0u) << j;      // (bit 4 + j: the slot's record is such a count, not a record for the slices)
           }
           asm volatile("" : "+v"(tsum), "+v"(tn));      // summed up here, not at the end of the scan (with every count kept until then)
           if (RESC) asm volatile("" : "+v"(rsum), "+v"(rn));
           // solid records that are not row keys: appended to the wave's slice of the tile (positions from ballots)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            const u64 bal = __ballot((ovm >> j) & 1u);
-            if (bal) {
+            u64 bal = __ballot((ovm >> j) & 1u);
+            if (bal) {      // (the same block without this branch around it: no difference, 2.29 ms either way)
+              if (NAR) {
+                const bool isbig = (ovm >> (4 + j)) & 1u;
+                if (__builtin_expect(__ballot(isbig) != 0, 0)) {
+                  if (isbig) { const u32 rw = ent_load(tab, cl_thash(cl_key(rec[g + j]), mult)).idx - 1; reinterpret_cast<u32*>(C.dense + (u64)(s0 + rw) * opitch)[li] = cl_cnt(rec[g + j]); rowbig[rw] = 1; }      // (its row: looked up again -- rare)
+                  ovm &= isbig ? ~(1u << j) : ~0u;
+                  bal = __ballot((ovm >> j) & 1u);
+                }
+              }
               const CKey kk = cl_key(rec[g + j]);
               const u64 pay = li_hi | cl_cnt(rec[g + j]) | ((RESC && cl_cnt(rec[g + j]) < smin) ? CL_NONSOLID : 0ULL);
 #if KMX_CL_KW == 1
@@ -745,6 +751,16 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           // a row's slice is (lists of the block) / 8 bytes (the block starts at a multiple of 8 lists): a byte per lane
           u8* const out0 = obase + (u64)s0 * opitch + (col0 >> 3);
           const u32 nby = (nbl + 7) >> 3;
+          if (ORD && nbs == 128u && (opitch & 15u) == 0 && (col0 >> 3) + 16u <= opitch) {      // (blocks of exactly 128 lists: every block's slice of a row is its own 16 bytes)
+            // the side store's rows are 16-byte aligned and a block's slice of a row is 16 bytes: a LANE per row, one 16-byte load from
+            // the image and one 16-byte store (round 5; a wave per row and a byte per lane before: 56 store instructions a tile
+            // where one does; the bits behind the last list are zeros in the row's padding)
+            for (u32 j = (wave - 1) * 64u + (u32)lane; j < rte; j += (CL_NW - 1) * 64u) {
+              uint4* const src = reinterpret_cast<uint4*>(img + j * 4u);
+              const uint4 v = *src; *src = make_uint4(0, 0, 0, 0);
+              *reinterpret_cast<uint4*>(out0 + (u64)j * opitch) = v;
+            }
+          } else
           for (u32 j = wave - 1; j < rte; j += CL_NW - 1) {
             u32* const src = img + j * iw;
             u8* const dst = out0 + (u64)j * opitch;
@@ -1426,9 +1442,13 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
             const u32 bitv = (MODE == 1 && RESC && cnt == 0) ? 0u : 1u;      // (RESC, recurrence-min 0: a lone non-solid record is a row of zeros)
             if (MODE == 0) {
               if ((row_bytes & 7u) == 0) {
-                u64* const r8 = reinterpret_cast<u64*>(row);
-                for (u32 t = sl; t < row_bytes / 8; t += SG)
-                  r8[t] = t < (u32)KW ? ((u64)kword(2 * t) | ((u64)kword(2 * t + 1) << 32)) : (t - KW == (li >> 1) ? (u64)cnt << ((li & 1u) * 32) : 0ULL);
+                // 16-byte stores (round 5): the rows are what this kernel is made of -- 10 GB of them per launch of configs[2] --, and a
+                // store INSTRUCTION is what it pays for: with 8-byte stores it ran at the ~7 bytes per cycle and CU that is the issue
+                // limit of dwordx2 stores (MI355X_MICROARCH.md), not at the memory's rate
+                auto word = [&](u32 t) -> u64 { return t < (u32)KW ? ((u64)kword(2 * t) | ((u64)kword(2 * t + 1) << 32)) : (t - KW == (li >> 1) ? (u64)cnt << ((li & 1u) * 32) : 0ULL); };
+                const u32 n8 = row_bytes / 8, n16 = n8 >> 1;
+                for (u32 t = sl; t < n16; t += SG) { u64x2 v; v.x = word(2 * t); v.y = word(2 * t + 1); *reinterpret_cast<u64x2*>(row + 16u * t) = v; }
+                if ((n8 & 1u) && sl == 0) reinterpret_cast<u64*>(row)[n8 - 1] = word(n8 - 1);
               } else {
                 u32* const r4 = reinterpret_cast<u32*>(row);
                 for (u32 t = sl; t < row_bytes / 4; t += SG) r4[t] = t < 2u * KW ? kword(t) : (t - 2u * KW == li ? cnt : 0u);
@@ -1441,8 +1461,10 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           if (MODE == 0) {
             // row = key + N counts: 8-byte stores (rows start at multiples of 8 when row_bytes is one: N even), else 4-byte ones
             if ((row_bytes & 7u) == 0) {
-              u64* const r8 = reinterpret_cast<u64*>(row);
-              for (u32 t = sl; t < row_bytes / 8; t += SG) r8[t] = t < (u32)KW ? ((u64)kword(2 * t) | ((u64)kword(2 * t + 1) << 32)) : 0ULL;
+              auto word = [&](u32 t) -> u64 { return t < (u32)KW ? ((u64)kword(2 * t) | ((u64)kword(2 * t + 1) << 32)) : 0ULL; };
+              const u32 n8 = row_bytes / 8, n16 = n8 >> 1;
+              for (u32 t = sl; t < n16; t += SG) { u64x2 v; v.x = word(2 * t); v.y = word(2 * t + 1); *reinterpret_cast<u64x2*>(row + 16u * t) = v; }
+              if ((n8 & 1u) && sl == 0) reinterpret_cast<u64*>(row)[n8 - 1] = word(n8 - 1);
             } else {
               u32* const r4 = reinterpret_cast<u32*>(row);
               for (u32 t = sl; t < row_bytes / 4; t += SG) r4[t] = t < 2u * KW ? kword(t) : 0u;
@@ -1473,20 +1495,20 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
             // above 254: its byte is 255 and the count lies in the 4-byte row).  A lane takes two groups of eight lists: an 8-byte load
             // each, four 8-byte stores each; the row's eight flag bytes in one (uniform) load.
             const u8* const nar = C.dnarrow; const u32 npitch = C.npitch, nbs = C.nb, NL = T.N, FO = npitch - 16u;      // (the row's last 16 bytes: a flag byte per column block)
-            const u32 ng = (NL + 7u) / 8u;      // (<= 128: row_bytes / 8 <= 512)
-            u32 fsh0[2], fsh1[2];                // 8 x the column block of my groups' first and last list
-#pragma unroll
-            for (int y = 0; y < 2; y++) { const u32 l = min(8u * (64u * y + lane), NL - 1u); fsh0[y] = 8u * (l / nbs); fsh1[y] = 8u * (min(l + 7u, NL - 1u) / nbs); }
+            // (a lane takes SIXTEEN lists: one 16-byte load, four 16-byte stores -- a block is a multiple of 16 lists wide, so the sixteen
+            //  share its flag byte)
+            const u32 ng = (NL + 15u) / 16u;      // (<= 64: row_bytes / 8 <= 512)
+            const u32 l0 = min(16u * lane, NL - 1u), fsh = 8u * (l0 / nbs);
+            const u32 nval = lane < ng ? min(16u, NL - 16u * lane) : 0u;      // my lists (even: the rows are whole 8-byte words)
             for (u32 c = 0; c < rounds; c++) {
               const u32 i0 = c * (CK_TPB / 64) * RF + wave * RF;
-              u64 nv[RF][2], fl[RF];
+              uint4 nv[RF]; u64 fl[RF];
 #pragma unroll
               for (int r = 0; r < RF; r++) {
                 const u32 i = i0 + r;
                 const u8* const nrow = nar + (u64)(d0 + dlo + (i < dnp ? i : 0)) * npitch;
                 fl[r] = i < dnp ? *reinterpret_cast<const u64*>(nrow + FO) : 0ULL;
-#pragma unroll
-                for (int y = 0; y < 2; y++) { const u32 g = 64u * y + lane; nv[r][y] = (i < dnp && g < ng) ? *reinterpret_cast<const u64*>(nrow + 8u * g) : 0ULL; }
+                nv[r] = (i < dnp && lane < ng) ? *reinterpret_cast<const uint4*>(nrow + 16u * lane) : make_uint4(0, 0, 0, 0);
               }
               sparse_rows((u32)(((u64)nk * c) / rounds), (u32)(((u64)nk * (c + 1)) / rounds));
 #pragma unroll
@@ -1500,23 +1522,20 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
 #pragma unroll
                   for (u32 d = 0; d < 2u * KW; d++) reinterpret_cast<u32*>(row)[d] = kw4[d];
                 }
-                u64* const out64 = reinterpret_cast<u64*>(row + 8u * KW);
+                if (nval == 0) continue;
+                u8* const out = row + 8u * KW + 64u * lane;      // my sixteen counts' place
+                const u32 by[4] = {nv[r].x, nv[r].y, nv[r].z, nv[r].w};
+                const bool flagged = ((fl[r] >> fsh) & 0xFFULL) != 0;
+                if (!flagged) {
 #pragma unroll
-                for (int y = 0; y < 2; y++) {
-                  const u32 g = 64u * y + lane;
-                  if (g >= ng) continue;
-                  const u64 v = nv[r][y];
-                  const u32 f = (u32)((fl[r] >> fsh0[y]) | (fl[r] >> fsh1[y])) & 0xFFu;
-                  if (!f) {      // (the row's last group may be ragged: N is even here -- rows of whole 8-byte words -- so it ends with a pair)
-                    const u32 npair = min(4u, (NL - 8u * g) >> 1);
-                    out64[4 * g + 0] = (v & 0xFFULL) | (((v >> 8) & 0xFFULL) << 32);
-                    if (npair > 1) out64[4 * g + 1] = ((v >> 16) & 0xFFULL) | (((v >> 24) & 0xFFULL) << 32);
-                    if (npair > 2) out64[4 * g + 2] = ((v >> 32) & 0xFFULL) | (((v >> 40) & 0xFFULL) << 32);
-                    if (npair > 3) out64[4 * g + 3] = ((v >> 48) & 0xFFULL) | ((v >> 56) << 32);
-                  } else {      // a block whose counts of this row are in the 4-byte row
-                    const u32* const wsrc = dense_src(i); u32* const cnt = reinterpret_cast<u32*>(out64);
-                    for (u32 l = 8u * g; l < min(NL, 8u * g + 8u); l++) { const u32 b = (u32)((v >> (8u * (l - 8u * g))) & 0xFFULL); cnt[l] = b == 255u ? wsrc[l] : b; }      // (255: the count is in the 4-byte row)
+                  for (u32 q4 = 0; q4 < 4; q4++) {      // four lists a store
+                    const u32 b = by[q4];
+                    if (4 * q4 + 4 <= nval) { u64x2 v; v.x = (u64)(b & 0xFFu) | ((u64)((b >> 8) & 0xFFu) << 32); v.y = (u64)((b >> 16) & 0xFFu) | ((u64)(b >> 24) << 32); *reinterpret_cast<u64x2*>(out + 16u * q4) = v; }
+                    else if (4 * q4 + 2 <= nval) *reinterpret_cast<u64*>(out + 16u * q4) = (u64)(b & 0xFFu) | ((u64)((b >> 8) & 0xFFu) << 32);
                   }
+                } else {      // a block some count of whose slice of this row lies in the 4-byte row (its byte is 255)
+                  const u32* const wsrc = dense_src(i); u32* const cnt = reinterpret_cast<u32*>(row + 8u * KW);
+                  for (u32 l = 0; l < nval; l++) { const u32 b = (by[l >> 2] >> (8u * (l & 3u))) & 0xFFu; cnt[16u * lane + l] = b == 255u ? wsrc[16u * lane + l] : b; }
                 }
               }
             }

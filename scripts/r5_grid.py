@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import argparse
 ap = argparse.ArgumentParser()
-ap.add_argument("--samples", type=int, default=1000)
+ap.add_argument("--samples", type=int, default=0)
 ap.add_argument("--parts", type=int, default=32)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--wl", default="count")
@@ -21,7 +21,7 @@ k = 31 if a.wl == "count" else 63
 kw = (k + 31) // 32
 mode = lib.MODE_COUNT if a.wl == "count" else lib.MODE_PA
 rec_min = 2 if a.wl == "count" else 1
-N = a.samples
+N = a.samples or (1000 if a.wl == "count" else 500)
 parts = shard.partitions_of_rank(a.parts, 1, 0)
 store, lists = bench.gen_counted(ctx, lib, N, k, 5_000_000, 0.001, 256, parts, 20240601, True)
 tasks = ctx.prepare([dict(lists=ls, key_words=kw, soft_min=[1] * N, rec_min=rec_min, share_min=0, mode=mode) for ls in lists])
