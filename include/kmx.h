@@ -109,7 +109,7 @@ typedef struct {
 typedef struct {
   uint32_t        n_lists;     /* N samples, fof order = column order (kmdir.hpp:65-72) */
   uint32_t        key_words;   /* ceil(k / 32) (kmer.hpp:215 m_n_data, io/kmer_file.hpp:84 kmer_slots): 1 for k <= 32 and hash keys, 2 up to 64,
-                                  3 up to 96, 4 up to 128.  3 and 4 (the reference's Kmer<96> / Kmer<128>): COUNT / PA rows, at most 2048 lists a task */
+                                  3 up to 96, 4 up to 128.  3 and 4 (the reference's Kmer<96> / Kmer<128>): COUNT / PA rows, at most 4096 (three words) / 3072 (four) lists a task */
   const kmx_list* lists;       /* [n_lists] */
   const uint32_t* soft_min;    /* [n_lists] per-sample abundance min (m_a_min_vec) */
   uint32_t        rec_min;     /* recurrence-min (m_r_min) */

@@ -591,7 +591,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     if (K.n_lists == 0 || !K.lists || !K.soft_min) return ctx->fail(KMX_E_INVAL, "task without lists / soft_min");
     H.N = K.n_lists; H.kw = kw; H.mode = mode; H.bitw = K.bitw;
     H.rec_min = K.rec_min; H.share_min = K.share_min; H.lower = K.lower; H.upper = K.upper;
-    if (!is_bf && H.N > (u32)rows_cap((int)kw)) return ctx->fail(KMX_E_UNSUPPORTED, "more than " + std::to_string(rows_cap((int)kw)) + " lists per merge task (COUNT/PA) not supported yet");
+    if (!is_bf && H.N > (u32)rows_cap((int)kw, ~0u)) return ctx->fail(KMX_E_UNSUPPORTED, "more than " + std::to_string(rows_cap((int)kw, ~0u)) + " lists per merge task (COUNT/PA) not supported yet");
     H.len.resize(H.N);
     u32 pivot = 0;
     for (u32 i = 0; i < H.N; i++) {
@@ -630,7 +630,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       }
     } else {
       H.row_bytes = kw * 8 + (mode == KMX_MODE_COUNT ? 4 * H.N : (H.N + 7) / 8);
-      u32 wl = 0; while (wl < 6 && (H.N << (wl + 1)) <= (u32)rows_cap((int)kw)) wl++;   // window <= one wave
+      u32 wl = 0; while (wl < 6 && (H.N << (wl + 1)) <= (u32)rows_cap((int)kw, H.N)) wl++;   // window <= one wave
       H.wl = wl;
       if (H.row_bytes > rows_image_bytes((int)kw)) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
       u64 guess = K.rows_hint ? K.rows_hint : 2ULL * longest + 4096;
@@ -690,7 +690,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       resc_ok = resc_ok && (!above || mode == KMX_MODE_COUNT); need_resc = need_resc || H.share_min > 0 || H.rec_min == 0;
       R->share_fix = R->share_fix || (above && mode == KMX_MODE_COUNT);
     }
-    bool can_cols = !is_bf && resc_ok && kw <= 2 && mx_n <= (u32)rows_cap((int)kw);      // (keys of three and four words: k_merge_rows)
+    bool can_cols = !is_bf && resc_ok && kw <= 2 && mx_n <= (u32)rows_cap((int)kw, mx_n);      // (keys of three and four words: k_merge_rows)
     R->cols_resc = need_resc;
     if (can_cols) {
       // k_merge_cols keeps worst-case room for the records it sets aside (a slice per half tile, block and wave: ~2.3 KB per
@@ -826,7 +826,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       }
       Q.pivot = (Q.N >= 2 && Q.len[Q.N / 2] > 0) ? Q.N / 2 : piv;
       Q.row_bytes = 8 * kw;                              // k_cols_skel writes keys only
-      u32 wl = 0; while (wl < 6 && (Q.N << (wl + 1)) <= (u32)rows_cap((int)kw)) wl++;
+      u32 wl = 0; while (wl < 6 && (Q.N << (wl + 1)) <= (u32)rows_cap((int)kw, Q.N)) wl++;
       Q.wl = wl;
       Q.rows_guess = std::max<u64>(1, std::min<u64>(H.rows_guess, Q.total_recs));
       // ranges of ~1500 records over the lists (k_cols_skel sorts a range in LDS, <= 2048 records): one segment per range

@@ -10,7 +10,7 @@ namespace kmx {
 
 // kernel launchers (defined next to their kernels)
 int rows_lds_bytes(int kw, u32 n_lists);
-int rows_cap(int kw);
+int rows_cap(int kw, u32 n_lists);
 int rows_wgs_per_cu(int kw);
 u32 rows_chunk_rows(u32 row_bytes);
 u32 rows_image_bytes(int kw);

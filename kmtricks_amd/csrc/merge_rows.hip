@@ -42,11 +42,15 @@ constexpr int WGS_PER_CU = (TPB <= 512 && (CAP * 8 + 2 * CAP * 4 + CAP * 2 + 409
 constexpr int NWAVE = TPB / 64;
 // keys of three and four words (k = 65 ... 96 and 97 ... 127: ceil(k / 32) words of a Kmer<96> / Kmer<128>; include/kmtricks/kmer.hpp:164-630, :215 of the reference): half the record
 // slots per tile -- the staged keys of 4096 slots alone would be 128 KB of the 160 KB, and a thread's keys leave the registers
-__host__ __device__ constexpr int cap_of(int kw) { return kw <= 2 ? CAP : CAP / 2; }
+// (BIG, round 5: for tasks of more lists than CAP / 2 -- three-word keys, k = 65 ... 96, with all CAP slots, four-word keys with 3 CAP / 4,
+// both under 140 KB of LDS; a thread's four / three records spill some 80 registers to scratch: the build for cohorts beyond 2048
+// samples, not for speed)
+__host__ __device__ constexpr int cap_of(int kw, bool big = false) { return kw <= 2 || (big && kw == 3) ? CAP : (big && kw == 4) ? 3 * CAP / 4 : CAP / 2; }
+__host__ __device__ constexpr int ts_of(int cap) { int t = 1; while (t < 2 * cap) t *= 2; return t; }      // hash set entries: a power of two, load factor <= 0.5
 
 // LDS image of the row batch being assembled: aliases the staged keys
-__host__ __device__ inline int rows_emit_bytes(int kw) { return cap_of(kw) * kw * 8; }
-__host__ __device__ inline int rows_fixed_bytes(int kw) { return cap_of(kw) * kw * 8 + 2 * cap_of(kw) * 4 + cap_of(kw) * 2 + 4096; }
+__host__ __device__ inline int rows_emit_bytes(int kw, bool big = false) { return cap_of(kw, big) * kw * 8; }
+__host__ __device__ inline int rows_fixed_bytes(int kw, bool big = false) { return cap_of(kw, big) * kw * 8 + ts_of(cap_of(kw, big)) * 4 + cap_of(kw, big) * 2 + 4096; }
 
 // ---- range bounds ------------------------------------------------------------------------------
 // bounds[j*N + i] = first record of list i whose key >= Q_j, Q_j = pivot[j * len_pivot / c].
@@ -99,14 +103,14 @@ __device__ u64 kmx_phase_prof[16];
 #endif
 
 // ---- the merge kernel ----------------------------------------------------------------------------
-template <int KW> __device__ __forceinline__ u32 key_hash(const Key<KW>& k)
+template <int KW, int TS> __device__ __forceinline__ u32 key_hash(const Key<KW>& k)
 { // cheap 32-bit mix (a handful of VALU ops); quality only matters for the probe length
   u32 x = (u32)k.w[0] ^ ((u32)(k.w[0] >> 32) * 0x9E3779B1u);
   if (KW >= 2) x ^= ((u32)k.w[KW - 1] * 0x85EBCA77u) ^ ((u32)(k.w[KW - 1] >> 32) * 0xC2B2AE3Du);
   if (KW >= 3) x ^= ((u32)k.w[1] * 0x27D4EB2Fu) ^ ((u32)(k.w[1] >> 32) * 0x165667B1u);
   if (KW >= 4) x ^= ((u32)k.w[2] * 0x9E3779B1u) ^ ((u32)(k.w[2] >> 32) * 0x85EBCA77u);
   x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
-  return x & (2 * cap_of(KW) - 1);
+  return x & (TS - 1);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt on gfx950
@@ -115,11 +119,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // linear probing past a hash collision (rare): returns table slot (low 32) | previous entry (high 32)
 // of `k`, claiming an empty slot for record slot `s` if the key is new (previous entry 0) -- out of line
-template <int KW>
+template <int KW, int TS>
 __device__ __noinline__ u64 probe_slow(u32* tab, const Key<KW>* keysL, Key<KW> k, u32 h, u32 s)
 {
   for (;;) {
-    h = (h + 1) & (2 * cap_of(KW) - 1);
+    h = (h + 1) & (TS - 1);
     u32 o = tab[h];
     if (o == 0) {
       o = atomicCAS(&tab[h], 0u, s + 1);
@@ -132,12 +136,12 @@ __device__ __noinline__ u64 probe_slow(u32* tab, const Key<KW>* keysL, Key<KW> k
 // One workgroup per CU: the per-slot state (record being merged, record in flight, statistics)
 // lives in registers.  The body is written for a low instruction count per record: the kernel is
 // issue-bound long before it is LDS- or HBM-bound.
-template <int KW, int MODE>
+template <int KW, int MODE, bool BIG>
 __global__ __launch_bounds__(TPB, (KW == 1 ? WGS_PER_CU : 1) * TPB / 256)
 void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ items, u32 n_items, u32* ticket)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int CAP = cap_of(KW), M = CAP / TPB, TS = 2 * CAP, KLBYTES = CAP * 2 + 4096;      // (the file's constants, for this key width)
+  constexpr int CAP = cap_of(KW, BIG), M = CAP / TPB, TS = ts_of(CAP), KLBYTES = CAP * 2 + 4096;      // (the file's constants, for this key width)
   constexpr int WMIN = KW <= 2 ? 256 : NWAVE * KW * 8;                                          // bytes of the waves' candidate keys
   constexpr int RB4 = (KW * 8 + 4) / 4;
   constexpr int KEYS_BYTES = CAP * KW * 8;
@@ -275,7 +279,7 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
       {
         u32 old[M];
 #pragma unroll
-        for (int m = 0; m < M; m++) { hs[m] = key_hash<KW>(key[m]); old[m] = 1; }
+        for (int m = 0; m < M; m++) { hs[m] = key_hash<KW, TS>(key[m]); old[m] = 1; }
 #pragma unroll
         for (int m = 0; m < M; m++) if ((consm >> m) & 1u) old[m] = tab[hs[m]];
 #pragma unroll
@@ -284,7 +288,7 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
             bool own = false;
             if (old[m] == 0) { old[m] = atomicCAS(&tab[hs[m]], 0u, (u32)(tid + m * TPB) + 1); own = old[m] == 0; }
             if (!own && !key_eq<KW>(keysL[(old[m] & 0xFFFFu) - 1], key[m])) {
-              const u64 pr = probe_slow<KW>(tab, keysL, key[m], hs[m], (u32)(tid + m * TPB));
+              const u64 pr = probe_slow<KW, TS>(tab, keysL, key[m], hs[m], (u32)(tid + m * TPB));
               hs[m] = (u32)pr; old[m] = (u32)(pr >> 32); own = old[m] == 0;
             }
             if (own) ownm |= 1u << m;
@@ -502,22 +506,27 @@ template __global__ void k_range_bounds<1>(const TaskDev*, u32);
 template __global__ void k_range_bounds<2>(const TaskDev*, u32);
 template __global__ void k_range_bounds<3>(const TaskDev*, u32);
 template __global__ void k_range_bounds<4>(const TaskDev*, u32);
-template __global__ void k_merge_rows<1, 0>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_rows<1, 1>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_rows<2, 0>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_rows<2, 1>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_rows<3, 0>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_rows<3, 1>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_rows<4, 0>(const TaskDev*, const uint2*, u32, u32*);
-template __global__ void k_merge_rows<4, 1>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<1, 0, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<1, 1, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<2, 0, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<2, 1, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<3, 0, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<3, 1, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<4, 0, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<4, 1, false>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<3, 0, true>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<3, 1, true>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<4, 0, true>(const TaskDev*, const uint2*, u32, u32*);
+template __global__ void k_merge_rows<4, 1, true>(const TaskDev*, const uint2*, u32, u32*);
 
 }  // namespace kmx
 
 // ---- host-side launchers (plain functions so other translation units need no device code) -----
 namespace kmx {
 
-int rows_lds_bytes(int kw, u32) { return rows_fixed_bytes(kw) + (kw <= 2 ? 384 : NWAVE * kw * 8 + 128); }
-int rows_cap(int kw) { return cap_of(kw); }
+static bool rows_big(int kw, u32 n) { return kw >= 3 && n > (u32)cap_of(kw); }
+int rows_lds_bytes(int kw, u32 n) { return rows_fixed_bytes(kw, rows_big(kw, n)) + (kw <= 2 ? 384 : NWAVE * kw * 8 + 128); }
+int rows_cap(int kw, u32 n) { return cap_of(kw, rows_big(kw, n)); }      // record slots of a tile = the most lists of a task (n: the task's lists; ~0u: the limit)
 int rows_wgs_per_cu(int kw) { return kw == 1 ? WGS_PER_CU : 1; }
 u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, (u32)KMX_CHUNK_BYTES / row_bytes); }
 u32 rows_image_bytes(int kw) { return (u32)rows_emit_bytes(kw); }
@@ -549,21 +558,25 @@ hipError_t launch_merge_rows(int kw, int mode, const TaskDev* tasks, const uint2
 {
   const int lds = rows_lds_bytes(kw, max_n);
   dim3 grid(grid_x), block(TPB);
-#define KMX_LAUNCH(KW_, MODE_)                                                                              \
+#define KMX_LAUNCH(KW_, MODE_, BIG_)                                                                              \
   do {                                                                                                      \
-    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_rows<KW_, MODE_>),           \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_merge_rows<KW_, MODE_, BIG_>),           \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                   \
     if (e_ != hipSuccess) return e_;                                                                        \
-    hipLaunchKernelGGL((k_merge_rows<KW_, MODE_>), grid, block, lds, st, tasks, items, n_items, ticket);    \
+    hipLaunchKernelGGL((k_merge_rows<KW_, MODE_, BIG_>), grid, block, lds, st, tasks, items, n_items, ticket);    \
   } while (0)
-  if (kw == 1 && mode == 0) KMX_LAUNCH(1, 0);
-  else if (kw == 1 && mode == 1) KMX_LAUNCH(1, 1);
-  else if (kw == 2 && mode == 0) KMX_LAUNCH(2, 0);
-  else if (kw == 2 && mode == 1) KMX_LAUNCH(2, 1);
-  else if (kw == 3 && mode == 0) KMX_LAUNCH(3, 0);
-  else if (kw == 3 && mode == 1) KMX_LAUNCH(3, 1);
-  else if (kw == 4 && mode == 0) KMX_LAUNCH(4, 0);
-  else if (kw == 4 && mode == 1) KMX_LAUNCH(4, 1);
+  if (kw == 1 && mode == 0) KMX_LAUNCH(1, 0, false);
+  else if (kw == 1 && mode == 1) KMX_LAUNCH(1, 1, false);
+  else if (kw == 2 && mode == 0) KMX_LAUNCH(2, 0, false);
+  else if (kw == 2 && mode == 1) KMX_LAUNCH(2, 1, false);
+  else if (kw == 3 && mode == 0 && rows_big(3, max_n)) KMX_LAUNCH(3, 0, true);
+  else if (kw == 3 && mode == 1 && rows_big(3, max_n)) KMX_LAUNCH(3, 1, true);
+  else if (kw == 4 && mode == 0 && rows_big(4, max_n)) KMX_LAUNCH(4, 0, true);
+  else if (kw == 4 && mode == 1 && rows_big(4, max_n)) KMX_LAUNCH(4, 1, true);
+  else if (kw == 3 && mode == 0) KMX_LAUNCH(3, 0, false);
+  else if (kw == 3 && mode == 1) KMX_LAUNCH(3, 1, false);
+  else if (kw == 4 && mode == 0) KMX_LAUNCH(4, 0, false);
+  else if (kw == 4 && mode == 1) KMX_LAUNCH(4, 1, false);
   else return hipErrorInvalidValue;
 #undef KMX_LAUNCH
   return hipGetLastError();

@@ -125,12 +125,31 @@ def test_synthetic_wide_key_rows(ctx, merge_kernel, case, mode, kw, k):
     check(ctx, lists, kw, [smin + (i % 2) for i in range(n)], rmin, share, mode)
 
 
+@pytest.mark.parametrize("case", [(2500, 60, 0.9, 2, 2, 2, 3), (2049, 30, 0.97, 1, 1, 1, 0), (4096, 12, 0.9, 1, 3, 40, 100)])
+@pytest.mark.parametrize("mode", [orc.MODE_COUNT, orc.MODE_PA])
+@pytest.mark.parametrize("kw,k", [(3, 80), (3, 96), (4, 97), (4, 127)])
+def test_wide_keys_beyond_2048_lists(ctx, case, mode, kw, k):
+    """keys of three and four words (k = 65 ... 127: Kmer<96> / Kmer<128>, the reference's KMER_LIST "32 64 96 128") on cohorts of more than
+    2048 samples -- configs[3]'s 2500 at k = 80: the builds of k_merge_rows<3|4> with 4096 / 3072 record slots a tile; rescue and
+    recurrence as everywhere"""
+    n, pool, pp, npriv, smin, rmin, share = case
+    n = min(n, 4096 if kw == 3 else 3072)
+    lists = synth_lists(17 * k + n, n, pool, pp, npriv, kw=kw, key_bits=2 * k)
+    check(ctx, lists, kw, [smin + (i % 2) for i in range(n)], rmin, share, mode)
+    mixed = lists[:300]      # the same context, a task below the limit afterwards: the half-tile build again
+    check(ctx, mixed, kw, [smin] * 300, min(rmin, 2), 0, mode)
+
+
 def test_wide_key_limits_fail_loudly(ctx):
-    """2048 lists per task with keys of three or four words (half a tile's record slots), refused beyond; Bloom modes take hash keys"""
+    """4096 lists per task with keys of three words, 3072 with four (the staged keys of 4096 would be 128 of the 160 KB), refused beyond;
+    Bloom modes take hash keys"""
     from kmtricks_amd import lib
-    lists = [(np.zeros((0, 3), np.uint64), np.zeros(0, np.uint32)) for _ in range(2049)]
-    with pytest.raises(lib.KmxError, match="2048 lists"):
-        ctx.merge(lists, 3, [1] * 2049, 1, 0, orc.MODE_COUNT)
+    lists = [(np.zeros((0, 4), np.uint64), np.zeros(0, np.uint32)) for _ in range(3073)]
+    with pytest.raises(lib.KmxError, match="3072 lists"):
+        ctx.merge(lists, 4, [1] * 3073, 1, 0, orc.MODE_COUNT)
+    lists = [(np.zeros((0, 3), np.uint64), np.zeros(0, np.uint32)) for _ in range(4097)]
+    with pytest.raises(lib.KmxError, match="4096 lists"):
+        ctx.merge(lists, 3, [1] * 4097, 1, 0, orc.MODE_COUNT)
     with pytest.raises(lib.KmxError, match="key_words"):
         ctx.merge(lists[:2], 5, [1, 1], 1, 0, orc.MODE_COUNT)
 
