@@ -471,10 +471,7 @@ struct CountOut {
   bool dev() const { return lists != nullptr; }
 };
 
-template <int KW> struct WideKey { u64 w[KW]; };      // keys of three and four words (k = 65 ... 127), low word first
-template <typename KeyT> __device__ __forceinline__ u32 key_dword(const KeyT& k, u32 w) { return (u32)(k >> (32 * w)); }
-template <> __device__ __forceinline__ u32 key_dword<WideKey<3>>(const WideKey<3>& k, u32 w) { return (u32)(k.w[w >> 1] >> (32 * (w & 1))); }
-template <> __device__ __forceinline__ u32 key_dword<WideKey<4>>(const WideKey<4>& k, u32 w) { return (u32)(k.w[w >> 1] >> (32 * (w & 1))); }
+// (WideKey<3|4> -- keys of three and four words, k = 65 ... 127, low word first -- and key_dword: count_sort.hpp)
 
 template <typename KeyT>
 __global__ __launch_bounds__(256)
@@ -624,6 +621,20 @@ template <> void cs_launch_bucket_count<__uint128_t>(u32 TB, hipStream_t st, con
   hipLaunchKernelGGL((k_cs_sort<__uint128_t, 2048>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, lo, 0u);
   hipLaunchKernelGGL((k_cs_sort<__uint128_t, 4096>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, 2048u, 1u);
 }
+// (three- and four-word keys: up to 1024 keys a wave as well -- 96 / 128 registers of keys at 16 per lane, one wave per SIMD of a 256-thread
+//  workgroup has 512 --, the LDS sort for up to 2048 behind it; a larger bucket sends the call to wide_sort_count)
+template <int KW> static void cs_launch_bucket_count_wide(u32 TB, hipStream_t st, const WideKey<KW>* bkeys, const u32* boff, u32 hard_min, WideKey<KW>* tk, u32* tc, u32* nkept,
+                                                          unsigned long long* hist, u32* overflow)
+{
+  typedef WideKey<KW> K;
+  hipLaunchKernelGGL((k_cs_wave_sort<K, 8, 16>), dim3((TB + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, bkeys, boff, TB, 0u, (u32)CsCap<K>::cap,
+                     hard_min, tk, tc, nkept, hist, overflow);
+  hipLaunchKernelGGL((k_cs_sort<K, CsCap<K>::cap>), dim3(TB), dim3(CS_TPB), 0, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow, (u32)CS_WAVE_MAX, 1u);
+}
+template <> void cs_launch_bucket_count<WideKey<3>>(u32 TB, hipStream_t st, const WideKey<3>* bkeys, const u32* boff, u32 hard_min, WideKey<3>* tk, u32* tc, u32* nkept,
+                                                    unsigned long long* hist, u32* overflow) { cs_launch_bucket_count_wide<3>(TB, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow); }
+template <> void cs_launch_bucket_count<WideKey<4>>(u32 TB, hipStream_t st, const WideKey<4>* bkeys, const u32* boff, u32 hard_min, WideKey<4>* tk, u32* tc, u32* nkept,
+                                                    unsigned long long* hist, u32* overflow) { cs_launch_bucket_count_wide<4>(TB, st, bkeys, boff, hard_min, tk, tc, nkept, hist, overflow); }
 __global__ void k_hist_add(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst)
 {
   if (threadIdx.x < 258 && src[threadIdx.x]) atomicAdd(&dst[threadIdx.x], src[threadIdx.x]);
@@ -646,7 +657,7 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
     if (nb > (u64)CS_MAXB || nb * 4 > (u64)CsCap<KeyT>::sample) return 1;      // a partition beyond the bucket / sample limits: the library sort takes the batch
     parts[p] = CsPart{(u32)kmoff[p], (u32)n, TB, (u32)nb};
     TB += (u32)nb;
-    for (u64 o = 0; o < n; o += CS_CHUNK) chunks.push_back(CsChunk{p, (u32)(kmoff[p] + o), (u32)std::min<u64>(CS_CHUNK, n - o), 0});
+    for (u64 o = 0; o < n; o += cs_chunk<KeyT>()) chunks.push_back(CsChunk{p, (u32)(kmoff[p] + o), (u32)std::min<u64>(cs_chunk<KeyT>(), n - o), 0});
   }
   hipStream_t st = ctx->stream;
   std::vector<void*> blocks;
@@ -663,7 +674,8 @@ static int partition_sort_count(kmx_ctx* ctx, StageClock& clk, KeyT* d_keys, con
   u8* d_tab = (u8*)dal(tab_bytes + 16);
   CsPart* d_parts = (CsPart*)d_tab;
   CsChunk* d_chunks = (CsChunk*)(d_tab + sizeof(CsPart) * n_parts);
-  KeyT* d_spl = (KeyT*)dal(sizeof(KeyT) * (size_t)TB);
+  typedef typename CsSpl<KeyT>::type SplT;      // (wide keys: their two most significant words)
+  SplT* d_spl = (SplT*)dal(sizeof(SplT) * (size_t)TB);
   u32* d_cnt = (u32*)dal(4 * ((size_t)TB + 1)), *d_boff = (u32*)dal(4 * ((size_t)TB + 1)), *d_cur = (u32*)dal(4 * ((size_t)TB + 1));
   u32* d_nkept = (u32*)dal(4 * ((size_t)TB + 1)), *d_koff = (u32*)dal(4 * ((size_t)TB + 2));
   KeyT* d_bkeys = (KeyT*)dal(sizeof(KeyT) * total);
@@ -984,7 +996,17 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
   clk.mark("decode");
   int rc;
   // partition-local sample sort / hash count first (count_sort.hpp); the library sort when a bucket is beyond it
-  if (!hash_mode && kw > 2) { rc = wide_sort_count(ctx, clk, (const u64*)d_keys, kw, kmoff, n_parts, (u32)total, hard_min, co); release(); return rc; }
+  if (!hash_mode && kw > 2) {
+    // (round 5: the same sample sort as below with keys of 24 / 32 bytes; a bucket beyond its LDS sort, KMX_COUNT_SORT=library: word by word)
+    rc = kw == 3 ? partition_sort_count<WideKey<3>>(ctx, clk, (WideKey<3>*)d_keys, kmoff, n_parts, hard_min, co)
+                 : partition_sort_count<WideKey<4>>(ctx, clk, (WideKey<4>*)d_keys, kmoff, n_parts, hard_min, co);
+    if (rc == 1) {
+      if (!co.dev()) for (u32 p = 0; p < n_parts; p++) { free(co.keys[p]); free(co.counts[p]); co.keys[p] = nullptr; co.counts[p] = nullptr; co.n_out[p] = 0; }
+      rc = wide_sort_count(ctx, clk, (const u64*)d_keys, kw, kmoff, n_parts, (u32)total, hard_min, co);
+    }
+    release();
+    return rc;
+  }
   if (hash_mode || kw == 1) rc = partition_sort_count<u64>(ctx, clk, (u64*)d_keys, kmoff, n_parts, hard_min, co);
   else rc = partition_sort_count<__uint128_t>(ctx, clk, (__uint128_t*)d_keys, kmoff, n_parts, hard_min, co);
   if (rc == 1) {

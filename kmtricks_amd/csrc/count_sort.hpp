@@ -27,20 +27,58 @@ namespace kmx {
 
 constexpr int CS_TPB = 256;
 constexpr int CS_WALK_TPB = 1024;
-constexpr int CS_CHUNK = 16 * CS_WALK_TPB;  // keys per workgroup in the count / scatter walks (a chunk holds ~11 keys per bucket of a partition cut into 1500: the pieces the scatter writes)
+constexpr int CS_CHUNK = 16 * CS_WALK_TPB;  // (one- and two-word keys; cs_chunk<K>() below)  // keys per workgroup in the count / scatter walks (a chunk holds ~11 keys per bucket of a partition cut into 1500: the pieces the scatter writes)
 constexpr int CS_MAXB = 2048;             // buckets per partition (partitions of up to ~1 M keys; beyond: the library sort)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "count_sort.hpp is written for gfx950 (MI355X): 160 KB of LDS per workgroup (k_cs_splitters: 128 KB), v_permlane16_swap / v_permlane32_swap"
 #endif
-template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 16384; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (16384 x 8 B or 8192 x 16 B = 128 KB of LDS in k_cs_splitters)
-template <> struct CsCap<__uint128_t> { static constexpr int cap = 4096, sample = 8192; };      // (cap: 64 + 16 KB of LDS in k_cs_sort, which only sees the buckets the wave kernel leaves)
+// keys of three and four words (k = 65 ... 127: Kmer<96> / Kmer<128>), low word first, compared most significant word first -- round 5:
+// they take the same kernels as the one- and two-word keys (before: the library's radix sort word by word, kw * 8 + 1 passes over the batch)
+template <int KW> struct WideKey { u64 w[KW]; };
+template <int KW> __host__ __device__ __forceinline__ bool operator<(const WideKey<KW>& a, const WideKey<KW>& b)
+{
+  bool lt = false, eq = true;
+#pragma unroll
+  for (int i = KW - 1; i >= 0; i--) { lt = lt || (eq && a.w[i] < b.w[i]); eq = eq && a.w[i] == b.w[i]; }
+  return lt;
+}
+template <int KW> __host__ __device__ __forceinline__ bool operator==(const WideKey<KW>& a, const WideKey<KW>& b)
+{
+  bool eq = true;
+#pragma unroll
+  for (int i = 0; i < KW; i++) eq = eq && a.w[i] == b.w[i];
+  return eq;
+}
+template <int KW> __host__ __device__ __forceinline__ bool operator!=(const WideKey<KW>& a, const WideKey<KW>& b) { return !(a == b); }
+template <int KW> __host__ __device__ __forceinline__ bool operator>(const WideKey<KW>& a, const WideKey<KW>& b) { return b < a; }
+template <int KW> __host__ __device__ __forceinline__ bool operator<=(const WideKey<KW>& a, const WideKey<KW>& b) { return !(b < a); }
+// dword w of a key (its record's layout: low dword first)
+template <typename K> __device__ __forceinline__ u32 key_dword(const K& k, u32 w) { return (u32)(k >> (32 * w)); }
+template <> __device__ __forceinline__ u32 key_dword<WideKey<3>>(const WideKey<3>& k, u32 w) { return (u32)(k.w[w >> 1] >> (32 * (w & 1))); }
+template <> __device__ __forceinline__ u32 key_dword<WideKey<4>>(const WideKey<4>& k, u32 w) { return (u32)(k.w[w >> 1] >> (32 * (w & 1))); }
+
+// what the splitters of a key type are: the key itself, or -- wide keys -- its two most significant words (the first 64 bases: a
+// partition's k-mers hardly ever share them, equal keys share them by definition, and 8192 samples of 16 bytes fit the LDS)
+template <typename K> struct CsSpl { typedef K type; static __device__ __forceinline__ K top(const K& k) { return k; } };
+template <int KW> struct CsSpl<WideKey<KW>> {
+  typedef __uint128_t type;
+  static __device__ __forceinline__ __uint128_t top(const WideKey<KW>& k) { return ((__uint128_t)k.w[KW - 1] << 64) | k.w[KW - 2]; }
+};
+
+// walk: keys a thread of the count / scatter walks holds (1024 threads: 128 registers each)
+template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 16384, walk = 16; };            // keys of a bucket that fit the sort's LDS; keys sampled per partition (16384 x 8 B or 8192 x 16 B = 128 KB of LDS in k_cs_splitters)
+template <> struct CsCap<__uint128_t> { static constexpr int cap = 4096, sample = 8192, walk = 16; };
+template <int KW> struct CsCap<WideKey<KW>> { static constexpr int cap = 2048, sample = 8192, walk = 8; };      // (cap: 48 / 64 + 8 KB in k_cs_sort; sample: of CsSpl's 16-byte tops)      // (cap: 64 + 16 KB of LDS in k_cs_sort, which only sees the buckets the wave kernel leaves)
 constexpr u32 CS_WAVE_MAX = 1024;         // keys of a bucket that one wave sorts in registers (16 per lane)
 template <typename K> __host__ __device__ inline u32 cs_target() { return CS_WAVE_MAX / 2; }      // aimed bucket size (a bucket may come out twice that and stay with the wave kernel, 4-8x and stay in LDS)
 
+template <typename K> __host__ __device__ constexpr u32 cs_chunk() { return (u32)CsCap<K>::walk * (u32)CS_WALK_TPB; }
 struct CsPart { u32 key0, nkeys, bucket0, nb; };      // a partition's keys [key0, key0 + nkeys), its buckets [bucket0, bucket0 + nb)
 struct CsChunk { u32 part, key0, nkeys, pad; };
 
 template <typename K> __device__ __forceinline__ K cs_max() { return ~(K)0; }
+template <> __device__ __forceinline__ WideKey<3> cs_max<WideKey<3>>() { return WideKey<3>{{~0ULL, ~0ULL, ~0ULL}}; }
+template <> __device__ __forceinline__ WideKey<4> cs_max<WideKey<4>>() { return WideKey<4>{{~0ULL, ~0ULL, ~0ULL, ~0ULL}}; }
 
 // ---- bitonic sort of P keys in LDS (P a power of two, pads = cs_max).  Steps between keys less than 128 apart stay inside a
 //      wave: it holds a chunk of 128 keys in registers, two per lane, and exchanges them with lane shuffles -- no workgroup
@@ -52,12 +90,30 @@ template <> __device__ __forceinline__ __uint128_t cs_shfl_xor<__uint128_t>(__ui
   const u64 lo = (u64)__shfl_xor((unsigned long long)(u64)k, m), hi = (u64)__shfl_xor((unsigned long long)(u64)(k >> 64), m);
   return ((__uint128_t)hi << 64) | lo;
 }
+template <int KW> __device__ __forceinline__ WideKey<KW> cs_shfl_xor_wide(const WideKey<KW>& k, int m)
+{
+  WideKey<KW> r;
+#pragma unroll
+  for (int i = 0; i < KW; i++) r.w[i] = (u64)__shfl_xor((unsigned long long)k.w[i], m);
+  return r;
+}
+template <> __device__ __forceinline__ WideKey<3> cs_shfl_xor<WideKey<3>>(WideKey<3> k, int m) { return cs_shfl_xor_wide<3>(k, m); }
+template <> __device__ __forceinline__ WideKey<4> cs_shfl_xor<WideKey<4>>(WideKey<4> k, int m) { return cs_shfl_xor_wide<4>(k, m); }
 // the key of lane ^ M, M a constant (kmx_dev.hpp: DPP moves and permlane swaps instead of ds_bpermute)
 template <typename K, int M> __device__ __forceinline__ K cs_xor(K k);
 template <typename K, int M> struct CsXor;
 template <int M> struct CsXor<u64, M> { static __device__ __forceinline__ u64 get(u64 k) { return xor_lane_u64<M>(k); } };
 template <int M> struct CsXor<__uint128_t, M> {
   static __device__ __forceinline__ __uint128_t get(__uint128_t k) { return ((__uint128_t)xor_lane_u64<M>((u64)(k >> 64)) << 64) | xor_lane_u64<M>((u64)k); }
+};
+template <int KW, int M> struct CsXor<WideKey<KW>, M> {
+  static __device__ __forceinline__ WideKey<KW> get(const WideKey<KW>& k)
+  {
+    WideKey<KW> r;
+#pragma unroll
+    for (int i = 0; i < KW; i++) r.w[i] = xor_lane_u64<M>(k.w[i]);
+    return r;
+  }
 };
 template <typename K, int J>
 __device__ __forceinline__ void cs_chunk_step(K (&k)[2], u32 base, u32 lane, u32 k2)      // steps J .. 1
@@ -131,10 +187,11 @@ __device__ __forceinline__ void cs_sort_lds(K* s, u32 P, u32 tid)
 constexpr int CS_SPL_TPB = 1024;          // (a workgroup per partition: few of them for few large partitions -- the sort of the samples is the kernel's time)
 template <typename K>
 __global__ __launch_bounds__(CS_SPL_TPB)
-void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, K* __restrict__ splitters)
+void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, typename CsSpl<K>::type* __restrict__ splitters)
 {
+  typedef typename CsSpl<K>::type S_t;
   constexpr u32 SMAX = (u32)CsCap<K>::sample;
-  __shared__ K sm[SMAX];
+  __shared__ S_t sm[SMAX];
   const CsPart P = parts[blockIdx.x];
   if (P.nb <= 1) return;
   const u32 tid = threadIdx.x;
@@ -143,10 +200,10 @@ void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts
   //  twice -- a genome given twice, paired files -- are the same keys twice, half as many samples as it looks)
   for (u32 i = tid; i < S; i += CS_SPL_TPB) {
     const u32 lo = (u32)(((u64)i * P.nkeys) / S), hi = (u32)(((u64)(i + 1) * P.nkeys) / S);
-    sm[i] = keys[P.key0 + lo + (hi > lo ? (i * 2654435761u >> 7) % (hi - lo) : 0u)];
+    sm[i] = CsSpl<K>::top(keys[P.key0 + lo + (hi > lo ? (i * 2654435761u >> 7) % (hi - lo) : 0u)]);
   }
   __syncthreads();
-  cs_sort_lds<K, CS_SPL_TPB>(sm, S, tid);
+  cs_sort_lds<S_t, CS_SPL_TPB>(sm, S, tid);
   // bucket b holds the keys k with splitter[b - 1] <= k < splitter[b]
   for (u32 b = tid; b + 1 < P.nb; b += CS_SPL_TPB) splitters[(u64)P.bucket0 + b] = sm[(u32)(((u64)(b + 1) * S) / P.nb)];
 }
@@ -163,10 +220,12 @@ template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32
 //  of one store: 0.32 -> 0.36 ms for the 24 M k-mer sample -- the pieces are as small either way; not kept.)
 template <typename K, bool SCATTER>
 __global__ __launch_bounds__(CS_WALK_TPB)
-void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, const CsChunk* __restrict__ chunks, const K* __restrict__ splitters,
+void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, const CsChunk* __restrict__ chunks, const typename CsSpl<K>::type* __restrict__ splitters,
                u32* __restrict__ counts_or_cursor, K* __restrict__ out)
 {
-  __shared__ K spl[CS_MAXB];
+  typedef typename CsSpl<K>::type S_t;
+  constexpr int IPT = CsCap<K>::walk;      // (the chunks are cut to IPT * CS_WALK_TPB keys by the host: cs_chunk<K>())
+  __shared__ S_t spl[CS_MAXB];
   __shared__ u32 hist[CS_MAXB];
   __shared__ u32 base[CS_MAXB];
   const CsChunk C = chunks[blockIdx.x];
@@ -174,19 +233,19 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   const u32 tid = threadIdx.x;
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
   __syncthreads();
-  K k[CS_CHUNK / CS_WALK_TPB]; u32 bk[CS_CHUNK / CS_WALK_TPB], rk[CS_CHUNK / CS_WALK_TPB];
+  K k[IPT]; u32 bk[IPT], rk[IPT];
 #pragma unroll
-  for (int x = 0; x < CS_CHUNK / CS_WALK_TPB; x++) {
+  for (int x = 0; x < IPT; x++) {
     const u32 i = tid + x * CS_WALK_TPB;
     bk[x] = 0xFFFFFFFFu;
-    if (i < C.nkeys) { k[x] = keys[C.key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<K>(spl, P.nb, k[x]) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
+    if (i < C.nkeys) { k[x] = keys[C.key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
   }
   __syncthreads();
   if (!SCATTER) { for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) if (hist[b]) atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]); return; }
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) base[b] = hist[b] ? atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]) : 0u;
   __syncthreads();
 #pragma unroll
-  for (int x = 0; x < CS_CHUNK / CS_WALK_TPB; x++) if (bk[x] != 0xFFFFFFFFu) out[base[bk[x]] + rk[x]] = k[x];
+  for (int x = 0; x < IPT; x++) if (bk[x] != 0xFFFFFFFFu) out[base[bk[x]] + rk[x]] = k[x];
 }
 
 // exclusive scan of n u32 values (n <= a few 100 k): one workgroup, 1024 threads; out[n] = total.  What the caller would otherwise
@@ -200,12 +259,22 @@ void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (u32 t0 = 0; t0 < n; t0 += 4096u) {      // tiles of 4 consecutive values per thread: coalesced both ways
-    const u32 i = t0 + tid * 4u;
-    u32 v[4];
+  // tiles of 16 consecutive values per thread (round 5; 4 before: the kernel is one workgroup whose tiles follow each other at the
+  // latency of their loads -- 12 of them for a sample's 48 k buckets, 33 us; now 3)
+  constexpr u32 VPT = 16;
+  for (u32 t0 = 0; t0 < n; t0 += 1024u * VPT) {
+    const u32 i = t0 + tid * VPT;
+    u32 v[VPT];
+    if (i + VPT <= n && ((uintptr_t)in & 15u) == 0) {
 #pragma unroll
-    for (int x = 0; x < 4; x++) v[x] = i + x < n ? in[i + x] : 0u;
-    const u32 s = v[0] + v[1] + v[2] + v[3];
+      for (u32 x = 0; x < VPT; x += 4) { const uint4 q = *reinterpret_cast<const uint4*>(in + i + x); v[x] = q.x; v[x + 1] = q.y; v[x + 2] = q.z; v[x + 3] = q.w; }
+    } else {
+#pragma unroll
+      for (u32 x = 0; x < VPT; x++) v[x] = i + x < n ? in[i + x] : 0u;
+    }
+    u32 s = 0;
+#pragma unroll
+    for (u32 x = 0; x < VPT; x++) s += v[x];
     const u32 incl = wave_incl_scan(s, (int)lane);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -213,7 +282,7 @@ void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __
 #pragma unroll
     for (u32 w = 0; w < 16; w++) { const u32 x = wsum[w]; if (w < wave) a += x; tot += x; }
 #pragma unroll
-    for (int x = 0; x < 4; x++) { if (i + x < n) { out[i + x] = a; if (out2) out2[i + x] = a; } a += v[x]; }
+    for (u32 x = 0; x < VPT; x++) { if (i + x < n) { out[i + x] = a; if (out2) out2[i + x] = a; } a += v[x]; }
     __syncthreads();
     if (tid == 0) carry_s += tot;
     __syncthreads();
@@ -429,6 +498,16 @@ template <> __device__ __forceinline__ __uint128_t cs_shfl_up1<__uint128_t>(__ui
   return ((__uint128_t)hi << 64) | lo;
 }
 
+template <int KW> __device__ __forceinline__ WideKey<KW> cs_shfl_up1_wide(const WideKey<KW>& k)
+{
+  WideKey<KW> r;
+#pragma unroll
+  for (int i = 0; i < KW; i++) r.w[i] = (u64)__shfl_up((unsigned long long)k.w[i], 1);
+  return r;
+}
+template <> __device__ __forceinline__ WideKey<3> cs_shfl_up1<WideKey<3>>(WideKey<3> k) { return cs_shfl_up1_wide<3>(k); }
+template <> __device__ __forceinline__ WideKey<4> cs_shfl_up1<WideKey<4>>(WideKey<4> k) { return cs_shfl_up1_wide<4>(k); }
+
 // the network, a step per instantiation (stage K2, distance J): every register index is a constant
 template <typename K, int NPL, u32 K2, u32 J>
 __device__ __forceinline__ void cs_wave_net(K (&k)[NPL], u32 lane)
@@ -551,7 +630,7 @@ void k_cs_compact_recs(const K* __restrict__ tk, const u32* __restrict__ tc, con
     u32* o = reinterpret_cast<u32*>(out + (dst + i) * (u64)(sizeof(K) + 4));
     const K k = tk[src + i];
 #pragma unroll
-    for (u32 w = 0; w < KWD; w++) o[w] = (u32)(k >> (32 * w));
+    for (u32 w = 0; w < KWD; w++) o[w] = key_dword<K>(k, w);
     o[KWD] = tc[src + i];
   }
 }
