@@ -13,12 +13,14 @@ import orc
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60); ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--scale", type=int, default=1, help="times as many reads per case (partitions of many buckets)")
+ap.add_argument("--kmers", choices=["narrow", "wide", "all"], default="narrow", help="k <= 63, k = 64 ... 127 (keys of two to four words), or both")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 ctx = lib.Context(0)
 done = 0
 for case in range(a.cases):
-    k = int(rng.choice([12, 15, 20, 21, 27, 31, 32, 33, 40, 47, 55, 63]))
+    ks = ([12, 15, 20, 21, 27, 31, 32, 33, 40, 47, 55, 63] if a.kmers != "wide" else []) + ([64, 65, 80, 95, 96, 97, 111, 127] if a.kmers != "narrow" else [])
+    k = int(rng.choice(ks))
     m = int(rng.integers(4, min(15, k) + 1)) if k < 20 else int(rng.choice([7, 8, 10, 11, 12]))
     P = int(rng.choice([1, 2, 3, 8, 16, 37, 64, 256]))
     hard_min = int(rng.choice([1, 1, 2, 3]))
