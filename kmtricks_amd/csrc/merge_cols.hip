@@ -821,8 +821,11 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 //        4. a directory entry per (group, pass) says where they are: the rows of a task are the row keys' rows (row r = row key r)
 //           and these, each list ascending; k_cols_gather interleaves them when the body is asked for.
 //      Groups with many entries are done in 2..8 passes split by hash bits (equal keys meet in the same pass). ----
-#ifndef KMX_CK_TPB
-#define KMX_CK_TPB 512
+#ifndef KMX_CK_TPB0
+#define KMX_CK_TPB0 256
+#endif
+#ifndef KMX_CK_TPB1
+#define KMX_CK_TPB1 512
 #endif
 #ifndef KMX_CK_Z
 #define KMX_CK_Z 16
@@ -830,14 +833,17 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 #ifndef KMX_CK_OCC1
 #define KMX_CK_OCC1 4
 #endif
-constexpr int CK_TPB = KMX_CK_TPB;
+// threads per workgroup of k_cols_sparse, by the rows' kind.  Count rows (4 N bytes each): 256, two workgroups per CU -- a group costs its
+// workgroup four dependent round trips (ticket, descriptor, slices, look-back) and a sort before it writes a byte, and the second workgroup's
+// stores fill that time: configs[2] in file order 2.68 -> 2.49 ms (round 5; with 128-VGPR workgroups of 512 it was 3.3).  PA rows: 512 --
+// their time is the candidates' sort, which half the threads run twice as long (configs[4]: 2.51 -> 2.78 ms with 256).
+template <int MODE> __host__ __device__ constexpr int ck_tpb() { return MODE == 0 ? KMX_CK_TPB0 : KMX_CK_TPB1; }
 constexpr int CK_Z = KMX_CK_Z;           // workgroups sharing the slice groups of a range
 constexpr int CK_SPEC = KW == 1 ? 5 : 4;               // entries per thread requested together with the slice's count
 constexpr int CK_CAND = 2048;            // candidates per pass (32 or 48 KB of LDS with their payloads)
 constexpr int CK_B2 = 1 << 15;           // bits of the candidate map
 constexpr int CK_NPASS = 8;              // directory entries per group
 constexpr int CK_UNI = CK_BITS / 8 + CK_B2 / 8;      // bytes of the LDS block that is the key maps while candidates are chosen and the rows' staging once they are sorted
-constexpr int CK_STAGE = CK_UNI / (CK_TPB / 64);     // ... a wave's part of it (2560 bytes: 32 PA rows of 500 lists and a 128-bit key)
 
 struct SpDir { u32 base, n, dense_first, dense_n; };      // rows [base, base + n) of the arena: a pass's rows; dense_* filled in entry 0 of a group
 
@@ -873,6 +879,7 @@ __device__ __forceinline__ void ck_chunk_steps(CKey (&k)[2], u64 (&p)[2], u32 ba
     }
   }
 }
+template <int CK_TPB>
 __device__ __forceinline__ void ck_sort_block(CKey* ck, u64* cp, u32 P, u32 tid)      // P: a power of two >= 128, pads = ck_inf()
 {
   const u32 lane = tid & 63u, wave = tid >> 6;
@@ -945,9 +952,13 @@ __device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mi
 // aside there, interleaved by key -- are one contiguous run of the body; the group's place comes from the look-back above.  A
 // group of several passes counts its rows first (every pass sorted once without writing), publishes, and sorts again to write.
 template <int MODE, bool RESC, bool ORD>
-__global__ __launch_bounds__(CK_TPB, MODE == 1 ? KMX_CK_OCC1 : ORD ? 2 : 3)      // (PA rows: <= 128 VGPRs, two workgroups per CU; count rows are bound by their stores: one workgroup per CU either way, and the ORD build keeps four row keys' rows per wave in flight)
+__global__ __launch_bounds__(ck_tpb<MODE>(), MODE == 1 ? KMX_CK_OCC1 : ORD ? 2 : 3)      // (waves per SIMD.  PA rows: <= 128 VGPRs, two workgroups of 512 per CU; count rows: two workgroups of 256, the ORD build with 234 VGPRs -- it keeps four row keys' rows per wave in flight)
 void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__ cols, const uint2* __restrict__ items, u32 n_items, u32 n_tasks, u32* tkt)
 {
+  constexpr int CK_TPB = ck_tpb<MODE>();
+  constexpr u32 CK_TS = CK_TPB >= 512 ? 4 : 2;         // threads per slice of a group when every slice has its threads at once (<= 128 slices)
+  constexpr int CK_PTM = CK_CAND / CK_TPB;             // sorted candidates per thread, at most
+  constexpr int CK_STAGE = CK_UNI / (CK_TPB / 64);     // a wave's part of the staging block (512 threads: 2560 bytes: 32 PA rows of 500 lists and a 128-bit key)
   __shared__ __attribute__((aligned(16))) u32 uni[CK_UNI / 4];      // the key maps | the row keys and interval counters (recurrence-min 1) | the rows' staging
   u32* const bits = uni;
   u32* const bits2 = uni + CK_BITS / 32;
@@ -988,7 +999,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     const u32 thr = RESC ? T.rec_min : max(1u, T.rec_min), share = RESC ? T.share_min : 0u, rt = C.rt, nsl = C.nblk * CL_NW, row_bytes = T.row_bytes;
     const u32 slot0 = (s_lo / rt + range) * CL_HALVES;
     SpDir* const dir = reinterpret_cast<SpDir*>(C.spdir);
-    const bool single = nsl <= (u32)CK_TPB / 4;
+    const bool single = nsl <= (u32)CK_TPB / CK_TS;
     const u64 sbase = (u64)(slot0 + q) * nsl;
     const u32 gid = slot0 + q;
     auto hand_back = [&](int why) { if (tid == 0) { atomicOr(&T.ctrl[2], (u64)ERR_FALLBACK); atomicAdd(&kmx_cols_dbg[why], 1u); } };
@@ -1005,7 +1016,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     u32 n0 = 0; CKey kk0[CK_SPEC]; u64 pp0[CK_SPEC];
     const u64* kp0 = C.ovkeys; const u64* kpx0 = C.ovx;
     if (single) {
-      const u32 sl = tid >> 2, sub = tid & 3u;
+      const u32 sl = tid / CK_TS, sub = tid % CK_TS;
       const bool ok = sl < nsl;
       const uint2 ce = ok ? reinterpret_cast<const uint2*>(C.ovcnt)[sbase + sl] : make_uint2(0u, 0u);
       const u32 nraw = ce.x, xb = ce.y;                                 // the slice's entries, and its extension if it has one
@@ -1013,7 +1024,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       const u32 lim0 = xb ? (u32)(CL_OVW + CL_XS) : (u32)CL_OVW;
       kp0 = C.ovkeys + (sbase + (ok ? sl : 0u)) * CL_OVW * EW;
 #pragma unroll
-      for (int x = 0; x < CK_SPEC; x++) { kk0[x] = ent_key(kp0, sub + 4 * x); pp0[x] = kp0[EW * (sub + 4 * x) + KW]; }
+      for (int x = 0; x < CK_SPEC; x++) { kk0[x] = ent_key(kp0, sub + CK_TS * x); pp0[x] = kp0[EW * (sub + CK_TS * x) + KW]; }
       n0 = min(nraw, lim0);
       if (nraw > lim0) sover = 1;
       if (sub == 0 && nraw) atomicAdd(&total, nraw);
@@ -1049,11 +1060,11 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     // each of my entries of the pass in hand through f(key, payload): four threads per slice
     auto each = [&](auto&& in_pass, auto&& f) {
       if (single) {
-        const u32 sub = tid & 3u;
+        const u32 sub = tid % CK_TS;
 #pragma unroll
         for (int x = 0; x < CK_SPEC; x++)
-          if (sub + 4 * x < n0 && in_pass(kk0[x])) f(kk0[x], pp0[x]);
-        for (u32 e = sub + 4 * CK_SPEC; e < n0; e += 4) {
+          if (sub + CK_TS * x < n0 && in_pass(kk0[x])) f(kk0[x], pp0[x]);
+        for (u32 e = sub + CK_TS * CK_SPEC; e < n0; e += CK_TS) {
           const u64* const kp = e < (u32)CL_OVW ? kp0 : kpx0; const u32 ee = e < (u32)CL_OVW ? e : e - (u32)CL_OVW;      // (the slice, then its extension)
           const CKey k = ent_key(kp, ee);
           if (!in_pass(k)) continue;
@@ -1137,7 +1148,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
           const u32 stride = (nc1 + NS - 1) / NS, ns = stride ? (nc1 + stride - 1) / stride : 0u, SP = ns <= 128u ? 128u : 256u;
           for (u32 t = tid; t < SP; t += CK_TPB) { sk[t] = t < ns ? ck[t * stride] : ck_inf(); sp[t] = t < ns ? cp[t * stride] : ~0ULL; }      // (key AND payload: a key that hundreds of lists hold is cut into intervals like any other stretch)
           __syncthreads();
-          ck_sort_block(sk, sp, SP, tid);
+          ck_sort_block<CK_TPB>(sk, sp, SP, tid);
           CKey mk[PER]; u64 mp[PER]; u32 mb[PER], mo[PER];
 #pragma unroll
           for (int x = 0; x < PER; x++) {
@@ -1222,17 +1233,18 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
         u32 P = 128; while (P < nc) P <<= 1;
         for (u32 t = nc + tid; t < P; t += CK_TPB) { ck[t] = ck_inf(); cp[t] = ~0ULL; }      // (pads: larger than any entry, the key of all ones included)
         __syncthreads();
-        ck_sort_block(ck, cp, P, tid);
+        ck_sort_block<CK_TPB>(ck, cp, P, tid);
       }
       SPPH(4);
       // kept runs: first entry of a run of >= thr equal keys (entries of one key come from different lists).  RESC: of >= thr SOLID
       // entries -- the payload sorts a key's non-solid entries behind its solid ones, so entry i + thr - 1 of the run decides; and a
       // run with at least `share` solid entries has its non-solid ones rescued: their statistics here, for every run, kept or not
       // (merge.hpp:234-247), their counts in the row below
-      u32 mine = 0, km = 0, rl[4] = {0, 0, 0, 0};
-      const u32 pt = (nc + CK_TPB - 1) / CK_TPB;     // consecutive entries per thread (<= 4)
+      u32 mine = 0, km = 0, rl[CK_PTM];
+      const u32 pt = (nc + CK_TPB - 1) / CK_TPB;     // consecutive entries per thread (<= CK_PTM)
 #pragma unroll
-      for (u32 x = 0; x < 4; x++) {
+      for (u32 x = 0; x < (u32)CK_PTM; x++) {
+        rl[x] = 0;
         const u32 i = tid * pt + x;
         if (x < pt && i < nc) {
           const CKey k = ck[i];
@@ -1264,7 +1276,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       u32 rank = incl - mine, nk = 0;
       for (u32 w = 0; w < CK_TPB / 64; w++) { if (w < wave) rank += wsum[w]; nk += wsum[w]; }
 #pragma unroll
-      for (u32 x = 0; x < 4; x++) if ((km >> x) & 1u) runs[rank++] = rl[x];
+      for (u32 x = 0; x < (u32)CK_PTM; x++) if ((km >> x) & 1u) runs[rank++] = rl[x];
       return nk;      // (runs[] is complete behind the caller's next barrier)
     };
 
@@ -1861,10 +1873,10 @@ static hipError_t launch_cols_sparse_ord(const TaskDev* tasks, const ColsDev* co
   static int per_cu = 0;
   if (per_cu == 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_cols_sparse<MODE, RESC, true>), CK_TPB, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&k_cols_sparse<MODE, RESC, true>), ck_tpb<MODE>(), 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
     per_cu = n;
   }
-  hipLaunchKernelGGL((k_cols_sparse<MODE, RESC, true>), dim3(n_cu * (u32)per_cu), dim3(CK_TPB), 0, st, tasks, cols, (const uint2*)nullptr, 0u, n_tasks, ticket);
+  hipLaunchKernelGGL((k_cols_sparse<MODE, RESC, true>), dim3(n_cu * (u32)per_cu), dim3(ck_tpb<MODE>()), 0, st, tasks, cols, (const uint2*)nullptr, 0u, n_tasks, ticket);
   return hipGetLastError();
 }
 // mode: bit 0 = PA rows, bit 1 = the RESC build, bit 2 = rows at their final place (ORD: persistent, tickets from ticket[1])
@@ -1878,12 +1890,12 @@ hipError_t launch_cols_sparse(int mode, const TaskDev* tasks, const ColsDev* col
       default: return launch_cols_sparse_ord<1, true>(tasks, cols, n_tasks, ticket, n_cu, st);
     }
   }
-  const dim3 grid(n_items, CK_Z), block(CK_TPB);
+  const dim3 grid(n_items, CK_Z), block(ck_tpb<0>()), block1(ck_tpb<1>());
   switch (mode & 3) {
     case 0: hipLaunchKernelGGL((k_cols_sparse<0, false, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
-    case 1: hipLaunchKernelGGL((k_cols_sparse<1, false, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
+    case 1: hipLaunchKernelGGL((k_cols_sparse<1, false, false>), grid, block1, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
     case 2: hipLaunchKernelGGL((k_cols_sparse<0, true, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
-    default: hipLaunchKernelGGL((k_cols_sparse<1, true, false>), grid, block, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
+    default: hipLaunchKernelGGL((k_cols_sparse<1, true, false>), grid, block1, 0, st, tasks, cols, range_items, n_items, n_tasks, ticket); break;
   }
   return hipGetLastError();
 }
