@@ -179,6 +179,9 @@ __device__ __forceinline__ u32 cl_mix(CKey key)
   x *= 0x85EBCA6Bu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 13;
   return x;
 }
+// (Round 5 tried four hashes at once -- a bit map of LDS per hash, a key sets its bit under each and sees whether it was set, the first
+//  hash nobody clashed under wins: k_merge_cols 2.29 -> 2.50 ms.  On real tiles the first or second cheap hash is collision free; four
+//  hashes' worth of work every time is more than the one or two tries below.)
 // wave 0: lane j holds row keys j, j + 64, ...  -> the hash, 0 when no try worked; slot[x] = entry of my key x
 __device__ __forceinline__ u32 cl_build(ClEnt* tab, const CKey (&key)[CL_KPL], const bool (&have)[CL_KPL], u32 lane, u32 (&slot)[CL_KPL])
 {
@@ -417,6 +420,10 @@ __device__ u64 kmx_sparse_prof[8];
 //  window slot, not its instructions: staged per lane in LDS and appended once per round they cost half as much as long as nothing
 //  overflows the stage, but every way of handling the overflow that was tried -- a branch per slot, per four slots, a second walk --
 //  gave it back in spilled registers around the loop, and the window's loads issued any later than they are cost more than all of it.)
+// (Also round 5, on the NAR build: two byte images in the image's room, a tile's image streamed out during the NEXT tile's walk -- right
+//  behind the walk's vmcnt(0), so that no later wait meets the stores -- instead of between two barriers of its own: correct, 2.29 ->
+//  2.37 ms, five registers spilled around the loop.  A walk skipped by the waves that have nothing below the tile's upper key in a
+//  further round: +-0, further rounds are rare.)
 // EXT: a wave whose set-aside slice is full claims an extension (cohorts with outlier samples; the plain build hands such a task
 // back and the context's next batches use this one: 1-2 % slower on cohorts that never need it)
 constexpr u64 CL_NONSOLID = 1ULL << 63;      // set-aside entry of a RESC build: the record is below its list's soft-min
@@ -581,6 +588,13 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
           for (int u = 0; u < CL_U; u++) consm |= (ck_lt(cl_key(rec[u]), khi) ? 1u : 0u) << u;      // (an empty slot holds the largest key)
         }
         asm volatile("" : "+v"(consm));      // one bit mask in a vector register, not 16 lane masks in scalar registers
+#if KMX_CL_KW == 1
+        // (the next tile's row keys, requested at the tile's start, have landed with the window: from here on they are plain registers.
+        //  Used where they were loaded, wave 0 met an s_waitcnt vmcnt(0) in front of its table build -- a wait for the window refills
+        //  requested in between, with fifteen waves at the barrier behind it: 2.30 -> 2.28 ms)
+#pragma unroll
+        for (int x = 0; x < CL_KPL; x++) asm volatile("" : "+v"(skn[x]));
+#endif
         CLPH(1);
 #pragma unroll
         for (int g = 0; g < CL_U; g += 4) {

@@ -17,10 +17,10 @@ import torch
 import bench
 from kmtricks_amd import lib, shard
 ctx = lib.Context(0); ctx.set_profiling(True)
-k = 31 if a.wl == "count" else 63
+k = 31 if a.wl == "count" else 63      # (count63: count rows with 128-bit keys)
 kw = (k + 31) // 32
-mode = lib.MODE_COUNT if a.wl == "count" else lib.MODE_PA
-rec_min = 2 if a.wl == "count" else 1
+mode = lib.MODE_COUNT if a.wl in ("count", "count63") else lib.MODE_PA
+rec_min = 2 if a.wl in ("count", "count63") else 1
 N = a.samples or (1000 if a.wl == "count" else 500)
 parts = shard.partitions_of_rank(a.parts, 1, 0)
 store, lists = bench.gen_counted(ctx, lib, N, k, 5_000_000, 0.001, 256, parts, 20240601, True)
