@@ -1019,6 +1019,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         C.gmap = reinterpret_cast<uint4*>(H.d_ov + H.o_spdir + 256 + ng * 8);
         C.gmax = reinterpret_cast<u32*>(R->d_meta + R->o_ticket) + 2;
         C.ngcap = (u32)ng;
+        // (ticket word 3: no task of the batch has room for more groups than this -- k_cols_sparse's tickets end there whatever word 2 says)
+        u32* const tk3 = reinterpret_cast<u32*>(R->h_meta + R->o_ticket) + 3;
+        *tk3 = std::max<u32>(*tk3, (u32)ng);
       }
       for (u32 j = 0; j < H.c * H.nblk; j++) citems[ci++] = make_uint2(t, j);   // y = range * nblk + block
     }

@@ -80,7 +80,7 @@ constexpr int CL_NW = CL_TPB / 64;
 constexpr int CK_BITS = 1 << 17;         // k_cols_sparse: bits of the key map (16 KB of LDS)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
 
-__device__ u32 kmx_cols_dbg[8];      // why tasks were handed back (KMX_TRACE=1 prints and clears them)
+__device__ u32 kmx_cols_dbg[16];     // why tasks were handed back (KMX_TRACE=1 prints and clears them); [8..11]: look-backs given up, the last one's task order / group / entries still to add
 
 namespace {
 
@@ -469,7 +469,9 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
     }
     const TaskDev& T = tasks[items[item].x];
     const ColsDev& C = cols[items[item].x];
-    if (__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) continue;
+    // (ONE decision per workgroup: the word is raised by other workgroups while this one reads it -- threads that saw it and threads that
+    //  did not went different ways through the barriers below, and a launch in a thousand took minutes: round 5, scripts/dev/stress_ord.py)
+    if (__syncthreads_or((__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) != 0)) continue;
     // (everything per work item is uniform; the readfirstlanes tell the compiler, which otherwise treats the tile loop's
     //  conditions as divergent and branches on them per window slot)
     const u32 N = cl_uni(T.N), row_bytes = cl_uni(T.row_bytes), nblk = cl_uni(C.nblk), nbs = cl_uni(C.nb), rt = cl_uni(C.rt);
@@ -935,9 +937,14 @@ constexpr u32 CK_OVF = 0xFFFFFFFFu;      // a pass found more candidates than th
 //      (status 1) as soon as it knows them -- before it waits for anything --, adds up its predecessors' entries backwards until it
 //      meets one that carries a whole prefix (status 2), and publishes its own prefix.  The holder of the lowest unfinished ticket
 //      never waits: no deadlock whatever the number of resident workgroups. ----
+// A look-back that meets an unpublished entry sleeps and looks again -- at most CK_LB_SPINS times (seconds; a whole launch is
+// milliseconds): then it gives up (returns ~0: the caller hands the task back to the general kernel and the chain goes on with a prefix
+// of 0), so that whatever keeps an entry from being published costs a task its fast path, not the launch its end.
+constexpr u32 CK_LB_SPINS = 1u << 20;
 __device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mine, const u32 lane)
 {
   constexpr u64 VAL = (1ULL << 62) - 1ULL;
+  u32 spins = 0;
   if (g == 0) { if (lane == 0) __hip_atomic_store(&chain[0], (2ULL << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
   if (lane == 0) __hip_atomic_store(&chain[g], (1ULL << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u64 excl = 0;
@@ -955,7 +962,16 @@ __device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mi
     excl += s;
     if (pm) break;
     i -= take;
-    if (take == 0) __builtin_amdgcn_s_sleep(8);
+    if (take == 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > CK_LB_SPINS) {
+        if (lane == 0) {
+          __hip_atomic_store(&chain[g], 2ULL << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicAdd(&kmx_cols_dbg[8], 1u); kmx_cols_dbg[10] = g; kmx_cols_dbg[11] = i;
+        }
+        return ~0ULL;
+      }
+    }
   }
   if (lane == 0) __hip_atomic_store(&chain[g], (2ULL << 62) | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return excl;
@@ -1647,6 +1663,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     __syncthreads();
     SPPH(5);
     if (failed) return false;
+    if (s_base == ~0ULL) { hand_back(2); return false; }      // (the look-back gave up: see ck_lookback)
     // (the task's row counters: behind the rows, where no barrier waits for the atomics -- the next one is the next ticket's)
     auto count_rows = [&]() { if (tid == 0 && nks) { atomicAdd(&T.ctrl[0], (u64)nks); atomicAdd(&T.ctrl[3], (u64)nks); atomicAdd(&T.ctrl[6], (u64)nks); } };
     const u64 base = s_base;
@@ -1672,7 +1689,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
     if (item < n_items) {
       const TaskDev& T = tasks[items[item].x];
       const ColsDev& C = cols[items[item].x];
-      if (!(T.ctrl[2] & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW))) {
+      if (!__syncthreads_or((__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) != 0)) {      // (one decision per workgroup: see k_merge_cols)
         const u32 range = items[item].y, rt = C.rt;
         const u32 s_lo = C.rbounds[range], s_hi = C.rbounds[range + 1];
         const u32 ngroups = max(1u, (s_hi - s_lo + rt - 1) / rt) * CL_HALVES;
@@ -1689,15 +1706,20 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       __syncthreads();
       const u32 t = s_tk;
       const u32 ti = t % n_tasks, g = t / n_tasks;
-      if (g >= tkt[2]) break;      // (k_cols_prep: the largest number of groups a task of the batch has)
+      if (g >= tkt[2] || g >= tkt[3]) {      // (k_cols_prep: the largest number of groups a task of the batch has; the host: the most any task has room for)
+        if (g < tkt[2] && tid == 0) atomicAdd(&kmx_cols_dbg[9], 1u);
+        break;
+      }
       const TaskDev& T = tasks[ti];
       const ColsDev& C = cols[ti];
       if (g >= C.ngcap) continue;
       // (the group's descriptor and the task's error word in one round trip: no branch between the two loads)
       const uint4 rq = C.gmap[g];
       const u64 terr = __hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (one decision per workgroup -- other workgroups raise the word while this one reads it: see k_merge_cols)
+      const bool dead = __syncthreads_or((terr & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) != 0) != 0;
       if (rq.x == 0) continue;      // (beyond the task's groups: the map is zeroed before every batch)
-      if (terr & (u64)(ERR_FALLBACK | ERR_ROWS_OVERFLOW)) {
+      if (dead) {
         // a task that is handed back anyway: nobody may wait for this group
         if (tid == 0) __hip_atomic_store(&C.chain[g], 2ULL << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         continue;
@@ -1812,8 +1834,10 @@ void k_cols_gather(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
 
 void cols_dbg_dump()
 {
-  u32 h[8];
+  u32 h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(kmx_cols_dbg), sizeof(h)) != hipSuccess) return;
+  if (h[9]) fprintf(stderr, "[kmx merge] k_cols_sparse: the group count of the batch was beyond every task's room (%u workgroups stopped at the room)\n", h[9]);
+  if (h[8]) fprintf(stderr, "[kmx merge] k_cols_sparse: %u look-backs given up (last: group %u, %u entries still unpublished in front of it)\n", h[8], h[10], h[11]);
   fprintf(stderr, "[kmx merge] k_merge_cols hand-back reasons: no collision-free row table %u, slice overflow %u (wave-tiles; largest %u, in a range's last tile %u, first tile %u), kept key outside the row keys %u, check table full %u, lists too divergent %u (tasks)\n", h[0], h[1], h[5], h[6], h[7], h[2], h[3], h[4]);
   memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(kmx_cols_dbg), h, sizeof(h));
 }

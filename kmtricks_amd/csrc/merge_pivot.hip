@@ -178,7 +178,7 @@ void k_merge_pivot(const TaskDev* __restrict__ tasks, const uint2* __restrict__ 
     const u32 chunk_rows = max(64u, (u32)KMX_CHUNK_BYTES / row_bytes);
     const u32 rows_cap = max(1u, min(32u, (u32)PV_IMG / row_bytes));      // image rows
     const u32 rt_cap = min((u32)PV_RTMAX, rows_cap);                      // pivot rows per tile; the rest is for adopted rows
-    if (__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)ERR_FALLBACK) continue;   // the batch is re-run anyway
+    if (__syncthreads_or((__hip_atomic_load(&T.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (u64)ERR_FALLBACK) != 0)) continue;   // the batch is re-run anyway (one decision per workgroup: the word is raised while it is read)
 
     // PV_G adjacent lanes per list; list p*PV_LPP + tid/PV_G in pass p
     const u32 npass = (N + PV_LPP - 1) / PV_LPP;

@@ -5,7 +5,8 @@ Prints the slowest launches and every one beyond 10x the median."""
 import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import argparse
+import argparse, faulthandler
+faulthandler.dump_traceback_later(75, repeat=True)
 ap = argparse.ArgumentParser()
 ap.add_argument("--wl", default="pa63"); ap.add_argument("--order", type=int, default=1); ap.add_argument("--fresh", type=int, default=1); ap.add_argument("--budget", type=float, default=240); ap.add_argument("--iters", type=int, default=150); ap.add_argument("--steps", type=int, default=8)
 a = ap.parse_args()
