@@ -154,6 +154,24 @@ def test_wide_key_limits_fail_loudly(ctx):
         ctx.merge(lists[:2], 5, [1, 1], 1, 0, orc.MODE_COUNT)
 
 
+def test_first_batches_of_fresh_contexts_in_file_order(merge_kernel):
+    """a context's first batches run with arenas it has to guess: tasks overflow them and are flagged WHILE other workgroups of the
+    same launch read the flag.  Before round 5's fix (one decision per workgroup, k_merge_cols / k_cols_sparse / k_merge_pivot) threads
+    of a workgroup that disagreed about the flag went different ways through its barriers and a first batch in ten took minutes
+    (scripts/dev/stress_ord.py at configs[4]'s size); here: several fresh contexts, PA and count rows of 128- and 64-bit keys, rows_hint 1 so
+    that the first attempt overflows, every result against the oracle (once per forced kernel: the fixture's environment reaches the contexts made here)"""
+    from kmtricks_amd import lib
+    lists2 = synth_lists(2024, 300, 4000, 0.9, 400, kw=2, key_bits=126)
+    lists1 = synth_lists(2025, 520, 3000, 0.9, 200, kw=1)
+    for it in range(4):
+        c = lib.Context(0)
+        try:
+            check(c, lists2, 2, [1] * 300, 1, 0, orc.MODE_PA, rows_hint=1)
+            check(c, lists1, 1, [1] * 520, 2, 0, orc.MODE_COUNT, rows_hint=1)
+        finally:
+            c.close()
+
+
 def test_sparse_many_distinct_per_tile(ctx):
     """few long lists: thousands of distinct keys per tile (slow ranking path)"""
     lists = synth_lists(5, 4, 20000, 0.3, 6000, kw=1)
