@@ -855,7 +855,11 @@ void k_merge_cols(const TaskDev* __restrict__ tasks, const ColsDev* __restrict__
 // their time is the candidates' sort, which half the threads run twice as long (configs[4]: 2.51 -> 2.78 ms with 256).
 template <int MODE> __host__ __device__ constexpr int ck_tpb() { return MODE == 0 ? KMX_CK_TPB0 : KMX_CK_TPB1; }
 constexpr int CK_Z = KMX_CK_Z;           // workgroups sharing the slice groups of a range
-constexpr int CK_SPEC = KW == 1 ? 5 : 4;               // entries per thread requested together with the slice's count
+#ifndef KMX_CK_SPEC2
+#define KMX_CK_SPEC2 (KW == 1 ? 7 : 4)      // (64-bit keys: 14 of a slice's usual ~14 entries in the first round trip -- with 5 the tail's second one cost 0.05 ms of configs[2]; 256 VGPRs, 32 bytes of scratch)
+#endif
+constexpr int CK_SPEC4 = KW == 1 ? 5 : 4;              // entries per thread requested together with the slice's count: four threads a slice ...
+constexpr int CK_SPEC2 = KMX_CK_SPEC2;                 // ... two threads a slice (workgroups of 256)
 constexpr int CK_CAND = 2048;            // candidates per pass (32 or 48 KB of LDS with their payloads)
 constexpr int CK_B2 = 1 << 15;           // bits of the candidate map
 constexpr int CK_NPASS = 8;              // directory entries per group
@@ -987,6 +991,7 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
 {
   constexpr int CK_TPB = ck_tpb<MODE>();
   constexpr u32 CK_TS = CK_TPB >= 512 ? 4 : 2;         // threads per slice of a group when every slice has its threads at once (<= 128 slices)
+  constexpr int CK_SPEC = CK_TS == 4 ? CK_SPEC4 : CK_SPEC2;
   constexpr int CK_PTM = CK_CAND / CK_TPB;             // sorted candidates per thread, at most
   constexpr int CK_STAGE = CK_UNI / (CK_TPB / 64);     // a wave's part of the staging block (512 threads: 2560 bytes: 32 PA rows of 500 lists and a 128-bit key)
   __shared__ __attribute__((aligned(16))) u32 uni[CK_UNI / 4];      // the key maps | the row keys and interval counters (recurrence-min 1) | the rows' staging
