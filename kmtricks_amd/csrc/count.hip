@@ -22,6 +22,7 @@
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include "skf.hpp"
 #include "count_sort.hpp"
 
 namespace kmx {
@@ -85,6 +86,7 @@ __device__ __forceinline__ u64 xxh64_words(const u64* w, int nw)
 // k-mers: the prefix entries of the records that hold them go to LDS (k_decode_block_starts found the first one), a lane finds its
 // record with a binary search there, and the keys leave as one coalesced store per wave.
 constexpr int DK = 1024;            // k-mers per workgroup (4 per thread)
+static_assert(DK == (int)SKF_DK, "k_sk_scatter names the first record of every block of DK k-mers");
 __global__ void k_decode_block_starts(const u64* __restrict__ prefix, u32 n_recs, u32* __restrict__ blk_first)
 {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,12 +104,14 @@ __device__ __forceinline__ u64 load8u(const u8* p) { u64 w; __builtin_memcpy(&w,
 template <int KW, int HASH, bool DIRECT>
 __global__ __launch_bounds__(256)
 void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ prefix, const u32* __restrict__ blk_first, const u16* __restrict__ rec_part,
-                           const u64* __restrict__ part_ids, u32 n_recs, u32 total, int k, u64 win, void* __restrict__ out, const u32* __restrict__ sbase)
+                           const u64* __restrict__ part_ids, u32 n_recs, u32 total, int k, u64 win, void* __restrict__ out, const u32* __restrict__ sbase,
+                           const SkfCtl* __restrict__ ctl = nullptr /* set: the sizes are the device's (the grid covers a bound) */)
 {
   __shared__ u64 pk[DK + 1];
   __shared__ u32 nrec_s;
   const u32 tid = threadIdx.x;
   const u32 g0 = blockIdx.x * DK;
+  if (ctl) { if (ctl->status) return; n_recs = ctl->nd; total = ctl->total; if (g0 >= total) return; }
   const u32 r0 = blk_first[blockIdx.x];
   const u32 avail = min((u32)DK + 1u, n_recs + 1u - r0);
   for (u32 t = tid; t < avail; t += 256) {
@@ -1127,6 +1131,76 @@ int kmx_count_from_device(kmx_ctx* ctx, const u8* d_recs, const u64* d_prefix, c
   if (rq.inner_parts && rq.hash_mode) { pid.resize(n_parts); for (u32 p = 0; p < n_parts; p++) pid[p] = p % rq.inner_parts; }      // (the window of p' = sample * inner + p is p's)
   std::vector<u64> kmoff(part_kmer_off, part_kmer_off + n_parts + 1);
   return decode_and_count(ctx, clk, d_recs, d_prefix, d_part, nr, total, n_parts, kmoff, pid, rq.k, rq.hash_mode, rq.window, rq.hard_min, co, d_sbase);
+}
+
+// ---- round 6: the count behind the sync-free split (superk_fast.hpp): the same kernels as decode_and_count + partition_sort_count,
+//      their sizes and tables read from the device (grids cover bounds, the surplus workgroups leave at once), nothing read back until
+//      the kept sizes are known -- then the lists are packed into the stores as before (compact_to_stores) ----
+kmx::SkfLayout kmx_fast_layout(int key_words)
+{
+  if (key_words <= 1) return SkfLayout{cs_target<u64>(), cs_chunk<u64>(), (u32)CS_MAXB, (u32)CsCap<u64>::sample};
+  return SkfLayout{cs_target<__uint128_t>(), cs_chunk<__uint128_t>(), (u32)CS_MAXB, (u32)CsCap<__uint128_t>::sample};
+}
+template <typename KeyT>
+static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F, const kmx_count_req& rq, const CountOut& co)
+{
+  typedef typename CsSpl<KeyT>::type SplT;
+  const u64 kb = F.kmer_bound; const u32 TBm = F.tb_max, P = F.n_parts;
+  hipStream_t st = ctx->stream; hipError_t e;
+  std::vector<void*> blocks;
+  auto dal = [&](size_t b) { void* p = ctx->dalloc(b); blocks.push_back(p); return p; };
+  auto release = [&]() { for (void* b : blocks) ctx->dfree(b); };
+  KeyT* d_keys = (KeyT*)dal(sizeof(KeyT) * kb), *d_bkeys = (KeyT*)dal(sizeof(KeyT) * kb), *d_tk = (KeyT*)dal(sizeof(KeyT) * kb);
+  u32* d_tc = (u32*)dal(4 * kb);
+  SplT* d_spl = (SplT*)dal(sizeof(SplT) * (size_t)TBm);
+  u32* d_boff = (u32*)dal(4 * ((size_t)TBm + 2)), *d_cur = (u32*)dal(4 * ((size_t)TBm + 2)), *d_nkept = (u32*)dal(4 * ((size_t)TBm + 2)), *d_koff = (u32*)dal(4 * ((size_t)TBm + 2));
+  u32* d_big = (u32*)dal(4 * (size_t)SKF_BIG_CAP);
+  u32* h_koff = (u32*)ctx->halloc(4 * ((size_t)TBm + 2));
+  struct HRel { kmx_ctx* c; void* p; ~HRel() { c->hfree(p); } } h_rel{ctx, h_koff};
+  bool ok = h_koff != nullptr;
+  for (void* b : blocks) ok = ok && b;
+  if (!ok) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
+  auto fail = [&](hipError_t er, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(er)); };
+  const CsPart* d_parts = reinterpret_cast<const CsPart*>(F.d_parts);
+  static_assert(sizeof(CsPart) == sizeof(uint4), "k_sk_scan writes the sample sort's partitions as uint4");
+  constexpr int KWD = sizeof(KeyT) == 8 ? 1 : 2;
+  const dim3 gd(F.nb_max), bd(256);
+#define KMX_DECODE_F(KW_, H_) hipLaunchKernelGGL((k_superk_decode_kmers<KW_, H_, true>), gd, bd, 0, st, (const u8*)F.d_words, F.d_boff, F.d_blk, F.d_part16, (const u64*)nullptr, 0u, 0u, (int)rq.k, rq.window, (void*)d_keys, F.d_sbase, (const SkfCtl*)F.d_ctl)
+  if (rq.hash_mode) { if (rq.k <= 32) KMX_DECODE_F(1, 1); else KMX_DECODE_F(2, 1); }
+  else if (KWD == 1) KMX_DECODE_F(1, 0); else KMX_DECODE_F(2, 0);
+#undef KMX_DECODE_F
+  hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(P), dim3(CS_SPL_TPB), 0, st, d_keys, d_parts, d_spl, (const SkfCtl*)F.d_ctl);
+  hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, F.d_cnt, (KeyT*)nullptr, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, F.d_cnt, 0u, d_boff, d_cur, (const u32*)nullptr, (const u32*)&F.d_ctl->TB);
+  hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+  hipLaunchKernelGGL((k_cs_wave_sort<KeyT, 8, 16>), dim3((TBm + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, d_bkeys, d_boff, 0u, 0u, (u32)CsCap<KeyT>::cap,
+                     rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, F.d_ctl, d_big);
+  // the buckets beyond a wave's registers (a k-mer repeated a thousand times, an unlucky sample): listed by the kernel above, a few workgroups take them
+  if constexpr (KWD == 1)
+    hipLaunchKernelGGL(k_cs_count_hash, dim3(256), dim3(CS_TPB), 0, st, d_bkeys, d_boff, rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, 0u, (const SkfCtl*)F.d_ctl, (const u32*)d_big);
+  else
+    hipLaunchKernelGGL((k_cs_sort<KeyT, 4096>), dim3(256), dim3(CS_TPB), 0, st, d_bkeys, d_boff, rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, 0u, 1u, (const SkfCtl*)F.d_ctl, (const u32*)d_big);
+  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_nkept, 0u, d_koff, (u32*)nullptr, (const u32*)nullptr, (const u32*)&F.d_ctl->TB);
+  if ((e = hipGetLastError()) != hipSuccess) return fail(e, "count kernels");
+  if ((e = hipMemcpyAsync(F.h_ctl, F.d_ctl, 64, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipMemcpyAsync(h_koff, d_koff, 4 * ((size_t)TBm + 2), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+      (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count read-back");
+  clk.mark("split+decode+sort+count");
+  if (F.h_ctl->status || F.h_ctl->overflow) { release(); return 1; }
+  const u32 TB = F.h_ctl->TB;
+  std::vector<CsPart> parts(P);
+  memcpy(parts.data(), F.h_parts, sizeof(CsPart) * P);
+  const int rc = compact_to_stores<KeyT>(ctx, d_tk, d_tc, d_boff, d_koff, h_koff, parts, TB, co);
+  release();
+  clk.mark("pack");
+  return rc;
+}
+int kmx_count_fast_tail(kmx_ctx* ctx, const kmx_fast_split& F, const kmx_count_req& rq)
+{
+  StageClock clk(ctx->stream, "count_reads_fast");
+  CountOut co; co.keys = rq.keys; co.counts = rq.counts; co.n_out = rq.n_out; co.stores = rq.stores; co.n_stores = rq.n_stores; co.lists = rq.lists; co.inner = rq.inner_parts;
+  if (rq.hash_mode || rq.k <= 32) return fast_tail_impl<u64>(ctx, clk, F, rq, co);
+  return fast_tail_impl<__uint128_t>(ctx, clk, F, rq, co);
 }
 
 // the bases of a batch, 2 bits each (see k_pack_bases); `out` holds (n + 31) / 32 + 2 words

@@ -22,6 +22,7 @@
 // the >= 128 B of an 8-pass LSD radix sort over the whole batch.
 #pragma once
 #include "kmx_dev.hpp"
+#include "skf.hpp"
 
 namespace kmx {
 
@@ -187,11 +188,12 @@ __device__ __forceinline__ void cs_sort_lds(K* s, u32 P, u32 tid)
 constexpr int CS_SPL_TPB = 1024;          // (a workgroup per partition: few of them for few large partitions -- the sort of the samples is the kernel's time)
 template <typename K>
 __global__ __launch_bounds__(CS_SPL_TPB)
-void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, typename CsSpl<K>::type* __restrict__ splitters)
+void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, typename CsSpl<K>::type* __restrict__ splitters, const SkfCtl* __restrict__ ctl = nullptr)
 {
   typedef typename CsSpl<K>::type S_t;
   constexpr u32 SMAX = (u32)CsCap<K>::sample;
   __shared__ S_t sm[SMAX];
+  if (ctl && ctl->status) return;      // (the sync-free path: the tables may name more than this kernel takes -- the call goes the old way)
   const CsPart P = parts[blockIdx.x];
   if (P.nb <= 1) return;
   const u32 tid = threadIdx.x;
@@ -221,14 +223,23 @@ template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32
 template <typename K, bool SCATTER>
 __global__ __launch_bounds__(CS_WALK_TPB)
 void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, const CsChunk* __restrict__ chunks, const typename CsSpl<K>::type* __restrict__ splitters,
-               u32* __restrict__ counts_or_cursor, K* __restrict__ out)
+               u32* __restrict__ counts_or_cursor, K* __restrict__ out,
+               const SkfCtl* __restrict__ ctl = nullptr, const u32* __restrict__ cfirst = nullptr /* [n_parts + 1] first chunk of every partition */, u32 n_parts = 0)
 {
   typedef typename CsSpl<K>::type S_t;
   constexpr int IPT = CsCap<K>::walk;      // (the chunks are cut to IPT * CS_WALK_TPB keys by the host: cs_chunk<K>())
   __shared__ S_t spl[CS_MAXB];
   __shared__ u32 hist[CS_MAXB];
   __shared__ u32 base[CS_MAXB];
-  const CsChunk C = chunks[blockIdx.x];
+  CsChunk C;
+  if (ctl) {      // the sync-free path: no chunk table -- chunk blockIdx.x belongs to the last partition whose first chunk is at or before it
+    if (ctl->status || blockIdx.x >= ctl->NC) return;
+    u32 lo = 0, hi = n_parts;
+    while (lo + 1 < hi) { const u32 mid = (lo + hi) >> 1; if (cfirst[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const CsPart Q = parts[lo];
+    const u32 o = (blockIdx.x - cfirst[lo]) * cs_chunk<K>();
+    C.part = lo; C.key0 = Q.key0 + o; C.nkeys = min(cs_chunk<K>(), Q.nkeys - o); C.pad = 0;
+  } else C = chunks[blockIdx.x];
   const CsPart P = parts[C.part];
   const u32 tid = threadIdx.x;
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
@@ -252,11 +263,12 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
 // queue as calls of their own rides along: a second copy of out[0, n) (the scatter's cursors), and a word brought next to the
 // result (out[n + 1] = *flag: one download for both)
 __global__ __launch_bounds__(1024)
-void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __restrict__ out2, const u32* __restrict__ flag)
+void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __restrict__ out2, const u32* __restrict__ flag, const u32* __restrict__ n_dev = nullptr)
 {
   __shared__ u32 wsum[16];
   __shared__ u32 carry_s;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (n_dev) n = *n_dev;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   // tiles of 16 consecutive values per thread (round 5; 4 before: the kernel is one workgroup whose tiles follow each other at the
@@ -355,18 +367,24 @@ __device__ __forceinline__ void cs_bucket_by_sort(K* sk, u32* starts, u32* wsum,
 template <typename K, int CAP = CsCap<K>::cap>
 __global__ __launch_bounds__(CS_TPB)
 void k_cs_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
-               unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */, u32 last = 1)
+               unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */, u32 last = 1,
+               const SkfCtl* __restrict__ ctl = nullptr, const u32* __restrict__ big = nullptr /* set: the buckets to take are listed (the sync-free path), ctl->n_big of them */)
 {
   __shared__ K sk[CAP];
   __shared__ u32 starts[CAP];      // positions of the run starts, in order
   __shared__ u32 wsum[CS_TPB / 64];
   __shared__ u32 hh[258];          // abundance histogram of the bucket's runs (hist != nullptr): see kmx_ctx::d_hist
-  const u32 b = blockIdx.x;
-  const u32 o = boff[b], n = boff[b + 1] - o;
-  if (lo && n <= lo) return;
-  if (n == 0) { if (threadIdx.x == 0) nkept[b] = 0; return; }
-  if (n > (u32)CAP) { if (last && threadIdx.x == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } return; }
-  cs_bucket_by_sort<K, CAP>(sk, starts, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
+  if (big && ctl->status) return;
+  const u32 nlist = big ? min(ctl->n_big, SKF_BIG_CAP) : 0u;
+  for (u32 it = blockIdx.x; big ? it < nlist : it == blockIdx.x; it += gridDim.x) {
+    __syncthreads();      // (the LDS of the bucket before)
+    const u32 b = big ? big[it] : blockIdx.x;
+    const u32 o = boff[b], n = boff[b + 1] - o;
+    if (lo && n <= lo) continue;
+    if (n == 0) { if (threadIdx.x == 0) nkept[b] = 0; continue; }
+    if (n > (u32)CAP) { if (last && threadIdx.x == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } continue; }
+    cs_bucket_by_sort<K, CAP>(sk, starts, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
+  }
 }
 
 // ---- 64-bit keys: a bucket by HASHING first.  The keys of a bucket are mostly repeats (a k-mer is seen once per read that covers it:
@@ -382,7 +400,8 @@ static_assert(CS_HT == (1 << 11), "cs_hash takes the top 11 bits of the product"
 
 __global__ __launch_bounds__(CS_TPB)
 void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, u64* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
-                     unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */)
+                     unsigned long long* __restrict__ hist, u32* __restrict__ overflow, u32 lo /* buckets of at most lo keys are another kernel's */,
+                     const SkfCtl* __restrict__ ctl = nullptr, const u32* __restrict__ big = nullptr /* set: the buckets to take are listed (the sync-free path), ctl->n_big of them */)
 {
   constexpr int CAP = CsCap<u64>::cap;
   __shared__ u64 la[CAP];          // hash set keys [0, CS_HT) + the distinct keys' dense copy [CS_HT, 2 * CS_HT)  |  the sort path's keys
@@ -392,10 +411,15 @@ void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff
   __shared__ u32 ndist;
   __shared__ volatile u32 full;
   static_assert(2 * CS_HT <= CAP, "the dense copy lies behind the hash set");
-  const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (big && ctl->status) return;
+  const u32 nlist = big ? min(ctl->n_big, SKF_BIG_CAP) : 0u;
+  for (u32 it = blockIdx.x; big ? it < nlist : it == blockIdx.x; it += gridDim.x) {
+  __syncthreads();      // (the LDS of the bucket before)
+  const u32 b = big ? big[it] : blockIdx.x;
   const u32 o = boff[b], n = boff[b + 1] - o;
-  if (lo && n <= lo) return;
-  if (n == 0) { if (tid == 0) nkept[b] = 0; return; }
+  if (lo && n <= lo) continue;
+  if (n == 0) { if (tid == 0) nkept[b] = 0; continue; }
   const u64 EMPTY = ~0ULL;           // (no canonical k-mer and no window hash is all ones)
   for (u32 i = tid; i < (u32)CS_HT; i += CS_TPB) { la[i] = EMPTY; lb[i] = 0; }
   if (tid == 0) { ndist = 0; full = 0; }
@@ -421,10 +445,10 @@ void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff
   }
   __syncthreads();
   if (full) {                        // too many distinct keys for the hash set
-    if (n > (u32)CAP) { if (tid == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } return; }
+    if (n > (u32)CAP) { if (tid == 0) { nkept[b] = 0; atomicOr(overflow, 1u); } continue; }
     __syncthreads();
     cs_bucket_by_sort<u64>(la, lb, wsum, hh, bkeys, o, n, b, hard_min, tk, tc, nkept, hist);
-    return;
+    continue;
   }
   // the distinct keys, dense: every thread's CS_HT / CS_TPB slots
   constexpr int SPT = CS_HT / CS_TPB;
@@ -477,6 +501,7 @@ void k_cs_count_hash(const u64* __restrict__ bkeys, const u32* __restrict__ boff
   if (tid == 0) nkept[b] = tot;
   if (hist) {
     for (u32 i = tid; i < 258; i += CS_TPB) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
+  }
   }
 }
 
@@ -588,10 +613,12 @@ constexpr int CS_WAVES = 4;      // buckets (waves) per workgroup
 template <typename K, int NPL_A, int NPL_B>
 __global__ __launch_bounds__(64 * CS_WAVES)
 void k_cs_wave_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 n_buckets, u32 lo /* this launch takes lo < n <= 64 * NPL_B */, u32 cap,
-                    u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept, unsigned long long* __restrict__ hist, u32* __restrict__ overflow)
+                    u32 hard_min, K* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept, unsigned long long* __restrict__ hist, u32* __restrict__ overflow,
+                    SkfCtl* __restrict__ ctl = nullptr, u32* __restrict__ big = nullptr /* [SKF_BIG_CAP]: the buckets beyond this kernel, for the LDS kernels behind it */)
 {
   __shared__ u32 hh[258];
   const u32 tid = threadIdx.x, b = blockIdx.x * CS_WAVES + (tid >> 6);
+  if (ctl) { if (ctl->status) return; n_buckets = ctl->TB; }      // (the sync-free path: the grid covers a bound)
   if (hist) { for (u32 i = tid; i < 258; i += 64 * CS_WAVES) hh[i] = 0; __syncthreads(); }
   if (b < n_buckets) {
     const u32 o = boff[b], n = boff[b + 1] - o;
@@ -600,6 +627,9 @@ void k_cs_wave_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u
     else if (n > lo && n <= 64u * NPL_B) {
       if (n <= 64u * NPL_A) cs_wave_bucket<K, NPL_A>(bkeys, o, n, b, hard_min, tk, tc, nkept, hist ? hh : nullptr);
       else cs_wave_bucket<K, NPL_B>(bkeys, o, n, b, hard_min, tk, tc, nkept, hist ? hh : nullptr);
+    } else if (big && n > 64u * NPL_B && (tid & 63u) == 0) {
+      const u32 at = atomicAdd(&ctl->n_big, 1u);
+      if (at < SKF_BIG_CAP) big[at] = b; else atomicOr(&ctl->status, (u32)SKF_ST_BUCKET);
     }
   }
   if (hist) {

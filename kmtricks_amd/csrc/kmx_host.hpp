@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include "kmx_dev.hpp"
+#include "skf.hpp"
 #include "../../include/kmx.h"
 
 namespace kmx {
@@ -71,6 +72,26 @@ int kmx_count_from_device(kmx_ctx* ctx, const kmx::u8* d_recs, const kmx::u64* d
                           kmx::u64 total_kmers, kmx::u32 n_parts, const kmx::u64* part_kmer_off /* n_parts + 1, host */, const kmx_count_req& rq,
                           const kmx::u32* d_sbase = nullptr /* set: no record stream -- d_recs are the batch's bases packed by kmx_launch_pack_bases, record i starts at base d_sbase[i] */);
 void kmx_launch_pack_bases(const char* d_bases, kmx::u64 n, kmx::u64* out /* (n + 31) / 32 + 2 words */, hipStream_t st);
+// ---- round 6: the same hand-over without a host round trip (superk_fast.hpp -> count.hip).  Everything is on the device, sizes
+//      included (d_ctl); the arrays are sized for bounds.  kmx_count_fast_tail queues decode + partition-local sample sort + count,
+//      reads the control block, the sample sort's tables and the kept sizes back ONCE, and packs the lists into the stores.
+//      Returns KMX_OK, a negative error, or 1: a status bit was raised on the device (h_ctl holds it) -- the caller takes the old path.
+struct kmx_fast_split {
+  const kmx::u64* d_words;        // the batch's bases, 2 bits each (kmx_launch_pack_bases)
+  const kmx::u32* d_sbase;        // [nd] first base of sorted record i
+  const kmx::u64* d_boff;         // [nd + 1] k-mers << 32 | record bytes in front of sorted record i
+  const kmx::u16* d_part16;       // [nd] its partition (hash mode; else null)
+  const kmx::u32* d_blk;          // first record of every block of SKF_DK k-mers
+  kmx::SkfCtl* d_ctl;             // control block; 8 more bytes behind it ride along in the read-back (64 bytes in all)
+  const uint4* d_parts;           // CsPart[n_parts]: the sample sort's layout (k_sk_scan)
+  const kmx::u32* d_cfirst;       // [n_parts + 1] first walk chunk of every partition
+  kmx::u32* d_cnt;                // [tb_max + 2] zeroed: the buckets' counters
+  kmx::u32 n_parts; kmx::u64 kmer_bound; kmx::u32 tb_max, nc_max, nb_max;      // bounds: k-mers, buckets, walk chunks, decode blocks
+  kmx::SkfCtl* h_ctl;             // page-locked, 64 bytes: the control block as read back
+  const uint4* h_parts;           // page-locked: d_parts as read back (the caller queued that copy on the context's stream)
+};
+kmx::SkfLayout kmx_fast_layout(int key_words /* of the sort's keys: 1 (k <= 32, hashes) or 2 */);
+int kmx_count_fast_tail(kmx_ctx* ctx, const kmx_fast_split& F, const kmx_count_req& rq);
 
 // page-locked host memory (kmx_api.hip: transparent huge pages + hipHostRegister for blocks of 2 MB and more, hipHostMalloc else)
 int kmx_peer_path(int from, int to);      // 1: GPU `from` reaches GPU `to`'s memory directly (peer access enabled on first use), 0: staged

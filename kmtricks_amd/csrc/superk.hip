@@ -29,9 +29,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
-namespace kmx {
+#include "skf.hpp"
 
-struct SkDesc { u32 base; u16 part; u8 n; u8 pad; };   // base = index of the record's first base in `bases`
+namespace kmx {
 
 __device__ __forceinline__ bool nt_valid(u8 c)
 { // gatb tools/misc/api/Data.hpp:179-196
@@ -105,17 +105,22 @@ struct SkLook { unsigned long long* state; u32* ticket; u32* over; u32 cap; };
 // s * parts + repart[minimizer], its per-minimizer tables start at s * nm.  first == nullptr: one sample
 struct SkMulti { const u32* first; u32 n; u32 parts; u32 nm; };      // state[workgroup]: flag << 62 | count or prefix; cap: descriptors that fit
 constexpr u32 SK_WCAP = 512;      // descriptors of one read the LDS takes (the host sends longer reads the two-pass way)
-template <bool EMIT, bool STATS, bool LB = false, bool DEFER = false>
+// CH (round 6, the sync-free count path): ONE walk -- a wave takes `rpw` consecutive reads (a chunk) and writes their descriptors
+// back to back from slot offsets[first read of the chunk] on (a read holds fewer super-k-mers than bases: the chunks' slot ranges
+// never meet), their number to counts[chunk].  No count pass, no scan, no size read back by the host: k_sk_hist / k_sk_scan /
+// k_sk_scatter below put the descriptors in partition order, read order kept inside a partition.
+template <bool EMIT, bool STATS, bool LB = false, bool DEFER = false, bool CH = false>
 __global__ __launch_bounds__(256)
 void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offsets, u64 n_seqs,
                    int k, int m, int maxs, const u16* __restrict__ repart,
-                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so, SkLook lk, SkMulti mu)
+                   u32* __restrict__ counts, const u32* __restrict__ desc_off, SkDesc* __restrict__ desc, SkStats S, SkSort so, SkLook lk, SkMulti mu, u32 rpw = 1)
 {
   __shared__ SkDesc wbuf[LB ? 4 : 1][LB ? SK_WCAP : 1];
   __shared__ u32 wcnt[4];
   __shared__ u32 bid_s, base_s;
   static_assert(!LB || EMIT, "the look-back places descriptors");
   static_assert(!DEFER || (EMIT && STATS && !LB), "deferred statistics travel with the descriptors of the two-pass path");
+  static_assert(!CH || (EMIT && !LB), "a chunk's descriptors are written where they are found");
   const int lane = threadIdx.x & 63;
   const u32 wave = threadIdx.x >> 6;
   u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -124,13 +129,19 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
     __syncthreads();
     r = (u64)bid_s * 4u + wave;
   }
+  const u64 chunk = r;
+  u64 r_end = r + 1;
+  if (CH) { r = chunk * rpw; r_end = r + rpw < n_seqs ? r + rpw : n_seqs; }
   if (!LB && r >= n_seqs) return;
+  u32 nsk = 0;
+  u32 out = CH ? (u32)offsets[r] : 0u;
+  const u32 out_first = out;
+  for (; r < r_end; r++) {
   const bool act = r < n_seqs;
   const u64 b0 = act ? offsets[r] : 0, len = act ? offsets[r + 1] - b0 : 0;
   u32 smp = 0;
   if (mu.first) while (smp + 1 < mu.n && r >= (u64)mu.first[smp + 1]) smp++;      // (a handful of samples: uniform over the wave)
   const u32 pbase = smp * mu.parts, sbase = smp * mu.nm;
-  u32 nsk = 0;
   if (len >= (u64)k) {
     const char* seq = bases + b0;
     const int nbm = k - m + 1;                       // m-mers per k-mer (<= 60)
@@ -143,7 +154,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
     const u64 nk = len - (u64)k + 1;
     const u64 kmask = (1ULL << k) - 1;               // k <= 63
     const u32 mmask = (1u << m) - 1;
-    u32 out = (EMIT && !LB) ? desc_off[r] : 0;
+    if (!CH) out = (EMIT && !LB) ? desc_off[r] : 0;
     bool pv = false; u32 pmin = 0; u64 run_start = 0, open_start = 0;   // state of the last owned k-mer of the previous chunk
     int pw = 0; u64 t_start = 0, x_start = 0; u32 rf_open = 0;          // (STATS) its strand, strand-run start, kx-mer start + that k-mer's radix
     u64 hist = 0;                                                       // (DEFER) the strands of the 64 positions before p0: bit 63 is p0 - 1
@@ -287,6 +298,10 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
       }
     }
   }
+  if (!CH) break;
+  }
+  if (CH) { if (lane == 0) counts[chunk] = out - out_first; return; }
+  r = chunk;
   if (!EMIT && lane == 0) { counts[r] = nsk; if (r == 0) counts[n_seqs] = 0; }      // (every read's entry is written, and the scan's terminating zero: no clear beforehand)
   if (LB) {
     if (lane == 0) wcnt[wave] = min(nsk, SK_WCAP);
@@ -653,6 +668,8 @@ void k_part_stats(const u32* __restrict__ ids, const u32* __restrict__ part_firs
   }
 }
 
+#include "superk_fast.hpp"
+
 }  // namespace kmx
 
 using namespace kmx;
@@ -937,6 +954,98 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     const int rc = sd.collect(ctx, st);
     release();
     return rc;
+  }
+  // ---- round 6, kmx_count_reads_dev's usual call (one sample, k < 64, at most SKF_MAXP partitions, results into device stores): the
+  //      split without a host round trip (superk_fast.hpp) handed to a count whose tables are made on the device (count.hip,
+  //      kmx_count_fast_tail).  One read-back, at the count's end.  A status bit raised on the device -- or KMX_COUNT_FAST=0 -- sends
+  //      the call down the path below (which reads three sizes back and has the library sort the descriptors). ----
+  {
+    const char* fe = getenv("KMX_COUNT_FAST");      // (read per call: the tests switch it)
+    const bool fast = creq && creq->lists && !streams_to_host && !wide_k && !segs && nb_parts <= SKF_MAXP && two_pass && (!sd.any() || sd.deferred) && !ctx->hist_on &&
+                      !(fe && !strcmp(fe, "0")) && !getenv("KMX_COUNT_SORT") && !getenv("KMX_COUNT_BUCKETS") && total_bases >= 1;
+    if (fast) {
+      const u32 P = nb_parts, wpg = skf_wpg(P);
+      const u32 n_chunks = (u32)((n_seqs + SKF_RPW - 1) / SKF_RPW), R = (n_chunks + wpg - 1) / wpg;
+      const u32 rpg = std::max<u32>(16u, (R + 127u) / 128u), Gc = (R + rpg - 1) / rpg;
+      u32 pbits = 1; while ((1u << pbits) < P) pbits++;
+      const u64 kb = total_bases;                                                   // k-mers of the batch: fewer than bases
+      const u32 nd_cap = (u32)std::min<u64>(total_bases, total_bases / 4 + n_seqs + 1024);      // records the sorted arrays take (a super-k-mer holds ~9 k-mers; beyond: the old path)
+      const int kw = (int)((k + 31) / 32);
+      const SkfLayout L = kmx_fast_layout(creq->hash_mode ? 1 : kw);
+      const u32 tb_max = (u32)(kb / L.target) + P + 1, nc_max = (u32)(kb / L.chunk) + P + 1, nb_max = (u32)((kb + SKF_DK - 1) / SKF_DK) + 1;
+      // the zeroed block: [control 32 B][minimizers that occur, u64][pad to 64][k_sk_scan's flags][the sample sort's bucket counters]
+      const size_t z_flags = 64, z_cnt = z_flags + 128 * 4, z_bytes = z_cnt + ((size_t)tb_max + 2) * 4;
+      u8* d_z = (u8*)ctx->dalloc(z_bytes);
+      // what the host reads at the end, one copy: [pp (P + 1) u64][info 2 P u64][parts P uint4][pf (P + 1) u32][cfirst (P + 1) u32]
+      const size_t P1f = (size_t)P + 1, o_info = P1f * 8, o_parts = o_info + (size_t)P * 16, o_pf = o_parts + (size_t)P * 16, o_cf = o_pf + P1f * 4, sumf = o_cf + P1f * 4;
+      u8* d_sumf = (u8*)ctx->dalloc(sumf);
+      u8* h_f = (u8*)ctx->halloc(64 + sumf);
+      struct HRelF { kmx_ctx* c; void* p; ~HRelF() { c->hfree(p); } } h_f_rel{ctx, h_f};
+      SkDesc* d_descf = (SkDesc*)ctx->dalloc(((size_t)total_bases + 64) * sizeof(SkDesc));
+      u32* d_ccnt = (u32*)ctx->dalloc((size_t)n_chunks * 4);
+      ulonglong2* d_T = (ulonglong2*)ctx->dalloc((size_t)R * P * 16), *d_agg = (ulonglong2*)ctx->dalloc((size_t)Gc * P * 16);
+      u32* d_sb = (u32*)ctx->dalloc((size_t)nd_cap * 4 + 16);
+      u64* d_bo = (u64*)ctx->dalloc(((size_t)nd_cap + 1) * 8);
+      u32* d_idf = sd.deferred ? (u32*)ctx->dalloc((size_t)nd_cap * 4 + 16) : nullptr;
+      u16* d_p16 = creq->hash_mode ? (u16*)ctx->dalloc((size_t)nd_cap * 2 + 16) : nullptr;
+      u32* d_bf = (u32*)ctx->dalloc((size_t)nb_max * 4);
+      u64* d_wordsf = (u64*)ctx->dalloc(((size_t)total_bases / 32 + 4) * 8);
+      std::vector<void*> fb = {d_z, d_sumf, d_descf, d_ccnt, d_T, d_agg, d_sb, d_bo, d_bf, d_wordsf};
+      bool ok = h_f != nullptr;
+      for (void* b : fb) ok = ok && b;
+      if (sd.deferred) { sd.S.sk_rec = (ulonglong2*)ctx->dalloc(((size_t)total_bases + 64) * 16); fb.push_back(sd.S.sk_rec); fb.push_back(d_idf); ok = ok && sd.S.sk_rec && d_idf; }
+      if (creq->hash_mode) { fb.push_back(d_p16); ok = ok && d_p16; }
+      auto frel = [&]() { for (void* b : fb) ctx->dfree(b); };
+      if (!ok) { frel(); release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
+      SkfCtl* d_ctl = (SkfCtl*)d_z; u64* d_nspf = (u64*)(d_z + 32);
+      u64* d_ppf = (u64*)d_sumf, *d_infof = (u64*)(d_sumf + o_info); uint4* d_partsf = (uint4*)(d_sumf + o_parts); u32* d_pff = (u32*)(d_sumf + o_pf), *d_cff = (u32*)(d_sumf + o_cf);
+      auto ffail = [&](hipError_t er, const char* what) { frel(); return fail(er, what); };
+      if ((e = hipMemsetAsync(d_z, 0, z_bytes, st)) != hipSuccess) return ffail(e, "memset");
+      kmx_launch_pack_bases(d_bases, total_bases, d_wordsf, st);
+      const dim3 gw((n_chunks + 3) / 4);
+      if (sd.deferred)
+        hipLaunchKernelGGL((k_superk_wave<true, true, false, true, true>), gw, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_ccnt,
+                           (const u32*)nullptr, d_descf, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu, (u32)SKF_RPW);
+      else
+        hipLaunchKernelGGL((k_superk_wave<true, false, false, false, true>), gw, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_ccnt,
+                           (const u32*)nullptr, d_descf, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu, (u32)SKF_RPW);
+      hipLaunchKernelGGL(k_sk_hist, dim3(R), dim3(64 * wpg), (size_t)P * 12, st, d_descf, d_offs, d_ccnt, n_chunks, wpg, P, (u32)k, d_T, d_ctl);
+      hipLaunchKernelGGL(k_sk_scan, dim3(Gc), dim3(256), 0, st, d_T, R, rpg, P, d_agg, (u32*)(d_z + z_flags), nd_cap, L, d_ctl, d_pff, d_ppf, d_bo, d_partsf, d_cff);
+      hipLaunchKernelGGL(k_sk_scatter, dim3(R), dim3(64 * wpg), (size_t)wpg * P * 12, st, d_descf, d_offs, d_ccnt, n_chunks, wpg, P, pbits, (u32)k, d_T, d_ctl,
+                         d_sb, d_bo, d_idf, d_p16, d_bf);
+      if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((P + 63) / 64), dim3(64), 0, st, d_pff, d_bo, P, d_infof);
+      sd.launch_part_stats(d_idf, d_pff, d_bases, k, d_nspf, st);
+      sd.launch_sparse(d_nspf, st);
+      if ((e = hipGetLastError()) != hipSuccess) return ffail(e, "split kernels");
+      if ((e = hipMemcpyAsync(h_f + 64, d_sumf, sumf, hipMemcpyDeviceToHost, st)) != hipSuccess) return ffail(e, "memcpy");
+      kmx_fast_split F{d_wordsf, d_sb, d_bo, d_p16, d_bf, d_ctl, d_partsf, d_cff, (u32*)(d_z + z_cnt), P, kb, tb_max, nc_max, nb_max,
+                       reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts)};
+      const int frc = kmx_count_fast_tail(ctx, F, *creq);      // (waits for the stream: the copies above are through when it returns)
+      if (frc < 0) { frel(); release(); return frc; }
+      const SkfCtl* hc = reinterpret_cast<const SkfCtl*>(h_f);
+      if (frc == 0 && (hc->status & SKF_ST_PART)) { frel(); release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
+      if (frc == 0) {
+        const u64* ppf = reinterpret_cast<const u64*>(h_f + 64);
+        sd.compacted();
+        if (superk_info) memcpy(superk_info, h_f + 64 + o_info, (size_t)P * 16);
+        for (u32 p = 0; p < P; p++) out_kmers[p] = (ppf[p + 1] >> 32) - (ppf[p] >> 32);
+        if (raw) {
+          raw[0].nb_superk = hc->nd;
+          aux_busy = true;
+          const u64 nsp = *reinterpret_cast<const u64*>(h_f + 32);
+          const int rc = sd.finish_raw(ctx, &nsp, ctx->aux ? ctx->aux : st);
+          if (rc != KMX_OK) { frel(); release(); return rc; }
+          if ((e = hipStreamSynchronize(ctx->aux ? ctx->aux : st)) != hipSuccess) return ffail(e, "sync");
+        }
+        frel(); release();
+        return KMX_OK;
+      }
+      // (a status bit: the old path takes the call from the start -- the statistics of the abandoned pass are cleared)
+      if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx count] the sync-free path handed the call back (status %u, overflow %u)\n", hc->status, hc->overflow);
+      frel();
+      if (sd.deferred) { ctx->dfree(sd.S.sk_rec); sd.S.sk_rec = nullptr; }
+      if ((e = sd.clear(st)) != hipSuccess) return fail(e, "memset");
+    }
   }
   // what the host reads back between the steps lands in one page-locked block (a copy into pageable memory is staged by the
   // runtime and waited for): [super-k-mers u64 + a spare] [pp (P + 1) u64] [info 2P u64] [minimizers that occur u64] [pf (P + 1) u32]
