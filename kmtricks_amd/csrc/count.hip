@@ -1171,8 +1171,14 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
 #undef KMX_DECODE_F
   hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(P), dim3(CS_SPL_TPB), 0, st, d_keys, d_parts, d_spl, (const SkfCtl*)F.d_ctl);
   hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, F.d_cnt, (KeyT*)nullptr, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
-  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, F.d_cnt, 0u, d_boff, d_cur, (const u32*)nullptr, (const u32*)&F.d_ctl->TB);
-  hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+  const dim3 gs((TBm + 1 + 4095) / 4096);      // (at most 256 workgroups: the caller bounds the batch)
+  u32* d_agg = (u32*)dal(4 * 512);
+  if (!d_agg || gs.x > 256) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
+  hipLaunchKernelGGL(k_cs_scan_mw, gs, dim3(1024), 0, st, F.d_cnt, (const u32*)&F.d_ctl->TB, d_boff, d_cur, d_agg, F.d_sflags);
+  if (getenv("KMX_COUNT_SCATTER_PLAIN"))      // (the scatter of rounds 3-5, for comparison)
+    hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+  else
+    hipLaunchKernelGGL((k_cs_scatter_staged<KeyT>), dim3(F.nc_max * (cs_chunk<KeyT>() / cs_schunk<KeyT>())), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
   hipLaunchKernelGGL((k_cs_wave_sort<KeyT, 8, 16>), dim3((TBm + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, d_bkeys, d_boff, 0u, 0u, (u32)CsCap<KeyT>::cap,
                      rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, F.d_ctl, d_big);
   // the buckets beyond a wave's registers (a k-mer repeated a thousand times, an unlucky sample): listed by the kernel above, a few workgroups take them
@@ -1180,16 +1186,39 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
     hipLaunchKernelGGL(k_cs_count_hash, dim3(256), dim3(CS_TPB), 0, st, d_bkeys, d_boff, rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, 0u, (const SkfCtl*)F.d_ctl, (const u32*)d_big);
   else
     hipLaunchKernelGGL((k_cs_sort<KeyT, 4096>), dim3(256), dim3(CS_TPB), 0, st, d_bkeys, d_boff, rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, 0u, 1u, (const SkfCtl*)F.d_ctl, (const u32*)d_big);
-  hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(1024), 0, st, d_nkept, 0u, d_koff, (u32*)nullptr, (const u32*)nullptr, (const u32*)&F.d_ctl->TB);
+  hipLaunchKernelGGL(k_cs_scan_mw, gs, dim3(1024), 0, st, d_nkept, (const u32*)&F.d_ctl->TB, d_koff, (u32*)nullptr, d_agg + 256, F.d_sflags + 256);
+  // one store on this GPU: room for 1.25 x what the last call kept per k-mer is reserved and the lists are written there before
+  // their size is known -- the read-back below is then the call's only wait
+  constexpr size_t RB = sizeof(KeyT) + 4;
+  kmx_store* const S0 = co.n_stores == 1 && co.stores[0]->device == ctx->device ? co.stores[0] : nullptr;
+  u8* d_resv = nullptr; u32 cap_recs = 0;
+  if (S0 && ctx->kept_per_kmer > 0.0) {
+    cap_recs = (u32)std::min<double>((double)kb, (double)kb * ctx->kept_per_kmer * 1.25 + 65536.0);
+    d_resv = (u8*)S0->try_reserve((size_t)cap_recs * RB);
+    if (d_resv) hipLaunchKernelGGL((k_cs_compact_recs<KeyT>), dim3(TBm), dim3(CS_TPB), 0, st, d_tk, d_tc, d_boff, d_koff, (const u32*)d_koff, d_resv, (const SkfCtl*)F.d_ctl, cap_recs);
+  }
+  struct Resv { kmx_store* s; u8* p; ~Resv() { if (s && p) s->commit(p, 0); } } resv{S0, d_resv};      // (left open by an error: given back)
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "count kernels");
   if ((e = hipMemcpyAsync(F.h_ctl, F.d_ctl, 64, hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipMemcpyAsync(h_koff, d_koff, 4 * ((size_t)TBm + 2), hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count read-back");
   clk.mark("split+decode+sort+count");
+  if (clk.on) fprintf(stderr, "[kmx count_reads_fast] records %u k-mers %u buckets %u walk chunks %u listed buckets %u status %u overflow %u\n", F.h_ctl->nd, F.h_ctl->total, F.h_ctl->TB, F.h_ctl->NC, F.h_ctl->n_big, F.h_ctl->status, F.h_ctl->overflow);
   if (F.h_ctl->status || F.h_ctl->overflow) { release(); return 1; }
   const u32 TB = F.h_ctl->TB;
   std::vector<CsPart> parts(P);
   memcpy(parts.data(), F.h_parts, sizeof(CsPart) * P);
+  if (F.h_ctl->total) ctx->kept_per_kmer = (double)h_koff[TB] / (double)F.h_ctl->total;
+  if (d_resv && h_koff[TB] <= cap_recs) {      // the lists are in the store already
+    for (u32 p = 0; p < P; p++) {
+      const u32 lo = h_koff[parts[p].bucket0], hi = h_koff[parts[p].bucket0 + parts[p].nb];
+      co.lists[p].n = hi - lo; co.lists[p].recs = hi > lo ? d_resv + (size_t)lo * RB : nullptr;
+    }
+    S0->commit(d_resv, (size_t)h_koff[TB] * RB); resv.p = nullptr;
+    release();
+    return KMX_OK;
+  }
+  if (d_resv) { S0->commit(d_resv, 0); resv.p = nullptr; }      // (more kept than estimated: the exact way)
   const int rc = compact_to_stores<KeyT>(ctx, d_tk, d_tc, d_boff, d_koff, h_koff, parts, TB, co);
   release();
   clk.mark("pack");

@@ -71,7 +71,10 @@ template <typename K> struct CsCap { static constexpr int cap = 4096, sample = 1
 template <> struct CsCap<__uint128_t> { static constexpr int cap = 4096, sample = 8192, walk = 16; };
 template <int KW> struct CsCap<WideKey<KW>> { static constexpr int cap = 2048, sample = 8192, walk = 8; };      // (cap: 48 / 64 + 8 KB in k_cs_sort; sample: of CsSpl's 16-byte tops)      // (cap: 64 + 16 KB of LDS in k_cs_sort, which only sees the buckets the wave kernel leaves)
 constexpr u32 CS_WAVE_MAX = 1024;         // keys of a bucket that one wave sorts in registers (16 per lane)
-template <typename K> __host__ __device__ inline u32 cs_target() { return CS_WAVE_MAX / 2; }      // aimed bucket size (a bucket may come out twice that and stay with the wave kernel, 4-8x and stay in LDS)
+// aimed bucket size.  Round 6: 416 with 8-16 samples a bucket (before: 512 with 4-8) -- a bucket's size then scatters by a third of
+// its aim: three in four fit the wave kernel's small network (512 keys: 0.7 compare-exchanges a key and stage against 0.86 in the
+// large one), and hardly one is beyond its 1024 (before: one in forty, 70 us of LDS kernel a sample)
+template <typename K> __host__ __device__ inline u32 cs_target() { return 416u; }
 
 template <typename K> __host__ __device__ constexpr u32 cs_chunk() { return (u32)CsCap<K>::walk * (u32)CS_WALK_TPB; }
 struct CsPart { u32 key0, nkeys, bucket0, nb; };      // a partition's keys [key0, key0 + nkeys), its buckets [bucket0, bucket0 + nb)
@@ -197,7 +200,7 @@ void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts
   const CsPart P = parts[blockIdx.x];
   if (P.nb <= 1) return;
   const u32 tid = threadIdx.x;
-  u32 S = 4 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 4-8 per bucket (the sort of the samples is this kernel; a bucket twice its aim still fits the wave kernel)
+  u32 S = 8 * P.nb; { u32 p2 = 64; while (p2 < S) p2 <<= 1; S = min(p2, SMAX); }      // samples: a power of two, 8-16 per bucket (4-8 for a partition of more than SMAX / 8 buckets; 16-32 cost the samples' sort 60 us a sample more than they saved)
   // (a sample per stratum of nkeys / S keys, at a hashed place inside it: evenly spaced samples of a batch that holds the same reads
   //  twice -- a genome given twice, paired files -- are the same keys twice, half as many samples as it looks)
   for (u32 i = tid; i < S; i += CS_SPL_TPB) {
@@ -215,6 +218,23 @@ template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32
   u32 lo = 0, hi = nb - 1;
   while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (spl[mid] <= k) lo = mid + 1; else hi = mid; }
   return lo;
+}
+// the same for N keys in step (round 6): every key tries the same stride at the same time -- N independent LDS reads in flight a
+// thread instead of one dependent read after another (a walk's time was half these searches).  top = the largest power of two
+// <= nb - 1 (0 when nb == 1); keys the caller does not hold get any value.
+template <typename S_t, int N> __device__ __forceinline__ void cs_bucket_n(const S_t* spl, u32 nb, u32 top, const S_t (&t)[N], u32 (&b)[N])
+{
+#pragma unroll
+  for (int x = 0; x < N; x++) b[x] = 0;
+  for (u32 step = top; step > 0; step >>= 1) {
+#pragma unroll
+    for (int x = 0; x < N; x++) {
+      const u32 at = b[x] + step;      // would be the number of splitters <= key: the at-th one (index at - 1) must exist and be <= key
+      const u32 idx = min(at, nb - 1u) - 1u;
+      const bool ok = at <= nb - 1u && spl[idx] <= t[x];
+      b[x] = ok ? at : b[x];
+    }
+  }
 }
 
 // SCATTER = false: bucket sizes.  SCATTER = true: keys to their buckets (cursor[] starts at the buckets' offsets).
@@ -245,11 +265,14 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
   __syncthreads();
   K k[IPT]; u32 bk[IPT], rk[IPT];
+  {
+    S_t tp[IPT];
 #pragma unroll
-  for (int x = 0; x < IPT; x++) {
-    const u32 i = tid + x * CS_WALK_TPB;
-    bk[x] = 0xFFFFFFFFu;
-    if (i < C.nkeys) { k[x] = keys[C.key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
+    for (int x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; k[x] = keys[C.key0 + (i < C.nkeys ? i : 0u)]; tp[x] = CsSpl<K>::top(k[x]); }
+    u32 top = 0; if (P.nb > 1) { top = 1; while (top * 2 <= P.nb - 1) top *= 2; }
+    cs_bucket_n<S_t, IPT>(spl, P.nb, top, tp, bk);
+#pragma unroll
+    for (int x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; if (i < C.nkeys) rk[x] = atomicAdd(&hist[bk[x]], 1u); else bk[x] = 0xFFFFFFFFu; }
   }
   __syncthreads();
   if (!SCATTER) { for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) if (hist[b]) atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]); return; }
@@ -257,6 +280,66 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   __syncthreads();
 #pragma unroll
   for (int x = 0; x < IPT; x++) if (bk[x] != 0xFFFFFFFFu) out[base[bk[x]] + rk[x]] = k[x];
+}
+
+// ---- the scatter walk, its pieces put together in LDS first (round 6, the sync-free path).  k_cs_walk<.., true> writes a key where its
+//      bucket's cursor says: 64 lanes, 64 cache lines, 8 bytes each -- 24 us of a workgroup's 35 are these stores.  Here a workgroup
+//      takes 64 KB of keys (half a count chunk of 8-byte keys), ranks them per bucket as before, lays them out bucket after bucket in
+//      LDS (a scan of the chunk's bucket sizes), claims each bucket's room with one global add, and writes the staged keys in order:
+//      a bucket's ~36 keys of the chunk leave as adjacent lanes of one store. ----
+template <typename K> __host__ __device__ constexpr u32 cs_schunk() { return 65536u / (u32)sizeof(K); }      // keys a workgroup of the staged scatter takes
+template <typename K>
+__global__ __launch_bounds__(CS_WALK_TPB)
+void k_cs_scatter_staged(const K* __restrict__ keys, const CsPart* __restrict__ parts, const typename CsSpl<K>::type* __restrict__ splitters,
+                         u32* __restrict__ cursor, K* __restrict__ out, const SkfCtl* __restrict__ ctl, const u32* __restrict__ cfirst, u32 n_parts)
+{
+  typedef typename CsSpl<K>::type S_t;
+  constexpr u32 SC = cs_schunk<K>(), IPT = SC / CS_WALK_TPB, SUB = cs_chunk<K>() / SC;      // (SUB staged chunks per count chunk)
+  static_assert(cs_chunk<K>() % SC == 0 && SC % CS_WALK_TPB == 0, "a count chunk is cut into whole staged chunks");
+  __shared__ S_t spl[CS_MAXB];
+  __shared__ u32 hist[CS_MAXB];       // keys of the chunk per bucket; then: where the bucket starts in `stage`
+  __shared__ u32 delta[CS_MAXB];      // the bucket's place in `out` minus its place in `stage`
+  __shared__ K stage[SC];
+  __shared__ u16 bid[SC];
+  __shared__ u32 wsum[CS_WALK_TPB / 64];
+  if (ctl->status) return;
+  const u32 cc = blockIdx.x / SUB, sub = blockIdx.x % SUB;
+  if (cc >= ctl->NC) return;
+  u32 plo = 0, phi = n_parts;
+  while (plo + 1 < phi) { const u32 mid = (plo + phi) >> 1; if (cfirst[mid] <= cc) plo = mid; else phi = mid; }
+  const CsPart P = parts[plo];
+  const u32 o = (cc - cfirst[plo]) * cs_chunk<K>() + sub * SC;
+  if (o >= P.nkeys) return;
+  const u32 key0 = P.key0 + o, nkeys = min(SC, P.nkeys - o);
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
+  __syncthreads();
+  K k[IPT]; u32 bk[IPT], rk[IPT];
+  {
+    S_t tp[IPT];
+#pragma unroll
+    for (u32 x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; k[x] = keys[key0 + (i < nkeys ? i : 0u)]; tp[x] = CsSpl<K>::top(k[x]); }
+    u32 top = 0; if (P.nb > 1) { top = 1; while (top * 2 <= P.nb - 1) top *= 2; }
+    cs_bucket_n<S_t, (int)IPT>(spl, P.nb, top, tp, bk);
+#pragma unroll
+    for (u32 x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; if (i < nkeys) rk[x] = atomicAdd(&hist[bk[x]], 1u); else bk[x] = 0xFFFFFFFFu; }
+  }
+  __syncthreads();
+  // the buckets' places in `stage`: exclusive scan of hist (two entries a thread: CS_MAXB = 2 * CS_WALK_TPB), their room in `out`
+  static_assert(CS_MAXB == 2 * CS_WALK_TPB, "two buckets a thread");
+  const u32 h0 = 2 * tid < P.nb ? hist[2 * tid] : 0u, h1 = 2 * tid + 1 < P.nb ? hist[2 * tid + 1] : 0u;
+  const u32 incl = wave_incl_scan(h0 + h1, (int)lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  u32 a = incl - (h0 + h1);
+  for (u32 w = 0; w < wave; w++) a += wsum[w];
+  if (2 * tid < P.nb) { hist[2 * tid] = a; delta[2 * tid] = (h0 ? atomicAdd(&cursor[P.bucket0 + 2 * tid], h0) : 0u) - a; }
+  if (2 * tid + 1 < P.nb) { hist[2 * tid + 1] = a + h0; delta[2 * tid + 1] = (h1 ? atomicAdd(&cursor[P.bucket0 + 2 * tid + 1], h1) : 0u) - (a + h0); }
+  __syncthreads();
+#pragma unroll
+  for (u32 x = 0; x < IPT; x++) if (bk[x] != 0xFFFFFFFFu) { const u32 at = hist[bk[x]] + rk[x]; stage[at] = k[x]; bid[at] = (u16)bk[x]; }
+  __syncthreads();
+  for (u32 i = tid; i < nkeys; i += CS_WALK_TPB) out[i + delta[bid[i]]] = stage[i];
 }
 
 // exclusive scan of n u32 values (n <= a few 100 k): one workgroup, 1024 threads; out[n] = total.  What the caller would otherwise
@@ -300,6 +383,42 @@ void k_cs_scan(const u32* __restrict__ in, u32 n, u32* __restrict__ out, u32* __
     __syncthreads();
   }
   if (tid == 0) { out[n] = carry_s; if (flag) out[n + 1] = *flag; }
+}
+
+// the same scan over several workgroups (round 6, the sync-free path: n is the device's, the grid covers a bound): workgroup g takes
+// values [4096 g, 4096 (g + 1)), publishes their sum, adds up the sums of the workgroups in front of it (at most 255 of them: all
+// resident) -- one tile's latency instead of a tile after a tile.  flags[gridDim.x] zeroed by the caller.
+__global__ __launch_bounds__(1024)
+void k_cs_scan_mw(const u32* __restrict__ in, const u32* __restrict__ n_dev, u32* __restrict__ out, u32* __restrict__ out2, u32* __restrict__ agg, u32* __restrict__ flags)
+{
+  __shared__ u32 wsum[16];
+  __shared__ u32 base_s;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, g = blockIdx.x, n = *n_dev;
+  const u32 i = g * 4096u + tid * 4u;
+  u32 v[4] = {0, 0, 0, 0};
+  if (i + 4 <= n && ((uintptr_t)in & 15u) == 0) { const uint4 q = *reinterpret_cast<const uint4*>(in + i); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+  else { for (u32 x = 0; x < 4; x++) if (i + x < n) v[x] = in[i + x]; }
+  const u32 s = v[0] + v[1] + v[2] + v[3];
+  const u32 incl = wave_incl_scan(s, (int)lane);
+  if (lane == 63) wsum[wave] = incl;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  u32 a = incl - s, tot = 0;
+#pragma unroll
+  for (u32 w = 0; w < 16; w++) { const u32 x = wsum[w]; if (w < wave) a += x; tot += x; }
+  if (tid == 0) { agg[g] = tot; __threadfence(); __hip_atomic_store(&flags[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+  if (tid < g) {
+    while (__hip_atomic_load(&flags[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+    const u32 x = __hip_atomic_load(&agg[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (x) atomicAdd(&base_s, x);
+  }
+  __syncthreads();
+  a += base_s;
+#pragma unroll
+  for (u32 x = 0; x < 4; x++) { if (i + x < n) { out[i + x] = a; if (out2) out2[i + x] = a; } a += v[x]; }
+  // out[n] = the total: the thread whose values end at n (or thread 0 of workgroup 0 when there is nothing)
+  if (n == 0) { if (g == 0 && tid == 0) out[0] = 0; }
+  else if (i < n && i + 4 >= n) out[n] = a;
 }
 
 // ---- a bucket by sorting: keys into LDS, bitonic sort, run starts by neighbour compare, run lengths = counts (n <= CsCap<K>::cap).
@@ -651,9 +770,12 @@ void k_cs_compact(const K* __restrict__ tk, const u32* __restrict__ tc, const u3
 template <typename K>
 __global__ __launch_bounds__(CS_TPB)
 void k_cs_compact_recs(const K* __restrict__ tk, const u32* __restrict__ tc, const u32* __restrict__ boff, const u32* __restrict__ koff,
-                       const u32* __restrict__ bdst, u8* __restrict__ out)
+                       const u32* __restrict__ bdst, u8* __restrict__ out, const SkfCtl* __restrict__ ctl = nullptr, u32 cap_recs = 0)
 {
   constexpr u32 KWD = sizeof(K) / 4;      // key dwords
+  if (ctl) {      // the sync-free path: the grid covers a bound, `out` is room for cap_recs records reserved on an estimate
+    if (ctl->status || ctl->overflow || blockIdx.x >= ctl->TB || koff[ctl->TB] > cap_recs) return;
+  }
   const u32 b = blockIdx.x, src = boff[b], n = koff[b + 1] - koff[b];
   const u64 dst = bdst[b];
   for (u32 i = threadIdx.x; i < n; i += CS_TPB) {

@@ -86,6 +86,7 @@ struct kmx_fast_split {
   const uint4* d_parts;           // CsPart[n_parts]: the sample sort's layout (k_sk_scan)
   const kmx::u32* d_cfirst;       // [n_parts + 1] first walk chunk of every partition
   kmx::u32* d_cnt;                // [tb_max + 2] zeroed: the buckets' counters
+  kmx::u32* d_sflags;             // [2 * 256] zeroed: the flags of the two bucket scans (k_cs_scan_mw)
   kmx::u32 n_parts; kmx::u64 kmer_bound; kmx::u32 tb_max, nc_max, nb_max;      // bounds: k-mers, buckets, walk chunks, decode blocks
   kmx::SkfCtl* h_ctl;             // page-locked, 64 bytes: the control block as read back
   const uint4* h_parts;           // page-locked: d_parts as read back (the caller queued that copy on the context's stream)
@@ -110,6 +111,11 @@ struct kmx_store {
   std::vector<Chunk> chunks;
   std::mutex mu;
   void* alloc(size_t bytes);      // 256-byte aligned; nullptr: over the limit or out of device memory
+  // round 6: a count call that does not know its lists' size yet takes room for an estimate, has its kernel write there, and gives
+  // back what it did not need once the size is read back (one reservation at a time per store; while it is open, alloc() leaves its chunk alone)
+  int resv_chunk = -1; size_t resv_off = 0, resv_bytes = 0;
+  void* try_reserve(size_t bytes);              // nullptr: another reservation is open, or no room
+  void commit(void* p, size_t used_bytes);      // keeps the first used_bytes of the reservation (0: none of it)
 };
 
 struct kmx_ctx {
@@ -141,6 +147,7 @@ struct kmx_ctx {
   // COUNT / PA rows of the column-blocked pair come out in file order (the matrix body as the reference streams it,
   // merge.hpp:262-272): kmx_set_file_order, KMX_FILE_ORDER=0 for the rows where the kernels leave them + a directory
   bool file_order = true;
+  double kept_per_kmer = 0.0;           // kmx_count_reads_dev: distinct kept k-mers per k-mer as the last call had it (the next one reserves room in the store for 1.25 x that)
   double keys_per_longest = 0.0;        // row keys per record of the longest list they were merged from, as completed batches had it
   // abundance histogram (kmx_hist_reset / kmx_hist_read): distinct keys per count 0..255, [256] = keys counted more than 255
   // times, [257] = the sum of those counts.  Every count call adds to it while it is on.

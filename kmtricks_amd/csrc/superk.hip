@@ -961,7 +961,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   //      the call down the path below (which reads three sizes back and has the library sort the descriptors). ----
   {
     const char* fe = getenv("KMX_COUNT_FAST");      // (read per call: the tests switch it)
-    const bool fast = creq && creq->lists && !streams_to_host && !wide_k && !segs && nb_parts <= SKF_MAXP && two_pass && (!sd.any() || sd.deferred) && !ctx->hist_on &&
+    const bool fast = creq && creq->lists && !streams_to_host && !wide_k && !segs && nb_parts <= SKF_MAXP && total_bases < (500ULL << 20) && two_pass && (!sd.any() || sd.deferred) && !ctx->hist_on &&
                       !(fe && !strcmp(fe, "0")) && !getenv("KMX_COUNT_SORT") && !getenv("KMX_COUNT_BUCKETS") && total_bases >= 1;
     if (fast) {
       const u32 P = nb_parts, wpg = skf_wpg(P);
@@ -973,8 +973,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       const int kw = (int)((k + 31) / 32);
       const SkfLayout L = kmx_fast_layout(creq->hash_mode ? 1 : kw);
       const u32 tb_max = (u32)(kb / L.target) + P + 1, nc_max = (u32)(kb / L.chunk) + P + 1, nb_max = (u32)((kb + SKF_DK - 1) / SKF_DK) + 1;
-      // the zeroed block: [control 32 B][minimizers that occur, u64][pad to 64][k_sk_scan's flags][the sample sort's bucket counters]
-      const size_t z_flags = 64, z_cnt = z_flags + 128 * 4, z_bytes = z_cnt + ((size_t)tb_max + 2) * 4;
+      // the zeroed block: [control 32 B][minimizers that occur, u64][pad to 64][k_sk_scan's flags][the bucket scans' flags][the sample sort's bucket counters]
+      const size_t z_flags = 64, z_sfl = z_flags + 128 * 4, z_cnt = z_sfl + 512 * 4, z_bytes = z_cnt + ((size_t)tb_max + 2) * 4;
       u8* d_z = (u8*)ctx->dalloc(z_bytes);
       // what the host reads at the end, one copy: [pp (P + 1) u64][info 2 P u64][parts P uint4][pf (P + 1) u32][cfirst (P + 1) u32]
       const size_t P1f = (size_t)P + 1, o_info = P1f * 8, o_parts = o_info + (size_t)P * 16, o_pf = o_parts + (size_t)P * 16, o_cf = o_pf + P1f * 4, sumf = o_cf + P1f * 4;
@@ -1018,7 +1018,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       sd.launch_sparse(d_nspf, st);
       if ((e = hipGetLastError()) != hipSuccess) return ffail(e, "split kernels");
       if ((e = hipMemcpyAsync(h_f + 64, d_sumf, sumf, hipMemcpyDeviceToHost, st)) != hipSuccess) return ffail(e, "memcpy");
-      kmx_fast_split F{d_wordsf, d_sb, d_bo, d_p16, d_bf, d_ctl, d_partsf, d_cff, (u32*)(d_z + z_cnt), P, kb, tb_max, nc_max, nb_max,
+      kmx_fast_split F{d_wordsf, d_sb, d_bo, d_p16, d_bf, d_ctl, d_partsf, d_cff, (u32*)(d_z + z_cnt), (u32*)(d_z + z_sfl), P, kb, tb_max, nc_max, nb_max,
                        reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts)};
       const int frc = kmx_count_fast_tail(ctx, F, *creq);      // (waits for the stream: the copies above are through when it returns)
       if (frc < 0) { frel(); release(); return frc; }

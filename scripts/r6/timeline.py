@@ -10,10 +10,12 @@ for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + r.get("Bytes", r.get("Size", ""))))
 ev.sort()
-# calls are separated by the k_pack_bases / first k_superk_wave of a call: take the events after the last 'k_superk_wave<false' start
-idx = [i for i, e in enumerate(ev) if "k_superk_wave<false" in e[2] or "k_superk_one" in e[2] or "k_sk_" in e[2] and "walk" in e[2]]
+# a call starts at its k_pack_bases (the sync-free path: behind one fill) or, the old path, at its first k_superk_wave<false
+idx = [i for i, e in enumerate(ev) if "k_pack_bases" in e[2]]
+old = [i for i, e in enumerate(ev) if "k_superk_wave<false" in e[2]]
 start = idx[-1] if idx else 0
-while start > 0 and ev[start][0] - ev[start - 1][1] < 200_000 and ev[start - 1][2].startswith(("COPY", "__amd")): start -= 1
+if old and old[-1] < start and start - old[-1] < 25: start = old[-1]
+while start > 0 and ev[start - 1][2].startswith("__amd_rocclr_fill") and ev[start][0] - ev[start - 1][1] < 100_000: start -= 1
 sel = ev[start:]
 t0 = sel[0][0]; busy = 0; prev_end = t0
 for s, e, n in sel:
