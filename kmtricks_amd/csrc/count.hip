@@ -1005,6 +1005,9 @@ static int decode_and_count(kmx_ctx* ctx, StageClock& clk, const u8* d_recs, con
     rc = kw == 3 ? partition_sort_count<WideKey<3>>(ctx, clk, (WideKey<3>*)d_keys, kmoff, n_parts, hard_min, co)
                  : partition_sort_count<WideKey<4>>(ctx, clk, (WideKey<4>*)d_keys, kmoff, n_parts, hard_min, co);
     if (rc == 1) {
+      // (a bucket beyond the LDS sort: wide keys are split on their two most significant words only, so k-mers that share their first 33-64
+      //  bases -- low-complexity reads -- crowd one bucket: the whole batch then takes the word-by-word library sort.  KMX_TRACE says so.)
+      if (list_copy_trace()) fprintf(stderr, "[kmx count] k = %u: a bucket of the sample sort overflowed -- the batch (%llu k-mers) goes through the library's radix passes\n", k, (unsigned long long)total);
       if (!co.dev()) for (u32 p = 0; p < n_parts; p++) { free(co.keys[p]); free(co.counts[p]); co.keys[p] = nullptr; co.counts[p] = nullptr; co.n_out[p] = 0; }
       rc = wide_sort_count(ctx, clk, (const u64*)d_keys, kw, kmoff, n_parts, (u32)total, hard_min, co);
     }
@@ -1195,7 +1198,7 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   if (S0 && ctx->kept_per_kmer > 0.0) {
     cap_recs = (u32)std::min<double>((double)kb, (double)kb * ctx->kept_per_kmer * 1.25 + 65536.0);
     d_resv = (u8*)S0->try_reserve((size_t)cap_recs * RB);
-    if (d_resv) hipLaunchKernelGGL((k_cs_compact_recs<KeyT>), dim3(TBm), dim3(CS_TPB), 0, st, d_tk, d_tc, d_boff, d_koff, (const u32*)d_koff, d_resv, (const SkfCtl*)F.d_ctl, cap_recs);
+    if (d_resv) hipLaunchKernelGGL((k_cs_compact_recs<KeyT>), dim3((TBm + CS_TPB / 64 - 1) / (CS_TPB / 64)), dim3(CS_TPB), 0, st, d_tk, d_tc, d_boff, d_koff, (const u32*)d_koff, d_resv, (const SkfCtl*)F.d_ctl, cap_recs);
   }
   struct Resv { kmx_store* s; u8* p; ~Resv() { if (s && p) s->commit(p, 0); } } resv{S0, d_resv};      // (left open by an error: given back)
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "count kernels");

@@ -219,24 +219,6 @@ template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32
   while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (spl[mid] <= k) lo = mid + 1; else hi = mid; }
   return lo;
 }
-// the same for N keys in step (round 6): every key tries the same stride at the same time -- N independent LDS reads in flight a
-// thread instead of one dependent read after another (a walk's time was half these searches).  top = the largest power of two
-// <= nb - 1 (0 when nb == 1); keys the caller does not hold get any value.
-template <typename S_t, int N> __device__ __forceinline__ void cs_bucket_n(const S_t* spl, u32 nb, u32 top, const S_t (&t)[N], u32 (&b)[N])
-{
-#pragma unroll
-  for (int x = 0; x < N; x++) b[x] = 0;
-  for (u32 step = top; step > 0; step >>= 1) {
-#pragma unroll
-    for (int x = 0; x < N; x++) {
-      const u32 at = b[x] + step;      // would be the number of splitters <= key: the at-th one (index at - 1) must exist and be <= key
-      const u32 idx = min(at, nb - 1u) - 1u;
-      const bool ok = at <= nb - 1u && spl[idx] <= t[x];
-      b[x] = ok ? at : b[x];
-    }
-  }
-}
-
 // SCATTER = false: bucket sizes.  SCATTER = true: keys to their buckets (cursor[] starts at the buckets' offsets).
 // (Round 3 tried ordering the chunk by bucket in LDS first, so that the ~5 keys a chunk holds for a bucket leave as adjacent lanes
 //  of one store: 0.32 -> 0.36 ms for the 24 M k-mer sample -- the pieces are as small either way; not kept.)
@@ -265,14 +247,13 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
   __syncthreads();
   K k[IPT]; u32 bk[IPT], rk[IPT];
-  {
-    S_t tp[IPT];
+  // (round 6 tried the IPT searches in step -- every key the same stride at the same time, IPT LDS reads in flight a thread: 70 -> 81 us
+  //  for the count walk of the 24 M k-mer sample, +-0 for the staged scatter: the registers it takes cost more than the latency it hides)
 #pragma unroll
-    for (int x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; k[x] = keys[C.key0 + (i < C.nkeys ? i : 0u)]; tp[x] = CsSpl<K>::top(k[x]); }
-    u32 top = 0; if (P.nb > 1) { top = 1; while (top * 2 <= P.nb - 1) top *= 2; }
-    cs_bucket_n<S_t, IPT>(spl, P.nb, top, tp, bk);
-#pragma unroll
-    for (int x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; if (i < C.nkeys) rk[x] = atomicAdd(&hist[bk[x]], 1u); else bk[x] = 0xFFFFFFFFu; }
+  for (int x = 0; x < IPT; x++) {
+    const u32 i = tid + x * CS_WALK_TPB;
+    bk[x] = 0xFFFFFFFFu;
+    if (i < C.nkeys) { k[x] = keys[C.key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
   }
   __syncthreads();
   if (!SCATTER) { for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) if (hist[b]) atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]); return; }
@@ -315,14 +296,11 @@ void k_cs_scatter_staged(const K* __restrict__ keys, const CsPart* __restrict__ 
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
   __syncthreads();
   K k[IPT]; u32 bk[IPT], rk[IPT];
-  {
-    S_t tp[IPT];
 #pragma unroll
-    for (u32 x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; k[x] = keys[key0 + (i < nkeys ? i : 0u)]; tp[x] = CsSpl<K>::top(k[x]); }
-    u32 top = 0; if (P.nb > 1) { top = 1; while (top * 2 <= P.nb - 1) top *= 2; }
-    cs_bucket_n<S_t, (int)IPT>(spl, P.nb, top, tp, bk);
-#pragma unroll
-    for (u32 x = 0; x < IPT; x++) { const u32 i = tid + x * CS_WALK_TPB; if (i < nkeys) rk[x] = atomicAdd(&hist[bk[x]], 1u); else bk[x] = 0xFFFFFFFFu; }
+  for (u32 x = 0; x < IPT; x++) {
+    const u32 i = tid + x * CS_WALK_TPB;
+    bk[x] = 0xFFFFFFFFu;
+    if (i < nkeys) { k[x] = keys[key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
   }
   __syncthreads();
   // the buckets' places in `stage`: exclusive scan of hist (two entries a thread: CS_MAXB = 2 * CS_WALK_TPB), their room in `out`
@@ -773,12 +751,14 @@ void k_cs_compact_recs(const K* __restrict__ tk, const u32* __restrict__ tc, con
                        const u32* __restrict__ bdst, u8* __restrict__ out, const SkfCtl* __restrict__ ctl = nullptr, u32 cap_recs = 0)
 {
   constexpr u32 KWD = sizeof(K) / 4;      // key dwords
-  if (ctl) {      // the sync-free path: the grid covers a bound, `out` is room for cap_recs records reserved on an estimate
-    if (ctl->status || ctl->overflow || blockIdx.x >= ctl->TB || koff[ctl->TB] > cap_recs) return;
+  u32 b = blockIdx.x, t0 = threadIdx.x, step = CS_TPB;
+  if (ctl) {      // the sync-free path: the grid covers a bound, `out` is room for cap_recs records reserved on an estimate; a WAVE per bucket (a bucket keeps ~80 pairs)
+    b = blockIdx.x * (CS_TPB / 64) + (threadIdx.x >> 6); t0 = threadIdx.x & 63u; step = 64;
+    if (ctl->status || ctl->overflow || b >= ctl->TB || koff[ctl->TB] > cap_recs) return;
   }
-  const u32 b = blockIdx.x, src = boff[b], n = koff[b + 1] - koff[b];
+  const u32 src = boff[b], n = koff[b + 1] - koff[b];
   const u64 dst = bdst[b];
-  for (u32 i = threadIdx.x; i < n; i += CS_TPB) {
+  for (u32 i = t0; i < n; i += step) {
     u32* o = reinterpret_cast<u32*>(out + (dst + i) * (u64)(sizeof(K) + 4));
     const K k = tk[src + i];
 #pragma unroll

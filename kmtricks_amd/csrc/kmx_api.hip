@@ -938,6 +938,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     for (auto& G : R->subs) ctx->dfree(G.d_out);
     ctx->dfree(R->d_meta); ctx->hfree(R->h_meta); ctx->dfree(R->d_rem); R->d_rem = nullptr;
   };
+  bool narrow_failed = false;
   for (auto& H : R->tasks) {
     H.d_out = (u8*)ctx->dalloc(H.out_bytes);
     if (H.d_out && cols) {
@@ -965,13 +966,14 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
         if (R->cols_narrow) {      // [N count bytes, padded to 16][16 bytes: a flag byte per column block]
           H.npitch = (u32)align_up((size_t)H.N, 16) + 16;
           H.d_narrow = (u8*)ctx->dalloc((size_t)H.dense_cap * H.npitch);
-          if (!H.d_narrow) { ctx->dfree(H.d_dense); H.d_dense = nullptr; }
+          if (!H.d_narrow) narrow_failed = true;      // (no room for the byte-wide rows: the batch runs with the 4-byte rows alone, as before round 5)
         }
       }
     }
     if (!H.d_out || (cols && !H.d_ov) || (R->cols_ord && !H.d_dense)) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "output arena allocation failed"); }
 
   }
+  if (narrow_failed) { for (auto& H : R->tasks) { ctx->dfree(H.d_narrow); H.d_narrow = nullptr; } R->cols_narrow = false; }      // (decided before the ColsDev structs are filled)
   for (auto& Q : R->subs) {
     Q.d_out = (u8*)ctx->dalloc(Q.out_bytes);
     if (!Q.d_out) { drop_blocks(); return ctx->fail(KMX_E_NOMEM, "row-key arena allocation failed"); }
@@ -1576,6 +1578,7 @@ extern "C" void kmx_result_free(kmx_merge_result* R)
   ctx->dfree(R->d_rem);
   if (R->ev_in) (void)hipEventDestroy(R->ev_in);
   if (R->ev0) { (void)hipEventDestroy(R->ev0); (void)hipEventDestroy(R->ev1); }
+  if (R->ev_mid) (void)hipEventDestroy(R->ev_mid);
   if (R->ev2) (void)hipEventDestroy(R->ev2);
   if (R->ev_pre) (void)hipEventDestroy(R->ev_pre);
   if (R->ev_up) (void)hipEventDestroy(R->ev_up);

@@ -80,7 +80,7 @@ constexpr int CL_NW = CL_TPB / 64;
 constexpr int CK_BITS = 1 << 17;         // k_cols_sparse: bits of the key map (16 KB of LDS)
 constexpr int CP_MAXSEG = 2048;          // k_cols_prep: segments of the row-key merge
 
-__device__ u32 kmx_cols_dbg[16];     // why tasks were handed back (KMX_TRACE=1 prints and clears them); [8..11]: look-backs given up, the last one's task order / group / entries still to add
+__device__ u32 kmx_cols_dbg[16];     // why tasks were handed back (KMX_TRACE=1 prints and clears them); [8..11]: look-backs given up, the last one's task order / group / entries still to add; [12]: tasks handed back for it
 
 namespace {
 
@@ -945,7 +945,7 @@ constexpr u32 CK_OVF = 0xFFFFFFFFu;      // a pass found more candidates than th
 // milliseconds): then it gives up (returns ~0: the caller hands the task back to the general kernel and the chain goes on with a prefix
 // of 0), so that whatever keeps an entry from being published costs a task its fast path, not the launch its end.
 constexpr u32 CK_LB_SPINS = 1u << 20;
-__device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mine, const u32 lane)
+__device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mine, const u32 lane, u64* err /* the task's error word: ERR_FALLBACK is raised there BEFORE a give-up publishes its empty prefix */)
 {
   constexpr u64 VAL = (1ULL << 62) - 1ULL;
   u32 spins = 0;
@@ -970,6 +970,8 @@ __device__ __forceinline__ u64 ck_lookback(u64* chain, const u32 g, const u64 mi
       __builtin_amdgcn_s_sleep(8);
       if (++spins > CK_LB_SPINS) {
         if (lane == 0) {
+          atomicOr(err, (u64)ERR_FALLBACK);      // (first: a later group that reads the empty prefix below finds the task handed back already)
+          __threadfence();
           __hip_atomic_store(&chain[g], 2ULL << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicAdd(&kmx_cols_dbg[8], 1u); kmx_cols_dbg[10] = g; kmx_cols_dbg[11] = i;
         }
@@ -1663,12 +1665,12 @@ void k_cols_sparse(const TaskDev* __restrict__ tasks, const ColsDev* __restrict_
       npass *= 2;      // (an uneven stretch of keys: finer passes)
     }
     const u64 grows = failed ? 0ULL : (u64)dn + nks;
-    if (wave == 0) { const u64 b = ck_lookback(C.chain, gord, grows, lane); if (lane == 0) s_base = b; }
+    if (wave == 0) { const u64 b = ck_lookback(C.chain, gord, grows, lane, &T.ctrl[2]); if (lane == 0) s_base = b; }
     else if (npass == 1 && !failed && tid - 64u < dn) dense_places(tid - 64u, nks, 0, dn);      // (beside the look-back: where the row keys' rows go)
     __syncthreads();
     SPPH(5);
     if (failed) return false;
-    if (s_base == ~0ULL) { hand_back(2); return false; }      // (the look-back gave up: see ck_lookback)
+    if (s_base == ~0ULL) { hand_back(12); return false; }      // (the look-back gave up: see ck_lookback; its own counter -- [2] counts kept keys outside the row keys)
     // (the task's row counters: behind the rows, where no barrier waits for the atomics -- the next one is the next ticket's)
     auto count_rows = [&]() { if (tid == 0 && nks) { atomicAdd(&T.ctrl[0], (u64)nks); atomicAdd(&T.ctrl[3], (u64)nks); atomicAdd(&T.ctrl[6], (u64)nks); } };
     const u64 base = s_base;

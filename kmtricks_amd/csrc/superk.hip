@@ -966,7 +966,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     if (fast) {
       const u32 P = nb_parts, wpg = skf_wpg(P);
       const u32 n_chunks = (u32)((n_seqs + SKF_RPW - 1) / SKF_RPW), R = (n_chunks + wpg - 1) / wpg;
-      const u32 rpg = std::max<u32>(16u, (R + 127u) / 128u), Gc = (R + rpg - 1) / rpg;
+      const u32 rpg = std::max<u32>(32u, (R + 127u) / 128u), Gc = (R + rpg - 1) / rpg;      // (k_sk_scan: at most 128 workgroups; its time goes with their number -- 16 rows each: 32 us, 7: 53 us)
       u32 pbits = 1; while ((1u << pbits) < P) pbits++;
       const u64 kb = total_bases;                                                   // k-mers of the batch: fewer than bases
       const u32 nd_cap = (u32)std::min<u64>(total_bases, total_bases / 4 + n_seqs + 1024);      // records the sorted arrays take (a super-k-mer holds ~9 k-mers; beyond: the old path)

@@ -584,7 +584,7 @@ int run(int argc, char** argv)
     // 0.71 -> 0.49 ms per sample at n = 4 when the call is timed by itself, scripts/bench_count_multi.py).  Through this driver it does
     // not pay yet: 1000 x 1 Mbp count in 0.89-0.95 s at n = 4 against 0.63 s at n = 1 (--skip-partiinfo; two workers), so the default is 1.
     uint32_t per_call = o.per_call ? o.per_call : getenv("KMX_COUNT_SAMPLES_PER_CALL") ? (uint32_t)std::max(1L, atol(getenv("KMX_COUNT_SAMPLES_PER_CALL"))) : 1u;
-    if (o.k >= 64) per_call = 1;      // (kmx_count_reads_dev_multi takes keys of one and two words: wider k-mers go a sample a call)
+    if (o.k >= 64) per_call = 1;      // (kmx_count_reads_dev_multi refuses k >= 64 -- the split of such k-mers, k_superk_wide, takes one sample a call; k = 64 is a two-word key but a wide split: the guard stays >= 64)
     rawpool.cap = ((size_t)per_call + 2) * NW + 2; rawpool.words = raw_words;
     std::atomic<uint32_t> next_sample{0};
     // A sample's batches must reach its worker in order; samples are taken in fof order by `readers` threads per round so the
@@ -993,15 +993,16 @@ int run(int argc, char** argv)
         // else counted: the files of a build with MAX_C <= 65535 hold 1- or 2-byte counts (CMakeLists.txt:25-41, utils.hpp:311-327; the
         // reference's own fixtures do) -- those go through read_kmer_records, which widens them
         bool direct = !hash_mode && !o.cpr;
-        if (direct && o.merge_only) {
-          for (size_t j = 0; j < parts.size() * N && direct; j++) {
-            if (res_flag[j % N] || sz[j] < 41) continue;
+        if (direct && o.merge_only) {      // (every file's header: a directory may mix builds, or hold an lz4 file among plain ones -- ADVICE r5)
+          std::atomic<int> widen{0};
+          pool.for_each(parts.size() * N, [&](size_t j) {
+            if (res_flag[j % N] || sz[j] < 41 || widen.load(std::memory_order_relaxed)) return;
             const std::string path = count_path(parts[j / N], (uint32_t)(j % N));
             const int fd = open(path.c_str(), O_RDONLY); uint8_t h[41];
-            if (fd < 0 || pread(fd, h, 41, 0) != 41 || rd<uint32_t>(h + 29) != 4 || h[12] != 0) direct = false;
+            if (fd < 0 || pread(fd, h, 41, 0) != 41 || rd<uint32_t>(h + 29) != 4 || h[12] != 0) widen = 1;
             if (fd >= 0) close(fd);
-            break;      // (a directory's files come from one build: the first one tells)
-          }
+          });
+          if (widen) direct = false;
         }
         B.parts.resize(parts.size());
         for (size_t a = 0; a < parts.size(); a++) {      // the resident lists: merged where they lie

@@ -336,9 +336,25 @@ class Context:
                 _lib.kmx_free(ob[p])
         return out, [int(x) for x in nk], st, np.array(list(info), dtype=np.uint64).reshape(nb_parts, 2)
 
-    def count_reads_dev(self, reads, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False, sparse=False, ahead=False):
+    def upload_reads(self, blob):
+        """kmx_reads_upload: the bases of a batch sent to the device ahead of the count call (from page-locked memory, on the context's
+        upload stream) -> a handle for count_reads_dev(resident=...) and release_reads.  What `kmx pipeline` does with the NEXT
+        sample while this one is counted."""
+        n = len(blob)
+        pin = _lib.kmx_alloc_pinned(max(n, 1))
+        C.memmove(pin, blob, n)
+        dev = _vp()
+        self._check(_lib.kmx_reads_upload(self._h, pin, n, C.byref(dev)), "kmx_reads_upload")
+        return (dev, pin)
+
+    def release_reads(self, handle):
+        _lib.kmx_reads_release(self._h, handle[0])
+        _lib.kmx_free_pinned(handle[1])
+
+    def count_reads_dev(self, reads, k, m, repart, nb_parts, hard_min, stores, window=0, raw=False, sparse=False, ahead=False, resident=None):
         """kmx_count_reads_dev: as count_reads, the results left on the device as packed records in `stores` (partition p ->
-        stores[p % len(stores)]) -> ([(device pointer, records)] per partition, k-mers per partition, raw tables or None)"""
+        stores[p % len(stores)]) -> ([(device pointer, records)] per partition, k-mers per partition, raw tables or None).
+        resident: a handle of upload_reads for the same bases (the call is given the device pointer; the handle stays the caller's)"""
         blob, offs = reads if isinstance(reads, tuple) else self.pack_reads(reads)
         rep = np.ascontiguousarray(repart, dtype=np.uint16)
         sp = (_vp * len(stores))(*[s._h for s in stores])
@@ -352,14 +368,17 @@ class Context:
                 spt = np.zeros((4 ** m, 3), np.uint32)
                 rw = KmxSuperkRaw(tabs[0].ctypes.data, None, None, 0, spt.ctypes.data, 4 ** m, 0)
         dev = None
-        if ahead:      # kmx_reads_upload: the bases sent to the device ahead of the call (from page-locked memory), the call given the device pointer
+        if resident is not None:
+            ahead = False
+            blob_arg = C.cast(resident[0], C.c_char_p)
+        elif ahead:      # kmx_reads_upload: the bases sent to the device ahead of the call (from page-locked memory), the call given the device pointer
             n = len(blob)
             pin = _lib.kmx_alloc_pinned(max(n, 1))
             C.memmove(pin, blob, n)
             dev = _vp()
             self._check(_lib.kmx_reads_upload(self._h, pin, n, C.byref(dev)), "kmx_reads_upload")
             blob_arg = C.cast(dev, C.c_char_p)
-        else:
+        elif resident is None:
             blob_arg = blob
         try:
             self._check(_lib.kmx_count_reads_dev(self._h, blob_arg, offs.ctypes.data, len(offs) - 1, k, m, rep.ctypes.data, nb_parts,

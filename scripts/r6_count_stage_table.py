@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r5cs/{kernel_stats.csv, counters.txt, bench.json} (scripts/r5_count_stage_profile.sh) -> profiles/count_stage_kernels.json:
+"""gpurun_out/r6cs/{kernel_stats.csv, counters.txt, bench.json} (scripts/r6_count_stage_profile.sh) -> profiles/count_stage_kernels.json:
 per kernel of the count stage its calls and time per sample, the wave instructions it issues and two fractions --
   issue = (VALU wave instructions x 2 cycles on a SIMD-32 + the other classes x 1) / (1024 SIMDs x 2.4 GHz x its time): how much of the chip's
           issue capacity the kernel uses (MI355X_MICROARCH.md: a wave64 VALU instruction takes a SIMD-32 for 2 cycles),
@@ -7,10 +7,10 @@ per kernel of the count stage its calls and time per sample, the wave instructio
 and the stage's algorithmic bytes (super-k-mer bytes + 12 per distinct solid k-mer) over the sum of the kernels' times."""
 import csv, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5cs")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r6cs")
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "count_stage_kernels.json")
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-reps = 20 + 3 + 1      # timed calls + warm-up calls + the count_reads call of the same shape behind them
+reps = 20 + 3      # timed calls + warm-up calls (round 6: the profiled runs skip the count_reads call that writes the record streams)
 def short(n):
     n = n.split("(")[0]
     return n.replace("kmx::", "").replace("void ", "").strip()
@@ -35,7 +35,7 @@ for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["total_ns"]):
                  "issue_frac": issue, "hbm_frac": hbm, "library": k.startswith("rocprim") or "rocprim::" in k})
 kern_us = tot_ns / reps / 1e3
 doc = {"_note": "one 30-Mbase sample (5 Mbp x 6x, 150-bp reads, k = 31, m = 10) through kmx_count_reads_dev; rocprofv3 --kernel-trace --stats and --pmc passes of their own "
-                "(scripts/r5_count_stage_profile.sh, scripts/r5_count_stage_table.py); issue_frac = (2 VALU + SALU + LDS + VMEM wave instructions) / (1024 SIMDs x 2.4 GHz x time), "
+                "(scripts/r6_count_stage_profile.sh, scripts/r6_count_stage_table.py); issue_frac = (2 VALU + SALU + LDS + VMEM wave instructions) / (1024 SIMDs x 2.4 GHz x time), "
                 "hbm_frac = (2 FETCH_SIZE + WRITE_SIZE) / time / 8 TB/s",
        "sample": {k: bench[k] for k in ("genome", "bases", "kmers", "superk_bytes", "distinct_solid", "partitions", "algorithmic_bytes", "count_reads_dev_ms_median")},
        "kernels_us_per_sample": kern_us, "launches_per_sample": sum(r["calls_per_sample"] for r in rows),
