@@ -1182,6 +1182,7 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
     hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
   else
     hipLaunchKernelGGL((k_cs_scatter_staged<KeyT>), dim3(F.nc_max * (cs_chunk<KeyT>() / cs_schunk<KeyT>())), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+  if (F.behind_scatter) { const int brc = F.behind_scatter(); if (brc != KMX_OK) { (void)hipStreamSynchronize(st); release(); return brc; } }
   hipLaunchKernelGGL((k_cs_wave_sort<KeyT, 8, 16>), dim3((TBm + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, d_bkeys, d_boff, 0u, 0u, (u32)CsCap<KeyT>::cap,
                      rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, F.d_ctl, d_big);
   // the buckets beyond a wave's registers (a k-mer repeated a thousand times, an unlucky sample): listed by the kernel above, a few workgroups take them
@@ -1203,8 +1204,9 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   struct Resv { kmx_store* s; u8* p; ~Resv() { if (s && p) s->commit(p, 0); } } resv{S0, d_resv};      // (left open by an error: given back)
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "count kernels");
   if ((e = hipMemcpyAsync(F.h_ctl, F.d_ctl, 64, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(h_koff, d_koff, 4 * ((size_t)TBm + 2), hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count read-back");
+      (e = hipMemcpyAsync(h_koff, d_koff, 4 * ((size_t)TBm + 2), hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "count read-back");
+  if (F.before_wait) { const int brc = F.before_wait(); if (brc != KMX_OK) { (void)hipStreamSynchronize(st); release(); return brc; } }
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count read-back");
   clk.mark("split+decode+sort+count");
   if (clk.on) fprintf(stderr, "[kmx count_reads_fast] records %u k-mers %u buckets %u walk chunks %u listed buckets %u status %u overflow %u\n", F.h_ctl->nd, F.h_ctl->total, F.h_ctl->TB, F.h_ctl->NC, F.h_ctl->n_big, F.h_ctl->status, F.h_ctl->overflow);
   if (F.h_ctl->status || F.h_ctl->overflow) { release(); return 1; }

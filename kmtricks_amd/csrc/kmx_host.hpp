@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <functional>
 #include <vector>
 #include "kmx_dev.hpp"
 #include "skf.hpp"
@@ -90,6 +91,8 @@ struct kmx_fast_split {
   kmx::u32 n_parts; kmx::u64 kmer_bound; kmx::u32 tb_max, nc_max, nb_max;      // bounds: k-mers, buckets, walk chunks, decode blocks
   kmx::SkfCtl* h_ctl;             // page-locked, 64 bytes: the control block as read back
   const uint4* h_parts;           // page-locked: d_parts as read back (the caller queued that copy on the context's stream)
+  std::function<int()> behind_scatter;   // run right after the scatter walk is queued: the caller starts its work on the second stream there (the kernels up to the scatter fill the LDS, the wave sort behind it uses none)
+  std::function<int()> before_wait;      // run once everything is queued, before the stream is waited for (the caller's work on its second stream)
 };
 kmx::SkfLayout kmx_fast_layout(int key_words /* of the sort's keys: 1 (k <= 32, hashes) or 2 */);
 int kmx_count_fast_tail(kmx_ctx* ctx, const kmx_fast_split& F, const kmx_count_req& rq);
@@ -128,6 +131,7 @@ struct kmx_ctx {
   struct ReadsAhead { char* d = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool live = false; };      // kmx_reads_upload
   ReadsAhead ahead[4];
   hipStream_t aux = nullptr;            // second stream: meta uploads, scratch clears (and, with KMX_COLS_PREP_OVERLAP, the small kernels that prepare a batch)
+  hipEvent_t ev_split = nullptr;        // kmx_count_reads_dev: the split is through -- the PartiInfo statistics run on `aux` beside the count kernels from here
   int n_cu = 0;
   std::string err;
   bool profiling = false;

@@ -979,7 +979,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       // what the host reads at the end, one copy: [pp (P + 1) u64][info 2 P u64][parts P uint4][pf (P + 1) u32][cfirst (P + 1) u32]
       const size_t P1f = (size_t)P + 1, o_info = P1f * 8, o_parts = o_info + (size_t)P * 16, o_pf = o_parts + (size_t)P * 16, o_cf = o_pf + P1f * 4, sumf = o_cf + P1f * 4;
       u8* d_sumf = (u8*)ctx->dalloc(sumf);
-      u8* h_f = (u8*)ctx->halloc(64 + sumf);
+      u8* h_f = (u8*)ctx->halloc(64 + sumf + 24);      // (+ the statistics' own read-back word, behind everything the main stream's copies write)
       struct HRelF { kmx_ctx* c; void* p; ~HRelF() { c->hfree(p); } } h_f_rel{ctx, h_f};
       SkDesc* d_descf = (SkDesc*)ctx->dalloc(((size_t)total_bases + 64) * sizeof(SkDesc));
       u32* d_ccnt = (u32*)ctx->dalloc((size_t)n_chunks * 4);
@@ -1014,16 +1014,42 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       hipLaunchKernelGGL(k_sk_scatter, dim3(R), dim3(64 * wpg), (size_t)wpg * P * 12, st, d_descf, d_offs, d_ccnt, n_chunks, wpg, P, pbits, (u32)k, d_T, d_ctl,
                          d_sb, d_bo, d_idf, d_p16, d_bf);
       if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((P + 63) / 64), dim3(64), 0, st, d_pff, d_bo, P, d_infof);
-      sd.launch_part_stats(d_idf, d_pff, d_bases, k, d_nspf, st);
-      sd.launch_sparse(d_nspf, st);
+      // the PartiInfo statistics (kmx_superk_raw): from the sorted descriptors, on the context's SECOND stream beside the count kernels --
+      // k_part_stats is a workgroup per partition waiting on gathers and LDS atomics (150 us by itself), the count kernels are bound by
+      // their instructions.  Their tables travel back on that stream as well, before the count is through (before_wait below).
+      hipStream_t sx = ctx->aux ? ctx->aux : st;
+      u64* h_nsp = reinterpret_cast<u64*>(h_f + ((64 + sumf + 7) & ~(size_t)7));      // (the minimizers that occur, read back on the second stream: its own 8 bytes -- the control block's 64 land at h_f whenever the main stream gets there)
+      auto launch_stats = [&]() -> int {      // (behind the scatter walk of the sample sort: up to there the count's kernels want the LDS k_part_stats holds -- started behind the split it kept k_cs_splitters off the CUs: 40 -> 160 us)
+        hipError_t er = hipSuccess;
+        if (sx != st) {
+          if (!ctx->ev_split) er = hipEventCreateWithFlags(&ctx->ev_split, hipEventDisableTiming);
+          if (er == hipSuccess) er = hipEventRecord(ctx->ev_split, st);
+          if (er == hipSuccess) er = hipStreamWaitEvent(sx, ctx->ev_split, 0);
+          aux_busy = true;
+        }
+        if (er == hipSuccess) {
+          sd.launch_part_stats(d_idf, d_pff, d_bases, k, d_nspf, sx);
+          sd.launch_sparse(d_nspf, sx);
+          er = hipMemcpyAsync(h_nsp, d_nspf, 8, hipMemcpyDeviceToHost, sx);
+        }
+        return er == hipSuccess ? KMX_OK : ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(er));
+      };
       if ((e = hipGetLastError()) != hipSuccess) return ffail(e, "split kernels");
       if ((e = hipMemcpyAsync(h_f + 64, d_sumf, sumf, hipMemcpyDeviceToHost, st)) != hipSuccess) return ffail(e, "memcpy");
       kmx_fast_split F{d_wordsf, d_sb, d_bo, d_p16, d_bf, d_ctl, d_partsf, d_cff, (u32*)(d_z + z_cnt), (u32*)(d_z + z_sfl), P, kb, tb_max, nc_max, nb_max,
-                       reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts)};
+                       reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts), nullptr, nullptr};
+      if (sd.deferred) F.behind_scatter = launch_stats;
+      bool raw_queued = false;
+      if (raw && sd.deferred && sx != st)
+        F.before_wait = [&]() -> int {      // the statistics are through long before the count: their size is read, their copies queued behind them
+          if (hipStreamSynchronize(sx) != hipSuccess) return ctx->fail(KMX_E_HIP, "superk statistics: the second stream failed");
+          raw_queued = true;
+          return sd.finish_raw(ctx, h_nsp, sx);
+        };
       const int frc = kmx_count_fast_tail(ctx, F, *creq);      // (waits for the stream: the copies above are through when it returns)
-      if (frc < 0) { frel(); release(); return frc; }
+      if (frc < 0) { if (sx != st) (void)hipStreamSynchronize(sx); frel(); release(); return frc; }
       const SkfCtl* hc = reinterpret_cast<const SkfCtl*>(h_f);
-      if (frc == 0 && (hc->status & SKF_ST_PART)) { frel(); release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
+      if (frc == 0 && (hc->status & SKF_ST_PART)) { if (sx != st) (void)hipStreamSynchronize(sx); frel(); release(); return ctx->fail(KMX_E_INVAL, "repartition table names a partition >= nb_parts"); }
       if (frc == 0) {
         const u64* ppf = reinterpret_cast<const u64*>(h_f + 64);
         sd.compacted();
@@ -1032,16 +1058,19 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
         if (raw) {
           raw[0].nb_superk = hc->nd;
           aux_busy = true;
-          const u64 nsp = *reinterpret_cast<const u64*>(h_f + 32);
-          const int rc = sd.finish_raw(ctx, &nsp, ctx->aux ? ctx->aux : st);
-          if (rc != KMX_OK) { frel(); release(); return rc; }
-          if ((e = hipStreamSynchronize(ctx->aux ? ctx->aux : st)) != hipSuccess) return ffail(e, "sync");
+          if (!raw_queued) {
+            if (sx != st && (e = hipStreamSynchronize(sx)) != hipSuccess) return ffail(e, "sync");
+            const int rc = sd.finish_raw(ctx, h_nsp, sx);
+            if (rc != KMX_OK) { frel(); release(); return rc; }
+          }
+          if ((e = hipStreamSynchronize(sx)) != hipSuccess) return ffail(e, "sync");
         }
         frel(); release();
         return KMX_OK;
       }
       // (a status bit: the old path takes the call from the start -- the statistics of the abandoned pass are cleared)
       if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx count] the sync-free path handed the call back (status %u, overflow %u)\n", hc->status, hc->overflow);
+      if (sx != st && (e = hipStreamSynchronize(sx)) != hipSuccess) return ffail(e, "sync");      // (the statistics kernels of the abandoned pass)
       frel();
       if (sd.deferred) { ctx->dfree(sd.S.sk_rec); sd.S.sk_rec = nullptr; }
       if ((e = sd.clear(st)) != hipSuccess) return fail(e, "memset");
