@@ -1205,8 +1205,12 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "count kernels");
   if ((e = hipMemcpyAsync(F.h_ctl, F.d_ctl, 64, hipMemcpyDeviceToHost, st)) != hipSuccess ||
       (e = hipMemcpyAsync(h_koff, d_koff, 4 * ((size_t)TBm + 2), hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "count read-back");
+  kmx_count_chain_end(ctx);      // (everything of this call is queued: the next call of this GPU may start behind it)
+  kmx_phase_mark(3);
   if (F.before_wait) { const int brc = F.before_wait(); if (brc != KMX_OK) { (void)hipStreamSynchronize(st); release(); return brc; } }
+  kmx_phase_mark(4);
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count read-back");
+  kmx_phase_mark(5);
   clk.mark("split+decode+sort+count");
   if (clk.on) fprintf(stderr, "[kmx count_reads_fast] records %u k-mers %u buckets %u walk chunks %u listed buckets %u status %u overflow %u\n", F.h_ctl->nd, F.h_ctl->total, F.h_ctl->TB, F.h_ctl->NC, F.h_ctl->n_big, F.h_ctl->status, F.h_ctl->overflow);
   if (F.h_ctl->status || F.h_ctl->overflow) { release(); return 1; }
@@ -1221,6 +1225,7 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
     }
     S0->commit(d_resv, (size_t)h_koff[TB] * RB); resv.p = nullptr;
     release();
+    kmx_phase_mark(6);
     return KMX_OK;
   }
   if (d_resv) { S0->commit(d_resv, 0); resv.p = nullptr; }      // (more kept than estimated: the exact way)

@@ -126,6 +126,7 @@ extern "C" void kmx_destroy(kmx_ctx* ctx)
   if (ctx->d_stat) (void)hipFree(ctx->d_stat);
   for (auto& b : ctx->hpool) if (b.p) kmx_pinned_free(b.p);
   (void)hipStreamDestroy(ctx->stream);
+  kmx_count_chain_forget(ctx);
   if (ctx->ev_split) (void)hipEventDestroy(ctx->ev_split);
   (void)hipStreamDestroy(ctx->aux);
   (void)hipStreamDestroy(ctx->copy);

@@ -96,6 +96,14 @@ struct kmx_fast_split {
 };
 kmx::SkfLayout kmx_fast_layout(int key_words /* of the sort's keys: 1 (k <= 32, hashes) or 2 */);
 int kmx_count_fast_tail(kmx_ctx* ctx, const kmx_fast_split& F, const kmx_count_req& rq);
+void kmx_phase_mark(int i);      // KMX_COUNT_PHASES (superk.hip)
+// the count calls of one GPU's contexts (the pipeline runs two or three workers a GPU, a context and a stream each) in a CHAIN: a call's
+// kernels start when the call queued before it -- whichever context's -- has left the GPU.  Side by side two calls' kernels share the
+// CUs, finish together, and their hosts then read back, pack and queue the next call at the same time with the GPU idle (36-47 % of
+// the count stage, profiles/r06_pipeline_count_trace.txt); chained, one call's host work lies under the other's kernels.
+void kmx_count_chain_begin(kmx_ctx* ctx);      // takes the GPU's chain lock, makes ctx->stream wait for the last queued call
+void kmx_count_chain_end(kmx_ctx* ctx);        // records this call's end on ctx->stream as the chain's new tail, releases the lock
+void kmx_count_chain_forget(kmx_ctx* ctx);     // (kmx_destroy)
 
 // page-locked host memory (kmx_api.hip: transparent huge pages + hipHostRegister for blocks of 2 MB and more, hipHostMalloc else)
 int kmx_peer_path(int from, int to);      // 1: GPU `from` reaches GPU `to`'s memory directly (peer access enabled on first use), 0: staged
@@ -131,6 +139,7 @@ struct kmx_ctx {
   struct ReadsAhead { char* d = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool live = false; };      // kmx_reads_upload
   ReadsAhead ahead[4];
   hipStream_t aux = nullptr;            // second stream: meta uploads, scratch clears (and, with KMX_COLS_PREP_OVERLAP, the small kernels that prepare a batch)
+  hipEvent_t ev_chain = nullptr;        // kmx_count_reads_dev: this context's last call has left the GPU (kmx_count_chain_*: the calls of a GPU's contexts run one behind the other)
   hipEvent_t ev_split = nullptr;        // kmx_count_reads_dev: the split is through -- the PartiInfo statistics run on `aux` beside the count kernels from here
   int n_cu = 0;
   std::string err;

@@ -839,6 +839,58 @@ struct StatsDev {
 // caller), its bases bases[i], which the concatenation holds from base_first[i] on; `parts` partitions per sample (nb_parts = n * parts)
 struct SkSegs { u32 n; const char* const* bases; const u64* base_first; const u32* seq_first; u32 parts; };
 
+// ---- the chain of count calls per GPU (kmx_host.hpp) ----
+#include <mutex>
+namespace {
+constexpr int CHAIN_DEV = 64;
+std::mutex g_chain_mu[CHAIN_DEV];
+hipEvent_t g_chain_tail[CHAIN_DEV] = {};
+thread_local bool tl_chain_held = false;
+bool chain_on() { const char* e = getenv("KMX_COUNT_CHAIN"); return !(e && !strcmp(e, "0")); }      // (read per call)
+}
+void kmx_count_chain_begin(kmx_ctx* ctx)
+{
+  if (!chain_on() || ctx->device < 0 || ctx->device >= CHAIN_DEV) return;
+  if (!ctx->ev_chain && hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming) != hipSuccess) { ctx->ev_chain = nullptr; (void)hipGetLastError(); return; }
+  g_chain_mu[ctx->device].lock(); tl_chain_held = true;
+  hipEvent_t tail = g_chain_tail[ctx->device];
+  if (tail && tail != ctx->ev_chain) (void)hipStreamWaitEvent(ctx->stream, tail, 0);      // (its own last call is in front of this one on the stream anyway)
+}
+void kmx_count_chain_end(kmx_ctx* ctx)
+{
+  if (!tl_chain_held) return;
+  if (hipEventRecord(ctx->ev_chain, ctx->stream) == hipSuccess) g_chain_tail[ctx->device] = ctx->ev_chain; else (void)hipGetLastError();
+  tl_chain_held = false; g_chain_mu[ctx->device].unlock();
+}
+void kmx_count_chain_forget(kmx_ctx* ctx)
+{
+  if (!ctx->ev_chain || ctx->device < 0 || ctx->device >= CHAIN_DEV) return;
+  std::lock_guard<std::mutex> lk(g_chain_mu[ctx->device]);
+  if (g_chain_tail[ctx->device] == ctx->ev_chain) g_chain_tail[ctx->device] = nullptr;
+  (void)hipEventDestroy(ctx->ev_chain); ctx->ev_chain = nullptr;
+}
+
+// KMX_COUNT_PHASES=1: where a kmx_count_reads_dev call spends its HOST time (sums over calls, a line every 200 calls on stderr)
+struct PhaseClock {
+  static constexpr int NP = 8;
+  bool on; std::chrono::steady_clock::time_point t;
+  PhaseClock() : on(getenv("KMX_COUNT_PHASES") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(int i) {
+    if (!on) return;
+    static std::atomic<unsigned long long> ns[NP]; static std::atomic<unsigned> calls{0};
+    const auto n = std::chrono::steady_clock::now();
+    ns[i] += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(); t = n;
+    if (i == NP - 1 && ++calls % 200 == 0) {
+      const double c = (double)calls.load();
+      fprintf(stderr, "[kmx count phases] %u calls, ms a call: setup+digest %.3f | uploads queued %.3f | split queued %.3f | count queued %.3f | statistics waited %.3f | stream waited %.3f | lists packed %.3f | tail %.3f\n",
+              calls.load(), ns[0] / c / 1e6, ns[1] / c / 1e6, ns[2] / c / 1e6, ns[3] / c / 1e6, ns[4] / c / 1e6, ns[5] / c / 1e6, ns[6] / c / 1e6, ns[7] / c / 1e6);
+    }
+  }
+};
+PhaseClock* g_phase_clock = nullptr;      // (the count's half marks its phases through this: set for the duration of a call, per thread below)
+static thread_local PhaseClock* tl_phase = nullptr;
+void kmx_phase_mark(int i) { if (tl_phase) tl_phase->mark(i); }
+
 static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_seqs,
                        uint32_t k, uint32_t m, const uint16_t* repart, uint32_t nb_parts,
                        uint8_t** out_bytes, uint64_t* out_len, uint64_t* out_kmers, kmx_superk_stats* stats,
@@ -907,6 +959,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   for (void* b : blocks) if (!b) { release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
   auto fail = [&](hipError_t e, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
   StageClock clk(st, "superk_partition");
+  PhaseClock ph; struct TlSet { PhaseClock* p; TlSet(PhaseClock* q) : p(q) { tl_phase = q; } ~TlSet() { tl_phase = nullptr; } } tlset(&ph);
+  ph.mark(0);
   hipError_t e;
   if (segs) {
     for (u32 i = 0; i < segs->n; i++) {
@@ -964,6 +1018,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
     const bool fast = creq && creq->lists && !streams_to_host && !wide_k && !segs && nb_parts <= SKF_MAXP && total_bases < (500ULL << 20) && two_pass && (!sd.any() || sd.deferred) && !ctx->hist_on &&
                       !(fe && !strcmp(fe, "0")) && !getenv("KMX_COUNT_SORT") && !getenv("KMX_COUNT_BUCKETS") && total_bases >= 1;
     if (fast) {
+      ph.mark(1);
       const u32 P = nb_parts, wpg = skf_wpg(P);
       const u32 n_chunks = (u32)((n_seqs + SKF_RPW - 1) / SKF_RPW), R = (n_chunks + wpg - 1) / wpg;
       const u32 rpg = std::max<u32>(32u, (R + 127u) / 128u), Gc = (R + rpg - 1) / rpg;      // (k_sk_scan: at most 128 workgroups; its time goes with their number -- 16 rows each: 32 us, 7: 53 us)
@@ -1000,6 +1055,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       SkfCtl* d_ctl = (SkfCtl*)d_z; u64* d_nspf = (u64*)(d_z + 32);
       u64* d_ppf = (u64*)d_sumf, *d_infof = (u64*)(d_sumf + o_info); uint4* d_partsf = (uint4*)(d_sumf + o_parts); u32* d_pff = (u32*)(d_sumf + o_pf), *d_cff = (u32*)(d_sumf + o_cf);
       auto ffail = [&](hipError_t er, const char* what) { frel(); return fail(er, what); };
+      kmx_count_chain_begin(ctx);
+      struct ChainEnd { kmx_ctx* c; ~ChainEnd() { kmx_count_chain_end(c); } } chain_end{ctx};      // (an error on the way out: the lock goes back; the count's half ends the chain itself once everything is queued)
       if ((e = hipMemsetAsync(d_z, 0, z_bytes, st)) != hipSuccess) return ffail(e, "memset");
       kmx_launch_pack_bases(d_bases, total_bases, d_wordsf, st);
       const dim3 gw((n_chunks + 3) / 4);
@@ -1036,6 +1093,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       };
       if ((e = hipGetLastError()) != hipSuccess) return ffail(e, "split kernels");
       if ((e = hipMemcpyAsync(h_f + 64, d_sumf, sumf, hipMemcpyDeviceToHost, st)) != hipSuccess) return ffail(e, "memcpy");
+      ph.mark(2);
       kmx_fast_split F{d_wordsf, d_sb, d_bo, d_p16, d_bf, d_ctl, d_partsf, d_cff, (u32*)(d_z + z_cnt), (u32*)(d_z + z_sfl), P, kb, tb_max, nc_max, nb_max,
                        reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts), nullptr, nullptr};
       if (sd.deferred) F.behind_scatter = launch_stats;
@@ -1066,6 +1124,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
           if ((e = hipStreamSynchronize(sx)) != hipSuccess) return ffail(e, "sync");
         }
         frel(); release();
+        ph.mark(7);
         return KMX_OK;
       }
       // (a status bit: the old path takes the call from the start -- the statistics of the abandoned pass are cleared)

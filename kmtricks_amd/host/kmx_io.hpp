@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cerrno>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
@@ -458,51 +459,92 @@ inline void bf_header(uint8_t* h /* BF_HEADER_BYTES */, uint32_t kmer_size, uint
 }
 
 // ---- FASTA / FASTQ (plain or gz) reader: kseq-style records, sequence lines joined (gatb BankFasta.cpp:390-570) ----
+// Round 6: a sample's 30 MB of FASTA took a reader thread 20-35 ms (every byte through zlib's pass-through buffer, a line string, a
+// per-character copy and the record's string before it reached the page-locked batch): 12-24 readers were the count stage's pace
+// at 1000 x 5 Mbp.  Now a plain file is read with read(2) into a 1 MB block (gzread only when the file starts with the gzip magic),
+// a line goes from there into the record with one memchr and one append, and its bytes are looked at one by one only when it holds a
+// blank or a carriage return.
 class SeqReader {
  public:
-  explicit SeqReader(const std::string& path) : gz_(gzopen(path.c_str(), "rb")), path_(path) {
-    if (!gz_) throw IoError("Unable to read at " + path);
-    gzbuffer(gz_, 1 << 20);
+  explicit SeqReader(const std::string& path) : path_(path), buf_(new char[BUF]) {
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw IoError("Unable to read at " + path);
+    unsigned char m[2] = {0, 0};
+    const ssize_t r = ::pread(fd_, m, 2, 0);
+    if (r == 2 && m[0] == 0x1f && m[1] == 0x8b) {
+      gz_ = gzdopen(fd_, "rb");
+      if (!gz_) { ::close(fd_); throw IoError("Unable to read at " + path); }
+      gzbuffer(gz_, 1 << 20);
+    } else {
+#ifdef POSIX_FADV_SEQUENTIAL
+      (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
+#endif
+    }
   }
   SeqReader(const SeqReader&) = delete;
-  ~SeqReader() { if (gz_) gzclose(gz_); }
+  ~SeqReader() { if (gz_) gzclose(gz_); else if (fd_ >= 0) ::close(fd_); }
   bool next(std::string& seq) {
     seq.clear();
-    std::string& line = line_;
-    if (!have_hdr_) { while (getline(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { hdr_ = line[0]; have_hdr_ = true; break; } if (!have_hdr_) return false; }
+    char c;
+    if (!have_hdr_) {      // up to the next header line
+      while (peek(c)) { if (c == '>' || c == '@') { hdr_ = c; have_hdr_ = true; skip_line(); break; } skip_line(); }
+      if (!have_hdr_) return false;
+    }
     have_hdr_ = false;
     if (hdr_ == '>') {
-      while (getline(line)) { if (!line.empty() && line[0] == '>') { have_hdr_ = true; hdr_ = '>'; break; } append(seq, line); }
+      while (peek(c)) { if (c == '>') { have_hdr_ = true; hdr_ = '>'; skip_line(); break; } take_line(seq); }
       return true;
     }
     // FASTQ: sequence lines until '+', then as many quality characters as bases
-    while (getline(line)) { if (!line.empty() && line[0] == '+') break; append(seq, line); }
+    while (peek(c)) { if (c == '+') { skip_line(); break; } take_line(seq); }
     size_t q = 0;
-    while (q < seq.size() && getline(line)) q += line.size();
+    while (q < seq.size() && peek(c)) q += skip_line();
     return true;
   }
  private:
-  static void append(std::string& s, const std::string& l) {
-    const size_t o = s.size(); s.resize(o + l.size()); size_t n = o;
-    for (char c : l) if (c != ' ' && c != '\t' && c != '\r') s[n++] = c;
-    s.resize(n);
+  static constexpr size_t BUF = 1 << 20;
+  bool fill() {
+    if (eof_) return false;
+    ssize_t r;
+    if (gz_) r = gzread(gz_, buf_.get(), (unsigned)BUF);
+    else { do r = ::read(fd_, buf_.get(), BUF); while (r < 0 && errno == EINTR); }
+    if (r <= 0) { eof_ = true; return false; }
+    pos_ = 0; end_ = (size_t)r;
+    return true;
   }
-  // own line buffering over gzread (gzgets costs a call per line)
-  bool getline(std::string& line) {
-    line.clear();
+  // the first character of the next line (false: end of file); an empty line gives '\n'
+  bool peek(char& c) { if (pos_ == end_ && !fill()) return false; c = buf_[pos_]; return true; }
+  // the rest of the current line is dropped; -> its length without the line end (and without a closing carriage return)
+  size_t skip_line() {
+    size_t n = 0; char last = 0;
     for (;;) {
-      if (pos_ == end_) { const int r = gzread(gz_, buf_, sizeof(buf_)); if (r <= 0) return !line.empty(); pos_ = 0; end_ = (size_t)r; }
-      const char* nl = (const char*)memchr(buf_ + pos_, '\n', end_ - pos_);
-      if (nl) {
-        line.append(buf_ + pos_, (size_t)(nl - (buf_ + pos_))); pos_ = (size_t)(nl - buf_) + 1;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        return true;
-      }
-      line.append(buf_ + pos_, end_ - pos_); pos_ = end_;
+      if (pos_ == end_ && !fill()) break;
+      const char* b = buf_.get() + pos_;
+      const char* nl = (const char*)memchr(b, '\n', end_ - pos_);
+      const size_t m = nl ? (size_t)(nl - b) : end_ - pos_;
+      if (m) last = b[m - 1];
+      n += m; pos_ += m + (nl ? 1 : 0);
+      if (nl) break;
+    }
+    return n - (n && last == '\r' ? 1 : 0);
+  }
+  // the rest of the current line goes behind `s`, blanks, tabs and carriage returns left out
+  void take_line(std::string& s) {
+    for (;;) {
+      if (pos_ == end_ && !fill()) return;
+      const char* b = buf_.get() + pos_;
+      const char* nl = (const char*)memchr(b, '\n', end_ - pos_);
+      const size_t m = nl ? (size_t)(nl - b) : end_ - pos_;
+      unsigned low = 0;
+      for (size_t i = 0; i < m; i++) low |= (unsigned)((unsigned char)b[i] <= ' ');      // (vectorised: a line with nothing but letters is appended as it is)
+      if (!low) s.append(b, m);
+      else { const size_t o = s.size(); s.resize(o + m); size_t n = o; for (size_t i = 0; i < m; i++) { const char c = b[i]; if (c != ' ' && c != '\t' && c != '\r') s[n++] = c; } s.resize(n); }
+      pos_ += m + (nl ? 1 : 0);
+      if (nl) return;
     }
   }
-  gzFile gz_; std::string path_, line_; char hdr_ = 0; bool have_hdr_ = false;
-  char buf_[1 << 16]; size_t pos_ = 0, end_ = 0;
+  gzFile gz_ = nullptr; int fd_ = -1; std::string path_; char hdr_ = 0; bool have_hdr_ = false, eof_ = false;
+  std::unique_ptr<char[]> buf_; size_t pos_ = 0, end_ = 0;
 };
 
 }  // namespace kmxio
