@@ -273,6 +273,8 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
                            for p in range(b0, min(total_parts, b0 + per))]) for b0 in range(0, total_parts, per)]
         run(0, False, jb)      # (once untimed: the context's pool then holds the blocks two batches in flight need)
         sync()
+        if os.environ.get("KMX_TRACE_ALLOC"):
+            print("[bench] whole job: the timed pass starts", file=sys.stderr, flush=True)
         t2 = time.perf_counter()
         run(0, False, jb)
         sync()

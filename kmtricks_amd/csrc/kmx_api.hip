@@ -20,14 +20,23 @@ static thread_local std::string g_create_err;
 void* kmx_ctx::dalloc(size_t bytes)
 {
   if (bytes == 0) bytes = 256;
+  // (round 6) large blocks come in size classes an eighth of a power of two apart: the arenas of a job's batches differ by a few per cent
+  // from batch to batch and from pass to pass (their size follows the running estimates), and a request a little above every free
+  // block was a hipMalloc of 600 MB -- 18 ms with the GPU idle, in the middle of the whole-job figure (profiles/r06_whole_job_timeline.txt)
+  if (bytes >= (8u << 20)) { size_t p2 = (size_t)1 << 23; while (p2 * 2 <= bytes) p2 *= 2; const size_t q = p2 >> 3; bytes = (bytes + q - 1) / q * q; }
   int best = -1;
   for (size_t i = 0; i < pool.size(); i++)
     if (!pool[i].used && pool[i].bytes >= bytes && pool[i].bytes <= 2 * bytes + (1u << 20) &&
         (best < 0 || pool[i].bytes < pool[best].bytes)) best = (int)i;
   if (best >= 0) { pool[best].used = true; return pool[best].p; }
+  // a large block that has to be made is made as large as the largest one asked for so far (when that is within 1.5 x): after a few
+  // batches every arena block of a job fits every arena request, and the pool stops growing (it had reached 104 GB in 431 blocks over
+  // the whole job of configs[2], a quarter of it free, and still missed)
+  if (bytes >= (64u << 20)) { big_max = std::max(big_max, bytes); if (big_max <= bytes + bytes / 2) bytes = big_max; }
   void* p = nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  struct Tr { size_t b; std::chrono::steady_clock::time_point t; ~Tr() { static const bool on = getenv("KMX_TRACE") != nullptr; if (on) fprintf(stderr, "[kmx alloc] device pool +%zu MB: %.2f ms\n", b >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); } } tr{bytes, t0};
+  struct Tr { size_t b; std::chrono::steady_clock::time_point t; kmx_ctx* c; ~Tr() { static const bool on = getenv("KMX_TRACE") != nullptr || getenv("KMX_TRACE_ALLOC") != nullptr; if (on) { size_t fr = 0, tot = 0; for (auto& x : c->pool) { tot += x.bytes; if (!x.used) fr += x.bytes; }
+    fprintf(stderr, "[kmx alloc] device pool +%zu MB: %.2f ms (pool %zu MB in %zu blocks, %zu MB of it free)\n", b >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(), tot >> 20, c->pool.size(), fr >> 20); } } } tr{bytes, t0, this};
   if (hipMalloc(&p, bytes) != hipSuccess) {
     // drop cached blocks and retry once
     for (auto& b : pool) if (!b.used && b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }

@@ -145,6 +145,7 @@ struct kmx_ctx {
   std::string err;
   bool profiling = false;
   std::vector<kmx_pool_block> pool;     // device blocks kept for reuse (bench steps allocate nothing)
+  size_t big_max = 0;                   // the largest block of 64 MB or more asked for so far (dalloc)
   std::vector<kmx_pool_block> hpool;    // pinned host blocks
   // the pivot merge kernel handed a batch back: the next `pivot_skip` eligible batches go straight to k_merge_rows
   // (doubling back-off, reset by the first batch the pivot kernel completes)
