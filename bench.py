@@ -626,6 +626,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # (an N > 1 line is printed only by the N ranks it names: --gpus, WORLD_SIZE and the process group must agree)
+    seen = dist.get_world_size() if dist is not None else 1
+    if a.gpus != world or seen != world:
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {a.gpus}, WORLD_SIZE {world} and the process group ({seen} ranks) disagree: no line", "n_gpus": a.gpus}))
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(2)
     from kmtricks_amd import lib, shard
     env = dict(torch=torch, dist=dist, lib=lib, shard=shard, rank=rank, world=world, local=local, dev=dev)
     out = run_workloads(a, wl, env)
@@ -688,11 +696,16 @@ def run_workloads(a, wl, env):
             except Exception as e:
                 pipe = {"error": repr(e)}
         env["dist"].barrier()
+    per_rank = None
+    if world > 1:
+        per_rank = rank_probe(env)      # (every rank takes part: a collective)
     if rank == 0:
         # what the scaling runs need to be read without a second look: the world the ranks saw, and the one-GPU line of the last round
         # the driver recorded (BENCH_r*.json at the repository's root), so that N ranks x that value is at hand
         out["ranks"] = {"world_size": world, "backend": ("nccl (RCCL)" if world > 1 else None),
                         "devices": env["torch"].cuda.device_count() if hasattr(env["torch"], "cuda") else None}
+        if per_rank is not None:
+            out["ranks"]["per_rank"] = per_rank
         try:
             import glob
             last = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")))[-1]
@@ -704,6 +717,41 @@ def run_workloads(a, wl, env):
             out["workloads"] = extras
         if pipe is not None:
             out["pipeline"] = pipe
+    return out
+
+
+def rank_probe(env):
+    """several ranks: what each of them bound and saw, and the path's one collective on real links -- a small hash:bft exchange
+    (kmtricks_amd/shard.py: per-sample Bloom rows, one all-to-all) with rows whose content names (partition, sample), checked on the
+    receiving side.  -> a list of one record per rank (gathered on every rank), or the error it died of."""
+    torch, dist, shard, rank, world, local, dev = (env[k] for k in ("torch", "dist", "shard", "rank", "world", "local", "dev"))
+    rec = {"rank": rank, "local_rank": local, "world_size_seen": dist.get_world_size() if dist is not None else 1}
+    try:
+        if hasattr(torch, "cuda") and dev.type == "cuda":
+            pr = torch.cuda.get_device_properties(local)
+            rec["device"] = {"index": local, "name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count, "hbm_GB": round(pr.total_memory / 1e9, 1)}
+        n_samples, n_parts, row_bytes = 8 * world + 3, 2 * world, 256
+        mine = shard.partitions_of_rank(n_parts, world, rank)
+        rows8 = (n_samples + 7) // 8 * 8
+        mats = []
+        for p in mine:      # row s of partition p: bytes (p * 131 + s * 7 + j) % 251
+            sidx = torch.arange(rows8, device=dev).view(-1, 1); j = torch.arange(row_bytes, device=dev).view(1, -1)
+            mats.append(((p * 131 + sidx * 7 + j) % 251).to(torch.uint8))
+        got = shard.bloom_exchange(dist, mats, n_samples, n_parts, world, rank)
+        my_s = shard.samples_of_rank(n_samples, world, rank)
+        ok = True
+        for a_, s_ in enumerate(my_s):
+            for p in range(n_parts):
+                exp = ((p * 131 + s_ * 7 + torch.arange(row_bytes, device=dev)) % 251).to(torch.uint8)
+                ok = ok and bool(torch.equal(got[a_, p], exp))
+        rec["bloom_exchange"] = {"ok": ok, "bytes_sent": len(mine) * n_samples * row_bytes, "bytes_received": int(got.numel()), "samples": n_samples, "partitions": n_parts}
+    except Exception as e:      # (reported, not fatal: the line's own figure does not depend on it)
+        rec["error"] = repr(e)
+    out = [None] * world
+    if dist is not None and world > 1:
+        dist.all_gather_object(out, rec)
+    else:
+        out = [rec]
     return out
 
 

@@ -86,3 +86,7 @@ def test_bench_rank_plumbing_two_ranks(wl, extra):
             assert log[i + 1:i + 3] == ["body0", "body1"] and log[i + 3] == "free"
     if wl == "bft":
         assert "all-to-all" in out0["config"]["parallelism"]
+    # round 6: the line names what every rank bound and saw, and the path's one collective has crossed the group once with checked content
+    pr = out0["ranks"]["per_rank"]
+    assert out0["ranks"]["world_size"] == 2 and [x["rank"] for x in pr] == [0, 1] and all(x["world_size_seen"] == 2 for x in pr)
+    assert all("error" not in x and x["bloom_exchange"]["ok"] and x["bloom_exchange"]["bytes_sent"] > 0 for x in pr)

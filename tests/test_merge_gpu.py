@@ -163,11 +163,35 @@ def test_first_batches_of_fresh_contexts_in_file_order(merge_kernel):
     from kmtricks_amd import lib
     lists2 = synth_lists(2024, 300, 4000, 0.9, 400, kw=2, key_bits=126)
     lists1 = synth_lists(2025, 520, 3000, 0.9, 200, kw=1)
-    for it in range(4):
+    for it in range(16):      # (round 6: 16 fresh contexts -- the stress script needed up to 9 to hit the stall; a context costs ~0.1 s)
         c = lib.Context(0)
         try:
             check(c, lists2, 2, [1] * 300, 1, 0, orc.MODE_PA, rows_hint=1)
             check(c, lists1, 1, [1] * 520, 2, 0, orc.MODE_COUNT, rows_hint=1)
+        finally:
+            c.close()
+
+
+def test_first_batches_of_fresh_contexts_bloom_rows(ctx):
+    """the same for the Bloom kernels (round 6's audit of the stall class: k_merge_bf / k_merge_bft / k_merge_rows / k_merge_pivot read
+    no cross-workgroup word per thread ahead of a barrier -- the error word is read by one thread and handed on through LDS, or through
+    __syncthreads_or): a fresh context's first hash:bft batch with the single walk's put-aside scratch at its first size, twice per
+    context, 16 contexts"""
+    from kmtricks_amd import lib
+    rng = np.random.default_rng(77)
+    n, W, lower = 300, 40960, 7 * 40960
+    lists = []
+    for i in range(n):
+        hs = np.unique(rng.integers(lower, lower + W, size=900, dtype=np.uint64))
+        lists.append((hs, rng.integers(1, 4, size=len(hs)).astype(np.uint32)))
+    soft = [2] * n
+    exp = orc.merge_matrix(lists, 1, soft, 1, 1, orc.MODE_BFT, lower, lower + W - 1)
+    for it in range(16):
+        c = lib.Context(0)
+        try:
+            for _ in range(2):
+                body, rows, st = c.merge(lists, 1, soft, 1, 1, orc.MODE_BFT, lower, lower + W - 1)
+                assert rows == exp[1] and body == exp[0] and np.array_equal(st, exp[2])
         finally:
             c.close()
 
@@ -932,6 +956,19 @@ def test_hand_worked_merge_vectors_through_the_hip_path(ctx):
                 body, n, st = ctx.merge(lists, kw, HAND_SOFT, r, s, mode)
                 assert n == len(rows) and body == body_of(rows, kw, 3, mode, shift), (kw, r, s, mode)
                 assert st.tolist() == stats, (kw, r, s, mode)
+
+
+@pytest.mark.gpu
+def test_hand_worked_bloom_vectors_through_the_hip_path(ctx):
+    """round 6: the hand-worked write_as_bf / bfc / bft vectors of tests/test_merge_independent.py (gap-filling zero rows, a hash nobody
+    holds solid, `current = m_current + 1`, MSB-first pack_v at widths 2 and 3, the closing fill to `upper`, the transposed rows with
+    their padding) through kmx_merge on the device, bodies and statistics"""
+    from test_merge_independent import bloom_cases, bloom_arrays, BLOOM_SOFT, BLOOM_LOWER, BLOOM_UPPER
+    for mode, r, s, w, body, stats in bloom_cases():
+        got, rows, st = ctx.merge(bloom_arrays(), 1, BLOOM_SOFT, r, s, mode, BLOOM_LOWER, BLOOM_UPPER, w)
+        assert got == body, (mode, r, s, w, got.hex(), body.hex())
+        assert rows == (8 if mode == orc.MODE_BFT else 15)
+        assert st.tolist() == stats, (mode, r, s, w)
 
 
 @pytest.mark.parametrize("seed", range(6))

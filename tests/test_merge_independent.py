@@ -136,6 +136,109 @@ def test_oracle_reproduces_the_hand_worked_vectors(case, mode, kw, shift):
     assert st.tolist() == stats
 
 
+# ---------------------------------------------------------------------------------------------------------------- the Bloom writers
+# Round 6: write_as_bf / write_as_bfc / write_as_bft (merge.hpp:575-644) pinned the same way -- the reference's own vectors give these
+# modes row counts and packc_test.cpp only.  One window [100, 114] (15 hash rows: not a multiple of 8), three samples, soft-min
+# [2, 2, 3]; every byte below was written down from the lines cited.
+#   hash 100: S0 5 (solid)                         -> counts [5, 0, 0]
+#   hash 101: S0 1 (not solid, nobody solid)       -> recurrence 0: no row of its own -- the NEXT kept hash's `while (m_current > current)`
+#             fills it with the empty vector (:581-585); with recurrence-min 0 it IS kept (0 >= 0, merge.hpp:503-504) and written as
+#             the zero vector, `current = m_current + 1` (:590): the same bytes
+#   hash 102: nobody                               -> empty (gap filling)
+#   hash 103: S0 1 (not solid), S1 4 (solid)       -> [0, 4, 0]; share-min 1: S0 rescued (solid_in 1 >= 1, :489-499) -> [1, 4, 0]
+#   hash 104: S0 1, S1 4, S2 3 (3 >= 3: solid)     -> [0, 4, 3]; rescued: [1, 4, 3]; recurrence 2
+#   hash 107: S0 2 (2 >= 2: solid), S1 7           -> [2, 7, 0]; recurrence 2
+#   hash 109: S2 1 (not solid, nobody solid)       -> no row
+#   hash 112: S0 9 (solid), S2 1 (not solid)       -> [9, 0, 0]; rescued: [9, 0, 1]
+#   hashes 113, 114: the closing `while (current <= upper)` (:593-597)
+BLOOM_LISTS = [{100: 5, 101: 1, 103: 1, 104: 1, 107: 2, 112: 9}, {103: 4, 104: 4, 107: 7}, {104: 3, 109: 1, 112: 1}]
+BLOOM_SOFT = [2, 2, 3]
+BLOOM_LOWER, BLOOM_UPPER = 100, 114
+_B_NS = [3, 0, 2]            # NON_SOLID: S0 hashes 101 103 104; S2 hashes 109 112 (inc_ns, merge.hpp:475-476)
+_B_UWO = [3, 3, 1]           # S0 100 107 112; S1 103 104 107; S2 104 (inc_uwo, :468-472)
+_B_TWO = [16, 15, 3]         # 5 + 2 + 9; 4 + 4 + 7; 3
+_B_STATS0 = [_B_NS, [0, 0, 0], _B_UWO, _B_UWO, _B_TWO, _B_TWO]
+_B_STATS1 = [_B_NS, [2, 0, 1], _B_UWO, [5, 3, 2], _B_TWO, [18, 15, 4]]      # rescued: S0 at 103 and 104 (1 + 1), S2 at 112 (1): inc_rd, inc_uw, inc_tw (:494-498)
+
+
+def _bf_rows(d):
+    """{hash: byte(s)} -> the window's rows, the others empty"""
+    w = len(next(iter(d.values())))
+    return b"".join(bytes(d.get(h, [0] * w)) for h in range(BLOOM_LOWER, BLOOM_UPPER + 1))
+
+
+# write_as_bf: a row is NBYTES(3) = 1 byte, sample i is bit i % 8 of byte i / 8 (set_bit_vector, utils.hpp:104-116: BITSET = 1 << (b % 8))
+BLOOM_BF = {
+    (1, 0): _bf_rows({100: [0x01], 103: [0x02], 104: [0x06], 107: [0x03], 112: [0x01]}),
+    (1, 1): _bf_rows({100: [0x01], 103: [0x03], 104: [0x07], 107: [0x03], 112: [0x05]}),
+    (2, 0): _bf_rows({104: [0x06], 107: [0x03]}),                     # recurrence-min 2: only 104 (S1, S2) and 107 (S0, S1) are kept
+    (2, 1): _bf_rows({104: [0x07], 107: [0x03]}),                     # ... the rescued S0 at 104 rides along; 103 and 112 are rescued but not kept
+    (0, 0): _bf_rows({100: [0x01], 103: [0x02], 104: [0x06], 107: [0x03], 112: [0x01]}),      # recurrence-min 0: 101 and 109 are kept as zero vectors
+}
+# write_as_bfc: pack_v (packc.hpp:26-43) -- field i holds to_n_b(count, w) = min(bit length, 2^w - 1) in w bits from bit offset i * w,
+# counted from the MOST significant bit of the first byte (bitpacker::insert).  to_n_b: 1 -> 1, 2 -> 2, 3 -> 2, 4 -> 3, 5 -> 3, 7 -> 3,
+# 9 -> 4 (w = 2 caps at 3).  share-min 1 rows: [5,0,0] [1,4,0] [1,4,3] [2,7,0] [9,0,1].
+#   w = 2, a row is byte_count_pack(3, 2) = 1 byte: 11 00 00 00 | 01 11 00 00 | 01 11 10 00 | 10 11 00 00 | 11 00 01 00
+#   w = 3, a row is 2 bytes: 011 000 000 -> 0110 0000 0 | 001 011 000 -> 0010 1100 0 | 001 011 010 -> 0010 1101 0 | 010 011 000 -> 0100 1100 0
+#          | 100 000 001 -> 1000 0000 1
+BLOOM_BFC = {
+    (1, 1, 2): _bf_rows({100: [0xC0], 103: [0x70], 104: [0x78], 107: [0xB0], 112: [0xC4]}),
+    (1, 0, 2): _bf_rows({100: [0xC0], 103: [0x30], 104: [0x38], 107: [0xB0], 112: [0xC0]}),      # not rescued: [0,4,0] [0,4,3] [9,0,0]
+    (1, 1, 3): _bf_rows({100: [0x60, 0x00], 103: [0x2C, 0x00], 104: [0x2D, 0x00], 107: [0x4C, 0x00], 112: [0x80, 0x80]}),
+    (2, 1, 3): _bf_rows({104: [0x2D, 0x00], 107: [0x4C, 0x00]}),
+}
+# write_as_bft: the bf rows in a BitMatrix(ROUND_UP(15, 8) = 16 rows, ROUND_UP(3, 8) / 8 = 1 byte), transposed (bitmatrix.hpp:209-289:
+# out row y, bit x % 8 of byte x / 8 = in row x, bit y) and dumped whole: 8 rows (samples 3..7 are padding) of 2 bytes, bit r of a
+# sample's row = hash 100 + r.  share-min 1: S0 holds hashes 100 103 104 107 112 -> bits 0 3 4 7 | 12 -> 99 10; S1 103 104 107 -> 98 00;
+# S2 104 112 -> 10 10.  share-min 0: S0 100 107 112 -> 81 10; S1 103 104 107 -> 98 00; S2 104 -> 10 00.
+BLOOM_BFT = {
+    (1, 1): bytes([0x99, 0x10, 0x98, 0x00, 0x10, 0x10] + [0] * 10),
+    (1, 0): bytes([0x81, 0x10, 0x98, 0x00, 0x10, 0x00] + [0] * 10),
+    (2, 1): bytes([0x90, 0x00, 0x90, 0x00, 0x10, 0x00] + [0] * 10),      # kept: 104 (all three, S0 rescued) and 107 (S0, S1)
+}
+BLOOM_STATS = {0: _B_STATS0, 1: _B_STATS1}
+
+
+def bloom_arrays():
+    return [(np.array(sorted(l), np.uint64), np.array([l[h] for h in sorted(l)], np.uint32)) for l in BLOOM_LISTS]
+
+
+def bloom_cases():
+    """(mode, recurrence-min, share-min, bitw, body, statistics)"""
+    out = []
+    for (r, s), body in BLOOM_BF.items():
+        out.append((orc.MODE_BF, r, s, 2, body, BLOOM_STATS[s]))
+    for (r, s, w), body in BLOOM_BFC.items():
+        out.append((orc.MODE_BFC, r, s, w, body, BLOOM_STATS[s]))
+    for (r, s), body in BLOOM_BFT.items():
+        out.append((orc.MODE_BFT, r, s, 2, body, BLOOM_STATS[s]))
+    return out
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_oracle_reproduces_the_hand_worked_bloom_vectors(case):
+    mode, r, s, w, body, stats = bloom_cases()[case]
+    got, rows, st = orc.merge_matrix(bloom_arrays(), 1, BLOOM_SOFT, r, s, mode, BLOOM_LOWER, BLOOM_UPPER, w)
+    assert got == body
+    assert rows == (8 if mode == orc.MODE_BFT else 15)
+    assert st.tolist() == stats
+
+
+def test_the_bloom_vectors_agree_with_each_other():
+    """what the three writers share: a bfc field is non-zero exactly where the bf bit is set, a bft row is the bf column"""
+    assert len(bloom_cases()) == 12
+    for (r, s), bf in BLOOM_BF.items():
+        if (r, s, 2) in BLOOM_BFC:
+            for row, (a, b) in enumerate(zip(bf, BLOOM_BFC[(r, s, 2)])):
+                for i in range(3):
+                    assert ((a >> i) & 1) == (1 if (b >> (6 - 2 * i)) & 3 else 0), (r, s, row, i)
+        if (r, s) in BLOOM_BFT:
+            t = BLOOM_BFT[(r, s)]
+            for row in range(15):
+                for i in range(3):
+                    assert ((bf[row] >> i) & 1) == ((t[2 * i + (row >> 3)] >> (row & 7)) & 1), (r, s, row, i)
+
+
 def random_cohort(rng, n, nkeys, kw):
     """a cohort with every kind of key: in most samples, in a few, in one; counts around the soft-mins"""
     top = 1 << (64 * kw - 2)
