@@ -143,8 +143,13 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     # COUNT / PA: the line's own step runs the library's default -- rows written at their final place (kmx_set_file_order on: the arena
     # IS the matrix body, the ascending row stream the reference writes, merge.hpp:262-272).  The pair's speed with the rows left where
     # the kernels put them (the headline of rounds 1-4) is timed right behind it and reported in roofline.rows_left_in_arena.
-    defaults = {"count": (1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
-    N = a.samples or defaults[0]
+    # count_200: configs[2]'s count rows for a cohort of 200 samples (round 6: every real cohort below 257 samples is k_merge_rows' -- its
+    # build for up to 256 lists, merge_rows_small.hip); the same code path as "count" otherwise
+    small = wl == "count_200"
+    if small:
+        wl = "count"
+    defaults = {"count": (200 if small else 1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
+    N = defaults[0] if small else (a.samples or defaults[0])
     P = a.partitions_per_gpu or defaults[1]
     k = defaults[2]
     rec_min = a.rec_min if a.rec_min >= 0 else defaults[3]
@@ -163,7 +168,7 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     if wl in ("count", "pa63"):
         mode = lib.MODE_COUNT if wl == "count" else lib.MODE_PA
         if lists_kind == "counted":
-            job_lists = [[] for _ in range(total_parts)] if (wl == "count" and world == 1 and a.whole_job) else None
+            job_lists = [[] for _ in range(total_parts)] if (wl == "count" and not small and world == 1 and a.whole_job) else None
             store, lists = gen_counted(ctx, lib, N, k, genome, a.subst_rate, total_parts, my_parts, 20240601, rank == 0, job_lists)
             keep.append(store)
             def host_lists(j):
@@ -583,7 +588,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["auto", "all", "count", "bf", "pa63", "bft", "pipeline", "count_stage"], default="auto")
+    ap.add_argument("--workload", choices=["auto", "all", "count", "count_200", "bf", "pa63", "bft", "pipeline", "count_stage"], default="auto")
     ap.add_argument("--lists", choices=["counted", "random"], default="counted")
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--partitions-per-gpu", type=int, default=0)
@@ -653,7 +658,7 @@ def run_workloads(a, wl, env):
     extras, pipe = {}, None
     if wl == "all":
         t_all = time.perf_counter()
-        for w in ("count_stage", "bf", "bft", "pa63"):
+        for w in ("count_stage", "bf", "bft", "pa63", "count_200"):
             try:
                 extras[w] = count_stage_workload(env, a) if w == "count_stage" else merge_workload(env, a, w, "counted", want_cpu)
             except Exception as e:      # (a side line must not cost the headline one)

@@ -408,6 +408,7 @@ struct kmx_merge_result {
   bool share_fix = false;                        // ... with a task whose share-min is above its recurrence-min: k_share_fix behind them
   bool cols_ord = false;                         // ... and their ORD builds: rows written at their final place
   bool back_other = false;           // tasks were handed back for another reason than ERR_DENSE_CAP
+  bool rows_small = false;           // k_merge_rows: the build for cohorts of up to 256 lists (merge_rows_small.hip) -- windows, grid and launch follow it
   bool cols_narrow = false;          // k_merge_cols' NAR build: every task's side store of row keys' rows is the byte-wide one
   bool rerun_rows = false;           // some tasks were re-run with k_merge_rows: any further re-run uses it for all
   bool pivot_auto = false;           // ... and it was libkmx's own choice (feeds the back-off in kmx_ctx)
@@ -546,6 +547,7 @@ static int launch_batch(kmx_merge_result* R, bool with_bounds)
     if (with_bounds) KMX_HIP(ctx, launch_range_bounds(kw, d_tasks, nt, R->max_n, R->max_c, ctx->stream));
     if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev0, ctx->stream));
     if (R->use_pivot) KMX_HIP(ctx, launch_merge_pivot(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, ctx->stream));
+    else if (R->rows_small) KMX_HIP(ctx, launch_merge_rows_s(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
     else KMX_HIP(ctx, launch_merge_rows(kw, mode, d_tasks, d_items, R->n_items, d_ticket, R->grid, R->max_n, ctx->stream));
   }
   if (R->ev0) KMX_HIP(ctx, hipEventRecord(R->ev1, ctx->stream));
@@ -629,6 +631,12 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
   R->ctx = ctx; R->is_bf = is_bf; R->is_bft = is_bft;
   R->tasks.resize(n_tasks);
   u64 grand_total = 0;
+  {   // cohorts of up to 256 lists (keys of one and two words): k_merge_rows' small build (KMX_ROWS_SMALL=0: never)
+    u32 mxn0 = 0; for (u32 t = 0; t < n_tasks; t++) mxn0 = std::max(mxn0, tasks[t].n_lists);
+    const char* e = getenv("KMX_ROWS_SMALL");      // (read per batch: the tests switch it)
+    R->rows_small = !is_bf && kw <= 2 && mxn0 <= 256 && !(e && e[0] == '0');
+  }
+  const bool rsm = R->rows_small;
   for (u32 t = 0; t < n_tasks; t++) {
     const kmx_merge_task& K = tasks[t];
     TaskHost& H = R->tasks[t];
@@ -675,9 +683,9 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
       }
     } else {
       H.row_bytes = kw * 8 + (mode == KMX_MODE_COUNT ? 4 * H.N : (H.N + 7) / 8);
-      u32 wl = 0; while (wl < 6 && (H.N << (wl + 1)) <= (u32)rows_cap((int)kw, H.N)) wl++;   // window <= one wave
+      u32 wl = 0; while (wl < 6 && (H.N << (wl + 1)) <= (u32)(rsm ? rows_s_cap((int)kw, H.N) : rows_cap((int)kw, H.N))) wl++;   // window <= one wave
       H.wl = wl;
-      if (H.row_bytes > rows_image_bytes((int)kw)) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
+      if (H.row_bytes > (rsm ? rows_s_image_bytes((int)kw) : rows_image_bytes((int)kw))) return ctx->fail(KMX_E_UNSUPPORTED, "row wider than the LDS row image");
       u64 guess = K.rows_hint ? K.rows_hint : 2ULL * longest + 4096;
       if (ctx->rows_per_longest > 0.0) guess = std::max<u64>(guess, (u64)(ctx->rows_per_longest * 1.125 * (double)longest) + 4096);
       if (guess > H.total_recs) guess = H.total_recs;
@@ -842,7 +850,7 @@ extern "C" int kmx_merge_dev(kmx_ctx* ctx, const kmx_merge_task* tasks, uint32_t
     max_n = std::max(max_n, H.N); max_c = std::max(max_c, H.c);
   }
   R->n_items = n_items; R->max_n = max_n; R->max_c = max_c;
-  R->grid = std::min(n_items, is_bf ? slots : (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)kw));
+  R->grid = std::min(n_items, is_bf ? slots : (u32)ctx->n_cu * (u32)(R->rows_small ? rows_s_wgs_per_cu((int)kw) : rows_wgs_per_cu((int)kw)));
   if (R->use_pivot) R->grid = std::min(n_items, (u32)ctx->n_cu);   // one 1024-thread workgroup per CU
   if (R->use_cols) {
     // the row-key merges: up to 8 lists spread over each task, same recurrence-min
@@ -1205,7 +1213,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
       const bool was_pivot = R->use_pivot, was_cols = R->use_cols; const u32 was_items = R->n_items, was_grid = R->grid;
       R->use_cols = false; R->use_pivot = to_pivot; R->n_items = (u32)redo.size();
       R->grid = to_pivot ? std::min(R->n_items, (u32)ctx->n_cu)
-                         : std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
+                         : std::min(R->n_items, (u32)ctx->n_cu * (u32)(R->rows_small ? rows_s_wgs_per_cu((int)R->tasks[0].kw) : rows_wgs_per_cu((int)R->tasks[0].kw)));
       rc = launch_batch(R, false);
       if (rc == KMX_OK) { hipError_t he = hipEventSynchronize(R->ev_done); if (he != hipSuccess) rc = ctx->fail(KMX_E_HIP, hipGetErrorString(he)); }
       // restore the full item list (an arena-overflow retry below re-runs the whole batch, with k_merge_rows)
@@ -1265,7 +1273,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
     if (R->use_cols || (R->rerun_rows && R->use_pivot)) {   // tasks a kernel handed back must not go through it again
       R->use_pivot = false; R->use_cols = false;
       for (auto& H : R->tasks) H.kernel = 0;
-      R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)rows_wgs_per_cu((int)R->tasks[0].kw));
+      R->grid = std::min(R->n_items, (u32)ctx->n_cu * (u32)(R->rows_small ? rows_s_wgs_per_cu((int)R->tasks[0].kw) : rows_wgs_per_cu((int)R->tasks[0].kw)));
     }
     rc = launch_batch(R, false);
     if (rc != KMX_OK) { R->waited = true; R->status = rc; return rc; }

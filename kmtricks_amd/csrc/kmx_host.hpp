@@ -19,6 +19,11 @@ u32 rows_image_bytes(int kw);
 hipError_t launch_range_bounds(int kw, const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st);
 hipError_t launch_merge_rows(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
                              u32 grid_x, u32 max_n, hipStream_t st);
+// the same kernel built for cohorts of up to 256 lists (merge_rows_small.hip: 512 threads, 2048 slots, two workgroups a CU; keys of one and two words)
+int rows_s_cap(int kw, u32 n_lists);
+int rows_s_wgs_per_cu(int kw);
+u32 rows_s_image_bytes(int kw);
+hipError_t launch_merge_rows_s(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket, u32 grid_x, u32 max_n, hipStream_t st);
 int pivot_lds_bytes(int kw);
 u32 pivot_max_lists();
 hipError_t launch_merge_pivot(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,

@@ -26,6 +26,26 @@
 #include <cstdio>
 #include <cstring>
 
+// Round 6: a second build of this file (merge_rows_small.hip: KMX_ROWS_SMALL, 512 threads, 2048 record slots, two workgroups a CU) for
+// cohorts of up to 256 lists -- there a list's window is 8-16 slots whatever the tile, and what the kernel waits for is its barriers
+// and the next records: two smaller workgroups a CU hide one another's (64 lists 0.18 -> 0.24 of the roofline, 128: 0.23 -> 0.27,
+// 256: 0.25 -> 0.27; profiles/r06_mid_cohorts.txt).  The build's names differ so that both live in one library.
+#ifdef KMX_ROWS_SMALL
+#define k_merge_rows k_merge_rows_s
+#define cap_of cap_of_s
+#define ts_of ts_of_s
+#define rows_emit_bytes rows_emit_bytes_s
+#define rows_fixed_bytes rows_fixed_bytes_s
+#define rows_big rows_big_s
+#define rows_lds_bytes rows_s_lds_bytes
+#define rows_cap rows_s_cap
+#define rows_wgs_per_cu rows_s_wgs_per_cu
+#define rows_image_bytes rows_s_image_bytes
+#define launch_merge_rows launch_merge_rows_s
+#define kmx_phase_prof kmx_phase_prof_s
+#define rows_phase_prof_dump rows_s_phase_prof_dump
+#endif
+
 namespace kmx {
 
 #ifndef KMX_ROWS_TPB
@@ -52,6 +72,7 @@ __host__ __device__ constexpr int ts_of(int cap) { int t = 1; while (t < 2 * cap
 __host__ __device__ inline int rows_emit_bytes(int kw, bool big = false) { return cap_of(kw, big) * kw * 8; }
 __host__ __device__ inline int rows_fixed_bytes(int kw, bool big = false) { return cap_of(kw, big) * kw * 8 + ts_of(cap_of(kw, big)) * 4 + cap_of(kw, big) * 2 + 4096; }
 
+#ifndef KMX_ROWS_SMALL
 // ---- range bounds ------------------------------------------------------------------------------
 // bounds[j*N + i] = first record of list i whose key >= Q_j, Q_j = pivot[j * len_pivot / c].
 template <int KW>
@@ -97,6 +118,7 @@ __global__ void k_range_bounds(const TaskDev* __restrict__ tasks, u32 max_c)
   }
   T.bounds[(u64)j * T.N + i] = res;
 }
+#endif
 
 #ifdef KMX_PHASE_PROF
 __device__ u64 kmx_phase_prof[16];
@@ -502,14 +524,17 @@ void k_merge_rows(const TaskDev* __restrict__ tasks, const uint2* __restrict__ i
 }
 
 // explicit instantiations used by the host side
+#ifndef KMX_ROWS_SMALL
 template __global__ void k_range_bounds<1>(const TaskDev*, u32);
 template __global__ void k_range_bounds<2>(const TaskDev*, u32);
 template __global__ void k_range_bounds<3>(const TaskDev*, u32);
 template __global__ void k_range_bounds<4>(const TaskDev*, u32);
+#endif
 template __global__ void k_merge_rows<1, 0, false>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<1, 1, false>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<2, 0, false>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<2, 1, false>(const TaskDev*, const uint2*, u32, u32*);
+#ifndef KMX_ROWS_SMALL      // (the small build: keys of one and two words)
 template __global__ void k_merge_rows<3, 0, false>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<3, 1, false>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<4, 0, false>(const TaskDev*, const uint2*, u32, u32*);
@@ -518,6 +543,7 @@ template __global__ void k_merge_rows<3, 0, true>(const TaskDev*, const uint2*, 
 template __global__ void k_merge_rows<3, 1, true>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<4, 0, true>(const TaskDev*, const uint2*, u32, u32*);
 template __global__ void k_merge_rows<4, 1, true>(const TaskDev*, const uint2*, u32, u32*);
+#endif
 
 }  // namespace kmx
 
@@ -528,7 +554,9 @@ static bool rows_big(int kw, u32 n) { return kw >= 3 && n > (u32)cap_of(kw); }
 int rows_lds_bytes(int kw, u32 n) { return rows_fixed_bytes(kw, rows_big(kw, n)) + (kw <= 2 ? 384 : NWAVE * kw * 8 + 128); }
 int rows_cap(int kw, u32 n) { return cap_of(kw, rows_big(kw, n)); }      // record slots of a tile = the most lists of a task (n: the task's lists; ~0u: the limit)
 int rows_wgs_per_cu(int kw) { return kw == 1 ? WGS_PER_CU : 1; }
+#ifndef KMX_ROWS_SMALL
 u32 rows_chunk_rows(u32 row_bytes) { return std::max(64u, (u32)KMX_CHUNK_BYTES / row_bytes); }
+#endif
 u32 rows_image_bytes(int kw) { return (u32)rows_emit_bytes(kw); }
 #ifdef KMX_PHASE_PROF
 void rows_phase_prof_dump()
@@ -543,6 +571,7 @@ void rows_phase_prof_dump()
 }
 #endif
 
+#ifndef KMX_ROWS_SMALL
 hipError_t launch_range_bounds(int kw, const TaskDev* tasks, u32 n_tasks, u32 max_n, u32 max_c, hipStream_t st)
 {
   dim3 grid((max_n + 255) / 256, max_c + 1, n_tasks), block(256);
@@ -552,6 +581,7 @@ hipError_t launch_range_bounds(int kw, const TaskDev* tasks, u32 n_tasks, u32 ma
   else hipLaunchKernelGGL(k_range_bounds<4>, grid, block, 0, st, tasks, max_c);
   return hipGetLastError();
 }
+#endif
 
 hipError_t launch_merge_rows(int kw, int mode, const TaskDev* tasks, const uint2* items, u32 n_items, u32* ticket,
                              u32 grid_x, u32 max_n, hipStream_t st)
@@ -569,6 +599,7 @@ hipError_t launch_merge_rows(int kw, int mode, const TaskDev* tasks, const uint2
   else if (kw == 1 && mode == 1) KMX_LAUNCH(1, 1, false);
   else if (kw == 2 && mode == 0) KMX_LAUNCH(2, 0, false);
   else if (kw == 2 && mode == 1) KMX_LAUNCH(2, 1, false);
+#ifndef KMX_ROWS_SMALL
   else if (kw == 3 && mode == 0 && rows_big(3, max_n)) KMX_LAUNCH(3, 0, true);
   else if (kw == 3 && mode == 1 && rows_big(3, max_n)) KMX_LAUNCH(3, 1, true);
   else if (kw == 4 && mode == 0 && rows_big(4, max_n)) KMX_LAUNCH(4, 0, true);
@@ -577,6 +608,7 @@ hipError_t launch_merge_rows(int kw, int mode, const TaskDev* tasks, const uint2
   else if (kw == 3 && mode == 1) KMX_LAUNCH(3, 1, false);
   else if (kw == 4 && mode == 0) KMX_LAUNCH(4, 0, false);
   else if (kw == 4 && mode == 1) KMX_LAUNCH(4, 1, false);
+#endif
   else return hipErrorInvalidValue;
 #undef KMX_LAUNCH
   return hipGetLastError();
