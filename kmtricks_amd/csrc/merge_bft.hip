@@ -41,25 +41,32 @@
 
 namespace kmx {
 
-constexpr int BT_TPB = 512;
+// (round 6: 768 threads -- 48 samples a block, twelve waves a CU instead of eight, rounds of 7 x 16 / 5 x 16 records a sample: 2.30 -> 2.04 ms
+//  for configs[3] on one box, 1.97 -> 1.88 on another (profiles/r06_bft_variants.txt); 1024 threads with rounds that fit their registers: 1.93-1.95)
+#ifndef KMX_BT_TPB
+#define KMX_BT_TPB 768
+#endif
+constexpr int BT_TPB = KMX_BT_TPB;
 #ifndef KMX_BT_G
 #define KMX_BT_G 16
 #endif
 constexpr int BT_G = KMX_BT_G;             // lanes per sample (16: a sample's ~80 records of a tile are 1 KB, read by 16 adjacent lanes)
 constexpr int BT_NB = BT_TPB / BT_G;       // samples per block (32)
 #ifndef KMX_BT_IMG_KB
-#define KMX_BT_IMG_KB 64
+#define KMX_BT_IMG_KB 66
 #endif
-constexpr int BT_RT = KMX_BT_IMG_KB * 1024 * 8 / BT_NB;   // hash rows per tile: a 64 KB image (16384 rows of 32 samples) ...
+constexpr int BT_RT = KMX_BT_IMG_KB * 1024 * 8 / BT_NB;   // hash rows per tile: a 66 KB image (11264 rows of 48 samples) ...
+static_assert((KMX_BT_IMG_KB * 1024 * 8) % BT_NB == 0 && BT_RT % 256 == 0, "a tile is a whole number of 256-row steps (bft_fit_rows)");
 #ifndef KMX_BT_IMG1_KB
 #define KMX_BT_IMG1_KB 96
 #endif
-constexpr int BT_RT1 = KMX_BT_IMG1_KB * 1024 * 8 / BT_NB; // ... 24576 rows (96 KB) when a row's recurrence is one bit (or not needed at all)
+constexpr int BT_RT1 = KMX_BT_IMG1_KB * 1024 * 8 / BT_NB; // ... 16384 rows (96 KB) when a row's recurrence is one bit (or not needed at all)
+static_assert((KMX_BT_IMG1_KB * 1024 * 8) % BT_NB == 0 && BT_RT1 % 256 == 0, "a tile is a whole number of 256-row steps");
 #ifndef KMX_BT_UNR
-#define KMX_BT_UNR 8
+#define KMX_BT_UNR 5
 #endif
 #ifndef KMX_BT_UNR1
-#define KMX_BT_UNR1 10
+#define KMX_BT_UNR1 7
 #endif
 #ifndef KMX_BT_RB
 #define KMX_BT_RB 2

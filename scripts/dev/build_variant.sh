@@ -7,7 +7,7 @@ name=$1; flags=$2
 root="$(cd "$(dirname "$0")/../.." && pwd)"
 obj=/tmp/kmx_objs_$name; rm -rf $obj; mkdir -p $obj
 cd $root/kmtricks_amd/csrc
-all="kmx_api merge_rows merge_pivot merge_cols merge_cols_k2 merge_bf merge_bft count transpose superk"
+all="kmx_api merge_rows merge_rows_small merge_pivot merge_cols merge_cols_k2 merge_bf merge_bft count transpose superk"
 for f in $all; do
   if [ -z "$FILES" ] || [[ " $FILES " == *" $f "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $flags -c $f.hip -o $obj/$f.o &
