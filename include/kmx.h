@@ -69,6 +69,13 @@ int  kmx_version(void);
 int  kmx_device_count(void);   /* HIP devices visible to this process (0: none -- libkmx has no CPU fallback) */
 /* free and total bytes of a device's memory (hipMemGetInfo) */
 int  kmx_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+/* Round 6.  Takes `bytes` of the device's memory in blocks of 1 GiB, holds them all, and gives them back: on a box whose HBM has not
+ * been used since boot the driver clears memory the first time it is handed out (~30 us a MB: 8 ms for a 256 MB store chunk, 18 ms
+ * for a 600 MB row arena, with the GPU idle behind the allocating call) and not again afterwards.  `kmx pipeline` calls it on a
+ * thread of its own while the first samples are read (KMX_WARM_GB, default 96, 0: never); the count and merge stages' own
+ * allocations then find memory that is handed out at once.  Returns the bytes it took (0: nothing to do, or no memory to spare). */
+uint64_t kmx_device_warm(int device, uint64_t bytes, const volatile int* stop /* or NULL: checked before every block; non-zero ends the call */);
+/* (it times its first block: memory that comes at once -- under 5 ms a GiB -- has been handed out before, and the call returns) */
 int  kmx_create(int device, kmx_ctx** out);
 void kmx_destroy(kmx_ctx* ctx);
 /* last error message of this ctx (or of the failed kmx_create when ctx == NULL) */

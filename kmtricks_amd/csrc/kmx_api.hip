@@ -90,6 +90,28 @@ extern "C" int kmx_device_memory(int device, uint64_t* free_bytes, uint64_t* tot
   return KMX_OK;
 }
 
+extern "C" uint64_t kmx_device_warm(int device, uint64_t bytes, const volatile int* stop)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || bytes == 0) return 0;
+  if (hipSetDevice(device) != hipSuccess) return 0;
+  const size_t piece = (size_t)1 << 30;
+  std::vector<void*> held;
+  uint64_t got = 0;
+  while (got < bytes) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < tot / 4 + piece) break;      // (a quarter of the device stays free for whoever is working)
+    if (stop && *stop) break;
+    void* p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipMalloc(&p, piece) != hipSuccess) { (void)hipGetLastError(); break; }
+    held.push_back(p); got += piece;
+    if (held.size() == 1 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < 5.0) break;      // (this memory has been handed out before)
+  }
+  for (void* p : held) (void)hipFree(p);
+  return got;
+}
+
 extern "C" int kmx_create(int device, kmx_ctx** out)
 {
   if (!out) { g_create_err = "kmx_create: out is NULL"; return KMX_E_INVAL; }
@@ -195,13 +217,45 @@ void kmx_pinned_free(void* p)
 extern "C" void* kmx_alloc_pinned(size_t bytes) { return kmx_pinned_alloc(bytes); }
 extern "C" void kmx_free_pinned(void* p) { kmx_pinned_free(p); }
 // ---- kmx_store: count lists resident in HBM between the count and the merge stage ---------------------------------
+void kmx_store::start_ahead()
+{
+  if (ahead_on) return;
+  ahead_on = true;
+  const char* e = getenv("KMX_STORE_AHEAD");
+  if (e && e[0] == '0') return;
+  ahead = std::thread([this]() {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [this]() { return stop || spare.size() < 2; });
+      if (stop) return;
+      size_t held = 0; for (auto& c : chunks) held += c.cap; for (auto& c : spare) held += c.cap;
+      if (limit && held + chunk_bytes > limit + chunk_bytes) { cv.wait_for(lk, std::chrono::milliseconds(50)); continue; }      // (at the limit: nothing more ahead)
+      lk.unlock();
+      void* p = nullptr;
+      const hipError_t er = hipMalloc(&p, chunk_bytes);
+      lk.lock();
+      if (er != hipSuccess) { (void)hipGetLastError(); cv.wait_for(lk, std::chrono::milliseconds(200)); continue; }
+      spare.push_back({(u8*)p, chunk_bytes, 0});
+    }
+  });
+}
+bool kmx_store::take_spare(size_t bytes, Chunk& out)
+{
+  if (bytes > chunk_bytes || spare.empty()) return false;
+  out = spare.back(); spare.pop_back();
+  cv.notify_one();
+  return true;
+}
 void* kmx_store::alloc(size_t bytes)
 {
   bytes = (bytes + 255) / 256 * 256;
   if (bytes == 0) bytes = 256;
   std::lock_guard<std::mutex> lk(mu);
+  start_ahead();
   if (limit && used + bytes > limit) return nullptr;
   for (size_t i = 0; i < chunks.size(); i++) { auto& c = chunks[i]; if ((int)i != resv_chunk && c.cap - c.fill >= bytes) { void* p = c.p + c.fill; c.fill += bytes; used += bytes; return p; } }
+  { Chunk sp; if (take_spare(bytes, sp)) { sp.fill = bytes; chunks.push_back(sp); used += bytes; return sp.p; } }
   int cur = -1; (void)hipGetDevice(&cur);
   if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
   size_t cap = std::max(bytes, chunk_bytes);
@@ -221,6 +275,7 @@ void* kmx_store::try_reserve(size_t bytes)
   bytes = (bytes + 255) / 256 * 256;
   if (bytes == 0) bytes = 256;
   std::lock_guard<std::mutex> lk(mu);
+  start_ahead();
   if (resv_chunk >= 0 || (limit && used + bytes > limit)) return nullptr;
   for (int pass = 0; pass < 2; pass++) {
     for (size_t i = 0; i < chunks.size(); i++) {
@@ -228,7 +283,8 @@ void* kmx_store::try_reserve(size_t bytes)
       if (c.cap - c.fill >= bytes) { resv_chunk = (int)i; resv_off = c.fill; resv_bytes = bytes; c.fill += bytes; used += bytes; return c.p + resv_off; }
     }
     if (pass) break;
-    // no chunk with that much room: a new one, as alloc() makes it
+    // no chunk with that much room: a new one, as alloc() makes it -- the one made ahead when there is one
+    { Chunk sp; if (take_spare(bytes, sp)) { chunks.push_back(sp); continue; } }
     int cur = -1; (void)hipGetDevice(&cur);
     if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
     const size_t cap = std::max(bytes, chunk_bytes);
@@ -275,6 +331,10 @@ extern "C" void kmx_store_destroy(kmx_store* s)
   int cur = -1; (void)hipGetDevice(&cur);
   (void)hipSetDevice(s->device);
   (void)hipDeviceSynchronize();
+  { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
+  s->cv.notify_all();
+  if (s->ahead.joinable()) s->ahead.join();
+  for (auto& c : s->spare) (void)hipFree(c.p);
   for (auto& c : s->chunks) (void)hipFree(c.p);
   if (cur >= 0 && cur != s->device) (void)hipSetDevice(cur);
   delete s;

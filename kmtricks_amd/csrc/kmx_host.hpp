@@ -120,6 +120,8 @@ struct kmx_pool_block { void* p; size_t bytes; bool used; };
 
 // ---- device arena of count lists (kmx_store_*): chunks of HBM on one GPU, bump-allocated, freed together ----
 #include <mutex>
+#include <thread>
+#include <condition_variable>
 struct kmx_store {
   int device = 0;
   size_t limit = 0, used = 0, chunk_bytes = 0;
@@ -130,6 +132,11 @@ struct kmx_store {
   // round 6: a count call that does not know its lists' size yet takes room for an estimate, has its kernel write there, and gives
   // back what it did not need once the size is read back (one reservation at a time per store; while it is open, alloc() leaves its chunk alone)
   int resv_chunk = -1; size_t resv_off = 0, resv_bytes = 0;
+  // a chunk made ahead of its need by a thread of the store's own (round 6): on a box whose HBM has not been touched since boot a
+  // hipMalloc of 256 MB takes ~8 ms (the driver clears it), 223 of them for configs[2]'s lists -- inside count calls, with the GPU idle
+  std::vector<Chunk> spare; std::thread ahead; std::condition_variable cv; bool stop = false, ahead_on = false;
+  void start_ahead();      // (first allocation; KMX_STORE_AHEAD=0: never)
+  bool take_spare(size_t bytes, Chunk& out);      // with mu held
   void* try_reserve(size_t bytes);              // nullptr: another reservation is open, or no room
   void commit(void* p, size_t used_bytes);      // keeps the first used_bytes of the reservation (0: none of it)
 };

@@ -44,8 +44,12 @@
 #endif
 #if KMX_CL_KW == 1
 #define CLNS cols_k1
-#else
+#elif KMX_CL_KW == 2
 #define CLNS cols_k2
+#elif KMX_CL_KW == 3
+#define CLNS cols_k3
+#else
+#define CLNS cols_k4
 #endif
 
 namespace kmx { namespace CLNS {
@@ -1974,7 +1978,11 @@ static const ColsOps g_ops = {cols_lds_bytes, cols_block_lists, cols_wgs_per_cu,
 }  // namespace CLNS
 #if KMX_CL_KW == 1
 const ColsOps& cols_ops_k1() { return cols_k1::g_ops; }
-#else
+#elif KMX_CL_KW == 2
 const ColsOps& cols_ops_k2() { return cols_k2::g_ops; }
+#elif KMX_CL_KW == 3
+const ColsOps& cols_ops_k3() { return cols_k3::g_ops; }
+#else
+const ColsOps& cols_ops_k4() { return cols_k4::g_ops; }
 #endif
 }  // namespace kmx

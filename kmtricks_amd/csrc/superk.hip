@@ -971,7 +971,12 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   } else if (ahead) { if ((e = hipStreamWaitEvent(st, ahead->ev, 0)) != hipSuccess) return fail(e, "wait for the uploaded bases"); }
   else if ((e = hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload bases");
   const SkMulti mu{segs ? d_first : nullptr, n_smp, segs ? segs->parts : 0u, segs ? (u32)nm : 0u};
-  if ((e = hipMemcpyAsync(d_offs, offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
+  // (round 6: the reads' offsets go through a page-locked block -- the caller's array is pageable as a rule, and a copy from pageable memory
+  //  is staged by the runtime with the calling thread waiting on the stream; 1.6 MB a sample)
+  u64* h_offs = segs ? nullptr : (u64*)ctx->halloc((n_seqs + 1) * 8);
+  struct HOffs { kmx_ctx* c; void* p; ~HOffs() { c->hfree(p); } } h_offs_rel{ctx, h_offs};
+  if (h_offs) memcpy(h_offs, offsets, (n_seqs + 1) * 8);
+  if ((e = hipMemcpyAsync(d_offs, h_offs ? (const void*)h_offs : (const void*)offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");
   if (repart) { if (rep_upload && (e = hipMemcpyAsync(d_rep, repart, nm * 2, hipMemcpyHostToDevice, st)) != hipSuccess) { ctx->rep_host = nullptr; return fail(e, "upload repartition"); } }
   else if ((e = hipMemsetAsync(d_rep, 0, nm * 2, st)) != hipSuccess) return fail(e, "memset");
   // (KMX_SUPERK_ONE_PASS: see below; KMX_STATS_ATOMICS=1: the statistics by atomics while the reads are walked, as rounds 1-3 had them)

@@ -483,6 +483,33 @@ class SeqReader {
   }
   SeqReader(const SeqReader&) = delete;
   ~SeqReader() { if (gz_) gzclose(gz_); else if (fd_ >= 0) ::close(fd_); }
+  // the next record's sequence as a VIEW: into the read block itself when the record is one header line and one sequence line that lie
+  // whole in the block with nothing to strip (short reads: every record but the ones that straddle a refill) -- the caller copies it
+  // once, to where it goes; else assembled in `tmp` as next() does.  The view holds until the next call.
+  bool next_view(std::string& tmp, const char*& p, size_t& n) {
+    if (hdr_ != '@' && pos_ < end_) {
+      const char* const b = buf_.get(); const char* const e = b + end_;
+      const char* s0 = nullptr;
+      if (have_hdr_ && hdr_ == '>') s0 = b + pos_;                                  // the header is behind us: at the sequence line
+      else if (!have_hdr_ && b[pos_] == '>') {                                      // at a header that lies in the block
+        const char* h = (const char*)memchr(b + pos_, '\n', end_ - pos_);
+        if (h && h + 1 < e) s0 = h + 1;
+      }
+      if (s0 && *s0 != '>') {
+        const char* l = (const char*)memchr(s0, '\n', (size_t)(e - s0));
+        // (the line behind it must start a new record: a second sequence line means joining, the end of the block means looking further)
+        if (l && l + 1 < e && l[1] == '>') {
+          const size_t m = (size_t)(l - s0);
+          unsigned low = 0;
+          for (size_t i = 0; i < m; i++) low |= (unsigned)((unsigned char)s0[i] <= ' ');
+          if (!low) { p = s0; n = m; pos_ = (size_t)(l + 1 - b); hdr_ = '>'; have_hdr_ = false; return true; }
+        }
+      }
+    }
+    if (!next(tmp)) return false;
+    p = tmp.data(); n = tmp.size();
+    return true;
+  }
   bool next(std::string& seq) {
     seq.clear();
     char c;

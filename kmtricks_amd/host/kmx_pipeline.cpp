@@ -308,6 +308,18 @@ int run(int argc, char** argv)
       stores.push_back(st_);
     }
   }
+  // (round 6) the devices' memory handed out once and given back, on threads of their own, while the first samples are read: a fresh
+  // box clears HBM the first time it is allocated -- 8 ms a store chunk, 18 ms a row arena, inside the count and merge calls
+  // (kmx_device_warm; KMX_WARM_GB=0: never)
+  std::vector<std::thread> warmers;
+  static volatile int warm_stop = 0;      // (raised when the count stage ends: the merge stage's allocations must not meet the warmers')
+  struct WarmJoin { std::vector<std::thread>& v; ~WarmJoin() { warm_stop = 1; for (auto& t : v) if (t.joinable()) t.join(); } } warm_join{warmers};
+  if (resident_mode) {
+    const char* e = getenv("KMX_WARM_GB");
+    const uint64_t gbs = e ? (uint64_t)std::max(0L, atol(e)) : 64;
+    const uint32_t nd = std::min<uint32_t>(G, (uint32_t)ndev);
+    if (gbs) for (uint32_t d = 0; d < nd; d++) warmers.emplace_back([d, gbs]() { (void)kmx_device_warm((int)d, gbs << 30, &warm_stop); });
+  }
   // how a count worker on one GPU fills the store of another: peer access is asked for here, once per ordered pair of devices in
   // use ("p2p": copies over xGMI; "staged": through host memory); the summary line says which
   uint32_t peer_pairs = 0, peer_direct = 0;
@@ -593,6 +605,7 @@ int run(int argc, char** argv)
       for (uint32_t si; (si = next_sample++) < N;) {
         Channel<ReadBatch>& ch = *chan[si % NW];
         ReadBatch b; b.si = si; b.offs.assign(1, 0);
+        b.offs.reserve(1u << 18);      // (short reads: a few hundred thousand a sample -- no regrowth under the parse)
         double rs = 0;
         // (a sample's reads reach the GPU in batches of 256 MB of bases; KMX_READ_BATCH_BYTES lowers that -- for the tests of the
         //  path that adds a sample's batches up)
@@ -604,16 +617,16 @@ int run(int argc, char** argv)
         b.bases = pinpool.get(want);
         try {
           for (const std::string& f : samples[si].files) {
-            SeqReader rd(f); std::string seq;
+            SeqReader rd(f); std::string seq; const char* sp = nullptr; size_t sn = 0;
             auto t = clk::now();
-            while (rd.next(seq)) {
-              if (b.bases.len + seq.size() > b.bases.cap || (b.bases.len + seq.size() > batch_bytes && b.offs.size() > 1)) {
+            while (rd.next_view(seq, sp, sn)) {      // (round 6: a short read is copied once, from the read block to the page-locked batch)
+              if (b.bases.len + sn > b.bases.cap || (b.bases.len + sn > batch_bytes && b.offs.size() > 1)) {
                 rs += since(t);
                 b.seal(); ch.push(std::move(b));
-                b = ReadBatch(); b.si = si; b.offs.assign(1, 0); b.bases = pinpool.get(std::max(want, seq.size()));
+                b = ReadBatch(); b.si = si; b.offs.assign(1, 0); b.bases = pinpool.get(std::max(want, sn));
                 t = clk::now();
               }
-              memcpy(b.bases.p + b.bases.len, seq.data(), seq.size()); b.bases.len += seq.size(); b.offs.push_back(b.bases.len);
+              memcpy(b.bases.p + b.bases.len, sp, sn); b.bases.len += sn; b.offs.push_back(b.bases.len);
             }
             rs += since(t);
           }
@@ -908,6 +921,7 @@ int run(int argc, char** argv)
     st.read = s_read; st.split = s_split; st.count = s_count;
   }
   st.count_wall = since(t_count_stage);
+  warm_stop = 1; for (auto& t : warmers) if (t.joinable()) t.join();      // (before the merge stage allocates)
   const auto t_merge_stage = clk::now();
   if (o.until == "superk" || o.until == "count") { report(); return 0; }
 

@@ -10,7 +10,7 @@ import csv, glob, json
 d = "$O/prof"
 ev = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
-    for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-60:], r.get("Stream_Id", r.get("Queue_Id", ""))))
+    for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-60:], r.get("Queue_Id", r.get("Stream_Id", ""))))
 cp = []
 for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)): cp.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Direction", ""), int(r.get("Bytes", r.get("Size", 0)) or 0)))
@@ -39,6 +39,18 @@ for e in allk[1:]:
     if e[0] > ce:
         g = gaps[(cek[-28:], e[2][-28:])]; g[0] += (e[0] - ce) / 1e3; g[1] += 1
     if e[1] > ce: ce, cek = e[1], e[2]
+# a window of the steady state: every kernel and copy with its queue, from the 150th sample's walk on (8 ms)
+walks = [e for e in last if "k_superk_wave" in e[2]]
+if len(walks) > 160:
+    w0 = walks[150][0]
+    print("window (us from the 150th walk; dur; queue; name):")
+    for e in sorted([x for x in last if w0 - 200_000 <= x[0] <= w0 + 8_000_000] + [(c[0], c[1], "COPY " + c[2][12:] + " " + str(c[3]), "-") for c in cp if w0 - 200_000 <= c[0] <= w0 + 8_000_000]):
+        print(f"  {(e[0] - w0) / 1e3:9.1f} {(e[1] - e[0]) / 1e3:8.1f}  q{e[3]}  {e[2][-44:]}")
+allev = sorted(last + [(c[0], c[1], "COPY " + c[2][12:] + " " + str(c[3]), "-") for c in cp if c[0] >= last[0][0] - 2_000_000_000])
+print("the run's first 45 kernels / copies (ms from the first; dur us):")
+for e in allev[:45]: print(f"  {(e[0] - allev[0][0]) / 1e6:9.3f} {(e[1] - e[0]) / 1e3:9.1f}  q{e[3]}  {e[2][-44:]}")
+wk = [e for e in last if "k_superk_wave" in e[2]]
+print("walk starts (ms from the first event), every 25th:", [round((w[0] - allev[0][0]) / 1e6, 1) for w in wk[::25]])
 print("idle gaps (us in all, count) by kernel in front -> kernel behind:")
 for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:14]: print(f"  {v[0]:10.0f} us  x{v[1]:5d}  {k[0]} -> {k[1]}")
 per = collections.defaultdict(float)

@@ -313,3 +313,32 @@ def test_combine_renames_duplicate_ids_and_checks_the_repartition(tmp_path):
     open(f"{runs[0]}/options.txt", "w").write("Options: mode=bf, count_format=hash\n")
     r = subprocess.run([KMX, "combine", "--fof", str(fof), "--output", str(tmp_path / "c3")], capture_output=True, text=True)
     assert r.returncode == 1 and "not supported by 'kmtricks combine'" in r.stderr
+
+
+def test_fasta_reader_views_equal_records(tmp_path):
+    """round 6: the pipeline's readers take a short read as a VIEW into the read block (SeqReader::next_view, kmx_io.hpp: one copy, to
+    the page-locked batch); it must cut every file into the records SeqReader::next does -- one-line and multi-line FASTA, CRLF, blanks
+    at a line's end, no final newline, gzip, FASTQ with quality lines that start with '>'"""
+    import gzip, random
+    exe = tmp_path / "reader_equiv"
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", f"-I{ROOT}/kmtricks_amd/host", f"{ROOT}/tests/helpers/reader_equiv.cpp", "-lz", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rnd = random.Random(5)
+    out = ""
+    for i in range(20000):
+        L = rnd.choice([0, 1, 5, 150, 150, 150, 150, 151, 400])
+        s = "".join(rnd.choice("ACGTN") for _ in range(L))
+        kind = rnd.random()
+        if kind < 0.8: out += f">r{i} some text\n{s}\n"
+        elif kind < 0.9: out += f">r{i}\n{s[:L // 2]}\n{s[L // 2:]}\n"
+        elif kind < 0.95: out += f">r{i}\n{s} \n\n"
+        else: out += f">r{i}\r\n{s}\r\n"
+    files = {"a.fa": out, "b.fa": out.rstrip("\n"), "d.fq": "".join(f"@q{i}\n{'ACGT' * 10}\n+\n{'>' * 40}\n" for i in range(3000)),
+             "e.fa": ">only\n" + "ACGT" * 700000 + "\n"}      # (a record longer than the reader's 1 MB block)
+    for name, text in files.items():
+        (tmp_path / name).write_text(text)
+    with gzip.open(tmp_path / "c.fa.gz", "wt") as f:
+        f.write(out)
+    for name in list(files) + ["c.fa.gz"]:
+        r = subprocess.run([str(exe), str(tmp_path / name)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.split()[-1] == "same", (name, r.stdout, r.stderr)
