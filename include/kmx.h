@@ -117,7 +117,7 @@ typedef struct {
   uint32_t        n_lists;     /* N samples, fof order = column order (kmdir.hpp:65-72).
                                   LIMIT (a deliberate deviation from KmerMerger, which takes any vector of paths, merge.hpp:115-125): a COUNT / PA
                                   task takes at most 4096 lists (3072 with keys of four words) -- a row's cursors and its image live in one
-                                  workgroup's LDS; a hash:bft task at most ~7000 (the cursors of every sample beside the 96 KB tile).  Beyond:
+                                  workgroup's LDS; a hash:bft task at most 18396 (the cursors of every sample beside the tile).  Beyond:
                                   KMX_E_UNSUPPORTED, nothing is merged.  BASELINE's largest cohort is 2500.  (BF / BFC windows: no limit of that kind.) */
   uint32_t        key_words;   /* ceil(k / 32) (kmer.hpp:215 m_n_data, io/kmer_file.hpp:84 kmer_slots): 1 for k <= 32 and hash keys, 2 up to 64,
                                   3 up to 96, 4 up to 128.  3 and 4 (the reference's Kmer<96> / Kmer<128>): COUNT / PA rows, at most 4096 (three words) / 3072 (four) lists a task */

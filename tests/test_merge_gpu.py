@@ -313,7 +313,7 @@ def test_limits_fail_loudly(ctx, merge_kernel):
         pytest.skip("one run is enough")
     empty = (np.zeros((0, 1), np.uint64), np.zeros(0, np.uint32))
     with pytest.raises(Exception, match="hash:bft"):
-        ctx.merge([empty] * 17000, 1, [1] * 17000, 1, 0, orc.MODE_BFT, 0, 6399)
+        ctx.merge([empty] * 19000, 1, [1] * 19000, 1, 0, orc.MODE_BFT, 0, 6399)      # (round 6: 18396 cursors fit beside the 768-thread build's smaller tile)
     one = (np.array([[7]], np.uint64), np.array([3], np.uint32))
     check(ctx, [one] + [empty] * 8999, 1, [1] * 9000, 1, 1, orc.MODE_BFT, 0, 6399)      # (9000 samples: the tables no longer fit the LDS, only the cursors; smaller tiles)
     with pytest.raises(Exception, match="4096 lists"):
