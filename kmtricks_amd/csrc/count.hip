@@ -105,7 +105,8 @@ template <int KW, int HASH, bool DIRECT>
 __global__ __launch_bounds__(256)
 void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ prefix, const u32* __restrict__ blk_first, const u16* __restrict__ rec_part,
                            const u64* __restrict__ part_ids, u32 n_recs, u32 total, int k, u64 win, void* __restrict__ out, const u32* __restrict__ sbase,
-                           const SkfCtl* __restrict__ ctl = nullptr /* set: the sizes are the device's (the grid covers a bound) */)
+                           const SkfCtl* __restrict__ ctl = nullptr /* set: the sizes are the device's (the grid covers a bound) */,
+                           unsigned long long* __restrict__ strand = nullptr /* set (DIRECT): bit g = k-mer g is its own canonical form (forward < reverse complement) */)
 {
   __shared__ u64 pk[DK + 1];
   __shared__ u32 nrec_s;
@@ -142,6 +143,7 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
         const u64 rev = revcomp64(fwd, k);
         const u64 c = fwd < rev ? fwd : rev;
         reinterpret_cast<u64*>(out)[g] = HASH ? (xxh64_words(&c, 1) % win + win * part) : c;
+        if (strand) { const u64 m = __ballot(fwd < rev); if ((tid & 63u) == 0) strand[g >> 6] = m; }      // (a wave's 64 k-mers are g .. g + 63, g a multiple of 64; lanes behind the batch's end are not in the ballot)
       } else {
         const u128 a = ((u128)W[w] << 64) | W[w + 1];
         const u64 l = W[w + 2];
@@ -150,6 +152,7 @@ void k_superk_decode_kmers(const u8* __restrict__ recs, const u64* __restrict__ 
         const u128 c = fwd < rev ? fwd : rev;
         if (HASH) { u64 x[2] = {(u64)c, (u64)(c >> 64)}; reinterpret_cast<u64*>(out)[g] = xxh64_words(x, 2) % win + win * part; }
         else reinterpret_cast<u128*>(out)[g] = c;
+        if (strand) { const u64 m = __ballot(fwd < rev); if ((tid & 63u) == 0) strand[g >> 6] = m; }
       }
     } else if (KW == 1) {
       const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
@@ -1168,20 +1171,27 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   static_assert(sizeof(CsPart) == sizeof(uint4), "k_sk_scan writes the sample sort's partitions as uint4");
   constexpr int KWD = sizeof(KeyT) == 8 ? 1 : 2;
   const dim3 gd(F.nb_max), bd(256);
-#define KMX_DECODE_F(KW_, H_) hipLaunchKernelGGL((k_superk_decode_kmers<KW_, H_, true>), gd, bd, 0, st, (const u8*)F.d_words, F.d_boff, F.d_blk, F.d_part16, (const u64*)nullptr, 0u, 0u, (int)rq.k, rq.window, (void*)d_keys, F.d_sbase, (const SkfCtl*)F.d_ctl)
+#define KMX_DECODE_F(KW_, H_) hipLaunchKernelGGL((k_superk_decode_kmers<KW_, H_, true>), gd, bd, 0, st, (const u8*)F.d_words, F.d_boff, F.d_blk, F.d_part16, (const u64*)nullptr, 0u, 0u, (int)rq.k, rq.window, (void*)d_keys, F.d_sbase, (const SkfCtl*)F.d_ctl, F.d_strand)
   if (rq.hash_mode) { if (rq.k <= 32) KMX_DECODE_F(1, 1); else KMX_DECODE_F(2, 1); }
   else if (KWD == 1) KMX_DECODE_F(1, 0); else KMX_DECODE_F(2, 0);
 #undef KMX_DECODE_F
-  hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(P), dim3(CS_SPL_TPB), 0, st, d_keys, d_parts, d_spl, (const SkfCtl*)F.d_ctl);
-  hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, F.d_cnt, (KeyT*)nullptr, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+  // the look-up table in front of the walks' bucket search: on the keys' top 32 significant bits (KMX_COUNT_LUT=0: the plain binary search)
+  u32 tshift = 0;
+  if (rq.hash_mode) { unsigned __int128 span = (unsigned __int128)rq.window * (rq.inner_parts ? rq.inner_parts : P); u32 bits = 0; while (bits < 64 && (span >> bits)) bits++; tshift = bits > 32 ? bits - 32 : 0; }
+  else tshift = 2 * rq.k > 32 ? 2 * rq.k - 32 : 0;
+  static_assert(sizeof(CsLut) % 4 == 0, "the walks copy the table as dwords");
+  CsLut* d_luts = nullptr;
+  { const char* le = getenv("KMX_COUNT_LUT"); if (!(le && le[0] == '0')) { d_luts = (CsLut*)dal(sizeof(CsLut) * (size_t)P); if (!d_luts) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); } } }
+  hipLaunchKernelGGL((k_cs_splitters<KeyT>), dim3(P), dim3(CS_SPL_TPB), 0, st, d_keys, d_parts, d_spl, (const SkfCtl*)F.d_ctl, d_luts, tshift);
+  hipLaunchKernelGGL((k_cs_walk<KeyT, false>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, F.d_cnt, (KeyT*)nullptr, (const SkfCtl*)F.d_ctl, F.d_cfirst, P, (const CsLut*)d_luts, tshift);
   const dim3 gs((TBm + 1 + 4095) / 4096);      // (at most 256 workgroups: the caller bounds the batch)
   u32* d_agg = (u32*)dal(4 * 512);
   if (!d_agg || gs.x > 256) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
   hipLaunchKernelGGL(k_cs_scan_mw, gs, dim3(1024), 0, st, F.d_cnt, (const u32*)&F.d_ctl->TB, d_boff, d_cur, d_agg, F.d_sflags);
   if (getenv("KMX_COUNT_SCATTER_PLAIN"))      // (the scatter of rounds 3-5, for comparison)
-    hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+    hipLaunchKernelGGL((k_cs_walk<KeyT, true>), dim3(F.nc_max), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, (const CsChunk*)nullptr, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P, (const CsLut*)d_luts, tshift);
   else
-    hipLaunchKernelGGL((k_cs_scatter_staged<KeyT>), dim3(F.nc_max * (cs_chunk<KeyT>() / cs_schunk<KeyT>())), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P);
+    hipLaunchKernelGGL((k_cs_scatter_staged<KeyT>), dim3(F.nc_max * (cs_chunk<KeyT>() / cs_schunk<KeyT>())), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P, (const CsLut*)d_luts, tshift);
   if (F.behind_scatter) { const int brc = F.behind_scatter(); if (brc != KMX_OK) { (void)hipStreamSynchronize(st); release(); return brc; } }
   hipLaunchKernelGGL((k_cs_wave_sort<KeyT, 8, 16>), dim3((TBm + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, d_bkeys, d_boff, 0u, 0u, (u32)CsCap<KeyT>::cap,
                      rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, F.d_ctl, d_big);

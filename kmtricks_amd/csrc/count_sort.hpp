@@ -189,13 +189,24 @@ __device__ __forceinline__ void cs_sort_lds(K* s, u32 P, u32 tid)
 }
 
 constexpr int CS_SPL_TPB = 1024;          // (a workgroup per partition: few of them for few large partitions -- the sort of the samples is the kernel's time)
+// ---- round 6: a look-up table in front of the bucket search.  A walk finds a key's bucket with a binary search over the partition's
+//      splitters: 8 dependent 8-byte LDS reads a key, half of a walk's time.  The table cuts a partition's key range -- seen through
+//      t(key) = 32 bits of the key from bit `tshift` on (its top 32 significant bits) -- into CS_LUT cells of equal width between the
+//      first and the last splitter and holds, per cell border, how many splitters lie below it: a key's cell leaves the exact search
+//      (the same compares on the same splitters) the splitters INSIDE the cell -- none or one as a rule, all of them only when every
+//      splitter shares its 32 bits.  k_cs_splitters builds it, 2 KB a partition. ----
+constexpr u32 CS_LUT = 1024;
+struct CsLut { u32 tmin, lsh; u16 lb[CS_LUT + 2]; };      // lb[c]: splitters whose t is below cell c's first value; lb[CS_LUT] = all of them
+template <typename K> __device__ __forceinline__ u32 cs_t32(const K& k, u32 tshift) { return (u32)(k >> tshift); }
 template <typename K>
 __global__ __launch_bounds__(CS_SPL_TPB)
-void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, typename CsSpl<K>::type* __restrict__ splitters, const SkfCtl* __restrict__ ctl = nullptr)
+void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts, typename CsSpl<K>::type* __restrict__ splitters, const SkfCtl* __restrict__ ctl = nullptr,
+                    CsLut* __restrict__ luts = nullptr /* [partitions]; with tshift */, u32 tshift = 0)
 {
   typedef typename CsSpl<K>::type S_t;
   constexpr u32 SMAX = (u32)CsCap<K>::sample;
   __shared__ S_t sm[SMAX];
+  __shared__ u32 tsp[CS_MAXB];      // (luts) t of the partition's splitters
   if (ctl && ctl->status) return;      // (the sync-free path: the tables may name more than this kernel takes -- the call goes the old way)
   const CsPart P = parts[blockIdx.x];
   if (P.nb <= 1) return;
@@ -210,7 +221,38 @@ void k_cs_splitters(const K* __restrict__ keys, const CsPart* __restrict__ parts
   __syncthreads();
   cs_sort_lds<S_t, CS_SPL_TPB>(sm, S, tid);
   // bucket b holds the keys k with splitter[b - 1] <= k < splitter[b]
-  for (u32 b = tid; b + 1 < P.nb; b += CS_SPL_TPB) splitters[(u64)P.bucket0 + b] = sm[(u32)(((u64)(b + 1) * S) / P.nb)];
+  for (u32 b = tid; b + 1 < P.nb; b += CS_SPL_TPB) {
+    const S_t v = sm[(u32)(((u64)(b + 1) * S) / P.nb)];
+    splitters[(u64)P.bucket0 + b] = v;
+    if constexpr (sizeof(S_t) == sizeof(K)) { if (luts) tsp[b] = cs_t32<S_t>(v, tshift); }
+  }
+  if constexpr (sizeof(S_t) == sizeof(K)) {
+    if (luts) {
+      __syncthreads();
+      const u32 ns = P.nb - 1, tmin = tsp[0], tmax = tsp[ns - 1];
+      u32 lsh = 0; while (((tmax - tmin) >> lsh) >= CS_LUT) lsh++;
+      CsLut& L = luts[blockIdx.x];
+      if (tid == 0) { L.tmin = tmin; L.lsh = lsh; }
+      for (u32 c = tid; c <= CS_LUT; c += CS_SPL_TPB) {
+        u32 lo = 0, hi = ns;
+        if (c == CS_LUT) lo = ns;
+        else {
+          const u64 start = (u64)tmin + ((u64)c << lsh);      // splitters with t < start
+          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u64)tsp[mid] < start) lo = mid + 1; else hi = mid; }
+        }
+        L.lb[c] = (u16)lo;
+      }
+    }
+  }
+}
+// the bucket of key k (= the number of splitters <= k) with the table in front: lt = the partition's table in LDS
+template <typename S_t> __device__ __forceinline__ u32 cs_bucket_lut(const S_t* spl, const CsLut* lt, u32 tshift, S_t k)
+{
+  const u32 t = cs_t32<S_t>(k, tshift);
+  const u32 c = t <= lt->tmin ? 0u : min(CS_LUT - 1u, (t - lt->tmin) >> lt->lsh);
+  u32 lo = lt->lb[c], hi = lt->lb[c + 1];
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (spl[mid] <= k) lo = mid + 1; else hi = mid; }
+  return lo;
 }
 
 template <typename K> __device__ __forceinline__ u32 cs_bucket(const K* spl, u32 nb, K k)
@@ -226,13 +268,15 @@ template <typename K, bool SCATTER>
 __global__ __launch_bounds__(CS_WALK_TPB)
 void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, const CsChunk* __restrict__ chunks, const typename CsSpl<K>::type* __restrict__ splitters,
                u32* __restrict__ counts_or_cursor, K* __restrict__ out,
-               const SkfCtl* __restrict__ ctl = nullptr, const u32* __restrict__ cfirst = nullptr /* [n_parts + 1] first chunk of every partition */, u32 n_parts = 0)
+               const SkfCtl* __restrict__ ctl = nullptr, const u32* __restrict__ cfirst = nullptr /* [n_parts + 1] first chunk of every partition */, u32 n_parts = 0,
+               const CsLut* __restrict__ luts = nullptr, u32 tshift = 0)
 {
   typedef typename CsSpl<K>::type S_t;
   constexpr int IPT = CsCap<K>::walk;      // (the chunks are cut to IPT * CS_WALK_TPB keys by the host: cs_chunk<K>())
   __shared__ S_t spl[CS_MAXB];
   __shared__ u32 hist[CS_MAXB];
   __shared__ u32 base[CS_MAXB];
+  __shared__ CsLut lt;
   CsChunk C;
   if (ctl) {      // the sync-free path: no chunk table -- chunk blockIdx.x belongs to the last partition whose first chunk is at or before it
     if (ctl->status || blockIdx.x >= ctl->NC) return;
@@ -245,6 +289,8 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   const CsPart P = parts[C.part];
   const u32 tid = threadIdx.x;
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
+  const bool use_lut = luts != nullptr && P.nb > 1 && sizeof(S_t) == sizeof(K);
+  if (use_lut) { const u32* src = reinterpret_cast<const u32*>(luts + C.part); u32* dst = reinterpret_cast<u32*>(&lt); for (u32 i = tid; i < sizeof(CsLut) / 4; i += CS_WALK_TPB) dst[i] = src[i]; }
   __syncthreads();
   K k[IPT]; u32 bk[IPT], rk[IPT];
   // (round 6 tried the IPT searches in step -- every key the same stride at the same time, IPT LDS reads in flight a thread: 70 -> 81 us
@@ -253,7 +299,12 @@ void k_cs_walk(const K* __restrict__ keys, const CsPart* __restrict__ parts, con
   for (int x = 0; x < IPT; x++) {
     const u32 i = tid + x * CS_WALK_TPB;
     bk[x] = 0xFFFFFFFFu;
-    if (i < C.nkeys) { k[x] = keys[C.key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
+    if (i < C.nkeys) {
+      k[x] = keys[C.key0 + i];
+      if constexpr (sizeof(S_t) == sizeof(K)) bk[x] = P.nb > 1 ? (use_lut ? cs_bucket_lut<S_t>(spl, &lt, tshift, k[x]) : cs_bucket<S_t>(spl, P.nb, k[x])) : 0u;
+      else bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u;
+      rk[x] = atomicAdd(&hist[bk[x]], 1u);
+    }
   }
   __syncthreads();
   if (!SCATTER) { for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) if (hist[b]) atomicAdd(&counts_or_cursor[P.bucket0 + b], hist[b]); return; }
@@ -272,7 +323,8 @@ template <typename K> __host__ __device__ constexpr u32 cs_schunk() { return 655
 template <typename K>
 __global__ __launch_bounds__(CS_WALK_TPB)
 void k_cs_scatter_staged(const K* __restrict__ keys, const CsPart* __restrict__ parts, const typename CsSpl<K>::type* __restrict__ splitters,
-                         u32* __restrict__ cursor, K* __restrict__ out, const SkfCtl* __restrict__ ctl, const u32* __restrict__ cfirst, u32 n_parts)
+                         u32* __restrict__ cursor, K* __restrict__ out, const SkfCtl* __restrict__ ctl, const u32* __restrict__ cfirst, u32 n_parts,
+                         const CsLut* __restrict__ luts = nullptr, u32 tshift = 0)
 {
   typedef typename CsSpl<K>::type S_t;
   constexpr u32 SC = cs_schunk<K>(), IPT = SC / CS_WALK_TPB, SUB = cs_chunk<K>() / SC;      // (SUB staged chunks per count chunk)
@@ -283,6 +335,7 @@ void k_cs_scatter_staged(const K* __restrict__ keys, const CsPart* __restrict__ 
   __shared__ K stage[SC];
   __shared__ u16 bid[SC];
   __shared__ u32 wsum[CS_WALK_TPB / 64];
+  __shared__ CsLut lt;
   if (ctl->status) return;
   const u32 cc = blockIdx.x / SUB, sub = blockIdx.x % SUB;
   if (cc >= ctl->NC) return;
@@ -294,13 +347,20 @@ void k_cs_scatter_staged(const K* __restrict__ keys, const CsPart* __restrict__ 
   const u32 key0 = P.key0 + o, nkeys = min(SC, P.nkeys - o);
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   for (u32 b = tid; b < P.nb; b += CS_WALK_TPB) { hist[b] = 0; if (b + 1 < P.nb) spl[b] = splitters[(u64)P.bucket0 + b]; }
+  const bool use_lut = luts != nullptr && P.nb > 1 && sizeof(S_t) == sizeof(K);
+  if (use_lut) { const u32* src = reinterpret_cast<const u32*>(luts + plo); u32* dst = reinterpret_cast<u32*>(&lt); for (u32 i = tid; i < sizeof(CsLut) / 4; i += CS_WALK_TPB) dst[i] = src[i]; }
   __syncthreads();
   K k[IPT]; u32 bk[IPT], rk[IPT];
 #pragma unroll
   for (u32 x = 0; x < IPT; x++) {
     const u32 i = tid + x * CS_WALK_TPB;
     bk[x] = 0xFFFFFFFFu;
-    if (i < nkeys) { k[x] = keys[key0 + i]; bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u; rk[x] = atomicAdd(&hist[bk[x]], 1u); }
+    if (i < nkeys) {
+      k[x] = keys[key0 + i];
+      if constexpr (sizeof(S_t) == sizeof(K)) bk[x] = P.nb > 1 ? (use_lut ? cs_bucket_lut<S_t>(spl, &lt, tshift, k[x]) : cs_bucket<S_t>(spl, P.nb, k[x])) : 0u;
+      else bk[x] = P.nb > 1 ? cs_bucket<S_t>(spl, P.nb, CsSpl<K>::top(k[x])) : 0u;
+      rk[x] = atomicAdd(&hist[bk[x]], 1u);
+    }
   }
   __syncthreads();
   // the buckets' places in `stage`: exclusive scan of hist (two entries a thread: CS_MAXB = 2 * CS_WALK_TPB), their room in `out`

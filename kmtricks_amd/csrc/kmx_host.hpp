@@ -96,6 +96,7 @@ struct kmx_fast_split {
   kmx::u32 n_parts; kmx::u64 kmer_bound; kmx::u32 tb_max, nc_max, nb_max;      // bounds: k-mers, buckets, walk chunks, decode blocks
   kmx::SkfCtl* h_ctl;             // page-locked, 64 bytes: the control block as read back
   const uint4* h_parts;           // page-locked: d_parts as read back (the caller queued that copy on the context's stream)
+  unsigned long long* d_strand;   // [kmer_bound / 64 + 2] or null: the decode leaves bit g = "k-mer g of the batch is its own canonical form" (the PartiInfo statistics' strands)
   std::function<int()> behind_scatter;   // run right after the scatter walk is queued: the caller starts its work on the second stream there (the kernels up to the scatter fill the LDS, the wave sort behind it uses none)
   std::function<int()> before_wait;      // run once everything is queued, before the stream is waited for (the caller's work on its second stream)
 };

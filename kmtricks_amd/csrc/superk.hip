@@ -225,6 +225,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
         else {
           desc[di] = d;
           if (so.keys) { so.keys[di] = d.part; so.ids[di] = di; so.sizes[di] = 1u + ((u32)k + d.n - 1u + 3u) / 4u; }
+          else if (CH && so.ids) so.ids[di] = mini;      // (round 6, the statistics of the sync-free path: the minimizer rides in the slot's word; the k-mers' strands come from the decode)
         }
       }
       int w = 0; u64 ts = 0, xs = 0; u32 rf_s = 0;
@@ -605,8 +606,10 @@ constexpr int PS_TPB = 1024;
 constexpr u32 PS_H = 4096, PS_PROBE = 48, PS_EMPTY = 0xFFFFFFFFu;
 __global__ __launch_bounds__(PS_TPB)
 void k_part_stats(const u32* __restrict__ ids, const u32* __restrict__ part_first, u32 part0, const ulonglong2* __restrict__ sk_rec, const char* __restrict__ bases, int k,
-                  u32* __restrict__ pc, u32* __restrict__ ms_dense, u32* __restrict__ mk_dense, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out)
-{
+                  u32* __restrict__ pc, u32* __restrict__ ms_dense, u32* __restrict__ mk_dense, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out,
+                  const u64* __restrict__ boff = nullptr, const u32* __restrict__ sbase = nullptr, const u32* __restrict__ mini_sorted = nullptr, const u64* __restrict__ strand = nullptr)
+{   // (round 6, sk_rec == null: the sorted records' own arrays -- prefix (k-mers << 32 | bytes), first base, minimizer -- read in order, and
+    //  the k-mers' strands as the decode left them, a bit per k-mer of the batch: no 16-byte record per super-k-mer, no gather)
   __shared__ u32 tab[5 * 256];
   __shared__ u32 hkey[PS_H], hms[PS_H], hmk[PS_H];
   __shared__ u32 wtot[PS_TPB / 64], out_base;
@@ -617,7 +620,17 @@ void k_part_stats(const u32* __restrict__ ids, const u32* __restrict__ part_firs
   __syncthreads();
   const u32 i1 = part_first[p + 1];
   for (u32 i = part_first[p] + tid; i < i1; i += PS_TPB) {
-    const ulonglong2 rec = sk_rec[ids[i]];
+    ulonglong2 rec;
+    if (sk_rec) rec = sk_rec[ids[i]];
+    else {
+      const u64 p0 = boff[i], p1 = boff[i + 1];
+      const u32 ko = (u32)(p0 >> 32), nn = (u32)(p1 >> 32) - ko;
+      const u64 w0 = strand[ko >> 6], w1 = strand[(ko >> 6) + 1];
+      const u32 sft = ko & 63u;
+      const u64 b = sft ? (w0 >> sft) | (w1 << (64u - sft)) : w0;
+      rec.x = (b & ((1ULL << nn) - 1ULL) & ((1ULL << 60) - 1ULL)) | ((u64)(nn & 15u) << 60);
+      rec.y = (u64)sbase[i] | ((u64)mini_sorted[i] << 32) | ((u64)(nn >> 4) << 62);
+    }
     const u32 mini = (u32)(rec.y >> 32) & 0x3FFFFFFFu, n = (u32)(rec.x >> 60) | ((u32)(rec.y >> 62) << 4);
     const u64 bits = rec.x & ((1ULL << 60) - 1ULL);
     {
@@ -778,11 +791,13 @@ struct StatsDev {
                          d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i), persistent ? 1 : 0, deferred ? 1 : 0);
   }
   // DEFER: the statistics from the sorted descriptors, a launch per sample (d_n[sample]: low word the triples, high word "the dense tables were used")
-  void launch_part_stats(const u32* ids_sorted, const u32* part_first, const char* bases, u32 k, u64* d_n, hipStream_t s) const {
+  void launch_part_stats(const u32* ids_sorted, const u32* part_first, const char* bases, u32 k, u64* d_n, hipStream_t s,
+                         const u64* boff = nullptr, const u32* sbase = nullptr, const u32* mini_sorted = nullptr, const u64* strand = nullptr) const {
     if (!deferred) return;
     for (u32 i = 0; i < ns; i++)
       hipLaunchKernelGGL(k_part_stats, dim3(parts1), dim3(PS_TPB), 0, s, ids_sorted, part_first, i * parts1, (const ulonglong2*)S.sk_rec, bases, (int)k,
-                         S.pc, S.ms + (size_t)i * nm1, S.mk + (size_t)i * nm1, d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i));
+                         S.pc, S.ms + (size_t)i * nm1, S.mk + (size_t)i * nm1, d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i),
+                         boff, sbase, mini_sorted, strand);
   }
   void compacted() const { if (persistent && pctx && d_sp) pctx->stat_dirty = false; }      // (the caller has waited for k_minim_sparse: the per-minimizer tables are zero again)
   // ... and once those numbers are on the host, the copies into the caller's (page-locked) buffers are queued: no synchronisation
@@ -1053,7 +1068,11 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       std::vector<void*> fb = {d_z, d_sumf, d_descf, d_ccnt, d_T, d_agg, d_sb, d_bo, d_bf, d_wordsf};
       bool ok = h_f != nullptr;
       for (void* b : fb) ok = ok && b;
-      if (sd.deferred) { sd.S.sk_rec = (ulonglong2*)ctx->dalloc(((size_t)total_bases + 64) * 16); fb.push_back(sd.S.sk_rec); fb.push_back(d_idf); ok = ok && sd.S.sk_rec && d_idf; }
+      // the statistics' inputs (round 6): the minimizer of every descriptor in its slot's word, gathered into sorted order by the scatter (d_idf), and
+      // the k-mers' strands, a bit each, written by the decode -- the walk is the build without statistics (0.28 instead of 0.36 ms)
+      u32* d_mslot = sd.deferred ? (u32*)ctx->dalloc(((size_t)total_bases + 64) * 4) : nullptr;
+      u64* d_strand = sd.deferred ? (u64*)ctx->dalloc((kb / 64 + 4) * 8) : nullptr;
+      if (sd.deferred) { fb.push_back(d_mslot); fb.push_back(d_strand); fb.push_back(d_idf); ok = ok && d_mslot && d_strand && d_idf; sd.S.sk_rec = nullptr; }
       if (creq->hash_mode) { fb.push_back(d_p16); ok = ok && d_p16; }
       auto frel = [&]() { for (void* b : fb) ctx->dfree(b); };
       if (!ok) { frel(); release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
@@ -1065,16 +1084,12 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       if ((e = hipMemsetAsync(d_z, 0, z_bytes, st)) != hipSuccess) return ffail(e, "memset");
       kmx_launch_pack_bases(d_bases, total_bases, d_wordsf, st);
       const dim3 gw((n_chunks + 3) / 4);
-      if (sd.deferred)
-        hipLaunchKernelGGL((k_superk_wave<true, true, false, true, true>), gw, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_ccnt,
-                           (const u32*)nullptr, d_descf, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu, (u32)SKF_RPW);
-      else
-        hipLaunchKernelGGL((k_superk_wave<true, false, false, false, true>), gw, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_ccnt,
-                           (const u32*)nullptr, d_descf, sd.S, SkSort{nullptr, nullptr, nullptr}, SkLook{}, mu, (u32)SKF_RPW);
+      hipLaunchKernelGGL((k_superk_wave<true, false, false, false, true>), gw, b1, 0, st, d_bases, d_offs, (u64)n_seqs, (int)k, (int)m, maxs, d_rep, d_ccnt,
+                         (const u32*)nullptr, d_descf, sd.S, SkSort{nullptr, d_mslot, nullptr}, SkLook{}, mu, (u32)SKF_RPW);
       hipLaunchKernelGGL(k_sk_hist, dim3(R), dim3(64 * wpg), (size_t)P * 12, st, d_descf, d_offs, d_ccnt, n_chunks, wpg, P, (u32)k, d_T, d_ctl);
       hipLaunchKernelGGL(k_sk_scan, dim3(Gc), dim3(256), 0, st, d_T, R, rpg, P, d_agg, (u32*)(d_z + z_flags), nd_cap, L, d_ctl, d_pff, d_ppf, d_bo, d_partsf, d_cff);
       hipLaunchKernelGGL(k_sk_scatter, dim3(R), dim3(64 * wpg), (size_t)wpg * P * 12, st, d_descf, d_offs, d_ccnt, n_chunks, wpg, P, pbits, (u32)k, d_T, d_ctl,
-                         d_sb, d_bo, d_idf, d_p16, d_bf);
+                         d_sb, d_bo, d_idf, d_p16, d_bf, (const u32*)d_mslot);
       if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((P + 63) / 64), dim3(64), 0, st, d_pff, d_bo, P, d_infof);
       // the PartiInfo statistics (kmx_superk_raw): from the sorted descriptors, on the context's SECOND stream beside the count kernels --
       // k_part_stats is a workgroup per partition waiting on gathers and LDS atomics (150 us by itself), the count kernels are bound by
@@ -1090,7 +1105,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
           aux_busy = true;
         }
         if (er == hipSuccess) {
-          sd.launch_part_stats(d_idf, d_pff, d_bases, k, d_nspf, sx);
+          sd.launch_part_stats(nullptr, d_pff, d_bases, k, d_nspf, sx, d_bo, d_sb, d_idf, d_strand);
           sd.launch_sparse(d_nspf, sx);
           er = hipMemcpyAsync(h_nsp, d_nspf, 8, hipMemcpyDeviceToHost, sx);
         }
@@ -1100,7 +1115,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       if ((e = hipMemcpyAsync(h_f + 64, d_sumf, sumf, hipMemcpyDeviceToHost, st)) != hipSuccess) return ffail(e, "memcpy");
       ph.mark(2);
       kmx_fast_split F{d_wordsf, d_sb, d_bo, d_p16, d_bf, d_ctl, d_partsf, d_cff, (u32*)(d_z + z_cnt), (u32*)(d_z + z_sfl), P, kb, tb_max, nc_max, nb_max,
-                       reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts), nullptr, nullptr};
+                       reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts), d_strand, nullptr, nullptr};
       if (sd.deferred) F.behind_scatter = launch_stats;
       bool raw_queued = false;
       if (raw && sd.deferred && sx != st)
@@ -1136,7 +1151,6 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx count] the sync-free path handed the call back (status %u, overflow %u)\n", hc->status, hc->overflow);
       if (sx != st && (e = hipStreamSynchronize(sx)) != hipSuccess) return ffail(e, "sync");      // (the statistics kernels of the abandoned pass)
       frel();
-      if (sd.deferred) { ctx->dfree(sd.S.sk_rec); sd.S.sk_rec = nullptr; }
       if ((e = sd.clear(st)) != hipSuccess) return fail(e, "memset");
     }
   }

@@ -141,7 +141,8 @@ void k_sk_scan(ulonglong2* __restrict__ T, u32 R, u32 rpg, u32 P, ulonglong2* __
 __global__ __launch_bounds__(1024)
 void k_sk_scatter(const SkDesc* __restrict__ desc, const u64* __restrict__ offsets, const u32* __restrict__ ccnt, u32 n_chunks, u32 wpg, u32 P, u32 pbits, u32 k,
                   const ulonglong2* __restrict__ T, const SkfCtl* __restrict__ ctl,
-                  u32* __restrict__ sbase, u64* __restrict__ boff, u32* __restrict__ ids /* or null */, u16* __restrict__ part16 /* or null */, u32* __restrict__ blk_first)
+                  u32* __restrict__ sbase, u64* __restrict__ boff, u32* __restrict__ ids /* or null */, u16* __restrict__ part16 /* or null */, u32* __restrict__ blk_first,
+                  const u32* __restrict__ slot_word = nullptr /* set: ids[pos] = slot_word[slot] (the descriptor's minimizer) instead of the slot */)
 {
   extern __shared__ u64 sk_lds[];
   u64* wsz = sk_lds;                                           // [wpg][P]
@@ -187,7 +188,7 @@ void k_sk_scatter(const SkDesc* __restrict__ desc, const u64* __restrict__ offse
     if (v && (peers >> lane) == 1ULL) { mpos[key] = pos + 1u; msz[key] = pre + sz; }      // the last of its partition in this step
     if (v) {
       sbase[pos] = d.base; boff[pos] = pre;
-      if (ids) ids[pos] = base + j;
+      if (ids) ids[pos] = slot_word ? slot_word[base + j] : base + j;
       if (part16) part16[pos] = (u16)key;
       const u32 ko = (u32)(pre >> 32), ke = ko + d.n, B = (ko + SKF_DK - 1u) / SKF_DK;
       if (B * SKF_DK < ke) blk_first[B] = pos;      // (a record holds at most 60 k-mers: at most one block of the decode starts inside it)
