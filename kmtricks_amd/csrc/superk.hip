@@ -534,10 +534,11 @@ __global__ void k_superk_part_bounds(const u16* __restrict__ part_sorted, u32 n,
 // What SuperKStorageWriter::SaveInfoFile reports per partition (io/superk_storage.hpp:205-225, 328-340; the file is saved before
 // the final flush): k-mers since the last full 32 KB block, bytes of the blocks flushed so far.  A thread per partition walks
 // its records' sizes (prefix differences).
-__global__ void k_superk_info(const u32* __restrict__ part_first, const u64* __restrict__ prefix, u32 nb_parts, u64* __restrict__ info)
+__global__ void k_superk_info(const u32* __restrict__ part_first, const u64* __restrict__ prefix, u32 nb_parts, u64* __restrict__ info, const SkfCtl* __restrict__ ctl = nullptr)
 {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nb_parts) return;
+  if (ctl && ctl->status) return;      // (the sync-free path handed the call back: the prefix array was not written, or not all of it)
   // a block = the longest run of whole records of at most 32768 bytes: its end is a binary search in the byte prefix (a step per
   // block, not per record); the last run is still in the writer's buffer when the info file is saved
   const u32 i1 = part_first[p + 1];
@@ -607,7 +608,8 @@ constexpr u32 PS_H = 4096, PS_PROBE = 48, PS_EMPTY = 0xFFFFFFFFu;
 __global__ __launch_bounds__(PS_TPB)
 void k_part_stats(const u32* __restrict__ ids, const u32* __restrict__ part_first, u32 part0, const ulonglong2* __restrict__ sk_rec, const char* __restrict__ bases, int k,
                   u32* __restrict__ pc, u32* __restrict__ ms_dense, u32* __restrict__ mk_dense, u32* __restrict__ out, u32 cap, u32* __restrict__ n_out,
-                  const u64* __restrict__ boff = nullptr, const u32* __restrict__ sbase = nullptr, const u32* __restrict__ mini_sorted = nullptr, const u64* __restrict__ strand = nullptr)
+                  const u64* __restrict__ boff = nullptr, const u32* __restrict__ sbase = nullptr, const u32* __restrict__ mini_sorted = nullptr, const u64* __restrict__ strand = nullptr,
+                  const SkfCtl* __restrict__ ctl = nullptr)
 {   // (round 6, sk_rec == null: the sorted records' own arrays -- prefix (k-mers << 32 | bytes), first base, minimizer -- read in order, and
     //  the k-mers' strands as the decode left them, a bit per k-mer of the batch: no 16-byte record per super-k-mer, no gather)
   __shared__ u32 tab[5 * 256];
@@ -615,6 +617,9 @@ void k_part_stats(const u32* __restrict__ ids, const u32* __restrict__ part_firs
   __shared__ u32 wtot[PS_TPB / 64], out_base;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 p = part0 + blockIdx.x;
+  // (the sync-free path: a status bit means the sorted arrays were not written, or not all of them -- the call is repeated the old way,
+  //  statistics included; found by scripts/fuzz_count.py: k = 12, m = 11, a super-k-mer a k-mer, more records than the arrays were sized for)
+  if (ctl && ctl->status) return;
   for (u32 j = tid; j < 5 * 256; j += PS_TPB) tab[j] = 0;
   for (u32 j = tid; j < PS_H; j += PS_TPB) { hkey[j] = PS_EMPTY; hms[j] = 0; hmk[j] = 0; }
   __syncthreads();
@@ -792,12 +797,12 @@ struct StatsDev {
   }
   // DEFER: the statistics from the sorted descriptors, a launch per sample (d_n[sample]: low word the triples, high word "the dense tables were used")
   void launch_part_stats(const u32* ids_sorted, const u32* part_first, const char* bases, u32 k, u64* d_n, hipStream_t s,
-                         const u64* boff = nullptr, const u32* sbase = nullptr, const u32* mini_sorted = nullptr, const u64* strand = nullptr) const {
+                         const u64* boff = nullptr, const u32* sbase = nullptr, const u32* mini_sorted = nullptr, const u64* strand = nullptr, const SkfCtl* ctl = nullptr) const {
     if (!deferred) return;
     for (u32 i = 0; i < ns; i++)
       hipLaunchKernelGGL(k_part_stats, dim3(parts1), dim3(PS_TPB), 0, s, ids_sorted, part_first, i * parts1, (const ulonglong2*)S.sk_rec, bases, (int)k,
                          S.pc, S.ms + (size_t)i * nm1, S.mk + (size_t)i * nm1, d_sp + (size_t)sp_off[i] * 3, sp_cap[i], reinterpret_cast<u32*>(d_n + i),
-                         boff, sbase, mini_sorted, strand);
+                         boff, sbase, mini_sorted, strand, ctl);
   }
   void compacted() const { if (persistent && pctx && d_sp) pctx->stat_dirty = false; }      // (the caller has waited for k_minim_sparse: the per-minimizer tables are zero again)
   // ... and once those numbers are on the host, the copies into the caller's (page-locked) buffers are queued: no synchronisation
@@ -1090,7 +1095,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       hipLaunchKernelGGL(k_sk_scan, dim3(Gc), dim3(256), 0, st, d_T, R, rpg, P, d_agg, (u32*)(d_z + z_flags), nd_cap, L, d_ctl, d_pff, d_ppf, d_bo, d_partsf, d_cff);
       hipLaunchKernelGGL(k_sk_scatter, dim3(R), dim3(64 * wpg), (size_t)wpg * P * 12, st, d_descf, d_offs, d_ccnt, n_chunks, wpg, P, pbits, (u32)k, d_T, d_ctl,
                          d_sb, d_bo, d_idf, d_p16, d_bf, (const u32*)d_mslot);
-      if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((P + 63) / 64), dim3(64), 0, st, d_pff, d_bo, P, d_infof);
+      if (superk_info) hipLaunchKernelGGL(k_superk_info, dim3((P + 63) / 64), dim3(64), 0, st, d_pff, d_bo, P, d_infof, (const SkfCtl*)d_ctl);
       // the PartiInfo statistics (kmx_superk_raw): from the sorted descriptors, on the context's SECOND stream beside the count kernels --
       // k_part_stats is a workgroup per partition waiting on gathers and LDS atomics (150 us by itself), the count kernels are bound by
       // their instructions.  Their tables travel back on that stream as well, before the count is through (before_wait below).
@@ -1105,7 +1110,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
           aux_busy = true;
         }
         if (er == hipSuccess) {
-          sd.launch_part_stats(nullptr, d_pff, d_bases, k, d_nspf, sx, d_bo, d_sb, d_idf, d_strand);
+          sd.launch_part_stats(nullptr, d_pff, d_bases, k, d_nspf, sx, d_bo, d_sb, d_idf, d_strand, d_ctl);
           sd.launch_sparse(d_nspf, sx);
           er = hipMemcpyAsync(h_nsp, d_nspf, 8, hipMemcpyDeviceToHost, sx);
         }

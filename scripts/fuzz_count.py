@@ -38,6 +38,8 @@ for case in range(a.cases):
         reads.append("".join(s))
     if style in (0, 3):
         reads = reads + reads[: len(reads) // 2]      # repeats: counts above 1, the splitter samples' strata
+    if os.environ.get("KMX_FUZZ_VERBOSE"):
+        print(f"case {case}: k={k} m={m} P={P} hard_min={hard_min} hashed={hashed} W={W} style={style} reads={len(reads)}", file=sys.stderr, flush=True)
     lut = orc.minimizer_lut(m)
     rep = orc.repart_static(m, P)
     exp = orc.superk_partition(reads, k, m, lut, rep, P)

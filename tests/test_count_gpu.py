@@ -526,3 +526,35 @@ def test_parti_info_through_hip_against_the_string_restatement(ctx, k, m, P):
     _, pin, ms, mk, _ = ctx.superk_partition_stats(reads, k, m, rep, P)
     assert pin.tolist() == exp
     assert {int(v): [int(ms[v]), int(mk[v])] for v in np.nonzero(ms)[0]} == minim
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["more records than estimated", "a partition beyond the sample sort"])
+def test_count_reads_dev_hands_back_to_the_two_walk_path(ctx, what, monkeypatch, capfd):
+    """round 6: the sync-free path of kmx_count_reads_dev raises a status word on the device and the call is repeated the old way --
+    k = 12 with 11-mer minimizers cuts a super-k-mer per k-mer (more records than the sorted arrays are sized for); one partition of a
+    million k-mers is beyond the sample sort's 2048 buckets.  (scripts/fuzz_count.py found the first: the statistics kernel, on the
+    second stream, read the sorted arrays the scatter had not written -- a memory fault; it leaves at once now.)  Counts, statistics and
+    the KMX_TRACE line that says so."""
+    from kmtricks_amd import lib
+    if what == "more records than estimated":
+        k, m, P, reads = 12, 11, 3, random_reads(4242, 300, 2000, n_rate=0.001)
+    else:
+        k, m, P, reads = 31, 10, 1, random_reads(4243, 600, 2000, n_rate=0.0)
+    lut, rep = orc.minimizer_lut(m), orc.repart_static(m, P)
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    epin, ems, emk, _ = orc.superk_stats(reads, k, m, lut, rep, P)
+    monkeypatch.setenv("KMX_TRACE", "1")
+    store = lib.Store(0)
+    try:
+        for _ in range(2):      # (twice: the second call meets the first one's estimates and pool)
+            lists, nk, raw = ctx.count_reads_dev(reads, k, m, rep, P, 1, [store], raw=True, sparse=True, ahead=True)
+            pr, ms, mk, nsk = raw
+            assert np.array_equal(pr.reshape(P, 1280).astype(np.uint64), epin[:, 2:]) and np.array_equal(ms, ems) and np.array_equal(mk, emk) and nsk == int(ems.sum())
+            for p in range(P):
+                ek, ec = orc.count_kmer(exp[p][0], k, 1)
+                gk, gc = ctx.read_list(lists[p][0], lists[p][1], 1)
+                assert nk[p] == exp[p][1] and np.array_equal(gk.reshape(ek.shape), ek) and np.array_equal(gc, ec)
+        assert capfd.readouterr().err.count("the sync-free path handed the call back") == 2
+    finally:
+        store.close()
