@@ -146,9 +146,10 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     # count_200: configs[2]'s count rows for a cohort of 200 samples (round 6: every real cohort below 257 samples is k_merge_rows' -- its
     # build for up to 256 lists, merge_rows_small.hip); the same code path as "count" otherwise
     small = wl == "count_200"
-    if small:
+    wide = wl == "count_k96"      # round 6: a cohort of 1000 samples at k = 96 (Kmer<96>, three-word keys: the reference's KMER_LIST "32 64 96 128")
+    if small or wide:
         wl = "count"
-    defaults = {"count": (200 if small else 1000, 32, 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
+    defaults = {"count": (200 if small else 1000, 32, 96 if wide else 31, 2), "bf": (100, 32, 31, 1), "pa63": (500, 32, 63, 1), "bft": (2500, 4, 31, 1)}[wl]
     N = defaults[0] if small else (a.samples or defaults[0])
     P = a.partitions_per_gpu or defaults[1]
     k = defaults[2]
@@ -168,7 +169,7 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
     if wl in ("count", "pa63"):
         mode = lib.MODE_COUNT if wl == "count" else lib.MODE_PA
         if lists_kind == "counted":
-            job_lists = [[] for _ in range(total_parts)] if (wl == "count" and not small and world == 1 and a.whole_job) else None
+            job_lists = [[] for _ in range(total_parts)] if (wl == "count" and not small and not wide and world == 1 and a.whole_job) else None
             store, lists = gen_counted(ctx, lib, N, k, genome, a.subst_rate, total_parts, my_parts, 20240601, rank == 0, job_lists)
             keep.append(store)
             def host_lists(j):
@@ -183,7 +184,7 @@ def merge_workload(env, a, wl, lists_kind, want_cpu):
                 return [(np.ascontiguousarray(h[offs[i]:offs[i + 1], :2 * kw]).view(np.uint64).reshape(-1, kw), np.ascontiguousarray(h[offs[i]:offs[i + 1], 2 * kw])) for i in range(N)]
         for ls in lists:
             tasks_d.append(dict(lists=ls, key_words=kw, soft_min=[1] * N, rec_min=rec_min, share_min=a.share_min, mode=mode))      # (no rows_hint: libkmx sizes the arenas from the batches it has seen)
-        label = (f"BASELINE configs[{2 if wl == 'count' else 4}]: {N} samples, k={k}, kmer:{'count' if wl == 'count' else 'pa'}:bin, recurrence-min {rec_min}, "
+        label = (f"BASELINE configs[{2 if wl == 'count' else 4}]{' at k = 96' if wide else ''}: {N} samples, k={k}, kmer:{'count' if wl == 'count' else 'pa'}:bin, recurrence-min {rec_min}, "
                  + (f"share-min {a.share_min}, " if a.share_min else "")
                  + f"{P} of {total_parts} partitions per GPU (G={genome} bp, d={a.subst_rate}), lists: "
                  + ("count stage output resident in HBM (kmx_count_reads_dev)" if lists_kind == "counted" else "random 62-bit keys"))
@@ -588,7 +589,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["auto", "all", "count", "count_200", "bf", "pa63", "bft", "pipeline", "count_stage"], default="auto")
+    ap.add_argument("--workload", choices=["auto", "all", "count", "count_200", "count_k96", "bf", "pa63", "bft", "pipeline", "count_stage"], default="auto")
     ap.add_argument("--lists", choices=["counted", "random"], default="counted")
     ap.add_argument("--samples", type=int, default=0)
     ap.add_argument("--partitions-per-gpu", type=int, default=0)

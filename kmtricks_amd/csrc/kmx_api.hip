@@ -233,7 +233,9 @@ void kmx_store::start_ahead()
       if (limit && held + chunk_bytes > limit + chunk_bytes) { cv.wait_for(lk, std::chrono::milliseconds(50)); continue; }      // (at the limit: nothing more ahead)
       lk.unlock();
       void* p = nullptr;
+      const auto t0 = std::chrono::steady_clock::now();
       const hipError_t er = hipMalloc(&p, chunk_bytes);
+      { static const bool trace = getenv("KMX_TRACE") != nullptr; if (trace) fprintf(stderr, "[kmx alloc] store chunk ahead %zu MB: %.2f ms\n", chunk_bytes >> 20, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
       lk.lock();
       if (er != hipSuccess) { (void)hipGetLastError(); cv.wait_for(lk, std::chrono::milliseconds(200)); continue; }
       spare.push_back({(u8*)p, chunk_bytes, 0});
@@ -322,6 +324,7 @@ extern "C" int kmx_store_create(int device, uint64_t limit_bytes, kmx_store** ou
   s->device = device;
   s->limit = limit_bytes ? (size_t)limit_bytes : (size_t)(tot / 10 * 6);
   s->chunk_bytes = (size_t)256 << 20;
+  { const char* e = getenv("KMX_STORE_CHUNK_MB"); if (e && atol(e) >= 16 && atol(e) <= 65536) s->chunk_bytes = (size_t)atol(e) << 20; }
   *out = s;
   return KMX_OK;
 }
@@ -1309,6 +1312,7 @@ extern "C" int kmx_result_wait(kmx_merge_result* R)
         ctx->dfree(H.d_out);
         // (what the kernel claimed, plus a chunk per range: the retry may run with another kernel -- tasks a cohort
         //  kernel handed back are re-run with k_merge_rows -- whose tiles leave other chunk tails unused)
+        if (getenv("KMX_TRACE")) fprintf(stderr, "[kmx merge] task %zu: the kernel asked for %llu rows, the arena had %llu (%u bytes a row, %u ranges)\n", t, (unsigned long long)H.arena_rows, (unsigned long long)H.out_cap_rows, H.row_bytes, H.c);
         H.out_cap_rows = H.arena_rows + (u64)(H.c + 1) * rows_chunk_rows(H.row_bytes); H.out_bytes = (size_t)(H.out_cap_rows * H.row_bytes);
         H.d_out = (u8*)ctx->dalloc(H.out_bytes);
         if (!H.d_out) { R->waited = true; R->status = ctx->fail(KMX_E_NOMEM, "output arena allocation failed (retry)"); return R->status; }

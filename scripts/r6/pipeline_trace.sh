@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r6ptrace${TAG:-}
 rm -rf $O; mkdir -p $O
 python $GRAFT_REPO_ROOT/scripts/bench_pipeline.py --samples ${SAMPLES:-200} --genome 5e6 --partitions 256 --tmp /dev/shm --extra "--hard-min 2 --recurrence-min 2 --static-repart ${EXTRA:-}" \
-  --variants ";" --env "KMX_SLOW_EXIT=1 KMX_READERS=12;KMX_SLOW_EXIT=1 KMX_READERS=12" --prof $O/prof --prof-flags=--memory-copy-trace --keep-trace > $O/lines.jsonl 2> $O/err.log
+  --variants ";" --env "KMX_SLOW_EXIT=1 ${ENVX:-};KMX_SLOW_EXIT=1 ${ENVX:-}" --prof $O/prof --prof-flags=--memory-copy-trace --keep-trace > $O/lines.jsonl 2> $O/err.log
 python - <<PY
 import csv, glob, json
 d = "$O/prof"
@@ -51,6 +51,17 @@ print("the run's first 45 kernels / copies (ms from the first; dur us):")
 for e in allev[:45]: print(f"  {(e[0] - allev[0][0]) / 1e6:9.3f} {(e[1] - e[0]) / 1e3:9.1f}  q{e[3]}  {e[2][-44:]}")
 wk = [e for e in last if "k_superk_wave" in e[2]]
 print("walk starts (ms from the first event), every 25th:", [round((w[0] - allev[0][0]) / 1e6, 1) for w in wk[::25]])
+# (the long intervals between two walks: when, and what the GPU and the link did inside)
+iv_w = [(wk[i + 1][0] - wk[i][0]) / 1e3 for i in range(len(wk) - 1)]
+import statistics
+print("walk-to-walk us: median", round(statistics.median(iv_w), 1), "mean", round(sum(iv_w) / len(iv_w), 1), "over 3 ms:", sum(1 for x in iv_w if x > 3000), "their sum ms", round(sum(x for x in iv_w if x > 3000) / 1e3, 1))
+shown = 0
+for i, x in enumerate(iv_w):
+    if x > 3000 and shown < 6 and i > 30:
+        shown += 1
+        a, b = wk[i][0], wk[i + 1][0]
+        print(f" long interval {x / 1e3:.1f} ms at sample {i} ({(a - allev[0][0]) / 1e6:.1f} ms):")
+        for e in [e for e in allev if a <= e[0] <= b][:60]: print(f"    {(e[0] - a) / 1e3:9.1f} {(e[1] - e[0]) / 1e3:8.1f}  q{e[3]}  {e[2][-44:]}")
 print("idle gaps (us in all, count) by kernel in front -> kernel behind:")
 for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:14]: print(f"  {v[0]:10.0f} us  x{v[1]:5d}  {k[0]} -> {k[1]}")
 per = collections.defaultdict(float)
