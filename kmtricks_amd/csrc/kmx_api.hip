@@ -256,7 +256,7 @@ void* kmx_store::alloc(size_t bytes)
   std::lock_guard<std::mutex> lk(mu);
   start_ahead();
   if (limit && used + bytes > limit) return nullptr;
-  for (size_t i = 0; i < chunks.size(); i++) { auto& c = chunks[i]; if ((int)i != resv_chunk && c.cap - c.fill >= bytes) { void* p = c.p + c.fill; c.fill += bytes; used += bytes; return p; } }
+  for (size_t i = 0; i < chunks.size(); i++) { auto& c = chunks[i]; if (!chunk_reserved(i) && c.cap - c.fill >= bytes) { void* p = c.p + c.fill; c.fill += bytes; used += bytes; return p; } }
   { Chunk sp; if (take_spare(bytes, sp)) { sp.fill = bytes; chunks.push_back(sp); used += bytes; return sp.p; } }
   int cur = -1; (void)hipGetDevice(&cur);
   if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
@@ -278,14 +278,14 @@ void* kmx_store::try_reserve(size_t bytes)
   if (bytes == 0) bytes = 256;
   std::lock_guard<std::mutex> lk(mu);
   start_ahead();
-  if (resv_chunk >= 0 || (limit && used + bytes > limit)) return nullptr;
+  if (resvs.size() >= 8 || (limit && used + bytes > limit)) return nullptr;
   for (int pass = 0; pass < 2; pass++) {
     for (size_t i = 0; i < chunks.size(); i++) {
       auto& c = chunks[i];
-      if (c.cap - c.fill >= bytes) { resv_chunk = (int)i; resv_off = c.fill; resv_bytes = bytes; c.fill += bytes; used += bytes; return c.p + resv_off; }
+      if (!chunk_reserved(i) && c.cap - c.fill >= bytes) { resvs.push_back({(int)i, c.fill, bytes}); void* p = c.p + c.fill; c.fill += bytes; used += bytes; return p; }
     }
     if (pass) break;
-    // no chunk with that much room: a new one, as alloc() makes it -- the one made ahead when there is one
+    // no free chunk with that much room: a new one, as alloc() makes it -- the one made ahead when there is one
     { Chunk sp; if (take_spare(bytes, sp)) { chunks.push_back(sp); continue; } }
     int cur = -1; (void)hipGetDevice(&cur);
     if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
@@ -293,7 +293,7 @@ void* kmx_store::try_reserve(size_t bytes)
     void* p = nullptr;
     const hipError_t e = hipMalloc(&p, cap);
     if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
-    if (e != hipSuccess) return nullptr;      // (the device is nearly full: the caller waits for its size and takes exactly what it needs)
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }      // (the device is nearly full: the caller waits for its size and takes exactly what it needs)
     chunks.push_back({(u8*)p, cap, 0});
   }
   return nullptr;
@@ -302,11 +302,15 @@ void kmx_store::commit(void* p, size_t used_bytes)
 {
   used_bytes = (used_bytes + 255) / 256 * 256;
   std::lock_guard<std::mutex> lk(mu);
-  if (resv_chunk < 0 || chunks[resv_chunk].p + resv_off != (u8*)p) return;
-  if (used_bytes > resv_bytes) used_bytes = resv_bytes;
-  chunks[resv_chunk].fill = resv_off + used_bytes;      // (nothing was allocated behind the reservation: alloc() left the chunk alone)
-  used -= resv_bytes - used_bytes;
-  resv_chunk = -1;
+  for (size_t j = 0; j < resvs.size(); j++) {
+    const Resv r = resvs[j];
+    if (chunks[r.chunk].p + r.off != (u8*)p) continue;
+    if (used_bytes > r.bytes) used_bytes = r.bytes;
+    chunks[r.chunk].fill = r.off + used_bytes;      // (nothing was allocated behind the reservation: the chunk was left alone)
+    used -= r.bytes - used_bytes;
+    resvs.erase(resvs.begin() + j);
+    return;
+  }
 }
 extern "C" int kmx_store_create(int device, uint64_t limit_bytes, kmx_store** out)
 {

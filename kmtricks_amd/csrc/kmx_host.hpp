@@ -131,14 +131,17 @@ struct kmx_store {
   std::mutex mu;
   void* alloc(size_t bytes);      // 256-byte aligned; nullptr: over the limit or out of device memory
   // round 6: a count call that does not know its lists' size yet takes room for an estimate, has its kernel write there, and gives
-  // back what it did not need once the size is read back (one reservation at a time per store; while it is open, alloc() leaves its chunk alone)
-  int resv_chunk = -1; size_t resv_off = 0, resv_bytes = 0;
+  // back what it did not need once the size is read back.  A reservation is the tail of a chunk, one per chunk; while it is open alloc()
+  // and the other reservations leave that chunk alone -- the calls of a GPU's workers run side by side, each with its own (up to 8 open)
+  struct Resv { int chunk; size_t off, bytes; };
+  std::vector<Resv> resvs;
+  bool chunk_reserved(size_t i) const { for (auto& r : resvs) if (r.chunk == (int)i) return true; return false; }
   // a chunk made ahead of its need by a thread of the store's own (round 6): on a box whose HBM has not been touched since boot a
   // hipMalloc of 256 MB takes ~8 ms (the driver clears it), 223 of them for configs[2]'s lists -- inside count calls, with the GPU idle
   std::vector<Chunk> spare; std::thread ahead; std::condition_variable cv; bool stop = false, ahead_on = false;
   void start_ahead();      // (first allocation; KMX_STORE_AHEAD=0: never)
   bool take_spare(size_t bytes, Chunk& out);      // with mu held
-  void* try_reserve(size_t bytes);              // nullptr: another reservation is open, or no room
+  void* try_reserve(size_t bytes);              // nullptr: eight reservations are open, or no room
   void commit(void* p, size_t used_bytes);      // keeps the first used_bytes of the reservation (0: none of it)
 };
 

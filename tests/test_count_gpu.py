@@ -558,3 +558,44 @@ def test_count_reads_dev_hands_back_to_the_two_walk_path(ctx, what, monkeypatch,
         assert capfd.readouterr().err.count("the sync-free path handed the call back") == 2
     finally:
         store.close()
+
+
+@pytest.mark.gpu
+def test_count_calls_side_by_side_into_one_store():
+    """round 6: `kmx pipeline`'s workers -- a context and a host thread each -- count their samples side by side into the GPU's one store;
+    each call reserves the tail of a chunk of its own for the lists it has not sized yet (kmx_store::try_reserve, several open at a
+    time).  Four threads, six samples each, every list against the oracle; then the store still takes a plain allocation."""
+    import threading
+    from kmtricks_amd import lib
+    k, m, P = 31, 10, 8
+    lut, rep = orc.minimizer_lut(m), orc.repart_static(m, P)
+    samples = [random_reads(900 + i, 260 + 7 * i, 300, n_rate=0.002) for i in range(6)]
+    expected = []
+    for reads in samples:
+        parts = orc.superk_partition(reads, k, m, lut, rep, P)
+        expected.append([orc.count_kmer(parts[p][0], k, 1) for p in range(P)])
+    store = lib.Store(0)
+    errors, results = [], {}
+
+    def worker(w):
+        try:
+            c = lib.Context(0)
+            for rnd in range(3):
+                for i, reads in enumerate(samples):
+                    lists, nk, _ = c.count_reads_dev(reads, k, m, rep, P, 1, [store])
+                    results[(w, rnd, i)] = [c.read_list(lists[p][0], lists[p][1], 1) for p in range(P)]
+            c.close()
+        except Exception as e:      # (an assertion in a thread is lost: collected and raised below)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    assert len(results) == 4 * 3 * len(samples)
+    for (w, rnd, i), got in results.items():
+        for p in range(P):
+            ek, ec = expected[i][p]
+            assert np.array_equal(got[p][0].reshape(ek.shape), ek) and np.array_equal(got[p][1], ec), (w, rnd, i, p)
+    assert store.used() > 0
+    store.close()
