@@ -25,8 +25,8 @@ Other workloads (`--workload`), each with its own roofline line:
   pipeline  the metric's second half: `kmx pipeline` end to end (FASTA files in, matrix files out) on configs[2]'s cohort at the
          size the GPU box's disk takes (1000 samples x 1 Mbp, 256 partitions), wall clock and k-mers merged/s end to end, with
          the oracle's split + count + merge on the host cores over a bounded sample of the same files beside it
-  all    (default on one GPU) bf, bft, pa63 and pipeline first -- their lines go into "workloads" / "pipeline" of the ONE JSON
-         line -- then the headline count workload, whose fields are the line's own
+  all    (default on one GPU) the headline count workload first -- its fields are the line's own --, then count_stage, bf, bft, pa63,
+         count_200 and pipeline: their lines go into "workloads" / "pipeline" of the ONE JSON line
 
 Prints ONE JSON line on rank 0.
 """
@@ -490,10 +490,12 @@ def pipeline_workload(a, n_gpus=1, genome=None, tmp_root=None, cpu=True):
         cmd = [os.path.join(ROOT, "kmtricks_amd", "kmx"), "pipeline", "--file", os.path.join(tmp, "in.fof"), "--run-dir", run, "--kmer-size", str(k),
                "--mode", "kmer:count:bin", "--hard-min", "2", "--recurrence-min", "2", "--nb-partitions", str(P), "--static-repart",
                "-t", str(threads), "--gpus", str(n_gpus)]
-        # the bench's warm-up, as its W untimed steps in front of the K timed ones: the same command over the cohort's first samples (the
-        # host's cores out of their idle states, the runtime's code objects and page-locked pools made, HBM touched once -- the first job on a
-        # fresh box is 0.3-0.5 s slower in its count stage than every later one)
-        warm_n = min(S, a.pipeline_warmup_samples) if genome is not None else 0
+        # the bench's warm-up, as its W untimed steps in front of the K timed ones: the same command once, untimed.  The boxes are fresh
+        # virtual machines whose memory the host backs on first touch: the first job that writes 92 GB of matrices into the RAM file system
+        # and page-locks its buffers is 0.3-1 s slower in EACH stage than every later one (reader threads 33 s of CPU against 15, the merge
+        # stage's writes 2.8-3.2 s against 1.8), and a fresh box's HBM is cleared on first touch as well (--pipeline-warmup-samples n: over
+        # the first n samples only; 0: none -- both the warm-up and the first run's penalty are then in the line's "warmup" field)
+        warm_n = (S if a.pipeline_warmup_samples < 0 else min(S, a.pipeline_warmup_samples)) if genome is not None else 0
         if warm_n > 0:
             wfof = os.path.join(tmp, "warm.fof")
             with open(wfof, "w") as fof:
@@ -521,7 +523,9 @@ def pipeline_workload(a, n_gpus=1, genome=None, tmp_root=None, cpu=True):
                "stages": {kk: d[kk] for kk in ("setup_wall_s", "count_wall_s", "merge_wall_s", "total_s", "read_s", "count_s", "merge_io_s", "merge_s", "gpu_workers", "resident_samples") if kk in d},
                "fasta_generation_s": gen_s}
         if warm_n > 0:
-            out["warmup"] = f"one untimed run of the same command over the first {warm_n} samples"
+            out["warmup"] = f"one untimed run of the same command over {'the cohort' if warm_n == S else 'the first ' + str(warm_n) + ' samples'} in front of the timed one"
+        elif genome is not None:
+            out["warmup"] = "none: the timed run is the first job of its size on this box"
         if genome is None:
             # the same files at k = 96 (Kmer<128>, keys of three words: the reference's default KMER_LIST reaches 128) -- the
             # split by k_superk_wide, the decode by k_superk_decode_wide, the word-by-word sort, k_merge_rows<3>
@@ -618,7 +622,7 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline-samples", type=int, default=1000)
     ap.add_argument("--pipeline-genome", type=float, default=1e6)
     ap.add_argument("--pipeline-cpu-samples", type=int, default=0, help="samples of the end-to-end cpu_baseline (0: one per host core)")
-    ap.add_argument("--pipeline-warmup-samples", type=int, default=96, help="the full-size end-to-end run: samples of the untimed warm-up run in front of it (0: none)")
+    ap.add_argument("--pipeline-warmup-samples", type=int, default=-1, help="the full-size end-to-end run: samples of the untimed warm-up run in front of it (-1: the whole cohort, 0: none)")
     ap.add_argument("--tmp", default=None, help="directory for the end-to-end workload's files (default: the system's temporary directory)")
     ap.add_argument("--tmp-ram", default="/dev/shm", help="RAM file system for the end-to-end workload at full size (5 Mbp genomes: 130 GB of files)")
     ap.add_argument("--no-full-size", dest="full_size", action="store_false", help="skip the end-to-end run at G = 5 Mbp")
@@ -671,9 +675,14 @@ def run_workloads(a, wl, env):
     test of this plumbing runs it under a two-rank gloo group with a stand-in for lib)"""
     rank, world = env["rank"], env["world"]
     want_cpu = not a.no_cpu_baseline and world == 1      # (the host baseline is a 1-GPU line: with more ranks the others would wait at the barrier for it)
-    extras, pipe = {}, None
+    extras, pipe, head = {}, None, None
     if wl == "all":
         t_all = time.perf_counter()
+        # the headline workload first (round 6): on device memory nothing has been carved up yet -- behind the other workloads and the
+        # end-to-end runs the same 20 steps read 3 % slower (4.95 against 4.79 ms on one box, the same build minutes apart)
+        head = merge_workload(env, a, "count", a.lists, want_cpu)
+        if rank == 0:
+            print(f"[bench] workload count (the line's own) done, {time.perf_counter() - t_all:.0f} s", file=sys.stderr, flush=True)
         for w in ("count_stage", "bf", "bft", "pa63", "count_200"):
             try:
                 extras[w] = count_stage_workload(env, a) if w == "count_stage" else merge_workload(env, a, w, "counted", want_cpu)
@@ -705,7 +714,7 @@ def run_workloads(a, wl, env):
         wl = "count"
     if wl == "count_stage":
         return count_stage_workload(env, a) if rank == 0 else None
-    out = merge_workload(env, a, wl, a.lists, want_cpu)
+    out = head if head is not None else merge_workload(env, a, wl, a.lists, want_cpu)
     if world > 1 and a.multi_gpu_pipeline and wl == "count" and env.get("run_pipeline", True):
         # several ranks (the scaling runs): the PRODUCT's own multi-GPU path gets a point too -- `kmx pipeline --gpus <world>`, one
         # process driving every GPU of the node (partitions p -> GPU p mod G, count lists to the merging GPU's store over xGMI),
