@@ -1193,6 +1193,16 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   else
     hipLaunchKernelGGL((k_cs_scatter_staged<KeyT>), dim3(F.nc_max * (cs_chunk<KeyT>() / cs_schunk<KeyT>())), dim3(CS_WALK_TPB), 0, st, d_keys, d_parts, d_spl, d_cur, d_bkeys, (const SkfCtl*)F.d_ctl, F.d_cfirst, P, (const CsLut*)d_luts, tshift);
   if (F.behind_scatter) { const int brc = F.behind_scatter(); if (brc != KMX_OK) { (void)hipStreamSynchronize(st); release(); return brc; } }
+  // 64-bit keys: the buckets by counting first (k_cs_wave_count) unless the context's last call had a quarter of its buckets' distinct keys
+  // overflow the waves' tables -- data without repeats: the full sort then (KMX_COUNT_HASH_FIRST=0: always; =1: never mind the last call)
+  u32* const d_lost = reinterpret_cast<u32*>(reinterpret_cast<u8*>(F.d_ctl) + 48);      // (a word of the control block's 64 bytes: cleared and read back with it)
+  bool hash_first = false;
+  if constexpr (KWD == 1) { const char* he = getenv("KMX_COUNT_HASH_FIRST"); hash_first = he ? he[0] != '0' : ctx->hash_lost_frac < 0.25; }
+  if constexpr (KWD == 1) {
+    if (hash_first)
+      hipLaunchKernelGGL(k_cs_wave_count, dim3((TBm + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, (const u64*)d_bkeys, d_boff, rq.hard_min, (u64*)d_tk, d_tc, d_nkept, F.d_ctl, d_big, d_lost);
+  }
+  if (!hash_first)
   hipLaunchKernelGGL((k_cs_wave_sort<KeyT, 8, 16>), dim3((TBm + CS_WAVES - 1) / CS_WAVES), dim3(64 * CS_WAVES), 0, st, d_bkeys, d_boff, 0u, 0u, (u32)CsCap<KeyT>::cap,
                      rq.hard_min, d_tk, d_tc, d_nkept, (unsigned long long*)nullptr, &F.d_ctl->overflow, F.d_ctl, d_big);
   // the buckets beyond a wave's registers (a k-mer repeated a thousand times, an unlucky sample): listed by the kernel above, a few workgroups take them
@@ -1228,6 +1238,7 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   std::vector<CsPart> parts(P);
   memcpy(parts.data(), F.h_parts, sizeof(CsPart) * P);
   if (F.h_ctl->total) ctx->kept_per_kmer = (double)h_koff[TB] / (double)F.h_ctl->total;
+  if (hash_first && TB) ctx->hash_lost_frac = (double)reinterpret_cast<const u32*>(F.h_ctl)[12] / (double)TB;      // (a call by the full sort leaves it: the next call of that context tries counting first again only when the environment says so)
   if (d_resv && h_koff[TB] <= cap_recs) {      // the lists are in the store already
     for (u32 p = 0; p < P; p++) {
       const u32 lo = h_koff[parts[p].bucket0], hi = h_koff[parts[p].bucket0 + parts[p].nb];

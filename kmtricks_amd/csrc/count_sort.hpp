@@ -766,7 +766,128 @@ __device__ __forceinline__ void cs_wave_bucket(const K* __restrict__ bkeys, u32 
   if (lane == 63) nkept[b] = incl;
 }
 
-constexpr int CS_WAVES = 4;      // buckets (waves) per workgroup
+// ---- round 6: a bucket by counting first.  Sequencing data repeats its k-mers (coverage: five occurrences of a distinct k-mer in
+// configs[2]'s samples), and the sort above is bound by its vector instructions (SQ_ACTIVE_INST_VALU: 92 % of the SIMDs' cycles): the
+// bucket's keys go into a hash table of the wave's own in LDS (512 entries: compare-and-swap a key, add to its count), the entries that
+// pass hard-min -- a fifth of the keys, fewer with sequencing errors -- are sorted by the 128-, 256- or 512-key network (28 / 36 / 45 steps on
+// 2 / 4 / 8 registers a lane -- the sort above takes 45 / 55 steps on 8 / 16 for the bucket's 512 / 1024 keys), each sorted key looks its count up
+// again.  A bucket whose distinct keys do not fit the table (data without repeats) takes the sort above.  Results identical: ascending keys, their counts.
+constexpr u32 CS_HW = 512;        // table entries per wave
+__device__ __forceinline__ u32 cs_hw_hash(u64 k) { return ((u32)k * 0x9E3779B1u + (u32)(k >> 32) * 0x85EBCA6Bu) >> 23; }
+static_assert(CS_HW == (1u << 9), "cs_hw_hash takes the top 9 bits");
+__device__ __forceinline__ void cs_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+// the network above with a payload: (key, count) pairs, ordered by key (the keys are distinct)
+template <int NPL, u32 K2, u32 J>
+__device__ __forceinline__ void cs_wave_net_kv(u64 (&k)[NPL], u32 (&v)[NPL], u32 lane)
+{
+  constexpr u32 N = 64u * NPL;
+  if constexpr (J >= (u32)NPL) {
+    constexpr u32 m = J / (u32)NPL;
+    const bool asc = K2 >= N ? true : ((lane & (K2 / (u32)NPL)) == 0);
+    const bool keep_min = ((lane & m) == 0) == asc;
+#pragma unroll
+    for (int x = 0; x < NPL; x++) {
+      const u64 p = xor_lane_u64<(int)m>(k[x]); const u32 pv = xor_lane_u32<(int)m>(v[x]);
+      if ((p < k[x]) == keep_min) { k[x] = p; v[x] = pv; }
+    }
+  } else {
+#pragma unroll
+    for (int x = 0; x < NPL; x++) {
+      if ((x & (int)J) == 0) {
+        const bool asc = K2 >= (u32)NPL ? (K2 >= N ? true : ((lane & (K2 / (u32)NPL)) == 0)) : (((u32)x & K2) == 0);
+        const u64 a = k[x], c = k[x | (int)J]; const u32 av = v[x], cv = v[x | (int)J];
+        if ((c < a) == asc) { k[x] = c; k[x | (int)J] = a; v[x] = cv; v[x | (int)J] = av; }
+      }
+    }
+  }
+  if constexpr (J > 1) cs_wave_net_kv<NPL, K2, J / 2>(k, v, lane);
+  else if constexpr (K2 < N) cs_wave_net_kv<NPL, K2 * 2, K2>(k, v, lane);
+}
+template <int NPL>
+__device__ __forceinline__ void cs_hw_sorted_out(const u64* sk, const u32* sc, u32 d, u32 o, u64* __restrict__ tk, u32* __restrict__ tc)
+{
+  const u32 lane = threadIdx.x & 63u;
+  u64 k[NPL]; u32 v[NPL];
+#pragma unroll
+  for (int x = 0; x < NPL; x++) { const u32 i = lane * (u32)NPL + (u32)x; k[x] = i < d ? sk[i] : ~0ULL; v[x] = i < d ? sc[i] : 0u; }
+  cs_wave_net_kv<NPL, 2, 1>(k, v, lane);
+#pragma unroll
+  for (int x = 0; x < NPL; x++) { const u32 i = lane * (u32)NPL + (u32)x; if (i < d) { tk[o + i] = k[x]; tc[o + i] = v[x]; } }
+}
+// -> false: the bucket is not this path's (nothing written)
+__device__ __forceinline__ bool cs_wave_bucket_hash(const u64* __restrict__ bkeys, u32 o, u32 n, u32 b, u32 hard_min, u64* __restrict__ tk, u32* __restrict__ tc,
+                                                    u32* __restrict__ nkept, u64* hk /* [CS_HW] */, u32* hc /* [CS_HW] */)
+{
+  const u32 lane = threadIdx.x & 63u;
+#pragma unroll
+  for (u32 j = 0; j < CS_HW / 64u; j++) { hk[lane + 64u * j] = ~0ULL; hc[lane + 64u * j] = 0u; }
+  cs_wave_lds_fence();
+  // (the key of all ones is the table's "empty": counted beside it.)  All of a lane's keys are requested, then all their compare-and-swaps:
+  // eight round trips side by side instead of one behind the other; the few that met another key in their entry walk on afterwards
+  u32 n_top = 0; bool lost = false;
+  for (u32 base = 0; base < n; base += 512u) {      // (a bucket of up to 1024 keys: two rounds of eight keys a lane)
+    u32 pend = 0;
+    u64 key[8]; u32 h[8]; u64 old[8];
+#pragma unroll
+    for (u32 x = 0; x < 8u; x++) { const u32 i = base + x * 64u + lane; key[x] = i < n ? bkeys[o + i] : ~0ULL; n_top += (i < n && key[x] == ~0ULL) ? 1u : 0u; }
+#pragma unroll
+    for (u32 x = 0; x < 8u; x++) {
+      h[x] = cs_hw_hash(key[x]); old[x] = key[x];
+      if (key[x] != ~0ULL) old[x] = (u64)atomicCAS(reinterpret_cast<unsigned long long*>(&hk[h[x]]), ~0ULL, (unsigned long long)key[x]);
+    }
+#pragma unroll
+    for (u32 x = 0; x < 8u; x++) {
+      if (key[x] != ~0ULL) { if (old[x] == ~0ULL || old[x] == key[x]) atomicAdd(&hc[h[x]], 1u); else pend |= 1u << x; }
+    }
+    for (u32 t = 0; t < 64u && __ballot(pend != 0u) != 0ULL; t++) {
+#pragma unroll
+      for (u32 x = 0; x < 8u; x++) {
+        if ((pend >> x) & 1u) {
+          h[x] = (h[x] + 1u) & (CS_HW - 1u);
+          const u64 o2 = (u64)atomicCAS(reinterpret_cast<unsigned long long*>(&hk[h[x]]), ~0ULL, (unsigned long long)key[x]);
+          if (o2 == ~0ULL || o2 == key[x]) { atomicAdd(&hc[h[x]], 1u); pend &= ~(1u << x); }
+        }
+      }
+    }
+    lost = lost || pend != 0u;
+    if (__ballot(lost) != 0ULL) return false;
+  }
+  if (__ballot(lost) != 0ULL) return false;
+  cs_wave_lds_fence();
+  // the entries that pass hard-min, packed to the table's front (over the table itself: every lane holds its entries by then), then
+  // sorted as (key, count) pairs
+  u64 ek[CS_HW / 64u]; u32 ec[CS_HW / 64u]; u32 km = 0, nk = 0;
+#pragma unroll
+  for (u32 j = 0; j < CS_HW / 64u; j++) {
+    ek[j] = hk[lane + 64u * j]; ec[j] = hc[lane + 64u * j];
+    const bool keep = ek[j] != ~0ULL && ec[j] >= hard_min;
+    km |= (keep ? 1u : 0u) << j; nk += keep ? 1u : 0u;
+  }
+  const u32 incl = wave_incl_scan(nk, (int)lane);
+  const u32 d = (u32)__shfl((int)incl, 63);
+  cs_wave_lds_fence();
+  u32 at = incl - nk;
+#pragma unroll
+  for (u32 j = 0; j < CS_HW / 64u; j++) if ((km >> j) & 1u) { hk[at] = ek[j]; hc[at] = ec[j]; at++; }
+  cs_wave_lds_fence();
+  if (d <= 128u) cs_hw_sorted_out<2>(hk, hc, d, o, tk, tc);
+  else if (d <= 256u) cs_hw_sorted_out<4>(hk, hc, d, o, tk, tc);
+  else cs_hw_sorted_out<8>(hk, hc, d, o, tk, tc);
+  // the key of all ones, the largest: behind the others
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n_top += (u32)__shfl_xor((int)n_top, off);
+  const bool top = n_top != 0u && n_top >= hard_min;
+  if (lane == 0) { if (top) { tk[o + d] = ~0ULL; tc[o + d] = n_top; } nkept[b] = d + (top ? 1u : 0u); }
+  return true;
+}
+
+#ifndef KMX_CS_WAVES
+#define KMX_CS_WAVES 4
+#endif
+constexpr int CS_WAVES = KMX_CS_WAVES;      // buckets (waves) per workgroup
+#ifndef KMX_CS_WC_OCC
+#define KMX_CS_WC_OCC 6
+#endif
 template <typename K, int NPL_A, int NPL_B>
 __global__ __launch_bounds__(64 * CS_WAVES)
 void k_cs_wave_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u32 n_buckets, u32 lo /* this launch takes lo < n <= 64 * NPL_B */, u32 cap,
@@ -792,6 +913,28 @@ void k_cs_wave_sort(const K* __restrict__ bkeys, const u32* __restrict__ boff, u
   if (hist) {
     __syncthreads();
     for (u32 i = tid; i < 258; i += 64 * CS_WAVES) if (hh[i]) atomicAdd(&hist[i], (unsigned long long)hh[i]);
+  }
+}
+
+// the sync-free path's wave kernel for 64-bit keys (round 6): every bucket of up to 1024 keys by counting first (cs_wave_bucket_hash);
+// one whose distinct keys do not fit the table is sorted here when it has up to 512 keys and listed for the LDS kernels beyond -- and
+// counted in *n_lost: a sample of data without repeats sends the next call to k_cs_wave_sort (the caller's choice).  6 KB of LDS a
+// wave and 80 registers a lane: six waves a SIMD (the walk through LDS round trips wants them: 207 us at four, 179 at five)
+__global__ __launch_bounds__(64 * CS_WAVES) __attribute__((amdgpu_waves_per_eu(KMX_CS_WC_OCC, KMX_CS_WC_OCC)))
+void k_cs_wave_count(const u64* __restrict__ bkeys, const u32* __restrict__ boff, u32 hard_min, u64* __restrict__ tk, u32* __restrict__ tc, u32* __restrict__ nkept,
+                     SkfCtl* __restrict__ ctl, u32* __restrict__ big, u32* __restrict__ n_lost)
+{
+  __shared__ u64 hw_k[CS_WAVES * CS_HW]; __shared__ u32 hw_c[CS_WAVES * CS_HW];
+  const u32 tid = threadIdx.x, w = tid >> 6, b = blockIdx.x * CS_WAVES + w;
+  if (ctl->status || b >= ctl->TB) return;
+  const u32 o = boff[b], n = boff[b + 1] - o;
+  if (n == 0) { if ((tid & 63u) == 0) nkept[b] = 0; return; }
+  if (n <= 1024u && cs_wave_bucket_hash(bkeys, o, n, b, hard_min, tk, tc, nkept, hw_k + w * CS_HW, hw_c + w * CS_HW)) return;
+  if (n <= 1024u && (tid & 63u) == 0) atomicAdd(n_lost, 1u);
+  if (n <= 512u) { cs_wave_bucket<u64, 8>(bkeys, o, n, b, hard_min, tk, tc, nkept, nullptr); return; }
+  if ((tid & 63u) == 0) {
+    const u32 at = atomicAdd(&ctl->n_big, 1u);
+    if (at < SKF_BIG_CAP) big[at] = b; else atomicOr(&ctl->status, (u32)SKF_ST_BUCKET);
   }
 }
 

@@ -177,6 +177,7 @@ struct kmx_ctx {
   // COUNT / PA rows of the column-blocked pair come out in file order (the matrix body as the reference streams it,
   // merge.hpp:262-272): kmx_set_file_order, KMX_FILE_ORDER=0 for the rows where the kernels leave them + a directory
   bool file_order = true;
+  double hash_lost_frac = 0.0;          // kmx_count_reads_dev: the share of the last call's buckets whose distinct keys did not fit k_cs_wave_count's tables (a quarter: the next call sorts)
   double kept_per_kmer = 0.0;           // kmx_count_reads_dev: distinct kept k-mers per k-mer as the last call had it (the next one reserves room in the store for 1.25 x that)
   double keys_per_longest = 0.0;        // row keys per record of the longest list they were merged from, as completed batches had it
   // abundance histogram (kmx_hist_reset / kmx_hist_read): distinct keys per count 0..255, [256] = keys counted more than 255

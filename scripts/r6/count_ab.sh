@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: A/B of count-stage builds on one box: kernel times of one 30-Mbase sample (rocprofv3 --kernel-trace --stats), interleaved
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r6cab; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-for rep in 1 2; do for V in product ${VARIANTS}; do
+for rep in ${REPS:-1 2}; do for V in product ${VARIANTS}; do
   L=""; [ "$V" != "product" ] && L="$R/kmtricks_amd/libkmx_$V.so"
   KMX_LIB=$L timeout 600 rocprofv3 --kernel-trace --stats -d $O/t_${V}_$rep --output-format csv -- python $R/scripts/bench_count_stage.py --genome 5e6 --partitions 256 --reps 20 --skip-streams ${EXTRA:-} > $O/b_${V}_$rep.json 2> $O/log_${V}_$rep.txt
   python - <<PY
