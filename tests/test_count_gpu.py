@@ -599,3 +599,35 @@ def test_count_calls_side_by_side_into_one_store():
             assert np.array_equal(got[p][0].reshape(ek.shape), ek) and np.array_equal(got[p][1], ec), (w, rnd, i, p)
     assert store.used() > 0
     store.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first", ["1", "0"])
+@pytest.mark.parametrize("k,m,P,hard_min,hashed,copies", [(31, 10, 2, 2, False, 6), (31, 10, 2, 1, False, 1), (32, 10, 3, 3, True, 5), (21, 8, 2, 1, False, 12), (25, 9, 2, 2, False, 2)])
+def test_count_buckets_by_counting_first(ctx, k, m, P, hard_min, hashed, copies, first, monkeypatch, capfd):
+    """round 6: k_cs_wave_count -- a bucket's keys into a hash table of the wave's own, the kept distinct keys sorted as (key, count) pairs --
+    against the full sort of the same buckets (KMX_COUNT_HASH_FIRST=0) and the oracle: reads given `copies` times over (sequencing depth: the
+    table holds a bucket's distinct keys), once (it does not: the bucket is sorted in the same kernel or listed for the LDS kernels), hard-min
+    1 .. 3, k-mers and hashes, partitions of a few hundred thousand k-mers = hundreds of buckets each"""
+    from kmtricks_amd import lib
+    monkeypatch.setenv("KMX_COUNT_HASH_FIRST", first)
+    monkeypatch.setenv("KMX_TRACE", "1")
+    lut, rep = orc.minimizer_lut(m), orc.repart_static(m, P)
+    base = random_reads(7000 + k + copies, 900 // max(1, copies // 2), 700, n_rate=0.001)
+    reads = []
+    for c in range(copies):      # (every copy's reads cut at other places: the same k-mers, other super-k-mers)
+        reads += [r[(37 * c) % 90:] for r in base[: len(base) - 11 * c]]
+    W = 1 << 22
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    store = lib.Store(0)
+    try:
+        for _ in range(2):
+            lists, nk, _ = ctx.count_reads_dev(reads, k, m, rep, P, hard_min, [store], window=W if hashed else 0)
+            for p in range(P):
+                ek, ec = (orc.count_hash(exp[p][0], k, W, p, hard_min) if hashed else orc.count_kmer(exp[p][0], k, hard_min))
+                gk, gc = ctx.read_list(lists[p][0], lists[p][1], 1)
+                assert nk[p] == exp[p][1] and np.array_equal(gk.reshape(ek.shape), ek) and np.array_equal(gc, ec)
+        err = capfd.readouterr().err
+        assert "count_reads_fast" in err and "handed the call back" not in err      # (the sync-free path took both calls: its kernels are the ones compared)
+    finally:
+        store.close()
