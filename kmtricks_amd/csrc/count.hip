@@ -1232,13 +1232,16 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "count read-back");
   kmx_phase_mark(5);
   clk.mark("split+decode+sort+count");
-  if (clk.on) fprintf(stderr, "[kmx count_reads_fast] records %u k-mers %u buckets %u walk chunks %u listed buckets %u status %u overflow %u\n", F.h_ctl->nd, F.h_ctl->total, F.h_ctl->TB, F.h_ctl->NC, F.h_ctl->n_big, F.h_ctl->status, F.h_ctl->overflow);
+  if (clk.on) fprintf(stderr, "[kmx count_reads_fast] records %u k-mers %u buckets %u walk chunks %u listed buckets %u status %u overflow %u; the buckets %s\n", F.h_ctl->nd, F.h_ctl->total, F.h_ctl->TB, F.h_ctl->NC, F.h_ctl->n_big, F.h_ctl->status, F.h_ctl->overflow,
+                      hash_first ? (std::string("by counting first (") + std::to_string(reinterpret_cast<const u32*>(F.h_ctl)[12]) + " of them sorted: their distinct keys beyond the table)").c_str() : "by the full sort");
+  // (before the status word is looked at: a sample whose lost buckets overflow the list hands the call back -- the next one must not try again)
+  if (hash_first && F.h_ctl->TB) ctx->hash_lost_frac = (double)reinterpret_cast<const u32*>(F.h_ctl)[12] / (double)F.h_ctl->TB;
+  else if (!hash_first) ctx->hash_lost_frac *= 0.9;      // (a call by the full sort: counting first is tried again a dozen samples on -- a cohort may hold an assembly among its read sets)
   if (F.h_ctl->status || F.h_ctl->overflow) { release(); return 1; }
   const u32 TB = F.h_ctl->TB;
   std::vector<CsPart> parts(P);
   memcpy(parts.data(), F.h_parts, sizeof(CsPart) * P);
   if (F.h_ctl->total) ctx->kept_per_kmer = (double)h_koff[TB] / (double)F.h_ctl->total;
-  if (hash_first && TB) ctx->hash_lost_frac = (double)reinterpret_cast<const u32*>(F.h_ctl)[12] / (double)TB;      // (a call by the full sort leaves it: the next call of that context tries counting first again only when the environment says so)
   if (d_resv && h_koff[TB] <= cap_recs) {      // the lists are in the store already
     for (u32 p = 0; p < P; p++) {
       const u32 lo = h_koff[parts[p].bucket0], hi = h_koff[parts[p].bucket0 + parts[p].nb];

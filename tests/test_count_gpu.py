@@ -631,3 +631,32 @@ def test_count_buckets_by_counting_first(ctx, k, m, P, hard_min, hashed, copies,
         assert "count_reads_fast" in err and "handed the call back" not in err      # (the sync-free path took both calls: its kernels are the ones compared)
     finally:
         store.close()
+
+
+@pytest.mark.gpu
+def test_counting_first_gives_way_to_the_sort_and_comes_back(monkeypatch, capfd):
+    """round 6: a sample without repeats overflows the waves' hash tables (k_cs_wave_count sorts or lists those buckets and counts them);
+    the context's next calls take k_cs_wave_sort, and try counting first again a dozen samples on.  The counts are the oracle's either way."""
+    from kmtricks_amd import lib
+    monkeypatch.delenv("KMX_COUNT_HASH_FIRST", raising=False)
+    monkeypatch.setenv("KMX_TRACE", "1")
+    k, m, P = 31, 10, 2
+    lut, rep = orc.minimizer_lut(m), orc.repart_static(m, P)
+    reads = random_reads(8111, 700, 900, n_rate=0.0)      # (630 k distinct k-mers, two partitions: ~750 buckets each, none with a repeat)
+    exp = orc.superk_partition(reads, k, m, lut, rep, P)
+    c = lib.Context(0); store = lib.Store(0)
+    try:
+        kinds = []
+        for call in range(16):
+            lists, nk, _ = c.count_reads_dev(reads, k, m, rep, P, 1, [store])
+            err = capfd.readouterr().err
+            assert "handed the call back" not in err
+            kinds.append("count" if "by counting first" in err else "sort")
+            if call in (0, 1, 15):
+                for p in range(P):
+                    ek, ec = orc.count_kmer(exp[p][0], k, 1)
+                    gk, gc = c.read_list(lists[p][0], lists[p][1], 1)
+                    assert np.array_equal(gk.reshape(ek.shape), ek) and np.array_equal(gc, ec)
+        assert kinds[0] == "count" and kinds[1] == "sort" and "count" in kinds[2:], kinds
+    finally:
+        store.close(); c.close()
