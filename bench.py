@@ -400,7 +400,7 @@ def count_stage_workload(env, a):
     st = torch.cuda.ExternalStream(ctx.stream() if callable(ctx.stream) else ctx.stream, device=env["dev"])
     # the sample's bases are resident in HBM when the timed region starts (kmx_reads_upload: what `kmx pipeline` does with the NEXT sample
     # while this one is counted); the same call with the bases handed over as a host buffer (30 MB over PCIe inside the call) beside it
-    handle = ctx.upload_reads(blob)
+    handle = ctx.upload_reads(blob, offs)      # (the offsets behind the bases in the page-locked block, as the pipeline's reader leaves them: no staging copy inside the call)
     for _ in range(3):
         ctx.count_reads_dev((blob, offs), K, M, table, P, 2, [store], resident=handle)
     reps, dev_ms, wall, dev_ms_up = 10, [], [], []

@@ -214,6 +214,13 @@ void kmx_pinned_free(void* p)
   if (n) { (void)hipHostUnregister(p); munmap(p, n); }
   else (void)hipHostFree(p);
 }
+// [p, p + n) lies in a block kmx_alloc_pinned made by mapping + registering (2 MB and up): a copy from it is a DMA by itself
+bool kmx_is_pinned(const void* p, size_t n)
+{
+  std::lock_guard<std::mutex> lk(g_pin_mutex);
+  for (auto& b : g_pin_mapped) if ((const char*)p >= (const char*)b.first && (const char*)p + n <= (const char*)b.first + b.second) return true;
+  return false;
+}
 extern "C" void* kmx_alloc_pinned(size_t bytes) { return kmx_pinned_alloc(bytes); }
 extern "C" void kmx_free_pinned(void* p) { kmx_pinned_free(p); }
 // ---- kmx_store: count lists resident in HBM between the count and the merge stage ---------------------------------

@@ -114,6 +114,7 @@ void kmx_count_chain_forget(kmx_ctx* ctx);     // (kmx_destroy)
 // page-locked host memory (kmx_api.hip: transparent huge pages + hipHostRegister for blocks of 2 MB and more, hipHostMalloc else)
 int kmx_peer_path(int from, int to);      // 1: GPU `from` reaches GPU `to`'s memory directly (peer access enabled on first use), 0: staged
 void* kmx_pinned_alloc(size_t bytes);
+bool kmx_is_pinned(const void* p, size_t n);      // inside a page-locked block of kmx_alloc_pinned's (the mapped + registered kind)
 void kmx_pinned_free(void* p);
 
 // ---- context -------------------------------------------------------------------------------------

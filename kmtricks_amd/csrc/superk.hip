@@ -995,7 +995,8 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
   const SkMulti mu{segs ? d_first : nullptr, n_smp, segs ? segs->parts : 0u, segs ? (u32)nm : 0u};
   // (round 6: the reads' offsets go through a page-locked block -- the caller's array is pageable as a rule, and a copy from pageable memory
   //  is staged by the runtime with the calling thread waiting on the stream; 1.6 MB a sample)
-  u64* h_offs = segs ? nullptr : (u64*)ctx->halloc((n_seqs + 1) * 8);
+  // (... unless they lie in page-locked memory already: `kmx pipeline` puts them behind the bases in the batch's block)
+  u64* h_offs = (segs || kmx_is_pinned(offsets, (n_seqs + 1) * 8)) ? nullptr : (u64*)ctx->halloc((n_seqs + 1) * 8);
   struct HOffs { kmx_ctx* c; void* p; ~HOffs() { c->hfree(p); } } h_offs_rel{ctx, h_offs};
   if (h_offs) memcpy(h_offs, offsets, (n_seqs + 1) * 8);
   if ((e = hipMemcpyAsync(d_offs, h_offs ? (const void*)h_offs : (const void*)offsets, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "upload offsets");

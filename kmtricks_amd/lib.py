@@ -336,16 +336,23 @@ class Context:
                 _lib.kmx_free(ob[p])
         return out, [int(x) for x in nk], st, np.array(list(info), dtype=np.uint64).reshape(nb_parts, 2)
 
-    def upload_reads(self, blob):
+    def upload_reads(self, blob, offs=None):
         """kmx_reads_upload: the bases of a batch sent to the device ahead of the count call (from page-locked memory, on the context's
         upload stream) -> a handle for count_reads_dev(resident=...) and release_reads.  What `kmx pipeline` does with the NEXT
-        sample while this one is counted."""
+        sample while this one is counted.  offs: the reads' offsets are put behind the bases in the same page-locked block, as
+        `kmx pipeline` does, and count_reads_dev(resident=handle) hands the call THAT array (a DMA, no staging copy inside the call)."""
         n = len(blob)
-        pin = _lib.kmx_alloc_pinned(max(n, 1))
+        at = (n + 63) & ~63
+        nb = 0 if offs is None else 8 * len(offs)
+        pin = _lib.kmx_alloc_pinned(max(at + nb, 1))
         C.memmove(pin, blob, n)
+        po = None
+        if offs is not None:
+            po = np.frombuffer((C.c_char * nb).from_address(pin + at), dtype=np.uint64)
+            po[:] = np.ascontiguousarray(offs, dtype=np.uint64)
         dev = _vp()
         self._check(_lib.kmx_reads_upload(self._h, pin, n, C.byref(dev)), "kmx_reads_upload")
-        return (dev, pin)
+        return (dev, pin, po)
 
     def release_reads(self, handle):
         _lib.kmx_reads_release(self._h, handle[0])
@@ -371,6 +378,8 @@ class Context:
         if resident is not None:
             ahead = False
             blob_arg = C.cast(resident[0], C.c_char_p)
+            if len(resident) > 2 and resident[2] is not None:
+                offs = resident[2]
         elif ahead:      # kmx_reads_upload: the bases sent to the device ahead of the call (from page-locked memory), the call given the device pointer
             n = len(blob)
             pin = _lib.kmx_alloc_pinned(max(n, 1))

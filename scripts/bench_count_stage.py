@@ -29,7 +29,7 @@ ctx = lib.Context(0)
 rep = orc.repart_static(M, P)
 W = 3125056 if a.hash else 0
 store = lib.Store(0)
-handle = ctx.upload_reads(blob) if a.resident else None      # (round 6: the bases resident in HBM, as the pipeline has them when the call starts)
+handle = ctx.upload_reads(blob, offs) if a.resident else None      # (round 6: the bases resident in HBM, as the pipeline has them when the call starts)
 for _ in range(3):
     ctx.count_reads_dev((blob, offs), K, M, rep, P, 2, [store], window=W, resident=handle)      # warm-up at full size (module load, pools)
 ts = []
