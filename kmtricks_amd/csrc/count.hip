@@ -1159,11 +1159,10 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   KeyT* d_keys = (KeyT*)dal(sizeof(KeyT) * kb), *d_bkeys = (KeyT*)dal(sizeof(KeyT) * kb), *d_tk = (KeyT*)dal(sizeof(KeyT) * kb);
   u32* d_tc = (u32*)dal(4 * kb);
   SplT* d_spl = (SplT*)dal(sizeof(SplT) * (size_t)TBm);
-  u32* d_boff = (u32*)dal(4 * ((size_t)TBm + 2)), *d_cur = (u32*)dal(4 * ((size_t)TBm + 2)), *d_nkept = (u32*)dal(4 * ((size_t)TBm + 2)), *d_koff = (u32*)dal(4 * ((size_t)TBm + 2));
+  u32* d_boff = (u32*)dal(4 * ((size_t)TBm + 2)), *d_cur = (u32*)dal(4 * ((size_t)TBm + 2)), *d_nkept = (u32*)dal(4 * ((size_t)TBm + 2)), *d_koff = F.d_koff;      // (the offsets of the kept pairs: in the caller's block, read back with the control block)
   u32* d_big = (u32*)dal(4 * (size_t)SKF_BIG_CAP);
-  u32* h_koff = (u32*)ctx->halloc(4 * ((size_t)TBm + 2));
-  struct HRel { kmx_ctx* c; void* p; ~HRel() { c->hfree(p); } } h_rel{ctx, h_koff};
-  bool ok = h_koff != nullptr;
+  u32* const h_koff = F.h_koff;
+  bool ok = h_koff != nullptr && d_koff != nullptr;
   for (void* b : blocks) ok = ok && b;
   if (!ok) { release(); return ctx->fail(KMX_E_NOMEM, "count: device allocation failed"); }
   auto fail = [&](hipError_t er, const char* what) { release(); return ctx->fail(KMX_E_HIP, std::string(what) + ": " + hipGetErrorString(er)); };
@@ -1223,8 +1222,7 @@ static int fast_tail_impl(kmx_ctx* ctx, StageClock& clk, const kmx_fast_split& F
   }
   struct Resv { kmx_store* s; u8* p; ~Resv() { if (s && p) s->commit(p, 0); } } resv{S0, d_resv};      // (left open by an error: given back)
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "count kernels");
-  if ((e = hipMemcpyAsync(F.h_ctl, F.d_ctl, 64, hipMemcpyDeviceToHost, st)) != hipSuccess ||
-      (e = hipMemcpyAsync(h_koff, d_koff, 4 * ((size_t)TBm + 2), hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "count read-back");
+  if ((e = hipMemcpyAsync(F.h_ctl, F.d_ctl, F.back_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail(e, "count read-back");      // (the call's one copy back: control block, tables, offsets)
   kmx_count_chain_end(ctx);      // (everything of this call is queued: the next call of this GPU may start behind it)
   kmx_phase_mark(3);
   if (F.before_wait) { const int brc = F.before_wait(); if (brc != KMX_OK) { (void)hipStreamSynchronize(st); release(); return brc; } }

@@ -95,10 +95,13 @@ struct kmx_fast_split {
   kmx::u32* d_sflags;             // [2 * 256] zeroed: the flags of the two bucket scans (k_cs_scan_mw)
   kmx::u32 n_parts; kmx::u64 kmer_bound; kmx::u32 tb_max, nc_max, nb_max;      // bounds: k-mers, buckets, walk chunks, decode blocks
   kmx::SkfCtl* h_ctl;             // page-locked, 64 bytes: the control block as read back
-  const uint4* h_parts;           // page-locked: d_parts as read back (the caller queued that copy on the context's stream)
+  const uint4* h_parts;           // page-locked: d_parts as read back (part of the one copy below)
   unsigned long long* d_strand;   // [kmer_bound / 64 + 2] or null: the decode leaves bit g = "k-mer g of the batch is its own canonical form" (the PartiInfo statistics' strands)
   std::function<int()> behind_scatter;   // run right after the scatter walk is queued: the caller starts its work on the second stream there (the kernels up to the scatter fill the LDS, the wave sort behind it uses none)
   std::function<int()> before_wait;      // run once everything is queued, before the stream is waited for (the caller's work on its second stream)
+  // the call's ONE read-back: back_bytes from d_ctl on -- the control block, the caller's tables (h_parts among them) and, at d_koff / h_koff,
+  // the kept pairs' offsets per bucket ([tb_max + 2]) that kmx_count_fast_tail fills -- to h_ctl on; queued by kmx_count_fast_tail at its end
+  kmx::u32* d_koff; kmx::u32* h_koff; size_t back_bytes;
 };
 kmx::SkfLayout kmx_fast_layout(int key_words /* of the sort's keys: 1 (k <= 32, hashes) or 2 */);
 int kmx_count_fast_tail(kmx_ctx* ctx, const kmx_fast_split& F, const kmx_count_req& rq);

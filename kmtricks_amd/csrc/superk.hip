@@ -1056,13 +1056,16 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       const int kw = (int)((k + 31) / 32);
       const SkfLayout L = kmx_fast_layout(creq->hash_mode ? 1 : kw);
       const u32 tb_max = (u32)(kb / L.target) + P + 1, nc_max = (u32)(kb / L.chunk) + P + 1, nb_max = (u32)((kb + SKF_DK - 1) / SKF_DK) + 1;
-      // the zeroed block: [control 32 B][minimizers that occur, u64][pad to 64][k_sk_scan's flags][the bucket scans' flags][the sample sort's bucket counters]
-      const size_t z_flags = 64, z_sfl = z_flags + 128 * 4, z_cnt = z_sfl + 512 * 4, z_bytes = z_cnt + ((size_t)tb_max + 2) * 4;
-      u8* d_z = (u8*)ctx->dalloc(z_bytes);
-      // what the host reads at the end, one copy: [pp (P + 1) u64][info 2 P u64][parts P uint4][pf (P + 1) u32][cfirst (P + 1) u32]
+      // ONE block: the part that is cleared -- [k_sk_scan's flags][the bucket scans' flags][the sample sort's bucket counters] ... [control 32 B]
+      // [minimizers that occur, u64][lost buckets, u32 at + 48][pad to 64], a multiple of 256 bytes (the runtime clears an unaligned tail with a
+      // launch of its own) -- and, right behind the control block, what the host reads at the call's end IN ONE COPY with it: [pp (P + 1) u64]
+      // [info 2 P u64][parts P uint4][pf (P + 1) u32][cfirst (P + 1) u32][pad to 16][the kept pairs' offsets per bucket, tb_max + 2 u32]
+      const size_t z_flags = 0, z_sfl = z_flags + 128 * 4, z_cnt = z_sfl + 512 * 4, z_bytes = ((z_cnt + ((size_t)tb_max + 2) * 4 + 64 + 255) & ~(size_t)255), z_ctl = z_bytes - 64;
       const size_t P1f = (size_t)P + 1, o_info = P1f * 8, o_parts = o_info + (size_t)P * 16, o_pf = o_parts + (size_t)P * 16, o_cf = o_pf + P1f * 4, sumf = o_cf + P1f * 4;
-      u8* d_sumf = (u8*)ctx->dalloc(sumf);
-      u8* h_f = (u8*)ctx->halloc(64 + sumf + 24);      // (+ the statistics' own read-back word, behind everything the main stream's copies write)
+      const size_t o_koff = (sumf + 15) & ~(size_t)15, back_bytes = 64 + o_koff + ((size_t)tb_max + 2) * 4;
+      u8* d_z = (u8*)ctx->dalloc(z_bytes + back_bytes - 64);
+      u8* d_sumf = d_z ? d_z + z_bytes : nullptr;
+      u8* h_f = (u8*)ctx->halloc(back_bytes + 24);      // (+ the statistics' own read-back word, behind everything the main stream's copy writes)
       struct HRelF { kmx_ctx* c; void* p; ~HRelF() { c->hfree(p); } } h_f_rel{ctx, h_f};
       SkDesc* d_descf = (SkDesc*)ctx->dalloc(((size_t)total_bases + 64) * sizeof(SkDesc));
       u32* d_ccnt = (u32*)ctx->dalloc((size_t)n_chunks * 4);
@@ -1073,7 +1076,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       u16* d_p16 = creq->hash_mode ? (u16*)ctx->dalloc((size_t)nd_cap * 2 + 16) : nullptr;
       u32* d_bf = (u32*)ctx->dalloc((size_t)nb_max * 4);
       u64* d_wordsf = (u64*)ctx->dalloc(((size_t)total_bases / 32 + 4) * 8);
-      std::vector<void*> fb = {d_z, d_sumf, d_descf, d_ccnt, d_T, d_agg, d_sb, d_bo, d_bf, d_wordsf};
+      std::vector<void*> fb = {d_z, d_descf, d_ccnt, d_T, d_agg, d_sb, d_bo, d_bf, d_wordsf};
       bool ok = h_f != nullptr;
       for (void* b : fb) ok = ok && b;
       // the statistics' inputs (round 6): the minimizer of every descriptor in its slot's word, gathered into sorted order by the scatter (d_idf), and
@@ -1084,7 +1087,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       if (creq->hash_mode) { fb.push_back(d_p16); ok = ok && d_p16; }
       auto frel = [&]() { for (void* b : fb) ctx->dfree(b); };
       if (!ok) { frel(); release(); return ctx->fail(KMX_E_NOMEM, "superk: device allocation failed"); }
-      SkfCtl* d_ctl = (SkfCtl*)d_z; u64* d_nspf = (u64*)(d_z + 32);
+      SkfCtl* d_ctl = (SkfCtl*)(d_z + z_ctl); u64* d_nspf = (u64*)(d_z + z_ctl + 32);
       u64* d_ppf = (u64*)d_sumf, *d_infof = (u64*)(d_sumf + o_info); uint4* d_partsf = (uint4*)(d_sumf + o_parts); u32* d_pff = (u32*)(d_sumf + o_pf), *d_cff = (u32*)(d_sumf + o_cf);
       auto ffail = [&](hipError_t er, const char* what) { frel(); return fail(er, what); };
       kmx_count_chain_begin(ctx);
@@ -1103,7 +1106,7 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
       // k_part_stats is a workgroup per partition waiting on gathers and LDS atomics (150 us by itself), the count kernels are bound by
       // their instructions.  Their tables travel back on that stream as well, before the count is through (before_wait below).
       hipStream_t sx = ctx->aux ? ctx->aux : st;
-      u64* h_nsp = reinterpret_cast<u64*>(h_f + ((64 + sumf + 7) & ~(size_t)7));      // (the minimizers that occur, read back on the second stream: its own 8 bytes -- the control block's 64 land at h_f whenever the main stream gets there)
+      u64* h_nsp = reinterpret_cast<u64*>(h_f + ((back_bytes + 7) & ~(size_t)7));      // (the minimizers that occur, read back on the second stream: its own 8 bytes -- the control block's 64 land at h_f whenever the main stream gets there)
       auto launch_stats = [&]() -> int {      // (behind the scatter walk of the sample sort: up to there the count's kernels want the LDS k_part_stats holds -- started behind the split it kept k_cs_splitters off the CUs: 40 -> 160 us)
         hipError_t er = hipSuccess;
         if (sx != st) {
@@ -1120,10 +1123,10 @@ static int superk_impl(kmx_ctx* ctx, const char* bases, const uint64_t* offsets,
         return er == hipSuccess ? KMX_OK : ctx->fail(KMX_E_HIP, std::string("superk statistics: ") + hipGetErrorString(er));
       };
       if ((e = hipGetLastError()) != hipSuccess) return ffail(e, "split kernels");
-      if ((e = hipMemcpyAsync(h_f + 64, d_sumf, sumf, hipMemcpyDeviceToHost, st)) != hipSuccess) return ffail(e, "memcpy");
       ph.mark(2);
       kmx_fast_split F{d_wordsf, d_sb, d_bo, d_p16, d_bf, d_ctl, d_partsf, d_cff, (u32*)(d_z + z_cnt), (u32*)(d_z + z_sfl), P, kb, tb_max, nc_max, nb_max,
-                       reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts), d_strand, nullptr, nullptr};
+                       reinterpret_cast<SkfCtl*>(h_f), reinterpret_cast<const uint4*>(h_f + 64 + o_parts), d_strand, nullptr, nullptr,
+                       reinterpret_cast<u32*>(d_sumf + o_koff), reinterpret_cast<u32*>(h_f + 64 + o_koff), back_bytes};
       if (sd.deferred) F.behind_scatter = launch_stats;
       bool raw_queued = false;
       if (raw && sd.deferred && sx != st)
