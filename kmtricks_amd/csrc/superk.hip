@@ -207,7 +207,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
       const u64 lowmask = (2ULL << lane) - 1;                              // lanes <= mine (lane 63: all)
       const u64 Bm = __ballot(brk) & lowmask;
       const u64 rs = Bm ? p0 + (63 - __clzll(Bm)) : run_start;            // start of my run
-      const bool start = valid && (brk || (u32)((pk - rs) % (u64)maxs) == 0);
+      const bool start = valid && (brk || ((u32)(pk - rs) % (u32)maxs) == 0);      // (32 bits: a run lies inside a read, and a 64-bit remainder is ~130 instructions a lane)
       const u64 Sall = __ballot(start);
       const int nvalid = __shfl_down((int)valid, 1), nstart = __shfl_down((int)start, 1);
       const bool owned = (u32)lane < own && pk < nk;
@@ -254,7 +254,7 @@ void k_superk_wave(const char* __restrict__ bases, const u64* __restrict__ offse
         const bool T = valid && (start || w != w_l);                       // first k-mer of a run of one strand
         const u64 Tm = __ballot(T) & lowmask;
         ts = Tm ? p0 + (63 - __clzll(Tm)) : t_start;
-        const bool X = valid && (T || (u32)((pk - ts) % 5u) == 0);         // first k-mer of a kx-mer (x <= 4)
+        const bool X = valid && (T || ((u32)(pk - ts) % 5u) == 0);         // first k-mer of a kx-mer (x <= 4)
         const u64 Xall = __ballot(X);
         const int nX = __shfl_down((int)X, 1);
         const bool xend = valid && owned && (endf || nX);
@@ -426,7 +426,7 @@ void k_superk_wide(const char* __restrict__ bases, const u64* __restrict__ offse
       const u64 lowmask = (2ULL << lane) - 1;
       const u64 Bm = __ballot(brk) & lowmask;
       const u64 rs = Bm ? p0 + (63 - __clzll(Bm)) : run_start;
-      const bool start = valid && (brk || (u32)((pk - rs) % (u64)maxs) == 0);
+      const bool start = valid && (brk || ((u32)(pk - rs) % (u32)maxs) == 0);      // (32 bits: a run lies inside a read, and a 64-bit remainder is ~130 instructions a lane)
       const u64 Sall = __ballot(start);
       const int nvalid = __shfl_down((int)valid, 1), nstart = __shfl_down((int)start, 1);
       const bool owned = (u32)lane < own && pk < nk;
@@ -459,7 +459,7 @@ void k_superk_wide(const char* __restrict__ bases, const u64* __restrict__ offse
         const bool T = valid && (start || w != w_l);
         const u64 Tm = __ballot(T) & lowmask;
         ts = Tm ? p0 + (63 - __clzll(Tm)) : t_start;
-        const bool X = valid && (T || (u32)((pk - ts) % 5u) == 0);
+        const bool X = valid && (T || ((u32)(pk - ts) % 5u) == 0);
         const u64 Xall = __ballot(X);
         const int nX = __shfl_down((int)X, 1);
         const bool xend = valid && owned && (endf || nX);
